@@ -1,0 +1,326 @@
+"""TEST INFRASTRUCTURE -- golden-vector generator.  Runs ONLY in the build container.
+
+Imports the reference's own Python from /root/reference (read-only, never copied) through
+an import shim (sys.modules aliases for the transformers 3.0.2 module
+paths + monkey-patches restoring the 3.0.2 arithmetic on the installed transformers 5.15),
+runs it on deterministic counter-hash inputs (oracle/weights.py), checks that the
+restatement in oracle/mag_bert_ref.py reproduces it, and writes small fixtures to
+tests/golden/*.npz.  Fixtures hold inputs-by-recipe (seeds, shapes) and expected outputs
+only -- no reference source text.
+
+    python -m oracle.make_golden            # regenerate all fixtures (about a minute of CPU)
+
+Neither /root/reference nor `transformers` is needed to *consume* the fixtures.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+REF = "/root/reference"
+
+
+def install_shim():
+    """Make `import modeling, bert, xlnet, multimodal_driver` work against transformers 5.x."""
+    sys.path.insert(0, REF)
+    from transformers.models.bert import modeling_bert as mb, configuration_bert as cb
+    from transformers.models.xlnet import modeling_xlnet as mx
+    import transformers.activations as A
+    import transformers.modeling_utils as MU
+    import transformers.pytorch_utils as PU
+    import transformers.optimization as O
+    sys.modules["transformers.modeling_bert"] = mb
+    sys.modules["transformers.configuration_bert"] = cb
+    sys.modules["transformers.modeling_xlnet"] = mx
+    MU.apply_chunking_to_forward = PU.apply_chunking_to_forward
+    MU.prune_linear_layer = PU.prune_linear_layer
+    MU.find_pruneable_heads_and_indices = lambda *a, **k: None
+    A.swish = A.silu
+    mx.SequenceSummary = mx.XLNetSequenceSummary
+    _iw = MU.PreTrainedModel.init_weights
+    MU.PreTrainedModel.init_weights = (
+        lambda self: self.post_init() if not hasattr(self, "all_tied_weights_keys") else _iw(self))
+    if not hasattr(MU.PreTrainedModel, "get_head_mask"):
+        MU.PreTrainedModel.get_head_mask = lambda self, head_mask, n, *a, **k: [None] * n
+    _lf = mx.XLNetLayer.forward
+    mx.XLNetLayer.forward = lambda self, *a, head_mask=None, **k: _lf(self, *a, **k)
+    wandb = types.ModuleType("wandb")
+    wandb.init = lambda *a, **k: None
+    wandb.log = lambda *a, **k: None
+    sys.modules["wandb"] = wandb
+    O.AdamW = torch.optim.AdamW            # import-only placeholder for the driver
+    import global_configs  # noqa: F401
+    import modeling
+    modeling.DEVICE = torch.device("cpu")
+    import bert
+    import xlnet
+    xlnet.DEVICE = torch.device("cpu")
+    # transformers 3.0.2 semantics of get_extended_attention_mask (bert.py:180-182)
+    bert.MAG_BertModel.get_extended_attention_mask = (
+        lambda self, m, shape, device=None: (1.0 - m[:, None, None, :].to(torch.float32)) * -10000.0)
+    return cb, modeling, bert, xlnet
+
+
+def _load(model, mode):
+    from oracle import weights
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(weights.make_param(n, tuple(p.shape), mode)))
+
+
+def _slice(t, n=32):
+    """Deterministic strided sample of a tensor (pins values without storing MBs)."""
+    from oracle import weights
+    return weights.strided_sample(t.detach().numpy(), n)
+
+
+def _maxdiff(a, b):
+    return float((a.detach() - b.detach()).abs().max())
+
+
+class MC(object):
+    def __init__(self, beta_shift, dropout_prob):
+        self.beta_shift = beta_shift
+        self.dropout_prob = dropout_prob
+
+
+def mag_inputs(B, L, V, A, H=768, salt=0):
+    from oracle import weights
+    e = weights.uniform("mag.e", (B, L, H), -1.5, 1.5, salt)
+    batch = weights.synthetic_bert_batch(B, L, V, A, seed=77 + salt, min_len=2)
+    return e, batch["visual"], batch["acoustic"]
+
+
+def gen_mag(modeling):
+    """G1: MAG forward + backward (modeling.py:25-51) for V in {47,35}, bias modes, beta in {1,1e-3}."""
+    from oracle import mag_bert_ref as R
+    out = {}
+    worst = 0.0
+    for V in (47, 35):
+        for mode in ("test", "init"):
+            for beta in (1.0, 1e-3):
+                modeling.VISUAL_DIM = V
+                ref = modeling.MAG(768, beta, 0.5)
+                named = {"bert.MAG." + n: p for n, p in ref.named_parameters()}
+                from oracle import weights
+                with torch.no_grad():
+                    for n, p in named.items():
+                        p.copy_(torch.from_numpy(weights.make_param(n, tuple(p.shape), mode)))
+                mine = R.MAG(768, beta, 0.5, V, 74)
+                mine.load_state_dict(ref.state_dict())
+                ref.eval(); mine.eval()
+                B, L = 2, 8
+                e_np, v_np, a_np = mag_inputs(B, L, V, 74)
+                res = []
+                for m in (ref, mine):
+                    e = torch.tensor(e_np, requires_grad=True)
+                    v = torch.tensor(v_np, requires_grad=True)
+                    a = torch.tensor(a_np, requires_grad=True)
+                    y = m(e, v, a)
+                    w = torch.from_numpy(weights.uniform("mag.dy", tuple(y.shape)))
+                    m.zero_grad()
+                    (y * w).sum().backward()
+                    res.append((y, e.grad, v.grad, a.grad, {n: p.grad.clone() for n, p in m.named_parameters()}))
+                (y0, de0, dv0, da0, g0), (y1, de1, dv1, da1, g1) = res
+                worst = max(worst, _maxdiff(y0, y1), _maxdiff(de0, de1), _maxdiff(dv0, dv1), _maxdiff(da0, da1))
+                for n in g0:
+                    worst = max(worst, _maxdiff(g0[n], g1[n]))
+                key = "V%d_%s_b%g" % (V, mode, beta)
+                out[key + "/out"] = y0.detach().numpy()
+                out[key + "/d_text"] = de0.numpy()
+                out[key + "/d_visual"] = dv0.numpy()
+                out[key + "/d_acoustic"] = da0.numpy()
+                for n, g in g0.items():
+                    out[key + "/gnorm/" + n] = np.float32(g.norm().item())
+                    out[key + "/gslice/" + n] = _slice(g)
+    modeling.VISUAL_DIM = 47
+    print("G1 MAG: restatement vs reference max |diff| = %.3g" % worst)
+    assert worst < 1e-5
+    np.savez_compressed(os.path.join(GOLD, "g1_mag.npz"), **out)
+
+
+def build_pair(cb, modeling, bert, V, L_layers=12, mode="test", beta=1.0, p_mag=0.5):
+    from oracle import mag_bert_ref as R
+    modeling.VISUAL_DIM = V
+    bert.VISUAL_DIM = V
+    cfg = cb.BertConfig(num_labels=1, num_hidden_layers=L_layers)
+    cfg._attn_implementation = "eager"
+    ref = bert.MAG_BertForSequenceClassification(cfg, MC(beta, p_mag))
+    _load(ref, mode)
+    mine = R.MAG_BertForSequenceClassification(R.BertConfigLite(num_hidden_layers=L_layers), R.MultimodalConfig(beta, p_mag), V, 74)
+    sd = {k: v for k, v in ref.state_dict().items() if "position_ids" not in k and "token_type_ids" not in k}
+    mine.load_state_dict(sd, strict=True)
+    modeling.VISUAL_DIM = 47
+    bert.VISUAL_DIM = 47
+    return ref, mine
+
+
+def _tb(batch):
+    return (torch.from_numpy(batch["input_ids"]), torch.from_numpy(batch["visual"]), torch.from_numpy(batch["acoustic"]),
+            torch.from_numpy(batch["input_mask"]), torch.from_numpy(batch["segment_ids"]), torch.from_numpy(batch["label_ids"]))
+
+
+def gen_embeddings_layer(cb, modeling, bert):
+    """G2 BertEmbeddings output; G3 one BertLayer fwd/bwd with a padded mask."""
+    from oracle import weights
+    ref, mine = build_pair(cb, modeling, bert, 47, L_layers=1)
+    ref.eval(); mine.eval()
+    batch = weights.synthetic_bert_batch(2, 8, 47, 74, seed=5, min_len=2)
+    ids, vis, aco, mask, seg, lab = _tb(batch)
+    seg = seg.clone(); seg[1, 3:] = 1          # exercise the token-type table
+    out = {}
+    e_ref = ref.bert.embeddings(input_ids=ids, token_type_ids=seg)
+    e_mine = mine.bert.embeddings(ids, seg)
+    d = _maxdiff(e_ref, e_mine)
+    print("G2 embeddings: max |diff| = %.3g" % d); assert d < 1e-5
+    out["emb/segment_ids"] = seg.numpy()
+    out["emb/out"] = e_ref.detach().numpy()
+    # one layer
+    x_np = weights.uniform("layer.x", (2, 8, 768), -1.0, 1.0)
+    ext = (1.0 - mask[:, None, None, :].float()) * -10000.0
+    res = []
+    for m, lyr in ((ref, ref.bert.encoder.layer[0]), (mine, mine.bert.encoder.layer[0])):
+        x = torch.tensor(x_np, requires_grad=True)
+        y = lyr(x, ext)
+        y = y[0] if isinstance(y, tuple) else y
+        w = torch.from_numpy(weights.uniform("layer.dy", tuple(y.shape)))
+        m.zero_grad()
+        (y * w).sum().backward()
+        res.append((y, x.grad, {n: p.grad.clone() for n, p in lyr.named_parameters()}))
+    (y0, dx0, g0), (y1, dx1, g1) = res
+    d = max([_maxdiff(y0, y1), _maxdiff(dx0, dx1)] + [_maxdiff(g0[n], g1[n]) for n in g0])
+    print("G3 BertLayer fwd/bwd: max |diff| = %.3g" % d); assert d < 2e-5
+    out["layer/out"] = y0.detach().numpy()
+    out["layer/dx"] = dx0.numpy()
+    for n, g in g0.items():
+        out["layer/gnorm/" + n] = np.float32(g.norm().item())
+        out["layer/gslice/" + n] = _slice(g)
+    np.savez_compressed(os.path.join(GOLD, "g2g3_embeddings_layer.npz"), **out)
+
+
+def gen_full(cb, modeling, bert):
+    """G4 eval logits (B=4,48 @L=50 V=47; B=4 @L=128 V=35); G5 train-mode p=0 loss + per-tensor grad norms."""
+    from oracle import weights
+    from oracle import mag_bert_ref as R
+    out = {}
+    for (B, L, V, seed) in ((4, 50, 47, 11), (48, 50, 47, 12), (4, 128, 35, 13)):
+        ref, mine = build_pair(cb, modeling, bert, V)
+        ref.eval(); mine.eval()
+        ids, vis, aco, mask, seg, lab = _tb(weights.synthetic_bert_batch(B, L, V, 74, seed=seed))
+        with torch.no_grad():
+            lr_ = ref(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
+            lm_ = mine(ids, vis, aco, attention_mask=mask, token_type_ids=seg)[0]
+        d = _maxdiff(lr_, lm_)
+        print("G4 logits B=%d L=%d V=%d: max |diff| = %.3g  (|logit| max %.3g)" % (B, L, V, d, float(lr_.abs().max())))
+        assert d < 2e-5
+        out["logits/B%d_L%d_V%d_seed%d" % (B, L, V, seed)] = lr_.numpy()
+    # G5: gradients, dropout p = 0 in train mode ("Dropout")
+    ref, mine = build_pair(cb, modeling, bert, 47, p_mag=0.0)
+    for m in (ref, mine):
+        m.train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+    ids, vis, aco, mask, seg, lab = _tb(weights.synthetic_bert_batch(4, 50, 47, 74, seed=21))
+    losses = []
+    grads = []
+    for m, kw in ((ref, dict(token_type_ids=seg, attention_mask=mask, labels=None)), (mine, dict(attention_mask=mask, token_type_ids=seg))):
+        m.zero_grad()
+        logits = m(ids, vis, aco, **kw)[0]
+        loss = torch.nn.MSELoss()(logits.view(-1), lab.view(-1))       # multimodal_driver.py:372-373
+        loss.backward()
+        losses.append(loss.detach())
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters()})
+    # key biases have a mathematically zero gradient (softmax is shift-invariant per row), so
+    # normalise by max(|g|_max of the tensor, 1e-3 * global |g|_max) instead of per-tensor only.
+    gmax = max(float(g.abs().max()) for g in grads[0].values())
+    rel = {n: _maxdiff(grads[0][n], grads[1][n]) / max(float(grads[0][n].abs().max()), 1e-3 * gmax) for n in grads[0]}
+    worst = max(rel, key=rel.get)
+    d = rel[worst]
+    print("G5 loss ref %.6f mine %.6f ; worst relative grad diff %.3g (%s)" % (losses[0], losses[1], d, worst))
+    assert abs(float(losses[0] - losses[1])) < 1e-5 and d < 1e-3
+    out["train/loss_B4_L50_seed21"] = np.float32(losses[0].item())
+    for n, g in grads[0].items():
+        out["train/gnorm/" + n] = np.float32(g.norm().item())
+        out["train/gslice/" + n] = _slice(g, 16)
+    np.savez_compressed(os.path.join(GOLD, "g4g5_full_model.npz"), **out)
+
+
+class FakeTokenizer(object):
+    """Stands in for BertTokenizer / XLNetTokenizer (no vocab files offline): splits a word into
+    2-character pieces and maps pieces to ids by a fixed hash, so integer layout can be pinned."""
+    def __init__(self, kind):
+        self.kind = kind
+        self.cls_token, self.sep_token = ("[CLS]", "[SEP]") if kind == "bert" else ("<cls>", "<sep>")
+        self.pad_token_id = 0 if kind == "bert" else 5
+
+    def tokenize(self, word):
+        return [word[i:i + 2] for i in range(0, len(word), 2)] or [word]
+
+    def convert_tokens_to_ids(self, toks):
+        special = {"[CLS]": 101, "[SEP]": 102, "<cls>": 3, "<sep>": 4}
+        import zlib
+        return [special.get(t, 1000 + zlib.crc32(t.encode()) % 20000) for t in toks]
+
+
+def gen_features():
+    """G7: convert_to_features / prepare_bert_input / prepare_xlnet_input integer layouts
+    (multimodal_driver.py:82-205) and G9: test_score_model metrics (:462-480)."""
+    argv = sys.argv
+    sys.argv = ["multimodal_driver.py"]
+    import multimodal_driver as D
+    sys.argv = argv
+    from oracle import weights
+    words_sets = [["hello", "world"], ["a"] * 3, ["abcdefgh"] * 30, ["xy"] * 48, ["pq"] * 49]
+    out = {}
+    for kind, model_name in (("bert", "bert-base-uncased"), ("xlnet", "xlnet-base-cased")):
+        D.args.model = model_name
+        D.args.max_seq_length = 50
+        examples = []
+        for i, words in enumerate(words_sets):
+            n = len(words)
+            vis = weights.uniform("feat.v%d" % i, (n, 47))
+            aco = weights.uniform("feat.a%d" % i, (n, 74))
+            examples.append(((words, vis, aco), float(i) - 1.5, "seg%d" % i))
+        feats = D.convert_to_features(examples, 50, FakeTokenizer(kind))
+        out[kind + "/input_ids"] = np.array([f.input_ids for f in feats], np.int64)
+        out[kind + "/input_mask"] = np.array([f.input_mask for f in feats], np.int64)
+        out[kind + "/segment_ids"] = np.array([f.segment_ids for f in feats], np.int64)
+        out[kind + "/visual"] = np.array([f.visual for f in feats], np.float32)
+        out[kind + "/acoustic"] = np.array([f.acoustic for f in feats], np.float32)
+    # G9 metrics
+    preds = weights.uniform("score.preds", (64,), -3, 3)
+    labels = np.round(weights.uniform("score.labels", (64,), -3, 3) * 2) / 2
+    D.test_epoch = lambda model, loader: (preds.copy(), labels.copy())
+    for uz in (False, True):
+        acc, mae, corr, f1 = D.test_score_model(None, None, use_zero=uz)
+        out["score/use_zero_%d" % int(uz)] = np.array([acc, mae, corr, f1], np.float64)
+    out["score/preds"] = preds
+    out["score/labels"] = labels.astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "g7g9_features_metrics.npz"), **out)
+    print("G7/G9 written")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    os.makedirs(GOLD, exist_ok=True)
+    cb, modeling, bert, xlnet = install_shim()
+    which = sys.argv[1:] or ["mag", "layer", "full", "features"]
+    if "mag" in which:
+        gen_mag(modeling)
+    if "layer" in which:
+        gen_embeddings_layer(cb, modeling, bert)
+    if "full" in which:
+        gen_full(cb, modeling, bert)
+    if "features" in which:
+        gen_features()
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(HERE))
+    main()
