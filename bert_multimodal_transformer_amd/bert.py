@@ -1,0 +1,429 @@
+"""MAG_BertModel / MAG_BertForSequenceClassification -- drop-in surfaces of /root/reference/bert.py:76-324,
+backed by the native MI355X step executor (csrc/engine.hip) instead of transformers' BertEmbeddings /
+BertEncoder / BertPooler.
+
+Kept verbatim from the reference: class names, constructor `(config, multimodal_config)`, forward argument order and
+defaults, returned tuples `((loss,) logits, ...)` / `(sequence_output, pooled_output)`, `from_pretrained(name,
+multimodal_config=..., num_labels=1)`, and every state-dict key (bert.embeddings.*, bert.encoder.layer.{i}.*,
+bert.pooler.dense.*, bert.MAG.*, classifier.*) so reference / HuggingFace checkpoints load unchanged.
+
+Different by design (MI355X-first):
+  * all parameters are views of ONE flat fp32 buffer (weight-decay group first) with a matching flat gradient buffer:
+    the optimizer is one fused launch and the data-parallel all-reduce runs on a handful of large contiguous ranges;
+  * forward/backward are single C calls that enqueue the whole pass on the current HIP stream;
+  * `compute_dtype=torch.bfloat16` (perf mode) keeps bf16 activations + a bf16 operand shadow of the GEMM weights;
+    `torch.float32` (parity mode) runs exact-fp32 MFMA and matches the CPU reference logits to < 1e-3;
+  * options the driver never uses (head_mask, inputs_embeds, position_ids, output_attentions/hidden_states,
+    encoder_hidden_states) raise NotImplementedError instead of silently taking a slow path.
+"""
+import ctypes as C
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .global_configs import ACOUSTIC_DIM, VISUAL_DIM
+
+
+class BertConfig(object):
+    """The subset of transformers.BertConfig the path reads (bert-base-uncased defaults)."""
+
+    def __init__(self, vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                 max_position_embeddings=512, type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-12,
+                 pad_token_id=0, num_labels=1, **kwargs):
+        if hidden_act != "gelu":
+            raise NotImplementedError("only erf-GELU (bert-base-uncased) is built")
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.num_hidden_layers = num_hidden_layers
+        self.num_attention_heads = num_attention_heads
+        self.intermediate_size = intermediate_size
+        self.hidden_act = hidden_act
+        self.hidden_dropout_prob = hidden_dropout_prob
+        self.attention_probs_dropout_prob = attention_probs_dropout_prob
+        self.max_position_embeddings = max_position_embeddings
+        self.type_vocab_size = type_vocab_size
+        self.initializer_range = initializer_range
+        self.layer_norm_eps = layer_norm_eps
+        self.pad_token_id = pad_token_id
+        self.num_labels = num_labels
+        self.output_attentions = False
+        self.output_hidden_states = False
+        self.is_decoder = False
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+
+class _Holder(nn.Module):
+    """Plain container so parameters get the reference's dotted names."""
+
+
+class _EngineFn(torch.autograd.Function):
+    """logits = model(batch): the forward was already enqueued; backward hands dlogits to the engine, which
+    accumulates into the flat gradient buffer (p.grad are views of it)."""
+
+    @staticmethod
+    def forward(ctx, anchor, logits, core):
+        ctx.core = core
+        return logits.view_as(logits)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.core._backward(dlogits.contiguous().float())
+        return torch.zeros((), device=dlogits.device), None, None
+
+
+class _Core(object):
+    """Flat parameter/gradient storage + engine handle shared by the model classes."""
+
+    def __init__(self, config, multimodal_config, visual_dim, acoustic_dim, compute_dtype, device):
+        if not torch.cuda.is_available():
+            raise _lib.MagbertError("MAG-BERT runs on the HIP path only: no ROCm device visible (no CPU fallback)")
+        self.lib = _lib.lib()
+        self.config = config
+        self.mc = multimodal_config
+        self.V, self.A = int(visual_dim), int(acoustic_dim)
+        self.compute_dtype = compute_dtype
+        self.dt = _lib.DT_BF16 if compute_dtype == torch.bfloat16 else _lib.DT_F32
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.handle = None
+        self.max_B, self.max_L = 0, 0
+        self.seed = int(torch.initial_seed())
+        self.step = 0
+        self.training_last = False
+        self.grad_hook = None          # set by distributed.DataParallel: hook(stage) after each backward stage
+        self._make_engine(1, 8)
+        n = self.lib.mb_bert_param_count(self.handle)
+        self.n_params = n
+        self.n_decay = self.lib.mb_bert_decay_count(self.handle)
+        b, e = C.c_size_t(), C.c_size_t()
+        self.lib.mb_bert_shadow_range(self.handle, C.byref(b), C.byref(e))
+        self.sh_begin, self.sh_end = b.value, e.value
+        self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.shadow = torch.zeros(n if self.dt == _lib.DT_BF16 else 1, dtype=torch.bfloat16, device=self.device)
+        self.ws = None
+        self.tensors = self._tensor_table()
+        self.anchor = torch.zeros((), device=self.device, requires_grad=True)
+        self.weights_dirty = True
+        self.loss_buf = torch.zeros(2, dtype=torch.float32, device=self.device)   # [last step, running sum]
+
+    # -- engine lifecycle ---------------------------------------------------------------------------
+    def _cfg(self, B, L):
+        c, mc = self.config, self.mc
+        return _lib.BertEngineConfig(
+            c.vocab_size, c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.intermediate_size,
+            c.max_position_embeddings, c.type_vocab_size, c.num_labels, self.V, self.A, c.pad_token_id,
+            c.layer_norm_eps, 1e-5, float(mc.beta_shift), c.hidden_dropout_prob, c.attention_probs_dropout_prob,
+            float(mc.dropout_prob), self.dt, int(B), int(L))
+
+    def _make_engine(self, B, L):
+        if self.handle is not None:
+            self.lib.mb_bert_destroy(self.handle)
+        h = C.c_void_p()
+        cfg = self._cfg(B, L)
+        _lib.check(self.lib.mb_bert_create(C.byref(cfg), C.byref(h)))
+        self.handle = h
+        self.max_B, self.max_L = B, L
+
+    def _ensure(self, B, L):
+        if B > self.max_B or L > self.max_L or self.ws is None:
+            self._make_engine(max(B, self.max_B), max(L, self.max_L))
+            nbytes = self.lib.mb_bert_workspace_bytes(self.handle)
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.mb_bert_bind(self.handle, _lib.ptr(self.params), _lib.ptr(self.grads),
+                                             _lib.ptr(self.shadow) if self.dt == _lib.DT_BF16 else None,
+                                             _lib.ptr(self.ws), nbytes))
+            self.weights_dirty = True
+
+    def _tensor_table(self):
+        out = []
+        name = C.create_string_buffer(160)
+        off, numel, ndim, decay = C.c_size_t(), C.c_size_t(), C.c_int(), C.c_int()
+        shape = (C.c_int64 * 4)()
+        for i in range(self.lib.mb_bert_num_tensors(self.handle)):
+            _lib.check(self.lib.mb_bert_tensor_info(self.handle, i, name, 160, C.byref(off), C.byref(numel), C.byref(ndim),
+                                                    shape, C.byref(decay)))
+            out.append((name.value.decode(), off.value, numel.value, tuple(shape[k] for k in range(ndim.value)),
+                        bool(decay.value)))
+        return out
+
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def sync_weights(self):
+        """refresh bf16 shadow + packed MAG operands from the fp32 masters (after load / manual edits)"""
+        _lib.check(self.lib.mb_bert_sync_weights(self.handle, self.stream()))
+        self.weights_dirty = False
+
+    # -- passes --------------------------------------------------------------------------------------
+    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, training):
+        B, L = input_ids.shape
+        dev = self.device
+        self._ensure(B, L)
+        if self.weights_dirty:
+            self.sync_weights()
+        ids = input_ids.to(dev, torch.int64).contiguous()
+        msk = attention_mask.to(dev, torch.int64).contiguous()
+        seg = token_type_ids.to(dev, torch.int64).contiguous()
+        vis = visual.to(dev, torch.float32).contiguous()
+        aco = acoustic.to(dev, torch.float32).contiguous()
+        if vis.shape != (B, L, self.V) or aco.shape != (B, L, self.A):
+            raise ValueError("visual/acoustic must be [B, L, %d] / [B, L, %d], got %s / %s" %
+                             (self.V, self.A, tuple(vis.shape), tuple(aco.shape)))
+        lab = None if labels is None else labels.to(dev, torch.float32).contiguous().view(-1)
+        logits = torch.empty(B, self.config.num_labels, dtype=torch.float32, device=dev)
+        if training:
+            self.step += 1
+        self._keep = (ids, msk, seg, vis, aco, lab, logits)      # engine keeps raw pointers until the backward
+        self.training_last = bool(training)
+        _lib.check(self.lib.mb_bert_forward(self.handle, _lib.ptr(ids), _lib.ptr(vis), _lib.ptr(aco), _lib.ptr(msk),
+                                            _lib.ptr(seg), _lib.ptr(lab), B, L, 1 if training else 0, self.seed, self.step,
+                                            _lib.ptr(logits), C.c_void_p(self.loss_buf.data_ptr()),
+                                            C.c_void_p(self.loss_buf.data_ptr() + 4) if lab is not None else None,
+                                            self.stream()))
+        return logits
+
+    def _backward(self, dlogits=None, loss_scale=1.0):
+        nstage = self.config.num_hidden_layers + 2
+        lab = self._keep[5]
+        if dlogits is None and lab is None:
+            raise ValueError("fused backward needs the labels passed to forward()")
+        for s in range(nstage):
+            _lib.check(self.lib.mb_bert_backward(self.handle, _lib.ptr(dlogits), _lib.ptr(lab) if dlogits is None else None,
+                                                 float(loss_scale), s, s + 1, self.stream()))
+            if self.grad_hook is not None:
+                self.grad_hook(s)
+
+    def sequence_output(self, B, L):
+        H = self.config.hidden_size
+        p = self.lib.mb_bert_sequence_output(self.handle)
+        es = 2 if self.dt == _lib.DT_BF16 else 4
+        off = p - self.ws.data_ptr()
+        raw = self.ws[off: off + B * L * H * es]
+        return raw.view(self.compute_dtype).view(B, L, H).float()
+
+    def pooled_output(self, B):
+        H = self.config.hidden_size
+        p = self.lib.mb_bert_pooled_output(self.handle)
+        off = p - self.ws.data_ptr()
+        return self.ws[off: off + B * H * 4].view(torch.float32).view(B, H).clone()
+
+    def stage_ranges(self, stage):
+        offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+        n = self.lib.mb_bert_stage_grad_ranges(self.handle, stage, offs, lens, 8)
+        return [(offs[i], lens[i]) for i in range(n)]
+
+    def __del__(self):
+        try:
+            if self.handle is not None:
+                self.lib.mb_bert_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def _attach_parameters(root, core, prefix_filter=None, strip=""):
+    """Registers one nn.Parameter per reference tensor, as a view of the flat buffer, under its dotted name."""
+    for name, off, numel, shape, decay in core.tensors:
+        if prefix_filter is not None and not name.startswith(prefix_filter):
+            continue
+        rel = name[len(strip):] if strip and name.startswith(strip) else name
+        parts = rel.split(".")
+        mod = root
+        for part in parts[:-1]:
+            if not hasattr(mod, part):
+                mod.add_module(part, _Holder())
+            mod = getattr(mod, part)
+        p = nn.Parameter(core.params[off: off + numel].view(shape))
+        p.grad = core.grads[off: off + numel].view(shape)
+        p._mb_flat = (core, off, numel, decay)
+        mod.register_parameter(parts[-1], p)
+
+
+def _init_weights(core):
+    """transformers PreTrainedModel._init_weights law (bert.py:90,249): Linear/Embedding ~ N(0, initializer_range),
+    biases 0, LayerNorm 1/0, embedding padding row 0 -- also applied to MAG's Linears, as in the reference where
+    init_weights() runs after self.MAG is built."""
+    std = core.config.initializer_range
+    g = torch.Generator(device=core.device)
+    g.manual_seed(int(torch.initial_seed()) & 0x7FFFFFFF)
+    with torch.no_grad():
+        for name, off, numel, shape, decay in core.tensors:
+            v = core.params[off: off + numel]
+            leaf = name.split(".")[-1]
+            if "LayerNorm" in name:
+                v.fill_(1.0 if leaf == "weight" else 0.0)
+            elif leaf == "bias":
+                v.zero_()
+            else:
+                v.normal_(0.0, std, generator=g)
+                if name.endswith("word_embeddings.weight"):
+                    H = shape[1]
+                    v[core.config.pad_token_id * H:(core.config.pad_token_id + 1) * H].zero_()
+    core.weights_dirty = True
+
+
+class _MagBertBase(nn.Module):
+    def _unsupported(self, **kw):
+        for k, v in kw.items():
+            if v is not None and v is not False:
+                raise NotImplementedError("%s is not supported by the HIP path (unused by multimodal_driver.py:363-370)" % k)
+
+    def to(self, *args, **kwargs):
+        # parameters are views of one flat HBM buffer created on the target device; the reference's
+        # model.to(DEVICE) (multimodal_driver.py:325) is therefore a no-op
+        dev = None
+        for a in args:
+            if isinstance(a, (torch.device, str)):
+                dev = torch.device(a)
+        dev = kwargs.get("device", dev)
+        if dev is not None and torch.device(dev).type != "cuda":
+            raise _lib.MagbertError("the HIP model cannot be moved off the ROCm device (no CPU fallback)")
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._core.weights_dirty = True
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        sd = {k: v for k, v in state_dict.items() if not k.endswith("position_ids")}
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        self._core.weights_dirty = True
+        return r
+
+    def init_weights(self):
+        _init_weights(self._core)
+
+    def zero_grad(self, set_to_none=False):
+        # p.grad are views of the flat gradient buffer the engine accumulates into: clear it in place
+        self._core.grads.zero_()
+
+    def sync_weights(self):
+        """call after editing parameters in place (bf16 mode keeps an operand shadow of the GEMM weights)"""
+        self._core.sync_weights()
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, **kwargs):
+        """multimodal_driver.py:317-319.  There is no network here: the argument must be a local directory
+        (or file) holding a `pytorch_model.bin`-style state dict; missing keys (bert.MAG.*, classifier.*) keep
+        their fresh init exactly like the reference."""
+        multimodal_config = kwargs.pop("multimodal_config", model_args[0] if model_args else None)
+        num_labels = kwargs.pop("num_labels", 1)
+        config = config or BertConfig(num_labels=num_labels)
+        config.num_labels = num_labels
+        model = cls(config, multimodal_config, **kwargs)
+        path = pretrained_model_name_or_path
+        if os.path.isdir(path):
+            path = os.path.join(path, "pytorch_model.bin")
+        if not os.path.isfile(path):
+            raise OSError("from_pretrained(%r): no local checkpoint (offline build; pass a directory or state-dict file, "
+                          "or construct %s(config, multimodal_config) and load_state_dict yourself)" %
+                          (pretrained_model_name_or_path, cls.__name__))
+        sd = torch.load(path, map_location="cpu")
+        own = model.state_dict().keys()
+        if not any(k in own for k in sd):          # plain BertModel checkpoint: keys lack the "bert." prefix
+            sd = {"bert." + k: v for k, v in sd.items()}
+        model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+        return model
+
+
+class MAG_BertModel(_MagBertBase):
+    """bert.py:76-237.  forward -> (sequence_output, pooled_output).  Outputs are fp32 copies of engine activations
+    (not differentiable; the trainable surface is MAG_BertForSequenceClassification, which is what the driver uses)."""
+
+    def __init__(self, config, multimodal_config, visual_dim=VISUAL_DIM, acoustic_dim=ACOUSTIC_DIM,
+                 compute_dtype=torch.float32, device=None, _core=None):
+        super().__init__()
+        self.config = config
+        own = _core is None
+        self._core = _core or _Core(config, multimodal_config, visual_dim, acoustic_dim, compute_dtype, device)
+        _attach_parameters(self, self._core, prefix_filter="bert.", strip="bert.")
+        if own:
+            self.init_weights()
+
+    def get_input_embeddings(self):
+        return self.embeddings.word_embeddings
+
+    def forward(self, input_ids, visual, acoustic, attention_mask=None, token_type_ids=None, position_ids=None,
+                head_mask=None, inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                output_attentions=None, output_hidden_states=None):
+        self._unsupported(position_ids=position_ids, head_mask=head_mask, inputs_embeds=inputs_embeds,
+                          encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask,
+                          output_attentions=output_attentions, output_hidden_states=output_hidden_states)
+        if input_ids is None:
+            raise ValueError("You have to specify either input_ids or inputs_embeds")      # bert.py:166-168
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)                                      # bert.py:173-174
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)                                     # bert.py:175-177
+        B, L = input_ids.shape
+        self._core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training)
+        return self._core.sequence_output(B, L), self._core.pooled_output(B)
+
+
+class MAG_BertForSequenceClassification(_MagBertBase):
+    """bert.py:240-324."""
+
+    def __init__(self, config, multimodal_config, visual_dim=VISUAL_DIM, acoustic_dim=ACOUSTIC_DIM,
+                 compute_dtype=torch.float32, device=None):
+        super().__init__()
+        self.config = config
+        self.num_labels = config.num_labels
+        self._core = _Core(config, multimodal_config, visual_dim, acoustic_dim, compute_dtype, device)
+        self.bert = MAG_BertModel(config, multimodal_config, visual_dim, acoustic_dim, compute_dtype, device, _core=self._core)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)        # bert.py:246 (p lives in the engine config)
+        _attach_parameters(self, self._core, prefix_filter="classifier.")
+        self.init_weights()
+
+    # reference API ------------------------------------------------------------------------------------
+    def forward(self, input_ids, visual, acoustic, attention_mask=None, token_type_ids=None, position_ids=None,
+                head_mask=None, inputs_embeds=None, labels=None, output_attentions=None, output_hidden_states=None):
+        self._unsupported(position_ids=position_ids, head_mask=head_mask, inputs_embeds=inputs_embeds,
+                          output_attentions=output_attentions, output_hidden_states=output_hidden_states)
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        core = self._core
+        logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training)
+        if torch.is_grad_enabled():
+            logits = _EngineFn.apply(core.anchor, logits, core)
+        outputs = (logits,)
+        if labels is not None:                                        # bert.py:313-322
+            if self.num_labels == 1:
+                loss = torch.nn.functional.mse_loss(logits.view(-1), labels.to(logits.device).float().view(-1))
+            else:
+                loss = torch.nn.functional.cross_entropy(logits.view(-1, self.num_labels), labels.to(logits.device).view(-1))
+            outputs = (loss,) + outputs
+        return outputs
+
+    # fused fast path (what the bundled driver / bench use) ----------------------------------------------
+    def training_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, loss_scale=1.0):
+        """forward + MSE (multimodal_driver.py:372-373) + backward in two C calls, no host sync.
+        Returns the device scalar holding this step's loss (running sum is in .loss_running())."""
+        if self.num_labels != 1:
+            raise NotImplementedError("fused loss is the regression MSE of the driver (num_labels == 1)")
+        core = self._core
+        core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, True)
+        core._backward(None, loss_scale)
+        return core.loss_buf[0]
+
+    def loss_running(self, reset=False):
+        v = self._core.loss_buf[1].clone()
+        if reset:
+            self._core.loss_buf[1].zero_()
+        return v
+
+    # flat views for the fused optimizer / data parallel -------------------------------------------------
+    @property
+    def flat_params(self):
+        return self._core.params
+
+    @property
+    def flat_grads(self):
+        return self._core.grads

@@ -1,0 +1,65 @@
+// transformers==3.0.2 AdamW (/root/reference/multimodal_driver.py:28,345,384) as ONE launch over flat buffers.
+//   m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; p <- p - step_size * m / (sqrt(v) + eps) ; p <- p - lr*wd*p
+// (eps OUTSIDE the sqrt and before bias correction, decoupled decay AFTER the update on the updated p --
+//  not torch.optim.AdamW).  HBM-bound: reads p,g,m,v and writes p,m,v = 28 B/param, + 4 B/param to zero the
+//  gradient in place (replaces optimizer.zero_grad()) + 2 B/param for the bf16 operand shadow of GEMM weights.
+// The flat layout puts every weight-decayed tensor first: elements [0, n_decay) decay, the rest do not.
+#include "kernels.h"
+
+namespace mb {
+
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16* __restrict__ shadow, size_t n4,
+                                                    size_t n_decay, size_t sh_begin, size_t sh_end, AdamArgs a,
+                                                    int zero_grad) {
+    const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
+    const float decay = a.lr * a.weight_decay;
+    for (size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * 256) {
+        const size_t i = i4 * 4;
+        f32x4 pv = *(const f32x4*)(p + i), gv = *(const f32x4*)(g + i), mv = *(const f32x4*)(m + i),
+              vv = *(const f32x4*)(v + i);
+        gv *= a.grad_scale;
+        mv = a.beta1 * mv + omb1 * gv;
+        vv = a.beta2 * vv + omb2 * gv * gv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] -= a.step_size * (mv[r] / (sqrtf(vv[r]) + a.eps));
+        if (i < n_decay && decay > 0.f) pv -= decay * pv;
+        *(f32x4*)(p + i) = pv;
+        *(f32x4*)(m + i) = mv;
+        *(f32x4*)(v + i) = vv;
+        if (zero_grad) *(f32x4*)(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (shadow && i >= sh_begin && i < sh_end) store4(shadow + i, pv);
+    }
+}
+
+// scalar tail (n % 4 elements) -- only hit by stand-alone tensors, the engine's flat buffers are 64-aligned
+__global__ void adamw_tail_kernel(float* p, float* g, float* m, float* v, size_t begin, size_t n, size_t n_decay, AdamArgs a,
+                                  int zero_grad) {
+    const size_t i = begin + threadIdx.x;
+    if (i >= n) return;
+    const float gv = g[i] * a.grad_scale;
+    const float mv = a.beta1 * m[i] + (1.0f - a.beta1) * gv;
+    const float vv = a.beta2 * v[i] + (1.0f - a.beta2) * gv * gv;
+    float pv = p[i] - a.step_size * (mv / (sqrtf(vv) + a.eps));
+    if (i < n_decay && a.lr * a.weight_decay > 0.f) pv -= a.lr * a.weight_decay * pv;
+    p[i] = pv; m[i] = mv; v[i] = vv;
+    if (zero_grad) g[i] = 0.f;
+}
+
+int adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, size_t n_decay, size_t sh_begin,
+               size_t sh_end, AdamArgs a, int zero_grad, hipStream_t st) {
+    if (n == 0) return MB_OK;
+    if ((n_decay % 4 && n_decay < n) || (sh_begin % 4) || (sh_end % 4)) return MB_ERR_SHAPE;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return MB_ERR_SHAPE;
+    const size_t n4 = n / 4;
+    if (n4) {
+        unsigned grid = (unsigned)((n4 + 255) / 256);
+        if (grid > 256 * 16) grid = 256 * 16;
+        hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16*)shadow, n4, n_decay, sh_begin,
+                           sh_end, a, zero_grad);
+    }
+    if (n % 4) hipLaunchKernelGGL(adamw_tail_kernel, dim3(1), dim3(64), 0, st, p, g, m, v, n4 * 4, n, n_decay, a, zero_grad);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mb

@@ -1,0 +1,397 @@
+// LDS-resident fused self-attention for the BERT encoder, forward and backward (dh = 64, L <= 128).
+//
+// Replaces BertSelfAttention's score bmm + scale + mask add + softmax + dropout + context bmm + permutes
+// (transformers 3.0.2, reached from /root/reference/bert.py:221-229):
+//     S = Q K^T / sqrt(64) + (1 - mask) * -10000 ;  P = dropout(softmax(S)) ;  ctx = P V
+// One workgroup per (batch, head).  Q/K/V (and dO in the backward) are read straight out of the token-major
+// fused-QKV GEMM output [T][3H] (128-byte rows per head) into [row][d] LDS images; scores never leave the CU.
+// Every product is built from the 16x16 MFMA tile primitive (common.h):
+//   * a 16-byte "natural" fragment when the reduction index is contiguous in the image,
+//   * a "k-major" fragment (strided element reads) when the operand is consumed transposed (V in P.V,
+//     K in dS.K, dO / Q in the key-side products) -- attention is ~1% of the layer's FLOPs, so no transposed
+//     copies are kept.
+// The accumulators are laid out so a lane owns 4 consecutive columns of one row: row max / sum are an in-lane
+// reduction plus two cross-lane steps (xor 16, 32).
+// Backward is the two-sweep flash form with recomputation (no P is stored by the forward):
+//   sweep A (query strips): recompute P, dP = dO V^T, D_i = sum_j dP_ij P_ij, dS -> dQ ; stash m_i, 1/l_i, D_i
+//   sweep B (key strips)  : recompute P^T from the stashed row statistics -> dV = Pd^T dO, dK = dS^T Q
+// Dropout masks are regenerated from the counter hash (common.h), index ((b*nh+h)*L + i)*L + j.
+#include "kernels.h"
+
+namespace mb {
+
+template <class T> struct AttnCfg;
+template <> struct AttnCfg<bf16> { static constexpr int SLAB = 32, EPV = 8, ROWB = 128; };
+template <> struct AttnCfg<float> { static constexpr int SLAB = 16, EPV = 4, ROWB = 256; };
+
+template <class T>
+__device__ __forceinline__ typename Frag<T>::type frag_nat(const char* img, int pitch, int row, int slab, int lane) {
+    return *(const typename Frag<T>::type*)(img + row * pitch + slab * 64 + (lane >> 4) * 16);
+}
+// fragment of the TRANSPOSED image: element e = img[k0 + e][col]
+__device__ __forceinline__ bf16x8 frag_kmaj(const char* img, int pitch, int k0, int col, bf16) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = *(const bf16*)(img + (k0 + e) * pitch + col * 2);
+    return v;
+}
+__device__ __forceinline__ f32x4 frag_kmaj(const char* img, int pitch, int k0, int col, float) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = *(const float*)(img + (k0 + e) * pitch + col * 4);
+    return v;
+}
+
+// stage rows [0, LP) x 64 elements of one head from the token-major tensor into an LDS image (rows >= L are zero)
+template <class T, int LP, int NTHR>
+__device__ __forceinline__ void stage_head(char* img, int pitch, const T* __restrict__ src, size_t ld, int L) {
+    constexpr int CPR = AttnCfg<T>::ROWB / 16;
+    for (int id = threadIdx.x; id < LP * CPR; id += NTHR) {
+        const int row = id / CPR, c = id % CPR;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < L) v = *(const u32x4*)((const char*)(src + (size_t)row * ld) + c * 16);
+        *(u32x4*)(img + row * pitch + c * 16) = v;
+    }
+}
+
+// row-wise reduction across the 4 lanes {i, i+16, i+32, i+48} that share a query/key row
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+constexpr float kMaskNeg = -10000.0f;     // transformers 3.0.2 get_extended_attention_mask
+constexpr float kPadNeg = -1.0e30f;       // keys beyond L (tile padding only)
+
+// =============================================================================================== forward
+template <class T, int LP, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                           T* __restrict__ ctx, int L, int nh, DropKey drop) {
+    typedef AttnCfg<T> C;
+    constexpr int PIT = C::ROWB + 16;                 // image pitch (bytes)
+    constexpr int SPIT = LP * (int)sizeof(T) + 16;    // strip pitch
+    constexpr int NT = LP / 16;                       // 16-wide tiles along L
+    constexpr int DSL = 64 / C::SLAB;                 // k-slabs along d
+    constexpr int LSL = LP / C::SLAB;                 // k-slabs along L
+    __shared__ __attribute__((aligned(16))) char smem[3 * LP * PIT + NW * 16 * SPIT + LP * 4];
+    char* Qi = smem;
+    char* Ki = smem + LP * PIT;
+    char* Vi = smem + 2 * LP * PIT;
+    char* strips = smem + 3 * LP * PIT;
+    float* mbias = (float*)(strips + NW * 16 * SPIT);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    const int H = nh * 64;
+    const size_t ld = (size_t)3 * H;
+    const T* base = qkv + (size_t)b * L * ld + h * 64;
+    stage_head<T, LP, NW * 64>(Qi, PIT, base, ld, L);
+    stage_head<T, LP, NW * 64>(Ki, PIT, base + H, ld, L);
+    stage_head<T, LP, NW * 64>(Vi, PIT, base + 2 * H, ld, L);
+    for (int j = threadIdx.x; j < LP; j += NW * 64)
+        mbias[j] = j < L ? (1.0f - (float)mask[(size_t)b * L + j]) * kMaskNeg : kPadNeg;
+    __syncthreads();
+
+    char* Ps = strips + wave * 16 * SPIT;
+    const float scale = 0.125f;
+    for (int s0 = 0; s0 < NT; s0 += NW) {
+        const int strip = s0 + wave;
+        const bool active = strip < NT;
+        if (active) {
+            f32x4 acc[NT];
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                acc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < DSL; ++sl)
+                    mma16(acc[jt], frag_nat<T>(Ki, PIT, jt * 16 + (lane & 15), sl, lane),
+                          frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
+            }
+            // acc[jt][r] = S[i][j], i = strip*16 + (lane&15), j = jt*16 + (lane>>4)*4 + r
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const f32x4 mb4 = *(const f32x4*)(mbias + jt * 16 + (lane >> 4) * 4);
+                acc[jt] = acc[jt] * scale + mb4;
+                mx = fmaxf(mx, fmaxf(fmaxf(acc[jt][0], acc[jt][1]), fmaxf(acc[jt][2], acc[jt][3])));
+            }
+            mx = quad_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[jt][r] = __expf(acc[jt][r] - mx); sum += acc[jt][r]; }
+            const float inv = 1.0f / quad_sum(sum);
+            const int i = strip * 16 + (lane & 15);
+            const uint32_t rowidx = ((uint32_t)blockIdx.x * L + (uint32_t)i) * L;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const int j = jt * 16 + (lane >> 4) * 4;
+                f32x4 p = acc[jt] * inv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] *= drop_mult(drop, rowidx + j + r);
+                store4((T*)(Ps + (lane & 15) * SPIT) + j, p);
+            }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < LSL; ++sl)
+                    mma16(o, frag_kmaj(Vi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
+                          frag_nat<T>(Ps, SPIT, lane & 15, sl, lane));
+                // o[r] = ctx[i = strip*16 + (lane&15)][d = dt*16 + (lane>>4)*4 + r]
+                const int i = strip * 16 + (lane & 15);
+                if (i < L) store4(ctx + ((size_t)b * L + i) * H + h * 64 + dt * 16 + (lane >> 4) * 4, o);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// =============================================================================================== backward
+template <class T, int LP, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                           const T* __restrict__ dctx, T* __restrict__ dqkv, int L, int nh,
+                                                           DropKey drop) {
+    typedef AttnCfg<T> C;
+    constexpr int PIT = C::ROWB + 16;
+    constexpr int SPIT = LP * (int)sizeof(T) + 16;
+    constexpr int NT = LP / 16;
+    constexpr int DSL = 64 / C::SLAB;
+    constexpr int LSL = LP / C::SLAB;
+    __shared__ __attribute__((aligned(16))) char smem[4 * LP * PIT + NW * 16 * SPIT + 4 * LP * 4];
+    char* Qi = smem;
+    char* Ki = smem + LP * PIT;
+    char* Vi = smem + 2 * LP * PIT;
+    char* Oi = smem + 3 * LP * PIT;          // dO image
+    char* strips = smem + 4 * LP * PIT;
+    float* mbias = (float*)(strips + NW * 16 * SPIT);
+    float* rmax = mbias + LP;
+    float* rinv = rmax + LP;
+    float* rD = rinv + LP;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    const int H = nh * 64;
+    const size_t ld = (size_t)3 * H;
+    const T* base = qkv + (size_t)b * L * ld + h * 64;
+    stage_head<T, LP, NW * 64>(Qi, PIT, base, ld, L);
+    stage_head<T, LP, NW * 64>(Ki, PIT, base + H, ld, L);
+    stage_head<T, LP, NW * 64>(Vi, PIT, base + 2 * H, ld, L);
+    stage_head<T, LP, NW * 64>(Oi, PIT, dctx + (size_t)b * L * H + h * 64, (size_t)H, L);
+    for (int j = threadIdx.x; j < LP; j += NW * 64)
+        mbias[j] = j < L ? (1.0f - (float)mask[(size_t)b * L + j]) * kMaskNeg : kPadNeg;
+    __syncthreads();
+
+    char* St = strips + wave * 16 * SPIT;
+    const float scale = 0.125f;
+    T* dq_base = dqkv + (size_t)b * L * ld + h * 64;
+
+    // ------------------------------------------------------------------ sweep A: query strips -> dQ, row stats
+    for (int s0 = 0; s0 < NT; s0 += NW) {
+        const int strip = s0 + wave;
+        const bool active = strip < NT;
+        if (active) {
+            f32x4 sp[NT], dp[NT];
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                sp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < DSL; ++sl) {
+                    mma16(sp[jt], frag_nat<T>(Ki, PIT, jt * 16 + (lane & 15), sl, lane),
+                          frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
+                    mma16(dp[jt], frag_nat<T>(Vi, PIT, jt * 16 + (lane & 15), sl, lane),
+                          frag_nat<T>(Oi, PIT, strip * 16 + (lane & 15), sl, lane));
+                }
+            }
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const f32x4 mb4 = *(const f32x4*)(mbias + jt * 16 + (lane >> 4) * 4);
+                sp[jt] = sp[jt] * scale + mb4;
+                mx = fmaxf(mx, fmaxf(fmaxf(sp[jt][0], sp[jt][1]), fmaxf(sp[jt][2], sp[jt][3])));
+            }
+            mx = quad_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sp[jt][r] = __expf(sp[jt][r] - mx); sum += sp[jt][r]; }
+            const float inv = 1.0f / quad_sum(sum);
+            const int i = strip * 16 + (lane & 15);
+            const uint32_t rowidx = ((uint32_t)blockIdx.x * L + (uint32_t)i) * L;
+            float dsum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const int j = jt * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sp[jt][r] *= inv;                                   // P_ij
+                    dp[jt][r] *= drop_mult(drop, rowidx + j + r);       // dP_ij (through the dropout)
+                    dsum += dp[jt][r] * sp[jt][r];
+                }
+            }
+            const float D = quad_sum(dsum);
+            if ((lane >> 4) == 0) { rmax[i] = mx; rinv[i] = inv; rD[i] = D; }
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const int j = jt * 16 + (lane >> 4) * 4;
+                const f32x4 ds = sp[jt] * (dp[jt] - D) * scale;
+                store4((T*)(St + (lane & 15) * SPIT) + j, ds);
+            }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < LSL; ++sl)
+                    mma16(o, frag_kmaj(Ki, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
+                          frag_nat<T>(St, SPIT, lane & 15, sl, lane));
+                const int i = strip * 16 + (lane & 15);
+                if (i < L) store4(dq_base + (size_t)i * ld + dt * 16 + (lane >> 4) * 4, o);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ sweep B: key strips -> dV, dK
+    for (int s0 = 0; s0 < NT; s0 += NW) {
+        const int strip = s0 + wave;
+        const bool active = strip < NT;
+        f32x4 sp[NT], dp[NT];
+        const int j = strip * 16 + (lane & 15);          // this lane's key
+        if (active) {
+#pragma unroll
+            for (int it = 0; it < NT; ++it) {
+                sp[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < DSL; ++sl) {
+                    mma16(sp[it], frag_nat<T>(Qi, PIT, it * 16 + (lane & 15), sl, lane),
+                          frag_nat<T>(Ki, PIT, strip * 16 + (lane & 15), sl, lane));
+                    mma16(dp[it], frag_nat<T>(Oi, PIT, it * 16 + (lane & 15), sl, lane),
+                          frag_nat<T>(Vi, PIT, strip * 16 + (lane & 15), sl, lane));
+                }
+            }
+            // sp[it][r] = S[i][j] (pre-scale), dp[it][r] = (dO V^T)[i][j],  i = it*16 + (lane>>4)*4 + r
+            const float mbj = mbias[j];
+#pragma unroll
+            for (int it = 0; it < NT; ++it) {
+                const int i0 = it * 16 + (lane >> 4) * 4;
+                f32x4 pd;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + r;
+                    const float p = __expf(sp[it][r] * scale + mbj - rmax[i]) * rinv[i];
+                    const float dm = drop_mult(drop, ((uint32_t)blockIdx.x * L + (uint32_t)i) * L + (uint32_t)j);
+                    pd[r] = p * dm;                                        // dropped P^T -> dV
+                    sp[it][r] = p * (dp[it][r] * dm - rD[i]) * scale;      // dS^T       -> dK
+                }
+                store4((T*)(St + (lane & 15) * SPIT) + i0, pd);
+            }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < LSL; ++sl)
+                    mma16(o, frag_kmaj(Oi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
+                          frag_nat<T>(St, SPIT, lane & 15, sl, lane));
+                if (j < L) store4(dq_base + (size_t)j * ld + 2 * H + dt * 16 + (lane >> 4) * 4, o);
+            }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+                store4((T*)(St + (lane & 15) * SPIT) + it * 16 + (lane >> 4) * 4, sp[it]);
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < LSL; ++sl)
+                    mma16(o, frag_kmaj(Qi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
+                          frag_nat<T>(St, SPIT, lane & 15, sl, lane));
+                if (j < L) store4(dq_base + (size_t)j * ld + H + dt * 16 + (lane >> 4) * 4, o);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// =============================================================================================== host
+template <class T, int LP, int NW>
+static int launch_fwd(const void* qkv, const int64_t* mask, void* ctx, int B, int L, int nh, DropKey drop, hipStream_t st) {
+    hipLaunchKernelGGL((attn_fwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, mask, (T*)ctx, L,
+                       nh, drop);
+    return (int)hipGetLastError();
+}
+template <class T, int LP, int NW>
+static int launch_bwd(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int nh,
+                      DropKey drop, hipStream_t st) {
+    hipLaunchKernelGGL((attn_bwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, mask,
+                       (const T*)dctx, (T*)dqkv, L, nh, drop);
+    return (int)hipGetLastError();
+}
+
+int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx, int B, int L, int nh, DropKey drop,
+                      hipStream_t st) {
+    if (L < 1 || L > 128) return MB_ERR_SHAPE;
+    const int LP = (L + 31) / 32 * 32;
+    if (dtype == DT_BF16) {
+        switch (LP) {
+            case 32: return launch_fwd<bf16, 32, 2>(qkv, mask, ctx, B, L, nh, drop, st);
+            case 64: return launch_fwd<bf16, 64, 4>(qkv, mask, ctx, B, L, nh, drop, st);
+            case 96: return launch_fwd<bf16, 96, 4>(qkv, mask, ctx, B, L, nh, drop, st);
+            default: return launch_fwd<bf16, 128, 4>(qkv, mask, ctx, B, L, nh, drop, st);
+        }
+    } else if (dtype == DT_F32) {
+        switch (LP) {
+            case 32: return launch_fwd<float, 32, 2>(qkv, mask, ctx, B, L, nh, drop, st);
+            case 64: return launch_fwd<float, 64, 4>(qkv, mask, ctx, B, L, nh, drop, st);
+            case 96: return launch_fwd<float, 96, 4>(qkv, mask, ctx, B, L, nh, drop, st);
+            default: return launch_fwd<float, 128, 4>(qkv, mask, ctx, B, L, nh, drop, st);
+        }
+    }
+    return MB_ERR_DTYPE;
+}
+
+int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx, void* dqkv,
+                       int B, int L, int nh, DropKey drop, hipStream_t st) {
+    (void)ctx;   // D_i is recomputed as sum_j dP_ij P_ij, the forward output is not needed
+    if (L < 1 || L > 128) return MB_ERR_SHAPE;
+    const int LP = (L + 31) / 32 * 32;
+    if (dtype == DT_BF16) {
+        switch (LP) {
+            case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
+            case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
+            case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
+            default: return launch_bwd<bf16, 128, 4>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
+        }
+    } else if (dtype == DT_F32) {
+        switch (LP) {
+            case 32: return launch_bwd<float, 32, 2>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
+            case 64: return launch_bwd<float, 64, 4>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
+            case 96: return launch_bwd<float, 96, 2>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
+            default: return launch_bwd<float, 128, 2>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);   // 2 waves: LDS budget
+        }
+    }
+    return MB_ERR_DTYPE;
+}
+
+}  // namespace mb

@@ -1,0 +1,108 @@
+// Device-side building blocks shared by every kernel of the MAG-BERT / MAG-XLNet hot path.
+// gfx950 (CDNA4) only: 64-wide wavefronts, MFMA 16x16 tiles, 160 KB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+namespace mb {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+
+// ---------------------------------------------------------------- scalar / vector conversions
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16 x) { return (float)x; }
+template <class T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float x) { return (bf16)x; }   // RNE (v_cvt_pk_bf16_f32)
+
+__device__ __forceinline__ f32x4 load4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 load4(const bf16* p) {
+    bf16x4 v = *(const bf16x4*)p;
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void store4(bf16* p, f32x4 v) {
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *(bf16x4*)p = o;
+}
+
+// ---------------------------------------------------------------- counter-based dropout RNG
+// keep(idx) is a pure function of (key, element index): forward and backward regenerate the same
+// mask, nothing is stored.  tests/rng_ref.py holds the numpy twin used for mask replay in parity.
+struct DropKey {
+    uint32_t k0, k1;      // per-site, per-step key (host: splitmix64(seed, step, site))
+    uint32_t thresh;      // drop if hash < thresh ; thresh = round(p * 2^32) ; 0 => dropout off
+    float scale;          // 1/(1-p)
+};
+__device__ __forceinline__ uint32_t hash32(uint32_t idx, uint32_t k0, uint32_t k1) {
+    uint32_t x = idx * 0x9E3779B1u + k0;
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x ^= k1; x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+// multiplier applied to element idx: 0 (dropped) or 1/(1-p) (kept)
+__device__ __forceinline__ float drop_mult(const DropKey& d, uint32_t idx) {
+    if (d.thresh == 0u) return 1.0f;
+    return hash32(idx, d.k0, d.k1) < d.thresh ? 0.0f : d.scale;
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reduce across the 16 lanes that share (lane >> 4)
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- MFMA 16x16 tile primitive
+// A "fragment" is the 16 bytes one lane reads from row (lane & 15), 16-byte chunk (lane >> 4) of a
+// 64-byte k-slab of an LDS/global image stored [row][k] with k contiguous:
+//   bf16 : 8 elements k = (lane>>4)*8 + j   -> one v_mfma_f32_16x16x32_bf16
+//   fp32 : 4 elements k = (lane>>4)*4 + j   -> four v_mfma_f32_16x16x4_f32 (exact fp32 fma chain)
+// mma16(acc, x, y):  acc[r] += sum_k X[(lane>>4)*4 + r][k] * Y[lane & 15][k]
+// where x / y are the fragments this lane loaded from images X / Y.
+template <class T> struct Frag;
+template <> struct Frag<bf16> { typedef bf16x8 type; };
+template <> struct Frag<float> { typedef f32x4 type; };
+
+__device__ __forceinline__ void mma16(f32x4& acc, bf16x8 x, bf16x8 y) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& acc, f32x4 x, f32x4 y) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[0], y[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[1], y[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2], y[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[3], y[3], acc, 0, 0, 0);
+}
+
+// erf-GELU (transformers 3.0.2 ACT2FN["gelu"]) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+}  // namespace mb

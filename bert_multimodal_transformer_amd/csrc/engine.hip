@@ -1,0 +1,609 @@
+// Native step executor for MAG_BertForSequenceClassification (/root/reference/bert.py:240-324 -> :76-237 ->
+// /root/reference/modeling.py:25-51) and the C ABI declared in include/magbert_hip.h.
+//
+// One call = one pass: every kernel of the forward (or of a backward stage range) is enqueued on the caller's
+// stream from C++, so the per-step host cost is ~100-300 plain launches and zero Python.  The engine owns no
+// device memory: parameters / gradients / bf16 operand shadow / workspace are caller buffers (torch tensors).
+//
+// Flat parameter layout (floats; every tensor 256-byte aligned; names = reference state-dict keys):
+//   [ weight-decay group | no-decay group ]   (multimodal_driver.py:329-343: "bias", "LayerNorm.*" do not decay)
+//   decay group   : per layer {query,key,value (contiguous = fused [3H][H] QKV), attention.output.dense,
+//                   intermediate.dense, output.dense}.weight ; pooler.dense.weight   <- bf16 shadow range
+//                   embeddings.{word,position,token_type}_embeddings.weight ; MAG.{W_hv,W_ha,W_v,W_a}.weight ;
+//                   classifier.weight
+//   no-decay group: per layer {q,k,v bias (contiguous [3H]), attn.out bias, LN1 w/b, inter bias, out bias, LN2 w/b};
+//                   embeddings.LayerNorm ; pooler bias ; MAG biases + LayerNorm ; classifier.bias
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include "kernels.h"
+#include "../../include/magbert_hip.h"
+
+using namespace mb;
+
+namespace {
+
+struct TensorInfo {
+    std::string name;
+    size_t off, numel;
+    int ndim;
+    int64_t shape[4];
+    int decay;
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+DropKey make_key(uint64_t seed, uint64_t step, uint32_t site, float p) {
+    DropKey k;
+    if (!(p > 0.f)) { k.k0 = k.k1 = k.thresh = 0; k.scale = 1.f; return k; }
+    const uint64_t h = splitmix64(splitmix64(seed) ^ splitmix64(step * 0x100000001B3ull + site));
+    k.k0 = (uint32_t)h;
+    k.k1 = (uint32_t)(h >> 32);
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    k.thresh = (uint32_t)(t + 0.5);
+    k.scale = 1.0f / (1.0f - p);
+    return k;
+}
+const DropKey kNoDrop = {0u, 0u, 0u, 1.0f};
+inline DropKey dk(const mb_dropkey* d) {
+    if (!d) return kNoDrop;
+    DropKey k = {d->k0, d->k1, d->thresh, d->scale};
+    return k;
+}
+
+enum { SITE_EMB = 0, SITE_MAG = 1, SITE_HEAD = 2, SITE_LAYER0 = 16 };   // layer l: 16+4l+{0 attn probs,1 attn out,2 ffn out}
+
+inline size_t esize(int dtype) { return dtype == DT_BF16 ? 2 : 4; }
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; }
+};
+
+// workspace of the MAG operator: saved activations + scratch (shared by the op-level API and the engine)
+struct MagWs {
+    int Vp, Ap;
+    size_t We, Wv, Wa, vp, ap, Ze, Zv, Za, mean, rstd;                       // forward (saved)
+    size_t dZe, dZv, dZa, dep, dWe, dWv, dWa, dvp, dap;                      // backward scratch
+    size_t bytes;
+    void init(int dtype, int T, int H, int V, int A) {
+        const size_t es = esize(dtype);
+        Vp = (V + 63) / 64 * 64;
+        Ap = (A + 63) / 64 * 64;
+        Carver c;
+        We = c.take((size_t)2 * H * H * es); Wv = c.take((size_t)2 * H * Vp * es); Wa = c.take((size_t)2 * H * Ap * es);
+        vp = c.take((size_t)T * Vp * es); ap = c.take((size_t)T * Ap * es);
+        Ze = c.take((size_t)T * 2 * H * es); Zv = c.take((size_t)T * 2 * H * es); Za = c.take((size_t)T * 2 * H * es);
+        mean = c.take((size_t)T * 4); rstd = c.take((size_t)T * 4);
+        dZe = c.take((size_t)T * 2 * H * es); dZv = c.take((size_t)T * 2 * H * es); dZa = c.take((size_t)T * 2 * H * es);
+        dep = c.take((size_t)T * H * es);
+        dWe = c.take((size_t)2 * H * H * 4); dWv = c.take((size_t)2 * H * Vp * 4); dWa = c.take((size_t)2 * H * Ap * 4);
+        dvp = c.take((size_t)T * Vp * 4); dap = c.take((size_t)T * Ap * 4);
+        bytes = c.off;
+    }
+};
+
+#define CK(x) do { int _e = (x); if (_e) return _e; } while (0)
+
+int gemm(int dtype, int layout, int mode, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+         int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, DropKey drop, int splits, int tile,
+         hipStream_t st) {
+    GemmArgs a;
+    a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
+    a.C = C; a.ldc = ldc; a.C2 = C2; a.Cf = Cf; a.bias = bias; a.R = R; a.ldr = ldr; a.alpha = 1.0f; a.drop = drop;
+    a.kchunk = K;
+    return gemm_launch(dtype, layout, mode, a, splits, tile, st);
+}
+
+// wgrad: dW[N'][K'] += dY^T X, reduction over `rows` tokens; picks tile + split-K to fill the 256 CUs
+int wgrad(int dtype, int Mo, int No, int rows, const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw,
+          hipStream_t st) {
+    const long t128 = (long)((Mo + 127) / 128) * ((No + 127) / 128);
+    const long t64 = (long)((Mo + 63) / 64) * ((No + 63) / 64);
+    int tile, splits;
+    if (t128 >= 128) { tile = 128; splits = (int)((320 + t128 / 2) / t128); }
+    else { tile = 64; splits = (int)((384 + t64 - 1) / t64); }
+    if (splits > 8) splits = 8;
+    while (splits > 1 && rows / splits < 128) --splits;
+    if (splits < 1) splits = 1;
+    return gemm(dtype, GEMM_TN, EPI_ACCUM_F32, Mo, No, rows, dY, ldy, X, ldx, nullptr, ldw, nullptr, dW, nullptr, nullptr, 0,
+                kNoDrop, splits, tile, st);
+}
+
+// ------------------------------------------------------------------------------------------------ MAG operator
+int mag_fwd_impl(int dtype, const void* text, const float* visual, const float* acoustic, const float* W_hv,
+                 const float* b_hv, const float* W_ha, const float* b_ha, const float* W_v, const float* b_v,
+                 const float* W_a, const float* b_a, const float* ln_w, const float* ln_b, float ln_eps, float beta_shift,
+                 DropKey drop, void* out, char* ws, const MagWs& w, int T, int H, int V, int A, bool repack, hipStream_t st) {
+    MagDims d = {T, H, V, A, w.Vp, w.Ap};
+    if (repack) CK(mag_pack_weights(dtype, W_hv, W_ha, W_v, W_a, ws + w.We, ws + w.Wv, ws + w.Wa, d, st));
+    CK(pack_pad(dtype, visual, V, ws + w.vp, w.Vp, T, st));
+    CK(pack_pad(dtype, acoustic, A, ws + w.ap, w.Ap, T, st));
+    CK(gemm(dtype, GEMM_NT, EPI_BIAS, T, 2 * H, H, text, H, ws + w.We, H, ws + w.Ze, 2 * H, nullptr, nullptr, nullptr,
+            nullptr, 0, kNoDrop, 1, 0, st));
+    CK(gemm(dtype, GEMM_NT, EPI_BIAS, T, 2 * H, w.Vp, ws + w.vp, w.Vp, ws + w.Wv, w.Vp, ws + w.Zv, 2 * H, nullptr, nullptr,
+            nullptr, nullptr, 0, kNoDrop, 1, 0, st));
+    CK(gemm(dtype, GEMM_NT, EPI_BIAS, T, 2 * H, w.Ap, ws + w.ap, w.Ap, ws + w.Wa, w.Ap, ws + w.Za, 2 * H, nullptr, nullptr,
+            nullptr, nullptr, 0, kNoDrop, 1, 0, st));
+    CK(mag_gate_forward(dtype, text, ws + w.Ze, ws + w.Zv, ws + w.Za, b_hv, b_ha, b_v, b_a, ln_w, ln_b, ln_eps, beta_shift,
+                        out, (float*)(ws + w.mean), (float*)(ws + w.rstd), d, drop, st));
+    return MB_OK;
+}
+
+int mag_bwd_impl(int dtype, const void* d_out, const void* text, const float* b_hv, const float* b_ha, const float* b_v,
+                 const float* b_a, const float* ln_w, float beta_shift, DropKey drop, char* ws, const MagWs& w, void* d_text,
+                 float* d_visual, float* d_acoustic, float* dW_hv, float* db_hv, float* dW_ha, float* db_ha, float* dW_v,
+                 float* db_v, float* dW_a, float* db_a, float* dln_w, float* dln_b, int T, int H, int V, int A,
+                 hipStream_t st) {
+    MagDims d = {T, H, V, A, w.Vp, w.Ap};
+    CK(mag_gate_backward(dtype, d_out, text, ws + w.Ze, ws + w.Zv, ws + w.Za, b_hv, b_ha, b_v, b_a, ln_w,
+                         (const float*)(ws + w.mean), (const float*)(ws + w.rstd), beta_shift, ws + w.dep, ws + w.dZe,
+                         ws + w.dZv, ws + w.dZa, db_hv, db_ha, db_v, db_a, dln_w, dln_b, d, drop, st));
+    // packed weight grads (dWe, dWv, dWa are contiguous in the workspace up to alignment: clear each)
+    CK((int)hipMemsetAsync(ws + w.dWe, 0, (size_t)2 * H * H * 4, st));
+    CK((int)hipMemsetAsync(ws + w.dWv, 0, (size_t)2 * H * w.Vp * 4, st));
+    CK((int)hipMemsetAsync(ws + w.dWa, 0, (size_t)2 * H * w.Ap * 4, st));
+    CK(wgrad(dtype, 2 * H, H, T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H, st));
+    CK(wgrad(dtype, 2 * H, w.Vp, T, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp, st));
+    CK(wgrad(dtype, 2 * H, w.Ap, T, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap, st));
+    CK(mag_unpack_wgrads((const float*)(ws + w.dWe), (const float*)(ws + w.dWv), (const float*)(ws + w.dWa), dW_hv, dW_ha,
+                         dW_v, dW_a, d, st));
+    // d_text = dZe . We + (ds + d||e|| term)
+    CK(gemm(dtype, GEMM_NN, EPI_ADD_RES, T, H, 2 * H, ws + w.dZe, 2 * H, ws + w.We, H, d_text, H, nullptr, nullptr, nullptr,
+            ws + w.dep, H, kNoDrop, 1, 0, st));
+    if (d_visual) {
+        CK(gemm(dtype, GEMM_NN, EPI_BIAS_F32, T, w.Vp, 2 * H, ws + w.dZv, 2 * H, ws + w.Wv, w.Vp, nullptr, w.Vp, nullptr,
+                (float*)(ws + w.dvp), nullptr, nullptr, 0, kNoDrop, 1, 0, st));
+        CK((int)hipMemcpy2DAsync(d_visual, (size_t)V * 4, ws + w.dvp, (size_t)w.Vp * 4, (size_t)V * 4, T,
+                                 hipMemcpyDeviceToDevice, st));
+    }
+    if (d_acoustic) {
+        CK(gemm(dtype, GEMM_NN, EPI_BIAS_F32, T, w.Ap, 2 * H, ws + w.dZa, 2 * H, ws + w.Wa, w.Ap, nullptr, w.Ap, nullptr,
+                (float*)(ws + w.dap), nullptr, nullptr, 0, kNoDrop, 1, 0, st));
+        CK((int)hipMemcpy2DAsync(d_acoustic, (size_t)A * 4, ws + w.dap, (size_t)w.Ap * 4, (size_t)A * 4, T,
+                                 hipMemcpyDeviceToDevice, st));
+    }
+    return MB_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ engine
+struct LayerOff { size_t wqkv, wo, w1, w2, bqkv, bo, ln1w, ln1b, b1, b2, ln2w, ln2b; };
+struct LayerWs { size_t qkv, ctx, s1, st1, y1, u, g, s2, st2; };
+
+struct mb_bert_engine {
+    mb_bert_config c;
+    std::vector<TensorInfo> tensors;
+    std::vector<LayerOff> lo;
+    size_t word, pos, type, emb_lnw, emb_lnb, wp, bp, wc, bc;
+    size_t mag_whv, mag_wha, mag_wv, mag_wa, mag_bhv, mag_bha, mag_bv, mag_ba, mag_lnw, mag_lnb;
+    size_t n_params, n_decay, sh_begin, sh_end;
+    // workspace
+    MagWs mw;
+    size_t ws_mag, ws_emb, ws_emb_st, ws_head_z, ws_head_pooled, ws_logits;
+    std::vector<size_t> ws_x;
+    std::vector<LayerWs> lw;
+    size_t ws_dxa, ws_dxb, ws_ds, ws_dzd, ws_du, ws_dqkv, ws_dctx, ws_dsum, ws_dz;
+    size_t ws_ids, ws_seg, ws_mask, ws_labels;    // (inputs are caller pointers; kept for the backward)
+    size_t ws_bytes;
+    // bound buffers
+    float* P = nullptr; float* G = nullptr; char* SH = nullptr; char* ws = nullptr;
+    // state of the last forward
+    const int64_t* ids = nullptr; const int64_t* seg = nullptr; const int64_t* mask = nullptr;
+    int B = 0, L = 0, training = 0;
+    uint64_t seed = 0, step = 0;
+    float* logits = nullptr;
+
+    size_t add(const std::string& name, std::vector<int64_t> shape, int decay, size_t& cursor) {
+        TensorInfo t;
+        t.name = name; t.ndim = (int)shape.size(); t.decay = decay; t.numel = 1;
+        for (int i = 0; i < 4; ++i) t.shape[i] = i < t.ndim ? shape[i] : 1;
+        for (auto s : shape) t.numel *= (size_t)s;
+        t.off = cursor;
+        cursor = align_up(cursor + t.numel, 64);
+        tensors.push_back(t);
+        return t.off;
+    }
+    const void* W(size_t off) const {   // GEMM operand view of a weight (bf16 shadow in perf mode, master in fp32 mode)
+        return c.dtype == DT_BF16 ? (const void*)(SH + off * 2) : (const void*)(P + off);
+    }
+    DropKey key(uint32_t site, float p) const { return training ? make_key(seed, step, site, p) : kNoDrop; }
+};
+
+static void build_layout(mb_bert_engine* e) {
+    const mb_bert_config& c = e->c;
+    const int64_t H = c.hidden_size, I = c.intermediate_size, V = c.visual_dim, A = c.acoustic_dim;
+    size_t cur = 0;
+    e->lo.resize(c.num_layers);
+    char buf[128];
+    auto nm = [&](int l, const char* s) { snprintf(buf, sizeof buf, "bert.encoder.layer.%d.%s", l, s); return std::string(buf); };
+    e->sh_begin = 0;
+    for (int l = 0; l < c.num_layers; ++l) {
+        LayerOff& o = e->lo[l];
+        o.wqkv = e->add(nm(l, "attention.self.query.weight"), {H, H}, 1, cur);
+        e->add(nm(l, "attention.self.key.weight"), {H, H}, 1, cur);
+        e->add(nm(l, "attention.self.value.weight"), {H, H}, 1, cur);
+        o.wo = e->add(nm(l, "attention.output.dense.weight"), {H, H}, 1, cur);
+        o.w1 = e->add(nm(l, "intermediate.dense.weight"), {I, H}, 1, cur);
+        o.w2 = e->add(nm(l, "output.dense.weight"), {H, I}, 1, cur);
+    }
+    e->wp = e->add("bert.pooler.dense.weight", {H, H}, 1, cur);
+    e->sh_end = cur;
+    e->word = e->add("bert.embeddings.word_embeddings.weight", {c.vocab_size, H}, 1, cur);
+    e->pos = e->add("bert.embeddings.position_embeddings.weight", {c.max_position, H}, 1, cur);
+    e->type = e->add("bert.embeddings.token_type_embeddings.weight", {c.type_vocab, H}, 1, cur);
+    e->mag_whv = e->add("bert.MAG.W_hv.weight", {H, V + H}, 1, cur);
+    e->mag_wha = e->add("bert.MAG.W_ha.weight", {H, A + H}, 1, cur);
+    e->mag_wv = e->add("bert.MAG.W_v.weight", {H, V}, 1, cur);
+    e->mag_wa = e->add("bert.MAG.W_a.weight", {H, A}, 1, cur);
+    e->wc = e->add("classifier.weight", {c.num_labels, H}, 1, cur);
+    e->n_decay = cur;
+    for (int l = 0; l < c.num_layers; ++l) {
+        LayerOff& o = e->lo[l];
+        o.bqkv = e->add(nm(l, "attention.self.query.bias"), {H}, 0, cur);
+        e->add(nm(l, "attention.self.key.bias"), {H}, 0, cur);
+        e->add(nm(l, "attention.self.value.bias"), {H}, 0, cur);
+        o.bo = e->add(nm(l, "attention.output.dense.bias"), {H}, 0, cur);
+        o.ln1w = e->add(nm(l, "attention.output.LayerNorm.weight"), {H}, 0, cur);
+        o.ln1b = e->add(nm(l, "attention.output.LayerNorm.bias"), {H}, 0, cur);
+        o.b1 = e->add(nm(l, "intermediate.dense.bias"), {I}, 0, cur);
+        o.b2 = e->add(nm(l, "output.dense.bias"), {H}, 0, cur);
+        o.ln2w = e->add(nm(l, "output.LayerNorm.weight"), {H}, 0, cur);
+        o.ln2b = e->add(nm(l, "output.LayerNorm.bias"), {H}, 0, cur);
+    }
+    e->emb_lnw = e->add("bert.embeddings.LayerNorm.weight", {H}, 0, cur);
+    e->emb_lnb = e->add("bert.embeddings.LayerNorm.bias", {H}, 0, cur);
+    e->bp = e->add("bert.pooler.dense.bias", {H}, 0, cur);
+    e->mag_bhv = e->add("bert.MAG.W_hv.bias", {H}, 0, cur);
+    e->mag_bha = e->add("bert.MAG.W_ha.bias", {H}, 0, cur);
+    e->mag_bv = e->add("bert.MAG.W_v.bias", {H}, 0, cur);
+    e->mag_ba = e->add("bert.MAG.W_a.bias", {H}, 0, cur);
+    e->mag_lnw = e->add("bert.MAG.LayerNorm.weight", {H}, 0, cur);
+    e->mag_lnb = e->add("bert.MAG.LayerNorm.bias", {H}, 0, cur);
+    e->bc = e->add("classifier.bias", {c.num_labels}, 0, cur);
+    e->n_params = cur;
+
+    // ---- workspace
+    const size_t es = esize(c.dtype);
+    const size_t T = (size_t)c.max_batch * c.max_seq;
+    Carver w;
+    e->mw.init(c.dtype, (int)T, (int)H, (int)V, (int)A);
+    e->ws_mag = w.take(e->mw.bytes);
+    e->ws_emb = w.take(T * H * es);
+    e->ws_emb_st = w.take(2 * T * 4);
+    e->ws_x.resize(c.num_layers + 1);
+    for (int l = 0; l <= c.num_layers; ++l) e->ws_x[l] = w.take(T * H * es);
+    e->lw.resize(c.num_layers);
+    for (int l = 0; l < c.num_layers; ++l) {
+        LayerWs& x = e->lw[l];
+        x.qkv = w.take(T * 3 * H * es); x.ctx = w.take(T * H * es); x.s1 = w.take(T * H * es); x.st1 = w.take(2 * T * 4);
+        x.y1 = w.take(T * H * es); x.u = w.take(T * I * es); x.g = w.take(T * I * es); x.s2 = w.take(T * H * es);
+        x.st2 = w.take(2 * T * 4);
+    }
+    e->ws_head_z = w.take((size_t)c.max_batch * H * 4);
+    e->ws_head_pooled = w.take((size_t)c.max_batch * H * 4);
+    e->ws_logits = w.take((size_t)c.max_batch * c.num_labels * 4);
+    e->ws_dxa = w.take(T * H * es); e->ws_dxb = w.take(T * H * es); e->ws_ds = w.take(T * H * es);
+    e->ws_dzd = w.take(T * H * es); e->ws_du = w.take(T * I * es); e->ws_dqkv = w.take(T * 3 * H * es);
+    e->ws_dctx = w.take(T * H * es); e->ws_dsum = w.take(T * H * 4); e->ws_dz = w.take((size_t)c.max_batch * H * es);
+    e->ws_bytes = w.off;
+}
+
+extern "C" {
+
+const char* mb_error_string(int code) {
+    switch (code) {
+        case MB_OK: return "ok";
+        case MB_ERR_SHAPE: return "magbert: unsupported shape or alignment";
+        case MB_ERR_MODE: return "magbert: unsupported layout/epilogue combination";
+        case MB_ERR_DTYPE: return "magbert: unsupported dtype";
+        case MB_ERR_ARG: return "magbert: invalid argument";
+        default: return hipGetErrorString((hipError_t)code);
+    }
+}
+int mb_version(void) { return 100; }
+
+void mb_make_dropkey(uint64_t seed, uint64_t step, uint32_t site, float p, mb_dropkey* out) {
+    DropKey k = make_key(seed, step, site, p);
+    out->k0 = k.k0; out->k1 = k.k1; out->thresh = k.thresh; out->scale = k.scale;
+}
+
+int mb_gemm(int dtype, int layout, int epilogue, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+            void* C, int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, float alpha,
+            const mb_dropkey* drop, int splits, int tile, void* stream) {
+    GemmArgs a;
+    a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.C = C; a.ldc = ldc; a.C2 = C2; a.Cf = Cf;
+    a.bias = bias; a.R = R; a.ldr = ldr; a.alpha = alpha; a.drop = dk(drop); a.kchunk = K;
+    return gemm_launch(dtype, layout, epilogue, a, splits, tile, (hipStream_t)stream);
+}
+
+int mb_layernorm_forward(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
+                         float* rstd, int rows, int H, const mb_dropkey* drop, void* stream) {
+    return ln_forward(dtype, x, gamma, beta, eps, y, mean, rstd, rows, H, dk(drop), (hipStream_t)stream);
+}
+int mb_layernorm_backward(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                          const float* rstd, void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias, int rows,
+                          int H, const mb_dropkey* drop_out, const mb_dropkey* drop_in, void* stream) {
+    return ln_backward(dtype, dy, x, gamma, mean, rstd, dx, dx_drop, dgamma, dbeta, dbias, rows, H, dk(drop_out),
+                       dk(drop_in), (hipStream_t)stream);
+}
+int mb_embed_forward(int dtype, const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
+                     const float* type, const float* gamma, const float* beta, float eps, void* out, float* mean,
+                     float* rstd, int B, int L, int H, const mb_dropkey* drop, void* stream) {
+    return embed_ln_forward(dtype, ids, seg, word, pos, type, gamma, beta, eps, out, mean, rstd, B, L, H, dk(drop),
+                            (hipStream_t)stream);
+}
+int mb_embed_backward(int dtype, const void* dout, const int64_t* ids, const int64_t* seg, const float* word,
+                      const float* pos, const float* type, const float* gamma, const float* mean, const float* rstd,
+                      float* dsum_ws, float* dword, float* dpos, float* dtype_, float* dgamma, float* dbeta, int B, int L,
+                      int H, int pad_id, const mb_dropkey* drop, void* stream) {
+    return embed_ln_backward(dtype, dout, ids, seg, word, pos, type, gamma, mean, rstd, dsum_ws, dword, dpos, dtype_,
+                             dgamma, dbeta, B, L, H, pad_id, dk(drop), (hipStream_t)stream);
+}
+int mb_attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx, int B, int L, int nh,
+                         const mb_dropkey* drop, void* stream) {
+    return attention_forward(dtype, qkv, mask, ctx, B, L, nh, dk(drop), (hipStream_t)stream);
+}
+int mb_attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L,
+                          int nh, const mb_dropkey* drop, void* stream) {
+    return attention_backward(dtype, qkv, mask, nullptr, dctx, dqkv, B, L, nh, dk(drop), (hipStream_t)stream);
+}
+
+size_t mb_mag_workspace_bytes(int dtype, int T, int H, int V, int A) {
+    MagWs w;
+    w.init(dtype, T, H, V, A);
+    return w.bytes;
+}
+int mb_mag_forward(int dtype, const void* text, const float* visual, const float* acoustic, const float* W_hv,
+                   const float* b_hv, const float* W_ha, const float* b_ha, const float* W_v, const float* b_v,
+                   const float* W_a, const float* b_a, const float* ln_w, const float* ln_b, float beta_shift,
+                   const mb_dropkey* drop, void* out, void* ws, int T, int H, int V, int A, void* stream) {
+    if (H != 768 || V < 1 || A < 1) return MB_ERR_SHAPE;
+    MagWs w;
+    w.init(dtype, T, H, V, A);
+    return mag_fwd_impl(dtype, text, visual, acoustic, W_hv, b_hv, W_ha, b_ha, W_v, b_v, W_a, b_a, ln_w, ln_b, 1e-5f,
+                        beta_shift, dk(drop), out, (char*)ws, w, T, H, V, A, true, (hipStream_t)stream);
+}
+int mb_mag_backward(int dtype, const void* d_out, const void* text, const float* W_hv, const float* b_hv,
+                    const float* W_ha, const float* b_ha, const float* W_v, const float* b_v, const float* W_a,
+                    const float* b_a, const float* ln_w, float beta_shift, const mb_dropkey* drop, void* ws, void* d_text,
+                    float* d_visual, float* d_acoustic, float* dW_hv, float* db_hv, float* dW_ha, float* db_ha,
+                    float* dW_v, float* db_v, float* dW_a, float* db_a, float* dln_w, float* dln_b, int T, int H, int V,
+                    int A, void* stream) {
+    (void)W_hv; (void)W_ha; (void)W_v; (void)W_a;   // the packed copies made by the forward are reused
+    if (H != 768) return MB_ERR_SHAPE;
+    MagWs w;
+    w.init(dtype, T, H, V, A);
+    return mag_bwd_impl(dtype, d_out, text, b_hv, b_ha, b_v, b_a, ln_w, beta_shift, dk(drop), (char*)ws, w, d_text,
+                        d_visual, d_acoustic, dW_hv, db_hv, dW_ha, db_ha, dW_v, db_v, dW_a, db_a, dln_w, dln_b, T, H, V, A,
+                        (hipStream_t)stream);
+}
+
+int mb_adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, size_t n_decay, size_t sh_begin,
+                  size_t sh_end, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  int correct_bias, float grad_scale, int zero_grad, void* stream) {
+    AdamArgs a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale;
+    double ss = lr;
+    if (correct_bias) ss = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+    a.step_size = (float)ss;
+    return adamw_step(p, g, m, v, shadow, n, n_decay, sh_begin, sh_end, a, zero_grad, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ engine API
+int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
+    if (!cfg || !out) return MB_ERR_ARG;
+    if (cfg->hidden_size != 768 || cfg->num_heads * 64 != cfg->hidden_size) return MB_ERR_SHAPE;
+    if (cfg->intermediate_size % 128 || cfg->max_seq < 1 || cfg->max_seq > 128 || cfg->max_batch < 1) return MB_ERR_SHAPE;
+    if (cfg->max_seq > cfg->max_position || cfg->num_labels < 1) return MB_ERR_SHAPE;
+    if (cfg->dtype != DT_F32 && cfg->dtype != DT_BF16) return MB_ERR_DTYPE;
+    mb_bert_engine* e = new mb_bert_engine();
+    e->c = *cfg;
+    build_layout(e);
+    *out = e;
+    return MB_OK;
+}
+void mb_bert_destroy(mb_bert_engine* e) { delete e; }
+int mb_bert_num_tensors(const mb_bert_engine* e) { return (int)e->tensors.size(); }
+int mb_bert_tensor_info(const mb_bert_engine* e, int i, char* name, int name_cap, size_t* offset, size_t* numel, int* ndim,
+                        int64_t* shape4, int* decay) {
+    if (i < 0 || i >= (int)e->tensors.size()) return MB_ERR_ARG;
+    const TensorInfo& t = e->tensors[i];
+    if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (offset) *offset = t.off;
+    if (numel) *numel = t.numel;
+    if (ndim) *ndim = t.ndim;
+    if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = t.shape[k];
+    if (decay) *decay = t.decay;
+    return MB_OK;
+}
+size_t mb_bert_param_count(const mb_bert_engine* e) { return e->n_params; }
+size_t mb_bert_decay_count(const mb_bert_engine* e) { return e->n_decay; }
+void mb_bert_shadow_range(const mb_bert_engine* e, size_t* b, size_t* en) { *b = e->sh_begin; *en = e->sh_end; }
+size_t mb_bert_workspace_bytes(const mb_bert_engine* e) { return e->ws_bytes; }
+
+int mb_bert_bind(mb_bert_engine* e, float* params, float* grads, void* shadow, void* workspace, size_t ws_bytes) {
+    if (!params || !workspace || ws_bytes < e->ws_bytes) return MB_ERR_ARG;
+    if (e->c.dtype == DT_BF16 && !shadow) return MB_ERR_ARG;
+    e->P = params; e->G = grads; e->SH = (char*)shadow; e->ws = (char*)workspace;
+    return MB_OK;
+}
+
+int mb_bert_sync_weights(mb_bert_engine* e, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!e->P) return MB_ERR_ARG;
+    if (e->c.dtype == DT_BF16)
+        CK(convert(DT_BF16, e->P + e->sh_begin, e->SH + e->sh_begin * 2, e->sh_end - e->sh_begin, st));
+    const mb_bert_config& c = e->c;
+    MagDims d = {0, c.hidden_size, c.visual_dim, c.acoustic_dim, e->mw.Vp, e->mw.Ap};
+    char* mws = e->ws + e->ws_mag;
+    CK(mag_pack_weights(c.dtype, e->P + e->mag_whv, e->P + e->mag_wha, e->P + e->mag_wv, e->P + e->mag_wa, mws + e->mw.We,
+                        mws + e->mw.Wv, mws + e->mw.Wa, d, st));
+    return MB_OK;
+}
+
+int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                    const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                    int training, uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const mb_bert_config& c = e->c;
+    if (!e->P || !e->ws) return MB_ERR_ARG;
+    if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
+    if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !logits) return MB_ERR_ARG;
+    const int dt = c.dtype, H = c.hidden_size, I = c.intermediate_size, T = B * L, nh = c.num_heads;
+    e->ids = input_ids; e->seg = token_type_ids; e->mask = attention_mask;
+    e->B = B; e->L = L; e->training = training; e->seed = seed; e->step = step; e->logits = logits;
+    float* P = e->P;
+    char* ws = e->ws;
+    // embeddings (bert.py:211-216)
+    CK(embed_ln_forward(dt, input_ids, token_type_ids, P + e->word, P + e->pos, P + e->type, P + e->emb_lnw, P + e->emb_lnb,
+                        c.layer_norm_eps, ws + e->ws_emb, (float*)(ws + e->ws_emb_st), (float*)(ws + e->ws_emb_st) + T, B, L,
+                        H, e->key(SITE_EMB, c.hidden_dropout), st));
+    // MAG (bert.py:219): packed weights are refreshed every pass (5.5 MB, one launch) so optimizer steps are seen
+    CK(mag_fwd_impl(dt, ws + e->ws_emb, visual, acoustic, P + e->mag_whv, P + e->mag_bhv, P + e->mag_wha, P + e->mag_bha,
+                    P + e->mag_wv, P + e->mag_bv, P + e->mag_wa, P + e->mag_ba, P + e->mag_lnw, P + e->mag_lnb,
+                    c.mag_layer_norm_eps, c.beta_shift, e->key(SITE_MAG, c.mag_dropout), ws + e->ws_x[0], ws + e->ws_mag,
+                    e->mw, T, H, c.visual_dim, c.acoustic_dim, true, st));
+    // encoder (bert.py:221-229)
+    for (int l = 0; l < c.num_layers; ++l) {
+        const LayerOff& o = e->lo[l];
+        const LayerWs& w = e->lw[l];
+        const char* x = ws + e->ws_x[l];
+        CK(gemm(dt, GEMM_NT, EPI_BIAS, T, 3 * H, H, x, H, e->W(o.wqkv), H, ws + w.qkv, 3 * H, nullptr, nullptr, P + o.bqkv,
+                nullptr, 0, kNoDrop, 1, 0, st));
+        CK(attention_forward(dt, ws + w.qkv, attention_mask, ws + w.ctx, B, L, nh,
+                             e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st));
+        CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, T, H, H, ws + w.ctx, H, e->W(o.wo), H, ws + w.s1, H, nullptr, nullptr,
+                P + o.bo, x, H, e->key(SITE_LAYER0 + 4 * l + 1, c.hidden_dropout), 1, 0, st));
+        CK(ln_forward(dt, ws + w.s1, P + o.ln1w, P + o.ln1b, c.layer_norm_eps, ws + w.y1, (float*)(ws + w.st1),
+                      (float*)(ws + w.st1) + T, T, H, kNoDrop, st));
+        CK(gemm(dt, GEMM_NT, EPI_BIAS_GELU, T, I, H, ws + w.y1, H, e->W(o.w1), H, ws + w.u, I, ws + w.g, nullptr, P + o.b1,
+                nullptr, 0, kNoDrop, 1, 0, st));
+        CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, T, H, I, ws + w.g, I, e->W(o.w2), I, ws + w.s2, H, nullptr, nullptr,
+                P + o.b2, ws + w.y1, H, e->key(SITE_LAYER0 + 4 * l + 2, c.hidden_dropout), 1, 0, st));
+        CK(ln_forward(dt, ws + w.s2, P + o.ln2w, P + o.ln2b, c.layer_norm_eps, ws + e->ws_x[l + 1], (float*)(ws + w.st2),
+                      (float*)(ws + w.st2) + T, T, H, kNoDrop, st));
+    }
+    // pooler + classifier (+ MSE) (bert.py:231, 304-307; multimodal_driver.py:372-373)
+    float* z = (float*)(ws + e->ws_head_z);
+    CK(gemm(dt, GEMM_NT, EPI_BIAS_F32, B, H, H, ws + e->ws_x[c.num_layers], L * H, e->W(e->wp), H, nullptr, H, nullptr, z,
+            P + e->bp, nullptr, 0, kNoDrop, 1, 64, st));
+    if (loss) CK((int)hipMemsetAsync(loss, 0, 4, st));
+    CK(head_forward(z, P + e->wc, P + e->bc, labels, (float*)(ws + e->ws_head_pooled), logits, loss, loss_run, B, H,
+                    c.num_labels, e->key(SITE_HEAD, c.hidden_dropout), st));
+    return MB_OK;
+}
+
+int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* labels, float loss_scale, int stage_begin,
+                     int stage_end, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const mb_bert_config& c = e->c;
+    if (!e->G || !e->ids) return MB_ERR_ARG;
+    const int dt = c.dtype, H = c.hidden_size, I = c.intermediate_size, B = e->B, L = e->L, T = B * L, nh = c.num_heads;
+    const int NL = c.num_layers;
+    if (stage_begin < 0) stage_begin = 0;
+    if (stage_end > NL + 2) stage_end = NL + 2;
+    float* P = e->P; float* G = e->G;
+    char* ws = e->ws;
+    const bool hd = e->training && c.hidden_dropout > 0.f;
+    for (int stage = stage_begin; stage < stage_end; ++stage) {
+        if (stage == 0) {
+            // ---- head + pooler
+            CK(head_backward(dt, dlogits, e->logits, labels, loss_scale, (const float*)(ws + e->ws_head_pooled), P + e->wc,
+                             ws + e->ws_dz, G + e->wc, G + e->bc, B, H, c.num_labels, e->key(SITE_HEAD, c.hidden_dropout),
+                             st));
+            const char* xf = ws + e->ws_x[NL];
+            CK(gemm(dt, GEMM_TN, EPI_ACCUM_F32, H, H, B, ws + e->ws_dz, H, xf, L * H, nullptr, H, nullptr, G + e->wp, nullptr,
+                    nullptr, 0, kNoDrop, 1, 64, st));
+            CK(colsum(dt, ws + e->ws_dz, H, G + e->bp, B, H, st));
+            CK((int)hipMemsetAsync(ws + e->ws_dxa, 0, (size_t)T * H * esize(dt), st));
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, B, H, H, ws + e->ws_dz, H, e->W(e->wp), H, ws + e->ws_dxa, L * H, nullptr,
+                    nullptr, nullptr, nullptr, 0, kNoDrop, 1, 64, st));
+        } else if (stage <= NL) {
+            const int l = NL - stage;
+            const LayerOff& o = e->lo[l];
+            const LayerWs& w = e->lw[l];
+            char* dx = ws + e->ws_dxa;     // grad wrt x[l+1] on entry, wrt x[l] on exit
+            char* dy1 = ws + e->ws_dxb;
+            char* ds = ws + e->ws_ds;
+            char* dzd = hd ? ws + e->ws_dzd : ds;
+            // LN2 + dropout backward
+            CK(ln_backward(dt, dx, ws + w.s2, P + o.ln2w, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, ds,
+                           hd ? dzd : nullptr, G + o.ln2w, G + o.ln2b, G + o.b2, T, H, kNoDrop,
+                           e->key(SITE_LAYER0 + 4 * l + 2, c.hidden_dropout), st));
+            CK(wgrad(dt, H, I, T, dzd, H, ws + w.g, I, G + o.w2, I, st));
+            CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzd, H, e->W(o.w2), I, ws + e->ws_du, I, nullptr, nullptr, nullptr,
+                    ws + w.u, I, kNoDrop, 1, 0, st));
+            CK(colsum(dt, ws + e->ws_du, I, G + o.b1, T, I, st));
+            CK(wgrad(dt, I, H, T, ws + e->ws_du, I, ws + w.y1, H, G + o.w1, H, st));
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, I, ws + e->ws_du, I, e->W(o.w1), H, dy1, H, nullptr, nullptr, nullptr, ds,
+                    H, kNoDrop, 1, 0, st));
+            // LN1 + dropout backward
+            CK(ln_backward(dt, dy1, ws + w.s1, P + o.ln1w, (const float*)(ws + w.st1), (const float*)(ws + w.st1) + T, ds,
+                           hd ? dzd : nullptr, G + o.ln1w, G + o.ln1b, G + o.bo, T, H, kNoDrop,
+                           e->key(SITE_LAYER0 + 4 * l + 1, c.hidden_dropout), st));
+            CK(wgrad(dt, H, H, T, dzd, H, ws + w.ctx, H, G + o.wo, H, st));
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzd, H, e->W(o.wo), H, ws + e->ws_dctx, H, nullptr, nullptr, nullptr,
+                    nullptr, 0, kNoDrop, 1, 0, st));
+            CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, ws + e->ws_dqkv, B, L, nh,
+                                  e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st));
+            CK(colsum(dt, ws + e->ws_dqkv, 3 * H, G + o.bqkv, T, 3 * H, st));
+            CK(wgrad(dt, 3 * H, H, T, ws + e->ws_dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H, st));
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, 3 * H, ws + e->ws_dqkv, 3 * H, e->W(o.wqkv), H, dx, H, nullptr, nullptr,
+                    nullptr, ds, H, kNoDrop, 1, 0, st));
+        } else {
+            // ---- MAG + embeddings
+            char* dx = ws + e->ws_dxa;
+            char* de = ws + e->ws_dxb;
+            CK(mag_bwd_impl(dt, dx, ws + e->ws_emb, P + e->mag_bhv, P + e->mag_bha, P + e->mag_bv, P + e->mag_ba,
+                            P + e->mag_lnw, c.beta_shift, e->key(SITE_MAG, c.mag_dropout), ws + e->ws_mag, e->mw, de, nullptr,
+                            nullptr, G + e->mag_whv, G + e->mag_bhv, G + e->mag_wha, G + e->mag_bha, G + e->mag_wv,
+                            G + e->mag_bv, G + e->mag_wa, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb, T, H, c.visual_dim,
+                            c.acoustic_dim, st));
+            CK(embed_ln_backward(dt, de, e->ids, e->seg, P + e->word, P + e->pos, P + e->type, P + e->emb_lnw,
+                                 (const float*)(ws + e->ws_emb_st), (const float*)(ws + e->ws_emb_st) + T,
+                                 (float*)(ws + e->ws_dsum), G + e->word, G + e->pos, G + e->type, G + e->emb_lnw,
+                                 G + e->emb_lnb, B, L, H, c.pad_token_id, e->key(SITE_EMB, c.hidden_dropout), st));
+        }
+    }
+    return MB_OK;
+}
+
+const void* mb_bert_sequence_output(const mb_bert_engine* e) { return e->ws ? e->ws + e->ws_x[e->c.num_layers] : nullptr; }
+const float* mb_bert_pooled_output(const mb_bert_engine* e) { return e->ws ? (const float*)(e->ws + e->ws_head_pooled) : nullptr; }
+
+int mb_bert_stage_grad_ranges(const mb_bert_engine* e, int stage, size_t* offs, size_t* lens, int cap) {
+    const int NL = e->c.num_layers;
+    std::vector<std::pair<size_t, size_t>> r;
+    auto span = [&](size_t a, size_t b) { r.push_back({a, b - a}); };
+    if (stage == 0) {
+        span(e->wp, e->sh_end);                               // pooler weight
+        span(e->wc, e->n_decay);                              // classifier weight
+        span(e->bp, e->mag_bhv);                              // pooler bias
+        span(e->bc, e->n_params);                             // classifier bias
+    } else if (stage <= NL) {
+        const int l = NL - stage;
+        const LayerOff& o = e->lo[l];
+        span(o.wqkv, l + 1 < NL ? e->lo[l + 1].wqkv : e->wp);
+        span(o.bqkv, l + 1 < NL ? e->lo[l + 1].bqkv : e->emb_lnw);
+    } else if (stage == NL + 1) {
+        span(e->word, e->wc);                                 // embeddings + MAG weights
+        span(e->emb_lnw, e->bp);                              // embeddings LayerNorm
+        span(e->mag_bhv, e->bc);                              // MAG biases + LayerNorm
+    } else return -1;
+    int n = 0;
+    for (auto& p : r) { if (n < cap) { offs[n] = p.first; lens[n] = p.second; } ++n; }
+    return n;
+}
+
+}  // extern "C"

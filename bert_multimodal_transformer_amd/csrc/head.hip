@@ -1,0 +1,119 @@
+// Classification head of MAG_BertForSequenceClassification (/root/reference/bert.py:304-322) fused with the
+// driver's MSE loss (/root/reference/multimodal_driver.py:372-373):
+//   pooled = tanh(z)  [z = h[:,0] Wp^T + bp comes from the GEMM]  ->  dropout(0.1)  ->  logits = . Wc^T + bc
+//   loss = mean((logits - labels)^2)
+// One wave per sample; H = 768 (3 chunks of 4 columns per lane).  Tiny, launch-latency bound.
+#include "kernels.h"
+
+namespace mb {
+
+template <int CH>
+__global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ z, const float* __restrict__ Wc,
+                                                       const float* __restrict__ bc, const float* __restrict__ labels,
+                                                       float* __restrict__ pooled, float* __restrict__ logits, float* loss,
+                                                       float* loss_run, int B, int nl, DropKey drop) {
+    constexpr int H = CH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    f32x4 pd[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * 64 + lane) * 4;
+        f32x4 t = *(const f32x4*)(z + (size_t)b * H + col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = tanhf(t[r]);
+        *(f32x4*)(pooled + (size_t)b * H + col) = t;
+        const uint32_t idx = (uint32_t)b * H + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pd[c][r] = t[r] * drop_mult(drop, idx + r);
+    }
+    for (int k = 0; k < nl; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const f32x4 w = *(const f32x4*)(Wc + (size_t)k * H + (c * 64 + lane) * 4);
+            const f32x4 t = pd[c] * w;
+            s += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+        s = wave_sum(s) + bc[k];
+        if (lane == 0) {
+            logits[(size_t)b * nl + k] = s;
+            if (labels) {
+                const float d = s - labels[(size_t)b * nl + k];
+                if (loss) atomicAdd(loss, d * d / (float)(B * nl));
+                if (loss_run) atomicAdd(loss_run, d * d / (float)(B * nl));
+            }
+        }
+    }
+}
+
+template <class T, int CH>
+__global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ logits,
+                                                       const float* __restrict__ labels, float loss_scale,
+                                                       const float* __restrict__ pooled, const float* __restrict__ Wc,
+                                                       T* __restrict__ dz, float* dWc, float* dbc, int B, int nl,
+                                                       DropKey drop) {
+    constexpr int H = CH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    f32x4 dpd[CH], pl[CH], dm[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * 64 + lane) * 4;
+        dpd[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pl[c] = *(const f32x4*)(pooled + (size_t)b * H + col);
+        const uint32_t idx = (uint32_t)b * H + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dm[c][r] = drop_mult(drop, idx + r);
+    }
+    for (int k = 0; k < nl; ++k) {
+        float dl;
+        if (dlogits) dl = dlogits[(size_t)b * nl + k];
+        else dl = 2.0f * (logits[(size_t)b * nl + k] - labels[(size_t)b * nl + k]) / (float)(B * nl) * loss_scale;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int col = (c * 64 + lane) * 4;
+            dpd[c] += dl * *(const f32x4*)(Wc + (size_t)k * H + col);
+            if (dWc) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(dWc + (size_t)k * H + col + r, dl * pl[c][r] * dm[c][r]);
+            }
+        }
+        if (dbc && lane == 0) atomicAdd(dbc + k, dl);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * 64 + lane) * 4;
+        const f32x4 d = dpd[c] * dm[c] * (1.0f - pl[c] * pl[c]);
+        store4(dz + (size_t)b * H + col, d);
+    }
+}
+
+int head_forward(const float* z, const float* Wc, const float* bc, const float* labels, float* pooled, float* logits,
+                 float* loss, float* loss_run, int B, int H, int nl, DropKey drop, hipStream_t st) {
+    if (H != 768) return MB_ERR_SHAPE;
+    if (B <= 0) return MB_OK;
+    hipLaunchKernelGGL((head_fwd_kernel<3>), dim3((B + 3) / 4), dim3(256), 0, st, z, Wc, bc, labels, pooled, logits, loss,
+                       loss_run, B, nl, drop);
+    return (int)hipGetLastError();
+}
+
+int head_backward(int dtype, const float* dlogits, const float* logits, const float* labels, float loss_scale,
+                  const float* pooled, const float* Wc, void* dz, float* dWc, float* dbc, int B, int H, int nl,
+                  DropKey drop, hipStream_t st) {
+    if (H != 768) return MB_ERR_SHAPE;
+    if (B <= 0) return MB_OK;
+    if (!dlogits && !(logits && labels)) return MB_ERR_ARG;
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL((head_bwd_kernel<bf16, 3>), dim3((B + 3) / 4), dim3(256), 0, st, dlogits, logits, labels,
+                           loss_scale, pooled, Wc, (bf16*)dz, dWc, dbc, B, nl, drop);
+    else if (dtype == DT_F32)
+        hipLaunchKernelGGL((head_bwd_kernel<float, 3>), dim3((B + 3) / 4), dim3(256), 0, st, dlogits, logits, labels,
+                           loss_scale, pooled, Wc, (float*)dz, dWc, dbc, B, nl, drop);
+    else return MB_ERR_DTYPE;
+    return (int)hipGetLastError();
+}
+
+}  // namespace mb

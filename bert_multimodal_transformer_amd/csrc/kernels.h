@@ -1,0 +1,123 @@
+// Internal C++ launch API of the HIP kernels (host side).  The public C ABI is include/magbert_hip.h.
+#pragma once
+#include "common.h"
+
+namespace mb {
+
+enum {
+    MB_OK = 0,
+    MB_ERR_SHAPE = 1001,     // unsupported shape / alignment
+    MB_ERR_MODE = 1002,      // unsupported epilogue / layout combination
+    MB_ERR_DTYPE = 1003,
+    MB_ERR_ARG = 1004,
+};
+
+// ------------------------------------------------------------------------------------------ GEMM
+enum { GEMM_NT = 0,   // A [M][K] row, B [N][K] row      : Y = X W^T            (forward Linear)
+       GEMM_NN = 1,   // A [M][K] row, B [K][N] kmaj     : dX = dY W            (dgrad)
+       GEMM_TN = 2 }; // A [K][M] kmaj, B [K][N] kmaj    : dW = dY^T X          (wgrad)
+
+enum { EPI_BIAS = 0,          // C = alpha*acc + bias                                   (T out)
+       EPI_BIAS_GELU = 1,     // C = acc + bias ; C2 = gelu(C)                          (T out x2)
+       EPI_BIAS_DROP_RES = 2, // C = dropout(acc + bias) + R                            (T out)
+       EPI_ADD_RES = 3,       // C = acc (+ R)                                          (T out)
+       EPI_DGELU = 4,         // C = acc * gelu'(R)                                     (T out)
+       EPI_ACCUM_F32 = 5,     // Cf += acc   (atomic when split-K)                      (fp32 out)
+       EPI_BIAS_F32 = 6 };    // Cf = alpha*acc + bias                                  (fp32 out)
+
+struct GemmArgs {
+    const void* A; const void* B;
+    int M, N, K, lda, ldb;
+    void* C; int ldc;          // T output (modes 0-4)
+    void* C2;                  // second T output (mode 1), same ldc
+    float* Cf;                 // fp32 output (modes 5, 6), ldc
+    const float* bias;         // [N] fp32 or null
+    const void* R; int ldr;    // residual / aux input (T)
+    float alpha;
+    DropKey drop;
+    int kchunk;                // filled by the launcher
+};
+
+// tile: 0 = auto, 64 or 128.  splits: split-K factor (only EPI_ACCUM_F32).
+int gemm_launch(int dtype, int layout, int mode, const GemmArgs& a, int splits, int tile, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------ row kernels (rowops.hip)
+// LayerNorm over the last dim H (H % 256 == 0, H <= 1024): y = (x-mean)*rstd*gamma + beta ; optional dropout on y.
+int ln_forward(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,
+               float* mean, float* rstd, int rows, int H, DropKey drop, hipStream_t st);
+// LayerNorm backward. dy: grad of LN output (after optional dropout `drop_out`), x: saved LN input.
+//   dx      = grad wrt LN input                         (T)  [required]
+//   dx_drop = dx * mask(drop_in)                        (T)  [optional: grad of the pre-dropout Linear output]
+//   dgamma, dbeta += column sums ; dbias += colsum(dx_drop or dx)   (fp32, atomics) [each optional]
+int ln_backward(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias,
+                int rows, int H, DropKey drop_out, DropKey drop_in, hipStream_t st);
+
+// BertEmbeddings: e = dropout(LN(word[ids] + pos[l] + type[seg])).
+int embed_ln_forward(int dtype, const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
+                     const float* type, const float* gamma, const float* beta, float eps, void* out,
+                     float* mean, float* rstd, int B, int L, int H, DropKey drop, hipStream_t st);
+int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int64_t* seg, const float* word,
+                      const float* pos, const float* type, const float* gamma, const float* mean, const float* rstd,
+                      float* dsum_ws, float* dword, float* dpos, float* dtype_, float* dgamma, float* dbeta,
+                      int B, int L, int H, int pad_id, DropKey drop, hipStream_t st);
+
+// column sums: out[n] += sum_m x[m][n]
+int colsum(int dtype, const void* x, int ldx, float* out, int rows, int cols, hipStream_t st);
+
+// fp32 [rows][cols] -> T [rows][cols_pad] zero padded (modality tensors -> MFMA operands)
+int pack_pad(int dtype, const float* src, int cols, void* dst, int cols_pad, int rows, hipStream_t st);
+// fp32 -> T contiguous conversion (n elements)
+int convert(int dtype, const float* src, void* dst, size_t n, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------ MAG (mag.hip)
+struct MagDims { int T, H, V, A, Vp, Ap; };
+// pack master weights (reference layout) into the MFMA operand layout:
+//   We [2H][H]  = [W_hv[:, V:] ; W_ha[:, A:]]     Wv [2H][Vp] = [W_hv[:, :V] ; W_v]     Wa [2H][Ap] = [W_ha[:, :A] ; W_a]
+int mag_pack_weights(int dtype, const float* W_hv, const float* W_ha, const float* W_v, const float* W_a,
+                     void* We, void* Wv, void* Wa, MagDims d, hipStream_t st);
+// scatter-add packed weight grads back into the reference layout
+int mag_unpack_wgrads(const float* dWe, const float* dWv, const float* dWa, float* dW_hv, float* dW_ha,
+                      float* dW_v, float* dW_a, MagDims d, hipStream_t st);
+// gate + norm-ratio clamp + residual + LayerNorm + dropout (modeling.py:27-49) from the three pre-activation panels
+int mag_gate_forward(int dtype, const void* e, const void* Ze, const void* Zv, const void* Za,
+                     const float* b_hv, const float* b_ha, const float* b_v, const float* b_a,
+                     const float* gamma, const float* beta, float ln_eps, float beta_shift,
+                     void* out, float* mean, float* rstd, MagDims d, DropKey drop, hipStream_t st);
+int mag_gate_backward(int dtype, const void* dout, const void* e, const void* Ze, const void* Zv, const void* Za,
+                      const float* b_hv, const float* b_ha, const float* b_v, const float* b_a,
+                      const float* gamma, const float* mean, const float* rstd, float beta_shift,
+                      void* de, void* dZe, void* dZv, void* dZa,
+                      float* db_hv, float* db_ha, float* db_v, float* db_a, float* dgamma, float* dbeta,
+                      MagDims d, DropKey drop, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------ attention (attention.hip)
+// qkv: [B*L][3H] token-major (q | k | v, head h at columns h*64..), mask: int64 [B][L] (1 = attend),
+// ctx: [B*L][H].  softmax(QK^T/sqrt(dh) + (1-mask)*-10000) -> dropout -> . V   (dh = 64, L <= 128)
+int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx, int B, int L, int nh,
+                      DropKey drop, hipStream_t st);
+int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx,
+                       void* dqkv, int B, int L, int nh, DropKey drop, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------ head (head.hip)
+// pooled = tanh(z) ; logits = dropout(pooled) Wc^T + bc ; optional MSE loss (mean over B*nl) accumulated into loss[0]
+// and (if non-null) into the running sum loss_run[0].
+int head_forward(const float* z, const float* Wc, const float* bc, const float* labels, float* pooled,
+                 float* logits, float* loss, float* loss_run, int B, int H, int nl, DropKey drop, hipStream_t st);
+// dlogits (given, or MSE grad if labels != null: 2*(logit-y)/(B*nl)*loss_scale) -> dz (grad wrt pooler pre-activation),
+// dWc, dbc accumulated.  dz is written in the activation dtype (operand of the pooler dgrad / wgrad GEMMs).
+int head_backward(int dtype, const float* dlogits, const float* logits, const float* labels, float loss_scale,
+                  const float* pooled, const float* Wc, void* dz, float* dWc, float* dbc,
+                  int B, int H, int nl, DropKey drop, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------ optimizer (adamw.hip)
+struct AdamArgs {
+    float lr, beta1, beta2, eps, weight_decay, step_size;   // step_size = lr*sqrt(1-b2^t)/(1-b1^t)
+    float grad_scale;                                        // multiply g before use (1/world_size for DP averaging)
+};
+// transformers 3.0.2 AdamW over flat fp32 buffers; elements [0, n_decay) use weight_decay, the rest 0.
+// shadow (bf16, may be null): shadow[i] = bf16(p[i]) for i in [sh_begin, sh_end). zero_grad: g <- 0 after use.
+int adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, size_t n_decay,
+               size_t sh_begin, size_t sh_end, AdamArgs a, int zero_grad, hipStream_t st);
+
+}  // namespace mb

@@ -1,0 +1,389 @@
+// HBM-bound row kernels of the MAG-BERT path: LayerNorm fwd/bwd (with the dropout that follows or precedes
+// it fused), BertEmbeddings gather+LN fwd / scatter bwd, column sums (bias grads), operand packing.
+//
+// Reference semantics:
+//   BertEmbeddings / BertSelfOutput / BertOutput LayerNorm + dropout (transformers 3.0.2, called from
+//   /root/reference/bert.py:211-229), MAG LayerNorm (/root/reference/modeling.py:22,47-49).
+//
+// Layout: one 64-lane wave owns one row of H = CH*256 elements; lane l holds CH chunks of 4 consecutive
+// elements at columns (c*64 + l)*4  -> every global access is a coalesced 8/16-byte vector.
+// Algorithmic HBM bytes per token are listed per kernel in DESIGN.md.
+#include "kernels.h"
+
+namespace mb {
+
+template <int CH>
+struct RowStat {
+    // two-pass mean / variance of a row held in registers (biased variance, like torch.nn.LayerNorm)
+    static __device__ __forceinline__ void compute(const f32x4 (&v)[CH], float eps, float& mu, float& rs) {
+        constexpr float invH = 1.0f / (CH * 256);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        mu = wave_sum(s) * invH;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = v[c][r] - mu; q += d * d; }
+        }
+        rs = 1.0f / sqrtf(wave_sum(q) * invH + eps);
+    }
+};
+
+// ------------------------------------------------------------------------------------------ LayerNorm forward
+template <class T, int CH>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     DropKey drop) {
+    constexpr int H = CH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    f32x4 v[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) v[c] = load4(x + (size_t)row * H + (c * 64 + lane) * 4);
+    float mu, rs;
+    RowStat<CH>::compute(v, eps, mu, rs);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * 64 + lane) * 4;
+        const f32x4 g = *(const f32x4*)(gamma + col), b = *(const f32x4*)(beta + col);
+        f32x4 o = (v[c] - mu) * rs * g + b;
+        const uint32_t idx = (uint32_t)row * H + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] *= drop_mult(drop, idx + r);
+        store4(y + (size_t)row * H + col, o);
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// shared tail of the backward kernels: reduce per-lane column partials over the block's 4 waves, then atomics.
+template <int CH, int NQ>
+__device__ __forceinline__ void block_colsum_atomic(f32x4 (&part)[NQ][CH], float* const (&dst)[NQ], float* lds) {
+    constexpr int H = CH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) *(f32x4*)(lds + (wave * NQ + q) * H + (c * 64 + lane) * 4) = part[q][c];
+    __syncthreads();
+    for (int i = threadIdx.x; i < NQ * H; i += 256) {
+        const int q = i / H, col = i % H;
+        if (dst[q] == nullptr) continue;
+        const float s = lds[(0 * NQ + q) * H + col] + lds[(1 * NQ + q) * H + col] + lds[(2 * NQ + q) * H + col] +
+                        lds[(3 * NQ + q) * H + col];
+        atomicAdd(dst[q] + col, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm backward
+template <class T, int CH, int RPW>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx,
+                                                     T* __restrict__ dx_drop, float* dgamma, float* dbeta, float* dbias,
+                                                     int rows, DropKey drop_out, DropKey drop_in) {
+    constexpr int H = CH * 256;
+    constexpr float invH = 1.0f / H;
+    __shared__ float lds[4 * 3 * H];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 part[3][CH];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) part[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 g[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) g[c] = *(const f32x4*)(gamma + (c * 64 + lane) * 4);
+
+    for (int i = 0; i < RPW; ++i) {
+        const int row = (blockIdx.x * 4 + wave) * RPW + i;
+        if (row >= rows) break;
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 dyv[CH], xh[CH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int col = (c * 64 + lane) * 4;
+            dyv[c] = load4(dy + (size_t)row * H + col);
+            const uint32_t idx = (uint32_t)row * H + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dyv[c][r] *= drop_mult(drop_out, idx + r);
+            xh[c] = (load4(x + (size_t)row * H + col) - mu) * rs;
+            const f32x4 dxh = dyv[c] * g[c];
+            s1 += (dxh[0] + dxh[1]) + (dxh[2] + dxh[3]);
+            const f32x4 t = dxh * xh[c];
+            s2 += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+        const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int col = (c * 64 + lane) * 4;
+            f32x4 d = (dyv[c] * g[c] - m1 - xh[c] * m2) * rs;
+            store4(dx + (size_t)row * H + col, d);
+            part[0][c] += dyv[c] * xh[c];
+            part[1][c] += dyv[c];
+            if (dx_drop) {
+                const uint32_t idx = (uint32_t)row * H + col;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] *= drop_mult(drop_in, idx + r);
+                store4(dx_drop + (size_t)row * H + col, d);
+            }
+            part[2][c] += d;
+        }
+    }
+    float* const dst[3] = {dgamma, dbeta, dbias};
+    block_colsum_atomic<CH, 3>(part, dst, lds);
+}
+
+// ------------------------------------------------------------------------------------------ embeddings
+template <class T, int CH>
+__global__ void __launch_bounds__(256) embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
+                                                        const float* __restrict__ word, const float* __restrict__ pos,
+                                                        const float* __restrict__ type, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, T* __restrict__ out,
+                                                        float* __restrict__ mean, float* __restrict__ rstd, int rows, int L,
+                                                        DropKey drop) {
+    constexpr int H = CH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const size_t id = (size_t)ids[row], sg = (size_t)seg[row], l = (size_t)(row % L);
+    f32x4 v[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * 64 + lane) * 4;
+        v[c] = *(const f32x4*)(word + id * H + col) + *(const f32x4*)(pos + l * H + col) +
+               *(const f32x4*)(type + sg * H + col);
+    }
+    float mu, rs;
+    RowStat<CH>::compute(v, eps, mu, rs);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * 64 + lane) * 4;
+        const f32x4 g = *(const f32x4*)(gamma + col), b = *(const f32x4*)(beta + col);
+        f32x4 o = (v[c] - mu) * rs * g + b;
+        const uint32_t idx = (uint32_t)row * H + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] *= drop_mult(drop, idx + r);
+        store4(out + (size_t)row * H + col, o);
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <class T, int CH, int RPW>
+__global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids,
+                                                        const int64_t* __restrict__ seg, const float* __restrict__ word,
+                                                        const float* __restrict__ pos, const float* __restrict__ type,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, float* __restrict__ dsum_ws,
+                                                        float* dword, float* dgamma, float* dbeta, int rows, int L,
+                                                        int pad_id, DropKey drop) {
+    constexpr int H = CH * 256;
+    constexpr float invH = 1.0f / H;
+    __shared__ float lds[4 * 2 * H];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 part[2][CH];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) part[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < RPW; ++i) {
+        const int row = (blockIdx.x * 4 + wave) * RPW + i;
+        if (row >= rows) break;
+        const size_t id = (size_t)ids[row], sg = (size_t)seg[row], l = (size_t)(row % L);
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 dyv[CH], xh[CH], gg[CH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int col = (c * 64 + lane) * 4;
+            const f32x4 xv = *(const f32x4*)(word + id * H + col) + *(const f32x4*)(pos + l * H + col) +
+                             *(const f32x4*)(type + sg * H + col);
+            xh[c] = (xv - mu) * rs;
+            dyv[c] = load4(dout + (size_t)row * H + col);
+            const uint32_t idx = (uint32_t)row * H + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dyv[c][r] *= drop_mult(drop, idx + r);
+            gg[c] = *(const f32x4*)(gamma + col);
+            const f32x4 dxh = dyv[c] * gg[c];
+            s1 += (dxh[0] + dxh[1]) + (dxh[2] + dxh[3]);
+            const f32x4 t = dxh * xh[c];
+            s2 += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+        const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int col = (c * 64 + lane) * 4;
+            const f32x4 d = (dyv[c] * gg[c] - m1 - xh[c] * m2) * rs;
+            *(f32x4*)(dsum_ws + (size_t)row * H + col) = d;
+            if ((int)id != pad_id) {      // nn.Embedding(padding_idx=pad_token_id): no gradient for the pad row
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(dword + id * H + col + r, d[r]);
+            }
+            part[0][c] += dyv[c] * xh[c];
+            part[1][c] += dyv[c];
+        }
+    }
+    float* const dst[2] = {dgamma, dbeta};
+    block_colsum_atomic<CH, 2>(part, dst, lds);
+}
+
+// position / token-type table grads: block l sums dsum over the batch (sole owner of dpos[l]).
+__global__ void __launch_bounds__(256) embed_pos_type_kernel(const float* __restrict__ dsum_ws, const int64_t* __restrict__ seg,
+                                                             float* dpos, float* dtype_, int B, int L, int H) {
+    const int l = blockIdx.x;
+    for (int col = threadIdx.x; col < H; col += 256) {
+        float ap = 0.f, a0 = 0.f, a1 = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const int t = b * L + l;
+            const float d = dsum_ws[(size_t)t * H + col];
+            const int64_t sg = seg[t];
+            ap += d;
+            if (sg == 0) a0 += d;
+            else if (sg == 1) a1 += d;
+            else atomicAdd(dtype_ + (size_t)sg * H + col, d);
+        }
+        dpos[(size_t)l * H + col] += ap;
+        atomicAdd(dtype_ + col, a0);
+        atomicAdd(dtype_ + H + col, a1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ column sum
+template <class T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int ldx, float* out, int rows, int cols,
+                                                     int rows_per_block) {
+    __shared__ f32x4 lds[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * 4;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (col < cols)
+        for (int r = r0 + wave; r < r1; r += 4) acc += load4(x + (size_t)r * ldx + col);
+    lds[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && col < cols) {
+        const f32x4 s = lds[0][lane] + lds[1][lane] + lds[2][lane] + lds[3][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(out + col + r, s[r]);
+    }
+}
+
+template <class T>
+__global__ void pack_pad_kernel(const float* __restrict__ src, int cols, T* __restrict__ dst, int cols_pad, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t r = i / cols_pad;
+    const int c = (int)(i % cols_pad);
+    dst[i] = from_f<T>(c < cols ? src[r * cols + c] : 0.f);
+}
+
+template <class T>
+__global__ void convert_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        store4(dst + i * 4, *(const f32x4*)(src + i * 4));
+}
+
+// ------------------------------------------------------------------------------------------ host launchers
+#define MB_DISPATCH_T(dtype, ...)                                  \
+    if ((dtype) == DT_BF16) { typedef bf16 T; __VA_ARGS__ }        \
+    else if ((dtype) == DT_F32) { typedef float T; __VA_ARGS__ }   \
+    else return MB_ERR_DTYPE;
+#define MB_DISPATCH_CH(H, ...)                                     \
+    if ((H) == 768) { constexpr int CH = 3; __VA_ARGS__ }          \
+    else if ((H) == 1024) { constexpr int CH = 4; __VA_ARGS__ }    \
+    else if ((H) == 512) { constexpr int CH = 2; __VA_ARGS__ }     \
+    else if ((H) == 256) { constexpr int CH = 1; __VA_ARGS__ }     \
+    else return MB_ERR_SHAPE;
+
+int ln_forward(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
+               float* rstd, int rows, int H, DropKey drop, hipStream_t st) {
+    if (rows <= 0) return MB_OK;
+    MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
+        hipLaunchKernelGGL((ln_fwd_kernel<T, CH>), dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)x, gamma, beta, eps,
+                           (T*)y, mean, rstd, rows, drop);
+    }))
+    return (int)hipGetLastError();
+}
+
+int ln_backward(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias, int rows, int H, DropKey drop_out,
+                DropKey drop_in, hipStream_t st) {
+    if (rows <= 0) return MB_OK;
+    constexpr int RPW = 4;
+    MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
+        hipLaunchKernelGGL((ln_bwd_kernel<T, CH, RPW>), dim3((rows + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st,
+                           (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, (T*)dx_drop, dgamma, dbeta, dbias, rows,
+                           drop_out, drop_in);
+    }))
+    return (int)hipGetLastError();
+}
+
+int embed_ln_forward(int dtype, const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
+                     const float* type, const float* gamma, const float* beta, float eps, void* out, float* mean,
+                     float* rstd, int B, int L, int H, DropKey drop, hipStream_t st) {
+    const int rows = B * L;
+    if (rows <= 0) return MB_OK;
+    MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
+        hipLaunchKernelGGL((embed_fwd_kernel<T, CH>), dim3((rows + 3) / 4), dim3(256), 0, st, ids, seg, word, pos, type,
+                           gamma, beta, eps, (T*)out, mean, rstd, rows, L, drop);
+    }))
+    return (int)hipGetLastError();
+}
+
+int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int64_t* seg, const float* word,
+                      const float* pos, const float* type, const float* gamma, const float* mean, const float* rstd,
+                      float* dsum_ws, float* dword, float* dpos, float* dtype_, float* dgamma, float* dbeta, int B, int L,
+                      int H, int pad_id, DropKey drop, hipStream_t st) {
+    const int rows = B * L;
+    if (rows <= 0) return MB_OK;
+    constexpr int RPW = 4;
+    MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
+        hipLaunchKernelGGL((embed_bwd_kernel<T, CH, RPW>), dim3((rows + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st,
+                           (const T*)dout, ids, seg, word, pos, type, gamma, mean, rstd, dsum_ws, dword, dgamma, dbeta,
+                           rows, L, pad_id, drop);
+    }))
+    hipLaunchKernelGGL(embed_pos_type_kernel, dim3(L), dim3(256), 0, st, dsum_ws, seg, dpos, dtype_, B, L, H);
+    return (int)hipGetLastError();
+}
+
+int colsum(int dtype, const void* x, int ldx, float* out, int rows, int cols, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return MB_OK;
+    if (cols % 4) return MB_ERR_SHAPE;
+    const int cblocks = (cols + 255) / 256;
+    int rblocks = (512 + cblocks - 1) / cblocks;
+    if (rblocks > (rows + 15) / 16) rblocks = (rows + 15) / 16;
+    if (rblocks < 1) rblocks = 1;
+    const int rpb = (rows + rblocks - 1) / rblocks;
+    rblocks = (rows + rpb - 1) / rpb;
+    MB_DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((colsum_kernel<T>), dim3(cblocks, rblocks), dim3(256), 0, st, (const T*)x, ldx, out, rows,
+                           cols, rpb);
+    })
+    return (int)hipGetLastError();
+}
+
+int pack_pad(int dtype, const float* src, int cols, void* dst, int cols_pad, int rows, hipStream_t st) {
+    const size_t total = (size_t)rows * cols_pad;
+    if (total == 0) return MB_OK;
+    MB_DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((pack_pad_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, cols,
+                           (T*)dst, cols_pad, total);
+    })
+    return (int)hipGetLastError();
+}
+
+int convert(int dtype, const float* src, void* dst, size_t n, hipStream_t st) {
+    if (n == 0) return MB_OK;
+    if (n % 4) return MB_ERR_SHAPE;
+    const size_t n4 = n / 4;
+    unsigned grid = (unsigned)((n4 + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((convert_kernel<T>), dim3(grid), dim3(256), 0, st, src, (T*)dst, n4); })
+    return (int)hipGetLastError();
+}
+
+}  // namespace mb

@@ -1,0 +1,123 @@
+"""Single-node data parallelism for MAG-BERT fine-tuning: one process per GPU, RCCL over xGMI.
+
+NEW relative to the reference, which is single-device (global_configs.py:4,7; DistributedSampler imported but unused,
+multimodal_driver.py:21).  Every sample is independent (no cross-sample statistics; MSE is a batch mean), so the
+minibatch shards across ranks and the only exchange is ONE logical all-reduce (sum) of the flat fp32 gradient
+buffer per optimizer step.  It is issued in pieces on a side HIP stream while the backward is still running:
+
+    backward stage s finishes (head | layer 11 | ... | layer 0 | MAG+embeddings)
+        -> event on the compute stream -> comm stream waits -> all_reduce(flat_grads[range of stage s])
+
+so layer-11 gradients travel while layer-10's dgrad/wgrad GEMMs run.  The flat layout makes each stage's weight
+gradients one contiguous 28 MB range (no bucket copy-in/copy-out); the ~100 K small no-decay parameters (biases,
+LayerNorm) plus the classifier go out as one final 0.4 MB piece.  The 1/world_size averaging is folded into the
+AdamW kernel (AdamW.grad_scale), so no extra pass over the gradients.  xGMI is point-to-point (7 links/GPU): large
+contiguous pieces let RCCL use all links; we never translate an NCCL bucket pattern.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n, rank, world, batch_size, seed, epoch, drop_last=False):
+    """Per-rank minibatch index lists for one epoch.  A global shuffle (same on all ranks) is cut into global
+    batches of world*batch_size; each rank takes its contiguous slice.  The ragged tail (n % (world*bs)) is split
+    evenly so every rank runs the same number of steps (collectives stay matched); ranks may differ by one sample
+    in the last step, which the SUM/world averaging weights by 1/world per rank (stated in DESIGN.md)."""
+    g = torch.Generator()
+    g.manual_seed(int(seed) * 1000003 + int(epoch))
+    perm = torch.randperm(n, generator=g).tolist()
+    gb = world * batch_size
+    out = []
+    full = n // gb
+    for i in range(full):
+        base = i * gb + rank * batch_size
+        out.append(perm[base: base + batch_size])
+    tail = perm[full * gb:]
+    if tail and not drop_last:
+        per = (len(tail) + world - 1) // world
+        mine = tail[rank * per: (rank + 1) * per]
+        if len(tail) >= world:          # every rank gets >= 1 sample
+            out.append(mine)
+    return out
+
+
+class GradReducer(object):
+    """All-reduce(sum) of ranges of a flat gradient tensor on a side stream (CUDA) or inline (CPU/gloo)."""
+
+    def __init__(self, flat_grads, process_group=None):
+        self.g = flat_grads
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.cuda = flat_grads.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=flat_grads.device) if self.cuda else None
+        self.pending = []
+
+    def reduce_ranges(self, ranges):
+        if self.world == 1 or not ranges:
+            return
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.g.device))
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                for off, n in ranges:
+                    dist.all_reduce(self.g[off: off + n], op=dist.ReduceOp.SUM, group=self.pg)
+        else:
+            for off, n in ranges:
+                dist.all_reduce(self.g[off: off + n], op=dist.ReduceOp.SUM, group=self.pg)
+
+    def wait(self):
+        """make the compute stream wait for every outstanding piece (call before optimizer.step())"""
+        if self.cuda and self.world > 1:
+            torch.cuda.current_stream(self.g.device).wait_stream(self.comm_stream)
+
+
+def stage_plan(core):
+    """[(stage, [large ranges])] + the final small range, from the engine's layout."""
+    nstage = core.config.num_hidden_layers + 2
+    small_begin = None
+    plan = []
+    for s in range(nstage):
+        big = []
+        for off, n in core.stage_ranges(s):
+            if n >= (1 << 16):
+                big.append((off, n))
+        plan.append(big)
+    # everything that is not in a big range: classifier weight + the whole no-decay group live at the tail
+    covered_end = max(off + n for big in plan for off, n in big if off < core.n_decay)
+    small_begin = covered_end
+    return plan, (small_begin, core.n_params - small_begin)
+
+
+class DataParallel(object):
+    """Wraps a MAG_BertForSequenceClassification: hooks the engine's backward stages to the reducer."""
+
+    def __init__(self, model, optimizer=None, process_group=None):
+        self.model = model
+        self.core = model._core
+        self.reducer = GradReducer(self.core.grads, process_group)
+        self.world = self.reducer.world
+        self.plan, self.tail = stage_plan(self.core)
+        self.core.grad_hook = self._on_stage
+        self.sync = True          # set False on gradient-accumulation micro-steps (multimodal_driver.py:383)
+        if optimizer is not None:
+            optimizer.grad_scale = 1.0 / self.world
+
+    def broadcast_parameters(self, src=0):
+        if self.world > 1:
+            dist.broadcast(self.core.params, src=src, group=self.reducer.pg)
+            self.core.weights_dirty = True
+
+    def _on_stage(self, stage):
+        if not self.sync:
+            return
+        self.reducer.reduce_ranges(self.plan[stage])
+        if stage == len(self.plan) - 1:
+            self.reducer.reduce_ranges([self.tail])
+            self.reducer.wait()
+
+    def __getattr__(self, name):
+        return getattr(self.model, name)
+
+    def __call__(self, *a, **k):
+        return self.model(*a, **k)

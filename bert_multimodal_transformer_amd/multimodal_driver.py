@@ -1,0 +1,434 @@
+"""Train / eval / test loop -- drop-in for /root/reference/multimodal_driver.py, on the HIP path.
+
+Same function names, argument lists and return values as the reference:
+    convert_to_features, prepare_bert_input, prepare_xlnet_input, get_appropriate_dataset, set_up_data_loader,
+    set_random_seed, prep_for_training, train_epoch, eval_epoch, test_epoch, test_score_model, train, main
+and the same CLI flags / defaults (multimodal_driver.py:35-57).  `args` is a module global like in the reference
+(parsed lazily by main(); tests assign driver.args = parse_args([...])).
+
+Differences (all additive):
+  * train_epoch runs the fused forward+MSE+backward step and accumulates the loss ON DEVICE; the per-step
+    `loss.item()` host sync of multimodal_driver.py:380 is gone (one sync per epoch).  `--reference_loop true`
+    runs the literal reference sequence (model(...) -> MSELoss -> loss.backward() -> optimizer.step()) instead.
+  * data parallel: launched under torchrun, each rank takes its shard of every global batch and gradients are
+    all-reduced over RCCL while the backward runs (distributed.py).
+  * `--synthetic N` builds an N-sample dataset in prepare_bert_input's exact layout (no mosi.pkl offline);
+    VISUAL_DIM follows --dataset (47 mosi / 35 mosei) instead of a hand-edited module constant.
+  * `--seed 7` works (the reference's argparse `seed` type rejects every integer string, argparse_utils.py:18-31).
+"""
+from __future__ import absolute_import, division, print_function
+
+import argparse
+import os
+import pickle
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import MSELoss
+from torch.utils.data import DataLoader, TensorDataset
+
+from .bert import BertConfig, MAG_BertForSequenceClassification
+from .global_configs import DATASET_DIMS
+from .optimization import AdamW, get_linear_schedule_with_warmup
+
+args = None
+DEVICE = None      # resolved in main() / _device(): the current ROCm device (reference: cuda:0, global_configs.py:7)
+
+
+def _device():
+    global DEVICE
+    if DEVICE is None:
+        DEVICE = torch.device("cuda", torch.cuda.current_device())
+    return DEVICE
+
+
+def str2bool(s):
+    if isinstance(s, bool):
+        return s
+    if s.lower() in ("yes", "true", "t", "y", "1"):
+        return True
+    if s.lower() in ("no", "false", "f", "n", "0"):
+        return False
+    raise argparse.ArgumentTypeError("Boolean value expected. Recieved {0}".format(s))
+
+
+def seed(s):
+    """argparse_utils.py:18-31, fixed to accept integer strings."""
+    if isinstance(s, str) and s == "random":
+        return random.randint(0, 9999)
+    try:
+        v = int(s)
+    except (TypeError, ValueError):
+        raise argparse.ArgumentTypeError("Integer value is expected. Recieved {0}".format(s))
+    if 0 <= v <= 9999:
+        return v
+    raise argparse.ArgumentTypeError("Seed must be between 0 and 9999. Received {0}".format(s))
+
+
+def get_parser():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--dataset", type=str, choices=["mosi", "mosei"], default="mosi")
+    parser.add_argument("--max_seq_length", type=int, default=50)
+    parser.add_argument("--train_batch_size", type=int, default=48)
+    parser.add_argument("--dev_batch_size", type=int, default=128)
+    parser.add_argument("--test_batch_size", type=int, default=128)
+    parser.add_argument("--n_epochs", type=int, default=40)
+    parser.add_argument("--beta_shift", type=float, default=1.0)
+    parser.add_argument("--dropout_prob", type=float, default=0.5)
+    parser.add_argument("--model", type=str, choices=["bert-base-uncased", "xlnet-base-cased"], default="bert-base-uncased")
+    parser.add_argument("--learning_rate", type=float, default=1e-5)
+    parser.add_argument("--gradient_accumulation_step", type=int, default=1)
+    parser.add_argument("--warmup_proportion", type=float, default=0.1)
+    parser.add_argument("--seed", type=seed, default="random")
+    # additions
+    parser.add_argument("--synthetic", type=int, default=0, help="use N synthetic training samples (no .pkl needed)")
+    parser.add_argument("--compute_dtype", choices=["bf16", "fp32"], default="bf16")
+    parser.add_argument("--reference_loop", type=str2bool, default=False)
+    parser.add_argument("--pretrained", type=str, default="", help="local checkpoint dir/file (offline)")
+    return parser
+
+
+def parse_args(argv=None):
+    return get_parser().parse_args(argv)
+
+
+class InputFeatures(object):
+    """A single set of features of data (multimodal_driver.py:64-73)."""
+
+    def __init__(self, input_ids, visual, acoustic, input_mask, segment_ids, label_id):
+        self.input_ids = input_ids
+        self.visual = visual
+        self.acoustic = acoustic
+        self.input_mask = input_mask
+        self.segment_ids = segment_ids
+        self.label_id = label_id
+
+
+class MultimodalConfig(object):
+    """multimodal_driver.py:76-79."""
+
+    def __init__(self, beta_shift, dropout_prob):
+        self.beta_shift = beta_shift
+        self.dropout_prob = dropout_prob
+
+
+def _dims():
+    d = DATASET_DIMS[args.dataset]
+    return d["visual_dim"], d["acoustic_dim"]
+
+
+# ------------------------------------------------------------------------------------------------- features
+def convert_to_features(examples, max_seq_length, tokenizer):
+    """multimodal_driver.py:82-140: per-word features repeated per wordpiece, truncated to L-2, then padded."""
+    features = []
+    for (ex_index, example) in enumerate(examples):
+        (words, visual, acoustic), label_id, segment = example
+        tokens, inversions = [], []
+        for idx, word in enumerate(words):
+            tokenized = tokenizer.tokenize(word)
+            tokens.extend(tokenized)
+            inversions.extend([idx] * len(tokenized))
+        assert len(tokens) == len(inversions)
+        inv = np.asarray(inversions, dtype=np.int64)
+        visual = np.asarray(visual)[inv] if len(inv) else np.zeros((0, np.asarray(visual).shape[1]))
+        acoustic = np.asarray(acoustic)[inv] if len(inv) else np.zeros((0, np.asarray(acoustic).shape[1]))
+        if len(tokens) > max_seq_length - 2:
+            tokens = tokens[: max_seq_length - 2]
+            acoustic = acoustic[: max_seq_length - 2]
+            visual = visual[: max_seq_length - 2]
+        if args.model == "bert-base-uncased":
+            prepare_input = prepare_bert_input
+        elif args.model == "xlnet-base-cased":
+            prepare_input = prepare_xlnet_input
+        input_ids, visual, acoustic, input_mask, segment_ids = prepare_input(tokens, visual, acoustic, tokenizer)
+        assert len(input_ids) == args.max_seq_length
+        assert len(input_mask) == args.max_seq_length
+        assert len(segment_ids) == args.max_seq_length
+        assert acoustic.shape[0] == args.max_seq_length
+        assert visual.shape[0] == args.max_seq_length
+        features.append(InputFeatures(input_ids=input_ids, input_mask=input_mask, segment_ids=segment_ids, visual=visual,
+                                      acoustic=acoustic, label_id=label_id))
+    return features
+
+
+def prepare_bert_input(tokens, visual, acoustic, tokenizer):
+    """multimodal_driver.py:143-173: [CLS] x [SEP] then right-pad; zero modality rows on special/pad slots."""
+    L = args.max_seq_length
+    A, V = acoustic.shape[1], visual.shape[1]
+    tokens = [tokenizer.cls_token] + tokens + [tokenizer.sep_token]
+    n = len(tokens)
+    aco = np.zeros((L, A)); aco[1:n - 1] = acoustic
+    vis = np.zeros((L, V)); vis[1:n - 1] = visual
+    input_ids = tokenizer.convert_tokens_to_ids(tokens) + [0] * (L - n)
+    input_mask = [1] * n + [0] * (L - n)
+    segment_ids = [0] * L
+    return input_ids, vis, aco, input_mask, segment_ids
+
+
+def prepare_xlnet_input(tokens, visual, acoustic, tokenizer):
+    """multimodal_driver.py:176-205: x [SEP] [CLS], LEFT-padded; segment ids 0.. / 2 for CLS / 3 for pad."""
+    L = args.max_seq_length
+    A, V = acoustic.shape[1], visual.shape[1]
+    tokens = tokens + [tokenizer.sep_token] + [tokenizer.cls_token]
+    n = len(tokens)
+    pad = L - n
+    aco = np.zeros((L, A)); aco[pad:pad + n - 2] = acoustic
+    vis = np.zeros((L, V)); vis[pad:pad + n - 2] = visual
+    input_ids = [tokenizer.pad_token_id] * pad + tokenizer.convert_tokens_to_ids(tokens)
+    input_mask = [0] * pad + [1] * n
+    segment_ids = [3] * pad + [0] * (n - 1) + [2]
+    return input_ids, vis, aco, input_mask, segment_ids
+
+
+def get_tokenizer(model):
+    """multimodal_driver.py:208-218.  Needs the vocab files in the local HF cache (no network)."""
+    try:
+        from transformers import BertTokenizer, XLNetTokenizer
+    except Exception as e:      # pragma: no cover
+        raise RuntimeError("transformers tokenizers unavailable: %s" % e)
+    if model == "bert-base-uncased":
+        return BertTokenizer.from_pretrained(model)
+    elif model == "xlnet-base-cased":
+        return XLNetTokenizer.from_pretrained(model)
+    raise ValueError("Expected 'bert-base-uncased' or 'xlnet-base-cased, but received {}".format(model))
+
+
+def features_to_dataset(features):
+    """multimodal_driver.py:226-246: six tensors, this order."""
+    all_input_ids = torch.tensor(np.array([f.input_ids for f in features]), dtype=torch.long)
+    all_input_mask = torch.tensor(np.array([f.input_mask for f in features]), dtype=torch.long)
+    all_segment_ids = torch.tensor(np.array([f.segment_ids for f in features]), dtype=torch.long)
+    all_visual = torch.tensor(np.array([f.visual for f in features]), dtype=torch.float)
+    all_acoustic = torch.tensor(np.array([f.acoustic for f in features]), dtype=torch.float)
+    all_label_ids = torch.tensor(np.array([f.label_id for f in features]), dtype=torch.float)
+    return TensorDataset(all_input_ids, all_visual, all_acoustic, all_input_mask, all_segment_ids, all_label_ids)
+
+
+def get_appropriate_dataset(data, tokenizer=None):
+    tokenizer = tokenizer or get_tokenizer(args.model)
+    return features_to_dataset(convert_to_features(data, args.max_seq_length, tokenizer))
+
+
+def synthetic_dataset(n, L, V, A, seed_=1234, vocab=30522):
+    """n samples in prepare_bert_input's layout: ids [101, tokens, 102, 0...], mask, seg 0,
+    modality rows N(0,1) on word rows and EXACT zeros on [CLS]/[SEP]/pad rows, labels U(-3, 3)."""
+    rs = np.random.RandomState(seed_)
+    lens = rs.randint(5, L - 2 + 1, size=n)
+    ids = np.zeros((n, L), np.int64)
+    mask = np.zeros((n, L), np.int64)
+    seg = np.zeros((n, L), np.int64)
+    vis = rs.randn(n, L, V).astype(np.float32)
+    aco = rs.randn(n, L, A).astype(np.float32)
+    tok = rs.randint(1000, vocab, size=(n, L))
+    pos = np.arange(L)[None, :]
+    word = (pos >= 1) & (pos <= lens[:, None])
+    ids[word] = tok[word]
+    ids[:, 0] = 101
+    ids[np.arange(n), lens + 1] = 102
+    mask[pos.repeat(n, 0) <= (lens[:, None] + 1)] = 1
+    vis[~word] = 0.0
+    aco[~word] = 0.0
+    label = rs.uniform(-3, 3, size=n).astype(np.float32)
+    t = torch.from_numpy
+    return TensorDataset(t(ids), t(vis), t(aco), t(mask), t(seg), t(label))
+
+
+def set_up_data_loader():
+    """multimodal_driver.py:249-286 (+ synthetic mode)."""
+    V, A = _dims()
+    if args.synthetic:
+        n = args.synthetic
+        train_dataset = synthetic_dataset(n, args.max_seq_length, V, A, 1234)
+        dev_dataset = synthetic_dataset(max(8, n // 6), args.max_seq_length, V, A, 1235)
+        test_dataset = synthetic_dataset(max(8, n // 2), args.max_seq_length, V, A, 1236)
+    else:
+        with open(f"datasets/{args.dataset}.pkl", "rb") as handle:
+            data = pickle.load(handle)
+        tok = get_tokenizer(args.model)
+        train_dataset = get_appropriate_dataset(data["train"], tok)
+        dev_dataset = get_appropriate_dataset(data["dev"], tok)
+        test_dataset = get_appropriate_dataset(data["test"], tok)
+    num_train_optimization_steps = (
+        int(len(train_dataset) / args.train_batch_size / args.gradient_accumulation_step) * args.n_epochs)
+    train_dataloader = DataLoader(train_dataset, batch_size=args.train_batch_size, shuffle=True)
+    dev_dataloader = DataLoader(dev_dataset, batch_size=args.dev_batch_size, shuffle=True)
+    test_dataloader = DataLoader(test_dataset, batch_size=args.test_batch_size, shuffle=True)
+    return train_dataloader, dev_dataloader, test_dataloader, num_train_optimization_steps
+
+
+def set_random_seed(seed: int):
+    """multimodal_driver.py:289-308."""
+    print("Seed: {}".format(seed))
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def optimizer_grouped_parameters(model, weight_decay=0.01):
+    """multimodal_driver.py:328-343."""
+    param_optimizer = list(model.named_parameters())
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    return [
+        {"params": [p for n, p in param_optimizer if not any(nd in n for nd in no_decay)], "weight_decay": weight_decay},
+        {"params": [p for n, p in param_optimizer if any(nd in n for nd in no_decay)], "weight_decay": 0.0},
+    ]
+
+
+def prep_for_training(num_train_optimization_steps: int):
+    """multimodal_driver.py:311-351."""
+    multimodal_config = MultimodalConfig(beta_shift=args.beta_shift, dropout_prob=args.dropout_prob)
+    V, A = _dims()
+    dt = torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32
+    if args.model == "bert-base-uncased":
+        if args.pretrained:
+            model = MAG_BertForSequenceClassification.from_pretrained(
+                args.pretrained, multimodal_config=multimodal_config, num_labels=1, visual_dim=V, acoustic_dim=A,
+                compute_dtype=dt)
+        else:       # offline: fresh init by the reference's init law
+            model = MAG_BertForSequenceClassification(BertConfig(num_labels=1), multimodal_config, visual_dim=V,
+                                                      acoustic_dim=A, compute_dtype=dt)
+    elif args.model == "xlnet-base-cased":
+        raise NotImplementedError("MAG-XLNet is the next row of the scope table (SURVEY.md section 8, config 4)")
+    model.to(_device())
+    optimizer = AdamW(optimizer_grouped_parameters(model), lr=args.learning_rate)
+    scheduler = get_linear_schedule_with_warmup(
+        optimizer, num_warmup_steps=args.warmup_proportion * num_train_optimization_steps,
+        num_training_steps=num_train_optimization_steps)
+    return model, optimizer, scheduler
+
+
+def _unpack(batch):
+    batch = tuple(t.to(_device(), non_blocking=True) for t in batch)
+    input_ids, visual, acoustic, input_mask, segment_ids, label_ids = batch
+    visual = torch.squeeze(visual, 1)
+    acoustic = torch.squeeze(acoustic, 1)
+    return input_ids, visual, acoustic, input_mask, segment_ids, label_ids
+
+
+def train_epoch(model: nn.Module, train_dataloader: DataLoader, optimizer, scheduler):
+    """multimodal_driver.py:354-388.  Returns the mean training loss of the epoch."""
+    model.train()
+    accum = args.gradient_accumulation_step
+    nb_tr_steps = 0
+    if args.reference_loop:
+        tr_loss = 0
+        for step, batch in enumerate(train_dataloader):
+            input_ids, visual, acoustic, input_mask, segment_ids, label_ids = _unpack(batch)
+            outputs = model(input_ids, visual, acoustic, token_type_ids=segment_ids, attention_mask=input_mask, labels=None)
+            logits = outputs[0]
+            loss = MSELoss()(logits.view(-1), label_ids.view(-1))
+            if accum > 1:
+                loss = loss / accum
+            loss.backward()
+            tr_loss += loss.item()
+            nb_tr_steps += 1
+            if (step + 1) % accum == 0:
+                optimizer.step()
+                scheduler.step()
+                optimizer.zero_grad()
+        return tr_loss / max(1, nb_tr_steps)
+    model.loss_running(reset=True)
+    for step, batch in enumerate(train_dataloader):
+        input_ids, visual, acoustic, input_mask, segment_ids, label_ids = _unpack(batch)
+        model.training_step(input_ids, visual, acoustic, input_mask, segment_ids, label_ids, loss_scale=1.0 / accum)
+        nb_tr_steps += 1
+        if (step + 1) % accum == 0:
+            optimizer.step()
+            scheduler.step()
+            optimizer.zero_grad()
+    total = float(model.loss_running(reset=True).item()) / accum      # the only host sync of the epoch
+    return total / max(1, nb_tr_steps)
+
+
+def eval_epoch(model: nn.Module, dev_dataloader: DataLoader, optimizer):
+    """multimodal_driver.py:391-421."""
+    model.eval()
+    dev_loss = torch.zeros((), device=_device())
+    nb_dev_steps = 0
+    with torch.no_grad():
+        for step, batch in enumerate(dev_dataloader):
+            input_ids, visual, acoustic, input_mask, segment_ids, label_ids = _unpack(batch)
+            outputs = model(input_ids, visual, acoustic, token_type_ids=segment_ids, attention_mask=input_mask, labels=None)
+            logits = outputs[0]
+            loss = MSELoss()(logits.view(-1), label_ids.view(-1))
+            if args.gradient_accumulation_step > 1:
+                loss = loss / args.gradient_accumulation_step
+            dev_loss += loss
+            nb_dev_steps += 1
+    return float(dev_loss.item()) / max(1, nb_dev_steps)
+
+
+def test_epoch(model: nn.Module, test_dataloader: DataLoader):
+    """multimodal_driver.py:424-459."""
+    model.eval()
+    preds, labels = [], []
+    with torch.no_grad():
+        for batch in test_dataloader:
+            input_ids, visual, acoustic, input_mask, segment_ids, label_ids = _unpack(batch)
+            outputs = model(input_ids, visual, acoustic, token_type_ids=segment_ids, attention_mask=input_mask, labels=None)
+            preds.append(outputs[0].detach().view(-1))
+            labels.append(label_ids.detach().view(-1))
+    preds = torch.cat(preds).cpu().numpy()
+    labels = torch.cat(labels).cpu().numpy()
+    return preds, labels
+
+
+def score_predictions(preds, y_test, use_zero=False):
+    """The metric block of test_score_model (multimodal_driver.py:465-480)."""
+    from sklearn.metrics import accuracy_score, f1_score
+    non_zeros = np.array([i for i, e in enumerate(y_test) if e != 0 or use_zero])
+    preds = preds[non_zeros]
+    y_test = y_test[non_zeros]
+    mae = np.mean(np.absolute(preds - y_test))
+    corr = np.corrcoef(preds, y_test)[0][1]
+    preds = preds >= 0
+    y_test = y_test >= 0
+    f_score = f1_score(y_test, preds, average="weighted")
+    acc = accuracy_score(y_test, preds)
+    return acc, mae, corr, f_score
+
+
+def test_score_model(model: nn.Module, test_dataloader: DataLoader, use_zero=False):
+    """multimodal_driver.py:462-480."""
+    preds, y_test = test_epoch(model, test_dataloader)
+    return score_predictions(preds, y_test, use_zero)
+
+
+def train(model, train_dataloader, validation_dataloader, test_data_loader, optimizer, scheduler):
+    """multimodal_driver.py:483-523 (wandb.log replaced by JSON lines on stdout)."""
+    import json
+    valid_losses, test_accuracies = [], []
+    for epoch_i in range(int(args.n_epochs)):
+        t0 = time.time()
+        train_loss = train_epoch(model, train_dataloader, optimizer, scheduler)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        valid_loss = eval_epoch(model, validation_dataloader, optimizer)
+        test_acc, test_mae, test_corr, test_f_score = test_score_model(model, test_data_loader)
+        print("epoch:{}, train_loss:{}, valid_loss:{}, test_acc:{}".format(epoch_i, train_loss, valid_loss, test_acc))
+        valid_losses.append(valid_loss)
+        test_accuracies.append(test_acc)
+        print(json.dumps({"train_loss": train_loss, "valid_loss": valid_loss, "test_acc": test_acc, "test_mae": test_mae,
+                          "test_corr": test_corr, "test_f_score": test_f_score, "best_valid_loss": min(valid_losses),
+                          "best_test_acc": max(test_accuracies),
+                          "train_samples_per_sec": len(train_dataloader.dataset) / dt}))
+
+
+def main(argv=None):
+    global args
+    args = parse_args(argv)
+    set_random_seed(args.seed)
+    train_data_loader, dev_data_loader, test_data_loader, num_train_optimization_steps = set_up_data_loader()
+    model, optimizer, scheduler = prep_for_training(num_train_optimization_steps)
+    train(model, train_data_loader, dev_data_loader, test_data_loader, optimizer, scheduler)
+
+
+if __name__ == "__main__":
+    main()

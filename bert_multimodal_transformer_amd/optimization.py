@@ -1,0 +1,129 @@
+"""AdamW + get_linear_schedule_with_warmup -- the transformers==3.0.2 API the reference imports
+(/root/reference/multimodal_driver.py:27-28, 345-350), running on the fused HIP kernel (csrc/adamw.hip).
+
+    optimizer = AdamW(optimizer_grouped_parameters, lr=args.learning_rate)
+    scheduler = get_linear_schedule_with_warmup(optimizer, num_warmup_steps=..., num_training_steps=...)
+
+Parameters that are views of a model's flat buffer (bert.py) are updated with ONE launch per param group over the
+contiguous flat range (m, v live in flat buffers too; the bf16 operand shadow is refreshed and the gradient cleared
+in the same pass); any other CUDA tensor gets one launch per tensor.  Formula: see oracle/optim_ref.py -- eps 1e-6
+outside the sqrt, bias correction folded into step_size, decoupled decay AFTER the update.
+"""
+import torch
+
+from . import _lib
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError("Invalid beta parameters: {}".format(betas))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias)
+        super().__init__(params, defaults)
+        self.grad_scale = 1.0          # data parallel: 1/world_size when gradients were SUM-reduced
+        self.fused_zero_grad = True    # clear gradients inside the update kernel (zero_grad() then costs nothing)
+        self._plan = None
+        self._t = 0
+
+    # -- planning: map groups onto contiguous flat ranges ------------------------------------------------
+    def _build_plan(self):
+        plan = []
+        for gi, group in enumerate(self.param_groups):
+            flat, loose = {}, []
+            for p in group["params"]:
+                info = getattr(p, "_mb_flat", None)
+                if info is None:
+                    loose.append(p)
+                else:
+                    core, off, numel, _ = info
+                    flat.setdefault(id(core), (core, []))[1].append((off, numel))
+            for core, spans in flat.values():
+                spans.sort()
+                merged = []
+                for off, numel in spans:
+                    end = (off + numel + 63) // 64 * 64          # tensors are 64-float aligned in the flat layout
+                    if merged and off <= merged[-1][1]:
+                        merged[-1][1] = max(merged[-1][1], end)
+                    else:
+                        merged.append([off, end])
+                if not hasattr(core, "_adam_m"):
+                    core._adam_m = torch.zeros_like(core.params)
+                    core._adam_v = torch.zeros_like(core.params)
+                for a, b in merged:
+                    plan.append(("flat", gi, core, a, min(b, core.n_params)))
+            for p in loose:
+                plan.append(("loose", gi, p))
+        self._plan = plan
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        if self._plan is None:
+            self._build_plan()
+        L = _lib.lib()
+        self._t += 1
+        for item in self._plan:
+            group = self.param_groups[item[1]]
+            b1, b2 = group["betas"]
+            if item[0] == "flat":
+                _, _, core, a, b = item
+                st = core.stream()
+                sh = core.shadow if core.dt == _lib.DT_BF16 else None
+                sb = min(max(core.sh_begin, a), b) - a
+                se = min(max(core.sh_end, a), b) - a
+                _lib.check(L.mb_adamw_step(
+                    core.params.data_ptr() + 4 * a, core.grads.data_ptr() + 4 * a, core._adam_m.data_ptr() + 4 * a,
+                    core._adam_v.data_ptr() + 4 * a, (sh.data_ptr() + 2 * a) if sh is not None else None, b - a,
+                    (b - a) if group["weight_decay"] > 0.0 else 0, sb, se, group["lr"], b1, b2, group["eps"],
+                    group["weight_decay"], self._t, 1 if group["correct_bias"] else 0, self.grad_scale,
+                    1 if self.fused_zero_grad else 0, st))
+            else:
+                p = item[2]
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise _lib.MagbertError("AdamW runs on the HIP kernel only: fp32 contiguous ROCm tensors required")
+                state = self.state[p]
+                if len(state) == 0:
+                    state["exp_avg"] = torch.zeros_like(p)
+                    state["exp_avg_sq"] = torch.zeros_like(p)
+                g = p.grad.contiguous()
+                n = p.numel()
+                _lib.check(L.mb_adamw_step(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(),
+                                           state["exp_avg_sq"].data_ptr(), None, n, n if group["weight_decay"] > 0.0 else 0,
+                                           0, 0, group["lr"], b1, b2, group["eps"], group["weight_decay"], self._t,
+                                           1 if group["correct_bias"] else 0, self.grad_scale, 0,
+                                           torch.cuda.current_stream(p.device).cuda_stream))
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        if self._plan is None:
+            self._build_plan()
+        done = set()
+        for item in self._plan:
+            if item[0] == "flat":
+                core = item[2]
+                if not self.fused_zero_grad and id(core) not in done:
+                    core.grads.zero_()
+                    done.add(id(core))
+            else:
+                p = item[2]
+                if p.grad is not None:
+                    p.grad.zero_()
+
+
+def linear_schedule_lambda(current_step, num_warmup_steps, num_training_steps):
+    """lr multiplier of transformers 3.0.2 get_linear_schedule_with_warmup (num_warmup_steps may be a float:
+    multimodal_driver.py:348 passes warmup_proportion * num_train_optimization_steps)."""
+    if current_step < num_warmup_steps:
+        return float(current_step) / float(max(1, num_warmup_steps))
+    return max(0.0, float(num_training_steps - current_step) / float(max(1, num_training_steps - num_warmup_steps)))
+
+
+def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, last_epoch=-1):
+    return torch.optim.lr_scheduler.LambdaLR(
+        optimizer, lambda s: linear_schedule_lambda(s, num_warmup_steps, num_training_steps), last_epoch)

@@ -1,0 +1,145 @@
+/* magbert_hip.h -- C ABI of libmagbert_hip.so: the MI355X (gfx950) MAG-BERT training hot path.
+ *
+ * Drop-in boundary.  The reference (WasifurRahman/BERT_multimodal_transformer) is pure Python: its "FFI" for this
+ * path is torch.nn.Module.forward / autograd / optimizer.step.  This library is what sits under those surfaces
+ * (INTEGRATION.md shows the ctypes binding a maintainer adds to bert.py / modeling.py / multimodal_driver.py).
+ * Every entry point is extern "C", takes plain device pointers + sizes and a hipStream_t (as void*), allocates
+ * nothing on the device, never synchronises, and returns 0 on success or a non-zero code (mb_error_string()).
+ * Device memory, streams and torch.distributed stay with the caller (PyTorch-ROCm is plumbing only).
+ *
+ * dtype: 0 = fp32 "parity mode" (exact-fp32 MFMA, logits within 1e-3 of the CPU reference),
+ *        1 = bf16 "perf mode" (bf16 activations / MFMA operands, fp32 accumulate, fp32 master weights).
+ * All row-major.  T = B*L tokens, H = 768, heads of 64.  Reference citations are relative to /root/reference.
+ */
+#ifndef MAGBERT_HIP_H
+#define MAGBERT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MB_DT_F32 0
+#define MB_DT_BF16 1
+
+/* dropout site key: mask(idx) = hash32(idx, k0, k1) < thresh ? drop : keep*scale.  thresh = 0 disables. */
+typedef struct { uint32_t k0, k1, thresh; float scale; } mb_dropkey;
+
+const char* mb_error_string(int code);
+int mb_version(void);
+/* fills the key for (seed, step, site) and probability p; p = 0 -> disabled */
+void mb_make_dropkey(uint64_t seed, uint64_t step, uint32_t site, float p, mb_dropkey* out);
+
+/* ------------------------------------------------------------------------------------------------ operators */
+
+/* C[M,N] = sum_k A(m,k) B(n,k) with fused epilogue.  Replaces torch.nn.Linear forward/backward (addmm / mm)
+ * under BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput (transformers 3.0.2, reached from
+ * bert.py:221-229) and MAG's Linears (modeling.py:15-19).
+ * layout 0 (NT): A[M][K], B[N][K]          forward  Y = X W^T
+ * layout 1 (NN): A[M][K], B[K][N]          dgrad    dX = dY W
+ * layout 2 (TN): A[K][M], B[K][N]          wgrad    dW += dY^T X   (fp32 accumulate, split-K)
+ * epilogue: 0 C=alpha*acc+bias | 1 C=acc+bias, C2=gelu(C) | 2 C=dropout(acc+bias)+R | 3 C=acc+R | 4 C=acc*gelu'(R)
+ *           5 Cf+=acc (fp32) | 6 Cf=alpha*acc+bias (fp32)                                                        */
+int mb_gemm(int dtype, int layout, int epilogue, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+            void* C, int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, float alpha,
+            const mb_dropkey* drop, int splits, int tile, void* stream);
+
+/* LayerNorm (+ dropout on the output) forward / backward -- torch.nn.LayerNorm under BertSelfOutput/BertOutput. */
+int mb_layernorm_forward(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,
+                         float* mean, float* rstd, int rows, int H, const mb_dropkey* drop, void* stream);
+int mb_layernorm_backward(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                          const float* rstd, void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias,
+                          int rows, int H, const mb_dropkey* drop_out, const mb_dropkey* drop_in, void* stream);
+
+/* BertEmbeddings (bert.py:81,211-216): LN(word[ids] + pos[0..L) + type[seg]) -> dropout. ids/seg int64 [B][L]. */
+int mb_embed_forward(int dtype, const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
+                     const float* type, const float* gamma, const float* beta, float eps, void* out, float* mean,
+                     float* rstd, int B, int L, int H, const mb_dropkey* drop, void* stream);
+int mb_embed_backward(int dtype, const void* dout, const int64_t* ids, const int64_t* seg, const float* word,
+                      const float* pos, const float* type, const float* gamma, const float* mean, const float* rstd,
+                      float* dsum_ws, float* dword, float* dpos, float* dtype_, float* dgamma, float* dbeta, int B, int L,
+                      int H, int pad_id, const mb_dropkey* drop, void* stream);
+
+/* BertSelfAttention core (bert.py:221-229): ctx = dropout(softmax(QK^T/8 + (1-mask)*-1e4)) V.
+ * qkv [T][3H] token-major, mask int64 [B][L], ctx/dctx [T][H], dqkv [T][3H].  L <= 128, head dim 64. */
+int mb_attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx, int B, int L, int nh,
+                         const mb_dropkey* drop, void* stream);
+int mb_attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L,
+                          int nh, const mb_dropkey* drop, void* stream);
+
+/* Multimodal Adaptation Gate, MAG.forward (modeling.py:25-51) and its adjoint, for T tokens.
+ * Parameters in the REFERENCE layout: W_hv [H][V+H], W_ha [H][A+H], W_v [H][V], W_a [H][A], biases [H], LayerNorm [H].
+ * text [T][H] in `dtype`; visual [T][V], acoustic [T][A] fp32 (as the DataLoader yields them).
+ * ws: caller scratch of mb_mag_workspace_bytes(); it also carries the activations saved for the backward. */
+size_t mb_mag_workspace_bytes(int dtype, int T, int H, int V, int A);
+int mb_mag_forward(int dtype, const void* text, const float* visual, const float* acoustic, const float* W_hv,
+                   const float* b_hv, const float* W_ha, const float* b_ha, const float* W_v, const float* b_v,
+                   const float* W_a, const float* b_a, const float* ln_w, const float* ln_b, float beta_shift,
+                   const mb_dropkey* drop, void* out, void* ws, int T, int H, int V, int A, void* stream);
+/* grads are ACCUMULATED (+=) into dW_*, db_*, dln_*; d_text [T][H] (dtype) is written; d_visual / d_acoustic
+ * (fp32 [T][V] / [T][A], may be NULL) are written. */
+int mb_mag_backward(int dtype, const void* d_out, const void* text, const float* W_hv, const float* b_hv,
+                    const float* W_ha, const float* b_ha, const float* W_v, const float* b_v, const float* W_a,
+                    const float* b_a, const float* ln_w, float beta_shift, const mb_dropkey* drop, void* ws,
+                    void* d_text, float* d_visual, float* d_acoustic, float* dW_hv, float* db_hv, float* dW_ha,
+                    float* db_ha, float* dW_v, float* db_v, float* dW_a, float* db_a, float* dln_w, float* dln_b,
+                    int T, int H, int V, int A, void* stream);
+
+/* transformers 3.0.2 AdamW.step over flat fp32 buffers (multimodal_driver.py:345,384). [0,n_decay) decays.
+ * shadow: optional bf16 copy of p written for [sh_begin, sh_end).  zero_grad != 0 clears g (optimizer.zero_grad). */
+int mb_adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, size_t n_decay, size_t sh_begin,
+                  size_t sh_end, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  int correct_bias, float grad_scale, int zero_grad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ MAG-BERT engine
+ * The whole MAG_BertForSequenceClassification forward / backward (bert.py:240-324 -> :76-237 -> modeling.py) as a
+ * native step executor: one call enqueues every kernel of the pass on the stream (no Python between launches).   */
+typedef struct {
+    int vocab_size, hidden_size, num_layers, num_heads, intermediate_size, max_position, type_vocab, num_labels;
+    int visual_dim, acoustic_dim, pad_token_id;
+    float layer_norm_eps, mag_layer_norm_eps, beta_shift;
+    float hidden_dropout, attn_dropout, mag_dropout;
+    int dtype;       /* MB_DT_* */
+    int max_batch, max_seq;
+} mb_bert_config;
+
+typedef struct mb_bert_engine mb_bert_engine;
+
+int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out);
+void mb_bert_destroy(mb_bert_engine* e);
+/* flat parameter layout (reference state-dict names).  decay != 0 -> weight_decay group of multimodal_driver.py:329-343 */
+int mb_bert_num_tensors(const mb_bert_engine* e);
+int mb_bert_tensor_info(const mb_bert_engine* e, int i, char* name, int name_cap, size_t* offset, size_t* numel,
+                        int* ndim, int64_t* shape4, int* decay);
+size_t mb_bert_param_count(const mb_bert_engine* e);   /* padded flat length (floats) */
+size_t mb_bert_decay_count(const mb_bert_engine* e);   /* elements [0, n) are the weight-decay group */
+void mb_bert_shadow_range(const mb_bert_engine* e, size_t* begin, size_t* end);   /* bf16 operand shadow range */
+size_t mb_bert_workspace_bytes(const mb_bert_engine* e);
+/* params / grads: flat fp32 [param_count]; shadow: bf16 [param_count] (dtype bf16) or NULL; ws: workspace. */
+int mb_bert_bind(mb_bert_engine* e, float* params, float* grads, void* shadow, void* workspace, size_t ws_bytes);
+/* refresh operand copies from the fp32 masters (bf16 shadow + packed MAG weights); call after loading weights. */
+int mb_bert_sync_weights(mb_bert_engine* e, void* stream);
+
+/* forward.  labels (fp32 [B*num_labels]) optional: fused MSE -> loss[0] (device, overwritten), loss_run += (optional).
+ * training != 0 enables dropout keyed by (seed, step).  logits: fp32 [B][num_labels] (device, written). */
+int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                    const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                    int training, uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run,
+                    void* stream);
+/* backward of the last forward.  dlogits fp32 [B][num_labels], or NULL to use the fused MSE gradient
+ * 2*(logit-label)/(B*num_labels)*loss_scale.  Gradients are ACCUMULATED into the bound flat grad buffer.
+ * stage_begin/stage_end select a sub-range of [0, num_layers+2): 0 = head+pooler, 1..num_layers = encoder layers
+ * (last layer first), num_layers+1 = MAG + embeddings -- lets the caller interleave gradient all-reduces. */
+int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* labels, float loss_scale, int stage_begin,
+                     int stage_end, void* stream);
+/* activations for API parity (device pointers into the workspace, valid until the next forward) */
+const void* mb_bert_sequence_output(const mb_bert_engine* e);   /* [B*L][H] in dtype */
+const float* mb_bert_pooled_output(const mb_bert_engine* e);    /* [B][H] fp32 (pre-dropout) */
+/* gradient buckets for data parallelism: range r of stage s covers flat elements [off, off+len) */
+int mb_bert_stage_grad_ranges(const mb_bert_engine* e, int stage, size_t* offs, size_t* lens, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
