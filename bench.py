@@ -1,0 +1,261 @@
+#!/usr/bin/env python
+"""bench.py -- train samples/sec of MAG-BERT fine-tuning (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one full optimizer step of /root/reference/multimodal_driver.py:354-388 on one minibatch per GPU:
+H2D of the six batch tensors -> forward (embeddings, MAG, 12 encoder layers, pooler, classifier) -> MSE -> backward ->
+(N>1: RCCL all-reduce of the flat gradients, overlapped with the backward) -> HF-AdamW -> linear-warmup schedule ->
+zero_grad.  Workload = BASELINE.json configs[1]: bert-base-uncased MAG-BERT, MOSI dims (V=47, A=74), B=48/GPU, L=50,
+bf16 MFMA with fp32 master weights, dropout ON (0.1/0.1/MAG 0.5), synthetic batches in prepare_bert_input's layout,
+random-init weights (no network).  Weak scaling: per-GPU batch fixed, global batch = 48*N.
+
+Prints ONE JSON line (rank 0) with the contract's keys plus
+  roofline     : the dominant kernel (MFMA GEMM) timed with HIP events on the launch stream
+  cpu_baseline : the CPU oracle (oracle/mag_bert_ref.py, kind "port") timed on this box's host cores, same step
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md); fp32 MFMA 157.3
+PEAK_F32_TFLOPS = 157.3
+# algorithmic FLOPs: forward 8.7234 GFLOP/sample at L=50, V=47; training = 3x
+TRAIN_GFLOP_PER_SAMPLE_L50 = 26.170
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=40)
+    p.add_argument("--warmup", type=int, default=8)
+    p.add_argument("--batch", type=int, default=48)
+    p.add_argument("--seq", type=int, default=50)
+    p.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    p.add_argument("--dataset", choices=["mosi", "mosei"], default="mosi")
+    p.add_argument("--cpu-baseline", type=int, default=1)
+    p.add_argument("--cpu-steps", type=int, default=2)
+    p.add_argument("--roofline", type=int, default=1)
+    p.add_argument("--roofline-only", type=int, default=0, help="skip the training loop, print the GEMM table only")
+    return p.parse_args()
+
+
+def make_batches(n, B, L, V, A, seed):
+    from bert_multimodal_transformer_amd.multimodal_driver import synthetic_dataset
+    ds = synthetic_dataset(n * B, L, V, A, seed_=seed)
+    out = []
+    for i in range(n):
+        out.append(tuple(t[i * B:(i + 1) * B].contiguous().pin_memory() for t in ds.tensors))
+    return out
+
+
+def cpu_baseline(B, L, V, A, steps):
+    """The same optimizer step on the host cores with the CPU oracle (pure torch restatement of the reference)."""
+    from oracle import mag_bert_ref as R, optim_ref as O
+    from bert_multimodal_transformer_amd.multimodal_driver import synthetic_dataset
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or cores
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = R.MAG_BertForSequenceClassification(R.BertConfigLite(), R.MultimodalConfig(1.0, 0.5), V, A).train()
+    opt = O.AdamW(O.grouped_parameters(model), lr=1e-5)
+    sch = O.get_linear_schedule_with_warmup(opt, 0.1 * 1040, 1040)
+    ds = synthetic_dataset(B * (steps + 1), L, V, A, seed_=7)
+    times = []
+    for s in range(steps + 1):
+        ids, vis, aco, mask, seg, lab = (t[s * B:(s + 1) * B] for t in ds.tensors)
+        t0 = time.perf_counter()
+        logits = model(ids, vis, aco, mask, seg)[0]
+        loss = torch.nn.functional.mse_loss(logits.view(-1), lab.view(-1))
+        loss.backward()
+        float(loss.item())
+        opt.step(); sch.step(); opt.zero_grad()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:])) if steps > 0 else float("nan")
+    return {"value": B / t, "unit": "samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "%d timed optimizer steps (1 warmup) of the same B=%d L=%d MAG-BERT step, fp32, dropout on, "
+                      "oracle/mag_bert_ref.py + HF-AdamW, median step %.2f s" % (steps, B, L, t)}
+
+
+def gemm_roofline(dtype_name, T, reps=30):
+    """Time the encoder's GEMM launches through the C ABI with HIP events on the launch stream.  Returns the list of
+    (name, shape, avg us, TFLOP/s) and the entry for the dominant kernel (largest share of a training step)."""
+    import ctypes as C
+    from bert_multimodal_transformer_amd import _lib
+    L = _lib.lib()
+    dt = _lib.DT_BF16 if dtype_name == "bf16" else _lib.DT_F32
+    tdt = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    dev = torch.device("cuda", torch.cuda.current_device())
+    H, I = 768, 3072
+    T = (T + 63) // 64 * 64        # the engine zero-pads the token dimension to the GEMM k-tile
+    st = torch.cuda.current_stream()
+    g = lambda *s: (torch.randn(*s, device=dev) * 0.05).to(tdt)
+    x, xi, w_qkv, w_o, w1, w2 = g(T, H), g(T, I), g(3 * H, H), g(H, H), g(I, H), g(H, I)
+    dqkv = g(T, 3 * H)
+    bias = torch.zeros(3 * I, device=dev)
+    out = torch.empty(T, I, dtype=tdt, device=dev); out2 = torch.empty(T, I, dtype=tdt, device=dev)
+    outf = torch.zeros(I, I, dtype=torch.float32, device=dev)
+    key = _lib.make_dropkey(1, 1, 17, 0.1)
+    NT, NN, TN = _lib.GEMM_NT, _lib.GEMM_NN, _lib.GEMM_TN
+    # (name, count per layer per step, layout, epilogue, M, N, K, A, lda, B, ldb, R, splits)
+    cases = [
+        ("fwd qkv   [T,768]x[2304,768]^T +bias", 1, NT, _lib.EPI_BIAS, T, 3 * H, H, x, H, w_qkv, H, None, 1),
+        ("fwd out   [T,768]x[768,768]^T +bias+drop+res", 1, NT, _lib.EPI_BIAS_DROP_RES, T, H, H, x, H, w_o, H, x, 1),
+        ("fwd ffn1  [T,768]x[3072,768]^T +bias+gelu", 1, NT, _lib.EPI_BIAS_GELU, T, I, H, x, H, w1, H, None, 1),
+        ("fwd ffn2  [T,3072]x[768,3072]^T +bias+drop+res", 1, NT, _lib.EPI_BIAS_DROP_RES, T, H, I, xi, I, w2, I, x, 1),
+        ("dgrad ffn2 [T,768]x[768,3072] *gelu'", 1, NN, _lib.EPI_DGELU, T, I, H, x, H, w2, I, xi, 1),
+        ("dgrad ffn1 [T,3072]x[3072,768] +res", 1, NN, _lib.EPI_ADD_RES, T, H, I, xi, I, w1, H, x, 1),
+        ("dgrad out  [T,768]x[768,768]", 1, NN, _lib.EPI_ADD_RES, T, H, H, x, H, w_o, H, None, 1),
+        ("dgrad qkv  [T,2304]x[2304,768] +res", 1, NN, _lib.EPI_ADD_RES, T, H, 3 * H, dqkv, 3 * H, w_qkv, H, x, 1),
+        ("wgrad ffn2 [768,T]x[T,3072]", 1, TN, _lib.EPI_ACCUM_F32, H, I, T, x, H, xi, I, None, 1),
+        ("wgrad ffn1 [3072,T]x[T,768]", 1, TN, _lib.EPI_ACCUM_F32, I, H, T, xi, I, x, H, None, 1),
+        ("wgrad out  [768,T]x[T,768]", 1, TN, _lib.EPI_ACCUM_F32, H, H, T, x, H, x, H, None, 1),
+        ("wgrad qkv  [2304,T]x[T,768]", 1, TN, _lib.EPI_ACCUM_F32, 3 * H, H, T, dqkv, 3 * H, x, H, None, 1),
+    ]
+    res = []
+    for name, cnt, layout, epi, M, N, K, A, lda, Bm, ldb, R, splits in cases:
+        def launch():
+            _lib.check(L.mb_gemm(dt, layout, epi, M, N, K, _lib.ptr(A), lda, _lib.ptr(Bm), ldb, _lib.ptr(out), N,
+                                 _lib.ptr(out2), _lib.ptr(outf), _lib.ptr(bias), _lib.ptr(R), N, 1.0, C.byref(key), splits, 0,
+                                 st.cuda_stream))
+        for _ in range(3):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            launch()
+        e1.record(st)
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        fl = 2.0 * M * N * K
+        res.append({"kernel": name, "M": M, "N": N, "K": K, "avg_us": round(us, 2), "tflops": round(fl / us * 1e-6, 1),
+                    "flop": fl})
+    return res
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if a.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d (using WORLD_SIZE)" % (a.gpus, world), file=sys.stderr)
+
+    if a.roofline_only:
+        rl = gemm_roofline(a.dtype, a.batch * a.seq)
+        for r in rl:
+            print("%-52s %8.2f us %8.1f TF/s" % (r["kernel"], r["avg_us"], r["tflops"]))
+        print("per-layer GEMM time %.1f us" % sum(r["avg_us"] for r in rl))
+        return
+    from bert_multimodal_transformer_amd import (AdamW, BertConfig, MAG_BertForSequenceClassification, MultimodalConfig,
+                                                 get_linear_schedule_with_warmup)
+    from bert_multimodal_transformer_amd.distributed import DataParallel
+    from bert_multimodal_transformer_amd.global_configs import DATASET_DIMS
+    from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
+
+    V, A = DATASET_DIMS[a.dataset]["visual_dim"], DATASET_DIMS[a.dataset]["acoustic_dim"]
+    B, L = a.batch, a.seq
+    torch.manual_seed(1234)        # same init on every rank (then broadcast anyway)
+    cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    model = MAG_BertForSequenceClassification(BertConfig(num_labels=1), MultimodalConfig(1.0, 0.5), visual_dim=V,
+                                              acoustic_dim=A, compute_dtype=cdt)
+    opt = AdamW(optimizer_grouped_parameters(model), lr=1e-5)
+    total_steps = a.steps + a.warmup
+    sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=0.1 * 1040, num_training_steps=1040)
+    dp = None
+    if world > 1:
+        dp = DataParallel(model, opt)
+        dp.broadcast_parameters(0)
+    model.train()
+    nb = 8
+    batches = make_batches(nb, B, L, V, A, seed=1234 + rank)
+    dev = torch.device("cuda", local)
+
+    def step(i):
+        batch = tuple(t.to(dev, non_blocking=True) for t in batches[i % nb])          # H2D (multimodal_driver.py:359)
+        ids, vis, aco, mask, seg, lab = batch
+        model.training_step(ids, vis, aco, mask, seg, lab)
+        opt.step(); sch.step(); opt.zero_grad()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = float(model.loss_running().item()) / max(1, total_steps)
+    value = world * B * a.steps / dt
+
+    out = None
+    if rank == 0:
+        gflop = TRAIN_GFLOP_PER_SAMPLE_L50 if (L == 50 and V == 47) else None
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        out = {"metric": "train samples/sec MAG-BERT MOSI seq_len=%d" % L, "value": round(value, 2), "unit": "samples/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": "MAG-BERT bert-base-uncased, %s dims (V=%d, A=%d), batch %d/GPU, seq_len %d, full "
+                                      "optimizer step (H2D+fwd+MSE+bwd%s+HF-AdamW+schedule), dropout on, random-init weights"
+                                      % (a.dataset.upper(), V, A, B, L, "+RCCL all-reduce" if world > 1 else ""),
+                          "global_batch": world * B, "seq_len": L, "parallelism": "dp%d" % world},
+               "mean_loss": round(loss, 4)}
+        if gflop:
+            out["step_tflops_algorithmic"] = round(value * gflop * 1e-3, 1)
+            out["step_mfma_frac"] = round(value * gflop * 1e-3 * 0.984 / (peak * world), 4)
+    if a.roofline and rank == 0:
+        rl = gemm_roofline(a.dtype, B * L)
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        # dominant kernel = the GEMM with the largest time per training step (each runs once per layer per step)
+        dom = max(rl, key=lambda r: r["avg_us"])
+        out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak,
+                           "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": None,
+                           "avg_us": dom["avg_us"], "flop_per_launch": dom["flop"]}
+        tot_us = sum(r["avg_us"] for r in rl)
+        tot_fl = sum(r["flop"] for r in rl)
+        out["roofline_gemms"] = {"per_layer_us": round(tot_us, 1), "aggregate_tflops": round(tot_fl / tot_us * 1e-6, 1),
+                                 "frac": round(tot_fl / tot_us * 1e-6 / peak, 4),
+                                 "kernels": [{k: r[k] for k in ("kernel", "avg_us", "tflops")} for r in rl]}
+    if a.cpu_baseline and rank == 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(B, L, V, A, a.cpu_steps)
+        out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,8 +75,9 @@ struct MagWs {
     size_t We, Wv, Wa, vp, ap, Ze, Zv, Za, mean, rstd;                       // forward (saved)
     size_t dZe, dZv, dZa, dep, dWe, dWv, dWa, dvp, dap;                      // backward scratch
     size_t bytes;
-    void init(int dtype, int T, int H, int V, int A) {
+    void init(int dtype, int T_, int H, int V, int A) {
         const size_t es = esize(dtype);
+        const size_t T = align_up((size_t)T_, 64);   // token rows padded to the GEMM k-tile (pad rows stay zero)
         Vp = (V + 63) / 64 * 64;
         Ap = (A + 63) / 64 * 64;
         Carver c;
@@ -109,12 +110,16 @@ int wgrad(int dtype, int Mo, int No, int rows, const void* dY, int ldy, const vo
           hipStream_t st) {
     const long t128 = (long)((Mo + 127) / 128) * ((No + 127) / 128);
     const long t64 = (long)((Mo + 63) / 64) * ((No + 63) / 64);
+    // split-K costs one fp32 atomic per output element per split (measured: 4.7 M atomics ~ 50 us), so it is used only
+    // when the tile grid alone cannot occupy the chip
     int tile, splits;
-    if (t128 >= 128) { tile = 128; splits = (int)((320 + t128 / 2) / t128); }
-    else { tile = 64; splits = (int)((384 + t64 - 1) / t64); }
+    if (t128 >= 100) { tile = 128; splits = 1; }
+    else if (t64 >= 100) { tile = 64; splits = 1; }
+    else { tile = 64; splits = (int)((256 + t64 - 1) / t64); }
     if (splits > 8) splits = 8;
     while (splits > 1 && rows / splits < 128) --splits;
     if (splits < 1) splits = 1;
+    (void)t128;
     return gemm(dtype, GEMM_TN, EPI_ACCUM_F32, Mo, No, rows, dY, ldy, X, ldx, nullptr, ldw, nullptr, dW, nullptr, nullptr, 0,
                 kNoDrop, splits, tile, st);
 }
@@ -128,6 +133,14 @@ int mag_fwd_impl(int dtype, const void* text, const float* visual, const float* 
     if (repack) CK(mag_pack_weights(dtype, W_hv, W_ha, W_v, W_a, ws + w.We, ws + w.Wv, ws + w.Wa, d, st));
     CK(pack_pad(dtype, visual, V, ws + w.vp, w.Vp, T, st));
     CK(pack_pad(dtype, acoustic, A, ws + w.ap, w.Ap, T, st));
+    {
+        const int Tp = (int)align_up((size_t)T, 64);
+        const size_t es = esize(dtype);
+        if (Tp > T) {
+            CK((int)hipMemsetAsync(ws + w.vp + (size_t)T * w.Vp * es, 0, (size_t)(Tp - T) * w.Vp * es, st));
+            CK((int)hipMemsetAsync(ws + w.ap + (size_t)T * w.Ap * es, 0, (size_t)(Tp - T) * w.Ap * es, st));
+        }
+    }
     CK(gemm(dtype, GEMM_NT, EPI_BIAS, T, 2 * H, H, text, H, ws + w.We, H, ws + w.Ze, 2 * H, nullptr, nullptr, nullptr,
             nullptr, 0, kNoDrop, 1, 0, st));
     CK(gemm(dtype, GEMM_NT, EPI_BIAS, T, 2 * H, w.Vp, ws + w.vp, w.Vp, ws + w.Wv, w.Vp, ws + w.Zv, 2 * H, nullptr, nullptr,
@@ -143,8 +156,15 @@ int mag_bwd_impl(int dtype, const void* d_out, const void* text, const float* b_
                  const float* b_a, const float* ln_w, float beta_shift, DropKey drop, char* ws, const MagWs& w, void* d_text,
                  float* d_visual, float* d_acoustic, float* dW_hv, float* db_hv, float* dW_ha, float* db_ha, float* dW_v,
                  float* db_v, float* dW_a, float* db_a, float* dln_w, float* dln_b, int T, int H, int V, int A,
-                 hipStream_t st) {
+                 bool text_padded, hipStream_t st) {
     MagDims d = {T, H, V, A, w.Vp, w.Ap};
+    const int Tp = (int)align_up((size_t)T, 64);      // zero-padded token rows of the workspace operands
+    const size_t es = esize(dtype);
+    if (Tp > T) {                                     // keep the pad rows of this call's k-major operands zero
+        CK((int)hipMemsetAsync(ws + w.dZe + (size_t)T * 2 * H * es, 0, (size_t)(Tp - T) * 2 * H * es, st));
+        CK((int)hipMemsetAsync(ws + w.dZv + (size_t)T * 2 * H * es, 0, (size_t)(Tp - T) * 2 * H * es, st));
+        CK((int)hipMemsetAsync(ws + w.dZa + (size_t)T * 2 * H * es, 0, (size_t)(Tp - T) * 2 * H * es, st));
+    }
     CK(mag_gate_backward(dtype, d_out, text, ws + w.Ze, ws + w.Zv, ws + w.Za, b_hv, b_ha, b_v, b_a, ln_w,
                          (const float*)(ws + w.mean), (const float*)(ws + w.rstd), beta_shift, ws + w.dep, ws + w.dZe,
                          ws + w.dZv, ws + w.dZa, db_hv, db_ha, db_v, db_a, dln_w, dln_b, d, drop, st));
@@ -152,9 +172,9 @@ int mag_bwd_impl(int dtype, const void* d_out, const void* text, const float* b_
     CK((int)hipMemsetAsync(ws + w.dWe, 0, (size_t)2 * H * H * 4, st));
     CK((int)hipMemsetAsync(ws + w.dWv, 0, (size_t)2 * H * w.Vp * 4, st));
     CK((int)hipMemsetAsync(ws + w.dWa, 0, (size_t)2 * H * w.Ap * 4, st));
-    CK(wgrad(dtype, 2 * H, H, T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H, st));
-    CK(wgrad(dtype, 2 * H, w.Vp, T, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp, st));
-    CK(wgrad(dtype, 2 * H, w.Ap, T, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap, st));
+    CK(wgrad(dtype, 2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H, st));
+    CK(wgrad(dtype, 2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp, st));
+    CK(wgrad(dtype, 2 * H, w.Ap, Tp, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap, st));
     CK(mag_unpack_wgrads((const float*)(ws + w.dWe), (const float*)(ws + w.dWv), (const float*)(ws + w.dWa), dW_hv, dW_ha,
                          dW_v, dW_a, d, st));
     // d_text = dZe . We + (ds + d||e|| term)
@@ -201,6 +221,8 @@ struct mb_bert_engine {
     // state of the last forward
     const int64_t* ids = nullptr; const int64_t* seg = nullptr; const int64_t* mask = nullptr;
     int B = 0, L = 0, training = 0;
+    int padT = -1;                 // token count whose pad rows [T, Tp) are currently known to be zero
+    bool ws_zeroed = false;
     uint64_t seed = 0, step = 0;
     float* logits = nullptr;
 
@@ -275,7 +297,7 @@ static void build_layout(mb_bert_engine* e) {
 
     // ---- workspace
     const size_t es = esize(c.dtype);
-    const size_t T = (size_t)c.max_batch * c.max_seq;
+    const size_t T = align_up((size_t)c.max_batch * c.max_seq, 64);   // token rows padded to the GEMM k-tile
     Carver w;
     e->mw.init(c.dtype, (int)T, (int)H, (int)V, (int)A);
     e->ws_mag = w.take(e->mw.bytes);
@@ -386,7 +408,7 @@ int mb_mag_backward(int dtype, const void* d_out, const void* text, const float*
     w.init(dtype, T, H, V, A);
     return mag_bwd_impl(dtype, d_out, text, b_hv, b_ha, b_v, b_a, ln_w, beta_shift, dk(drop), (char*)ws, w, d_text,
                         d_visual, d_acoustic, dW_hv, db_hv, dW_ha, db_ha, dW_v, db_v, dW_a, db_a, dln_w, dln_b, T, H, V, A,
-                        (hipStream_t)stream);
+                        false, (hipStream_t)stream);
 }
 
 int mb_adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, size_t n_decay, size_t sh_begin,
@@ -436,6 +458,7 @@ int mb_bert_bind(mb_bert_engine* e, float* params, float* grads, void* shadow, v
     if (!params || !workspace || ws_bytes < e->ws_bytes) return MB_ERR_ARG;
     if (e->c.dtype == DT_BF16 && !shadow) return MB_ERR_ARG;
     e->P = params; e->G = grads; e->SH = (char*)shadow; e->ws = (char*)workspace;
+    e->ws_zeroed = false; e->padT = -1;
     return MB_OK;
 }
 
@@ -465,6 +488,20 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     e->B = B; e->L = L; e->training = training; e->seed = seed; e->step = step; e->logits = logits;
     float* P = e->P;
     char* ws = e->ws;
+    const int Tp = (int)align_up((size_t)T, 64);
+    if (!e->ws_zeroed) { CK((int)hipMemsetAsync(ws, 0, e->ws_bytes, st)); e->ws_zeroed = true; e->padT = T; }
+    if (e->padT != T && Tp > T) {
+        // a different batch shape ran before: rows [T, Tp) of every buffer that feeds a wgrad as the k-major operand
+        // may hold stale tokens -> clear them (kernels never write rows >= T)
+        const size_t es = esize(dt);
+        auto zp = [&](size_t off, size_t cols) {
+            return (int)hipMemsetAsync(ws + off + (size_t)T * cols * es, 0, (size_t)(Tp - T) * cols * es, st);
+        };
+        CK(zp(e->ws_emb, H)); CK(zp(e->ws_ds, H)); CK(zp(e->ws_dzd, H)); CK(zp(e->ws_du, I)); CK(zp(e->ws_dqkv, 3 * H));
+        for (int l = 0; l <= c.num_layers; ++l) CK(zp(e->ws_x[l], H));
+        for (int l = 0; l < c.num_layers; ++l) { CK(zp(e->lw[l].ctx, H)); CK(zp(e->lw[l].y1, H)); CK(zp(e->lw[l].g, I)); }
+    }
+    e->padT = T;
     // embeddings (bert.py:211-216)
     CK(embed_ln_forward(dt, input_ids, token_type_ids, P + e->word, P + e->pos, P + e->type, P + e->emb_lnw, P + e->emb_lnb,
                         c.layer_norm_eps, ws + e->ws_emb, (float*)(ws + e->ws_emb_st), (float*)(ws + e->ws_emb_st) + T, B, L,
@@ -511,6 +548,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
     if (!e->G || !e->ids) return MB_ERR_ARG;
     const int dt = c.dtype, H = c.hidden_size, I = c.intermediate_size, B = e->B, L = e->L, T = B * L, nh = c.num_heads;
     const int NL = c.num_layers;
+    const int Tk = (int)align_up((size_t)T, 64);      // zero-padded reduction length of the wgrad GEMMs
     if (stage_begin < 0) stage_begin = 0;
     if (stage_end > NL + 2) stage_end = NL + 2;
     float* P = e->P; float* G = e->G;
@@ -541,24 +579,24 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             CK(ln_backward(dt, dx, ws + w.s2, P + o.ln2w, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, ds,
                            hd ? dzd : nullptr, G + o.ln2w, G + o.ln2b, G + o.b2, T, H, kNoDrop,
                            e->key(SITE_LAYER0 + 4 * l + 2, c.hidden_dropout), st));
-            CK(wgrad(dt, H, I, T, dzd, H, ws + w.g, I, G + o.w2, I, st));
+            CK(wgrad(dt, H, I, Tk, dzd, H, ws + w.g, I, G + o.w2, I, st));
             CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzd, H, e->W(o.w2), I, ws + e->ws_du, I, nullptr, nullptr, nullptr,
                     ws + w.u, I, kNoDrop, 1, 0, st));
             CK(colsum(dt, ws + e->ws_du, I, G + o.b1, T, I, st));
-            CK(wgrad(dt, I, H, T, ws + e->ws_du, I, ws + w.y1, H, G + o.w1, H, st));
+            CK(wgrad(dt, I, H, Tk, ws + e->ws_du, I, ws + w.y1, H, G + o.w1, H, st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, I, ws + e->ws_du, I, e->W(o.w1), H, dy1, H, nullptr, nullptr, nullptr, ds,
                     H, kNoDrop, 1, 0, st));
             // LN1 + dropout backward
             CK(ln_backward(dt, dy1, ws + w.s1, P + o.ln1w, (const float*)(ws + w.st1), (const float*)(ws + w.st1) + T, ds,
                            hd ? dzd : nullptr, G + o.ln1w, G + o.ln1b, G + o.bo, T, H, kNoDrop,
                            e->key(SITE_LAYER0 + 4 * l + 1, c.hidden_dropout), st));
-            CK(wgrad(dt, H, H, T, dzd, H, ws + w.ctx, H, G + o.wo, H, st));
+            CK(wgrad(dt, H, H, Tk, dzd, H, ws + w.ctx, H, G + o.wo, H, st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzd, H, e->W(o.wo), H, ws + e->ws_dctx, H, nullptr, nullptr, nullptr,
                     nullptr, 0, kNoDrop, 1, 0, st));
             CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, ws + e->ws_dqkv, B, L, nh,
                                   e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st));
             CK(colsum(dt, ws + e->ws_dqkv, 3 * H, G + o.bqkv, T, 3 * H, st));
-            CK(wgrad(dt, 3 * H, H, T, ws + e->ws_dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H, st));
+            CK(wgrad(dt, 3 * H, H, Tk, ws + e->ws_dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H, st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, 3 * H, ws + e->ws_dqkv, 3 * H, e->W(o.wqkv), H, dx, H, nullptr, nullptr,
                     nullptr, ds, H, kNoDrop, 1, 0, st));
         } else {
@@ -569,7 +607,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                             P + e->mag_lnw, c.beta_shift, e->key(SITE_MAG, c.mag_dropout), ws + e->ws_mag, e->mw, de, nullptr,
                             nullptr, G + e->mag_whv, G + e->mag_bhv, G + e->mag_wha, G + e->mag_bha, G + e->mag_wv,
                             G + e->mag_bv, G + e->mag_wa, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb, T, H, c.visual_dim,
-                            c.acoustic_dim, st));
+                            c.acoustic_dim, true, st));
             CK(embed_ln_backward(dt, de, e->ids, e->seg, P + e->word, P + e->pos, P + e->type, P + e->emb_lnw,
                                  (const float*)(ws + e->ws_emb_st), (const float*)(ws + e->ws_emb_st) + T,
                                  (float*)(ws + e->ws_dsum), G + e->word, G + e->pos, G + e->type, G + e->emb_lnw,

@@ -19,6 +19,7 @@
 //
 // The accumulator is computed transposed (mma16(acc, Bfrag, Afrag)) so that a lane owns 4 CONSECUTIVE
 // columns n of one row m: epilogue loads/stores are 8/16-byte vectors and bias is one float4.
+#include <cstdlib>
 #include "kernels.h"
 
 namespace mb {
@@ -98,6 +99,76 @@ struct Stager {
     }
 };
 
+// XCD-aware tile placement.  Block b runs on XCD b % 8 (8 XCDs, private 4 MB L2 each).  The tile grid is cut into
+// reg_m x reg_n = 8 rectangular regions, one per XCD, so the A row-panels and B column-panels an XCD touches fit its
+// L2 and are fetched from HBM / Infinity Cache once per XCD instead of once per tile.  The grid is padded to
+// 8 * (tiles per region); blocks that fall outside the tile grid exit.
+template <int BM, int BN>
+__device__ __forceinline__ bool tile_origin(const GemmArgs& p, int& m0, int& n0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xm = xcd / p.reg_n, xn = xcd % p.reg_n;
+    const int tm = xm * p.tpr_m + j / p.tpr_n, tn = xn * p.tpr_n + j % p.tpr_n;
+    m0 = tm * BM;
+    n0 = tn * BN;
+    return m0 < p.M && n0 < p.N && (j / p.tpr_n) < p.tpr_m;
+}
+
+// ------------------------------------------------------------------ shared epilogue
+template <class T, int BM, int BN, int MODE>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0, int wr,
+                                              int wc, int lane) {
+    constexpr int MT = BM / 32, NT = BN / 32;
+    // acc[i][j][r] = C[m][n + r],  m = m0 + wr*BM/2 + i*16 + (lane&15),  n = n0 + wc*BN/2 + j*16 + (lane>>4)*4
+    T* __restrict__ C = (T*)p.C;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wr * (BM / 2) + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wc * (BN / 2) + j * 16 + (lane >> 4) * 4;
+            if (n >= p.N) continue;
+            f32x4 v = acc[i][j];
+            if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_F32) {
+                v *= p.alpha;
+                if (p.bias) v += *(const f32x4*)(p.bias + n);
+                if constexpr (MODE == EPI_BIAS) store4(C + (size_t)m * p.ldc + n, v);
+                else store4(p.Cf + (size_t)m * p.ldc + n, v);
+            } else if constexpr (MODE == EPI_BIAS_GELU) {
+                v += *(const f32x4*)(p.bias + n);
+                f32x4 g = {gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+                store4(C + (size_t)m * p.ldc + n, v);
+                store4((T*)p.C2 + (size_t)m * p.ldc + n, g);
+            } else if constexpr (MODE == EPI_BIAS_DROP_RES) {
+                v += *(const f32x4*)(p.bias + n);
+                const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= drop_mult(p.drop, idx + r);
+                v += load4((const T*)p.R + (size_t)m * p.ldr + n);
+                store4(C + (size_t)m * p.ldc + n, v);
+            } else if constexpr (MODE == EPI_ADD_RES) {
+                if (p.R) v += load4((const T*)p.R + (size_t)m * p.ldr + n);
+                store4(C + (size_t)m * p.ldc + n, v);
+            } else if constexpr (MODE == EPI_DGELU) {
+                f32x4 u = load4((const T*)p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
+                store4(C + (size_t)m * p.ldc + n, v);
+            } else if constexpr (MODE == EPI_ACCUM_F32) {
+                float* dst = p.Cf + (size_t)m * p.ldc + n;
+                if (gridDim.y > 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
+                } else {
+                    f32x4 o = *(f32x4*)dst;
+                    o += v;
+                    *(f32x4*)dst = o;
+                }
+            }
+        }
+    }
+}
+
 template <class T, int BM, int BN, bool AK, bool BK, int MODE>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
     constexpr int BKE = 128 / sizeof(T);
@@ -108,16 +179,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
-    // XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous run of tiles so that
-    // tiles sharing an A row-panel / neighbouring B panels hit the same private L2 (bijective for any nwg).
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int swz;
-    {
-        const int q = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + j;
-    }
-    const int m0 = (swz / tiles_n) * BM, n0 = (swz % tiles_n) * BN;
+    int m0, n0;
+    if (!tile_origin<BM, BN>(p, m0, n0)) return;
 
     const int kbeg = blockIdx.y * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
@@ -172,71 +235,199 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
-    // ------------------------------------------------------------------ epilogue
-    // acc[i][j][r] = C[m][n + r],  m = m0 + wr*BM/2 + i*16 + (lane&15),  n = n0 + wc*BN/2 + j*16 + (lane>>4)*4
-    T* __restrict__ C = (T*)p.C;
+    gemm_epilogue<T, BM, BN, MODE>(p, acc, m0, n0, wr, wc, lane);
+}
+
+
+// ============================================================================================== v2: LDS-DMA ring
+// Same math, different data path: both operands go global -> LDS with global_load_lds (16 B per lane, no VGPR
+// round trip) into an NSTAGE-deep ring, loads for tiles t+1 .. t+NSTAGE-2 stay in flight across the single
+// s_barrier per k-tile (counted s_waitcnt vmcnt, never 0 in steady state).
+//   row operands : image [row][128 B], 16-B chunks XOR-swizzled with (row & 7) on the SOURCE address and on the
+//                  fragment read (the DMA destination is lane-linear) -> conflict-free ds_read_b128
+//   kmaj operands: image [k][rows] exactly as stored in HBM (coalesced 256/512-B row segments); bf16 MFMA fragments
+//                  are built with ds_read_b64_tr_b16 (hardware 4x16 transpose, two reads per fragment), fp32 with
+//                  four ds_read_b32.  32-B blocks XOR-swizzled with the k row against bank conflicts.
+// Requirements (else the v1 kernel above runs): K % BKE == 0 (callers zero-pad the token dimension of wgrad
+// operands), kmaj operands have rows % tile == 0, row strides are 16-byte multiples.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+#define LDS_PTR(p) ((__attribute__((address_space(3))) char*)(p))
+
+template <int RB> __device__ __forceinline__ int kswz(int k) { return RB >= 256 ? ((k & 3) << 1) : (((k >> 1) & 1) << 1); }
+
+template <class T, int BROWS, bool KMAJ>
+struct Dma {
+    static constexpr int EPV = 16 / sizeof(T);
+    static constexpr int RB = BROWS * (int)sizeof(T);      // kmaj image row bytes
+    static constexpr int NI = BROWS / 32;                  // 1-KB pieces per wave per stage
+    typedef typename Frag<T>::type frag_t;
+
+    static __device__ __forceinline__ void issue(const T* __restrict__ base, int ld, int row0, int nrows, int k0,
+                                                 char* lds, int lane, int wave) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m = m0 + wr * (BM / 2) + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + wc * (BN / 2) + j * 16 + (lane >> 4) * 4;
-            if (n >= p.N) continue;
-            f32x4 v = acc[i][j];
-            if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_F32) {
-                v *= p.alpha;
-                if (p.bias) v += *(const f32x4*)(p.bias + n);
-                if constexpr (MODE == EPI_BIAS) store4(C + (size_t)m * p.ldc + n, v);
-                else store4(p.Cf + (size_t)m * p.ldc + n, v);
-            } else if constexpr (MODE == EPI_BIAS_GELU) {
-                v += *(const f32x4*)(p.bias + n);
-                f32x4 g = {gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
-                store4(C + (size_t)m * p.ldc + n, v);
-                store4((T*)p.C2 + (size_t)m * p.ldc + n, g);
-            } else if constexpr (MODE == EPI_BIAS_DROP_RES) {
-                v += *(const f32x4*)(p.bias + n);
-                const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= drop_mult(p.drop, idx + r);
-                v += load4((const T*)p.R + (size_t)m * p.ldr + n);
-                store4(C + (size_t)m * p.ldc + n, v);
-            } else if constexpr (MODE == EPI_ADD_RES) {
-                if (p.R) v += load4((const T*)p.R + (size_t)m * p.ldr + n);
-                store4(C + (size_t)m * p.ldc + n, v);
-            } else if constexpr (MODE == EPI_DGELU) {
-                f32x4 u = load4((const T*)p.R + (size_t)m * p.ldr + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
-                store4(C + (size_t)m * p.ldc + n, v);
-            } else if constexpr (MODE == EPI_ACCUM_F32) {
-                float* dst = p.Cf + (size_t)m * p.ldc + n;
-                if (gridDim.y > 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
-                } else {
-                    f32x4 o = *(f32x4*)dst;
-                    o += v;
-                    *(f32x4*)dst = o;
-                }
+        for (int i = 0; i < NI; ++i) {
+            const int blk = i * 4 + wave;
+            const T* src;
+            if constexpr (!KMAJ) {
+                const int r = blk * 8 + (lane >> 3);
+                const int lc = (lane & 7) ^ (r & 7);
+                int g = row0 + r;
+                g = g < nrows ? g : nrows - 1;          // rows past the edge: any valid row (their outputs are never stored)
+                src = base + (size_t)g * ld + k0 + lc * EPV;
+            } else {
+                constexpr int RPK = 1024 / RB;
+                const int kl = blk * RPK + (lane * 16) / RB;
+                const int pc = ((lane * 16) % RB) >> 4;
+                const int lc = pc ^ kswz<RB>(kl);
+                src = base + (size_t)(k0 + kl) * ld + row0 + lc * EPV;
             }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)LDS_PTR(lds + blk * 1024), 16, 0, 0);
         }
     }
+
+    // fragment for image rows rbase + (lane & 15), k-slab s (64 bytes of k)
+    static __device__ __forceinline__ frag_t frag(const char* lds, int rbase, int s, int lane) {
+        if constexpr (!KMAJ) {
+            const int r = rbase + (lane & 15);
+            const int lc = s * 4 + (lane >> 4);
+            return *(const frag_t*)(lds + r * 128 + ((lc ^ (r & 7)) << 4));
+        } else if constexpr (sizeof(T) == 2) {
+            const int i = lane & 15;
+            const int colb = (rbase + (i & 3) * 4) * 2;
+            union { s16x4 h[2]; bf16x8 v; } u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = s * 32 + (lane >> 4) * 8 + h * 4 + (i >> 2);
+                const int pc = (colb >> 4) ^ kswz<RB>(k);
+                u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)LDS_PTR(lds + k * RB + (pc << 4) + (colb & 15)));
+            }
+            return u.v;
+        } else {
+            const int colb = (rbase + (lane & 15)) * 4;
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = s * 16 + (lane >> 4) * 4 + j;
+                const int pc = (colb >> 4) ^ kswz<RB>(k);
+                v[j] = *(const float*)(lds + k * RB + (pc << 4) + (colb & 15));
+            }
+            return v;
+        }
+    }
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE>
+__global__ void __launch_bounds__(256) gemm2_kernel(const GemmArgs p) {
+    constexpr int BKE = 128 / sizeof(T);
+    constexpr int MT = BM / 32, NT = BN / 32;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int G = (BM + BN) / 32;             // DMA instructions per wave per stage
+    typedef typename Frag<T>::type frag_t;
+    typedef Dma<T, BM, AK> DA;
+    typedef Dma<T, BN, BK> DB;
+    __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    int m0, n0;
+    if (!tile_origin<BM, BN>(p, m0, n0)) return;
+    const int kbeg = blockIdx.y * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nt = (kend - kbeg) / BKE;
+    const T* __restrict__ A = (const T*)p.A;
+    const T* __restrict__ B = (const T*)p.B;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int t) {
+        char* st = smem + (t % NSTAGE) * STAGE;
+        DA::issue(A, p.lda, m0, p.M, kbeg + t * BKE, st, lane, wave);
+        DB::issue(B, p.ldb, n0, p.N, kbeg + t * BKE, st + BM * 128, lane, wave);
+    };
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nt) issue(s);
+
+    for (int t = 0; t < nt; ++t) {
+        // stage t must have landed; up to NSTAGE-2 younger stages may stay in flight
+        const int younger = min(NSTAGE - 2, nt - 1 - t);
+        if (NSTAGE >= 4 && younger >= 2) wait_vmcnt<2 * G>();
+        else if (NSTAGE >= 3 && younger >= 1) wait_vmcnt<G>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();            // everyone's piece of stage t landed; everyone left stage t-1
+        if (t + NSTAGE - 1 < nt) issue(t + NSTAGE - 1);
+        const char* cur = smem + (t % NSTAGE) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            frag_t a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = DA::frag(cur, wr * (BM / 2) + i * 16, s, lane);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = DB::frag(cur + BM * 128, wc * (BN / 2) + j * 16, s, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) mma16(acc[i][j], b[j], a[i]);
+        }
+    }
+    gemm_epilogue<T, BM, BN, MODE>(p, acc, m0, n0, wr, wc, lane);
 }
 
 // ---------------------------------------------------------------------------------------------- host
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static int g_impl = -1, g_stages = -1;      // MB_GEMM_IMPL: 0 auto, 1 = register-staged v1, 2 = LDS-DMA v2 ; MB_GEMM_STAGES: 2|3|4
+
 template <class T, int BM, int BN, bool AK, bool BK, int MODE>
 static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
     GemmArgs p = a;
     constexpr int BKE = 128 / sizeof(T);
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    constexpr int EPV = 16 / sizeof(T);
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    {   // choose the 8-region decomposition with the smallest per-XCD panel footprint
+        long best = -1;
+        for (int rm = 1; rm <= 8; rm *= 2) {
+            const int rn = 8 / rm;
+            const int pm = (tiles_m + rm - 1) / rm, pn = (tiles_n + rn - 1) / rn;
+            const long cost = (long)pm * BM + (long)pn * BN + 4L * ((long)pm * pn * 8 - (long)tiles_m * tiles_n);   // footprint + padding waste
+            if (best < 0 || cost < best) { best = cost; p.reg_m = rm; p.reg_n = rn; p.tpr_m = pm; p.tpr_n = pn; }
+        }
+    }
+    const int tiles = 8 * p.tpr_m * p.tpr_n;
     if (splits < 1) splits = 1;
     int kchunk = (p.K + splits - 1) / splits;
     kchunk = (kchunk + BKE - 1) / BKE * BKE;
     splits = (p.K + kchunk - 1) / kchunk;
     p.kchunk = kchunk;
     dim3 grid(tiles, splits);
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, AK, BK, MODE>), grid, dim3(256), 0, st, p);
+    if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); }
+    // v2 preconditions (see the kernel header)
+    bool v2ok = (p.K % BKE == 0) && (p.lda % EPV == 0) && (p.ldb % EPV == 0) && (((uintptr_t)p.A | (uintptr_t)p.B) % 16 == 0);
+    if (AK) v2ok = v2ok && (p.M % BM == 0);
+    if (BK) v2ok = v2ok && (p.N % BN == 0);
+    if (g_impl == 1) v2ok = false;
+    if (v2ok) {
+        int ns = g_stages ? g_stages : (BM == 128 ? 2 : 3);
+        if (BM == 128 && ns > 3) ns = 3;          // 3 x 32 KB = 96 KB of the 160 KB LDS
+        if (ns == 2) hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, 2>), grid, dim3(256), 0, st, p);
+        else if (ns == 3) hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, 3>), grid, dim3(256), 0, st, p);
+        else {
+            if constexpr (BM == 64) hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, 4>), grid, dim3(256), 0, st, p);
+        }
+    } else {
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, AK, BK, MODE>), grid, dim3(256), 0, st, p);
+    }
     return (int)hipGetLastError();
 }
 

@@ -36,6 +36,7 @@ struct GemmArgs {
     float alpha;
     DropKey drop;
     int kchunk;                // filled by the launcher
+    int reg_m, reg_n, tpr_m, tpr_n;   // XCD regions (filled by the launcher): reg_m*reg_n == 8, tiles per region
 };
 
 // tile: 0 = auto, 64 or 128.  splits: split-K factor (only EPI_ACCUM_F32).

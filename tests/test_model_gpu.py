@@ -1,0 +1,235 @@
+"""GPU: whole-path parity of MAG_BertForSequenceClassification (HIP engine) against
+  (a) the golden logits produced by the reference's own Python (tests/golden/g4g5_full_model.npz), and
+  (b) the CPU oracle run live on the same inputs (gradients, dropout with mask replay, optimizer trajectory).
+
+Tolerances:
+  fp32 parity mode: logits |err| <= 1e-3 (north_star) -- measured ~1e-5; gradients <= 2e-3 of the tensor's max (or of
+                    1e-3 * the global max for tensors whose gradient is mathematically ~0, e.g. key biases)
+  bf16 perf mode  : logits |err| <= 5e-2 absolute on |logit| ~ 0.4 (12 layers of bf16 activations); stated, not 1e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from bert_multimodal_transformer_amd import (AdamW, BertConfig, MAG_BertForSequenceClassification, MultimodalConfig,
+                                             get_linear_schedule_with_warmup, rng)
+from oracle import mag_bert_ref as R
+from oracle import optim_ref as O
+from oracle import weights
+
+DEV = "cuda:0"
+
+
+def build(V=47, layers=12, cdt=torch.float32, p_mag=0.5, beta=1.0, hidden_p=0.1, attn_p=0.1, mode="test"):
+    cfg = BertConfig(num_hidden_layers=layers, num_labels=1, hidden_dropout_prob=hidden_p, attention_probs_dropout_prob=attn_p)
+    m = MAG_BertForSequenceClassification(cfg, MultimodalConfig(beta, p_mag), visual_dim=V, acoustic_dim=74, compute_dtype=cdt)
+    sd = {n: torch.from_numpy(weights.make_param(n, tuple(p.shape), mode)) for n, p in m.named_parameters()}
+    m.load_state_dict(sd)
+    return m
+
+
+def oracle(V=47, layers=12, p_mag=0.5, beta=1.0, mode="test"):
+    o = R.MAG_BertForSequenceClassification(R.BertConfigLite(num_hidden_layers=layers), R.MultimodalConfig(beta, p_mag), V, 74)
+    return R.load_deterministic(o, mode)
+
+
+def tb(b, dev="cpu"):
+    t = lambda k: torch.from_numpy(b[k]).to(dev)
+    return t("input_ids"), t("visual"), t("acoustic"), t("input_mask"), t("segment_ids"), t("label_ids")
+
+
+def test_state_dict_is_the_reference_key_set():
+    m = build(layers=2)
+    o = oracle(layers=2)
+    assert set(m.state_dict().keys()) == set(o.state_dict().keys())
+    for k, v in o.state_dict().items():
+        assert tuple(m.state_dict()[k].shape) == tuple(v.shape)
+        assert torch.equal(m.state_dict()[k].cpu(), v), k
+
+
+@pytest.mark.parametrize("B,L,V,seed", [(4, 50, 47, 11), (48, 50, 47, 12), (4, 128, 35, 13)])
+def test_eval_logits_match_reference_golden_fp32(golden, B, L, V, seed):
+    m = build(V).eval()
+    ids, vis, aco, mask, seg, lab = tb(weights.synthetic_bert_batch(B, L, V, 74, seed=seed), DEV)
+    with torch.no_grad():
+        logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
+    ref = golden["g4g5_full_model"]["logits/B%d_L%d_V%d_seed%d" % (B, L, V, seed)]
+    err = float(np.abs(logits.cpu().numpy() - ref).max())
+    print("fp32 logits max|err| vs reference golden:", err)
+    assert err <= 1e-3
+
+
+@pytest.mark.parametrize("B,L,V,seed", [(48, 50, 47, 12), (4, 128, 35, 13)])
+def test_eval_logits_bf16(golden, B, L, V, seed):
+    m = build(V, cdt=torch.bfloat16).eval()
+    ids, vis, aco, mask, seg, lab = tb(weights.synthetic_bert_batch(B, L, V, 74, seed=seed), DEV)
+    with torch.no_grad():
+        logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
+    ref = golden["g4g5_full_model"]["logits/B%d_L%d_V%d_seed%d" % (B, L, V, seed)]
+    err = float(np.abs(logits.cpu().numpy() - ref).max())
+    print("bf16 logits max|err| vs reference golden:", err, "max|logit|", float(np.abs(ref).max()))
+    assert err <= 5e-2
+
+
+def _grad_report(m, o, tol, frobenius=False):
+    """worst per-tensor relative gradient error.  Element-wise max norm for fp32; for bf16 the relative Frobenius
+    error (a relu / clamp / dropout-scaled term that flips on a near-zero bf16 pre-activation moves single elements)."""
+    gmax = max(float(p.grad.abs().max()) for p in o.parameters())
+    gnorm = max(float(p.grad.norm()) for p in o.parameters())
+    worst = (0.0, None)
+    om = dict(o.named_parameters())
+    for n, p in m.named_parameters():
+        g = p.grad.detach().cpu()
+        r = om[n].grad
+        if frobenius:
+            rel = float((g - r).norm()) / max(float(r.norm()), 1e-3 * gnorm)
+        else:
+            rel = float((g - r).abs().max()) / max(float(r.abs().max()), 1e-3 * gmax)
+        if rel > worst[0]:
+            worst = (rel, n)
+    print("worst relative gradient error %.3e at %s" % worst)
+    assert worst[0] <= tol, worst
+
+
+def test_gradients_match_oracle_fp32(golden):
+    """train mode, every dropout p = 0: loss and all 211 parameter gradients vs the oracle (and the golden loss)."""
+    m = build(p_mag=0.0, hidden_p=0.0, attn_p=0.0).train()
+    o = R.set_dropout(oracle(p_mag=0.0), 0.0, 0.0, 0.0).train()
+    b = weights.synthetic_bert_batch(4, 50, 47, 74, seed=21)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
+    loss = torch.nn.MSELoss()(logits.view(-1), lab.view(-1))            # the reference loop (multimodal_driver.py:371-378)
+    loss.backward()
+    i2, v2, a2, m2, s2, l2 = tb(b)
+    lo = torch.nn.functional.mse_loss(o(i2, v2, a2, m2, s2)[0].view(-1), l2.view(-1))
+    lo.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(golden["g4g5_full_model"]["train/loss_B4_L50_seed21"])) < 1e-4
+    assert abs(float(loss) - float(lo)) < 1e-4
+    _grad_report(m, o, 2e-3)
+    # gradient accumulation semantics: a second backward doubles the flat buffer
+    g0 = m.flat_grads.clone()
+    logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
+    torch.nn.MSELoss()(logits.view(-1), lab.view(-1)).backward()
+    assert float((m.flat_grads - 2 * g0).abs().max()) <= 1e-3 * float(g0.abs().max())
+
+
+def test_fused_training_step_equals_autograd_path():
+    m = build(layers=2, p_mag=0.0, hidden_p=0.0, attn_p=0.0).train()
+    b = weights.synthetic_bert_batch(6, 50, 47, 74, seed=31)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
+    loss = torch.nn.MSELoss()(logits.view(-1), lab.view(-1))
+    loss.backward()
+    g_ref = m.flat_grads.clone()
+    m.zero_grad()
+    l2 = m.training_step(ids, vis, aco, mask, seg, lab)
+    assert abs(float(l2) - float(loss)) < 1e-5
+    assert float((m.flat_grads - g_ref).abs().max()) <= 1e-5 * float(g_ref.abs().max()) + 1e-9
+
+
+class _Replay(torch.nn.Module):
+    """dropout with a fixed multiplier tensor (the device mask regenerated on the host)"""
+
+    def __init__(self, mult):
+        super().__init__()
+        self.mult = mult
+
+    def forward(self, x):
+        return x * self.mult.view(x.shape)
+
+
+@pytest.mark.parametrize("cdt,tol_logit,tol_grad", [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 5e-2, 8e-2)])
+def test_train_mode_dropout_mask_replay(cdt, tol_logit, tol_grad):
+    """Dropout ON at every site (0.1 / 0.1 / MAG 0.5): the device masks are regenerated on the host from the
+    counter hash and replayed inside the oracle -> exact train-mode parity, forward and backward."""
+    layers, B, L, V, nh, H = 2, 3, 24, 47, 12, 768
+    torch.manual_seed(99)
+    m = build(V, layers, cdt).train()
+    o = oracle(V, layers).train()
+    core = m._core
+    b = weights.synthetic_bert_batch(B, L, V, 74, seed=41)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
+    torch.nn.MSELoss()(logits.view(-1), lab.view(-1)).backward()
+    seed, step = core.seed, core.step
+    mult = lambda site, p, n: torch.from_numpy(rng.keep_mult(n, rng.make_key(seed, step, site, p)))
+    T = B * L
+    o.bert.embeddings.dropout = _Replay(mult(rng.SITE_EMB, 0.1, T * H))
+    o.bert.MAG.dropout = _Replay(mult(rng.SITE_MAG, 0.5, T * H))
+    o.dropout = _Replay(mult(rng.SITE_HEAD, 0.1, B * H))
+    for l, lyr in enumerate(o.bert.encoder.layer):
+        lyr.attention.self.dropout = _Replay(mult(rng.SITE_LAYER0 + 4 * l + 0, 0.1, B * nh * L * L))
+        lyr.attention.output.dropout = _Replay(mult(rng.SITE_LAYER0 + 4 * l + 1, 0.1, T * H))
+        lyr.output.dropout = _Replay(mult(rng.SITE_LAYER0 + 4 * l + 2, 0.1, T * H))
+    i2, v2, a2, m2, s2, l2 = tb(b)
+    lo = o(i2, v2, a2, m2, s2)[0]
+    torch.nn.functional.mse_loss(lo.view(-1), l2.view(-1)).backward()
+    torch.cuda.synchronize()
+    err = float((logits.detach().cpu() - lo.detach()).abs().max())
+    print("train-mode logits max|err|:", err)
+    assert err <= tol_logit
+    _grad_report(m, o, tol_grad, frobenius=(cdt == torch.bfloat16))
+
+
+def test_three_optimizer_steps_track_the_oracle_fp32():
+    """fwd + bwd + fused HF-AdamW + linear warmup, 3 steps, dropout off: parameters and logits follow the oracle."""
+    layers = 2
+    m = build(layers=layers, p_mag=0.0, hidden_p=0.0, attn_p=0.0).train()
+    o = R.set_dropout(oracle(layers=layers, p_mag=0.0), 0.0, 0.0, 0.0).train()
+    from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
+    opt = AdamW(optimizer_grouped_parameters(m), lr=1e-3)
+    sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=1.0, num_training_steps=10)
+    oo = O.AdamW(O.grouped_parameters(o), lr=1e-3)
+    so = O.get_linear_schedule_with_warmup(oo, num_warmup_steps=1.0, num_training_steps=10)
+    for s in range(3):
+        b = weights.synthetic_bert_batch(4, 50, 47, 74, seed=50 + s)
+        ids, vis, aco, mask, seg, lab = tb(b, DEV)
+        m.training_step(ids, vis, aco, mask, seg, lab)
+        opt.step(); sch.step(); opt.zero_grad()
+        i2, v2, a2, m2, s2, l2 = tb(b)
+        oo.zero_grad()
+        torch.nn.functional.mse_loss(o(i2, v2, a2, m2, s2)[0].view(-1), l2.view(-1)).backward()
+        oo.step(); so.step()
+    torch.cuda.synchronize()
+    assert float(m.flat_grads.abs().max()) == 0.0                      # gradients cleared inside the AdamW kernel
+    om = dict(o.named_parameters())
+    worst = 0.0
+    for n, p in m.named_parameters():
+        worst = max(worst, float((p.detach().cpu() - om[n].detach()).abs().max()))
+    print("max |param - oracle param| after 3 steps:", worst)
+    assert worst <= 2e-4            # lr 1e-3 * O(1) Adam updates; sign flips of ~0 gradients bound this, not fp error
+    m.eval(); o.eval()
+    b = weights.synthetic_bert_batch(4, 50, 47, 74, seed=60)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    with torch.no_grad():
+        l1 = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0].cpu()
+        i2, v2, a2, m2, s2, _ = tb(b)
+        l0 = o(i2, v2, a2, m2, s2)[0]
+    assert float((l1 - l0).abs().max()) <= 5e-3
+
+
+def test_driver_epoch_runs_and_learns():
+    """bundled driver, synthetic MOSI-shaped data, bf16 perf mode, dropout on: finite, decreasing loss."""
+    from bert_multimodal_transformer_amd import multimodal_driver as D
+    D.args = D.parse_args(["--synthetic", "192", "--n_epochs", "1", "--seed", "5", "--train_batch_size", "48",
+                           "--learning_rate", "5e-5"])
+    D.set_random_seed(D.args.seed)
+    tr, dev, te, nsteps = D.set_up_data_loader()
+    # small encoder keeps the GPU test short; the full 12-layer model is what bench.py runs
+    cfg = BertConfig(num_hidden_layers=2)
+    model = MAG_BertForSequenceClassification(cfg, MultimodalConfig(1.0, 0.5), compute_dtype=torch.bfloat16)
+    opt = AdamW(D.optimizer_grouped_parameters(model), lr=D.args.learning_rate)
+    sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=0, num_training_steps=1000)
+    losses = [D.train_epoch(model, tr, opt, sch) for _ in range(4)]
+    print("epoch losses", losses)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    vl = D.eval_epoch(model, dev, opt)
+    acc, mae, corr, f1 = D.test_score_model(model, te)
+    assert np.isfinite(vl) and 0.0 <= acc <= 1.0 and np.isfinite(mae)
+    # the literal reference loop gives the same kind of result through autograd
+    D.args.reference_loop = True
+    l_ref = D.train_epoch(model, tr, opt, sch)
+    assert np.isfinite(l_ref)
