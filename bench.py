@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--cpu-baseline", type=int, default=1)
     p.add_argument("--cpu-steps", type=int, default=2)
     p.add_argument("--roofline", type=int, default=1)
+    p.add_argument("--overlap-optimizer", type=int, default=0,
+                   help="EXPERIMENTAL: update each stage's parameters during the backward (see DESIGN.md, known issue)")
     p.add_argument("--roofline-only", type=int, default=0, help="skip the training loop, print the GEMM table only")
     return p.parse_args()
 
@@ -187,6 +189,8 @@ def main():
     if world > 1:
         dp = DataParallel(model, opt)
         dp.broadcast_parameters(0)
+    if a.overlap_optimizer:
+        opt.enable_overlap(model)
     model.train()
     nb = 8
     batches = make_batches(nb, B, L, V, A, seed=1234 + rank)

@@ -93,7 +93,8 @@ class _Core(object):
         self.seed = int(torch.initial_seed())
         self.step = 0
         self.training_last = False
-        self.grad_hook = None          # set by distributed.DataParallel: hook(stage) after each backward stage
+        self._own_stream = None
+        self.stage_hooks = []          # callables hook(stage) run after each backward stage (DataParallel, AdamW overlap)
         self._make_engine(1, 8)
         n = self.lib.mb_bert_param_count(self.handle)
         self.n_params = n
@@ -153,9 +154,36 @@ class _Core(object):
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    class _Hop(object):
+        """The engine forks/joins internal side streams with events.  On the legacy NULL stream those hand-offs were
+        observed to be unreliable on ROCm 7.2 (intermittent stale gradients), so when the caller is on the default
+        stream the pass hops onto a private non-default stream and joins back afterwards."""
+
+        def __init__(self, core):
+            self.core = core
+            self.cur = torch.cuda.current_stream(core.device)
+            self.hop = self.cur.cuda_stream == 0
+            self.ctx = None
+
+        def __enter__(self):
+            if self.hop:
+                if self.core._own_stream is None:
+                    self.core._own_stream = torch.cuda.Stream(device=self.core.device)
+                self.core._own_stream.wait_stream(self.cur)
+                self.ctx = torch.cuda.stream(self.core._own_stream)
+                self.ctx.__enter__()
+            return self
+
+        def __exit__(self, *exc):
+            if self.hop:
+                self.ctx.__exit__(*exc)
+                self.cur.wait_stream(self.core._own_stream)
+            return False
+
     def sync_weights(self):
         """refresh bf16 shadow + packed MAG operands from the fp32 masters (after load / manual edits)"""
-        _lib.check(self.lib.mb_bert_sync_weights(self.handle, self.stream()))
+        with _Core._Hop(self):
+            _lib.check(self.lib.mb_bert_sync_weights(self.handle, self.stream()))
         self.weights_dirty = False
 
     # -- passes --------------------------------------------------------------------------------------
@@ -179,11 +207,12 @@ class _Core(object):
             self.step += 1
         self._keep = (ids, msk, seg, vis, aco, lab, logits)      # engine keeps raw pointers until the backward
         self.training_last = bool(training)
-        _lib.check(self.lib.mb_bert_forward(self.handle, _lib.ptr(ids), _lib.ptr(vis), _lib.ptr(aco), _lib.ptr(msk),
-                                            _lib.ptr(seg), _lib.ptr(lab), B, L, 1 if training else 0, self.seed, self.step,
-                                            _lib.ptr(logits), C.c_void_p(self.loss_buf.data_ptr()),
-                                            C.c_void_p(self.loss_buf.data_ptr() + 4) if lab is not None else None,
-                                            self.stream()))
+        with _Core._Hop(self):
+            _lib.check(self.lib.mb_bert_forward(self.handle, _lib.ptr(ids), _lib.ptr(vis), _lib.ptr(aco), _lib.ptr(msk),
+                                                _lib.ptr(seg), _lib.ptr(lab), B, L, 1 if training else 0, self.seed,
+                                                self.step, _lib.ptr(logits), C.c_void_p(self.loss_buf.data_ptr()),
+                                                C.c_void_p(self.loss_buf.data_ptr() + 4) if lab is not None else None,
+                                                self.stream()))
         return logits
 
     def _backward(self, dlogits=None, loss_scale=1.0):
@@ -191,11 +220,13 @@ class _Core(object):
         lab = self._keep[5]
         if dlogits is None and lab is None:
             raise ValueError("fused backward needs the labels passed to forward()")
-        for s in range(nstage):
-            _lib.check(self.lib.mb_bert_backward(self.handle, _lib.ptr(dlogits), _lib.ptr(lab) if dlogits is None else None,
-                                                 float(loss_scale), s, s + 1, self.stream()))
-            if self.grad_hook is not None:
-                self.grad_hook(s)
+        with _Core._Hop(self):
+            for s in range(nstage):
+                _lib.check(self.lib.mb_bert_backward(self.handle, _lib.ptr(dlogits),
+                                                     _lib.ptr(lab) if dlogits is None else None, float(loss_scale), s, s + 1,
+                                                     self.stream()))
+                for hook in self.stage_hooks:
+                    hook(s)
 
     def sequence_output(self, B, L):
         H = self.config.hidden_size

@@ -158,15 +158,15 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
 // =============================================================================================== backward
 template <class T, int LP, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
-                                                           const T* __restrict__ dctx, T* __restrict__ dqkv, int L, int nh,
-                                                           DropKey drop) {
+                                                           const T* __restrict__ dctx, T* __restrict__ dqkv,
+                                                           float* __restrict__ dbias, int L, int nh, DropKey drop) {
     typedef AttnCfg<T> C;
     constexpr int PIT = C::ROWB + 16;
     constexpr int SPIT = LP * (int)sizeof(T) + 16;
     constexpr int NT = LP / 16;
     constexpr int DSL = 64 / C::SLAB;
     constexpr int LSL = LP / C::SLAB;
-    __shared__ __attribute__((aligned(16))) char smem[4 * LP * PIT + NW * 16 * SPIT + 4 * LP * 4];
+    __shared__ __attribute__((aligned(16))) char smem[4 * LP * PIT + NW * 16 * SPIT + 4 * LP * 4 + NW * 64 * 4];
     char* Qi = smem;
     char* Ki = smem + LP * PIT;
     char* Vi = smem + 2 * LP * PIT;
@@ -176,6 +176,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
     float* rmax = mbias + LP;
     float* rinv = rmax + LP;
     float* rD = rinv + LP;
+    float* csum = rD + LP;                   // [NW][64] scratch for the fused QKV bias gradient (column sums of dqkv)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x / nh, h = blockIdx.x % nh;
@@ -188,6 +189,30 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
     stage_head<T, LP, NW * 64>(Oi, PIT, dctx + (size_t)b * L * H + h * 64, (size_t)H, L);
     for (int j = threadIdx.x; j < LP; j += NW * 64)
         mbias[j] = j < L ? (1.0f - (float)mask[(size_t)b * L + j]) * kMaskNeg : kPadNeg;
+    // per-lane running column sums of the dQ / dK / dV tiles this wave produces (its own row only; rows >= L excluded);
+    // reduced over the 16 rows and the waves once, at the end of each sweep
+    f32x4 cq[4], ck[4], cv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) cq[dt] = ck[dt] = cv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* csw = csum;                       // [NW][64] scratch, reused per flush
+    auto flush = [&](f32x4 (&c4)[4], int which) {    // called by every thread of the block (uniform)
+        if (dbias == nullptr) return;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sred = group16_sum(c4[dt][r]);
+                if ((lane & 15) == 0) csw[wave * 64 + dt * 16 + (lane >> 4) * 4 + r] = sred;
+            }
+        __syncthreads();
+        for (int j = threadIdx.x; j < 64; j += NW * 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += csw[w * 64 + j];
+            atomicAdd(dbias + (size_t)which * H + h * 64 + j, t);
+        }
+        __syncthreads();
+    };
     __syncthreads();
 
     char* St = strips + wave * 16 * SPIT;
@@ -259,10 +284,13 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
                           frag_nat<T>(St, SPIT, lane & 15, sl, lane));
                 const int i = strip * 16 + (lane & 15);
                 if (i < L) store4(dq_base + (size_t)i * ld + dt * 16 + (lane >> 4) * 4, o);
+                if (i < L) cq[dt] += o;
             }
         }
         __syncthreads();
     }
+
+    flush(cq, 0);
 
     // ------------------------------------------------------------------ sweep B: key strips -> dV, dK
     for (int s0 = 0; s0 < NT; s0 += NW) {
@@ -310,6 +338,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
                     mma16(o, frag_kmaj(Oi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
                           frag_nat<T>(St, SPIT, lane & 15, sl, lane));
                 if (j < L) store4(dq_base + (size_t)j * ld + 2 * H + dt * 16 + (lane >> 4) * 4, o);
+                if (j < L) cv[dt] += o;
             }
         }
         __syncthreads();
@@ -328,10 +357,13 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
                     mma16(o, frag_kmaj(Qi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
                           frag_nat<T>(St, SPIT, lane & 15, sl, lane));
                 if (j < L) store4(dq_base + (size_t)j * ld + H + dt * 16 + (lane >> 4) * 4, o);
+                if (j < L) ck[dt] += o;
             }
         }
         __syncthreads();
     }
+    flush(ck, 1);
+    flush(cv, 2);
 }
 
 // =============================================================================================== host
@@ -342,10 +374,10 @@ static int launch_fwd(const void* qkv, const int64_t* mask, void* ctx, int B, in
     return (int)hipGetLastError();
 }
 template <class T, int LP, int NW>
-static int launch_bwd(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int nh,
+static int launch_bwd(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, float* dbias, int B, int L, int nh,
                       DropKey drop, hipStream_t st) {
     hipLaunchKernelGGL((attn_bwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, mask,
-                       (const T*)dctx, (T*)dqkv, L, nh, drop);
+                       (const T*)dctx, (T*)dqkv, dbias, L, nh, drop);
     return (int)hipGetLastError();
 }
 
@@ -372,23 +404,23 @@ int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx
 }
 
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx, void* dqkv,
-                       int B, int L, int nh, DropKey drop, hipStream_t st) {
+                       float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st) {
     (void)ctx;   // D_i is recomputed as sum_j dP_ij P_ij, the forward output is not needed
     if (L < 1 || L > 128) return MB_ERR_SHAPE;
     const int LP = (L + 31) / 32 * 32;
     if (dtype == DT_BF16) {
         switch (LP) {
-            case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
-            case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
-            case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
-            default: return launch_bwd<bf16, 128, 4>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
+            case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
+            case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
+            case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
+            default: return launch_bwd<bf16, 128, 4>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
         }
     } else if (dtype == DT_F32) {
         switch (LP) {
-            case 32: return launch_bwd<float, 32, 2>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
-            case 64: return launch_bwd<float, 64, 4>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
-            case 96: return launch_bwd<float, 96, 2>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);
-            default: return launch_bwd<float, 128, 2>(qkv, mask, dctx, dqkv, B, L, nh, drop, st);   // 2 waves: LDS budget
+            case 32: return launch_bwd<float, 32, 2>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
+            case 64: return launch_bwd<float, 64, 4>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
+            case 96: return launch_bwd<float, 96, 2>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
+            default: return launch_bwd<float, 128, 2>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);   // 2 waves: LDS budget
         }
     }
     return MB_ERR_DTYPE;

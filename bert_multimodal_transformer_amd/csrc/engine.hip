@@ -17,6 +17,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include "kernels.h"
 #include "../../include/magbert_hip.h"
 
@@ -101,7 +102,8 @@ int gemm(int dtype, int layout, int mode, int M, int N, int K, const void* A, in
     GemmArgs a;
     a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
     a.C = C; a.ldc = ldc; a.C2 = C2; a.Cf = Cf; a.bias = bias; a.R = R; a.ldr = ldr; a.alpha = 1.0f; a.drop = drop;
-    a.kchunk = K;
+    a.kchunk = K; a.colsum = nullptr;
+    if (mode == EPI_DGELU) { a.colsum = Cf; a.Cf = nullptr; }     // EPI_DGELU: the fp32 pointer carries the fused bias grad
     return gemm_launch(dtype, layout, mode, a, splits, tile, st);
 }
 
@@ -113,8 +115,8 @@ int wgrad(int dtype, int Mo, int No, int rows, const void* dY, int ldy, const vo
     // split-K costs one fp32 atomic per output element per split (measured: 4.7 M atomics ~ 50 us), so it is used only
     // when the tile grid alone cannot occupy the chip
     int tile, splits;
-    if (t128 >= 100) { tile = 128; splits = 1; }
-    else if (t64 >= 100) { tile = 64; splits = 1; }
+    if (t128 >= 256) { tile = 128; splits = 1; }
+    else if (t64 >= 100) { tile = 64; splits = 1; }        // measured: [768x3072] K=2432: 64^2 32 us vs 128^2 52 us
     else { tile = 64; splits = (int)((256 + t64 - 1) / t64); }
     if (splits > 8) splits = 8;
     while (splits > 1 && rows / splits < 128) --splits;
@@ -213,7 +215,7 @@ struct mb_bert_engine {
     size_t ws_mag, ws_emb, ws_emb_st, ws_head_z, ws_head_pooled, ws_logits;
     std::vector<size_t> ws_x;
     std::vector<LayerWs> lw;
-    size_t ws_dxa, ws_dxb, ws_ds, ws_dzd, ws_du, ws_dqkv, ws_dctx, ws_dsum, ws_dz;
+    size_t ws_dxa, ws_dxb, ws_ds, ws_dzd, ws_ds2, ws_dzd2, ws_du, ws_dqkv, ws_dctx, ws_dsum, ws_dz, ws_lnp_a, ws_lnp_b;
     size_t ws_ids, ws_seg, ws_mask, ws_labels;    // (inputs are caller pointers; kept for the backward)
     size_t ws_bytes;
     // bound buffers
@@ -222,6 +224,10 @@ struct mb_bert_engine {
     const int64_t* ids = nullptr; const int64_t* seg = nullptr; const int64_t* mask = nullptr;
     int B = 0, L = 0, training = 0;
     int padT = -1;                 // token count whose pad rows [T, Tp) are currently known to be zero
+    // weight-gradient GEMMs run on an internal side stream, concurrently with the dgrad chain of the same layer
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> evs;      // 5 events per encoder stage (4 forks + 1 join), never reused within a backward
+    int overlap_wgrad = 1;
     bool ws_zeroed = false;
     uint64_t seed = 0, step = 0;
     float* logits = nullptr;
@@ -316,8 +322,9 @@ static void build_layout(mb_bert_engine* e) {
     e->ws_head_pooled = w.take((size_t)c.max_batch * H * 4);
     e->ws_logits = w.take((size_t)c.max_batch * c.num_labels * 4);
     e->ws_dxa = w.take(T * H * es); e->ws_dxb = w.take(T * H * es); e->ws_ds = w.take(T * H * es);
-    e->ws_dzd = w.take(T * H * es); e->ws_du = w.take(T * I * es); e->ws_dqkv = w.take(T * 3 * H * es);
+    e->ws_dzd = w.take(T * H * es); e->ws_ds2 = w.take(T * H * es); e->ws_dzd2 = w.take(T * H * es); e->ws_du = w.take(T * I * es); e->ws_dqkv = w.take(T * 3 * H * es);
     e->ws_dctx = w.take(T * H * es); e->ws_dsum = w.take(T * H * 4); e->ws_dz = w.take((size_t)c.max_batch * H * es);
+    e->ws_lnp_a = w.take(ln_partials_floats((int)T, (int)H) * 4); e->ws_lnp_b = w.take(ln_partials_floats((int)T, (int)H) * 4);
     e->ws_bytes = w.off;
 }
 
@@ -345,7 +352,7 @@ int mb_gemm(int dtype, int layout, int epilogue, int M, int N, int K, const void
             const mb_dropkey* drop, int splits, int tile, void* stream) {
     GemmArgs a;
     a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.C = C; a.ldc = ldc; a.C2 = C2; a.Cf = Cf;
-    a.bias = bias; a.R = R; a.ldr = ldr; a.alpha = alpha; a.drop = dk(drop); a.kchunk = K;
+    a.bias = bias; a.R = R; a.ldr = ldr; a.alpha = alpha; a.drop = dk(drop); a.kchunk = K; a.colsum = nullptr;
     return gemm_launch(dtype, layout, epilogue, a, splits, tile, (hipStream_t)stream);
 }
 
@@ -378,7 +385,7 @@ int mb_attention_forward(int dtype, const void* qkv, const int64_t* mask, void* 
 }
 int mb_attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L,
                           int nh, const mb_dropkey* drop, void* stream) {
-    return attention_backward(dtype, qkv, mask, nullptr, dctx, dqkv, B, L, nh, dk(drop), (hipStream_t)stream);
+    return attention_backward(dtype, qkv, mask, nullptr, dctx, dqkv, nullptr, B, L, nh, dk(drop), (hipStream_t)stream);
 }
 
 size_t mb_mag_workspace_bytes(int dtype, int T, int H, int V, int A) {
@@ -431,11 +438,17 @@ int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
     if (cfg->dtype != DT_F32 && cfg->dtype != DT_BF16) return MB_ERR_DTYPE;
     mb_bert_engine* e = new mb_bert_engine();
     e->c = *cfg;
+    if (const char* v = getenv("MB_OVERLAP_WGRAD")) e->overlap_wgrad = atoi(v);
     build_layout(e);
     *out = e;
     return MB_OK;
 }
-void mb_bert_destroy(mb_bert_engine* e) { delete e; }
+void mb_bert_destroy(mb_bert_engine* e) {
+    if (!e) return;
+    if (e->side) hipStreamDestroy(e->side);
+    for (auto& ev : e->evs) if (ev) hipEventDestroy(ev);
+    delete e;
+}
 int mb_bert_num_tensors(const mb_bert_engine* e) { return (int)e->tensors.size(); }
 int mb_bert_tensor_info(const mb_bert_engine* e, int i, char* name, int name_cap, size_t* offset, size_t* numel, int* ndim,
                         int64_t* shape4, int* decay) {
@@ -497,7 +510,8 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
         auto zp = [&](size_t off, size_t cols) {
             return (int)hipMemsetAsync(ws + off + (size_t)T * cols * es, 0, (size_t)(Tp - T) * cols * es, st);
         };
-        CK(zp(e->ws_emb, H)); CK(zp(e->ws_ds, H)); CK(zp(e->ws_dzd, H)); CK(zp(e->ws_du, I)); CK(zp(e->ws_dqkv, 3 * H));
+        CK(zp(e->ws_emb, H)); CK(zp(e->ws_ds, H)); CK(zp(e->ws_dzd, H)); CK(zp(e->ws_ds2, H)); CK(zp(e->ws_dzd2, H));
+        CK(zp(e->ws_du, I)); CK(zp(e->ws_dqkv, 3 * H));
         for (int l = 0; l <= c.num_layers; ++l) CK(zp(e->ws_x[l], H));
         for (int l = 0; l < c.num_layers; ++l) { CK(zp(e->lw[l].ctx, H)); CK(zp(e->lw[l].y1, H)); CK(zp(e->lw[l].g, I)); }
     }
@@ -573,32 +587,65 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             const LayerWs& w = e->lw[l];
             char* dx = ws + e->ws_dxa;     // grad wrt x[l+1] on entry, wrt x[l] on exit
             char* dy1 = ws + e->ws_dxb;
-            char* ds = ws + e->ws_ds;
-            char* dzd = hd ? ws + e->ws_dzd : ds;
-            // LN2 + dropout backward
-            CK(ln_backward(dt, dx, ws + w.s2, P + o.ln2w, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, ds,
-                           hd ? dzd : nullptr, G + o.ln2w, G + o.ln2b, G + o.b2, T, H, kNoDrop,
-                           e->key(SITE_LAYER0 + 4 * l + 2, c.hidden_dropout), st));
-            CK(wgrad(dt, H, I, Tk, dzd, H, ws + w.g, I, G + o.w2, I, st));
-            CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzd, H, e->W(o.w2), I, ws + e->ws_du, I, nullptr, nullptr, nullptr,
+            char* dsA = ws + e->ws_ds;                  // LN2 (FFN output) backward
+            char* dzdA = hd ? ws + e->ws_dzd : dsA;
+            char* dsB = ws + e->ws_ds2;                 // LN1 (attention output) backward
+            char* dzdB = hd ? ws + e->ws_dzd2 : dsB;
+            // wgrad GEMMs go to the side stream: they only read (dY, saved X) and accumulate into G, so they overlap the
+            // dgrad chain; dY buffers are per-LayerNorm (A/B) and the stage ends with a join, which keeps them race-free.
+            hipStream_t ss = st;
+            if (e->overlap_wgrad) {
+                if (!e->side) {
+                    CK((int)hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+                    e->evs.assign((size_t)NL * 5, nullptr);
+                    for (auto& ev : e->evs) CK((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                }
+                ss = e->side;
+            }
+            hipEvent_t* sev = e->overlap_wgrad ? &e->evs[(size_t)l * 5] : nullptr;
+            auto fork = [&](int k) -> int {      // side stream may start once main has produced dY number k
+                if (ss == st) return 0;
+                int r = (int)hipEventRecord(sev[k], st);
+                if (r) return r;
+                return (int)hipStreamWaitEvent(ss, sev[k], 0);
+            };
+            int nblk = 0;
+            float* lnp_a = (float*)(ws + e->ws_lnp_a);
+            float* lnp_b = (float*)(ws + e->ws_lnp_b);
+            // LN2 + dropout backward (column sums -> per-block partial slabs, reduced once per layer below)
+            CK(ln_backward_partials(dt, dx, ws + w.s2, P + o.ln2w, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, dsA,
+                                    hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(SITE_LAYER0 + 4 * l + 2, c.hidden_dropout), st));
+            CK(fork(0));
+            CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, ss));
+            // du = (dzd . W2) * gelu'(u), with the intermediate bias gradient (column sums of du) fused into the epilogue
+            CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, ws + e->ws_du, I, nullptr, G + o.b1, nullptr,
                     ws + w.u, I, kNoDrop, 1, 0, st));
-            CK(colsum(dt, ws + e->ws_du, I, G + o.b1, T, I, st));
-            CK(wgrad(dt, I, H, Tk, ws + e->ws_du, I, ws + w.y1, H, G + o.w1, H, st));
-            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, I, ws + e->ws_du, I, e->W(o.w1), H, dy1, H, nullptr, nullptr, nullptr, ds,
+            CK(fork(1));
+            CK(wgrad(dt, I, H, Tk, ws + e->ws_du, I, ws + w.y1, H, G + o.w1, H, ss));
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, I, ws + e->ws_du, I, e->W(o.w1), H, dy1, H, nullptr, nullptr, nullptr, dsA,
                     H, kNoDrop, 1, 0, st));
             // LN1 + dropout backward
-            CK(ln_backward(dt, dy1, ws + w.s1, P + o.ln1w, (const float*)(ws + w.st1), (const float*)(ws + w.st1) + T, ds,
-                           hd ? dzd : nullptr, G + o.ln1w, G + o.ln1b, G + o.bo, T, H, kNoDrop,
-                           e->key(SITE_LAYER0 + 4 * l + 1, c.hidden_dropout), st));
-            CK(wgrad(dt, H, H, Tk, dzd, H, ws + w.ctx, H, G + o.wo, H, st));
-            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzd, H, e->W(o.wo), H, ws + e->ws_dctx, H, nullptr, nullptr, nullptr,
+            CK(ln_backward_partials(dt, dy1, ws + w.s1, P + o.ln1w, (const float*)(ws + w.st1), (const float*)(ws + w.st1) + T, dsB,
+                                    hd ? dzdB : nullptr, lnp_b, &nblk, T, H, e->key(SITE_LAYER0 + 4 * l + 1, c.hidden_dropout), st));
+            CK(fork(2));
+            CK(wgrad(dt, H, H, Tk, dzdB, H, ws + w.ctx, H, G + o.wo, H, ss));
+            {
+                float* const dst6[6] = {G + o.ln2w, G + o.ln2b, G + o.b2, G + o.ln1w, G + o.ln1b, G + o.bo};
+                CK(ln_reduce_partials(lnp_a, lnp_b, nblk, H, dst6, st));
+            }
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.wo), H, ws + e->ws_dctx, H, nullptr, nullptr, nullptr,
                     nullptr, 0, kNoDrop, 1, 0, st));
-            CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, ws + e->ws_dqkv, B, L, nh,
+            // attention backward; the fused-QKV bias gradient (column sums of dqkv) is accumulated inside the kernel
+            CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, ws + e->ws_dqkv, G + o.bqkv, B, L, nh,
                                   e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st));
-            CK(colsum(dt, ws + e->ws_dqkv, 3 * H, G + o.bqkv, T, 3 * H, st));
-            CK(wgrad(dt, 3 * H, H, Tk, ws + e->ws_dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H, st));
+            CK(fork(3));
+            CK(wgrad(dt, 3 * H, H, Tk, ws + e->ws_dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H, ss));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, 3 * H, ws + e->ws_dqkv, 3 * H, e->W(o.wqkv), H, dx, H, nullptr, nullptr,
-                    nullptr, ds, H, kNoDrop, 1, 0, st));
+                    nullptr, dsB, H, kNoDrop, 1, 0, st));
+            if (ss != st) {      // join: the stage's gradients are complete (and dY buffers reusable) once main passes this
+                CK((int)hipEventRecord(sev[4], ss));
+                CK((int)hipStreamWaitEvent(st, sev[4], 0));
+            }
         } else {
             // ---- MAG + embeddings
             char* dx = ws + e->ws_dxa;

@@ -114,56 +114,131 @@ __device__ __forceinline__ bool tile_origin(const GemmArgs& p, int& m0, int& n0)
 }
 
 // ------------------------------------------------------------------ shared epilogue
+// The MFMA accumulator layout gives a lane 4 columns of 16 different rows: stored directly that is 32-byte pieces of
+// 16 cache lines per instruction (measured: the epilogue alone was 60 % of the FFN-1 GEMM).  Instead the tile is
+// transposed through LDS (the operand ring is free by now): fp32 tile [BM][BN], 16-byte chunks XOR-swizzled by row,
+// then every thread owns 8 consecutive columns of a row -> bias / residual / output accesses are 16-32-byte vectors
+// and a wave writes whole 128-512-byte row segments.
+template <class T> struct Vec8;
+template <> struct Vec8<bf16> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&v)[8]) {
+        const bf16x8 x = *(const bf16x8*)p;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = (float)x[r];
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float (&v)[8]) {
+        bf16x8 x;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = (bf16)v[r];
+        *(bf16x8*)p = x;
+    }
+};
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = a[r]; v[4 + r] = b[r]; }
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+};
+
 template <class T, int BM, int BN, int MODE>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0, int wr,
-                                              int wc, int lane) {
+                                              int wc, int lane, char* smem) {
     constexpr int MT = BM / 32, NT = BN / 32;
-    // acc[i][j][r] = C[m][n + r],  m = m0 + wr*BM/2 + i*16 + (lane&15),  n = n0 + wc*BN/2 + j*16 + (lane>>4)*4
-    T* __restrict__ C = (T*)p.C;
+    constexpr int RBY = BN * 4;                     // staged row bytes (fp32)
+    constexpr int TPR = BN / 8;                     // threads per row in the row-major pass
+    constexpr int RPP = 256 / TPR;                  // rows per pass
+    __syncthreads();                                // every wave is done with the operand stages
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m = m0 + wr * (BM / 2) + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int n = n0 + wc * (BN / 2) + j * 16 + (lane >> 4) * 4;
-            if (n >= p.N) continue;
-            f32x4 v = acc[i][j];
-            if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_F32) {
-                v *= p.alpha;
-                if (p.bias) v += *(const f32x4*)(p.bias + n);
-                if constexpr (MODE == EPI_BIAS) store4(C + (size_t)m * p.ldc + n, v);
-                else store4(p.Cf + (size_t)m * p.ldc + n, v);
-            } else if constexpr (MODE == EPI_BIAS_GELU) {
-                v += *(const f32x4*)(p.bias + n);
-                f32x4 g = {gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
-                store4(C + (size_t)m * p.ldc + n, v);
-                store4((T*)p.C2 + (size_t)m * p.ldc + n, g);
-            } else if constexpr (MODE == EPI_BIAS_DROP_RES) {
-                v += *(const f32x4*)(p.bias + n);
-                const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+            const int r = wr * (BM / 2) + i * 16 + (lane & 15);
+            const int ch = (wc * (BN / 2) + j * 16 + (lane >> 4) * 4) >> 2;
+            *(f32x4*)(smem + r * RBY + ((ch ^ (r & 7)) << 4)) = acc[i][j];
+        }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    const int c = (tid % TPR) * 8;
+    const int n = n0 + c;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_F32 || MODE == EPI_BIAS_GELU || MODE == EPI_BIAS_DROP_RES) {
+        if (p.bias && n < p.N) Vec8<float>::load(p.bias + n, bias8);
+    }
+    T* __restrict__ C = (T*)p.C;
+#pragma unroll 2
+    for (int r = tid / TPR; r < BM; r += RPP) {
+        const int m = m0 + r;
+        if (m >= p.M || n >= p.N) continue;
+        float v[8];
+        {
+            const int ch = c >> 2;
+            const f32x4 a = *(const f32x4*)(smem + r * RBY + ((ch ^ (r & 7)) << 4));
+            const f32x4 b = *(const f32x4*)(smem + r * RBY + (((ch + 1) ^ (r & 7)) << 4));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= drop_mult(p.drop, idx + r);
-                v += load4((const T*)p.R + (size_t)m * p.ldr + n);
-                store4(C + (size_t)m * p.ldc + n, v);
-            } else if constexpr (MODE == EPI_ADD_RES) {
-                if (p.R) v += load4((const T*)p.R + (size_t)m * p.ldr + n);
-                store4(C + (size_t)m * p.ldc + n, v);
-            } else if constexpr (MODE == EPI_DGELU) {
-                f32x4 u = load4((const T*)p.R + (size_t)m * p.ldr + n);
+            for (int q = 0; q < 4; ++q) { v[q] = a[q]; v[4 + q] = b[q]; }
+        }
+        const size_t off = (size_t)m * p.ldc + n;
+        if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_F32) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
-                store4(C + (size_t)m * p.ldc + n, v);
-            } else if constexpr (MODE == EPI_ACCUM_F32) {
-                float* dst = p.Cf + (size_t)m * p.ldc + n;
-                if (gridDim.y > 1) {
+            for (int q = 0; q < 8; ++q) v[q] = v[q] * p.alpha + bias8[q];
+            if constexpr (MODE == EPI_BIAS) Vec8<T>::store(C + off, v);
+            else Vec8<float>::store(p.Cf + off, v);
+        } else if constexpr (MODE == EPI_BIAS_GELU) {
+            float g[8];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
-                } else {
-                    f32x4 o = *(f32x4*)dst;
-                    o += v;
-                    *(f32x4*)dst = o;
-                }
+            for (int q = 0; q < 8; ++q) { v[q] += bias8[q]; g[q] = gelu_f(v[q]); }
+            Vec8<T>::store(C + off, v);
+            Vec8<T>::store((T*)p.C2 + off, g);
+        } else if constexpr (MODE == EPI_BIAS_DROP_RES) {
+            float res[8];
+            Vec8<T>::load((const T*)p.R + (size_t)m * p.ldr + n, res);
+            const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (v[q] + bias8[q]) * drop_mult(p.drop, idx + q) + res[q];
+            Vec8<T>::store(C + off, v);
+        } else if constexpr (MODE == EPI_ADD_RES) {
+            if (p.R) {
+                float res[8];
+                Vec8<T>::load((const T*)p.R + (size_t)m * p.ldr + n, res);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += res[q];
+            }
+            Vec8<T>::store(C + off, v);
+        } else if constexpr (MODE == EPI_DGELU) {
+            float u[8];
+            Vec8<T>::load((const T*)p.R + (size_t)m * p.ldr + n, u);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { v[q] *= dgelu_f(u[q]); cs[q] += v[q]; }
+            Vec8<T>::store(C + off, v);
+        } else if constexpr (MODE == EPI_ACCUM_F32) {
+            float* dst = p.Cf + off;
+            if (gridDim.y > 1) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) atomicAdd(dst + q, v[q]);
+            } else {
+                float o[8];
+                Vec8<float>::load(dst, o);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] += v[q];
+                Vec8<float>::store(dst, o);
+            }
+        }
+    }
+    if constexpr (MODE == EPI_DGELU) {
+        // fused bias gradient: this thread summed its rows; lanes that share the column group differ by TPR in lane id
+        if (p.colsum) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float s = cs[q];
+#pragma unroll
+                for (int o = TPR; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+                if (lane < TPR && n < p.N) atomicAdd(p.colsum + n + q, s);
             }
         }
     }
@@ -235,7 +310,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
-    gemm_epilogue<T, BM, BN, MODE>(p, acc, m0, n0, wr, wc, lane);
+    gemm_epilogue<T, BM, BN, MODE>(p, acc, m0, n0, wr, wc, lane, smem);
 }
 
 
@@ -255,12 +330,19 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 template <int RB> __device__ __forceinline__ int kswz(int k) { return RB >= 256 ? ((k & 3) << 1) : (((k >> 1) & 1) << 1); }
 
-template <class T, int BROWS, bool KMAJ>
+// KB = bytes of k per stage row (128 or 64).  A smaller KB halves the stage, so twice as many stages (bytes in flight)
+// fit next to the stage being multiplied -- the fill rate of a CU is latency x bytes-in-flight bound.
+template <class T, int BROWS, bool KMAJ, int KB>
 struct Dma {
     static constexpr int EPV = 16 / sizeof(T);
     static constexpr int RB = BROWS * (int)sizeof(T);      // kmaj image row bytes
-    static constexpr int NI = BROWS / 32;                  // 1-KB pieces per wave per stage
+    static constexpr int CPR = KB / 16;                    // 16-B chunks per row-image row (8 or 4)
+    static constexpr int RPI = 64 / CPR;                   // row-image rows per 1-KB DMA piece (8 or 16)
+    static constexpr int NI = BROWS * KB / 4096;           // 1-KB pieces per wave per stage
     typedef typename Frag<T>::type frag_t;
+
+    // physical chunk of logical chunk lc in row r of the row image (conflict-free ds_read_b128)
+    static __device__ __forceinline__ int rswz(int lc, int r) { return KB == 128 ? (lc ^ (r & 7)) : (lc ^ ((r >> 1) & 3)); }
 
     static __device__ __forceinline__ void issue(const T* __restrict__ base, int ld, int row0, int nrows, int k0,
                                                  char* lds, int lane, int wave) {
@@ -269,8 +351,8 @@ struct Dma {
             const int blk = i * 4 + wave;
             const T* src;
             if constexpr (!KMAJ) {
-                const int r = blk * 8 + (lane >> 3);
-                const int lc = (lane & 7) ^ (r & 7);
+                const int r = blk * RPI + lane / CPR;
+                const int lc = rswz(lane % CPR, r);       // XOR swizzle is an involution: physical -> logical
                 int g = row0 + r;
                 g = g < nrows ? g : nrows - 1;          // rows past the edge: any valid row (their outputs are never stored)
                 src = base + (size_t)g * ld + k0 + lc * EPV;
@@ -291,7 +373,7 @@ struct Dma {
         if constexpr (!KMAJ) {
             const int r = rbase + (lane & 15);
             const int lc = s * 4 + (lane >> 4);
-            return *(const frag_t*)(lds + r * 128 + ((lc ^ (r & 7)) << 4));
+            return *(const frag_t*)(lds + r * KB + (rswz(lc, r) << 4));
         } else if constexpr (sizeof(T) == 2) {
             const int i = lane & 15;
             const int colb = (rbase + (i & 3) * 4) * 2;
@@ -320,16 +402,17 @@ struct Dma {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE>
+template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB>
 __global__ void __launch_bounds__(256) gemm2_kernel(const GemmArgs p) {
-    constexpr int BKE = 128 / sizeof(T);
+    constexpr int BKE = KB / sizeof(T);
     constexpr int MT = BM / 32, NT = BN / 32;
-    constexpr int STAGE = (BM + BN) * 128;
-    constexpr int G = (BM + BN) / 32;             // DMA instructions per wave per stage
+    constexpr int STAGE = (BM + BN) * KB;
     typedef typename Frag<T>::type frag_t;
-    typedef Dma<T, BM, AK> DA;
-    typedef Dma<T, BN, BK> DB;
-    __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
+    typedef Dma<T, BM, AK, KB> DA;
+    typedef Dma<T, BN, BK, KB> DB;
+    constexpr int G = DA::NI + DB::NI;            // DMA instructions per wave per stage
+    constexpr int SMEM = NSTAGE * STAGE > BM * BN * 4 ? NSTAGE * STAGE : BM * BN * 4;     // ring, reused by the epilogue tile
+    __shared__ __attribute__((aligned(1024))) char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -349,9 +432,10 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const GemmArgs p) {
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto issue = [&](int t) {
+        if (p.dbg & 1) return;
         char* st = smem + (t % NSTAGE) * STAGE;
         DA::issue(A, p.lda, m0, p.M, kbeg + t * BKE, st, lane, wave);
-        DB::issue(B, p.ldb, n0, p.N, kbeg + t * BKE, st + BM * 128, lane, wave);
+        DB::issue(B, p.ldb, n0, p.N, kbeg + t * BKE, st + BM * KB, lane, wave);
     };
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
@@ -360,26 +444,41 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const GemmArgs p) {
     for (int t = 0; t < nt; ++t) {
         // stage t must have landed; up to NSTAGE-2 younger stages may stay in flight
         const int younger = min(NSTAGE - 2, nt - 1 - t);
-        if (NSTAGE >= 4 && younger >= 2) wait_vmcnt<2 * G>();
+        if (NSTAGE >= 5 && younger >= 3) wait_vmcnt<3 * G>();
+        else if (NSTAGE >= 4 && younger >= 2) wait_vmcnt<2 * G>();
         else if (NSTAGE >= 3 && younger >= 1) wait_vmcnt<G>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();            // everyone's piece of stage t landed; everyone left stage t-1
         if (t + NSTAGE - 1 < nt) issue(t + NSTAGE - 1);
         const char* cur = smem + (t % NSTAGE) * STAGE;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < KB / 64; ++s) {
             frag_t a[MT], b[NT];
+            if (!(p.dbg & 4)) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = DA::frag(cur, wr * (BM / 2) + i * 16, s, lane);
+                for (int i = 0; i < MT; ++i) a[i] = DA::frag(cur, wr * (BM / 2) + i * 16, s, lane);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = DB::frag(cur + BM * 128, wc * (BN / 2) + j * 16, s, lane);
+                for (int j = 0; j < NT; ++j) b[j] = DB::frag(cur + BM * KB, wc * (BN / 2) + j * 16, s, lane);
+            } else {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i) asm volatile("" : "=v"(a[i]));
 #pragma unroll
-                for (int j = 0; j < NT; ++j) mma16(acc[i][j], b[j], a[i]);
+                for (int j = 0; j < NT; ++j) asm volatile("" : "=v"(b[j]));
+            }
+            if (!(p.dbg & 2)) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) mma16(acc[i][j], b[j], a[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(a[i]));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(b[j]));
+            }
         }
     }
-    gemm_epilogue<T, BM, BN, MODE>(p, acc, m0, n0, wr, wc, lane);
+    gemm_epilogue<T, BM, BN, MODE>(p, acc, m0, n0, wr, wc, lane, smem);
 }
 
 // ---------------------------------------------------------------------------------------------- host
@@ -387,7 +486,7 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-static int g_impl = -1, g_stages = -1;      // MB_GEMM_IMPL: 0 auto, 1 = register-staged v1, 2 = LDS-DMA v2 ; MB_GEMM_STAGES: 2|3|4
+static int g_impl = -1, g_stages = -1, g_dbg = 0;      // MB_GEMM_IMPL: 0 auto, 1 = register-staged v1, 2 = LDS-DMA v2 ; MB_GEMM_STAGES: 2|3|4
 
 template <class T, int BM, int BN, bool AK, bool BK, int MODE>
 static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
@@ -411,40 +510,50 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
     splits = (p.K + kchunk - 1) / kchunk;
     p.kchunk = kchunk;
     dim3 grid(tiles, splits);
-    if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); }
+    if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
+    p.dbg = g_dbg;
     // v2 preconditions (see the kernel header)
     bool v2ok = (p.K % BKE == 0) && (p.lda % EPV == 0) && (p.ldb % EPV == 0) && (((uintptr_t)p.A | (uintptr_t)p.B) % 16 == 0);
     if (AK) v2ok = v2ok && (p.M % BM == 0);
     if (BK) v2ok = v2ok && (p.N % BN == 0);
     if (g_impl == 1) v2ok = false;
     if (v2ok) {
-        int ns = g_stages ? g_stages : (BM == 128 ? 2 : 3);
-        if (BM == 128 && ns > 3) ns = 3;          // 3 x 32 KB = 96 KB of the 160 KB LDS
-        if (ns == 2) hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, 2>), grid, dim3(256), 0, st, p);
-        else if (ns == 3) hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, 3>), grid, dim3(256), 0, st, p);
-        else {
-            if constexpr (BM == 64) hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, 4>), grid, dim3(256), 0, st, p);
+        // (KB, NSTAGE) per tile: MB_GEMM_STAGES = 10*KBsel + stages overrides (KBsel 1 -> 128-byte rows, 2 -> 64-byte rows)
+        int ns = 2, kb = 128;      // measured best (per-layer GEMM 290 us): deeper rings / 64-byte rows do not pay
+        if (g_stages > 0) { kb = (g_stages / 10 == 2) ? 64 : 128; ns = g_stages % 10; }
+        if (kb == 64 && (p.kchunk % (64 / (int)sizeof(T)) != 0)) kb = 128;
+#define MB_LAUNCH2(NS, KBV) hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, NS, KBV>), grid, dim3(256), 0, st, p)
+        if (kb == 128) {
+            if (BM == 128) { if (ns <= 2) MB_LAUNCH2(2, 128); else MB_LAUNCH2(3, 128); }
+            else { if (ns <= 2) MB_LAUNCH2(2, 128); else if (ns == 3) MB_LAUNCH2(3, 128); else MB_LAUNCH2(4, 128); }
+        } else {
+            if (ns <= 3) MB_LAUNCH2(3, 64); else if (ns == 4) MB_LAUNCH2(4, 64); else MB_LAUNCH2(5, 64);
         }
+#undef MB_LAUNCH2
     } else {
         hipLaunchKernelGGL((gemm_kernel<T, BM, BN, AK, BK, MODE>), grid, dim3(256), 0, st, p);
     }
     return (int)hipGetLastError();
 }
 
+static int g_tile_n768 = -1;       // MB_GEMM_TILE_N768: tile code for auto-selected narrow GEMMs (64 | 12864 | 128)
+
 template <class T, bool AK, bool BK, int MODE>
 static int launch_tile(const GemmArgs& a, int splits, int tile, hipStream_t st) {
     if (tile == 0) {   // heuristic: fill >= ~1 wave of the 256 CUs
         const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (splits < 1 ? 1 : splits);
-        tile = (t128 >= 224) ? 128 : 64;
+        if (g_tile_n768 < 0) g_tile_n768 = env_int("MB_GEMM_TILE_N768", 64);
+        tile = (t128 >= 224) ? 128 : g_tile_n768;
     }
     if (tile == 128) return launch_cfg<T, 128, 128, AK, BK, MODE>(a, splits, st);
+    if (tile == 12864) return launch_cfg<T, 128, 64, AK, BK, MODE>(a, splits, st);
     return launch_cfg<T, 64, 64, AK, BK, MODE>(a, splits, st);
 }
 
 template <class T>
 static int launch_T(const GemmArgs& a, int layout, int mode, int splits, int tile, hipStream_t st) {
     constexpr int BKE = 128 / sizeof(T);
-    if (a.N % 4 != 0) return MB_ERR_SHAPE;
+    if (a.N % 8 != 0 || a.ldc % 8 != 0) return MB_ERR_SHAPE;      // the row-major epilogue pass owns 8 columns per thread
     if (layout == GEMM_NT) {
         if (a.K % BKE != 0) return MB_ERR_SHAPE;
         switch (mode) {

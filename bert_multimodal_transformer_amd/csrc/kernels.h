@@ -32,10 +32,12 @@ struct GemmArgs {
     void* C2;                  // second T output (mode 1), same ldc
     float* Cf;                 // fp32 output (modes 5, 6), ldc
     const float* bias;         // [N] fp32 or null
+    float* colsum;             // EPI_DGELU: if non-null, colsum[n] += sum_m C[m][n] (bias grad of the previous Linear)
     const void* R; int ldr;    // residual / aux input (T)
     float alpha;
     DropKey drop;
     int kchunk;                // filled by the launcher
+    int dbg;                   // ablation switches (MB_GEMM_DBG): 1 = no DMA issue, 2 = no MFMA, 4 = no LDS fragment reads
     int reg_m, reg_n, tpr_m, tpr_n;   // XCD regions (filled by the launcher): reg_m*reg_n == 8, tiles per region
 };
 
@@ -53,6 +55,12 @@ int ln_forward(int dtype, const void* x, const float* gamma, const float* beta, 
 int ln_backward(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                 void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias,
                 int rows, int H, DropKey drop_out, DropKey drop_in, hipStream_t st);
+// same, but the three column sums go to per-block partial slabs partials[nblk][3][H] (no atomics); returns nblk through
+// *nblk.  ln_reduce_partials adds them into up to 6 destinations in one launch (two LayerNorms of a layer).
+size_t ln_partials_floats(int rows, int H);
+int ln_backward_partials(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                         void* dx, void* dx_drop, float* partials, int* nblk, int rows, int H, DropKey drop_in, hipStream_t st);
+int ln_reduce_partials(const float* partials_a, const float* partials_b, int nblk, int H, float* const* dst6, hipStream_t st);
 
 // BertEmbeddings: e = dropout(LN(word[ids] + pos[l] + type[seg])).
 int embed_ln_forward(int dtype, const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
@@ -97,8 +105,9 @@ int mag_gate_backward(int dtype, const void* dout, const void* e, const void* Ze
 // ctx: [B*L][H].  softmax(QK^T/sqrt(dh) + (1-mask)*-10000) -> dropout -> . V   (dh = 64, L <= 128)
 int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx, int B, int L, int nh,
                       DropKey drop, hipStream_t st);
+// dbias (fp32 [3H], may be null): += column sums of dqkv (bias grads of the fused QKV Linear)
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx,
-                       void* dqkv, int B, int L, int nh, DropKey drop, hipStream_t st);
+                       void* dqkv, float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------ head (head.hip)
 // pooled = tanh(z) ; logits = dropout(pooled) Wc^T + bc ; optional MSE loss (mean over B*nl) accumulated into loss[0]

@@ -79,7 +79,7 @@ __device__ __forceinline__ void block_colsum_atomic(f32x4 (&part)[NQ][CH], float
 }
 
 // ------------------------------------------------------------------------------------------ LayerNorm backward
-template <class T, int CH, int RPW>
+template <class T, int CH, int RPW, bool PARTIAL>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
@@ -134,8 +134,48 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, c
             part[2][c] += d;
         }
     }
-    float* const dst[3] = {dgamma, dbeta, dbias};
-    block_colsum_atomic<CH, 3>(part, dst, lds);
+    if constexpr (PARTIAL) {
+        // dgamma points at partials[nblk][3][H]: this block's slab gets the 4-wave sums, no atomics
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) *(f32x4*)(lds + (wave * 3 + q) * H + (c * 64 + lane) * 4) = part[q][c];
+        __syncthreads();
+        float* slab = dgamma + (size_t)blockIdx.x * 3 * H;
+        for (int i = threadIdx.x; i < 3 * H; i += 256) {
+            const int q = i / H, col = i % H;
+            slab[i] = lds[(0 * 3 + q) * H + col] + lds[(1 * 3 + q) * H + col] + lds[(2 * 3 + q) * H + col] +
+                      lds[(3 * 3 + q) * H + col];
+        }
+    } else {
+        float* const dst[3] = {dgamma, dbeta, dbias};
+        block_colsum_atomic<CH, 3>(part, dst, lds);
+    }
+}
+
+// out[q][col] += sum_b partials[b][q][col] for two partial sets (q = 0..2 from set a, 3..5 from set b).
+// grid (H/64, 6, 8): the slabs are split 8 ways across blocks and 4 ways across the waves of a block, one atomic per
+// column per block at the end (8-way contention).
+__global__ void __launch_bounds__(256) ln_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int nblk,
+                                                        int H, float* d0, float* d1, float* d2, float* d3, float* d4,
+                                                        float* d5) {
+    const int q = blockIdx.y;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = (threadIdx.x >> 6) + 4 * blockIdx.z;    // 0 .. 4*gridDim.z-1
+    const int nparts = 4 * gridDim.z;
+    __shared__ float red[4][64];
+    float* dsts[6] = {d0, d1, d2, d3, d4, d5};
+    float* dst = dsts[q];
+    const float* src = q < 3 ? pa : pb;
+    float s = 0.f;
+    if (dst != nullptr && src != nullptr && col < H) {
+        const int qq = q % 3;
+        for (int b = part; b < nblk; b += nparts) s += src[((size_t)b * 3 + qq) * H + col];
+    }
+    red[threadIdx.x >> 6][threadIdx.x & 63] = s;
+    __syncthreads();
+    if ((threadIdx.x >> 6) == 0 && dst != nullptr && src != nullptr && col < H)
+        atomicAdd(dst + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------ embeddings
@@ -315,10 +355,34 @@ int ln_backward(int dtype, const void* dy, const void* x, const float* gamma, co
     if (rows <= 0) return MB_OK;
     constexpr int RPW = 4;
     MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
-        hipLaunchKernelGGL((ln_bwd_kernel<T, CH, RPW>), dim3((rows + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st,
+        hipLaunchKernelGGL((ln_bwd_kernel<T, CH, RPW, false>), dim3((rows + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st,
                            (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, (T*)dx_drop, dgamma, dbeta, dbias, rows,
                            drop_out, drop_in);
     }))
+    return (int)hipGetLastError();
+}
+
+constexpr int LN_RPW = 2;     // rows per wave in the partial-sum variant (8 rows per block -> 300 blocks at T = 2400)
+size_t ln_partials_floats(int rows, int H) { return (size_t)((rows + 4 * LN_RPW - 1) / (4 * LN_RPW)) * 3 * H; }
+
+int ln_backward_partials(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                         void* dx, void* dx_drop, float* partials, int* nblk, int rows, int H, DropKey drop_in,
+                         hipStream_t st) {
+    if (rows <= 0) { *nblk = 0; return MB_OK; }
+    const int nb = (rows + 4 * LN_RPW - 1) / (4 * LN_RPW);
+    *nblk = nb;
+    const DropKey nodrop = {0u, 0u, 0u, 1.0f};
+    MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
+        hipLaunchKernelGGL((ln_bwd_kernel<T, CH, LN_RPW, true>), dim3(nb), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma,
+                           mean, rstd, (T*)dx, (T*)dx_drop, partials, (float*)nullptr, (float*)nullptr, rows, nodrop, drop_in);
+    }))
+    return (int)hipGetLastError();
+}
+
+int ln_reduce_partials(const float* pa, const float* pb, int nblk, int H, float* const* d, hipStream_t st) {
+    if (nblk <= 0) return MB_OK;
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((H + 63) / 64, 6, 8), dim3(256), 0, st, pa, pb, nblk, H, d[0], d[1], d[2], d[3], d[4],
+                       d[5]);
     return (int)hipGetLastError();
 }
 

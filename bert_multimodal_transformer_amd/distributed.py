@@ -98,15 +98,23 @@ class DataParallel(object):
         self.reducer = GradReducer(self.core.grads, process_group)
         self.world = self.reducer.world
         self.plan, self.tail = stage_plan(self.core)
-        self.core.grad_hook = self._on_stage
+        self.core.stage_hooks.insert(0, self._on_stage)      # before any optimizer-overlap hook
         self.sync = True          # set False on gradient-accumulation micro-steps (multimodal_driver.py:383)
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
+            optimizer._dp = self
 
     def broadcast_parameters(self, src=0):
         if self.world > 1:
             dist.broadcast(self.core.params, src=src, group=self.reducer.pg)
             self.core.weights_dirty = True
+
+    def ready_ranges(self, stage):
+        """flat gradient ranges whose all-reduce has been enqueued once `stage` is done"""
+        r = list(self.plan[stage])
+        if stage == len(self.plan) - 1:
+            r.append(self.tail)
+        return r
 
     def _on_stage(self, stage):
         if not self.sync:
@@ -114,7 +122,8 @@ class DataParallel(object):
         self.reducer.reduce_ranges(self.plan[stage])
         if stage == len(self.plan) - 1:
             self.reducer.reduce_ranges([self.tail])
-            self.reducer.wait()
+            if not getattr(self, "defer_wait", False):
+                self.reducer.wait()
 
     def __getattr__(self, name):
         return getattr(self.model, name)
