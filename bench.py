@@ -156,11 +156,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the product path)")
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local if torch.cuda.device_count() > local else 0)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        dist.init_process_group(os.environ.get("MB_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
+                                **({"device_id": torch.device("cuda", local)} if os.environ.get("MB_DIST_BACKEND", "nccl") == "nccl" else {}))
     if a.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d (using WORLD_SIZE)" % (a.gpus, world), file=sys.stderr)
 
@@ -194,7 +195,7 @@ def main():
     model.train()
     nb = 8
     batches = make_batches(nb, B, L, V, A, seed=1234 + rank)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", torch.cuda.current_device())
 
     def step(i):
         batch = tuple(t.to(dev, non_blocking=True) for t in batches[i % nb])          # H2D (multimodal_driver.py:359)
