@@ -1,0 +1,188 @@
+"""TEST INFRASTRUCTURE -- pure-torch fp32 CPU restatement of the MAG-XLNet hot path (BASELINE.json config 4).
+
+Restates MAG_XLNetModel.forward / MAG_XLNetForSequenceClassification.forward (xlnet.py:148-429, 443-527) for the only
+configuration the driver exercises (xlnet-base-cased: attn_type "bi", bi_data False, clamp_len -1, mem_len None, no
+perm_mask / target_mapping / mems; multimodal_driver.py:363-370) and the transformers==3.0.2 XLNetLayer
+(XLNetRelativeAttention + XLNetFeedForward) and SequenceSummary it calls (xlnet.py:30,374-385,438,508).  Checked against
+the reference's own Python by oracle/make_golden.py (G6 fixtures).  Works in the reference's [L, B, .] layout internally.
+
+State-dict keys = the reference's: transformer.word_embedding.weight, transformer.mask_emb,
+transformer.layer.{i}.rel_attn.{q,k,v,o,r,r_r_bias,r_s_bias,r_w_bias,seg_embed,layer_norm.*},
+transformer.layer.{i}.ff.{layer_norm,layer_1,layer_2}.*, transformer.MAG.*, sequence_summary.summary.*, logits_proj.*
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .mag_bert_ref import MAG, MultimodalConfig  # noqa: F401
+
+
+class XLNetConfigLite(object):
+    def __init__(self, vocab_size=32000, d_model=768, n_layer=12, n_head=12, d_inner=3072, dropout=0.1,
+                 layer_norm_eps=1e-12, summary_last_dropout=0.1, num_labels=1, initializer_range=0.02):
+        self.vocab_size = vocab_size
+        self.d_model = d_model
+        self.hidden_size = d_model
+        self.n_layer = n_layer
+        self.n_head = n_head
+        self.d_head = d_model // n_head
+        self.d_inner = d_inner
+        self.dropout = dropout
+        self.layer_norm_eps = layer_norm_eps
+        self.summary_last_dropout = summary_last_dropout
+        self.num_labels = num_labels
+        self.initializer_range = initializer_range
+
+
+class XLNetRelativeAttention(nn.Module):
+    """3.0.2 XLNetRelativeAttention, single-stream branch (g is None)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.n_head, self.d_head, self.scale = c.n_head, c.d_head, 1 / (c.d_head ** 0.5)
+        for n in ("q", "k", "v", "o", "r"):
+            setattr(self, n, nn.Parameter(torch.zeros(c.d_model, c.n_head, c.d_head)))
+        self.r_r_bias = nn.Parameter(torch.zeros(c.n_head, c.d_head))
+        self.r_s_bias = nn.Parameter(torch.zeros(c.n_head, c.d_head))
+        self.r_w_bias = nn.Parameter(torch.zeros(c.n_head, c.d_head))
+        self.seg_embed = nn.Parameter(torch.zeros(2, c.n_head, c.d_head))
+        self.layer_norm = nn.LayerNorm(c.d_model, eps=c.layer_norm_eps)
+        self.dropout = nn.Dropout(c.dropout)
+
+    @staticmethod
+    def rel_shift_bnij(x, klen):
+        s = x.shape
+        x = x.reshape(s[0], s[1], s[3], s[2])[:, :, 1:, :]
+        x = x.reshape(s[0], s[1], s[2], s[3] - 1)
+        return x[:, :, :, :klen]          # => bd[i, j] = raw[i, L - i + j]
+
+    def forward(self, h, attn_mask, r, seg_mat):
+        q = torch.einsum("ibh,hnd->ibnd", h, self.q)
+        k = torch.einsum("ibh,hnd->ibnd", h, self.k)
+        v = torch.einsum("ibh,hnd->ibnd", h, self.v)
+        kr = torch.einsum("ibh,hnd->ibnd", r, self.r)
+        ac = torch.einsum("ibnd,jbnd->bnij", q + self.r_w_bias, k)
+        bd = self.rel_shift_bnij(torch.einsum("ibnd,jbnd->bnij", q + self.r_r_bias, kr), ac.shape[3])
+        ef = torch.einsum("ibnd,snd->ibns", q + self.r_s_bias, self.seg_embed)
+        ef = torch.einsum("ijbs,ibns->bnij", seg_mat, ef)
+        score = (ac + bd + ef) * self.scale
+        score = score - 1e30 * torch.einsum("ijbn->bnij", attn_mask)
+        p = self.dropout(F.softmax(score, dim=3))
+        vec = torch.einsum("bnij,jbnd->ibnd", p, v)
+        out = self.dropout(torch.einsum("ibnd,hnd->ibh", vec, self.o))
+        return self.layer_norm(out + h)
+
+
+class XLNetFeedForward(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(c.d_model, eps=c.layer_norm_eps)
+        self.layer_1 = nn.Linear(c.d_model, c.d_inner)
+        self.layer_2 = nn.Linear(c.d_inner, c.d_model)
+        self.dropout = nn.Dropout(c.dropout)
+
+    def forward(self, inp):
+        out = self.dropout(F.gelu(self.layer_1(inp)))
+        out = self.dropout(self.layer_2(out))
+        return self.layer_norm(out + inp)
+
+
+class XLNetLayer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.rel_attn = XLNetRelativeAttention(c)
+        self.ff = XLNetFeedForward(c)
+
+    def forward(self, h, attn_mask, r, seg_mat):
+        return self.ff(self.rel_attn(h, attn_mask, r, seg_mat))
+
+
+class MAG_XLNetModel(nn.Module):
+    """xlnet.py:15-429 (driver configuration only)."""
+
+    def __init__(self, config, multimodal_config, visual_dim=47, acoustic_dim=74, injection_index=1):
+        super().__init__()
+        self.d_model, self.n_layer, self.injection_index = config.d_model, config.n_layer, injection_index
+        self.word_embedding = nn.Embedding(config.vocab_size, config.d_model)          # xlnet.py:28
+        self.mask_emb = nn.Parameter(torch.zeros(1, 1, config.d_model))                # xlnet.py:29 (unused here)
+        self.layer = nn.ModuleList([XLNetLayer(config) for _ in range(config.n_layer)])
+        self.dropout = nn.Dropout(config.dropout)
+        self.MAG = MAG(config.d_model, multimodal_config.beta_shift, multimodal_config.dropout_prob, visual_dim, acoustic_dim)
+
+    def relative_positional_encoding(self, qlen, klen, bsz):
+        """xlnet.py:104-146 with attn_type "bi", bi_data False, clamp_len -1; positional_embedding :93-102."""
+        freq_seq = torch.arange(0, self.d_model, 2.0, dtype=torch.float)
+        inv_freq = 1 / torch.pow(10000, (freq_seq / self.d_model))
+        pos_seq = torch.arange(klen, -qlen, -1.0)
+        sinusoid = torch.einsum("i,d->id", pos_seq, inv_freq)
+        pos_emb = torch.cat([torch.sin(sinusoid), torch.cos(sinusoid)], dim=-1)
+        return pos_emb[:, None, :].expand(-1, bsz, -1)
+
+    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids):
+        ids = input_ids.transpose(0, 1).contiguous()                                    # xlnet.py:206
+        L, B = ids.shape
+        visual = visual.transpose(0, 1).contiguous()                                    # xlnet.py:215-216
+        acoustic = acoustic.transpose(0, 1).contiguous()
+        seg = token_type_ids.transpose(0, 1).contiguous()
+        input_mask = 1.0 - attention_mask.transpose(0, 1).contiguous().float()          # xlnet.py:263-264
+        attn_mask = (input_mask[None][:, :, :, None] > 0).float()                       # xlnet.py:267-286 : [1, L, B, 1]
+        non_tgt = ((attn_mask - torch.eye(L)[:, :, None, None]) > 0).float()            # xlnet.py:288-296 : [L, L, B, 1]
+        h = self.dropout(self.word_embedding(ids))                                      # xlnet.py:304-305
+        seg_mat = (seg[:, None] != seg[None, :]).long()                                 # xlnet.py:326
+        seg_mat = F.one_hot(seg_mat, num_classes=2).float()                             # xlnet.py:327
+        pos_emb = self.dropout(self.relative_positional_encoding(L, L, B))              # xlnet.py:332-333
+        for i, layer in enumerate(self.layer):
+            if i == self.injection_index:
+                h = self.MAG(h, visual, acoustic)                                       # xlnet.py:371-372
+            h = layer(h, non_tgt, pos_emb, seg_mat)                                     # xlnet.py:374-385
+        return self.dropout(h).permute(1, 0, 2).contiguous()                            # xlnet.py:396-399
+
+
+class SequenceSummary(nn.Module):
+    """3.0.2 SequenceSummary for xlnet-base-cased: summary_type "last", use_proj, tanh, last dropout 0.1."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.summary = nn.Linear(c.d_model, c.d_model)
+        self.last_dropout = nn.Dropout(c.summary_last_dropout)
+
+    def forward(self, hidden):
+        return self.last_dropout(torch.tanh(self.summary(hidden[:, -1])))
+
+
+class MAG_XLNetForSequenceClassification(nn.Module):
+    """xlnet.py:432-527."""
+
+    def __init__(self, config, multimodal_config, visual_dim=47, acoustic_dim=74, injection_index=1):
+        super().__init__()
+        self.num_labels = config.num_labels
+        self.transformer = MAG_XLNetModel(config, multimodal_config, visual_dim, acoustic_dim, injection_index)
+        self.sequence_summary = SequenceSummary(config)
+        self.logits_proj = nn.Linear(config.d_model, config.num_labels)
+
+    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels=None):
+        out = self.transformer(input_ids, visual, acoustic, attention_mask, token_type_ids)
+        logits = self.logits_proj(self.sequence_summary(out))                           # xlnet.py:506-509
+        outputs = (logits,)
+        if labels is not None:
+            outputs = (F.mse_loss(logits.view(-1), labels.view(-1)),) + outputs
+        return outputs
+
+
+def load_deterministic(model, mode="test"):
+    from . import weights
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(torch.from_numpy(weights.make_param(name, tuple(p.shape), mode)))
+    return model
+
+
+def set_dropout(model, p_hidden=None, p_mag=None):
+    for name, m in model.named_modules():
+        if isinstance(m, nn.Dropout):
+            if name.endswith("MAG.dropout"):
+                if p_mag is not None:
+                    m.p = p_mag
+            elif p_hidden is not None:
+                m.p = p_hidden
+    return model

@@ -250,6 +250,60 @@ def gen_full(cb, modeling, bert):
     np.savez_compressed(os.path.join(GOLD, "g4g5_full_model.npz"), **out)
 
 
+def gen_xlnet(modeling, xlnet):
+    """G6: MAG-XLNet -- eval logits (B=4, 48; L=50), train-mode p=0 loss + per-tensor grad norms, one XLNetLayer out."""
+    from transformers.models.xlnet import modeling_xlnet as mx, configuration_xlnet as cx
+    from oracle import weights
+    from oracle import mag_xlnet_ref as X
+    out = {}
+
+    def pair(n_layer=12, p_mag=0.5):
+        modeling.VISUAL_DIM = 47
+        cfg = cx.XLNetConfig(d_model=768, n_layer=n_layer, n_head=12, d_inner=3072, mem_len=None, num_labels=1)
+        ref = xlnet.MAG_XLNetForSequenceClassification(cfg, MC(1.0, p_mag))
+        _load(ref, "test")
+        mine = X.MAG_XLNetForSequenceClassification(X.XLNetConfigLite(n_layer=n_layer), X.MultimodalConfig(1.0, p_mag), 47, 74)
+        mine.load_state_dict(ref.state_dict(), strict=True)
+        return ref, mine
+
+    ref, mine = pair()
+    ref.eval(); mine.eval()
+    for (B, L, seed) in ((4, 50, 31), (48, 50, 32)):
+        ids, vis, aco, mask, seg, lab = _tb(weights.synthetic_xlnet_batch(B, L, 47, 74, seed=seed))
+        with torch.no_grad():
+            a = ref(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
+            b = mine(ids, vis, aco, mask, seg)[0]
+        d = _maxdiff(a, b)
+        print("G6 xlnet logits B=%d L=%d: max |diff| = %.3g (|logit| max %.3g)" % (B, L, d, float(a.abs().max())))
+        assert d < 2e-5
+        out["logits/B%d_L%d_seed%d" % (B, L, seed)] = a.numpy()
+    ref, mine = pair(p_mag=0.0)
+    for m in (ref, mine):
+        m.train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+    ids, vis, aco, mask, seg, lab = _tb(weights.synthetic_xlnet_batch(4, 50, 47, 74, seed=33))
+    losses, grads = [], []
+    for m, call in ((ref, lambda m: m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]),
+                    (mine, lambda m: m(ids, vis, aco, mask, seg)[0])):
+        m.zero_grad()
+        loss = torch.nn.MSELoss()(call(m).view(-1), lab.view(-1))
+        loss.backward()
+        losses.append(loss.detach())
+        grads.append({n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()})
+    gmax = max(float(g.abs().max()) for g in grads[0].values())
+    rel = {n: _maxdiff(grads[0][n], grads[1][n]) / max(float(grads[0][n].abs().max()), 1e-3 * gmax) for n in grads[0]}
+    worst = max(rel, key=rel.get)
+    print("G6 xlnet loss ref %.6f mine %.6f ; worst relative grad diff %.3g (%s)" % (losses[0], losses[1], rel[worst], worst))
+    assert abs(float(losses[0] - losses[1])) < 1e-5 and rel[worst] < 1e-3
+    out["train/loss_B4_L50_seed33"] = np.float32(losses[0].item())
+    for n, g in grads[0].items():
+        out["train/gnorm/" + n] = np.float32(g.norm().item())
+        out["train/gslice/" + n] = _slice(g, 16)
+    np.savez_compressed(os.path.join(GOLD, "g6_xlnet.npz"), **out)
+
+
 class FakeTokenizer(object):
     """Stands in for BertTokenizer / XLNetTokenizer (no vocab files offline): splits a word into
     2-character pieces and maps pieces to ids by a fixed hash, so integer layout can be pinned."""
@@ -310,7 +364,7 @@ def main():
     torch.set_num_threads(4)
     os.makedirs(GOLD, exist_ok=True)
     cb, modeling, bert, xlnet = install_shim()
-    which = sys.argv[1:] or ["mag", "layer", "full", "features"]
+    which = sys.argv[1:] or ["mag", "layer", "full", "features", "xlnet"]
     if "mag" in which:
         gen_mag(modeling)
     if "layer" in which:
@@ -319,6 +373,8 @@ def main():
         gen_full(cb, modeling, bert)
     if "features" in which:
         gen_features()
+    if "xlnet" in which:
+        gen_xlnet(modeling, xlnet)
 
 
 if __name__ == "__main__":

@@ -99,3 +99,30 @@ def strided_sample(arr, n=32):
         return f[:k].astype(np.float32)
     idx = (np.arange(k, dtype=np.int64) * (f.size - 1)) // (k - 1)
     return f[idx].astype(np.float32)
+
+
+def synthetic_xlnet_batch(B, L, V, A, seed=1234, vocab=32000, min_len=5):
+    """Synthetic batch in the layout prepare_xlnet_input produces (multimodal_driver.py:176-205): LEFT padded,
+    ids = [5(pad)..., tokens, 4(<sep>), 3(<cls>)], mask 0 on pads, segment ids 3 on pads / 0 on tokens+sep / 2 on cls,
+    modality rows exact zeros on pad / sep / cls rows."""
+    tag = "xbatch%d" % seed
+    n = randint(tag + ".len", (B,), min_len, L - 2 + 1)
+    ids = np.full((B, L), 5, np.int64)
+    mask = np.zeros((B, L), np.int64)
+    seg = np.full((B, L), 3, np.int64)
+    vis = uniform(tag + ".vis", (B, L, V), -2.0, 2.0)
+    aco = uniform(tag + ".aco", (B, L, A), -2.0, 2.0)
+    tok = randint(tag + ".tok", (B, L), 10, vocab)
+    for b in range(B):
+        k = int(n[b])
+        pad = L - k - 2
+        ids[b, pad:pad + k] = tok[b, :k]
+        ids[b, L - 2] = 4
+        ids[b, L - 1] = 3
+        mask[b, pad:] = 1
+        seg[b, pad:L - 1] = 0
+        seg[b, L - 1] = 2
+        vis[b, :pad] = 0; vis[b, L - 2:] = 0
+        aco[b, :pad] = 0; aco[b, L - 2:] = 0
+    label = uniform(tag + ".label", (B,), -3.0, 3.0)
+    return dict(input_ids=ids, visual=vis, acoustic=aco, input_mask=mask, segment_ids=seg, label_ids=label)
