@@ -12,9 +12,10 @@ from . import _lib
 from .global_configs import ACOUSTIC_DIM, VISUAL_DIM, TEXT_DIM
 from .modeling import MAG
 from .bert import BertConfig, MAG_BertModel, MAG_BertForSequenceClassification
+from .xlnet import XLNetConfig, MAG_XLNetModel, MAG_XLNetForSequenceClassification
 from .optimization import AdamW, get_linear_schedule_with_warmup
 from .multimodal_driver import MultimodalConfig
 
-__all__ = ["MAG", "MAG_BertModel", "MAG_BertForSequenceClassification", "BertConfig", "MultimodalConfig", "AdamW",
+__all__ = ["MAG", "MAG_BertModel", "MAG_BertForSequenceClassification", "BertConfig", "XLNetConfig", "MAG_XLNetModel", "MAG_XLNetForSequenceClassification", "MultimodalConfig", "AdamW",
            "get_linear_schedule_with_warmup", "ACOUSTIC_DIM", "VISUAL_DIM", "TEXT_DIM"]
 __version__ = "0.1.0"

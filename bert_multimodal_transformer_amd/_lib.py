@@ -24,6 +24,14 @@ class BertEngineConfig(C.Structure):
                 ("dtype", C.c_int), ("max_batch", C.c_int), ("max_seq", C.c_int)]
 
 
+class XlnetEngineConfig(C.Structure):
+    _fields_ = [("vocab_size", C.c_int), ("d_model", C.c_int), ("n_layer", C.c_int), ("n_head", C.c_int), ("d_inner", C.c_int),
+                ("num_labels", C.c_int), ("visual_dim", C.c_int), ("acoustic_dim", C.c_int), ("injection_index", C.c_int),
+                ("layer_norm_eps", C.c_float), ("mag_layer_norm_eps", C.c_float), ("beta_shift", C.c_float),
+                ("dropout", C.c_float), ("summary_last_dropout", C.c_float), ("mag_dropout", C.c_float),
+                ("dtype", C.c_int), ("max_batch", C.c_int), ("max_seq", C.c_int)]
+
+
 _vp, _i, _f, _sz, _u64, _u32 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64, C.c_uint32
 _dk = C.POINTER(DropKey)
 
@@ -60,6 +68,21 @@ PROTOTYPES = {
     "mb_bert_sequence_output": (_vp, [_vp]),
     "mb_bert_pooled_output": (_vp, [_vp]),
     "mb_bert_stage_grad_ranges": (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz), _i]),
+    "mb_xlnet_create": (_i, [C.POINTER(XlnetEngineConfig), C.POINTER(_vp)]),
+    "mb_xlnet_destroy": (None, [_vp]),
+    "mb_xlnet_num_tensors": (_i, [_vp]),
+    "mb_xlnet_tensor_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i),
+                                  C.POINTER(C.c_int64), C.POINTER(_i)]),
+    "mb_xlnet_param_count": (_sz, [_vp]),
+    "mb_xlnet_decay_count": (_sz, [_vp]),
+    "mb_xlnet_shadow_range": (None, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
+    "mb_xlnet_workspace_bytes": (_sz, [_vp]),
+    "mb_xlnet_bind": (_i, [_vp, _vp, _vp, _vp, _vp, _sz]),
+    "mb_xlnet_sync_weights": (_i, [_vp, _vp]),
+    "mb_xlnet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "mb_xlnet_backward": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp]),
+    "mb_xlnet_sequence_output": (_vp, [_vp]),
+    "mb_xlnet_stage_grad_ranges": (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz), _i]),
 }
 
 _lib = None

@@ -78,7 +78,10 @@ class _EngineFn(torch.autograd.Function):
 class _Core(object):
     """Flat parameter/gradient storage + engine handle shared by the model classes."""
 
-    def __init__(self, config, multimodal_config, visual_dim, acoustic_dim, compute_dtype, device):
+    def __init__(self, config, multimodal_config, visual_dim, acoustic_dim, compute_dtype, device, kind="bert",
+                 injection_index=1):
+        self.kind = kind                     # "bert" (mb_bert_*) or "xlnet" (mb_xlnet_*)
+        self.injection_index = injection_index
         if not torch.cuda.is_available():
             raise _lib.MagbertError("MAG-BERT runs on the HIP path only: no ROCm device visible (no CPU fallback)")
         self.lib = _lib.lib()
@@ -96,11 +99,11 @@ class _Core(object):
         self._own_stream = None
         self.stage_hooks = []          # callables hook(stage) run after each backward stage (DataParallel, AdamW overlap)
         self._make_engine(1, 8)
-        n = self.lib.mb_bert_param_count(self.handle)
+        n = self._fn("param_count")(self.handle)
         self.n_params = n
-        self.n_decay = self.lib.mb_bert_decay_count(self.handle)
+        self.n_decay = self._fn("decay_count")(self.handle)
         b, e = C.c_size_t(), C.c_size_t()
-        self.lib.mb_bert_shadow_range(self.handle, C.byref(b), C.byref(e))
+        self._fn("shadow_range")(self.handle, C.byref(b), C.byref(e))
         self.sh_begin, self.sh_end = b.value, e.value
         self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.grads = torch.zeros(n, dtype=torch.float32, device=self.device)
@@ -112,8 +115,20 @@ class _Core(object):
         self.loss_buf = torch.zeros(2, dtype=torch.float32, device=self.device)   # [last step, running sum]
 
     # -- engine lifecycle ---------------------------------------------------------------------------
+    def _fn(self, name):
+        return getattr(self.lib, "mb_%s_%s" % (self.kind, name))
+
+    @property
+    def n_layers(self):
+        return self.config.num_hidden_layers if self.kind == "bert" else self.config.n_layer
+
     def _cfg(self, B, L):
         c, mc = self.config, self.mc
+        if self.kind == "xlnet":
+            return _lib.XlnetEngineConfig(
+                c.vocab_size, c.d_model, c.n_layer, c.n_head, c.d_inner, c.num_labels, self.V, self.A, int(self.injection_index),
+                c.layer_norm_eps, 1e-5, float(mc.beta_shift), c.dropout, c.summary_last_dropout, float(mc.dropout_prob),
+                self.dt, int(B), int(L))
         return _lib.BertEngineConfig(
             c.vocab_size, c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.intermediate_size,
             c.max_position_embeddings, c.type_vocab_size, c.num_labels, self.V, self.A, c.pad_token_id,
@@ -122,19 +137,19 @@ class _Core(object):
 
     def _make_engine(self, B, L):
         if self.handle is not None:
-            self.lib.mb_bert_destroy(self.handle)
+            self._fn("destroy")(self.handle)
         h = C.c_void_p()
         cfg = self._cfg(B, L)
-        _lib.check(self.lib.mb_bert_create(C.byref(cfg), C.byref(h)))
+        _lib.check(self._fn("create")(C.byref(cfg), C.byref(h)))
         self.handle = h
         self.max_B, self.max_L = B, L
 
     def _ensure(self, B, L):
         if B > self.max_B or L > self.max_L or self.ws is None:
             self._make_engine(max(B, self.max_B), max(L, self.max_L))
-            nbytes = self.lib.mb_bert_workspace_bytes(self.handle)
+            nbytes = self._fn("workspace_bytes")(self.handle)
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            _lib.check(self.lib.mb_bert_bind(self.handle, _lib.ptr(self.params), _lib.ptr(self.grads),
+            _lib.check(self._fn("bind")(self.handle, _lib.ptr(self.params), _lib.ptr(self.grads),
                                              _lib.ptr(self.shadow) if self.dt == _lib.DT_BF16 else None,
                                              _lib.ptr(self.ws), nbytes))
             self.weights_dirty = True
@@ -144,11 +159,11 @@ class _Core(object):
         name = C.create_string_buffer(160)
         off, numel, ndim, decay = C.c_size_t(), C.c_size_t(), C.c_int(), C.c_int()
         shape = (C.c_int64 * 4)()
-        for i in range(self.lib.mb_bert_num_tensors(self.handle)):
-            _lib.check(self.lib.mb_bert_tensor_info(self.handle, i, name, 160, C.byref(off), C.byref(numel), C.byref(ndim),
+        for i in range(self._fn("num_tensors")(self.handle)):
+            _lib.check(self._fn("tensor_info")(self.handle, i, name, 160, C.byref(off), C.byref(numel), C.byref(ndim),
                                                     shape, C.byref(decay)))
             out.append((name.value.decode(), off.value, numel.value, tuple(shape[k] for k in range(ndim.value)),
-                        bool(decay.value)))
+                        int(decay.value)))      # 1 decay, 0 no-decay, 2 frozen (never receives a gradient)
         return out
 
     def stream(self):
@@ -183,7 +198,7 @@ class _Core(object):
     def sync_weights(self):
         """refresh bf16 shadow + packed MAG operands from the fp32 masters (after load / manual edits)"""
         with _Core._Hop(self):
-            _lib.check(self.lib.mb_bert_sync_weights(self.handle, self.stream()))
+            _lib.check(self._fn("sync_weights")(self.handle, self.stream()))
         self.weights_dirty = False
 
     # -- passes --------------------------------------------------------------------------------------
@@ -208,7 +223,7 @@ class _Core(object):
         self._keep = (ids, msk, seg, vis, aco, lab, logits)      # engine keeps raw pointers until the backward
         self.training_last = bool(training)
         with _Core._Hop(self):
-            _lib.check(self.lib.mb_bert_forward(self.handle, _lib.ptr(ids), _lib.ptr(vis), _lib.ptr(aco), _lib.ptr(msk),
+            _lib.check(self._fn("forward")(self.handle, _lib.ptr(ids), _lib.ptr(vis), _lib.ptr(aco), _lib.ptr(msk),
                                                 _lib.ptr(seg), _lib.ptr(lab), B, L, 1 if training else 0, self.seed,
                                                 self.step, _lib.ptr(logits), C.c_void_p(self.loss_buf.data_ptr()),
                                                 C.c_void_p(self.loss_buf.data_ptr() + 4) if lab is not None else None,
@@ -216,13 +231,13 @@ class _Core(object):
         return logits
 
     def _backward(self, dlogits=None, loss_scale=1.0):
-        nstage = self.config.num_hidden_layers + 2
+        nstage = self.n_layers + 2
         lab = self._keep[5]
         if dlogits is None and lab is None:
             raise ValueError("fused backward needs the labels passed to forward()")
         with _Core._Hop(self):
             for s in range(nstage):
-                _lib.check(self.lib.mb_bert_backward(self.handle, _lib.ptr(dlogits),
+                _lib.check(self._fn("backward")(self.handle, _lib.ptr(dlogits),
                                                      _lib.ptr(lab) if dlogits is None else None, float(loss_scale), s, s + 1,
                                                      self.stream()))
                 for hook in self.stage_hooks:
@@ -230,7 +245,7 @@ class _Core(object):
 
     def sequence_output(self, B, L):
         H = self.config.hidden_size
-        p = self.lib.mb_bert_sequence_output(self.handle)
+        p = self._fn("sequence_output")(self.handle)
         es = 2 if self.dt == _lib.DT_BF16 else 4
         off = p - self.ws.data_ptr()
         raw = self.ws[off: off + B * L * H * es]
@@ -244,13 +259,13 @@ class _Core(object):
 
     def stage_ranges(self, stage):
         offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
-        n = self.lib.mb_bert_stage_grad_ranges(self.handle, stage, offs, lens, 8)
+        n = self._fn("stage_grad_ranges")(self.handle, stage, offs, lens, 8)
         return [(offs[i], lens[i]) for i in range(n)]
 
     def __del__(self):
         try:
             if self.handle is not None:
-                self.lib.mb_bert_destroy(self.handle)
+                self._fn("destroy")(self.handle)
         except Exception:
             pass
 
@@ -268,8 +283,11 @@ def _attach_parameters(root, core, prefix_filter=None, strip=""):
                 mod.add_module(part, _Holder())
             mod = getattr(mod, part)
         p = nn.Parameter(core.params[off: off + numel].view(shape))
-        p.grad = core.grads[off: off + numel].view(shape)
-        p._mb_flat = (core, off, numel, decay)
+        if decay == 2:          # frozen (e.g. XLNet mask_emb): no gradient ever -> HF AdamW would skip it; so do we
+            p._mb_flat = None
+        else:
+            p.grad = core.grads[off: off + numel].view(shape)
+            p._mb_flat = (core, off, numel, decay)
         mod.register_parameter(parts[-1], p)
 
 
@@ -284,13 +302,13 @@ def _init_weights(core):
         for name, off, numel, shape, decay in core.tensors:
             v = core.params[off: off + numel]
             leaf = name.split(".")[-1]
-            if "LayerNorm" in name:
+            if "LayerNorm" in name or "layer_norm" in name:
                 v.fill_(1.0 if leaf == "weight" else 0.0)
             elif leaf == "bias":
                 v.zero_()
             else:
                 v.normal_(0.0, std, generator=g)
-                if name.endswith("word_embeddings.weight"):
+                if name.endswith("word_embeddings.weight"):       # BERT: nn.Embedding(padding_idx=pad_token_id)
                     H = shape[1]
                     v[core.config.pad_token_id * H:(core.config.pad_token_id + 1) * H].zero_()
     core.weights_dirty = True

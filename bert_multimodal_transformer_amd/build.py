@@ -9,8 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmagbert_hip.so")
-SOURCES = ["gemm.hip", "rowops.hip", "mag.hip", "attention.hip", "head.hip", "adamw.hip", "engine.hip"]
-HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "magbert_hip.h")]
+SOURCES = ["gemm.hip", "rowops.hip", "mag.hip", "attention.hip", "xlnet_attention.hip", "xlnet_rowops.hip", "head.hip", "adamw.hip",
+           "engine.hip", "xlnet_engine.hip"]
+HEADERS = ["common.h", "kernels.h", "attn_common.h", "engine_common.h", os.path.join("..", "..", "include", "magbert_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fvisibility=default",
          "-Wno-unused-result"]
 

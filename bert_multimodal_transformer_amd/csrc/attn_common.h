@@ -1,0 +1,55 @@
+// Shared building blocks of the LDS-resident attention kernels (BERT: attention.hip, XLNet: xlnet_attention.hip).
+#pragma once
+#include "kernels.h"
+
+namespace mb {
+
+template <class T> struct AttnCfg;
+template <> struct AttnCfg<bf16> { static constexpr int SLAB = 32, EPV = 8, ROWB = 128; };
+template <> struct AttnCfg<float> { static constexpr int SLAB = 16, EPV = 4, ROWB = 256; };
+
+template <class T>
+__device__ __forceinline__ typename Frag<T>::type frag_nat(const char* img, int pitch, int row, int slab, int lane) {
+    return *(const typename Frag<T>::type*)(img + row * pitch + slab * 64 + (lane >> 4) * 16);
+}
+// fragment of the TRANSPOSED image: element e = img[k0 + e][col]
+__device__ __forceinline__ bf16x8 frag_kmaj(const char* img, int pitch, int k0, int col, bf16) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = *(const bf16*)(img + (k0 + e) * pitch + col * 2);
+    return v;
+}
+__device__ __forceinline__ f32x4 frag_kmaj(const char* img, int pitch, int k0, int col, float) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = *(const float*)(img + (k0 + e) * pitch + col * 4);
+    return v;
+}
+
+// stage rows [0, LP) x 64 elements of one head from the token-major tensor into an LDS image (rows >= L are zero)
+template <class T, int LP, int NTHR>
+__device__ __forceinline__ void stage_head(char* img, int pitch, const T* __restrict__ src, size_t ld, int L) {
+    constexpr int CPR = AttnCfg<T>::ROWB / 16;
+    for (int id = threadIdx.x; id < LP * CPR; id += NTHR) {
+        const int row = id / CPR, c = id % CPR;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < L) v = *(const u32x4*)((const char*)(src + (size_t)row * ld) + c * 16);
+        *(u32x4*)(img + row * pitch + c * 16) = v;
+    }
+}
+
+// row-wise reduction across the 4 lanes {i, i+16, i+32, i+48} that share a query/key row
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+constexpr float kMaskNeg = -10000.0f;     // transformers 3.0.2 get_extended_attention_mask
+constexpr float kPadNeg = -1.0e30f;       // keys beyond L (tile padding only)
+
+
+}  // namespace mb

@@ -13,191 +13,7 @@
 //                   classifier.weight
 //   no-decay group: per layer {q,k,v bias (contiguous [3H]), attn.out bias, LN1 w/b, inter bias, out bias, LN2 w/b};
 //                   embeddings.LayerNorm ; pooler bias ; MAG biases + LayerNorm ; classifier.bias
-#include <string>
-#include <vector>
-#include <cstring>
-#include <cstdio>
-#include <cstdlib>
-#include "kernels.h"
-#include "../../include/magbert_hip.h"
-
-using namespace mb;
-
-namespace {
-
-struct TensorInfo {
-    std::string name;
-    size_t off, numel;
-    int ndim;
-    int64_t shape[4];
-    int decay;
-};
-
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-
-uint64_t splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-
-DropKey make_key(uint64_t seed, uint64_t step, uint32_t site, float p) {
-    DropKey k;
-    if (!(p > 0.f)) { k.k0 = k.k1 = k.thresh = 0; k.scale = 1.f; return k; }
-    const uint64_t h = splitmix64(splitmix64(seed) ^ splitmix64(step * 0x100000001B3ull + site));
-    k.k0 = (uint32_t)h;
-    k.k1 = (uint32_t)(h >> 32);
-    double t = (double)p * 4294967296.0;
-    if (t > 4294967295.0) t = 4294967295.0;
-    k.thresh = (uint32_t)(t + 0.5);
-    k.scale = 1.0f / (1.0f - p);
-    return k;
-}
-const DropKey kNoDrop = {0u, 0u, 0u, 1.0f};
-inline DropKey dk(const mb_dropkey* d) {
-    if (!d) return kNoDrop;
-    DropKey k = {d->k0, d->k1, d->thresh, d->scale};
-    return k;
-}
-
-enum { SITE_EMB = 0, SITE_MAG = 1, SITE_HEAD = 2, SITE_LAYER0 = 16 };   // layer l: 16+4l+{0 attn probs,1 attn out,2 ffn out}
-
-inline size_t esize(int dtype) { return dtype == DT_BF16 ? 2 : 4; }
-
-struct Carver {
-    size_t off = 0;
-    size_t take(size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; }
-};
-
-// workspace of the MAG operator: saved activations + scratch (shared by the op-level API and the engine)
-struct MagWs {
-    int Vp, Ap;
-    size_t We, Wv, Wa, vp, ap, Ze, Zv, Za, mean, rstd;                       // forward (saved)
-    size_t dZe, dZv, dZa, dep, dWe, dWv, dWa, dvp, dap;                      // backward scratch
-    size_t bytes;
-    void init(int dtype, int T_, int H, int V, int A) {
-        const size_t es = esize(dtype);
-        const size_t T = align_up((size_t)T_, 64);   // token rows padded to the GEMM k-tile (pad rows stay zero)
-        Vp = (V + 63) / 64 * 64;
-        Ap = (A + 63) / 64 * 64;
-        Carver c;
-        We = c.take((size_t)2 * H * H * es); Wv = c.take((size_t)2 * H * Vp * es); Wa = c.take((size_t)2 * H * Ap * es);
-        vp = c.take((size_t)T * Vp * es); ap = c.take((size_t)T * Ap * es);
-        Ze = c.take((size_t)T * 2 * H * es); Zv = c.take((size_t)T * 2 * H * es); Za = c.take((size_t)T * 2 * H * es);
-        mean = c.take((size_t)T * 4); rstd = c.take((size_t)T * 4);
-        dZe = c.take((size_t)T * 2 * H * es); dZv = c.take((size_t)T * 2 * H * es); dZa = c.take((size_t)T * 2 * H * es);
-        dep = c.take((size_t)T * H * es);
-        dWe = c.take((size_t)2 * H * H * 4); dWv = c.take((size_t)2 * H * Vp * 4); dWa = c.take((size_t)2 * H * Ap * 4);
-        dvp = c.take((size_t)T * Vp * 4); dap = c.take((size_t)T * Ap * 4);
-        bytes = c.off;
-    }
-};
-
-#define CK(x) do { int _e = (x); if (_e) return _e; } while (0)
-
-int gemm(int dtype, int layout, int mode, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
-         int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, DropKey drop, int splits, int tile,
-         hipStream_t st) {
-    GemmArgs a;
-    a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
-    a.C = C; a.ldc = ldc; a.C2 = C2; a.Cf = Cf; a.bias = bias; a.R = R; a.ldr = ldr; a.alpha = 1.0f; a.drop = drop;
-    a.kchunk = K; a.colsum = nullptr;
-    if (mode == EPI_DGELU) { a.colsum = Cf; a.Cf = nullptr; }     // EPI_DGELU: the fp32 pointer carries the fused bias grad
-    return gemm_launch(dtype, layout, mode, a, splits, tile, st);
-}
-
-// wgrad: dW[N'][K'] += dY^T X, reduction over `rows` tokens; picks tile + split-K to fill the 256 CUs
-int wgrad(int dtype, int Mo, int No, int rows, const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw,
-          hipStream_t st) {
-    const long t128 = (long)((Mo + 127) / 128) * ((No + 127) / 128);
-    const long t64 = (long)((Mo + 63) / 64) * ((No + 63) / 64);
-    // split-K costs one fp32 atomic per output element per split (measured: 4.7 M atomics ~ 50 us), so it is used only
-    // when the tile grid alone cannot occupy the chip
-    int tile, splits;
-    if (t128 >= 256) { tile = 128; splits = 1; }
-    else if (t64 >= 100) { tile = 64; splits = 1; }        // measured: [768x3072] K=2432: 64^2 32 us vs 128^2 52 us
-    else { tile = 64; splits = (int)((256 + t64 - 1) / t64); }
-    if (splits > 8) splits = 8;
-    while (splits > 1 && rows / splits < 128) --splits;
-    if (splits < 1) splits = 1;
-    (void)t128;
-    return gemm(dtype, GEMM_TN, EPI_ACCUM_F32, Mo, No, rows, dY, ldy, X, ldx, nullptr, ldw, nullptr, dW, nullptr, nullptr, 0,
-                kNoDrop, splits, tile, st);
-}
-
-// ------------------------------------------------------------------------------------------------ MAG operator
-int mag_fwd_impl(int dtype, const void* text, const float* visual, const float* acoustic, const float* W_hv,
-                 const float* b_hv, const float* W_ha, const float* b_ha, const float* W_v, const float* b_v,
-                 const float* W_a, const float* b_a, const float* ln_w, const float* ln_b, float ln_eps, float beta_shift,
-                 DropKey drop, void* out, char* ws, const MagWs& w, int T, int H, int V, int A, bool repack, hipStream_t st) {
-    MagDims d = {T, H, V, A, w.Vp, w.Ap};
-    if (repack) CK(mag_pack_weights(dtype, W_hv, W_ha, W_v, W_a, ws + w.We, ws + w.Wv, ws + w.Wa, d, st));
-    CK(pack_pad(dtype, visual, V, ws + w.vp, w.Vp, T, st));
-    CK(pack_pad(dtype, acoustic, A, ws + w.ap, w.Ap, T, st));
-    {
-        const int Tp = (int)align_up((size_t)T, 64);
-        const size_t es = esize(dtype);
-        if (Tp > T) {
-            CK((int)hipMemsetAsync(ws + w.vp + (size_t)T * w.Vp * es, 0, (size_t)(Tp - T) * w.Vp * es, st));
-            CK((int)hipMemsetAsync(ws + w.ap + (size_t)T * w.Ap * es, 0, (size_t)(Tp - T) * w.Ap * es, st));
-        }
-    }
-    CK(gemm(dtype, GEMM_NT, EPI_BIAS, T, 2 * H, H, text, H, ws + w.We, H, ws + w.Ze, 2 * H, nullptr, nullptr, nullptr,
-            nullptr, 0, kNoDrop, 1, 0, st));
-    CK(gemm(dtype, GEMM_NT, EPI_BIAS, T, 2 * H, w.Vp, ws + w.vp, w.Vp, ws + w.Wv, w.Vp, ws + w.Zv, 2 * H, nullptr, nullptr,
-            nullptr, nullptr, 0, kNoDrop, 1, 0, st));
-    CK(gemm(dtype, GEMM_NT, EPI_BIAS, T, 2 * H, w.Ap, ws + w.ap, w.Ap, ws + w.Wa, w.Ap, ws + w.Za, 2 * H, nullptr, nullptr,
-            nullptr, nullptr, 0, kNoDrop, 1, 0, st));
-    CK(mag_gate_forward(dtype, text, ws + w.Ze, ws + w.Zv, ws + w.Za, b_hv, b_ha, b_v, b_a, ln_w, ln_b, ln_eps, beta_shift,
-                        out, (float*)(ws + w.mean), (float*)(ws + w.rstd), d, drop, st));
-    return MB_OK;
-}
-
-int mag_bwd_impl(int dtype, const void* d_out, const void* text, const float* b_hv, const float* b_ha, const float* b_v,
-                 const float* b_a, const float* ln_w, float beta_shift, DropKey drop, char* ws, const MagWs& w, void* d_text,
-                 float* d_visual, float* d_acoustic, float* dW_hv, float* db_hv, float* dW_ha, float* db_ha, float* dW_v,
-                 float* db_v, float* dW_a, float* db_a, float* dln_w, float* dln_b, int T, int H, int V, int A,
-                 bool text_padded, hipStream_t st) {
-    MagDims d = {T, H, V, A, w.Vp, w.Ap};
-    const int Tp = (int)align_up((size_t)T, 64);      // zero-padded token rows of the workspace operands
-    const size_t es = esize(dtype);
-    if (Tp > T) {                                     // keep the pad rows of this call's k-major operands zero
-        CK((int)hipMemsetAsync(ws + w.dZe + (size_t)T * 2 * H * es, 0, (size_t)(Tp - T) * 2 * H * es, st));
-        CK((int)hipMemsetAsync(ws + w.dZv + (size_t)T * 2 * H * es, 0, (size_t)(Tp - T) * 2 * H * es, st));
-        CK((int)hipMemsetAsync(ws + w.dZa + (size_t)T * 2 * H * es, 0, (size_t)(Tp - T) * 2 * H * es, st));
-    }
-    CK(mag_gate_backward(dtype, d_out, text, ws + w.Ze, ws + w.Zv, ws + w.Za, b_hv, b_ha, b_v, b_a, ln_w,
-                         (const float*)(ws + w.mean), (const float*)(ws + w.rstd), beta_shift, ws + w.dep, ws + w.dZe,
-                         ws + w.dZv, ws + w.dZa, db_hv, db_ha, db_v, db_a, dln_w, dln_b, d, drop, st));
-    // packed weight grads (dWe, dWv, dWa are contiguous in the workspace up to alignment: clear each)
-    CK((int)hipMemsetAsync(ws + w.dWe, 0, (size_t)2 * H * H * 4, st));
-    CK((int)hipMemsetAsync(ws + w.dWv, 0, (size_t)2 * H * w.Vp * 4, st));
-    CK((int)hipMemsetAsync(ws + w.dWa, 0, (size_t)2 * H * w.Ap * 4, st));
-    CK(wgrad(dtype, 2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H, st));
-    CK(wgrad(dtype, 2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp, st));
-    CK(wgrad(dtype, 2 * H, w.Ap, Tp, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap, st));
-    CK(mag_unpack_wgrads((const float*)(ws + w.dWe), (const float*)(ws + w.dWv), (const float*)(ws + w.dWa), dW_hv, dW_ha,
-                         dW_v, dW_a, d, st));
-    // d_text = dZe . We + (ds + d||e|| term)
-    CK(gemm(dtype, GEMM_NN, EPI_ADD_RES, T, H, 2 * H, ws + w.dZe, 2 * H, ws + w.We, H, d_text, H, nullptr, nullptr, nullptr,
-            ws + w.dep, H, kNoDrop, 1, 0, st));
-    if (d_visual) {
-        CK(gemm(dtype, GEMM_NN, EPI_BIAS_F32, T, w.Vp, 2 * H, ws + w.dZv, 2 * H, ws + w.Wv, w.Vp, nullptr, w.Vp, nullptr,
-                (float*)(ws + w.dvp), nullptr, nullptr, 0, kNoDrop, 1, 0, st));
-        CK((int)hipMemcpy2DAsync(d_visual, (size_t)V * 4, ws + w.dvp, (size_t)w.Vp * 4, (size_t)V * 4, T,
-                                 hipMemcpyDeviceToDevice, st));
-    }
-    if (d_acoustic) {
-        CK(gemm(dtype, GEMM_NN, EPI_BIAS_F32, T, w.Ap, 2 * H, ws + w.dZa, 2 * H, ws + w.Wa, w.Ap, nullptr, w.Ap, nullptr,
-                (float*)(ws + w.dap), nullptr, nullptr, 0, kNoDrop, 1, 0, st));
-        CK((int)hipMemcpy2DAsync(d_acoustic, (size_t)A * 4, ws + w.dap, (size_t)w.Ap * 4, (size_t)A * 4, T,
-                                 hipMemcpyDeviceToDevice, st));
-    }
-    return MB_OK;
-}
-
-}  // namespace
+#include "engine_common.h"
 
 // ================================================================================================ engine
 struct LayerOff { size_t wqkv, wo, w1, w2, bqkv, bo, ln1w, ln1b, b1, b2, ln2w, ln2b; };

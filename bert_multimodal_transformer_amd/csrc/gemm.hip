@@ -191,8 +191,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
             else Vec8<float>::store(p.Cf + off, v);
         } else if constexpr (MODE == EPI_BIAS_GELU) {
             float g[8];
+            const uint32_t gidx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;   // XLNet drops the activation (modeling_xlnet FF)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { v[q] += bias8[q]; g[q] = gelu_f(v[q]); }
+            for (int q = 0; q < 8; ++q) { v[q] += bias8[q]; g[q] = gelu_f(v[q]) * drop_mult(p.drop, gidx + q); }
             Vec8<T>::store(C + off, v);
             Vec8<T>::store((T*)p.C2 + off, g);
         } else if constexpr (MODE == EPI_BIAS_DROP_RES) {
@@ -213,8 +214,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         } else if constexpr (MODE == EPI_DGELU) {
             float u[8];
             Vec8<T>::load((const T*)p.R + (size_t)m * p.ldr + n, u);
+            const uint32_t gidx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { v[q] *= dgelu_f(u[q]); cs[q] += v[q]; }
+            for (int q = 0; q < 8; ++q) { v[q] *= dgelu_f(u[q]) * drop_mult(p.drop, gidx + q); cs[q] += v[q]; }
             Vec8<T>::store(C + off, v);
         } else if constexpr (MODE == EPI_ACCUM_F32) {
             float* dst = p.Cf + off;

@@ -109,6 +109,24 @@ int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx,
                        void* dqkv, float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st);
 
+// ------------------------------------------------------------------------------------------ XLNet (xlnet_attention.hip, xlnet_rowops.hip)
+// relative attention core, L <= 64.  qkv [T][3H] token-major, kr [B][2L][H], psave/gsave [B][nh][L][L].
+int xlnet_attention_forward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
+                            const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask, void* vec,
+                            void* psave, int B, int L, int nh, DropKey drop, hipStream_t st);
+int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
+                             const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask,
+                             const void* psave, const void* dvec, void* gsave, void* dqkv, void* dkr, float* d_rwb,
+                             float* d_rrb, float* d_rsb, float* d_seg, int B, int L, int nh, DropKey drop, hipStream_t st);
+// out[t] = dropout(word[ids[t]])  (xlnet.py:304-305) ; backward scatter-adds into dword
+int gather_drop_forward(int dtype, const int64_t* ids, const float* word, void* out, int rows, int H, DropKey drop, hipStream_t st);
+int gather_drop_backward(int dtype, const void* dout, const int64_t* ids, float* dword, int rows, int H, DropKey drop, hipStream_t st);
+// pos[b][p][:] = dropout([sin(pos_p * inv_freq) | cos(...)]) with pos_p = L - p, p in [0, 2L)   (xlnet.py:93-146,332-333)
+int xlnet_pos_emb(int dtype, void* out, int B, int L, int H, DropKey drop, hipStream_t st);
+// xs[b] = x[b, L-1, :] * dropout   (final dropout xlnet.py:396 + SequenceSummary "last") ; backward scatters into a zeroed dx
+int last_token_forward(int dtype, const void* x, void* xs, int B, int L, int H, DropKey drop, hipStream_t st);
+int last_token_backward(int dtype, const void* dxs, void* dx, int B, int L, int H, DropKey drop, hipStream_t st);
+
 // ------------------------------------------------------------------------------------------ head (head.hip)
 // pooled = tanh(z) ; logits = dropout(pooled) Wc^T + bc ; optional MSE loss (mean over B*nl) accumulated into loss[0]
 // and (if non-null) into the running sum loss_run[0].

@@ -1,0 +1,493 @@
+// XLNet relative attention core (transformers 3.0.2 XLNetRelativeAttention.rel_attn_core, reached from
+// /root/reference/xlnet.py:374-385), forward and backward, L <= 64, head dim 64, one workgroup per (batch, head):
+//     ac[i,j] = (q_i + r_w_bias) . k_j
+//     bd[i,j] = (q_i + r_r_bias) . kr_{L-i+j}          (rel_shift folded into the index: no [L,2L] reshape tricks)
+//     ef[i,j] = (q_i + r_s_bias) . seg_embed[seg_i != seg_j]
+//     P = dropout(softmax((ac+bd+ef)/8 - 1e30 * [key j is padding and i != j])) ;  vec = P V
+// q|k|v come token-major from three projections into one [T][3H] buffer, kr = (dropped sinusoid) . W_r is [B][2L][H].
+// The biases are folded as per-column constants ((q+b).k = q.k + b.k), so one Q image serves all three terms.
+// Unlike the BERT kernel the probabilities ARE written out (P, and G = dL/d(ac+bd+ef) in the backward, [B,nh,L,L],
+// 2.9 MB/layer in bf16): the backward needs them in three index spaces (query-major, key-major, shifted position-major)
+// and keeping three transposed copies plus five operand images in LDS does not fit 160 KB in fp32.
+//   xl_attn_fwd    : scores -> softmax -> P (saved, undropped) -> vec
+//   xl_attn_bwd_q  : dP, G (saved), dq = G.K + Gshift.KR + sum_j G.seg ; r_w/r_r/r_s bias and seg_embed gradients
+//   xl_attn_bwd_kv : dv = Pd^T dO ; dk = G^T (q + r_w_bias) ; dkr[p] = sum_i G[i, p-L+i] (q_i + r_r_bias)
+#include "attn_common.h"
+
+namespace mb {
+
+constexpr float kXlMask = 1.0e30f;      // modeling_xlnet: attn_score - 1e30 * attn_mask (fp32)
+
+struct XlParams {
+    const float* r_w_bias; const float* r_r_bias; const float* r_s_bias;   // [nh][64]
+    const float* seg_embed;                                                // [2][nh][64]
+    const int64_t* seg; const int64_t* mask;                               // [B][L]
+};
+
+template <class T> __device__ __forceinline__ float ldT(const char* img, int pitch, int row, int d) {
+    return to_f(*(const T*)(img + row * pitch + d * (int)sizeof(T)));
+}
+
+// ================================================================================================ forward
+template <class T, int LP, int NW>
+__global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ kr,
+                                                              XlParams xp, T* __restrict__ vec, T* __restrict__ psave,
+                                                              int L, int nh, DropKey drop) {
+    typedef AttnCfg<T> C;
+    constexpr int RP = 2 * LP;
+    constexpr int PIT = C::ROWB + 16;
+    constexpr int SPIT = LP * (int)sizeof(T) + 16;
+    constexpr int RPIT = RP * 4 + 16;                  // raw (fp32) strip pitch
+    constexpr int NT = LP / 16, DSL = 64 / C::SLAB, LSL = LP / C::SLAB;
+    __shared__ __attribute__((aligned(16))) char smem[(3 * LP + RP + 16) * PIT + NW * 16 * (RPIT + SPIT) + (LP + RP + 4 + 2 * LP) * 4];
+    char* Qi = smem;
+    char* Ki = Qi + LP * PIT;
+    char* Vi = Ki + LP * PIT;
+    char* Ri = Vi + LP * PIT;                          // KR image [RP][64]
+    char* Si = Ri + RP * PIT;                          // seg_embed image [16][64] (rows 0,1)
+    char* raws = Si + 16 * PIT;
+    char* pstr = raws + NW * 16 * RPIT;
+    float* cK = (float*)(pstr + NW * 16 * SPIT);
+    float* cR = cK + LP;
+    float* cS = cR + RP;
+    int* segv = (int*)(cS + 4);
+    int* padf = segv + LP;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    const int H = nh * 64;
+    const size_t ld = (size_t)3 * H;
+    const T* base = qkv + (size_t)b * L * ld + h * 64;
+    stage_head<T, LP, NW * 64>(Qi, PIT, base, ld, L);
+    stage_head<T, LP, NW * 64>(Ki, PIT, base + H, ld, L);
+    stage_head<T, LP, NW * 64>(Vi, PIT, base + 2 * H, ld, L);
+    stage_head<T, RP, NW * 64>(Ri, PIT, kr + (size_t)b * 2 * L * H + h * 64, (size_t)H, 2 * L);
+    for (int t = threadIdx.x; t < 16 * 64; t += NW * 64) {
+        const int row = t >> 6, d = t & 63;
+        *(T*)(Si + row * PIT + d * (int)sizeof(T)) = from_f<T>(row < 2 ? xp.seg_embed[((size_t)row * nh + h) * 64 + d] : 0.f);
+    }
+    for (int j = threadIdx.x; j < LP; j += NW * 64) {
+        segv[j] = j < L ? (int)xp.seg[(size_t)b * L + j] : -1;
+        padf[j] = (j < L && xp.mask[(size_t)b * L + j] == 0) ? 1 : 0;
+    }
+    __syncthreads();
+    const float* rwb = xp.r_w_bias + h * 64;
+    const float* rrb = xp.r_r_bias + h * 64;
+    const float* rsb = xp.r_s_bias + h * 64;
+    for (int t = threadIdx.x; t < LP + RP + 2; t += NW * 64) {
+        float s = 0.f;
+        if (t < LP) { for (int d = 0; d < 64; ++d) s += rwb[d] * ldT<T>(Ki, PIT, t, d); cK[t] = s; }
+        else if (t < LP + RP) { for (int d = 0; d < 64; ++d) s += rrb[d] * ldT<T>(Ri, PIT, t - LP, d); cR[t - LP] = s; }
+        else { for (int d = 0; d < 64; ++d) s += rsb[d] * ldT<T>(Si, PIT, t - LP - RP, d); cS[t - LP - RP] = s; }
+    }
+    __syncthreads();
+
+    char* raw = raws + wave * 16 * RPIT;
+    char* Ps = pstr + wave * 16 * SPIT;
+    const float scale = 0.125f;
+    for (int s0 = 0; s0 < NT; s0 += NW) {
+        const int strip = s0 + wave;
+        const bool active = strip < NT;
+        f32x4 ac[NT];
+        float e0 = 0.f, e1 = 0.f;
+        if (active) {
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                ac[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < DSL; ++sl)
+                    mma16(ac[jt], frag_nat<T>(Ki, PIT, jt * 16 + (lane & 15), sl, lane),
+                          frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
+            }
+#pragma unroll
+            for (int pt = 0; pt < 2 * NT; ++pt) {
+                f32x4 rw = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < DSL; ++sl)
+                    mma16(rw, frag_nat<T>(Ri, PIT, pt * 16 + (lane & 15), sl, lane),
+                          frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
+                const int p0 = pt * 16 + (lane >> 4) * 4;
+                rw += *(const f32x4*)(cR + p0);
+                *(f32x4*)(raw + (lane & 15) * RPIT + p0 * 4) = rw;          // raw[i][p] = (q_i + r_r_bias) . kr_p
+            }
+            f32x4 ev = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sl = 0; sl < DSL; ++sl)
+                mma16(ev, frag_nat<T>(Si, PIT, lane & 15, sl, lane), frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
+            e0 = __shfl(ev[0] + cS[0], lane & 15, 64);     // lanes 0..15 hold E[i][s = 0, 1]
+            e1 = __shfl(ev[1] + cS[1], lane & 15, 64);
+        }
+        __syncthreads();
+        if (active) {
+            const int i = strip * 16 + (lane & 15);
+            const int si = segv[i];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jt * 16 + (lane >> 4) * 4 + r;
+                    int p = L - i + j;
+                    p = p < 0 ? 0 : (p > RP - 1 ? RP - 1 : p);
+                    const float bd = *(const float*)(raw + (lane & 15) * RPIT + p * 4);
+                    float s = (ac[jt][r] + cK[j] + bd + (si == segv[j] ? e0 : e1)) * scale;
+                    if (j >= L) s = kPadNeg;
+                    else if (padf[j] && i != j) s -= kXlMask;
+                    ac[jt][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+            }
+            mx = quad_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ac[jt][r] = __expf(ac[jt][r] - mx); sum += ac[jt][r]; }
+            const float inv = 1.0f / quad_sum(sum);
+            const uint32_t rowidx = ((uint32_t)blockIdx.x * L + (uint32_t)i) * L;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const int j = jt * 16 + (lane >> 4) * 4;
+                f32x4 p = ac[jt] * inv;
+                if (psave != nullptr && i < L) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (j + r < L) psave[(size_t)rowidx + j + r] = from_f<T>(p[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] *= drop_mult(drop, rowidx + j + r);
+                store4((T*)(Ps + (lane & 15) * SPIT) + j, p);
+            }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < LSL; ++sl)
+                    mma16(o, frag_kmaj(Vi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
+                          frag_nat<T>(Ps, SPIT, lane & 15, sl, lane));
+                const int i = strip * 16 + (lane & 15);
+                if (i < L) store4(vec + ((size_t)b * L + i) * H + h * 64 + dt * 16 + (lane >> 4) * 4, o);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// block-level column-sum flush: per-lane partials (own row only) -> 16-row shuffle tree -> waves summed in LDS -> atomics
+template <int NW>
+__device__ __forceinline__ void flush_colsum(f32x4 (&c4)[4], float* dst64, float* scratch, int lane, int wave) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s = group16_sum(c4[dt][r]);
+            if ((lane & 15) == 0) scratch[wave * 64 + dt * 16 + (lane >> 4) * 4 + r] = s;
+        }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 64; j += NW * 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += scratch[w * 64 + j];
+        atomicAdd(dst64 + j, t);
+    }
+    __syncthreads();
+}
+
+// ================================================================================================ backward, query side
+template <class T, int LP, int NW>
+__global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restrict__ qkv, const T* __restrict__ kr, XlParams xp,
+                                                                const T* __restrict__ psave, const T* __restrict__ dvec,
+                                                                T* __restrict__ gsave, T* __restrict__ dqkv, float* d_rwb,
+                                                                float* d_rrb, float* d_rsb, float* d_seg, int L, int nh,
+                                                                DropKey drop) {
+    typedef AttnCfg<T> C;
+    constexpr int RP = 2 * LP;
+    constexpr int PIT = C::ROWB + 16;
+    constexpr int SPIT = LP * (int)sizeof(T) + 16;
+    constexpr int GPIT = RP * (int)sizeof(T) + 16;     // shifted-G strip pitch
+    constexpr int NT = LP / 16, DSL = 64 / C::SLAB, LSL = LP / C::SLAB, RSL = RP / C::SLAB;
+    __shared__ __attribute__((aligned(16))) char smem[(4 * LP + RP) * PIT + NW * 16 * (SPIT + GPIT) + (NW * 64 + 192 + 2 * LP) * 4];
+    char* Qi = smem;
+    char* Ki = Qi + LP * PIT;
+    char* Vi = Ki + LP * PIT;
+    char* Oi = Vi + LP * PIT;                          // dvec image
+    char* Ri = Oi + LP * PIT;
+    char* gstr = Ri + RP * PIT;
+    char* sstr = gstr + NW * 16 * SPIT;
+    float* scratch = (float*)(sstr + NW * 16 * GPIT);
+    float* sef = scratch + NW * 64;                    // se0[64] | se1[64] | rsb[64]
+    int* segv = (int*)(sef + 192);
+    int* padf = segv + LP;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    const int H = nh * 64;
+    const size_t ld = (size_t)3 * H;
+    const T* base = qkv + (size_t)b * L * ld + h * 64;
+    stage_head<T, LP, NW * 64>(Qi, PIT, base, ld, L);
+    stage_head<T, LP, NW * 64>(Ki, PIT, base + H, ld, L);
+    stage_head<T, LP, NW * 64>(Vi, PIT, base + 2 * H, ld, L);
+    stage_head<T, LP, NW * 64>(Oi, PIT, dvec + (size_t)b * L * H + h * 64, (size_t)H, L);
+    stage_head<T, RP, NW * 64>(Ri, PIT, kr + (size_t)b * 2 * L * H + h * 64, (size_t)H, 2 * L);
+    for (int t = threadIdx.x; t < 192; t += NW * 64)
+        sef[t] = t < 128 ? xp.seg_embed[((size_t)(t >> 6) * nh + h) * 64 + (t & 63)] : xp.r_s_bias[h * 64 + (t & 63)];
+    for (int j = threadIdx.x; j < LP; j += NW * 64) {
+        segv[j] = j < L ? (int)xp.seg[(size_t)b * L + j] : -1;
+        padf[j] = 0;
+    }
+    __syncthreads();
+
+    f32x4 cw[4], cr[4], cs[4], d0[4], d1[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) cw[dt] = cr[dt] = cs[dt] = d0[dt] = d1[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    char* Gs = gstr + wave * 16 * SPIT;
+    char* Ss = sstr + wave * 16 * GPIT;
+    const float scale = 0.125f;
+    T* dq_base = dqkv + (size_t)b * L * ld + h * 64;
+
+    for (int s0 = 0; s0 < NT; s0 += NW) {
+        const int strip = s0 + wave;
+        const bool active = strip < NT;
+        const int i = strip * 16 + (lane & 15);
+        float g0 = 0.f, g1 = 0.f;
+        if (active) {
+            // zero this wave's shifted strip, then fill G (natural) and G shifted to position space
+            for (int t = lane; t < 16 * GPIT / 16; t += 64) *(u32x4*)(Ss + t * 16) = u32x4{0u, 0u, 0u, 0u};
+            f32x4 dp[NT];
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < DSL; ++sl)
+                    mma16(dp[jt], frag_nat<T>(Vi, PIT, jt * 16 + (lane & 15), sl, lane),
+                          frag_nat<T>(Oi, PIT, strip * 16 + (lane & 15), sl, lane));
+            }
+            const uint32_t rowidx = ((uint32_t)blockIdx.x * L + (uint32_t)i) * L;
+            f32x4 pv[NT];
+            float dsum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jt * 16 + (lane >> 4) * 4 + r;
+                    const bool ok = i < L && j < L;
+                    pv[jt][r] = ok ? to_f(psave[(size_t)rowidx + j]) : 0.f;
+                    dp[jt][r] *= ok ? drop_mult(drop, rowidx + j) : 0.f;
+                    dsum += dp[jt][r] * pv[jt][r];
+                }
+            const float D = quad_sum(dsum);
+            const int si = segv[i < LP ? i : 0];
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const int j0 = jt * 16 + (lane >> 4) * 4;
+                f32x4 g = pv[jt] * (dp[jt] - D) * scale;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + r;
+                    if (i < L && j < L) {
+                        gsave[(size_t)rowidx + j] = from_f<T>(g[r]);
+                        if (si == segv[j]) g0 += g[r]; else g1 += g[r];
+                        *(T*)(Ss + (lane & 15) * GPIT + (L - i + j) * (int)sizeof(T)) = from_f<T>(g[r]);
+                    } else g[r] = 0.f;
+                }
+                store4((T*)(Gs + (lane & 15) * SPIT) + j0, g);
+            }
+            g0 = quad_sum(g0);
+            g1 = quad_sum(g1);
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < LSL; ++sl)
+                    mma16(oa, frag_kmaj(Ki, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
+                          frag_nat<T>(Gs, SPIT, lane & 15, sl, lane));
+#pragma unroll
+                for (int sl = 0; sl < RSL; ++sl)
+                    mma16(ob, frag_kmaj(Ri, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
+                          frag_nat<T>(Ss, GPIT, lane & 15, sl, lane));
+                const int d = dt * 16 + (lane >> 4) * 4;
+                const f32x4 s0v = *(const f32x4*)(sef + d), s1v = *(const f32x4*)(sef + 64 + d), rs = *(const f32x4*)(sef + 128 + d);
+                const f32x4 oe = g0 * s0v + g1 * s1v;
+                if (i < L) {
+                    store4(dq_base + (size_t)i * ld + d, oa + ob + oe);
+                    cw[dt] += oa; cr[dt] += ob; cs[dt] += oe;
+                    const f32x4 qv = load4((const T*)(Qi + i * PIT) + d) + rs;       // q_i + r_s_bias
+                    d0[dt] += g0 * qv; d1[dt] += g1 * qv;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    flush_colsum<NW>(cw, d_rwb + h * 64, scratch, lane, wave);
+    flush_colsum<NW>(cr, d_rrb + h * 64, scratch, lane, wave);
+    flush_colsum<NW>(cs, d_rsb + h * 64, scratch, lane, wave);
+    flush_colsum<NW>(d0, d_seg + (size_t)h * 64, scratch, lane, wave);
+    flush_colsum<NW>(d1, d_seg + ((size_t)nh + h) * 64, scratch, lane, wave);
+}
+
+// ================================================================================================ backward, key / position side
+template <class T, int LP, int NW>
+__global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv_kernel(const T* __restrict__ qkv, XlParams xp, const T* __restrict__ psave,
+                                                                 const T* __restrict__ gsave, const T* __restrict__ dvec,
+                                                                 T* __restrict__ dqkv, T* __restrict__ dkr, int L, int nh,
+                                                                 DropKey drop) {
+    typedef AttnCfg<T> C;
+    constexpr int PIT = C::ROWB + 16;
+    constexpr int SPIT = LP * (int)sizeof(T) + 16;
+    constexpr int NT = LP / 16, LSL = LP / C::SLAB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * LP * PIT + NW * 16 * SPIT + 128 * 4];
+    char* Qi = smem;
+    char* Oi = Qi + LP * PIT;
+    char* strips = Oi + LP * PIT;
+    float* bia = (float*)(strips + NW * 16 * SPIT);     // r_w_bias[64] | r_r_bias[64]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    const int H = nh * 64;
+    const size_t ld = (size_t)3 * H;
+    stage_head<T, LP, NW * 64>(Qi, PIT, qkv + (size_t)b * L * ld + h * 64, ld, L);
+    stage_head<T, LP, NW * 64>(Oi, PIT, dvec + (size_t)b * L * H + h * 64, (size_t)H, L);
+    for (int t = threadIdx.x; t < 128; t += NW * 64) bia[t] = t < 64 ? xp.r_w_bias[h * 64 + t] : xp.r_r_bias[h * 64 + t - 64];
+    __syncthreads();
+    char* St = strips + wave * 16 * SPIT;
+    const size_t pbase = (size_t)blockIdx.x * L * L;
+    T* dq_base = dqkv + (size_t)b * L * ld + h * 64;
+
+    // ---- key strips: dv, dk
+    for (int s0 = 0; s0 < NT; s0 += NW) {
+        const int strip = s0 + wave;
+        const bool active = strip < NT;
+        const int j = strip * 16 + (lane & 15);
+        f32x4 gt[NT];
+        float csum = 0.f;
+        if (active) {
+#pragma unroll
+            for (int it = 0; it < NT; ++it) {
+                const int i0 = it * 16 + (lane >> 4) * 4;
+                f32x4 pd;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + r;
+                    const bool ok = i < L && j < L;
+                    const size_t idx = pbase + (size_t)i * L + j;
+                    pd[r] = ok ? to_f(psave[idx]) * drop_mult(drop, (uint32_t)idx) : 0.f;
+                    gt[it][r] = ok ? to_f(gsave[idx]) : 0.f;
+                    csum += gt[it][r];
+                }
+                store4((T*)(St + (lane & 15) * SPIT) + i0, pd);
+            }
+            csum = quad_sum(csum);
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < LSL; ++sl)
+                    mma16(o, frag_kmaj(Oi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
+                          frag_nat<T>(St, SPIT, lane & 15, sl, lane));
+                if (j < L) store4(dq_base + (size_t)j * ld + 2 * H + dt * 16 + (lane >> 4) * 4, o);
+            }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int it = 0; it < NT; ++it) store4((T*)(St + (lane & 15) * SPIT) + it * 16 + (lane >> 4) * 4, gt[it]);
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < LSL; ++sl)
+                    mma16(o, frag_kmaj(Qi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
+                          frag_nat<T>(St, SPIT, lane & 15, sl, lane));
+                const int d = dt * 16 + (lane >> 4) * 4;
+                o += csum * *(const f32x4*)(bia + d);                 // + (sum_i G[i,j]) * r_w_bias
+                if (j < L) store4(dq_base + (size_t)j * ld + H + d, o);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- position strips: dkr[p] = sum_i G[i, p - L + i] (q_i + r_r_bias)
+    for (int s0 = 0; s0 < 2 * NT; s0 += NW) {
+        const int strip = s0 + wave;
+        const bool active = strip < 2 * NT;
+        const int p = strip * 16 + (lane & 15);
+        float csum = 0.f;
+        if (active) {
+#pragma unroll
+            for (int it = 0; it < NT; ++it) {
+                const int i0 = it * 16 + (lane >> 4) * 4;
+                f32x4 g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + r, j = p - L + i;
+                    g[r] = (i < L && j >= 0 && j < L) ? to_f(gsave[pbase + (size_t)i * L + j]) : 0.f;
+                    csum += g[r];
+                }
+                store4((T*)(St + (lane & 15) * SPIT) + i0, g);
+            }
+            csum = quad_sum(csum);
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < LSL; ++sl)
+                    mma16(o, frag_kmaj(Qi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
+                          frag_nat<T>(St, SPIT, lane & 15, sl, lane));
+                const int d = dt * 16 + (lane >> 4) * 4;
+                o += csum * *(const f32x4*)(bia + 64 + d);
+                if (p < 2 * L) store4(dkr + ((size_t)b * 2 * L + p) * H + h * 64 + d, o);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ================================================================================================ host
+#define XL_DISPATCH(KERNEL_CALL)                                                   \
+    if (L < 1 || L > 64) return MB_ERR_SHAPE;                                      \
+    {                                                                              \
+        const int LPv = (L + 31) / 32 * 32;                                        \
+        if (dtype == DT_BF16) { typedef bf16 T; if (LPv == 32) { constexpr int LP = 32, NW = 2; KERNEL_CALL } else { constexpr int LP = 64, NW = 4; KERNEL_CALL } } \
+        else if (dtype == DT_F32) { typedef float T; if (LPv == 32) { constexpr int LP = 32, NW = 2; KERNEL_CALL } else { constexpr int LP = 64, NW = 4; KERNEL_CALL } } \
+        else return MB_ERR_DTYPE;                                                  \
+    }                                                                              \
+    return (int)hipGetLastError();
+
+int xlnet_attention_forward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
+                            const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask, void* vec,
+                            void* psave, int B, int L, int nh, DropKey drop, hipStream_t st) {
+    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask};
+    XL_DISPATCH({
+        hipLaunchKernelGGL((xl_attn_fwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, (const T*)kr, xp,
+                           (T*)vec, (T*)psave, L, nh, drop);
+    })
+}
+
+int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
+                             const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask,
+                             const void* psave, const void* dvec, void* gsave, void* dqkv, void* dkr, float* d_rwb,
+                             float* d_rrb, float* d_rsb, float* d_seg, int B, int L, int nh, DropKey drop, hipStream_t st) {
+    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask};
+    XL_DISPATCH({
+        hipLaunchKernelGGL((xl_attn_bwd_q_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, (const T*)kr,
+                           xp, (const T*)psave, (const T*)dvec, (T*)gsave, (T*)dqkv, d_rwb, d_rrb, d_rsb, d_seg, L, nh, drop);
+        hipLaunchKernelGGL((xl_attn_bwd_kv_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, xp,
+                           (const T*)psave, (const T*)gsave, (const T*)dvec, (T*)dqkv, (T*)dkr, L, nh, drop);
+    })
+}
+
+}  // namespace mb

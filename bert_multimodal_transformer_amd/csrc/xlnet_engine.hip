@@ -1,0 +1,365 @@
+// Native step executor for MAG_XLNetForSequenceClassification (/root/reference/xlnet.py:432-527 -> :15-429 ->
+// /root/reference/modeling.py:25-51), BASELINE.json config 4.  Same contract as engine.hip: one C call enqueues a whole pass,
+// caller-owned flat parameter / gradient / bf16-shadow / workspace buffers, reference state-dict names.
+//
+// Only the configuration the reference driver exercises is built (xlnet-base-cased: attn_type "bi", no mems / perm_mask /
+// target_mapping; multimodal_driver.py:363-370), sequence length <= 64 (MOSI: 50).
+//
+// Flat layout:  [ decay | no-decay | frozen ]
+//   decay    : per layer rel_attn.{q,k,v,o,r} ([d_model][n_head*d_head], consumed k-major as stored), ff.layer_1.weight,
+//              ff.layer_2.weight ; sequence_summary.summary.weight            <- bf16 shadow range
+//              per layer rel_attn.seg_embed, rel_attn.layer_norm.weight, ff.layer_norm.weight (XLNet's LayerNorm is called
+//              `layer_norm`, so its weight IS decayed by the driver's substring rule, multimodal_driver.py:329-343) ;
+//              word_embedding ; MAG weights ; logits_proj.weight
+//   no-decay : per layer r_r_bias, r_s_bias, r_w_bias, both layer_norm.bias, ff biases ; MAG biases + MAG.LayerNorm.* ;
+//              summary.bias ; logits_proj.bias
+//   frozen   : transformer.mask_emb (never receives a gradient in this configuration; HF AdamW skips grad-less parameters)
+#include "engine_common.h"
+
+struct XlLayerOff { size_t q, k, v, o, r, w1, w2, seg, ralnw, fflnw, rrb, rsb, rwb, ralnb, fflnb, b1, b2; };
+struct XlLayerWs { size_t qkv, kr, vec, psave, s1, st1, y1, u, g, s2, st2; };
+
+struct mb_xlnet_engine {
+    mb_xlnet_config c;
+    std::vector<TensorInfo> tensors;
+    std::vector<XlLayerOff> lo;
+    size_t word, wsum, bsum, wc, bc, mask_emb, small_decay_begin;
+    size_t mag_whv, mag_wha, mag_wv, mag_wa, mag_bhv, mag_bha, mag_bv, mag_ba, mag_lnw, mag_lnb;
+    size_t n_params, n_trainable, n_decay, sh_begin, sh_end;
+    MagWs mw;
+    size_t ws_mag, ws_magout, ws_pos, ws_xs, ws_head_z, ws_head_pooled;
+    std::vector<size_t> ws_x;
+    std::vector<XlLayerWs> lw;
+    size_t ws_dxa, ws_dxb, ws_dsa, ws_dzda, ws_dsb, ws_dzdb, ws_du, ws_dqkv, ws_dvec, ws_dkr, ws_gsave, ws_dz, ws_dxs, ws_lnp_a,
+        ws_lnp_b;
+    size_t ws_bytes;
+    float* P = nullptr; float* G = nullptr; char* SH = nullptr; char* ws = nullptr;
+    const int64_t* ids = nullptr; const int64_t* seg = nullptr; const int64_t* mask = nullptr;
+    int B = 0, L = 0, training = 0, padT = -1;
+    bool ws_zeroed = false;
+    uint64_t seed = 0, step = 0;
+    float* logits = nullptr;
+
+    size_t add(const std::string& name, std::vector<int64_t> shape, int decay, size_t& cursor) {
+        TensorInfo t;
+        t.name = name; t.ndim = (int)shape.size(); t.decay = decay; t.numel = 1;
+        for (int i = 0; i < 4; ++i) t.shape[i] = i < t.ndim ? shape[i] : 1;
+        for (auto s : shape) t.numel *= (size_t)s;
+        t.off = cursor;
+        cursor = align_up(cursor + t.numel, 64);
+        tensors.push_back(t);
+        return t.off;
+    }
+    const void* W(size_t off) const { return c.dtype == DT_BF16 ? (const void*)(SH + off * 2) : (const void*)(P + off); }
+    DropKey key(uint32_t site, float p) const { return training ? make_key(seed, step, site, p) : kNoDrop; }
+};
+
+// dropout sites: 0 word embedding, 1 MAG, 2 summary-last, 3 final output, 4 pos_emb ; layer l: 16+8l+{0 attn probs, 1 attn out,
+// 2 ff activation, 3 ff out}
+enum { XS_EMB = 0, XS_MAG = 1, XS_HEAD = 2, XS_FINAL = 3, XS_POS = 4, XS_LAYER0 = 16 };
+
+static void xl_build_layout(mb_xlnet_engine* e) {
+    const mb_xlnet_config& c = e->c;
+    const int64_t H = c.d_model, I = c.d_inner, V = c.visual_dim, A = c.acoustic_dim, nh = c.n_head, dh = H / nh;
+    size_t cur = 0;
+    e->lo.resize(c.n_layer);
+    char buf[128];
+    auto nm = [&](int l, const char* s) { snprintf(buf, sizeof buf, "transformer.layer.%d.%s", l, s); return std::string(buf); };
+    e->sh_begin = 0;
+    for (int l = 0; l < c.n_layer; ++l) {
+        XlLayerOff& o = e->lo[l];
+        o.q = e->add(nm(l, "rel_attn.q"), {H, nh, dh}, 1, cur);
+        o.k = e->add(nm(l, "rel_attn.k"), {H, nh, dh}, 1, cur);
+        o.v = e->add(nm(l, "rel_attn.v"), {H, nh, dh}, 1, cur);
+        o.o = e->add(nm(l, "rel_attn.o"), {H, nh, dh}, 1, cur);
+        o.r = e->add(nm(l, "rel_attn.r"), {H, nh, dh}, 1, cur);
+        o.w1 = e->add(nm(l, "ff.layer_1.weight"), {I, H}, 1, cur);
+        o.w2 = e->add(nm(l, "ff.layer_2.weight"), {H, I}, 1, cur);
+    }
+    e->wsum = e->add("sequence_summary.summary.weight", {H, H}, 1, cur);
+    e->sh_end = cur;
+    e->small_decay_begin = cur;
+    for (int l = 0; l < c.n_layer; ++l) {
+        XlLayerOff& o = e->lo[l];
+        o.seg = e->add(nm(l, "rel_attn.seg_embed"), {2, nh, dh}, 1, cur);
+        o.ralnw = e->add(nm(l, "rel_attn.layer_norm.weight"), {H}, 1, cur);
+        o.fflnw = e->add(nm(l, "ff.layer_norm.weight"), {H}, 1, cur);
+    }
+    e->word = e->add("transformer.word_embedding.weight", {c.vocab_size, H}, 1, cur);
+    e->mag_whv = e->add("transformer.MAG.W_hv.weight", {H, V + H}, 1, cur);
+    e->mag_wha = e->add("transformer.MAG.W_ha.weight", {H, A + H}, 1, cur);
+    e->mag_wv = e->add("transformer.MAG.W_v.weight", {H, V}, 1, cur);
+    e->mag_wa = e->add("transformer.MAG.W_a.weight", {H, A}, 1, cur);
+    e->wc = e->add("logits_proj.weight", {c.num_labels, H}, 1, cur);
+    e->n_decay = cur;
+    for (int l = 0; l < c.n_layer; ++l) {
+        XlLayerOff& o = e->lo[l];
+        o.rrb = e->add(nm(l, "rel_attn.r_r_bias"), {nh, dh}, 0, cur);
+        o.rsb = e->add(nm(l, "rel_attn.r_s_bias"), {nh, dh}, 0, cur);
+        o.rwb = e->add(nm(l, "rel_attn.r_w_bias"), {nh, dh}, 0, cur);
+        o.ralnb = e->add(nm(l, "rel_attn.layer_norm.bias"), {H}, 0, cur);
+        o.fflnb = e->add(nm(l, "ff.layer_norm.bias"), {H}, 0, cur);
+        o.b1 = e->add(nm(l, "ff.layer_1.bias"), {I}, 0, cur);
+        o.b2 = e->add(nm(l, "ff.layer_2.bias"), {H}, 0, cur);
+    }
+    e->mag_bhv = e->add("transformer.MAG.W_hv.bias", {H}, 0, cur);
+    e->mag_bha = e->add("transformer.MAG.W_ha.bias", {H}, 0, cur);
+    e->mag_bv = e->add("transformer.MAG.W_v.bias", {H}, 0, cur);
+    e->mag_ba = e->add("transformer.MAG.W_a.bias", {H}, 0, cur);
+    e->mag_lnw = e->add("transformer.MAG.LayerNorm.weight", {H}, 0, cur);
+    e->mag_lnb = e->add("transformer.MAG.LayerNorm.bias", {H}, 0, cur);
+    e->bsum = e->add("sequence_summary.summary.bias", {H}, 0, cur);
+    e->bc = e->add("logits_proj.bias", {c.num_labels}, 0, cur);
+    e->n_trainable = cur;
+    e->mask_emb = e->add("transformer.mask_emb", {1, 1, H}, 2, cur);      // decay code 2 = frozen
+    e->n_params = cur;
+
+    const size_t es = esize(c.dtype);
+    const size_t T = align_up((size_t)c.max_batch * c.max_seq, 64);
+    const size_t R = align_up((size_t)c.max_batch * 2 * c.max_seq, 64);
+    const size_t PP = (size_t)c.max_batch * nh * c.max_seq * c.max_seq;
+    Carver w;
+    e->mw.init(c.dtype, (int)T, (int)H, (int)V, (int)A);
+    e->ws_mag = w.take(e->mw.bytes);
+    e->ws_magout = w.take(T * H * es);
+    e->ws_pos = w.take(R * H * es);
+    e->ws_x.resize(c.n_layer + 1);
+    for (int l = 0; l <= c.n_layer; ++l) e->ws_x[l] = w.take(T * H * es);
+    e->lw.resize(c.n_layer);
+    for (int l = 0; l < c.n_layer; ++l) {
+        XlLayerWs& x = e->lw[l];
+        x.qkv = w.take(T * 3 * H * es); x.kr = w.take(R * H * es); x.vec = w.take(T * H * es); x.psave = w.take(PP * es);
+        x.s1 = w.take(T * H * es); x.st1 = w.take(2 * T * 4); x.y1 = w.take(T * H * es); x.u = w.take(T * I * es);
+        x.g = w.take(T * I * es); x.s2 = w.take(T * H * es); x.st2 = w.take(2 * T * 4);
+    }
+    e->ws_xs = w.take((size_t)c.max_batch * H * es);
+    e->ws_head_z = w.take((size_t)c.max_batch * H * 4);
+    e->ws_head_pooled = w.take((size_t)c.max_batch * H * 4);
+    e->ws_dxa = w.take(T * H * es); e->ws_dxb = w.take(T * H * es);
+    e->ws_dsa = w.take(T * H * es); e->ws_dzda = w.take(T * H * es); e->ws_dsb = w.take(T * H * es); e->ws_dzdb = w.take(T * H * es);
+    e->ws_du = w.take(T * I * es); e->ws_dqkv = w.take(T * 3 * H * es); e->ws_dvec = w.take(T * H * es);
+    e->ws_dkr = w.take(R * H * es); e->ws_gsave = w.take(PP * es);
+    e->ws_dz = w.take((size_t)c.max_batch * H * es); e->ws_dxs = w.take((size_t)c.max_batch * H * es);
+    e->ws_lnp_a = w.take(ln_partials_floats((int)T, (int)H) * 4); e->ws_lnp_b = w.take(ln_partials_floats((int)T, (int)H) * 4);
+    e->ws_bytes = w.off;
+}
+
+extern "C" {
+
+int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out) {
+    if (!cfg || !out) return MB_ERR_ARG;
+    if (cfg->d_model != 768 || cfg->n_head * 64 != cfg->d_model) return MB_ERR_SHAPE;
+    if (cfg->d_inner % 128 || cfg->max_seq < 1 || cfg->max_seq > 64 || cfg->max_batch < 1 || cfg->num_labels < 1) return MB_ERR_SHAPE;
+    if (cfg->injection_index < 0 || cfg->injection_index >= cfg->n_layer) return MB_ERR_ARG;
+    if (cfg->dtype != DT_F32 && cfg->dtype != DT_BF16) return MB_ERR_DTYPE;
+    mb_xlnet_engine* e = new mb_xlnet_engine();
+    e->c = *cfg;
+    xl_build_layout(e);
+    *out = e;
+    return MB_OK;
+}
+void mb_xlnet_destroy(mb_xlnet_engine* e) { delete e; }
+int mb_xlnet_num_tensors(const mb_xlnet_engine* e) { return (int)e->tensors.size(); }
+int mb_xlnet_tensor_info(const mb_xlnet_engine* e, int i, char* name, int name_cap, size_t* offset, size_t* numel, int* ndim,
+                         int64_t* shape4, int* decay) {
+    if (i < 0 || i >= (int)e->tensors.size()) return MB_ERR_ARG;
+    const TensorInfo& t = e->tensors[i];
+    if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (offset) *offset = t.off;
+    if (numel) *numel = t.numel;
+    if (ndim) *ndim = t.ndim;
+    if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = t.shape[k];
+    if (decay) *decay = t.decay;
+    return MB_OK;
+}
+size_t mb_xlnet_param_count(const mb_xlnet_engine* e) { return e->n_params; }
+size_t mb_xlnet_decay_count(const mb_xlnet_engine* e) { return e->n_decay; }
+void mb_xlnet_shadow_range(const mb_xlnet_engine* e, size_t* b, size_t* en) { *b = e->sh_begin; *en = e->sh_end; }
+size_t mb_xlnet_workspace_bytes(const mb_xlnet_engine* e) { return e->ws_bytes; }
+int mb_xlnet_bind(mb_xlnet_engine* e, float* params, float* grads, void* shadow, void* workspace, size_t ws_bytes) {
+    if (!params || !workspace || ws_bytes < e->ws_bytes) return MB_ERR_ARG;
+    if (e->c.dtype == DT_BF16 && !shadow) return MB_ERR_ARG;
+    e->P = params; e->G = grads; e->SH = (char*)shadow; e->ws = (char*)workspace;
+    e->ws_zeroed = false; e->padT = -1;
+    return MB_OK;
+}
+int mb_xlnet_sync_weights(mb_xlnet_engine* e, void* stream) {
+    if (!e->P) return MB_ERR_ARG;
+    if (e->c.dtype == DT_BF16)
+        CK(convert(DT_BF16, e->P + e->sh_begin, e->SH + e->sh_begin * 2, e->sh_end - e->sh_begin, (hipStream_t)stream));
+    return MB_OK;
+}
+
+int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                     const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                     int training, uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const mb_xlnet_config& c = e->c;
+    if (!e->P || !e->ws) return MB_ERR_ARG;
+    if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
+    if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !logits) return MB_ERR_ARG;
+    const int dt = c.dtype, H = c.d_model, I = c.d_inner, T = B * L, nh = c.n_head, R = B * 2 * L;
+    const size_t es = esize(dt);
+    e->ids = input_ids; e->seg = token_type_ids; e->mask = attention_mask;
+    e->B = B; e->L = L; e->training = training; e->seed = seed; e->step = step; e->logits = logits;
+    float* P = e->P;
+    char* ws = e->ws;
+    if (!e->ws_zeroed || e->padT != T) {      // pad rows of every k-major wgrad operand must be zero
+        CK((int)hipMemsetAsync(ws, 0, e->ws_bytes, st));
+        e->ws_zeroed = true;
+    }
+    e->padT = T;
+    const float pd = c.dropout;
+    CK(gather_drop_forward(dt, input_ids, P + e->word, ws + e->ws_x[0], T, H, e->key(XS_EMB, pd), st));            // xlnet.py:304-305
+    CK(xlnet_pos_emb(dt, ws + e->ws_pos, B, L, H, e->key(XS_POS, pd), st));                                         // xlnet.py:332-333
+    for (int l = 0; l < c.n_layer; ++l) {
+        const XlLayerOff& o = e->lo[l];
+        const XlLayerWs& w = e->lw[l];
+        const char* xin = ws + e->ws_x[l];
+        if (l == c.injection_index) {                                                                                // xlnet.py:371-372
+            CK(mag_fwd_impl(dt, xin, visual, acoustic, P + e->mag_whv, P + e->mag_bhv, P + e->mag_wha, P + e->mag_bha,
+                            P + e->mag_wv, P + e->mag_bv, P + e->mag_wa, P + e->mag_ba, P + e->mag_lnw, P + e->mag_lnb,
+                            c.mag_layer_norm_eps, c.beta_shift, e->key(XS_MAG, c.mag_dropout), ws + e->ws_magout,
+                            ws + e->ws_mag, e->mw, T, H, c.visual_dim, c.acoustic_dim, true, st));
+            xin = ws + e->ws_magout;
+        }
+        char* qkv = ws + w.qkv;
+        // q | k | v | kr projections: x . W with W stored [d_model][n_head*d_head] (einsum "ibh,hnd->ibnd")
+        CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, xin, H, e->W(o.q), H, qkv, 3 * H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
+        CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, xin, H, e->W(o.k), H, qkv + (size_t)H * es, 3 * H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
+        CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, xin, H, e->W(o.v), H, qkv + (size_t)2 * H * es, 3 * H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
+        CK(gemm(dt, GEMM_NN, EPI_ADD_RES, R, H, H, ws + e->ws_pos, H, e->W(o.r), H, ws + w.kr, H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
+        CK(xlnet_attention_forward(dt, qkv, ws + w.kr, P + o.rwb, P + o.rrb, P + o.rsb, P + o.seg, token_type_ids, attention_mask,
+                                   ws + w.vec, ws + w.psave, B, L, nh, e->key(XS_LAYER0 + 8 * l + 0, pd), st));
+        // post_attention: dropout(vec . o^T) + h -> LayerNorm
+        CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, T, H, H, ws + w.vec, H, e->W(o.o), H, ws + w.s1, H, nullptr, nullptr, nullptr, xin, H,
+                e->key(XS_LAYER0 + 8 * l + 1, pd), 1, 0, st));
+        CK(ln_forward(dt, ws + w.s1, P + o.ralnw, P + o.ralnb, c.layer_norm_eps, ws + w.y1, (float*)(ws + w.st1),
+                      (float*)(ws + w.st1) + T, T, H, kNoDrop, st));
+        // feed forward: layer_1 -> gelu -> dropout -> layer_2 -> dropout -> LayerNorm(. + inp)
+        CK(gemm(dt, GEMM_NT, EPI_BIAS_GELU, T, I, H, ws + w.y1, H, e->W(o.w1), H, ws + w.u, I, ws + w.g, nullptr, P + o.b1, nullptr, 0,
+                e->key(XS_LAYER0 + 8 * l + 2, pd), 1, 0, st));
+        CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, T, H, I, ws + w.g, I, e->W(o.w2), I, ws + w.s2, H, nullptr, nullptr, P + o.b2,
+                ws + w.y1, H, e->key(XS_LAYER0 + 8 * l + 3, pd), 1, 0, st));
+        CK(ln_forward(dt, ws + w.s2, P + o.fflnw, P + o.fflnb, c.layer_norm_eps, ws + e->ws_x[l + 1], (float*)(ws + w.st2),
+                      (float*)(ws + w.st2) + T, T, H, kNoDrop, st));
+    }
+    // final dropout (xlnet.py:396) on the only row SequenceSummary("last") reads, then summary -> tanh -> dropout -> logits_proj
+    CK(last_token_forward(dt, ws + e->ws_x[c.n_layer], ws + e->ws_xs, B, L, H, e->key(XS_FINAL, pd), st));
+    float* z = (float*)(ws + e->ws_head_z);
+    CK(gemm(dt, GEMM_NT, EPI_BIAS_F32, B, H, H, ws + e->ws_xs, H, e->W(e->wsum), H, nullptr, H, nullptr, z, P + e->bsum, nullptr, 0,
+            kNoDrop, 1, 64, st));
+    if (loss) CK((int)hipMemsetAsync(loss, 0, 4, st));
+    CK(head_forward(z, P + e->wc, P + e->bc, labels, (float*)(ws + e->ws_head_pooled), logits, loss, loss_run, B, H, c.num_labels,
+                    e->key(XS_HEAD, c.summary_last_dropout), st));
+    return MB_OK;
+}
+
+int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* labels, float loss_scale, int stage_begin,
+                      int stage_end, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const mb_xlnet_config& c = e->c;
+    if (!e->G || !e->ids) return MB_ERR_ARG;
+    const int dt = c.dtype, H = c.d_model, I = c.d_inner, B = e->B, L = e->L, T = B * L, nh = c.n_head, NL = c.n_layer;
+    const int Tk = (int)align_up((size_t)T, 64), Rk = (int)align_up((size_t)B * 2 * L, 64);
+    const size_t es = esize(dt);
+    if (stage_begin < 0) stage_begin = 0;
+    if (stage_end > NL + 2) stage_end = NL + 2;
+    float* P = e->P; float* G = e->G;
+    char* ws = e->ws;
+    const float pd = c.dropout;
+    const bool hd = e->training && pd > 0.f;
+    for (int stage = stage_begin; stage < stage_end; ++stage) {
+        if (stage == 0) {
+            CK(head_backward(dt, dlogits, e->logits, labels, loss_scale, (const float*)(ws + e->ws_head_pooled), P + e->wc,
+                             ws + e->ws_dz, G + e->wc, G + e->bc, B, H, c.num_labels, e->key(XS_HEAD, c.summary_last_dropout), st));
+            CK(gemm(dt, GEMM_TN, EPI_ACCUM_F32, H, H, B, ws + e->ws_dz, H, ws + e->ws_xs, H, nullptr, H, nullptr, G + e->wsum, nullptr,
+                    nullptr, 0, kNoDrop, 1, 64, st));
+            CK(colsum(dt, ws + e->ws_dz, H, G + e->bsum, B, H, st));
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, B, H, H, ws + e->ws_dz, H, e->W(e->wsum), H, ws + e->ws_dxs, H, nullptr, nullptr, nullptr,
+                    nullptr, 0, kNoDrop, 1, 64, st));
+            CK((int)hipMemsetAsync(ws + e->ws_dxa, 0, (size_t)T * H * es, st));
+            CK(last_token_backward(dt, ws + e->ws_dxs, ws + e->ws_dxa, B, L, H, e->key(XS_FINAL, pd), st));
+        } else if (stage <= NL) {
+            const int l = NL - stage;
+            const XlLayerOff& o = e->lo[l];
+            const XlLayerWs& w = e->lw[l];
+            const char* xin = (l == c.injection_index) ? ws + e->ws_magout : ws + e->ws_x[l];
+            char* dx = ws + e->ws_dxa;
+            char* t1 = ws + e->ws_dxb;
+            char* dsA = ws + e->ws_dsa;
+            char* dzdA = hd ? ws + e->ws_dzda : dsA;
+            char* dsB = ws + e->ws_dsb;
+            char* dzdB = hd ? ws + e->ws_dzdb : dsB;
+            int nblk = 0;
+            float* lnp_a = (float*)(ws + e->ws_lnp_a);
+            float* lnp_b = (float*)(ws + e->ws_lnp_b);
+            // ---- feed-forward block
+            CK(ln_backward_partials(dt, dx, ws + w.s2, P + o.fflnw, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, dsA,
+                                    hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(XS_LAYER0 + 8 * l + 3, pd), st));
+            CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, st));
+            CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, ws + e->ws_du, I, nullptr, G + o.b1, nullptr, ws + w.u, I,
+                    e->key(XS_LAYER0 + 8 * l + 2, pd), 1, 0, st));
+            CK(wgrad(dt, I, H, Tk, ws + e->ws_du, I, ws + w.y1, H, G + o.w1, H, st));
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, I, ws + e->ws_du, I, e->W(o.w1), H, t1, H, nullptr, nullptr, nullptr, dsA, H,
+                    kNoDrop, 1, 0, st));
+            // ---- relative attention block
+            CK(ln_backward_partials(dt, t1, ws + w.s1, P + o.ralnw, (const float*)(ws + w.st1), (const float*)(ws + w.st1) + T, dsB,
+                                    hd ? dzdB : nullptr, lnp_b, &nblk, T, H, e->key(XS_LAYER0 + 8 * l + 1, pd), st));
+            {
+                float* const dst6[6] = {G + o.fflnw, G + o.fflnb, G + o.b2, G + o.ralnw, G + o.ralnb, nullptr};
+                CK(ln_reduce_partials(lnp_a, lnp_b, nblk, H, dst6, st));
+            }
+            CK(wgrad(dt, H, H, Tk, dzdB, H, ws + w.vec, H, G + o.o, H, st));                       // d o[h][nd] = dzd^T vec
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.o), H, ws + e->ws_dvec, H, nullptr, nullptr, nullptr, nullptr, 0,
+                    kNoDrop, 1, 0, st));
+            char* dqkv = ws + e->ws_dqkv;
+            CK(xlnet_attention_backward(dt, ws + w.qkv, ws + w.kr, P + o.rwb, P + o.rrb, P + o.rsb, P + o.seg, e->seg, e->mask,
+                                        ws + w.psave, ws + e->ws_dvec, ws + e->ws_gsave, dqkv, ws + e->ws_dkr, G + o.rwb, G + o.rrb,
+                                        G + o.rsb, G + o.seg, B, L, nh, e->key(XS_LAYER0 + 8 * l + 0, pd), st));
+            CK(wgrad(dt, H, H, Rk, ws + e->ws_pos, H, ws + e->ws_dkr, H, G + o.r, H, st));         // d r = pos^T dkr
+            CK(wgrad(dt, H, H, Tk, xin, H, dqkv, 3 * H, G + o.q, H, st));
+            CK(wgrad(dt, H, H, Tk, xin, H, dqkv + (size_t)H * es, 3 * H, G + o.k, H, st));
+            CK(wgrad(dt, H, H, Tk, xin, H, dqkv + (size_t)2 * H * es, 3 * H, G + o.v, H, st));
+            // dx_in = dq Wq^T + dk Wk^T + dv Wv^T + dsB   (W stored [h_in][nd] = the row operand of an NT GEMM)
+            char* t2 = ws + e->ws_dvec;
+            CK(gemm(dt, GEMM_NT, EPI_ADD_RES, T, H, H, dqkv, 3 * H, e->W(o.q), H, t1, H, nullptr, nullptr, nullptr, dsB, H, kNoDrop, 1, 0, st));
+            CK(gemm(dt, GEMM_NT, EPI_ADD_RES, T, H, H, dqkv + (size_t)H * es, 3 * H, e->W(o.k), H, t2, H, nullptr, nullptr, nullptr, t1, H,
+                    kNoDrop, 1, 0, st));
+            CK(gemm(dt, GEMM_NT, EPI_ADD_RES, T, H, H, dqkv + (size_t)2 * H * es, 3 * H, e->W(o.v), H, dx, H, nullptr, nullptr, nullptr, t2,
+                    H, kNoDrop, 1, 0, st));
+            if (l == c.injection_index) {      // MAG sits in front of this layer
+                CK(mag_bwd_impl(dt, dx, ws + e->ws_x[l], P + e->mag_bhv, P + e->mag_bha, P + e->mag_bv, P + e->mag_ba,
+                                P + e->mag_lnw, c.beta_shift, e->key(XS_MAG, c.mag_dropout), ws + e->ws_mag, e->mw, t1, nullptr,
+                                nullptr, G + e->mag_whv, G + e->mag_bhv, G + e->mag_wha, G + e->mag_bha, G + e->mag_wv, G + e->mag_bv,
+                                G + e->mag_wa, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb, T, H, c.visual_dim, c.acoustic_dim, true,
+                                st));
+                CK((int)hipMemcpyAsync(dx, t1, (size_t)T * H * es, hipMemcpyDeviceToDevice, st));
+            }
+        } else {
+            CK(gather_drop_backward(dt, ws + e->ws_dxa, e->ids, G + e->word, T, H, e->key(XS_EMB, pd), st));
+        }
+    }
+    return MB_OK;
+}
+
+const void* mb_xlnet_sequence_output(const mb_xlnet_engine* e) { return e->ws ? e->ws + e->ws_x[e->c.n_layer] : nullptr; }
+
+int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap) {
+    const int NL = e->c.n_layer;
+    std::vector<std::pair<size_t, size_t>> r;
+    auto span = [&](size_t a, size_t b) { r.push_back({a, b - a}); };
+    if (stage == 0) span(e->wsum, e->sh_end);
+    else if (stage <= NL) {
+        const int l = NL - stage;
+        span(e->lo[l].q, l + 1 < NL ? e->lo[l + 1].q : e->wsum);
+    } else if (stage == NL + 1) {
+        span(e->small_decay_begin, e->n_decay);      // seg_embed / layer_norm weights, word embedding, MAG weights, logits_proj.weight
+        span(e->n_decay, e->n_trainable);            // every no-decay parameter
+    } else return -1;
+    int n = 0;
+    for (auto& p : r) { if (n < cap) { offs[n] = p.first; lens[n] = p.second; } ++n; }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// Small HBM-bound kernels of the MAG-XLNet path (/root/reference/xlnet.py): word-embedding gather + dropout, the relative
+// sinusoid table with its dropout, and the "last token" summary gather.
+#include "kernels.h"
+
+namespace mb {
+
+template <class T>
+__global__ void __launch_bounds__(256) gather_drop_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                                              T* __restrict__ out, int rows, int H, DropKey drop) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const size_t id = (size_t)ids[row];
+    for (int col = lane * 4; col < H; col += 256) {
+        f32x4 v = *(const f32x4*)(word + id * H + col);
+        const uint32_t idx = (uint32_t)row * H + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= drop_mult(drop, idx + r);
+        store4(out + (size_t)row * H + col, v);
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) gather_drop_bwd_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids,
+                                                              float* dword, int rows, int H, DropKey drop) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const size_t id = (size_t)ids[row];
+    for (int col = lane * 4; col < H; col += 256) {
+        const f32x4 v = load4(dout + (size_t)row * H + col);
+        const uint32_t idx = (uint32_t)row * H + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(dword + id * H + col + r, v[r] * drop_mult(drop, idx + r));
+    }
+}
+
+// pos_seq = arange(L, -L, -1): row p <-> position L - p ; freq d in [0, H/2): inv = 10000^(-2d/H) ; [sin | cos]
+template <class T>
+__global__ void __launch_bounds__(256) pos_emb_kernel(T* __restrict__ out, int B, int L, int H, DropKey drop) {
+    const size_t total = (size_t)B * 2 * L * H;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % H);
+        const int p = (int)((i / H) % (2 * L));
+        const int b = (int)(i / ((size_t)H * 2 * L));
+        const int half = H / 2;
+        const int d = c < half ? c : c - half;
+        const float inv_freq = 1.0f / powf(10000.0f, (float)(2 * d) / (float)H);
+        const float a = (float)(L - p) * inv_freq;
+        float v = c < half ? sinf(a) : cosf(a);
+        // reference index space: pos_emb is [2L, B, H] (xlnet.py:99-100,333) -> element ((p*B + b)*H + c)
+        v *= drop_mult(drop, (uint32_t)(((size_t)p * B + b) * H + c));
+        out[i] = from_f<T>(v);
+    }
+}
+
+template <class T>
+__global__ void last_token_fwd_kernel(const T* __restrict__ x, T* __restrict__ xs, int B, int L, int H, DropKey drop) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, c = i % H;
+    const size_t src = ((size_t)b * L + (L - 1)) * H + c;
+    xs[i] = from_f<T>(to_f(x[src]) * drop_mult(drop, (uint32_t)src));
+}
+template <class T>
+__global__ void last_token_bwd_kernel(const T* __restrict__ dxs, T* __restrict__ dx, int B, int L, int H, DropKey drop) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, c = i % H;
+    const size_t dst = ((size_t)b * L + (L - 1)) * H + c;
+    dx[dst] = from_f<T>(to_f(dxs[i]) * drop_mult(drop, (uint32_t)dst));
+}
+
+#define MB_DISPATCH_T(dtype, ...)                                  \
+    if ((dtype) == DT_BF16) { typedef bf16 T; __VA_ARGS__ }        \
+    else if ((dtype) == DT_F32) { typedef float T; __VA_ARGS__ }   \
+    else return MB_ERR_DTYPE;
+
+int gather_drop_forward(int dtype, const int64_t* ids, const float* word, void* out, int rows, int H, DropKey drop, hipStream_t st) {
+    if (rows <= 0) return MB_OK;
+    if (H % 4) return MB_ERR_SHAPE;
+    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((gather_drop_fwd_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, st, ids, word, (T*)out, rows, H, drop); })
+    return (int)hipGetLastError();
+}
+int gather_drop_backward(int dtype, const void* dout, const int64_t* ids, float* dword, int rows, int H, DropKey drop, hipStream_t st) {
+    if (rows <= 0) return MB_OK;
+    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((gather_drop_bwd_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)dout, ids, dword, rows, H, drop); })
+    return (int)hipGetLastError();
+}
+int xlnet_pos_emb(int dtype, void* out, int B, int L, int H, DropKey drop, hipStream_t st) {
+    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((pos_emb_kernel<T>), dim3(1024), dim3(256), 0, st, (T*)out, B, L, H, drop); })
+    return (int)hipGetLastError();
+}
+int last_token_forward(int dtype, const void* x, void* xs, int B, int L, int H, DropKey drop, hipStream_t st) {
+    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((last_token_fwd_kernel<T>), dim3((B * H + 255) / 256), dim3(256), 0, st, (const T*)x, (T*)xs, B, L, H, drop); })
+    return (int)hipGetLastError();
+}
+int last_token_backward(int dtype, const void* dxs, void* dx, int B, int L, int H, DropKey drop, hipStream_t st) {
+    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((last_token_bwd_kernel<T>), dim3((B * H + 255) / 256), dim3(256), 0, st, (const T*)dxs, (T*)dx, B, L, H, drop); })
+    return (int)hipGetLastError();
+}
+
+}  // namespace mb

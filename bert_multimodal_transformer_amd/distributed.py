@@ -74,7 +74,7 @@ class GradReducer(object):
 
 def stage_plan(core):
     """[(stage, [large ranges])] + the final small range, from the engine's layout."""
-    nstage = core.config.num_hidden_layers + 2
+    nstage = core.n_layers + 2
     small_begin = None
     plan = []
     for s in range(nstage):

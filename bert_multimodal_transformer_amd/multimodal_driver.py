@@ -295,7 +295,14 @@ def prep_for_training(num_train_optimization_steps: int):
             model = MAG_BertForSequenceClassification(BertConfig(num_labels=1), multimodal_config, visual_dim=V,
                                                       acoustic_dim=A, compute_dtype=dt)
     elif args.model == "xlnet-base-cased":
-        raise NotImplementedError("MAG-XLNet is the next row of the scope table (SURVEY.md section 8, config 4)")
+        from .xlnet import MAG_XLNetForSequenceClassification, XLNetConfig
+        if args.pretrained:
+            model = MAG_XLNetForSequenceClassification.from_pretrained(
+                args.pretrained, multimodal_config=multimodal_config, num_labels=1, visual_dim=V, acoustic_dim=A,
+                compute_dtype=dt)
+        else:
+            model = MAG_XLNetForSequenceClassification(XLNetConfig(num_labels=1), multimodal_config, visual_dim=V,
+                                                       acoustic_dim=A, compute_dtype=dt)
     model.to(_device())
     optimizer = AdamW(optimizer_grouped_parameters(model), lr=args.learning_rate)
     scheduler = get_linear_schedule_with_warmup(

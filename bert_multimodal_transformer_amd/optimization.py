@@ -113,7 +113,7 @@ class AdamW(torch.optim.Optimizer):
         if ov is None or not self.overlap_armed:
             return
         core = ov["core"]
-        nstage = core.config.num_hidden_layers + 2
+        nstage = core.n_layers + 2
         if stage == 0:
             self._t_next = self._t + 1
             ov["pending"] = True

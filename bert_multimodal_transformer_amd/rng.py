@@ -2,7 +2,10 @@
 to replay the exact device masks inside the CPU oracle ("mask replay")."""
 import numpy as np
 
-SITE_EMB, SITE_MAG, SITE_HEAD, SITE_LAYER0 = 0, 1, 2, 16
+SITE_EMB, SITE_MAG, SITE_HEAD, SITE_LAYER0 = 0, 1, 2, 16           # MAG-BERT: layer l sites 16 + 4l + {0 probs, 1 attn out, 2 ffn out}
+# MAG-XLNet (csrc/xlnet_engine.hip): 0 word embedding [B,L,H], 1 MAG [B,L,H], 2 summary last_dropout [B,H], 3 final output
+# [B,L,H], 4 pos_emb [2L,B,H]; layer l sites 16 + 8l + {0 probs [B,nh,L,L], 1 attn out [B,L,H], 2 ff act [B,L,d_inner], 3 ff out}
+XS_EMB, XS_MAG, XS_HEAD, XS_FINAL, XS_POS, XS_LAYER0 = 0, 1, 2, 3, 4, 16
 _M64 = (1 << 64) - 1
 
 

@@ -1,0 +1,160 @@
+"""MAG_XLNetModel / MAG_XLNetForSequenceClassification -- drop-in surfaces of /root/reference/xlnet.py:15-527 on the native
+MI355X step executor (csrc/xlnet_engine.hip, csrc/xlnet_attention.hip).
+
+Same class names, constructor `(config, multimodal_config)`, forward argument order and state-dict keys as the reference
+(transformer.word_embedding.weight, transformer.mask_emb, transformer.layer.{i}.rel_attn.{q,k,v,o,r,r_r_bias,r_s_bias,
+r_w_bias,seg_embed,layer_norm.*}, transformer.layer.{i}.ff.{layer_norm,layer_1,layer_2}.*, transformer.MAG.*,
+sequence_summary.summary.*, logits_proj.*).  Built for the configuration the reference driver runs
+(multimodal_driver.py:363-370: attention_mask + token_type_ids, no mems / perm_mask / target_mapping / input_mask /
+head_mask / inputs_embeds; those raise NotImplementedError), sequence length <= 64, MAG injected in front of layer
+XLNET_INJECTION_INDEX (global_configs.py:19, xlnet.py:371-372).
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .bert import _Core, _EngineFn, _MagBertBase, _attach_parameters, _init_weights
+from .global_configs import ACOUSTIC_DIM, VISUAL_DIM, XLNET_INJECTION_INDEX
+
+
+class XLNetConfig(object):
+    """The subset of transformers.XLNetConfig (xlnet-base-cased) the path reads."""
+
+    def __init__(self, vocab_size=32000, d_model=768, n_layer=12, n_head=12, d_inner=3072, ff_activation="gelu",
+                 attn_type="bi", initializer_range=0.02, layer_norm_eps=1e-12, dropout=0.1, mem_len=None, reuse_len=None,
+                 bi_data=False, clamp_len=-1, same_length=False, summary_type="last", summary_use_proj=True,
+                 summary_activation="tanh", summary_last_dropout=0.1, num_labels=1, **kwargs):
+        if ff_activation != "gelu" or attn_type != "bi" or bi_data or clamp_len != -1 or mem_len not in (None, 0) \
+                or summary_type != "last" or not summary_use_proj or summary_activation != "tanh":
+            raise NotImplementedError("only the xlnet-base-cased configuration used by multimodal_driver.py is built")
+        self.vocab_size = vocab_size
+        self.d_model = d_model
+        self.hidden_size = d_model
+        self.n_layer = n_layer
+        self.n_head = n_head
+        self.d_head = d_model // n_head
+        self.d_inner = d_inner
+        self.initializer_range = initializer_range
+        self.layer_norm_eps = layer_norm_eps
+        self.dropout = dropout
+        self.summary_last_dropout = summary_last_dropout
+        self.num_labels = num_labels
+        self.mem_len = mem_len
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+
+class _XlBase(_MagBertBase):
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, **kwargs):
+        import os
+        multimodal_config = kwargs.pop("multimodal_config", model_args[0] if model_args else None)
+        num_labels = kwargs.pop("num_labels", 1)
+        config = config or XLNetConfig(num_labels=num_labels)
+        config.num_labels = num_labels
+        model = cls(config, multimodal_config, **kwargs)
+        path = pretrained_model_name_or_path
+        if os.path.isdir(path):
+            path = os.path.join(path, "pytorch_model.bin")
+        if not os.path.isfile(path):
+            raise OSError("from_pretrained(%r): no local checkpoint (offline build)" % (pretrained_model_name_or_path,))
+        sd = torch.load(path, map_location="cpu")
+        own = model.state_dict().keys()
+        model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+        return model
+
+
+class MAG_XLNetModel(_XlBase):
+    """xlnet.py:15-429.  forward -> (output [B, L, d_model],) as an fp32 copy of the engine activation."""
+
+    def __init__(self, config, multimodal_config, visual_dim=VISUAL_DIM, acoustic_dim=ACOUSTIC_DIM,
+                 compute_dtype=torch.float32, device=None, injection_index=XLNET_INJECTION_INDEX, _core=None):
+        super().__init__()
+        self.config = config
+        own = _core is None
+        self._core = _core or _Core(config, multimodal_config, visual_dim, acoustic_dim, compute_dtype, device, kind="xlnet",
+                                    injection_index=injection_index)
+        _attach_parameters(self, self._core, prefix_filter="transformer.", strip="transformer.")
+        if own:
+            self.init_weights()
+
+    def get_input_embeddings(self):
+        return self.word_embedding
+
+    def forward(self, input_ids, visual, acoustic, attention_mask=None, mems=None, perm_mask=None, target_mapping=None,
+                token_type_ids=None, input_mask=None, head_mask=None, inputs_embeds=None, use_cache=True,
+                output_attentions=None, output_hidden_states=None):
+        self._unsupported(mems=mems, perm_mask=perm_mask, target_mapping=target_mapping, input_mask=input_mask,
+                          head_mask=head_mask, inputs_embeds=inputs_embeds, output_attentions=output_attentions,
+                          output_hidden_states=output_hidden_states)
+        if input_ids is None:
+            raise ValueError("You have to specify either input_ids or inputs_embeds")          # xlnet.py:211-213
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        B, L = input_ids.shape
+        self._core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training)
+        return (self._core.sequence_output(B, L),)
+
+
+class MAG_XLNetForSequenceClassification(_XlBase):
+    """xlnet.py:432-527."""
+
+    def __init__(self, config, multimodal_config, visual_dim=VISUAL_DIM, acoustic_dim=ACOUSTIC_DIM,
+                 compute_dtype=torch.float32, device=None, injection_index=XLNET_INJECTION_INDEX):
+        super().__init__()
+        self.config = config
+        self.num_labels = config.num_labels
+        self._core = _Core(config, multimodal_config, visual_dim, acoustic_dim, compute_dtype, device, kind="xlnet",
+                           injection_index=injection_index)
+        self.transformer = MAG_XLNetModel(config, multimodal_config, visual_dim, acoustic_dim, compute_dtype, device,
+                                          injection_index, _core=self._core)
+        _attach_parameters(self, self._core, prefix_filter="sequence_summary.")
+        _attach_parameters(self, self._core, prefix_filter="logits_proj.")
+        self.init_weights()
+
+    def forward(self, input_ids, visual, acoustic, attention_mask=None, mems=None, perm_mask=None, target_mapping=None,
+                token_type_ids=None, input_mask=None, head_mask=None, inputs_embeds=None, use_cache=True, labels=None,
+                output_attentions=None, output_hidden_states=None):
+        self._unsupported(mems=mems, perm_mask=perm_mask, target_mapping=target_mapping, input_mask=input_mask,
+                          head_mask=head_mask, inputs_embeds=inputs_embeds, output_attentions=output_attentions,
+                          output_hidden_states=output_hidden_states)
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        core = self._core
+        logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training)
+        if torch.is_grad_enabled():
+            logits = _EngineFn.apply(core.anchor, logits, core)
+        outputs = (logits,)
+        if labels is not None:                                        # xlnet.py:515-524
+            if self.num_labels == 1:
+                loss = torch.nn.functional.mse_loss(logits.view(-1), labels.to(logits.device).float().view(-1))
+            else:
+                loss = torch.nn.functional.cross_entropy(logits.view(-1, self.num_labels), labels.to(logits.device).view(-1))
+            outputs = (loss,) + outputs
+        return outputs
+
+    def training_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, loss_scale=1.0):
+        if self.num_labels != 1:
+            raise NotImplementedError("fused loss is the regression MSE of the driver (num_labels == 1)")
+        core = self._core
+        core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, True)
+        core._backward(None, loss_scale)
+        return core.loss_buf[0]
+
+    def loss_running(self, reset=False):
+        v = self._core.loss_buf[1].clone()
+        if reset:
+            self._core.loss_buf[1].zero_()
+        return v
+
+    @property
+    def flat_params(self):
+        return self._core.params
+
+    @property
+    def flat_grads(self):
+        return self._core.grads

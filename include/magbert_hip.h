@@ -139,6 +139,43 @@ const float* mb_bert_pooled_output(const mb_bert_engine* e);    /* [B][H] fp32 (
 /* gradient buckets for data parallelism: range r of stage s covers flat elements [off, off+len) */
 int mb_bert_stage_grad_ranges(const mb_bert_engine* e, int stage, size_t* offs, size_t* lens, int cap);
 
+/* ------------------------------------------------------------------------------------------------ MAG-XLNet engine
+ * MAG_XLNetForSequenceClassification forward / backward (xlnet.py:432-527 -> :15-429; XLNetLayer / SequenceSummary of
+ * transformers 3.0.2) for the driver's configuration (bi-directional, no mems / perm_mask / target_mapping), L <= 64.
+ * Same calling conventions as the mb_bert_* family.  Backward stages: 0 = summary + logits_proj, 1..n_layer = layers (last
+ * first; the MAG backward runs inside the stage of layer `injection_index`), n_layer+1 = word embedding. */
+typedef struct {
+    int vocab_size, d_model, n_layer, n_head, d_inner, num_labels;
+    int visual_dim, acoustic_dim, injection_index;
+    float layer_norm_eps, mag_layer_norm_eps, beta_shift;
+    float dropout, summary_last_dropout, mag_dropout;
+    int dtype;
+    int max_batch, max_seq;
+} mb_xlnet_config;
+
+typedef struct mb_xlnet_engine mb_xlnet_engine;
+
+int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out);
+void mb_xlnet_destroy(mb_xlnet_engine* e);
+int mb_xlnet_num_tensors(const mb_xlnet_engine* e);
+/* decay: 1 = weight-decay group, 0 = no-decay group, 2 = frozen (transformer.mask_emb: no gradient in this configuration) */
+int mb_xlnet_tensor_info(const mb_xlnet_engine* e, int i, char* name, int name_cap, size_t* offset, size_t* numel,
+                         int* ndim, int64_t* shape4, int* decay);
+size_t mb_xlnet_param_count(const mb_xlnet_engine* e);
+size_t mb_xlnet_decay_count(const mb_xlnet_engine* e);
+void mb_xlnet_shadow_range(const mb_xlnet_engine* e, size_t* begin, size_t* end);
+size_t mb_xlnet_workspace_bytes(const mb_xlnet_engine* e);
+int mb_xlnet_bind(mb_xlnet_engine* e, float* params, float* grads, void* shadow, void* workspace, size_t ws_bytes);
+int mb_xlnet_sync_weights(mb_xlnet_engine* e, void* stream);
+int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                     const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                     int training, uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run,
+                     void* stream);
+int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* labels, float loss_scale, int stage_begin,
+                      int stage_end, void* stream);
+const void* mb_xlnet_sequence_output(const mb_xlnet_engine* e);
+int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap);
+
 #ifdef __cplusplus
 }
 #endif

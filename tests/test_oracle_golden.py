@@ -89,3 +89,26 @@ def test_full_model_logits_and_grads(golden):
     assert abs(float(loss) - float(g["train/loss_B4_L50_seed21"])) < 1e-5
     for n, p in m.named_parameters():
         np.testing.assert_allclose(float(p.grad.norm()), float(g["train/gnorm/" + n]), rtol=2e-3, atol=1e-6)
+
+
+def test_xlnet_oracle_logits_and_grads(golden):
+    """G6: the MAG-XLNet restatement vs outputs of the reference's own xlnet.py (oracle/make_golden.py gen_xlnet)."""
+    from oracle import mag_xlnet_ref as X
+    g = golden["g6_xlnet"]
+    torch.set_num_threads(8)
+    t = lambda b: (torch.from_numpy(b["input_ids"]), torch.from_numpy(b["visual"]), torch.from_numpy(b["acoustic"]),
+                   torch.from_numpy(b["input_mask"]), torch.from_numpy(b["segment_ids"]))
+    m = X.load_deterministic(X.MAG_XLNetForSequenceClassification(X.XLNetConfigLite(), X.MultimodalConfig(1.0, 0.5), 47, 74)).eval()
+    with torch.no_grad():
+        logits = m(*t(weights.synthetic_xlnet_batch(4, 50, 47, 74, seed=31)))[0]
+    np.testing.assert_allclose(logits.numpy(), g["logits/B4_L50_seed31"], atol=2e-5)
+    m = X.set_dropout(m, 0.0, 0.0).train()
+    b = weights.synthetic_xlnet_batch(4, 50, 47, 74, seed=33)
+    loss = torch.nn.functional.mse_loss(m(*t(b))[0].view(-1), torch.from_numpy(b["label_ids"]).view(-1))
+    loss.backward()
+    assert abs(float(loss) - float(g["train/loss_B4_L50_seed33"])) < 1e-5
+    assert m.transformer.mask_emb.grad is None                      # unused parameter (xlnet.py:29): frozen in the engine too
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            np.testing.assert_allclose(float(p.grad.norm()), float(g["train/gnorm/" + n]), rtol=2e-3, atol=1e-6)
+            np.testing.assert_allclose(weights.strided_sample(p.grad.numpy(), 16), g["train/gslice/" + n], rtol=5e-3, atol=1e-6)

@@ -1,0 +1,249 @@
+"""GPU: whole-path parity of MAG_XLNetForSequenceClassification (HIP engine) against
+  (a) golden logits / loss produced by the reference's own xlnet.py (tests/golden/g6_xlnet.npz), and
+  (b) the CPU oracle (oracle/mag_xlnet_ref.py) run live on the same inputs: gradients, dropout with mask replay,
+      optimizer trajectory.
+Tolerances as in test_model_gpu.py: fp32 parity mode logits <= 1e-3 (north_star); bf16 stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from bert_multimodal_transformer_amd import (AdamW, MAG_XLNetForSequenceClassification, MAG_XLNetModel, MultimodalConfig,
+                                             XLNetConfig, get_linear_schedule_with_warmup, rng)
+from oracle import mag_xlnet_ref as X
+from oracle import optim_ref as O
+from oracle import weights
+
+DEV = "cuda:0"
+
+
+def build(layers=12, cdt=torch.float32, p_mag=0.5, p=0.1, mode="test", V=47):
+    cfg = XLNetConfig(n_layer=layers, num_labels=1, dropout=p, summary_last_dropout=p)
+    m = MAG_XLNetForSequenceClassification(cfg, MultimodalConfig(1.0, p_mag), visual_dim=V, acoustic_dim=74, compute_dtype=cdt)
+    sd = {n: torch.from_numpy(weights.make_param(n, tuple(q.shape), mode)) for n, q in m.named_parameters()}
+    m.load_state_dict(sd)
+    return m
+
+
+def oracle(layers=12, p_mag=0.5, mode="test", V=47):
+    o = X.MAG_XLNetForSequenceClassification(X.XLNetConfigLite(n_layer=layers), X.MultimodalConfig(1.0, p_mag), V, 74)
+    return X.load_deterministic(o, mode)
+
+
+def tb(b, dev="cpu"):
+    t = lambda k: torch.from_numpy(b[k]).to(dev)
+    return t("input_ids"), t("visual"), t("acoustic"), t("input_mask"), t("segment_ids"), t("label_ids")
+
+
+def _grad_report(m, o, tol, frobenius=False):
+    og = {n: p.grad for n, p in o.named_parameters() if p.grad is not None}
+    gmax = max(float(g.abs().max()) for g in og.values())
+    gnorm = max(float(g.norm()) for g in og.values())
+    worst = (0.0, None)
+    for n, p in m.named_parameters():
+        if n not in og:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        g, r = p.grad.detach().cpu(), og[n]
+        if frobenius:
+            rel = float((g - r).norm()) / max(float(r.norm()), 1e-3 * gnorm)
+        else:
+            rel = float((g - r).abs().max()) / max(float(r.abs().max()), 1e-3 * gmax)
+        if not rel <= worst[0]:
+            worst = (rel, n)
+    print("worst relative gradient error %.3e at %s" % worst)
+    assert worst[0] <= tol, worst
+
+
+def test_state_dict_and_frozen_mask_emb():
+    m, o = build(layers=2), oracle(layers=2)
+    assert set(m.state_dict().keys()) == set(o.state_dict().keys())
+    for k, v in o.state_dict().items():
+        assert torch.equal(m.state_dict()[k].cpu(), v), k
+    assert m.transformer.mask_emb.grad is None
+    # reference grouping rule (multimodal_driver.py:328-343): "layer_norm.weight" IS decayed (only "LayerNorm" is matched)
+    from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
+    groups = optimizer_grouped_parameters(m)
+    names = {id(p): n for n, p in m.named_parameters()}
+    assert "transformer.layer.0.rel_attn.layer_norm.weight" in {names[id(p)] for p in groups[0]["params"]}
+    assert "transformer.layer.0.rel_attn.r_r_bias" in {names[id(p)] for p in groups[1]["params"]}
+
+
+@pytest.mark.parametrize("B,L,seed", [(4, 50, 31), (48, 50, 32)])
+def test_eval_logits_match_reference_golden_fp32(golden, B, L, seed):
+    m = build().eval()
+    ids, vis, aco, mask, seg, _ = tb(weights.synthetic_xlnet_batch(B, L, 47, 74, seed=seed), DEV)
+    with torch.no_grad():
+        logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
+    ref = golden["g6_xlnet"]["logits/B%d_L%d_seed%d" % (B, L, seed)]
+    err = float(np.abs(logits.cpu().numpy() - ref).max())
+    print("xlnet fp32 eval logits max|err| = %.3e (|logit| max %.3f)" % (err, float(np.abs(ref).max())))
+    assert err <= 1e-3
+
+
+def test_eval_logits_bf16(golden):
+    m = build(cdt=torch.bfloat16).eval()
+    ids, vis, aco, mask, seg, _ = tb(weights.synthetic_xlnet_batch(48, 50, 47, 74, seed=32), DEV)
+    with torch.no_grad():
+        logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0]
+    ref = golden["g6_xlnet"]["logits/B48_L50_seed32"]
+    err = float(np.abs(logits.cpu().numpy() - ref).max())
+    print("xlnet bf16 eval logits max|err| = %.3e (|logit| max %.3f)" % (err, float(np.abs(ref).max())))
+    assert err <= 5e-2
+
+
+@pytest.mark.parametrize("B,L", [(3, 17), (2, 64), (5, 33)])
+def test_ragged_shapes_eval_fp32(B, L):
+    """sequence lengths that are not multiples of 16, the L = 64 maximum, all-pad-free rows"""
+    m = build(layers=2).eval()
+    o = oracle(layers=2).eval()
+    b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=70 + L)
+    b["input_mask"][0, :] = 1                                    # one row without padding
+    ids, vis, aco, mask, seg, _ = tb(b, DEV)
+    with torch.no_grad():
+        l1 = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0].cpu()
+        l0 = o(*tb(b)[:5])[0]
+    err = float((l1 - l0).abs().max())
+    print("B=%d L=%d max|err| %.3e" % (B, L, err))
+    assert err <= 1e-3
+
+
+def test_base_model_sequence_output_fp32():
+    cfg = XLNetConfig(n_layer=2)
+    m = MAG_XLNetModel(cfg, MultimodalConfig(1.0, 0.5), 47, 74).eval()
+    o = X.MAG_XLNetModel(X.XLNetConfigLite(n_layer=2), X.MultimodalConfig(1.0, 0.5), 47, 74).eval()
+    sd = {n: torch.from_numpy(weights.make_param("transformer." + n, tuple(q.shape), "test")) for n, q in m.named_parameters()}
+    m.load_state_dict(sd); o.load_state_dict(sd)
+    b = weights.synthetic_xlnet_batch(4, 50, 47, 74, seed=81)
+    ids, vis, aco, mask, seg, _ = tb(b, DEV)
+    with torch.no_grad():
+        y1 = m(ids, vis, aco, attention_mask=mask, token_type_ids=seg)[0].cpu()
+        y0 = o(*tb(b)[:5])
+    err = float((y1 - y0).abs().max())
+    print("sequence output max|err| %.3e (max %.3f)" % (err, float(y0.abs().max())))
+    assert err <= 1e-3
+
+
+def test_gradients_match_oracle_fp32(golden):
+    """train mode, every dropout p = 0: loss and all parameter gradients vs the oracle (and the golden loss)."""
+    m = build(p_mag=0.0, p=0.0).train()
+    o = X.set_dropout(oracle(p_mag=0.0), 0.0, 0.0).train()
+    b = weights.synthetic_xlnet_batch(4, 50, 47, 74, seed=33)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
+    loss = torch.nn.MSELoss()(logits.view(-1), lab.view(-1))
+    loss.backward()
+    i2, v2, a2, m2, s2, l2 = tb(b)
+    lo = torch.nn.functional.mse_loss(o(i2, v2, a2, m2, s2)[0].view(-1), l2.view(-1))
+    lo.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(golden["g6_xlnet"]["train/loss_B4_L50_seed33"])) < 1e-4
+    assert abs(float(loss.detach()) - float(lo.detach())) < 1e-4
+    _grad_report(m, o, 2e-3)
+    for n, p in m.named_parameters():                       # and against the reference's own gradient samples
+        if p.grad is not None:
+            np.testing.assert_allclose(float(p.grad.norm()), float(golden["g6_xlnet"]["train/gnorm/" + n]), rtol=5e-3, atol=1e-5)
+
+
+def test_fused_training_step_equals_autograd_path():
+    m = build(layers=2, p_mag=0.0, p=0.0).train()
+    ids, vis, aco, mask, seg, lab = tb(weights.synthetic_xlnet_batch(6, 50, 47, 74, seed=34), DEV)
+    logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
+    loss = torch.nn.MSELoss()(logits.view(-1), lab.view(-1))
+    loss.backward()
+    g_ref = m.flat_grads.clone()
+    m.zero_grad()
+    l2 = m.training_step(ids, vis, aco, mask, seg, lab)
+    assert abs(float(l2) - float(loss.detach())) < 1e-5
+    assert float((m.flat_grads - g_ref).abs().max()) <= 1e-5 * float(g_ref.abs().max()) + 1e-9
+
+
+class _SeqReplay(torch.nn.Module):
+    """dropout module that multiplies its k-th call by the k-th host-regenerated device mask"""
+
+    def __init__(self, mults):
+        super().__init__()
+        self.mults, self.k = mults, 0
+
+    def forward(self, x):
+        mlt = self.mults[self.k % len(self.mults)]
+        self.k += 1
+        assert mlt.shape == x.shape, (mlt.shape, x.shape)
+        return x * mlt
+
+
+@pytest.mark.parametrize("cdt,tol_logit,tol_grad", [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 5e-2, 8e-2)])
+def test_train_mode_dropout_mask_replay(cdt, tol_logit, tol_grad):
+    """Dropout ON at every site (0.1 hidden / attention / pos_emb / summary, MAG 0.5): device masks regenerated on the
+    host and replayed inside the oracle (which works in the reference's [L, B, .] layout) -> exact train-mode parity."""
+    layers, B, L, nh, H, DI = 2, 3, 24, 12, 768, 3072
+    m = build(layers, cdt).train()
+    o = oracle(layers).train()
+    core = m._core
+    b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=41)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
+    torch.nn.MSELoss()(logits.view(-1), lab.view(-1)).backward()
+    seed, step = core.seed, core.step
+    mult = lambda site, p, n: torch.from_numpy(rng.keep_mult(n, rng.make_key(seed, step, site, p)))
+    blx = lambda site, p, Xd: mult(site, p, B * L * Xd).view(B, L, Xd).permute(1, 0, 2)        # engine [B,L,X] -> oracle [L,B,X]
+    o.transformer.dropout = _SeqReplay([blx(rng.XS_EMB, 0.1, H), mult(rng.XS_POS, 0.1, 2 * L * B * H).view(2 * L, B, H),
+                                        blx(rng.XS_FINAL, 0.1, H)])
+    o.transformer.MAG.dropout = _SeqReplay([blx(rng.XS_MAG, 0.5, H)])
+    o.sequence_summary.last_dropout = _SeqReplay([mult(rng.XS_HEAD, 0.1, B * H).view(B, H)])
+    for l, lyr in enumerate(o.transformer.layer):
+        s0 = rng.XS_LAYER0 + 8 * l
+        lyr.rel_attn.dropout = _SeqReplay([mult(s0 + 0, 0.1, B * nh * L * L).view(B, nh, L, L), blx(s0 + 1, 0.1, H)])
+        lyr.ff.dropout = _SeqReplay([blx(s0 + 2, 0.1, DI), blx(s0 + 3, 0.1, H)])
+    i2, v2, a2, m2, s2, l2 = tb(b)
+    lo = o(i2, v2, a2, m2, s2)[0]
+    torch.nn.functional.mse_loss(lo.view(-1), l2.view(-1)).backward()
+    torch.cuda.synchronize()
+    err = float((logits.detach().cpu() - lo.detach()).abs().max())
+    print("xlnet train-mode logits max|err|:", err)
+    assert err <= tol_logit
+    _grad_report(m, o, tol_grad, frobenius=(cdt == torch.bfloat16))
+
+
+def test_three_optimizer_steps_track_the_oracle_fp32():
+    layers = 2
+    m = build(layers=layers, p_mag=0.0, p=0.0).train()
+    o = X.set_dropout(oracle(layers=layers, p_mag=0.0), 0.0, 0.0).train()
+    from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
+    opt = AdamW(optimizer_grouped_parameters(m), lr=1e-3)
+    sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=1.0, num_training_steps=10)
+    oo = O.AdamW(O.grouped_parameters(o), lr=1e-3)
+    so = O.get_linear_schedule_with_warmup(oo, num_warmup_steps=1.0, num_training_steps=10)
+    mask0 = m.transformer.mask_emb.detach().clone()
+    for s in range(3):
+        b = weights.synthetic_xlnet_batch(4, 50, 47, 74, seed=50 + s)
+        ids, vis, aco, mask, seg, lab = tb(b, DEV)
+        m.training_step(ids, vis, aco, mask, seg, lab)
+        opt.step(); sch.step(); opt.zero_grad()
+        i2, v2, a2, m2, s2, l2 = tb(b)
+        oo.zero_grad()
+        torch.nn.functional.mse_loss(o(i2, v2, a2, m2, s2)[0].view(-1), l2.view(-1)).backward()
+        oo.step(); so.step()
+    torch.cuda.synchronize()
+    assert float(m.flat_grads.abs().max()) == 0.0
+    assert torch.equal(m.transformer.mask_emb.detach(), mask0)         # no gradient -> HF AdamW never touches it (no decay either)
+    om = dict(o.named_parameters())
+    worst = max(float((p.detach().cpu() - om[n].detach()).abs().max()) for n, p in m.named_parameters())
+    print("max |param - oracle param| after 3 steps:", worst)
+    assert worst <= 2e-4
+    m.eval(); o.eval()
+    b = weights.synthetic_xlnet_batch(4, 50, 47, 74, seed=60)
+    ids, vis, aco, mask, seg, _ = tb(b, DEV)
+    with torch.no_grad():
+        l1 = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0].cpu()
+        l0 = o(*tb(b)[:5])[0]
+    assert float((l1 - l0).abs().max()) <= 5e-3
+
+
+def test_too_long_sequence_is_rejected():
+    m = build(layers=1).eval()
+    ids, vis, aco, mask, seg, _ = tb(weights.synthetic_xlnet_batch(2, 80, 47, 74, seed=5), DEV)
+    with pytest.raises(Exception):
+        m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)
