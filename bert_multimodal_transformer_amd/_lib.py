@@ -41,6 +41,7 @@ PROTOTYPES = {
     "mb_version": (_i, []),
     "mb_make_dropkey": (None, [_u64, _u64, _u32, _f, _dk]),
     "mb_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _dk, _i, _i, _vp]),
+    "mb_gemm_grouped_wgrad": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mb_layernorm_forward": (_i, [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _dk, _vp]),
     "mb_layernorm_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _dk, _dk, _vp]),
     "mb_embed_forward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _dk, _vp]),
@@ -68,6 +69,8 @@ PROTOTYPES = {
     "mb_bert_sequence_output": (_vp, [_vp]),
     "mb_bert_pooled_output": (_vp, [_vp]),
     "mb_bert_stage_grad_ranges": (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz), _i]),
+    "mb_bert_set_profiling": (_i, [_vp, _i]),
+    "mb_bert_profile_wgrad_us": (_i, [_vp, C.POINTER(_f)]),
     "mb_xlnet_create": (_i, [C.POINTER(XlnetEngineConfig), C.POINTER(_vp)]),
     "mb_xlnet_destroy": (None, [_vp]),
     "mb_xlnet_num_tensors": (_i, [_vp]),

@@ -136,11 +136,12 @@ class _Core(object):
             float(mc.dropout_prob), self.dt, int(B), int(L))
 
     def _make_engine(self, B, L):
-        if self.handle is not None:
-            self._fn("destroy")(self.handle)
         h = C.c_void_p()
         cfg = self._cfg(B, L)
-        _lib.check(self._fn("create")(C.byref(cfg), C.byref(h)))
+        _lib.check(self._fn("create")(C.byref(cfg), C.byref(h)))       # raises (and keeps the old engine) on a bad shape
+        if self.handle is not None:
+            self._fn("destroy")(self.handle)
+            self.ws = None
         self.handle = h
         self.max_B, self.max_L = B, L
 

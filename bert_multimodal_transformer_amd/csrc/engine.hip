@@ -31,7 +31,8 @@ struct mb_bert_engine {
     size_t ws_mag, ws_emb, ws_emb_st, ws_head_z, ws_head_pooled, ws_logits;
     std::vector<size_t> ws_x;
     std::vector<LayerWs> lw;
-    size_t ws_dxa, ws_dxb, ws_ds, ws_dzd, ws_ds2, ws_dzd2, ws_du, ws_dqkv, ws_dctx, ws_dsum, ws_dz, ws_lnp_a, ws_lnp_b;
+    size_t ws_ds[2], ws_dzd[2], ws_ds2[2], ws_dzd2[2], ws_du[2], ws_dqkv[2];   // dY operands of the wgrads: ping-pong by layer parity
+    size_t ws_dxa, ws_dxb, ws_dctx, ws_dsum, ws_dz, ws_lnp_a, ws_lnp_b;
     size_t ws_ids, ws_seg, ws_mask, ws_labels;    // (inputs are caller pointers; kept for the backward)
     size_t ws_bytes;
     // bound buffers
@@ -44,6 +45,10 @@ struct mb_bert_engine {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> evs;      // 5 events per encoder stage (4 forks + 1 join), never reused within a backward
     int overlap_wgrad = 1;
+    int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128), 0 = four launches
+    bool deferred = false;         // grouped launch on the side stream, joined one stage later
+    bool prof = false;             // mb_bert_set_profiling: timing events around every grouped wgrad launch (on the side stream)
+    std::vector<hipEvent_t> pev;   // [2 * num_layers]
     bool ws_zeroed = false;
     uint64_t seed = 0, step = 0;
     float* logits = nullptr;
@@ -137,8 +142,11 @@ static void build_layout(mb_bert_engine* e) {
     e->ws_head_z = w.take((size_t)c.max_batch * H * 4);
     e->ws_head_pooled = w.take((size_t)c.max_batch * H * 4);
     e->ws_logits = w.take((size_t)c.max_batch * c.num_labels * 4);
-    e->ws_dxa = w.take(T * H * es); e->ws_dxb = w.take(T * H * es); e->ws_ds = w.take(T * H * es);
-    e->ws_dzd = w.take(T * H * es); e->ws_ds2 = w.take(T * H * es); e->ws_dzd2 = w.take(T * H * es); e->ws_du = w.take(T * I * es); e->ws_dqkv = w.take(T * 3 * H * es);
+    e->ws_dxa = w.take(T * H * es); e->ws_dxb = w.take(T * H * es);
+    for (int k = 0; k < 2; ++k) {
+        e->ws_ds[k] = w.take(T * H * es); e->ws_dzd[k] = w.take(T * H * es); e->ws_ds2[k] = w.take(T * H * es);
+        e->ws_dzd2[k] = w.take(T * H * es); e->ws_du[k] = w.take(T * I * es); e->ws_dqkv[k] = w.take(T * 3 * H * es);
+    }
     e->ws_dctx = w.take(T * H * es); e->ws_dsum = w.take(T * H * 4); e->ws_dz = w.take((size_t)c.max_batch * H * es);
     e->ws_lnp_a = w.take(ln_partials_floats((int)T, (int)H) * 4); e->ws_lnp_b = w.take(ln_partials_floats((int)T, (int)H) * 4);
     e->ws_bytes = w.off;
@@ -170,6 +178,15 @@ int mb_gemm(int dtype, int layout, int epilogue, int M, int N, int K, const void
     a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.C = C; a.ldc = ldc; a.C2 = C2; a.Cf = Cf;
     a.bias = bias; a.R = R; a.ldr = ldr; a.alpha = alpha; a.drop = dk(drop); a.kchunk = K; a.colsum = nullptr;
     return gemm_launch(dtype, layout, epilogue, a, splits, tile, (hipStream_t)stream);
+}
+
+int mb_gemm_grouped_wgrad(int dtype, int count, const int* M, const int* N, int K, const void* const* dY, const int* ldy,
+                          const void* const* X, const int* ldx, float* const* dW, const int* ldw, int tile, void* stream) {
+    if (count < 1 || count > MB_MAX_GROUP || !M || !N || !dY || !X || !dW || !ldy || !ldx || !ldw) return MB_ERR_ARG;
+    GemmArgs g[MB_MAX_GROUP];
+    for (int i = 0; i < count; ++i) g[i] = wgrad_args(M[i], N[i], K, dY[i], ldy[i], X[i], ldx[i], dW[i], ldw[i]);
+    if (!gemm_grouped_tn_ok(dtype, g, count, tile)) return MB_ERR_SHAPE;
+    return gemm_grouped_tn_launch(dtype, g, count, tile, (hipStream_t)stream);
 }
 
 int mb_layernorm_forward(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
@@ -255,6 +272,9 @@ int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
     mb_bert_engine* e = new mb_bert_engine();
     e->c = *cfg;
     if (const char* v = getenv("MB_OVERLAP_WGRAD")) e->overlap_wgrad = atoi(v);
+    if (const char* v = getenv("MB_GROUP_WGRAD")) e->group_wgrad = atoi(v);
+    e->deferred = e->overlap_wgrad && (e->group_wgrad == 64 || e->group_wgrad == 128) &&
+                  cfg->hidden_size % e->group_wgrad == 0 && cfg->intermediate_size % e->group_wgrad == 0;
     build_layout(e);
     *out = e;
     return MB_OK;
@@ -263,6 +283,7 @@ void mb_bert_destroy(mb_bert_engine* e) {
     if (!e) return;
     if (e->side) hipStreamDestroy(e->side);
     for (auto& ev : e->evs) if (ev) hipEventDestroy(ev);
+    for (auto& ev : e->pev) if (ev) hipEventDestroy(ev);
     delete e;
 }
 int mb_bert_num_tensors(const mb_bert_engine* e) { return (int)e->tensors.size(); }
@@ -318,6 +339,8 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     float* P = e->P;
     char* ws = e->ws;
     const int Tp = (int)align_up((size_t)T, 64);
+    if (e->deferred && e->side)       // a backward that was not run to its last stage may still have weight-gradient GEMMs reading activations
+        for (size_t l = 0; l < 2 && l * 5 + 4 < e->evs.size(); ++l) CK((int)hipStreamWaitEvent(st, e->evs[l * 5 + 4], 0));
     if (!e->ws_zeroed) { CK((int)hipMemsetAsync(ws, 0, e->ws_bytes, st)); e->ws_zeroed = true; e->padT = T; }
     if (e->padT != T && Tp > T) {
         // a different batch shape ran before: rows [T, Tp) of every buffer that feeds a wgrad as the k-major operand
@@ -326,8 +349,11 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
         auto zp = [&](size_t off, size_t cols) {
             return (int)hipMemsetAsync(ws + off + (size_t)T * cols * es, 0, (size_t)(Tp - T) * cols * es, st);
         };
-        CK(zp(e->ws_emb, H)); CK(zp(e->ws_ds, H)); CK(zp(e->ws_dzd, H)); CK(zp(e->ws_ds2, H)); CK(zp(e->ws_dzd2, H));
-        CK(zp(e->ws_du, I)); CK(zp(e->ws_dqkv, 3 * H));
+        CK(zp(e->ws_emb, H));
+        for (int k = 0; k < 2; ++k) {
+            CK(zp(e->ws_ds[k], H)); CK(zp(e->ws_dzd[k], H)); CK(zp(e->ws_ds2[k], H)); CK(zp(e->ws_dzd2[k], H));
+            CK(zp(e->ws_du[k], I)); CK(zp(e->ws_dqkv[k], 3 * H));
+        }
         for (int l = 0; l <= c.num_layers; ++l) CK(zp(e->ws_x[l], H));
         for (int l = 0; l < c.num_layers; ++l) { CK(zp(e->lw[l].ctx, H)); CK(zp(e->lw[l].y1, H)); CK(zp(e->lw[l].g, I)); }
     }
@@ -403,10 +429,13 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             const LayerWs& w = e->lw[l];
             char* dx = ws + e->ws_dxa;     // grad wrt x[l+1] on entry, wrt x[l] on exit
             char* dy1 = ws + e->ws_dxb;
-            char* dsA = ws + e->ws_ds;                  // LN2 (FFN output) backward
-            char* dzdA = hd ? ws + e->ws_dzd : dsA;
-            char* dsB = ws + e->ws_ds2;                 // LN1 (attention output) backward
-            char* dzdB = hd ? ws + e->ws_dzd2 : dsB;
+            const int par = l & 1;                      // the grouped wgrad of layer l reads these while layer l-1 runs
+            char* dsA = ws + e->ws_ds[par];             // LN2 (FFN output) backward
+            char* dzdA = hd ? ws + e->ws_dzd[par] : dsA;
+            char* dsB = ws + e->ws_ds2[par];            // LN1 (attention output) backward
+            char* dzdB = hd ? ws + e->ws_dzd2[par] : dsB;
+            char* du = ws + e->ws_du[par];
+            char* dqkv = ws + e->ws_dqkv[par];
             // wgrad GEMMs go to the side stream: they only read (dY, saved X) and accumulate into G, so they overlap the
             // dgrad chain; dY buffers are per-LayerNorm (A/B) and the stage ends with a join, which keeps them race-free.
             hipStream_t ss = st;
@@ -431,20 +460,34 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             // LN2 + dropout backward (column sums -> per-block partial slabs, reduced once per layer below)
             CK(ln_backward_partials(dt, dx, ws + w.s2, P + o.ln2w, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, dsA,
                                     hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(SITE_LAYER0 + 4 * l + 2, c.hidden_dropout), st));
+            // The four weight gradients of the layer: one grouped launch once dqkv exists (MB_GROUP_WGRAD=0: four launches,
+            // each forked as soon as its dY is final).
+            GemmArgs wg[4] = {wgrad_args(H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I),
+                              wgrad_args(I, H, Tk, du, I, ws + w.y1, H, G + o.w1, H),
+                              wgrad_args(H, H, Tk, dzdB, H, ws + w.ctx, H, G + o.wo, H),
+                              wgrad_args(3 * H, H, Tk, dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H)};
+            const bool grouped = e->deferred;
+            if (grouped && !gemm_grouped_tn_ok(dt, wg, 4, e->group_wgrad)) return MB_ERR_SHAPE;
+            if (!grouped) {
             CK(fork(0));
             CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, ss));
+            }
             // du = (dzd . W2) * gelu'(u), with the intermediate bias gradient (column sums of du) fused into the epilogue
-            CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, ws + e->ws_du, I, nullptr, G + o.b1, nullptr,
+            CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, du, I, nullptr, G + o.b1, nullptr,
                     ws + w.u, I, kNoDrop, 1, 0, st));
+            if (!grouped) {
             CK(fork(1));
-            CK(wgrad(dt, I, H, Tk, ws + e->ws_du, I, ws + w.y1, H, G + o.w1, H, ss));
-            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, I, ws + e->ws_du, I, e->W(o.w1), H, dy1, H, nullptr, nullptr, nullptr, dsA,
+            CK(wgrad(dt, I, H, Tk, du, I, ws + w.y1, H, G + o.w1, H, ss));
+            }
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, I, du, I, e->W(o.w1), H, dy1, H, nullptr, nullptr, nullptr, dsA,
                     H, kNoDrop, 1, 0, st));
             // LN1 + dropout backward
             CK(ln_backward_partials(dt, dy1, ws + w.s1, P + o.ln1w, (const float*)(ws + w.st1), (const float*)(ws + w.st1) + T, dsB,
                                     hd ? dzdB : nullptr, lnp_b, &nblk, T, H, e->key(SITE_LAYER0 + 4 * l + 1, c.hidden_dropout), st));
+            if (!grouped) {
             CK(fork(2));
             CK(wgrad(dt, H, H, Tk, dzdB, H, ws + w.ctx, H, G + o.wo, H, ss));
+            }
             {
                 float* const dst6[6] = {G + o.ln2w, G + o.ln2b, G + o.b2, G + o.ln1w, G + o.ln1b, G + o.bo};
                 CK(ln_reduce_partials(lnp_a, lnp_b, nblk, H, dst6, st));
@@ -452,18 +495,28 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.wo), H, ws + e->ws_dctx, H, nullptr, nullptr, nullptr,
                     nullptr, 0, kNoDrop, 1, 0, st));
             // attention backward; the fused-QKV bias gradient (column sums of dqkv) is accumulated inside the kernel
-            CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, ws + e->ws_dqkv, G + o.bqkv, B, L, nh,
+            CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, dqkv, G + o.bqkv, B, L, nh,
                                   e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st));
             CK(fork(3));
-            CK(wgrad(dt, 3 * H, H, Tk, ws + e->ws_dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H, ss));
-            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, 3 * H, ws + e->ws_dqkv, 3 * H, e->W(o.wqkv), H, dx, H, nullptr, nullptr,
+            if (grouped) {
+                if (e->prof) CK((int)hipEventRecord(e->pev[2 * l], ss));
+                CK(gemm_grouped_tn_launch(dt, wg, 4, e->group_wgrad, ss));
+                if (e->prof) CK((int)hipEventRecord(e->pev[2 * l + 1], ss));
+                CK((int)hipEventRecord(sev[4], ss));          // "weight gradients of layer l are final"
+            } else CK(wgrad(dt, 3 * H, H, Tk, dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H, ss));
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, 3 * H, dqkv, 3 * H, e->W(o.wqkv), H, dx, H, nullptr, nullptr,
                     nullptr, dsB, H, kNoDrop, 1, 0, st));
-            if (ss != st) {      // join: the stage's gradients are complete (and dY buffers reusable) once main passes this
+            if (ss != st && !grouped) {      // join: the stage's gradients are complete (and dY buffers reusable) once main passes this
                 CK((int)hipEventRecord(sev[4], ss));
                 CK((int)hipStreamWaitEvent(st, sev[4], 0));
             }
+            // deferred join: the grouped wgrad of layer l keeps running under the dgrad chain of layer l-1; main only
+            // waits for layer l+1's (whose dY buffers, same parity as l-1, are written next).  What is final on `st` when
+            // this stage returns is therefore: weights of layer l+1, biases / LayerNorm of layer l (mb_bert_stage_grad_ranges)
+            if (grouped && l + 1 < NL) CK((int)hipStreamWaitEvent(st, e->evs[(size_t)(l + 1) * 5 + 4], 0));
         } else {
             // ---- MAG + embeddings
+            if (e->deferred && e->side) CK((int)hipStreamWaitEvent(st, e->evs[4], 0));      // weight gradients of layer 0
             char* dx = ws + e->ws_dxa;
             char* de = ws + e->ws_dxb;
             CK(mag_bwd_impl(dt, dx, ws + e->ws_emb, P + e->mag_bhv, P + e->mag_bha, P + e->mag_bv, P + e->mag_ba,
@@ -477,6 +530,29 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                                  G + e->emb_lnb, B, L, H, c.pad_token_id, e->key(SITE_EMB, c.hidden_dropout), st));
         }
     }
+    return MB_OK;
+}
+
+int mb_bert_set_profiling(mb_bert_engine* e, int on) {
+    if (!e) return MB_ERR_ARG;
+    if (on && e->pev.empty()) {
+        e->pev.assign((size_t)2 * e->c.num_layers, nullptr);
+        for (auto& ev : e->pev) CK((int)hipEventCreate(&ev));
+    }
+    e->prof = on != 0;
+    return MB_OK;
+}
+
+int mb_bert_profile_wgrad_us(mb_bert_engine* e, float* avg_us) {
+    if (!e || !avg_us || !e->prof || !e->deferred) return MB_ERR_ARG;
+    double sum = 0.0;
+    for (int l = 0; l < e->c.num_layers; ++l) {
+        float ms = 0.f;
+        CK((int)hipEventSynchronize(e->pev[2 * l + 1]));
+        CK((int)hipEventElapsedTime(&ms, e->pev[2 * l], e->pev[2 * l + 1]));
+        sum += ms;
+    }
+    *avg_us = (float)(sum * 1e3 / e->c.num_layers);
     return MB_OK;
 }
 
@@ -495,9 +571,12 @@ int mb_bert_stage_grad_ranges(const mb_bert_engine* e, int stage, size_t* offs, 
     } else if (stage <= NL) {
         const int l = NL - stage;
         const LayerOff& o = e->lo[l];
-        span(o.wqkv, l + 1 < NL ? e->lo[l + 1].wqkv : e->wp);
+        auto wspan = [&](int k) { span(e->lo[k].wqkv, k + 1 < NL ? e->lo[k + 1].wqkv : e->wp); };
+        if (!e->deferred) wspan(l);
+        else if (l + 1 < NL) wspan(l + 1);       // deferred join: the weights arrive one stage late
         span(o.bqkv, l + 1 < NL ? e->lo[l + 1].bqkv : e->emb_lnw);
     } else if (stage == NL + 1) {
+        if (e->deferred) span(e->lo[0].wqkv, NL > 1 ? e->lo[1].wqkv : e->wp);
         span(e->word, e->wc);                                 // embeddings + MAG weights
         span(e->emb_lnw, e->bp);                              // embeddings LayerNorm
         span(e->mag_bhv, e->bc);                              // MAG biases + LayerNorm

@@ -94,6 +94,15 @@ inline int gemm(int dtype, int layout, int mode, int M, int N, int K, const void
     return gemm_launch(dtype, layout, mode, a, splits, tile, st);
 }
 
+// operands of one weight gradient dW[Mo][No] += dY[rows][Mo]^T X[rows][No] (GEMM_TN, EPI_ACCUM_F32)
+inline GemmArgs wgrad_args(int Mo, int No, int rows, const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw) {
+    GemmArgs a;
+    a.A = dY; a.B = X; a.M = Mo; a.N = No; a.K = rows; a.lda = ldy; a.ldb = ldx;
+    a.C = nullptr; a.ldc = ldw; a.C2 = nullptr; a.Cf = dW; a.bias = nullptr; a.colsum = nullptr; a.R = nullptr; a.ldr = 0;
+    a.alpha = 1.0f; a.drop = kNoDrop; a.kchunk = rows; a.dbg = 0; a.reg_m = a.reg_n = a.tpr_m = a.tpr_n = 0;
+    return a;
+}
+
 // wgrad: dW[N'][K'] += dY^T X, reduction over `rows` tokens; picks tile + split-K to fill the 256 CUs
 inline int wgrad(int dtype, int Mo, int No, int rows, const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw,
           hipStream_t st) {

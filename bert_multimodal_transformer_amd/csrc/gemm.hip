@@ -104,8 +104,8 @@ struct Stager {
 // L2 and are fetched from HBM / Infinity Cache once per XCD instead of once per tile.  The grid is padded to
 // 8 * (tiles per region); blocks that fall outside the tile grid exit.
 template <int BM, int BN>
-__device__ __forceinline__ bool tile_origin(const GemmArgs& p, int& m0, int& n0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+__device__ __forceinline__ bool tile_origin(const GemmArgs& p, int& m0, int& n0, int bid = blockIdx.x) {
+    const int xcd = bid & 7, j = bid >> 3;
     const int xm = xcd / p.reg_n, xn = xcd % p.reg_n;
     const int tm = xm * p.tpr_m + j / p.tpr_n, tn = xn * p.tpr_n + j % p.tpr_n;
     m0 = tm * BM;
@@ -404,8 +404,12 @@ struct Dma {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <int BM, int BN, int NSTAGE, int KB>
+struct Gemm2Smem { static constexpr int STAGE = (BM + BN) * KB;
+                   static constexpr int BYTES = NSTAGE * STAGE > BM * BN * 4 ? NSTAGE * STAGE : BM * BN * 4; };   // ring, reused by the epilogue tile
+
 template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB>
-__global__ void __launch_bounds__(256) gemm2_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int bid, const int ky, char* smem) {
     constexpr int BKE = KB / sizeof(T);
     constexpr int MT = BM / 32, NT = BN / 32;
     constexpr int STAGE = (BM + BN) * KB;
@@ -413,15 +417,13 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const GemmArgs p) {
     typedef Dma<T, BM, AK, KB> DA;
     typedef Dma<T, BN, BK, KB> DB;
     constexpr int G = DA::NI + DB::NI;            // DMA instructions per wave per stage
-    constexpr int SMEM = NSTAGE * STAGE > BM * BN * 4 ? NSTAGE * STAGE : BM * BN * 4;     // ring, reused by the epilogue tile
-    __shared__ __attribute__((aligned(1024))) char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     int m0, n0;
-    if (!tile_origin<BM, BN>(p, m0, n0)) return;
-    const int kbeg = blockIdx.y * p.kchunk;
+    if (!tile_origin<BM, BN>(p, m0, n0, bid)) return;
+    const int kbeg = ky * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nt = (kend - kbeg) / BKE;
     const T* __restrict__ A = (const T*)p.A;
@@ -483,6 +485,27 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const GemmArgs p) {
     gemm_epilogue<T, BM, BN, MODE>(p, acc, m0, n0, wr, wc, lane, smem);
 }
 
+template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB>
+__global__ void __launch_bounds__(256) gemm2_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB>::BYTES];
+    gemm2_body<T, BM, BN, AK, BK, MODE, NSTAGE, KB>(p, blockIdx.x, blockIdx.y, smem);
+}
+
+// Grouped wgrad: up to MB_MAX_GROUP independent dW += dY^T X problems in ONE launch.  Each of a layer's four weight
+// gradients alone is at most ~2 blocks per CU (one under-filled round whose duration is set by the K = T loop latency,
+// not by its size); launched together they are one grid of ~7 blocks per CU that keeps every CU's LDS ring full.
+// Problem g owns blocks [first[g], first[g+1]) (multiples of 8, so block -> XCD mapping is unchanged).
+template <class T, int BM, int BN, int NSTAGE, int KB>
+__global__ void __launch_bounds__(256) gemm2_grouped_tn_kernel(const GroupedGemmArgs ga) {
+    __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB>::BYTES];
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < MB_MAX_GROUP; ++i)
+        if (i < ga.count && (int)blockIdx.x >= ga.first[i]) g = i;
+    g = __builtin_amdgcn_readfirstlane(g);
+    gemm2_body<T, BM, BN, true, true, EPI_ACCUM_F32, NSTAGE, KB>(ga.g[g], (int)blockIdx.x - ga.first[g], 0, smem);
+}
+
 // ---------------------------------------------------------------------------------------------- host
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -490,22 +513,26 @@ static int env_int(const char* name, int dflt) {
 }
 static int g_impl = -1, g_stages = -1, g_dbg = 0;      // MB_GEMM_IMPL: 0 auto, 1 = register-staged v1, 2 = LDS-DMA v2 ; MB_GEMM_STAGES: 2|3|4
 
+// choose the 8-region (one per XCD) decomposition with the smallest per-XCD panel footprint; returns the padded grid size
+template <int BM, int BN>
+static int choose_regions(GemmArgs& p) {
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    long best = -1;
+    for (int rm = 1; rm <= 8; rm *= 2) {
+        const int rn = 8 / rm;
+        const int pm = (tiles_m + rm - 1) / rm, pn = (tiles_n + rn - 1) / rn;
+        const long cost = (long)pm * BM + (long)pn * BN + 4L * ((long)pm * pn * 8 - (long)tiles_m * tiles_n);   // footprint + padding waste
+        if (best < 0 || cost < best) { best = cost; p.reg_m = rm; p.reg_n = rn; p.tpr_m = pm; p.tpr_n = pn; }
+    }
+    return 8 * p.tpr_m * p.tpr_n;
+}
+
 template <class T, int BM, int BN, bool AK, bool BK, int MODE>
 static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
     GemmArgs p = a;
     constexpr int BKE = 128 / sizeof(T);
     constexpr int EPV = 16 / sizeof(T);
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    {   // choose the 8-region decomposition with the smallest per-XCD panel footprint
-        long best = -1;
-        for (int rm = 1; rm <= 8; rm *= 2) {
-            const int rn = 8 / rm;
-            const int pm = (tiles_m + rm - 1) / rm, pn = (tiles_n + rn - 1) / rn;
-            const long cost = (long)pm * BM + (long)pn * BN + 4L * ((long)pm * pn * 8 - (long)tiles_m * tiles_n);   // footprint + padding waste
-            if (best < 0 || cost < best) { best = cost; p.reg_m = rm; p.reg_n = rn; p.tpr_m = pm; p.tpr_n = pn; }
-        }
-    }
-    const int tiles = 8 * p.tpr_m * p.tpr_n;
+    const int tiles = choose_regions<BM, BN>(p);
     if (splits < 1) splits = 1;
     int kchunk = (p.K + splits - 1) / splits;
     kchunk = (kchunk + BKE - 1) / BKE * BKE;
@@ -583,6 +610,49 @@ static int launch_T(const GemmArgs& a, int layout, int mode, int splits, int til
         }
     }
     return MB_ERR_MODE;
+}
+
+template <class T, int BM, int BN>
+static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
+    constexpr int BKE = 128 / sizeof(T);
+    constexpr int EPV = 16 / sizeof(T);
+    GroupedGemmArgs ga;
+    ga.count = count;
+    int total = 0;
+    for (int i = 0; i < count; ++i) {
+        GemmArgs& p = ga.g[i];
+        p = probs[i];
+        // LDS-DMA path preconditions (as in launch_cfg): whole tiles, whole 128-byte K rows, 16-byte aligned operands
+        if (p.K % BKE || p.M % BM || p.N % BN || p.lda % EPV || p.ldb % EPV || p.N % 8 || p.ldc % 8 ||
+            (((uintptr_t)p.A | (uintptr_t)p.B) % 16))
+            return MB_ERR_SHAPE;
+        ga.first[i] = total;
+        total += choose_regions<BM, BN>(p);
+        p.kchunk = p.K;
+        p.dbg = 0;
+    }
+    ga.first[count] = total;
+    hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128>), dim3(total), dim3(256), 0, st, ga);
+    return (int)hipGetLastError();
+}
+
+int gemm_grouped_tn_ok(int dtype, const GemmArgs* probs, int count, int tile) {
+    const int BKE = dtype == DT_BF16 ? 64 : 32, EPV = dtype == DT_BF16 ? 8 : 4;
+    if (count < 1 || count > MB_MAX_GROUP || (tile != 64 && tile != 128)) return 0;
+    for (int i = 0; i < count; ++i) {
+        const GemmArgs& p = probs[i];
+        if (p.K % BKE || p.M % tile || p.N % tile || p.lda % EPV || p.ldb % EPV || p.ldc % 8 ||
+            (((uintptr_t)p.A | (uintptr_t)p.B) % 16))
+            return 0;
+    }
+    return 1;
+}
+
+int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st) {
+    if (count < 1 || count > MB_MAX_GROUP) return MB_ERR_ARG;
+    if (dtype == DT_BF16) return tile == 128 ? launch_grouped<bf16, 128, 128>(probs, count, st) : launch_grouped<bf16, 64, 64>(probs, count, st);
+    if (dtype == DT_F32) return tile == 128 ? launch_grouped<float, 128, 128>(probs, count, st) : launch_grouped<float, 64, 64>(probs, count, st);
+    return MB_ERR_DTYPE;
 }
 
 int gemm_launch(int dtype, int layout, int mode, const GemmArgs& a, int splits, int tile, hipStream_t st) {

@@ -44,6 +44,17 @@ struct GemmArgs {
 // tile: 0 = auto, 64 or 128.  splits: split-K factor (only EPI_ACCUM_F32).
 int gemm_launch(int dtype, int layout, int mode, const GemmArgs& a, int splits, int tile, hipStream_t st);
 
+// Grouped wgrad (GEMM_TN, EPI_ACCUM_F32): `count` <= MB_MAX_GROUP problems Cf_g[M_g][N_g] += A_g^T B_g in one launch.
+// Needs whole tiles and whole 128-byte K rows for every problem (gemm_grouped_tn_ok tells); tile = 64 | 128.
+#define MB_MAX_GROUP 4
+struct GroupedGemmArgs {
+    GemmArgs g[MB_MAX_GROUP];
+    int first[MB_MAX_GROUP + 1];
+    int count;
+};
+int gemm_grouped_tn_ok(int dtype, const GemmArgs* probs, int count, int tile);
+int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st);
+
 // ------------------------------------------------------------------------------------------ row kernels (rowops.hip)
 // LayerNorm over the last dim H (H % 256 == 0, H <= 1024): y = (x-mean)*rstd*gamma + beta ; optional dropout on y.
 int ln_forward(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,

@@ -45,6 +45,12 @@ int mb_gemm(int dtype, int layout, int epilogue, int M, int N, int K, const void
             void* C, int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, float alpha,
             const mb_dropkey* drop, int splits, int tile, void* stream);
 
+/* `count` (<= 4) weight gradients dW_g[M_g][N_g] += dY_g[K][M_g]^T X_g[K][N_g] in ONE launch (fp32 accumulate) -- the
+ * four torch.nn.Linear weight gradients autograd produces per BertLayer (mm_backward under loss.backward(),
+ * multimodal_driver.py:378).  Every M_g, N_g must be a multiple of `tile` (64 | 128) and K a multiple of 128 bytes. */
+int mb_gemm_grouped_wgrad(int dtype, int count, const int* M, const int* N, int K, const void* const* dY, const int* ldy,
+                          const void* const* X, const int* ldx, float* const* dW, const int* ldw, int tile, void* stream);
+
 /* LayerNorm (+ dropout on the output) forward / backward -- torch.nn.LayerNorm under BertSelfOutput/BertOutput. */
 int mb_layernorm_forward(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,
                          float* mean, float* rstd, int rows, int H, const mb_dropkey* drop, void* stream);
@@ -138,6 +144,13 @@ const void* mb_bert_sequence_output(const mb_bert_engine* e);   /* [B*L][H] in d
 const float* mb_bert_pooled_output(const mb_bert_engine* e);    /* [B][H] fp32 (pre-dropout) */
 /* gradient buckets for data parallelism: range r of stage s covers flat elements [off, off+len) */
 int mb_bert_stage_grad_ranges(const mb_bert_engine* e, int stage, size_t* offs, size_t* lens, int cap);
+
+/* Measurement hooks (bench.py): with profiling on, every per-layer grouped weight-gradient launch of mb_bert_backward is
+ * bracketed by HIP timing events on the engine's internal side stream -- the stream that kernel runs on, which the
+ * caller cannot see.  mb_bert_profile_wgrad_us waits for the last backward's events and returns the mean launch
+ * duration over the layers, i.e. the in-step duration (concurrent with the dgrad chain), comparable with rocprofv3. */
+int mb_bert_set_profiling(mb_bert_engine* e, int on);
+int mb_bert_profile_wgrad_us(mb_bert_engine* e, float* avg_us);
 
 /* ------------------------------------------------------------------------------------------------ MAG-XLNet engine
  * MAG_XLNetForSequenceClassification forward / backward (xlnet.py:432-527 -> :15-429; XLNetLayer / SequenceSummary of

@@ -117,6 +117,32 @@ def test_gemm_tn_wgrad(dt, tdt, M, N, K, splits, tile):
 
 
 @pytest.mark.parametrize("dt,tdt", DTS)
+@pytest.mark.parametrize("tile", [64, 128])
+def test_gemm_grouped_wgrad(dt, tdt, tile):
+    """the per-layer grouped weight-gradient launch == four independent fp32-accumulating TN GEMMs"""
+    L = _lib.lib()
+    K = 2432
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]          # [M_g = dY cols][N_g = X cols]
+    dY = [rnd((K, m), 20 + i, tdt).to(DEV, tdt) for i, (m, n) in enumerate(shapes)]
+    X = [rnd((K, n), 30 + i, tdt, 0.1).to(DEV, tdt) for i, (m, n) in enumerate(shapes)]
+    init = [rnd((m, n), 40 + i, torch.float32) for i, (m, n) in enumerate(shapes)]
+    dW = [t.to(DEV).clone() for t in init]
+    ia = lambda v: (C.c_int * 4)(*v)
+    pa = lambda ts: (C.c_void_p * 4)(*[t.data_ptr() for t in ts])
+    _lib.check(L.mb_gemm_grouped_wgrad(dt, 4, ia([m for m, n in shapes]), ia([n for m, n in shapes]), K, pa(dY),
+                                       ia([m for m, n in shapes]), pa(X), ia([n for m, n in shapes]), pa(dW),
+                                       ia([n for m, n in shapes]), tile, stream()))
+    torch.cuda.synchronize()
+    for i in range(4):
+        ref = dY[i].double().t() @ X[i].double() + init[i].to(DEV).double()
+        close(dW[i].cpu(), ref.float().cpu(), _lib.DT_F32, "grouped wgrad %d" % i, 1.0)
+    # shapes that are not whole tiles are refused (the engine then uses the single-problem launches)
+    bad = L.mb_gemm_grouped_wgrad(dt, 1, ia([100, 0, 0, 0]), ia([128, 0, 0, 0]), K, pa(dY), ia([100, 0, 0, 0]), pa(X),
+                                  ia([128, 0, 0, 0]), pa(dW), ia([128, 0, 0, 0]), tile, stream())
+    assert bad != 0
+
+
+@pytest.mark.parametrize("dt,tdt", DTS)
 def test_layernorm_forward_backward(dt, tdt):
     L = _lib.lib()
     rows, H = 301, 768

@@ -243,7 +243,7 @@ def test_three_optimizer_steps_track_the_oracle_fp32():
 
 
 def test_too_long_sequence_is_rejected():
-    m = build(layers=1).eval()
+    m = build(layers=2).eval()
     ids, vis, aco, mask, seg, _ = tb(weights.synthetic_xlnet_batch(2, 80, 47, 74, seed=5), DEV)
     with pytest.raises(Exception):
         m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)
