@@ -43,6 +43,8 @@ def parse():
     p.add_argument("--seq", type=int, default=50)
     p.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     p.add_argument("--dataset", choices=["mosi", "mosei"], default="mosi")
+    p.add_argument("--model", choices=["bert", "xlnet"], default="bert",
+                   help="bert = the headline workload (BASELINE.json configs[1]); xlnet = configs[3] (MAG-XLNet), informational")
     p.add_argument("--cpu-baseline", type=int, default=1)
     p.add_argument("--cpu-steps", type=int, default=2)
     p.add_argument("--roofline", type=int, default=1)
@@ -52,18 +54,19 @@ def parse():
     return p.parse_args()
 
 
-def make_batches(n, B, L, V, A, seed):
+def make_batches(n, B, L, V, A, seed, layout="bert"):
     from bert_multimodal_transformer_amd.multimodal_driver import synthetic_dataset
-    ds = synthetic_dataset(n * B, L, V, A, seed_=seed)
+    ds = synthetic_dataset(n * B, L, V, A, seed_=seed, layout=layout)
     out = []
     for i in range(n):
         out.append(tuple(t[i * B:(i + 1) * B].contiguous().pin_memory() for t in ds.tensors))
     return out
 
 
-def cpu_baseline(B, L, V, A, steps):
+def cpu_baseline(B, L, V, A, steps, kind="bert"):
     """The same optimizer step on the host cores with the CPU oracle (pure torch restatement of the reference)."""
     from oracle import mag_bert_ref as R, optim_ref as O
+    from oracle import mag_xlnet_ref as X
     from bert_multimodal_transformer_amd.multimodal_driver import synthetic_dataset
     cores = os.cpu_count() or 1
     try:
@@ -73,10 +76,13 @@ def cpu_baseline(B, L, V, A, steps):
         pass
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    model = R.MAG_BertForSequenceClassification(R.BertConfigLite(), R.MultimodalConfig(1.0, 0.5), V, A).train()
+    if kind == "xlnet":
+        model = X.MAG_XLNetForSequenceClassification(X.XLNetConfigLite(), X.MultimodalConfig(1.0, 0.5), V, A).train()
+    else:
+        model = R.MAG_BertForSequenceClassification(R.BertConfigLite(), R.MultimodalConfig(1.0, 0.5), V, A).train()
     opt = O.AdamW(O.grouped_parameters(model), lr=1e-5)
     sch = O.get_linear_schedule_with_warmup(opt, 0.1 * 1040, 1040)
-    ds = synthetic_dataset(B * (steps + 1), L, V, A, seed_=7)
+    ds = synthetic_dataset(B * (steps + 1), L, V, A, seed_=7, layout=kind)
     times = []
     for s in range(steps + 1):
         ids, vis, aco, mask, seg, lab = (t[s * B:(s + 1) * B] for t in ds.tensors)
@@ -89,8 +95,8 @@ def cpu_baseline(B, L, V, A, steps):
         times.append(time.perf_counter() - t0)
     t = float(np.median(times[1:])) if steps > 0 else float("nan")
     return {"value": B / t, "unit": "samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "%d timed optimizer steps (1 warmup) of the same B=%d L=%d MAG-BERT step, fp32, dropout on, "
-                      "oracle/mag_bert_ref.py + HF-AdamW, median step %.2f s" % (steps, B, L, t)}
+            "sample": "%d timed optimizer steps (1 warmup) of the same B=%d L=%d MAG-%s step, fp32, dropout on, "
+                      "oracle/mag_%s_ref.py + HF-AdamW, median step %.2f s" % (steps, B, L, kind.upper(), kind, t)}
 
 
 def gemm_roofline(dtype_name, T, reps=30):
@@ -189,8 +195,13 @@ def main():
     B, L = a.batch, a.seq
     torch.manual_seed(1234)        # same init on every rank (then broadcast anyway)
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    model = MAG_BertForSequenceClassification(BertConfig(num_labels=1), MultimodalConfig(1.0, 0.5), visual_dim=V,
-                                              acoustic_dim=A, compute_dtype=cdt)
+    if a.model == "xlnet":
+        from bert_multimodal_transformer_amd import MAG_XLNetForSequenceClassification, XLNetConfig
+        model = MAG_XLNetForSequenceClassification(XLNetConfig(num_labels=1), MultimodalConfig(1.0, 0.5), visual_dim=V,
+                                                   acoustic_dim=A, compute_dtype=cdt)
+    else:
+        model = MAG_BertForSequenceClassification(BertConfig(num_labels=1), MultimodalConfig(1.0, 0.5), visual_dim=V,
+                                                  acoustic_dim=A, compute_dtype=cdt)
     opt = AdamW(optimizer_grouped_parameters(model), lr=1e-5)
     total_steps = a.steps + a.warmup
     sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=0.1 * 1040, num_training_steps=1040)
@@ -202,7 +213,7 @@ def main():
         opt.enable_overlap(model)
     model.train()
     nb = 8
-    batches = make_batches(nb, B, L, V, A, seed=1234 + rank)
+    batches = make_batches(nb, B, L, V, A, seed=1234 + rank, layout=a.model)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     # `value` is quoted with the inputs already resident in HBM; the H2D-inclusive rate (the reference moves every batch
@@ -249,6 +260,8 @@ def main():
         import ctypes as C
         from bert_multimodal_transformer_amd import _lib
         core = model._core
+        if core.kind != "bert":
+            raise RuntimeError("the MAG-XLNet engine launches its weight gradients one by one on the main stream")
         _lib.check(_lib.lib().mb_bert_set_profiling(core.handle, 1))
         acc = []
         for i in range(6):
@@ -267,12 +280,13 @@ def main():
 
     out = None
     if rank == 0:
-        gflop = TRAIN_GFLOP_PER_SAMPLE_L50 if (L == 50 and V == 47) else None
+        gflop = TRAIN_GFLOP_PER_SAMPLE_L50 if (L == 50 and V == 47 and a.model == "bert") else None
+        mname = "MAG-BERT" if a.model == "bert" else "MAG-XLNet"
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
-        out = {"metric": "train samples/sec MAG-BERT MOSI seq_len=%d" % L, "value": round(value, 2), "unit": "samples/s",
+        out = {"metric": "train samples/sec %s MOSI seq_len=%d" % (mname, L), "value": round(value, 2), "unit": "samples/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": "MAG-BERT bert-base-uncased, %s dims (V=%d, A=%d), batch %d/GPU, seq_len %d, full "
+               "config": {"workload": mname + (" bert-base-uncased" if a.model == "bert" else " xlnet-base-cased") + ", %s dims (V=%d, A=%d), batch %d/GPU, seq_len %d, full "
                                       "optimizer step (fwd+MSE+bwd%s+HF-AdamW+schedule; inputs resident in HBM), dropout on, random-init weights"
                                       % (a.dataset.upper(), V, A, B, L, "+RCCL all-reduce" if world > 1 else ""),
                           "global_batch": world * B, "seq_len": L, "parallelism": "dp%d" % world},
@@ -301,7 +315,7 @@ def main():
                                  "frac": round(tot_fl / tot_us * 1e-6 / peak, 4),
                                  "kernels": [{k: r[k] for k in ("kernel", "avg_us", "tflops")} for r in rl]}
     if a.cpu_baseline and rank == 0 and world == 1:
-        out["cpu_baseline"] = cpu_baseline(B, L, V, A, a.cpu_steps)
+        out["cpu_baseline"] = cpu_baseline(B, L, V, A, a.cpu_steps, a.model)
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(out))

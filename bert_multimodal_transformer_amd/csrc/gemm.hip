@@ -632,7 +632,10 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
         p.dbg = 0;
     }
     ga.first[count] = total;
-    hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128>), dim3(total), dim3(256), 0, st, ga);
+    static int g_gstages = -1;       // MB_GROUP_STAGES: ring depth of the grouped kernel (2 | 3)
+    if (g_gstages < 0) g_gstages = env_int("MB_GROUP_STAGES", 2);
+    if (g_gstages >= 3) hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 3, 128>), dim3(total), dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128>), dim3(total), dim3(256), 0, st, ga);
     return (int)hipGetLastError();
 }
 

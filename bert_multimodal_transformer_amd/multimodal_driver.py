@@ -213,11 +213,32 @@ def get_appropriate_dataset(data, tokenizer=None):
     return features_to_dataset(convert_to_features(data, args.max_seq_length, tokenizer))
 
 
-def synthetic_dataset(n, L, V, A, seed_=1234, vocab=30522):
+def synthetic_dataset(n, L, V, A, seed_=1234, vocab=30522, layout="bert"):
     """n samples in prepare_bert_input's layout: ids [101, tokens, 102, 0...], mask, seg 0,
-    modality rows N(0,1) on word rows and EXACT zeros on [CLS]/[SEP]/pad rows, labels U(-3, 3)."""
+    modality rows N(0,1) on word rows and EXACT zeros on [CLS]/[SEP]/pad rows, labels U(-3, 3).
+    layout="xlnet": prepare_xlnet_input's layout (multimodal_driver.py:176-205) -- LEFT padded, ids [5.., tokens, 4, 3],
+    mask 0 on pads, segment ids 3 (pad) / 0 (tokens, <sep>) / 2 (<cls>)."""
     rs = np.random.RandomState(seed_)
     lens = rs.randint(5, L - 2 + 1, size=n)
+    if layout == "xlnet":
+        vocab = min(vocab, 32000)
+        pos = np.arange(L)[None, :]
+        pad = (L - 2 - lens)[:, None]
+        word = (pos >= pad) & (pos < L - 2)
+        ids = np.full((n, L), 5, np.int64)
+        tok = rs.randint(10, vocab, size=(n, L))
+        ids[word] = tok[word]
+        ids[:, L - 2], ids[:, L - 1] = 4, 3
+        mask = (pos >= pad).astype(np.int64)
+        seg = np.where(pos >= pad, 0, 3).astype(np.int64)
+        seg[:, L - 1] = 2
+        vis = rs.randn(n, L, V).astype(np.float32)
+        aco = rs.randn(n, L, A).astype(np.float32)
+        vis[~word] = 0.0
+        aco[~word] = 0.0
+        label = rs.uniform(-3, 3, size=n).astype(np.float32)
+        t = torch.from_numpy
+        return TensorDataset(t(ids), t(vis), t(aco), t(mask), t(seg), t(label))
     ids = np.zeros((n, L), np.int64)
     mask = np.zeros((n, L), np.int64)
     seg = np.zeros((n, L), np.int64)
@@ -242,9 +263,10 @@ def set_up_data_loader():
     V, A = _dims()
     if args.synthetic:
         n = args.synthetic
-        train_dataset = synthetic_dataset(n, args.max_seq_length, V, A, 1234)
-        dev_dataset = synthetic_dataset(max(8, n // 6), args.max_seq_length, V, A, 1235)
-        test_dataset = synthetic_dataset(max(8, n // 2), args.max_seq_length, V, A, 1236)
+        lay = "xlnet" if args.model == "xlnet-base-cased" else "bert"
+        train_dataset = synthetic_dataset(n, args.max_seq_length, V, A, 1234, layout=lay)
+        dev_dataset = synthetic_dataset(max(8, n // 6), args.max_seq_length, V, A, 1235, layout=lay)
+        test_dataset = synthetic_dataset(max(8, n // 2), args.max_seq_length, V, A, 1236, layout=lay)
     else:
         with open(f"datasets/{args.dataset}.pkl", "rb") as handle:
             data = pickle.load(handle)

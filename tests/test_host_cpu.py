@@ -129,6 +129,21 @@ def test_synthetic_dataset_layout():
     assert (vis[~word] == 0).all() and (aco[~word] == 0).all() and (vis[word].abs().sum(-1) > 0).all()
 
 
+def test_synthetic_dataset_xlnet_layout_matches_prepare_xlnet_input():
+    """the synthetic XLNet samples have exactly the integer layout prepare_xlnet_input produces (multimodal_driver.py:176-205)"""
+    from bert_multimodal_transformer_amd import multimodal_driver as D
+    L = 50
+    ds = D.synthetic_dataset(32, L, 47, 74, layout="xlnet")
+    ids, vis, aco, mask, seg, lab = ds.tensors
+    n = mask.sum(1)                                         # tokens + <sep> + <cls>
+    for b in range(32):
+        pad = L - int(n[b])
+        assert (ids[b, :pad] == 5).all() and (mask[b, :pad] == 0).all() and (seg[b, :pad] == 3).all()
+        assert ids[b, L - 2] == 4 and ids[b, L - 1] == 3 and seg[b, L - 1] == 2 and (seg[b, pad:L - 1] == 0).all()
+        assert (vis[b, :pad] == 0).all() and (vis[b, L - 2:] == 0).all() and (aco[b, :pad] == 0).all() and (aco[b, L - 2:] == 0).all()
+        assert (vis[b, pad:L - 2].abs().sum(-1) > 0).all()
+
+
 def test_shard_indices_cover_dataset_once():
     from bert_multimodal_transformer_amd.distributed import shard_indices
     n, world, bs = 1281, 8, 48

@@ -247,3 +247,23 @@ def test_too_long_sequence_is_rejected():
     ids, vis, aco, mask, seg, _ = tb(weights.synthetic_xlnet_batch(2, 80, 47, 74, seed=5), DEV)
     with pytest.raises(Exception):
         m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)
+
+
+def test_driver_epoch_xlnet_runs_and_learns():
+    """bundled driver with --model xlnet-base-cased on synthetic prepare_xlnet_input-shaped data (bf16, dropout on)"""
+    from bert_multimodal_transformer_amd import multimodal_driver as D
+    D.args = D.parse_args(["--synthetic", "192", "--n_epochs", "1", "--seed", "5", "--train_batch_size", "48",
+                           "--learning_rate", "5e-5", "--model", "xlnet-base-cased"])
+    D.set_random_seed(D.args.seed)
+    tr, dev, te, nsteps = D.set_up_data_loader()
+    model = MAG_XLNetForSequenceClassification(XLNetConfig(n_layer=2), MultimodalConfig(1.0, 0.5), compute_dtype=torch.bfloat16)
+    opt = AdamW(D.optimizer_grouped_parameters(model), lr=D.args.learning_rate)
+    sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=0, num_training_steps=1000)
+    losses = [D.train_epoch(model, tr, opt, sch) for _ in range(4)]
+    print("xlnet epoch losses", losses)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    vl = D.eval_epoch(model, dev, opt)
+    acc, mae, corr, f1 = D.test_score_model(model, te)
+    assert np.isfinite(vl) and 0.0 <= acc <= 1.0 and np.isfinite(mae)
+    D.args.reference_loop = True
+    assert np.isfinite(D.train_epoch(model, tr, opt, sch))
