@@ -235,6 +235,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    scope = model.stream_scope()          # the whole loop on one private HIP stream (see _MagBertBase.stream_scope)
+    scope.__enter__()
     for i in range(a.warmup):
         step(i)
     fence()
@@ -275,6 +277,7 @@ def main():
         n2 += 6
     except Exception as ex:          # MB_GROUP_WGRAD=0 (four separate launches): no grouped kernel to time
         print("note: in-step wgrad timing unavailable (%s)" % ex, file=sys.stderr)
+    scope.__exit__(None, None, None)
     loss = float(model.loss_running().item()) / max(1, total_steps + n2)
     value = world * B * a.steps / dt
 

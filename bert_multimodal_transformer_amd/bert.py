@@ -349,6 +349,28 @@ class _MagBertBase(nn.Module):
     def init_weights(self):
         _init_weights(self._core)
 
+    def stream_scope(self):
+        """Context manager for a training / evaluation loop: when the caller sits on the legacy NULL stream, the whole
+        loop (engine passes, AdamW, H2D copies) runs on the model's private stream instead of hopping NULL -> private ->
+        NULL around every pass.  Each hop is a cross-queue dependency (measured: ~25 us between forward and backward,
+        ~90 us between AdamW and the next forward)."""
+        import contextlib
+        core = self._core
+
+        @contextlib.contextmanager
+        def scope():
+            cur = torch.cuda.current_stream(core.device)
+            if cur.cuda_stream != 0:
+                yield
+                return
+            if core._own_stream is None:
+                core._own_stream = torch.cuda.Stream(device=core.device)
+            core._own_stream.wait_stream(cur)
+            with torch.cuda.stream(core._own_stream):
+                yield
+            cur.wait_stream(core._own_stream)
+        return scope()
+
     def zero_grad(self, set_to_none=False):
         # p.grad are views of the flat gradient buffer the engine accumulates into: clear it in place
         self._core.grads.zero_()

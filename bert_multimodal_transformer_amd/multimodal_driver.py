@@ -363,16 +363,18 @@ def train_epoch(model: nn.Module, train_dataloader: DataLoader, optimizer, sched
                 scheduler.step()
                 optimizer.zero_grad()
         return tr_loss / max(1, nb_tr_steps)
-    model.loss_running(reset=True)
-    for step, batch in enumerate(train_dataloader):
-        input_ids, visual, acoustic, input_mask, segment_ids, label_ids = _unpack(batch)
-        model.training_step(input_ids, visual, acoustic, input_mask, segment_ids, label_ids, loss_scale=1.0 / accum)
-        nb_tr_steps += 1
-        if (step + 1) % accum == 0:
-            optimizer.step()
-            scheduler.step()
-            optimizer.zero_grad()
-    total = float(model.loss_running(reset=True).item()) / accum      # the only host sync of the epoch
+    with model.stream_scope():                        # one private HIP stream for the whole epoch (no NULL-stream hops)
+        model.loss_running(reset=True)
+        for step, batch in enumerate(train_dataloader):
+            input_ids, visual, acoustic, input_mask, segment_ids, label_ids = _unpack(batch)
+            model.training_step(input_ids, visual, acoustic, input_mask, segment_ids, label_ids, loss_scale=1.0 / accum)
+            nb_tr_steps += 1
+            if (step + 1) % accum == 0:
+                optimizer.step()
+                scheduler.step()
+                optimizer.zero_grad()
+        running = model.loss_running(reset=True)
+    total = float(running.item()) / accum             # the only host sync of the epoch
     return total / max(1, nb_tr_steps)
 
 
@@ -381,7 +383,7 @@ def eval_epoch(model: nn.Module, dev_dataloader: DataLoader, optimizer):
     model.eval()
     dev_loss = torch.zeros((), device=_device())
     nb_dev_steps = 0
-    with torch.no_grad():
+    with torch.no_grad(), model.stream_scope():
         for step, batch in enumerate(dev_dataloader):
             input_ids, visual, acoustic, input_mask, segment_ids, label_ids = _unpack(batch)
             outputs = model(input_ids, visual, acoustic, token_type_ids=segment_ids, attention_mask=input_mask, labels=None)
