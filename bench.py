@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--roofline", type=int, default=1)
     p.add_argument("--overlap-optimizer", type=int, default=0,
                    help="EXPERIMENTAL: update each stage's parameters during the backward (see DESIGN.md, known issue)")
+    p.add_argument("--fused-optimizer", type=int, default=0,
+                   help="N=1 only: AdamW for the encoder GEMM weights runs in the weight-gradient GEMM epilogue (same arithmetic; "
+                        "measured neutral, so the default keeps the same code path at every N)")
     p.add_argument("--roofline-only", type=int, default=0, help="skip the training loop, print the GEMM table only")
     return p.parse_args()
 
@@ -211,6 +214,7 @@ def main():
         dp.broadcast_parameters(0)
     if a.overlap_optimizer:
         opt.enable_overlap(model)
+    fused_opt = bool(a.fused_optimizer) and world == 1 and opt.enable_fused_backward(model)
     model.train()
     nb = 8
     batches = make_batches(nb, B, L, V, A, seed=1234 + rank, layout=a.model)
@@ -290,8 +294,9 @@ def main():
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": mname + (" bert-base-uncased" if a.model == "bert" else " xlnet-base-cased") + ", %s dims (V=%d, A=%d), batch %d/GPU, seq_len %d, full "
-                                      "optimizer step (fwd+MSE+bwd%s+HF-AdamW+schedule; inputs resident in HBM), dropout on, random-init weights"
-                                      % (a.dataset.upper(), V, A, B, L, "+RCCL all-reduce" if world > 1 else ""),
+                                      "optimizer step (fwd+MSE+bwd%s+HF-AdamW%s+schedule; inputs resident in HBM), dropout on, random-init weights"
+                                      % (a.dataset.upper(), V, A, B, L, "+RCCL all-reduce" if world > 1 else "",
+                                         " (encoder weights updated in the wgrad epilogue)" if fused_opt else ""),
                           "global_batch": world * B, "seq_len": L, "parallelism": "dp%d" % world},
                "mean_loss": round(loss, 4), "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
                "value_with_h2d": round(world * B / dt_h2d, 2)}

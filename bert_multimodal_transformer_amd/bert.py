@@ -98,6 +98,7 @@ class _Core(object):
         self.training_last = False
         self._own_stream = None
         self.stage_hooks = []          # callables hook(stage) run after each backward stage (DataParallel, AdamW overlap)
+        self.pre_backward_hooks = []   # callables run before the first backward stage (AdamW.enable_fused_backward)
         self._make_engine(1, 8)
         n = self._fn("param_count")(self.handle)
         self.n_params = n
@@ -237,6 +238,8 @@ class _Core(object):
         if dlogits is None and lab is None:
             raise ValueError("fused backward needs the labels passed to forward()")
         with _Core._Hop(self):
+            for hook in self.pre_backward_hooks:
+                hook()
             for s in range(nstage):
                 _lib.check(self._fn("backward")(self.handle, _lib.ptr(dlogits),
                                                      _lib.ptr(lab) if dlogits is None else None, float(loss_scale), s, s + 1,
@@ -257,6 +260,15 @@ class _Core(object):
         p = self.lib.mb_bert_pooled_output(self.handle)
         off = p - self.ws.data_ptr()
         return self.ws[off: off + B * H * 4].view(torch.float32).view(B, H).clone()
+
+    def fused_range(self):
+        """flat [begin, end) the engine can update inside the backward (mb_bert_fuse_adamw); None if unsupported"""
+        if self.kind != "bert":
+            return None
+        b, e = C.c_size_t(), C.c_size_t()
+        if self.lib.mb_bert_fused_range(self.handle, C.byref(b), C.byref(e)) != 0:
+            return None
+        return b.value, e.value
 
     def stage_ranges(self, stage):
         offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()

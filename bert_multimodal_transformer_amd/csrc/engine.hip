@@ -47,6 +47,10 @@ struct mb_bert_engine {
     int overlap_wgrad = 1;
     int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128), 0 = four launches
     bool deferred = false;         // grouped launch on the side stream, joined one stage later
+    // optimizer-in-backward (mb_bert_fuse_adamw): the grouped wgrad applies HF AdamW to the encoder GEMM weights in its epilogue
+    bool fuse = false;
+    float* FM = nullptr; float* FV = nullptr;      // Adam moments, flat, parallel to P
+    AdamArgs fa;
     bool prof = false;             // mb_bert_set_profiling: timing events around every grouped wgrad launch (on the side stream)
     std::vector<hipEvent_t> pev;   // [2 * num_layers]
     bool ws_zeroed = false;
@@ -174,7 +178,7 @@ void mb_make_dropkey(uint64_t seed, uint64_t step, uint32_t site, float p, mb_dr
 int mb_gemm(int dtype, int layout, int epilogue, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
             void* C, int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, float alpha,
             const mb_dropkey* drop, int splits, int tile, void* stream) {
-    GemmArgs a;
+    GemmArgs a = {};
     a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.C = C; a.ldc = ldc; a.C2 = C2; a.Cf = Cf;
     a.bias = bias; a.R = R; a.ldr = ldr; a.alpha = alpha; a.drop = dk(drop); a.kchunk = K; a.colsum = nullptr;
     return gemm_launch(dtype, layout, epilogue, a, splits, tile, (hipStream_t)stream);
@@ -441,7 +445,14 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             hipStream_t ss = st;
             if (e->overlap_wgrad) {
                 if (!e->side) {
-                    CK((int)hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+                    // MB_SIDE_PRIORITY=1: lowest dispatch priority for the weight-gradient stream (the dgrad chain is the critical
+                    // path).  Measured: no effect -- resident wgrad blocks keep their LDS slots for a whole K = T loop, priority
+                    // only orders NEW workgroups -- so the default stays the normal priority.
+                    int least = 0, greatest = 0;
+                    CK((int)hipDeviceGetStreamPriorityRange(&least, &greatest));
+                    const char* pv = getenv("MB_SIDE_PRIORITY");
+                    const int prio = (pv && atoi(pv) != 0) ? least : 0;
+                    CK((int)hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio));
                     e->evs.assign((size_t)NL * 5, nullptr);
                     for (auto& ev : e->evs) CK((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
                 }
@@ -468,6 +479,14 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                               wgrad_args(3 * H, H, Tk, dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H)};
             const bool grouped = e->deferred;
             if (grouped && !gemm_grouped_tn_ok(dt, wg, 4, e->group_wgrad)) return MB_ERR_SHAPE;
+            const bool fused = grouped && e->fuse;
+            if (fused)
+                for (GemmArgs& a : wg) {
+                    const size_t off = (size_t)(a.Cf - G);
+                    a.ad_p = P + off; a.ad_m = e->FM + off; a.ad_v = e->FV + off;
+                    a.ad_sh = dt == DT_BF16 ? (void*)((bf16*)e->SH + off) : nullptr;
+                    a.adam = e->fa;
+                }
             if (!grouped) {
             CK(fork(0));
             CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, ss));
@@ -497,15 +516,23 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             // attention backward; the fused-QKV bias gradient (column sums of dqkv) is accumulated inside the kernel
             CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, dqkv, G + o.bqkv, B, L, nh,
                                   e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st));
-            CK(fork(3));
-            if (grouped) {
+            auto launch_group = [&]() -> int {
+                CK(fork(3));
                 if (e->prof) CK((int)hipEventRecord(e->pev[2 * l], ss));
-                CK(gemm_grouped_tn_launch(dt, wg, 4, e->group_wgrad, ss));
+                CK(gemm_grouped_tn_launch(dt, wg, 4, e->group_wgrad, ss, fused ? EPI_ADAMW : EPI_ACCUM_F32));
                 if (e->prof) CK((int)hipEventRecord(e->pev[2 * l + 1], ss));
-                CK((int)hipEventRecord(sev[4], ss));          // "weight gradients of layer l are final"
-            } else CK(wgrad(dt, 3 * H, H, Tk, dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H, ss));
+                return (int)hipEventRecord(sev[4], ss);       // "weight gradients (or updated weights) of layer l are final"
+            };
+            if (grouped && !fused) CK(launch_group());
+            if (!grouped) {
+                CK(fork(3));
+                CK(wgrad(dt, 3 * H, H, Tk, dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H, ss));
+            }
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, 3 * H, dqkv, 3 * H, e->W(o.wqkv), H, dx, H, nullptr, nullptr,
                     nullptr, dsB, H, kNoDrop, 1, 0, st));
+            // fused optimizer: the launch rewrites this layer's weights, so it may only start once the layer's last reader
+            // (the dgrad above) has been enqueued in front of the fork event
+            if (fused) CK(launch_group());
             if (ss != st && !grouped) {      // join: the stage's gradients are complete (and dY buffers reusable) once main passes this
                 CK((int)hipEventRecord(sev[4], ss));
                 CK((int)hipStreamWaitEvent(st, sev[4], 0));
@@ -517,6 +544,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
         } else {
             // ---- MAG + embeddings
             if (e->deferred && e->side) CK((int)hipStreamWaitEvent(st, e->evs[4], 0));      // weight gradients of layer 0
+            e->fuse = false;                                                                  // one-shot: re-arm every step
             char* dx = ws + e->ws_dxa;
             char* de = ws + e->ws_dxb;
             CK(mag_bwd_impl(dt, dx, ws + e->ws_emb, P + e->mag_bhv, P + e->mag_bha, P + e->mag_bv, P + e->mag_ba,
@@ -531,6 +559,28 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
         }
     }
     return MB_OK;
+}
+
+int mb_bert_fuse_adamw(mb_bert_engine* e, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int step, int correct_bias, float grad_scale) {
+    if (!e) return MB_ERR_ARG;
+    if (!m || !v) { e->fuse = false; return MB_OK; }
+    if (!e->deferred) return MB_ERR_MODE;
+    e->FM = m; e->FV = v;
+    AdamArgs& a = e->fa;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale;
+    double ss = lr;
+    if (correct_bias) ss = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+    a.step_size = (float)ss;
+    e->fuse = true;
+    return MB_OK;
+}
+
+int mb_bert_fused_range(const mb_bert_engine* e, size_t* begin, size_t* end) {
+    if (!e || !begin || !end) return MB_ERR_ARG;
+    *begin = e->lo[0].wqkv;            // the encoder GEMM weights: layer 0 query ... layer NL-1 output.dense
+    *end = e->wp;
+    return e->deferred ? MB_OK : MB_ERR_MODE;
 }
 
 int mb_bert_set_profiling(mb_bert_engine* e, int on) {

@@ -86,7 +86,7 @@ struct MagWs {
 inline int gemm(int dtype, int layout, int mode, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
          int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, DropKey drop, int splits, int tile,
          hipStream_t st) {
-    GemmArgs a;
+    GemmArgs a = {};
     a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
     a.C = C; a.ldc = ldc; a.C2 = C2; a.Cf = Cf; a.bias = bias; a.R = R; a.ldr = ldr; a.alpha = 1.0f; a.drop = drop;
     a.kchunk = K; a.colsum = nullptr;
@@ -96,10 +96,11 @@ inline int gemm(int dtype, int layout, int mode, int M, int N, int K, const void
 
 // operands of one weight gradient dW[Mo][No] += dY[rows][Mo]^T X[rows][No] (GEMM_TN, EPI_ACCUM_F32)
 inline GemmArgs wgrad_args(int Mo, int No, int rows, const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw) {
-    GemmArgs a;
+    GemmArgs a = {};
     a.A = dY; a.B = X; a.M = Mo; a.N = No; a.K = rows; a.lda = ldy; a.ldb = ldx;
     a.C = nullptr; a.ldc = ldw; a.C2 = nullptr; a.Cf = dW; a.bias = nullptr; a.colsum = nullptr; a.R = nullptr; a.ldr = 0;
     a.alpha = 1.0f; a.drop = kNoDrop; a.kchunk = rows; a.dbg = 0; a.reg_m = a.reg_n = a.tpr_m = a.tpr_n = 0;
+    a.ad_p = a.ad_m = a.ad_v = nullptr; a.ad_sh = nullptr; a.adam = AdamArgs{};
     return a;
 }
 

@@ -171,6 +171,51 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         if (p.bias && n < p.N) Vec8<float>::load(p.bias + n, bias8);
     }
     T* __restrict__ C = (T*)p.C;
+    if constexpr (MODE == EPI_ADAMW) {
+        // optimizer-in-backward: the fp32 accumulator is the complete gradient of these weights (the gradient buffer is not
+        // touched and stays zero).  p / m / v come cold from HBM: the loads of CH rows (12 x 32 B per thread) are issued
+        // before the first use so the epilogue is bandwidth- and not latency-bound.  Same operation order as adamw_kernel.
+        constexpr int CH = 4;
+        const float omb1 = 1.0f - p.adam.beta1, omb2 = 1.0f - p.adam.beta2, decay = p.adam.lr * p.adam.weight_decay;
+        for (int r0 = tid / TPR; r0 < BM; r0 += RPP * CH) {
+            float pv[CH][8], mv[CH][8], vv[CH][8];
+            bool ok[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int r = r0 + k * RPP, m = m0 + r;
+                ok[k] = r < BM && m < p.M && n < p.N;
+                if (ok[k]) {
+                    const size_t off = (size_t)m * p.ldc + n;
+                    Vec8<float>::load(p.ad_p + off, pv[k]);
+                    Vec8<float>::load(p.ad_m + off, mv[k]);
+                    Vec8<float>::load(p.ad_v + off, vv[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                if (!ok[k]) continue;
+                const int r = r0 + k * RPP;
+                const size_t off = (size_t)(m0 + r) * p.ldc + n;
+                const int ch = c >> 2;
+                const f32x4 a = *(const f32x4*)(smem + r * RBY + ((ch ^ (r & 7)) << 4));
+                const f32x4 b = *(const f32x4*)(smem + r * RBY + (((ch + 1) ^ (r & 7)) << 4));
+                const float gr[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float g = gr[q] * p.adam.grad_scale;
+                    mv[k][q] = p.adam.beta1 * mv[k][q] + omb1 * g;
+                    vv[k][q] = p.adam.beta2 * vv[k][q] + omb2 * g * g;
+                    pv[k][q] -= p.adam.step_size * (mv[k][q] / (sqrtf(vv[k][q]) + p.adam.eps));
+                    if (decay > 0.f) pv[k][q] -= decay * pv[k][q];
+                }
+                Vec8<float>::store(p.ad_p + off, pv[k]);
+                Vec8<float>::store(p.ad_m + off, mv[k]);
+                Vec8<float>::store(p.ad_v + off, vv[k]);
+                if (p.ad_sh) Vec8<bf16>::store((bf16*)p.ad_sh + off, pv[k]);
+            }
+        }
+        return;
+    }
 #pragma unroll 2
     for (int r = tid / TPR; r < BM; r += RPP) {
         const int m = m0 + r;
@@ -495,15 +540,17 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const GemmArgs p) {
 // gradients alone is at most ~2 blocks per CU (one under-filled round whose duration is set by the K = T loop latency,
 // not by its size); launched together they are one grid of ~7 blocks per CU that keeps every CU's LDS ring full.
 // Problem g owns blocks [first[g], first[g+1]) (multiples of 8, so block -> XCD mapping is unchanged).
-template <class T, int BM, int BN, int NSTAGE, int KB>
+template <class T, int BM, int BN, int NSTAGE, int KB, int MODE>
 __global__ void __launch_bounds__(256) gemm2_grouped_tn_kernel(const GroupedGemmArgs ga) {
     __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB>::BYTES];
+    // (A persistent variant that holds only one LDS slot per CU -- MB_GROUP_GRID = 128 / 256 / 384 blocks looping over the 432
+    //  tiles -- was measured: no gain at 384, slower below; the launch is needed at full width to finish inside its layer.)
     int g = 0;
 #pragma unroll
     for (int i = 1; i < MB_MAX_GROUP; ++i)
         if (i < ga.count && (int)blockIdx.x >= ga.first[i]) g = i;
     g = __builtin_amdgcn_readfirstlane(g);
-    gemm2_body<T, BM, BN, true, true, EPI_ACCUM_F32, NSTAGE, KB>(ga.g[g], (int)blockIdx.x - ga.first[g], 0, smem);
+    gemm2_body<T, BM, BN, true, true, MODE, NSTAGE, KB>(ga.g[g], (int)blockIdx.x - ga.first[g], 0, smem);
 }
 
 // ---------------------------------------------------------------------------------------------- host
@@ -613,7 +660,7 @@ static int launch_T(const GemmArgs& a, int layout, int mode, int splits, int til
 }
 
 template <class T, int BM, int BN>
-static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
+static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st, int mode) {
     constexpr int BKE = 128 / sizeof(T);
     constexpr int EPV = 16 / sizeof(T);
     GroupedGemmArgs ga;
@@ -634,8 +681,16 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
     ga.first[count] = total;
     static int g_gstages = -1;       // MB_GROUP_STAGES: ring depth of the grouped kernel (2 | 3)
     if (g_gstages < 0) g_gstages = env_int("MB_GROUP_STAGES", 2);
-    if (g_gstages >= 3) hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 3, 128>), dim3(total), dim3(256), 0, st, ga);
-    else hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128>), dim3(total), dim3(256), 0, st, ga);
+    const int grid = total;
+    if (mode == EPI_ADAMW) {
+        for (int i = 0; i < count; ++i)
+            if (!ga.g[i].ad_p || !ga.g[i].ad_m || !ga.g[i].ad_v) return MB_ERR_ARG;
+        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128, EPI_ADAMW>), dim3(grid), dim3(256), 0, st, ga);
+    } else if (g_gstages >= 3) {
+        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 3, 128, EPI_ACCUM_F32>), dim3(grid), dim3(256), 0, st, ga);
+    } else {
+        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128, EPI_ACCUM_F32>), dim3(grid), dim3(256), 0, st, ga);
+    }
     return (int)hipGetLastError();
 }
 
@@ -651,10 +706,11 @@ int gemm_grouped_tn_ok(int dtype, const GemmArgs* probs, int count, int tile) {
     return 1;
 }
 
-int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st) {
+int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st, int mode) {
     if (count < 1 || count > MB_MAX_GROUP) return MB_ERR_ARG;
-    if (dtype == DT_BF16) return tile == 128 ? launch_grouped<bf16, 128, 128>(probs, count, st) : launch_grouped<bf16, 64, 64>(probs, count, st);
-    if (dtype == DT_F32) return tile == 128 ? launch_grouped<float, 128, 128>(probs, count, st) : launch_grouped<float, 64, 64>(probs, count, st);
+    if (mode != EPI_ACCUM_F32 && mode != EPI_ADAMW) return MB_ERR_MODE;
+    if (dtype == DT_BF16) return tile == 128 ? launch_grouped<bf16, 128, 128>(probs, count, st, mode) : launch_grouped<bf16, 64, 64>(probs, count, st, mode);
+    if (dtype == DT_F32) return tile == 128 ? launch_grouped<float, 128, 128>(probs, count, st, mode) : launch_grouped<float, 64, 64>(probs, count, st, mode);
     return MB_ERR_DTYPE;
 }
 

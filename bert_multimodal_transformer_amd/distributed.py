@@ -101,6 +101,8 @@ class DataParallel(object):
         self.core.stage_hooks.insert(0, self._on_stage)      # before any optimizer-overlap hook
         self.sync = True          # set False on gradient-accumulation micro-steps (multimodal_driver.py:383)
         if optimizer is not None:
+            if getattr(optimizer, "_fb", None) is not None:
+                raise RuntimeError("AdamW.enable_fused_backward() updates weights from local gradients: not usable with DataParallel")
             optimizer.grad_scale = 1.0 / self.world
             optimizer._dp = self
 

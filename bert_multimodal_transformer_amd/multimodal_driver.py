@@ -88,6 +88,8 @@ def get_parser():
     parser.add_argument("--synthetic", type=int, default=0, help="use N synthetic training samples (no .pkl needed)")
     parser.add_argument("--compute_dtype", choices=["bf16", "fp32"], default="bf16")
     parser.add_argument("--reference_loop", type=str2bool, default=False)
+    parser.add_argument("--fused_optimizer", type=str2bool, default=False,
+                        help="single process, gradient_accumulation_step 1: AdamW for the encoder weights runs inside the backward GEMMs")
     parser.add_argument("--pretrained", type=str, default="", help="local checkpoint dir/file (offline)")
     return parser
 
@@ -258,9 +260,47 @@ def synthetic_dataset(n, L, V, A, seed_=1234, vocab=30522, layout="bert"):
     return TensorDataset(t(ids), t(vis), t(aco), t(mask), t(seg), t(label))
 
 
+def _dist():
+    """(rank, world) of a torchrun launch; initialises the process group (RCCL) on first use."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("MB_DIST_BACKEND", "nccl")
+        kw = {"device_id": torch.device("cuda", torch.cuda.current_device())} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=int(os.environ.get("RANK", "0")), world_size=world, **kw)
+    return dist.get_rank(), world
+
+
+class ShardedBatchSampler(object):
+    """Per-rank minibatches of the data-parallel run (distributed.shard_indices): every global batch of
+    world * train_batch_size shuffled samples is cut into one contiguous slice per rank; reshuffled every epoch."""
+
+    def __init__(self, n, rank, world, batch_size, seed_):
+        self.n, self.rank, self.world, self.batch_size, self.seed, self.epoch = n, rank, world, batch_size, seed_, 0
+
+    def _batches(self):
+        from .distributed import shard_indices
+        return shard_indices(self.n, self.rank, self.world, self.batch_size, self.seed, self.epoch)
+
+    def __iter__(self):
+        b = self._batches()
+        self.epoch += 1
+        return iter(b)
+
+    def __len__(self):
+        return len(self._batches())
+
+
 def set_up_data_loader():
-    """multimodal_driver.py:249-286 (+ synthetic mode)."""
+    """multimodal_driver.py:249-286 (+ synthetic mode, + per-rank sharding under torchrun)."""
     V, A = _dims()
+    rank, world = _dist()
     if args.synthetic:
         n = args.synthetic
         lay = "xlnet" if args.model == "xlnet-base-cased" else "bert"
@@ -275,8 +315,12 @@ def set_up_data_loader():
         dev_dataset = get_appropriate_dataset(data["dev"], tok)
         test_dataset = get_appropriate_dataset(data["test"], tok)
     num_train_optimization_steps = (
-        int(len(train_dataset) / args.train_batch_size / args.gradient_accumulation_step) * args.n_epochs)
-    train_dataloader = DataLoader(train_dataset, batch_size=args.train_batch_size, shuffle=True)
+        int(len(train_dataset) / (args.train_batch_size * world) / args.gradient_accumulation_step) * args.n_epochs)
+    if world > 1:      # weak scaling: train_batch_size stays the PER-GPU batch, the global batch is world times larger
+        sampler = ShardedBatchSampler(len(train_dataset), rank, world, args.train_batch_size, args.seed if isinstance(args.seed, int) else 0)
+        train_dataloader = DataLoader(train_dataset, batch_sampler=sampler)
+    else:
+        train_dataloader = DataLoader(train_dataset, batch_size=args.train_batch_size, shuffle=True)
     dev_dataloader = DataLoader(dev_dataset, batch_size=args.dev_batch_size, shuffle=True)
     test_dataloader = DataLoader(test_dataset, batch_size=args.test_batch_size, shuffle=True)
     return train_dataloader, dev_dataloader, test_dataloader, num_train_optimization_steps
@@ -330,6 +374,13 @@ def prep_for_training(num_train_optimization_steps: int):
     scheduler = get_linear_schedule_with_warmup(
         optimizer, num_warmup_steps=args.warmup_proportion * num_train_optimization_steps,
         num_training_steps=num_train_optimization_steps)
+    rank, world = _dist()
+    if world > 1:
+        from .distributed import DataParallel
+        model._dp = DataParallel(model, optimizer)          # hooks the backward stages: RCCL all-reduce during the backward
+        model._dp.broadcast_parameters(0)
+    if getattr(args, "fused_optimizer", False) and world == 1 and args.gradient_accumulation_step == 1:
+        optimizer.enable_fused_backward(model)        # no-op (False) where the engine has no grouped wgrad launch
     return model, optimizer, scheduler
 
 
@@ -346,6 +397,7 @@ def train_epoch(model: nn.Module, train_dataloader: DataLoader, optimizer, sched
     model.train()
     accum = args.gradient_accumulation_step
     nb_tr_steps = 0
+    dp = getattr(model, "_dp", None)
     if args.reference_loop:
         tr_loss = 0
         for step, batch in enumerate(train_dataloader):
@@ -355,6 +407,8 @@ def train_epoch(model: nn.Module, train_dataloader: DataLoader, optimizer, sched
             loss = MSELoss()(logits.view(-1), label_ids.view(-1))
             if accum > 1:
                 loss = loss / accum
+            if dp is not None:
+                dp.sync = (step + 1) % accum == 0
             loss.backward()
             tr_loss += loss.item()
             nb_tr_steps += 1
@@ -367,6 +421,8 @@ def train_epoch(model: nn.Module, train_dataloader: DataLoader, optimizer, sched
         model.loss_running(reset=True)
         for step, batch in enumerate(train_dataloader):
             input_ids, visual, acoustic, input_mask, segment_ids, label_ids = _unpack(batch)
+            if dp is not None:
+                dp.sync = (step + 1) % accum == 0           # all-reduce only on the micro-step that is followed by step()
             model.training_step(input_ids, visual, acoustic, input_mask, segment_ids, label_ids, loss_scale=1.0 / accum)
             nb_tr_steps += 1
             if (step + 1) % accum == 0:
@@ -443,6 +499,8 @@ def train(model, train_dataloader, validation_dataloader, test_data_loader, opti
         dt = time.time() - t0
         valid_loss = eval_epoch(model, validation_dataloader, optimizer)
         test_acc, test_mae, test_corr, test_f_score = test_score_model(model, test_data_loader)
+        if _dist()[0] != 0:
+            continue
         print("epoch:{}, train_loss:{}, valid_loss:{}, test_acc:{}".format(epoch_i, train_loss, valid_loss, test_acc))
         valid_losses.append(valid_loss)
         test_accuracies.append(test_acc)

@@ -30,6 +30,8 @@ class AdamW(torch.optim.Optimizer):
         self._t = 0
         self._dp = None              # set by distributed.DataParallel
         self._ov = None              # overlap state (enable_overlap)
+        self._fb = None              # fused-backward state (enable_fused_backward)
+        self.fused_backward_armed = False
 
     # -- planning: map groups onto contiguous flat ranges ------------------------------------------------
     def _build_plan(self):
@@ -60,6 +62,58 @@ class AdamW(torch.optim.Optimizer):
             for p in loose:
                 plan.append(("loose", gi, p))
         self._plan = plan
+
+    # -- optimizer fused into the backward GEMMs --------------------------------------------------------------
+    def enable_fused_backward(self, model):
+        """Apply this optimizer's update to the encoder GEMM weights (77 % of the parameters) INSIDE the backward: the
+        engine's per-layer grouped weight-gradient GEMM runs the AdamW arithmetic in its epilogue on the fp32 accumulators
+        (mb_bert_fuse_adamw), so those gradients are never stored, re-read or zeroed; step() then only updates the rest
+        (embeddings, MAG, pooler, classifier, biases, LayerNorms).  Same arithmetic and the same hyper-parameters
+        (lr of the current scheduler state, betas, eps, weight decay, bias correction) as step().
+
+        Contract: every backward after this call IS an optimizer step for that range -- use it only where each
+        backward is followed by step() (gradient_accumulation_step == 1), in a single process (no gradient all-reduce),
+        and do not expect `.grad` of the encoder weights to hold anything but zeros.  Returns False (and changes
+        nothing) when the engine cannot do it (MAG-XLNet, MB_GROUP_WGRAD=0)."""
+        if self._dp is not None:
+            raise _lib.MagbertError("fused backward needs the full gradient locally: not available under DataParallel")
+        core = model._core
+        rng = core.fused_range()
+        if rng is None:
+            return False
+        if self._plan is None:
+            self._build_plan()
+        a, b = rng
+        plan, owner = [], None
+        for item in self._plan:
+            if item[0] == "flat" and item[2] is core and item[3] < b and a < item[4]:
+                if not (item[3] <= a and b <= item[4]):
+                    raise _lib.MagbertError("the fused range straddles parameter groups")
+                owner = item[1]
+                if item[3] < a:
+                    plan.append(("flat", item[1], core, item[3], a))
+                if b < item[4]:
+                    plan.append(("flat", item[1], core, b, item[4]))
+            else:
+                plan.append(item)
+        if owner is None:
+            return False
+        self._plan = plan
+        self._fb = dict(core=core, group=owner)
+        self.fused_backward_armed = True          # set False for a backward that must not update (then call step_skipped())
+        core.pre_backward_hooks.append(self._arm_fused)
+        return True
+
+    def _arm_fused(self):
+        fb = self._fb
+        core, group = fb["core"], self.param_groups[fb["group"]]
+        if not self.fused_backward_armed:
+            _lib.check(core.lib.mb_bert_fuse_adamw(core.handle, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 1, 0, 1.0))
+            return
+        b1, b2 = group["betas"]
+        _lib.check(core.lib.mb_bert_fuse_adamw(core.handle, _lib.ptr(core._adam_m), _lib.ptr(core._adam_v), group["lr"], b1, b2,
+                                               group["eps"], group["weight_decay"], self._t + 1,
+                                               1 if group["correct_bias"] else 0, self.grad_scale))
 
     # -- optimizer-in-backward ---------------------------------------------------------------------------
     def enable_overlap(self, model):

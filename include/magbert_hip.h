@@ -145,6 +145,19 @@ const float* mb_bert_pooled_output(const mb_bert_engine* e);    /* [B][H] fp32 (
 /* gradient buckets for data parallelism: range r of stage s covers flat elements [off, off+len) */
 int mb_bert_stage_grad_ranges(const mb_bert_engine* e, int stage, size_t* offs, size_t* lens, int cap);
 
+/* Optimizer-in-backward for the encoder GEMM weights (77 % of the parameters).  Arms the NEXT mb_bert_backward: the
+ * grouped weight-gradient launch of every layer applies transformers-3.0.2 AdamW (same arithmetic as mb_adamw_step:
+ * moments, eps outside the sqrt, decoupled decay after the update, bf16 operand shadow) to its four weights in the GEMM
+ * epilogue, straight from the fp32 accumulators.  Replaces, for flat range mb_bert_fused_range = [begin, end),
+ * `loss.backward()` gradient stores + `optimizer.step()` + `optimizer.zero_grad()` (multimodal_driver.py:378-386): the
+ * gradient buffer of that range is neither written nor read (it stays zero), which removes 16 B/param of HBM traffic.
+ * m, v: Adam moment buffers parallel to the bound parameter buffer; m == NULL disarms.  One-shot (re-arm every step).
+ * Only valid when nothing else needs those gradients: single process (no all-reduce), gradient_accumulation_step == 1.
+ * MB_ERR_MODE when the engine does not run the grouped launch (MB_GROUP_WGRAD=0 / MB_OVERLAP_WGRAD=0). */
+int mb_bert_fuse_adamw(mb_bert_engine* e, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, int step, int correct_bias, float grad_scale);
+int mb_bert_fused_range(const mb_bert_engine* e, size_t* begin, size_t* end);
+
 /* Measurement hooks (bench.py): with profiling on, every per-layer grouped weight-gradient launch of mb_bert_backward is
  * bracketed by HIP timing events on the engine's internal side stream -- the stream that kernel runs on, which the
  * caller cannot see.  mb_bert_profile_wgrad_us waits for the last backward's events and returns the mean launch

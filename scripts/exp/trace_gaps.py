@@ -51,3 +51,15 @@ for i in range(1, len(seg)):
 big.sort(reverse=True)
 for g, a, b in big[:12]:
     print("  gap %.1f us between %s -> %s" % (g / 1e3, a, b))
+
+# per-kernel in-step durations (the same kernel is slower here than back-to-back: cold operands + CU sharing)
+agg = {}
+for s_, e_, nme, qq in seg:
+    k = (nme[:64], qq)
+    a = agg.setdefault(k, [0, 0])
+    a[0] += 1; a[1] += e_ - s_
+print("top kernels inside the step (name, queue): launches/step, avg us, ms/step")
+for (nme, qq), (cnt, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
+    print("  %-64s q%s %5.1f %8.1f %7.3f" % (nme, qq, cnt / steps, tot / cnt / 1e3, tot / steps / 1e6))
+# wall time from the first backward kernel (head_bwd) to the last kernel before adamw
+import re
