@@ -317,6 +317,18 @@ def main():
                            "avg_us": round(us, 2), "avg_us_standalone": dom["avg_us"], "flop_per_launch": dom["flop"],
                            "timing": "HIP events on the launch stream, in-step" if us is not dom["avg_us"] else
                                      "HIP events on the launch stream, back-to-back launches"}
+        # HBM-side bytes per launch of that kernel: PMC counters cannot be collected from inside this process; the figure
+        # comes from the committed rocprofv3 --pmc passes over this same command (profiles/r01_pmc_step.md), else null
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
+                pm = json.load(fh)
+            if dom["kernel"].startswith(pm["kernel"]) and a.dtype == "bf16" and B == 48 and L == 50:
+                out["roofline"]["traffic"] = pm["fetch_bytes"] + pm["write_bytes"]
+                out["roofline"]["traffic_unit"] = "bytes/launch"
+                out["roofline"]["traffic_source"] = pm["source"]
+                out["roofline"]["algorithmic_bytes"] = 116391936
+        except Exception:
+            pass
         tot_us = sum(r["avg_us"] for r in rl)
         tot_fl = sum(r["flop"] for r in rl)
         out["roofline_gemms"] = {"per_layer_us": round(tot_us, 1), "aggregate_tflops": round(tot_fl / tot_us * 1e-6, 1),
