@@ -361,6 +361,14 @@ class _MagBertBase(nn.Module):
     def init_weights(self):
         _init_weights(self._core)
 
+    def get_rng_state(self):
+        """(seed, step) of the counter-hash dropout: every mask is a pure function of (seed, step, site, element), so a
+        resumed run that restores this pair draws exactly the masks the uninterrupted run would have drawn."""
+        return {"seed": int(self._core.seed), "step": int(self._core.step)}
+
+    def set_rng_state(self, state):
+        self._core.seed, self._core.step = int(state["seed"]), int(state["step"])
+
     def stream_scope(self):
         """Context manager for a training / evaluation loop: when the caller sits on the legacy NULL stream, the whole
         loop (engine passes, AdamW, H2D copies) runs on the model's private stream instead of hopping NULL -> private ->

@@ -53,9 +53,9 @@ struct GemmArgs {
 // tile: 0 = auto, 64 or 128.  splits: split-K factor (only EPI_ACCUM_F32).
 int gemm_launch(int dtype, int layout, int mode, const GemmArgs& a, int splits, int tile, hipStream_t st);
 
-// Grouped wgrad (GEMM_TN, EPI_ACCUM_F32): `count` <= MB_MAX_GROUP problems Cf_g[M_g][N_g] += A_g^T B_g in one launch.
+// Grouped wgrad (GEMM_TN, EPI_ACCUM_F32): `count` <= MB_MAX_GROUP (8) problems Cf_g[M_g][N_g] += A_g^T B_g in one launch.
 // Needs whole tiles and whole 128-byte K rows for every problem (gemm_grouped_tn_ok tells); tile = 64 | 128.
-#define MB_MAX_GROUP 4
+#define MB_MAX_GROUP 8
 struct GroupedGemmArgs {
     GemmArgs g[MB_MAX_GROUP];
     int first[MB_MAX_GROUP + 1];

@@ -36,6 +36,7 @@ struct mb_xlnet_engine {
     float* P = nullptr; float* G = nullptr; char* SH = nullptr; char* ws = nullptr;
     const int64_t* ids = nullptr; const int64_t* seg = nullptr; const int64_t* mask = nullptr;
     int B = 0, L = 0, training = 0, padT = -1;
+    int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped weight-gradient launch (64 | 128), 0 = one by one
     bool ws_zeroed = false;
     uint64_t seed = 0, step = 0;
     float* logits = nullptr;
@@ -153,6 +154,7 @@ int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out) {
     if (cfg->injection_index < 0 || cfg->injection_index >= cfg->n_layer) return MB_ERR_ARG;
     if (cfg->dtype != DT_F32 && cfg->dtype != DT_BF16) return MB_ERR_DTYPE;
     mb_xlnet_engine* e = new mb_xlnet_engine();
+    if (const char* v = getenv("MB_GROUP_WGRAD")) e->group_wgrad = atoi(v);
     e->c = *cfg;
     xl_build_layout(e);
     *out = e;
@@ -297,10 +299,20 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
             // ---- feed-forward block
             CK(ln_backward_partials(dt, dx, ws + w.s2, P + o.fflnw, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, dsA,
                                     hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(XS_LAYER0 + 8 * l + 3, pd), st));
-            CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, st));
+            // the layer's seven weight gradients go out as ONE grouped launch once every dY exists (MB_GROUP_WGRAD=0: one by one)
+            char* dqkv = ws + e->ws_dqkv;
+            GemmArgs wg[7] = {wgrad_args(H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I),
+                              wgrad_args(I, H, Tk, ws + e->ws_du, I, ws + w.y1, H, G + o.w1, H),
+                              wgrad_args(H, H, Tk, dzdB, H, ws + w.vec, H, G + o.o, H),                 // d o[h][nd] = dzd^T vec
+                              wgrad_args(H, H, Rk, ws + e->ws_pos, H, ws + e->ws_dkr, H, G + o.r, H),   // d r = pos^T dkr
+                              wgrad_args(H, H, Tk, xin, H, dqkv, 3 * H, G + o.q, H),
+                              wgrad_args(H, H, Tk, xin, H, dqkv + (size_t)H * es, 3 * H, G + o.k, H),
+                              wgrad_args(H, H, Tk, xin, H, dqkv + (size_t)2 * H * es, 3 * H, G + o.v, H)};
+            const bool grouped = e->group_wgrad > 0 && gemm_grouped_tn_ok(dt, wg, 7, e->group_wgrad);
+            if (!grouped) CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, st));
             CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, ws + e->ws_du, I, nullptr, G + o.b1, nullptr, ws + w.u, I,
                     e->key(XS_LAYER0 + 8 * l + 2, pd), 1, 0, st));
-            CK(wgrad(dt, I, H, Tk, ws + e->ws_du, I, ws + w.y1, H, G + o.w1, H, st));
+            if (!grouped) CK(wgrad(dt, I, H, Tk, ws + e->ws_du, I, ws + w.y1, H, G + o.w1, H, st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, I, ws + e->ws_du, I, e->W(o.w1), H, t1, H, nullptr, nullptr, nullptr, dsA, H,
                     kNoDrop, 1, 0, st));
             // ---- relative attention block
@@ -310,17 +322,20 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                 float* const dst6[6] = {G + o.fflnw, G + o.fflnb, G + o.b2, G + o.ralnw, G + o.ralnb, nullptr};
                 CK(ln_reduce_partials(lnp_a, lnp_b, nblk, H, dst6, st));
             }
-            CK(wgrad(dt, H, H, Tk, dzdB, H, ws + w.vec, H, G + o.o, H, st));                       // d o[h][nd] = dzd^T vec
+            if (!grouped) CK(wgrad(dt, H, H, Tk, dzdB, H, ws + w.vec, H, G + o.o, H, st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.o), H, ws + e->ws_dvec, H, nullptr, nullptr, nullptr, nullptr, 0,
                     kNoDrop, 1, 0, st));
-            char* dqkv = ws + e->ws_dqkv;
             CK(xlnet_attention_backward(dt, ws + w.qkv, ws + w.kr, P + o.rwb, P + o.rrb, P + o.rsb, P + o.seg, e->seg, e->mask,
                                         ws + w.psave, ws + e->ws_dvec, ws + e->ws_gsave, dqkv, ws + e->ws_dkr, G + o.rwb, G + o.rrb,
                                         G + o.rsb, G + o.seg, B, L, nh, e->key(XS_LAYER0 + 8 * l + 0, pd), st));
-            CK(wgrad(dt, H, H, Rk, ws + e->ws_pos, H, ws + e->ws_dkr, H, G + o.r, H, st));         // d r = pos^T dkr
-            CK(wgrad(dt, H, H, Tk, xin, H, dqkv, 3 * H, G + o.q, H, st));
-            CK(wgrad(dt, H, H, Tk, xin, H, dqkv + (size_t)H * es, 3 * H, G + o.k, H, st));
-            CK(wgrad(dt, H, H, Tk, xin, H, dqkv + (size_t)2 * H * es, 3 * H, G + o.v, H, st));
+            if (grouped) {
+                CK(gemm_grouped_tn_launch(dt, wg, 7, e->group_wgrad, st));
+            } else {
+                CK(wgrad(dt, H, H, Rk, ws + e->ws_pos, H, ws + e->ws_dkr, H, G + o.r, H, st));
+                CK(wgrad(dt, H, H, Tk, xin, H, dqkv, 3 * H, G + o.q, H, st));
+                CK(wgrad(dt, H, H, Tk, xin, H, dqkv + (size_t)H * es, 3 * H, G + o.k, H, st));
+                CK(wgrad(dt, H, H, Tk, xin, H, dqkv + (size_t)2 * H * es, 3 * H, G + o.v, H, st));
+            }
             // dx_in = dq Wq^T + dk Wk^T + dv Wv^T + dsB   (W stored [h_in][nd] = the row operand of an NT GEMM)
             char* t2 = ws + e->ws_dvec;
             CK(gemm(dt, GEMM_NT, EPI_ADD_RES, T, H, H, dqkv, 3 * H, e->W(o.q), H, t1, H, nullptr, nullptr, nullptr, dsB, H, kNoDrop, 1, 0, st));

@@ -241,6 +241,41 @@ class AdamW(torch.optim.Optimizer):
                                            torch.cuda.current_stream(p.device).cuda_stream))
         return loss
 
+    # -- checkpoint / resume ---------------------------------------------------------
+    def state_dict(self):
+        """torch.optim.Optimizer.state_dict() plus what lives outside `self.state`: the step count and, per model, the flat
+        Adam moment buffers (tensors on the host, keyed by position among the distinct flat buffers of the plan)."""
+        if self._plan is None:
+            self._build_plan()
+        sd = super().state_dict()
+        cores = []
+        for item in self._plan:
+            if item[0] == "flat" and all(item[2] is not c for c in cores):
+                cores.append(item[2])
+        sd["magbert"] = {"t": self._t,
+                         "flat": [{"exp_avg": c._adam_m.detach().cpu(), "exp_avg_sq": c._adam_v.detach().cpu()} for c in cores]}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        extra = state_dict.pop("magbert", None)
+        super().load_state_dict(state_dict)
+        self._plan = None
+        self._build_plan()
+        if self._fb is not None:
+            raise _lib.MagbertError("load_state_dict() before enable_fused_backward(), not after")
+        if extra is not None:
+            self._t = int(extra["t"])
+            cores = []
+            for item in self._plan:
+                if item[0] == "flat" and all(item[2] is not c for c in cores):
+                    cores.append(item[2])
+            if len(cores) != len(extra["flat"]):
+                raise ValueError("optimizer checkpoint holds %d flat buffers, this optimizer has %d" % (len(extra["flat"]), len(cores)))
+            for c, st in zip(cores, extra["flat"]):
+                c._adam_m.copy_(st["exp_avg"])
+                c._adam_v.copy_(st["exp_avg_sq"])
+
     def zero_grad(self, set_to_none=False):
         if self._plan is None:
             self._build_plan()
