@@ -37,17 +37,21 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
     constexpr int RP = 2 * LP;
     constexpr int PIT = C::ROWB + 16;
     constexpr int SPIT = LP * (int)sizeof(T) + 16;
-    constexpr int RPIT = RP * 4 + 16;                  // raw (fp32) strip pitch
+    // A 16-row strip only needs the positional scores of a window of L + 15 <= 79 relative positions (row i reads raw[i][L-i+j]):
+    // 6 tiles of 16 starting at tile pt0(strip).  The probability strip re-uses the same LDS (written after the last raw read of
+    // the wave, which executes in lock-step).  92.7 KB -> 75.3 KB per block: two blocks per CU.
+    constexpr int RWT = 2 * (LP / 16) < 6 ? 2 * (LP / 16) : 6;      // window tiles
+    constexpr int RPIT = RWT * 16 * 4 + 16;            // raw (fp32) strip pitch
     constexpr int NT = LP / 16, DSL = 64 / C::SLAB, LSL = LP / C::SLAB;
-    __shared__ __attribute__((aligned(16))) char smem[(3 * LP + RP + 16) * PIT + NW * 16 * (RPIT + SPIT) + (LP + RP + 4 + 2 * LP) * 4];
+    static_assert(16 * SPIT <= 16 * RPIT, "probability strip must fit inside the raw strip it aliases");
+    __shared__ __attribute__((aligned(16))) char smem[(3 * LP + RP + 16) * PIT + NW * 16 * RPIT + (LP + RP + 4 + 2 * LP) * 4];
     char* Qi = smem;
     char* Ki = Qi + LP * PIT;
     char* Vi = Ki + LP * PIT;
     char* Ri = Vi + LP * PIT;                          // KR image [RP][64]
     char* Si = Ri + RP * PIT;                          // seg_embed image [16][64] (rows 0,1)
     char* raws = Si + 16 * PIT;
-    char* pstr = raws + NW * 16 * RPIT;
-    float* cK = (float*)(pstr + NW * 16 * SPIT);
+    float* cK = (float*)(raws + NW * 16 * RPIT);
     float* cR = cK + LP;
     float* cS = cR + RP;
     int* segv = (int*)(cS + 4);
@@ -83,13 +87,15 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
     __syncthreads();
 
     char* raw = raws + wave * 16 * RPIT;
-    char* Ps = pstr + wave * 16 * SPIT;
+    char* Ps = raw;                                    // aliases the raw strip (see above)
     const float scale = 0.125f;
     for (int s0 = 0; s0 < NT; s0 += NW) {
         const int strip = s0 + wave;
         const bool active = strip < NT;
         f32x4 ac[NT];
         float e0 = 0.f, e1 = 0.f;
+        int pt0 = (L - strip * 16 - 15) >> 4;          // first position tile any row of this strip can touch
+        pt0 = pt0 < 0 ? 0 : (pt0 > 2 * NT - RWT ? 2 * NT - RWT : pt0);
         if (active) {
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
@@ -100,7 +106,8 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
                           frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
             }
 #pragma unroll
-            for (int pt = 0; pt < 2 * NT; ++pt) {
+            for (int q = 0; q < RWT; ++q) {
+                const int pt = pt0 + q;
                 f32x4 rw = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int sl = 0; sl < DSL; ++sl)
@@ -108,7 +115,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
                           frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
                 const int p0 = pt * 16 + (lane >> 4) * 4;
                 rw += *(const f32x4*)(cR + p0);
-                *(f32x4*)(raw + (lane & 15) * RPIT + p0 * 4) = rw;          // raw[i][p] = (q_i + r_r_bias) . kr_p
+                *(f32x4*)(raw + (lane & 15) * RPIT + (p0 - pt0 * 16) * 4) = rw;          // raw[i][p] = (q_i + r_r_bias) . kr_p
             }
             f32x4 ev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -127,8 +134,8 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = jt * 16 + (lane >> 4) * 4 + r;
-                    int p = L - i + j;
-                    p = p < 0 ? 0 : (p > RP - 1 ? RP - 1 : p);
+                    int p = L - i + j - pt0 * 16;          // inside the window for every real (i < L, j < L) pair
+                    p = p < 0 ? 0 : (p > RWT * 16 - 1 ? RWT * 16 - 1 : p);
                     const float bd = *(const float*)(raw + (lane & 15) * RPIT + p * 4);
                     float s = (ac[jt][r] + cK[j] + bd + (si == segv[j] ? e0 : e1)) * scale;
                     if (j >= L) s = kPadNeg;
@@ -209,9 +216,10 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
     constexpr int SPIT = LP * (int)sizeof(T) + 16;
     constexpr int GPIT = RP * (int)sizeof(T) + 16;     // shifted-G strip pitch
     constexpr int NT = LP / 16, DSL = 64 / C::SLAB, LSL = LP / C::SLAB, RSL = RP / C::SLAB;
-    __shared__ __attribute__((aligned(16))) char smem[(4 * LP + RP) * PIT + NW * 16 * (SPIT + GPIT) + (NW * 64 + 192 + 2 * LP) * 4];
-    char* Qi = smem;
-    char* Ki = Qi + LP * PIT;
+    // Q is not staged: it is only read once per row at the end (q_i + r_s_bias for the segment-embedding gradient), straight from
+    // HBM/L2.  Without its image the block needs 75 KB of LDS instead of 84 KB -> two blocks per CU (576 blocks: 2 rounds, not 3).
+    __shared__ __attribute__((aligned(16))) char smem[(3 * LP + RP) * PIT + NW * 16 * (SPIT + GPIT) + (NW * 64 + 192 + 2 * LP) * 4];
+    char* Ki = smem;
     char* Vi = Ki + LP * PIT;
     char* Oi = Vi + LP * PIT;                          // dvec image
     char* Ri = Oi + LP * PIT;
@@ -227,7 +235,6 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
     const int H = nh * 64;
     const size_t ld = (size_t)3 * H;
     const T* base = qkv + (size_t)b * L * ld + h * 64;
-    stage_head<T, LP, NW * 64>(Qi, PIT, base, ld, L);
     stage_head<T, LP, NW * 64>(Ki, PIT, base + H, ld, L);
     stage_head<T, LP, NW * 64>(Vi, PIT, base + 2 * H, ld, L);
     stage_head<T, LP, NW * 64>(Oi, PIT, dvec + (size_t)b * L * H + h * 64, (size_t)H, L);
@@ -317,7 +324,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
                 if (i < L) {
                     store4(dq_base + (size_t)i * ld + d, oa + ob + oe);
                     cw[dt] += oa; cr[dt] += ob; cs[dt] += oe;
-                    const f32x4 qv = load4((const T*)(Qi + i * PIT) + d) + rs;       // q_i + r_s_bias
+                    const f32x4 qv = load4(base + (size_t)i * ld + d) + rs;          // q_i + r_s_bias
                     d0[dt] += g0 * qv; d1[dt] += g1 * qv;
                 }
             }

@@ -154,6 +154,22 @@ def test_shard_indices_cover_dataset_once():
     assert all(len(b) == bs for p in per_rank for b in p[:-1])
 
 
+def test_sharded_batch_sampler_epochs_and_coverage():
+    """the driver's per-rank sampler (torchrun launch): all ranks see the same number of batches, together they cover the
+    dataset exactly once per epoch, and the shuffle changes from epoch to epoch"""
+    from bert_multimodal_transformer_amd.multimodal_driver import ShardedBatchSampler
+    n, world, bs = 1000, 4, 48
+    samplers = [ShardedBatchSampler(n, r, world, bs, 7) for r in range(world)]
+    assert len({len(s) for s in samplers}) == 1
+    e0 = [list(s) for s in samplers]
+    e1 = [list(s) for s in samplers]
+    for ep in (e0, e1):
+        flat = [i for per_rank in ep for b in per_rank for i in b]
+        assert sorted(flat) == list(range(n))
+        assert len({len(per_rank) for per_rank in ep}) == 1
+    assert e0[0][0] != e1[0][0]
+
+
 _DDP_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["REPO_ROOT"])
