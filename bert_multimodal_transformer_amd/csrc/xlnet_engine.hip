@@ -30,13 +30,18 @@ struct mb_xlnet_engine {
     size_t ws_mag, ws_magout, ws_pos, ws_xs, ws_head_z, ws_head_pooled;
     std::vector<size_t> ws_x;
     std::vector<XlLayerWs> lw;
-    size_t ws_dxa, ws_dxb, ws_dsa, ws_dzda, ws_dsb, ws_dzdb, ws_du, ws_dqkv, ws_dvec, ws_dkr, ws_gsave, ws_dz, ws_dxs, ws_lnp_a,
-        ws_lnp_b;
+    size_t ws_dsa[2], ws_dzda[2], ws_dsb[2], ws_dzdb[2], ws_du[2], ws_dqkv[2], ws_dkr[2];   // dY operands of the weight gradients: ping-pong by layer parity
+    size_t ws_dxa, ws_dxb, ws_dvec, ws_gsave, ws_dz, ws_dxs, ws_lnp_a, ws_lnp_b;
     size_t ws_bytes;
     float* P = nullptr; float* G = nullptr; char* SH = nullptr; char* ws = nullptr;
     const int64_t* ids = nullptr; const int64_t* seg = nullptr; const int64_t* mask = nullptr;
     int B = 0, L = 0, training = 0, padT = -1;
     int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped weight-gradient launch (64 | 128), 0 = one by one
+    // the grouped launch of layer l runs on an internal side stream under the dgrad chain of layer l-1 (as in the MAG-BERT engine)
+    int overlap_wgrad = 1;
+    bool deferred = false;
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> evs;   // [2 * n_layer]: fork, done
     bool ws_zeroed = false;
     uint64_t seed = 0, step = 0;
     float* logits = nullptr;
@@ -137,9 +142,12 @@ static void xl_build_layout(mb_xlnet_engine* e) {
     e->ws_head_z = w.take((size_t)c.max_batch * H * 4);
     e->ws_head_pooled = w.take((size_t)c.max_batch * H * 4);
     e->ws_dxa = w.take(T * H * es); e->ws_dxb = w.take(T * H * es);
-    e->ws_dsa = w.take(T * H * es); e->ws_dzda = w.take(T * H * es); e->ws_dsb = w.take(T * H * es); e->ws_dzdb = w.take(T * H * es);
-    e->ws_du = w.take(T * I * es); e->ws_dqkv = w.take(T * 3 * H * es); e->ws_dvec = w.take(T * H * es);
-    e->ws_dkr = w.take(R * H * es); e->ws_gsave = w.take(PP * es);
+    for (int k = 0; k < 2; ++k) {
+        e->ws_dsa[k] = w.take(T * H * es); e->ws_dzda[k] = w.take(T * H * es); e->ws_dsb[k] = w.take(T * H * es);
+        e->ws_dzdb[k] = w.take(T * H * es); e->ws_du[k] = w.take(T * I * es); e->ws_dqkv[k] = w.take(T * 3 * H * es);
+        e->ws_dkr[k] = w.take(R * H * es);
+    }
+    e->ws_dvec = w.take(T * H * es); e->ws_gsave = w.take(PP * es);
     e->ws_dz = w.take((size_t)c.max_batch * H * es); e->ws_dxs = w.take((size_t)c.max_batch * H * es);
     e->ws_lnp_a = w.take(ln_partials_floats((int)T, (int)H) * 4); e->ws_lnp_b = w.take(ln_partials_floats((int)T, (int)H) * 4);
     e->ws_bytes = w.off;
@@ -155,12 +163,20 @@ int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out) {
     if (cfg->dtype != DT_F32 && cfg->dtype != DT_BF16) return MB_ERR_DTYPE;
     mb_xlnet_engine* e = new mb_xlnet_engine();
     if (const char* v = getenv("MB_GROUP_WGRAD")) e->group_wgrad = atoi(v);
+    if (const char* v = getenv("MB_OVERLAP_WGRAD")) e->overlap_wgrad = atoi(v);
+    e->deferred = e->overlap_wgrad && (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->d_inner % e->group_wgrad == 0 &&
+                  cfg->d_model % e->group_wgrad == 0;
     e->c = *cfg;
     xl_build_layout(e);
     *out = e;
     return MB_OK;
 }
-void mb_xlnet_destroy(mb_xlnet_engine* e) { delete e; }
+void mb_xlnet_destroy(mb_xlnet_engine* e) {
+    if (!e) return;
+    if (e->side) hipStreamDestroy(e->side);
+    for (auto& ev : e->evs) if (ev) hipEventDestroy(ev);
+    delete e;
+}
 int mb_xlnet_num_tensors(const mb_xlnet_engine* e) { return (int)e->tensors.size(); }
 int mb_xlnet_tensor_info(const mb_xlnet_engine* e, int i, char* name, int name_cap, size_t* offset, size_t* numel, int* ndim,
                          int64_t* shape4, int* decay) {
@@ -206,6 +222,8 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
     e->B = B; e->L = L; e->training = training; e->seed = seed; e->step = step; e->logits = logits;
     float* P = e->P;
     char* ws = e->ws;
+    if (e->deferred && e->side)      // a backward that was not run to its last stage may still have weight-gradient GEMMs in flight
+        for (size_t l = 0; l < 2 && 2 * l + 1 < e->evs.size(); ++l) CK((int)hipStreamWaitEvent(st, e->evs[2 * l + 1], 0));
     if (!e->ws_zeroed || e->padT != T) {      // pad rows of every k-major wgrad operand must be zero
         CK((int)hipMemsetAsync(ws, 0, e->ws_bytes, st));
         e->ws_zeroed = true;
@@ -289,10 +307,13 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
             const char* xin = (l == c.injection_index) ? ws + e->ws_magout : ws + e->ws_x[l];
             char* dx = ws + e->ws_dxa;
             char* t1 = ws + e->ws_dxb;
-            char* dsA = ws + e->ws_dsa;
-            char* dzdA = hd ? ws + e->ws_dzda : dsA;
-            char* dsB = ws + e->ws_dsb;
-            char* dzdB = hd ? ws + e->ws_dzdb : dsB;
+            const int par = l & 1;
+            char* dsA = ws + e->ws_dsa[par];
+            char* dzdA = hd ? ws + e->ws_dzda[par] : dsA;
+            char* dsB = ws + e->ws_dsb[par];
+            char* dzdB = hd ? ws + e->ws_dzdb[par] : dsB;
+            char* du = ws + e->ws_du[par];
+            char* dkr = ws + e->ws_dkr[par];
             int nblk = 0;
             float* lnp_a = (float*)(ws + e->ws_lnp_a);
             float* lnp_b = (float*)(ws + e->ws_lnp_b);
@@ -300,20 +321,20 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
             CK(ln_backward_partials(dt, dx, ws + w.s2, P + o.fflnw, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, dsA,
                                     hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(XS_LAYER0 + 8 * l + 3, pd), st));
             // the layer's seven weight gradients go out as ONE grouped launch once every dY exists (MB_GROUP_WGRAD=0: one by one)
-            char* dqkv = ws + e->ws_dqkv;
+            char* dqkv = ws + e->ws_dqkv[par];
             GemmArgs wg[7] = {wgrad_args(H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I),
-                              wgrad_args(I, H, Tk, ws + e->ws_du, I, ws + w.y1, H, G + o.w1, H),
+                              wgrad_args(I, H, Tk, du, I, ws + w.y1, H, G + o.w1, H),
                               wgrad_args(H, H, Tk, dzdB, H, ws + w.vec, H, G + o.o, H),                 // d o[h][nd] = dzd^T vec
-                              wgrad_args(H, H, Rk, ws + e->ws_pos, H, ws + e->ws_dkr, H, G + o.r, H),   // d r = pos^T dkr
+                              wgrad_args(H, H, Rk, ws + e->ws_pos, H, dkr, H, G + o.r, H),   // d r = pos^T dkr
                               wgrad_args(H, H, Tk, xin, H, dqkv, 3 * H, G + o.q, H),
                               wgrad_args(H, H, Tk, xin, H, dqkv + (size_t)H * es, 3 * H, G + o.k, H),
                               wgrad_args(H, H, Tk, xin, H, dqkv + (size_t)2 * H * es, 3 * H, G + o.v, H)};
             const bool grouped = e->group_wgrad > 0 && gemm_grouped_tn_ok(dt, wg, 7, e->group_wgrad);
             if (!grouped) CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, st));
-            CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, ws + e->ws_du, I, nullptr, G + o.b1, nullptr, ws + w.u, I,
+            CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, du, I, nullptr, G + o.b1, nullptr, ws + w.u, I,
                     e->key(XS_LAYER0 + 8 * l + 2, pd), 1, 0, st));
-            if (!grouped) CK(wgrad(dt, I, H, Tk, ws + e->ws_du, I, ws + w.y1, H, G + o.w1, H, st));
-            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, I, ws + e->ws_du, I, e->W(o.w1), H, t1, H, nullptr, nullptr, nullptr, dsA, H,
+            if (!grouped) CK(wgrad(dt, I, H, Tk, du, I, ws + w.y1, H, G + o.w1, H, st));
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, I, du, I, e->W(o.w1), H, t1, H, nullptr, nullptr, nullptr, dsA, H,
                     kNoDrop, 1, 0, st));
             // ---- relative attention block
             CK(ln_backward_partials(dt, t1, ws + w.s1, P + o.ralnw, (const float*)(ws + w.st1), (const float*)(ws + w.st1) + T, dsB,
@@ -326,12 +347,22 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.o), H, ws + e->ws_dvec, H, nullptr, nullptr, nullptr, nullptr, 0,
                     kNoDrop, 1, 0, st));
             CK(xlnet_attention_backward(dt, ws + w.qkv, ws + w.kr, P + o.rwb, P + o.rrb, P + o.rsb, P + o.seg, e->seg, e->mask,
-                                        ws + w.psave, ws + e->ws_dvec, ws + e->ws_gsave, dqkv, ws + e->ws_dkr, G + o.rwb, G + o.rrb,
+                                        ws + w.psave, ws + e->ws_dvec, ws + e->ws_gsave, dqkv, dkr, G + o.rwb, G + o.rrb,
                                         G + o.rsb, G + o.seg, B, L, nh, e->key(XS_LAYER0 + 8 * l + 0, pd), st));
-            if (grouped) {
+            if (grouped && e->deferred) {
+                if (!e->side) {
+                    CK((int)hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+                    e->evs.assign((size_t)2 * NL, nullptr);
+                    for (auto& ev : e->evs) CK((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                }
+                CK((int)hipEventRecord(e->evs[2 * l], st));                       // every dY of the layer is final on `st`
+                CK((int)hipStreamWaitEvent(e->side, e->evs[2 * l], 0));
+                CK(gemm_grouped_tn_launch(dt, wg, 7, e->group_wgrad, e->side));
+                CK((int)hipEventRecord(e->evs[2 * l + 1], e->side));              // "weight gradients of layer l are final"
+            } else if (grouped) {
                 CK(gemm_grouped_tn_launch(dt, wg, 7, e->group_wgrad, st));
             } else {
-                CK(wgrad(dt, H, H, Rk, ws + e->ws_pos, H, ws + e->ws_dkr, H, G + o.r, H, st));
+                CK(wgrad(dt, H, H, Rk, ws + e->ws_pos, H, dkr, H, G + o.r, H, st));
                 CK(wgrad(dt, H, H, Tk, xin, H, dqkv, 3 * H, G + o.q, H, st));
                 CK(wgrad(dt, H, H, Tk, xin, H, dqkv + (size_t)H * es, 3 * H, G + o.k, H, st));
                 CK(wgrad(dt, H, H, Tk, xin, H, dqkv + (size_t)2 * H * es, 3 * H, G + o.v, H, st));
@@ -351,7 +382,10 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                                 st));
                 CK((int)hipMemcpyAsync(dx, t1, (size_t)T * H * es, hipMemcpyDeviceToDevice, st));
             }
+            // deferred join: main waits for layer l+1's launch only now (its dY buffers have the parity of layer l-1, written next)
+            if (grouped && e->deferred && l + 1 < NL) CK((int)hipStreamWaitEvent(st, e->evs[2 * (l + 1) + 1], 0));
         } else {
+            if (e->deferred && e->side) CK((int)hipStreamWaitEvent(st, e->evs[1], 0));       // weight gradients of layer 0
             CK(gather_drop_backward(dt, ws + e->ws_dxa, e->ids, G + e->word, T, H, e->key(XS_EMB, pd), st));
         }
     }
@@ -367,8 +401,11 @@ int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs
     if (stage == 0) span(e->wsum, e->sh_end);
     else if (stage <= NL) {
         const int l = NL - stage;
-        span(e->lo[l].q, l + 1 < NL ? e->lo[l + 1].q : e->wsum);
+        auto wspan = [&](int k) { span(e->lo[k].q, k + 1 < NL ? e->lo[k + 1].q : e->wsum); };
+        if (!e->deferred) wspan(l);
+        else if (l + 1 < NL) wspan(l + 1);           // deferred join: a layer's weights are final one stage later
     } else if (stage == NL + 1) {
+        if (e->deferred) span(e->lo[0].q, NL > 1 ? e->lo[1].q : e->wsum);
         span(e->small_decay_begin, e->n_decay);      // seg_embed / layer_norm weights, word embedding, MAG weights, logits_proj.weight
         span(e->n_decay, e->n_trainable);            // every no-decay parameter
     } else return -1;
