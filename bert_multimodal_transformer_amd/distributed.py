@@ -14,6 +14,8 @@ LayerNorm) plus the classifier go out as one final 0.4 MB piece.  The 1/world_si
 AdamW kernel (AdamW.grad_scale), so no extra pass over the gradients.  xGMI is point-to-point (7 links/GPU): large
 contiguous pieces let RCCL use all links; we never translate an NCCL bucket pattern.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -48,12 +50,14 @@ class GradReducer(object):
         self.g = flat_grads
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # MB_DP_FORCE=1: issue the collectives even in a 1-rank group (exercises the RCCL call path on a single GPU; tests)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("MB_DP_FORCE") == "1")
         self.cuda = flat_grads.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grads.device) if self.cuda else None
         self.pending = []
 
     def reduce_ranges(self, ranges):
-        if self.world == 1 or not ranges:
+        if not self.active or not ranges:
             return
         if self.cuda:
             ev = torch.cuda.Event()
@@ -68,7 +72,7 @@ class GradReducer(object):
 
     def wait(self):
         """make the compute stream wait for every outstanding piece (call before optimizer.step())"""
-        if self.cuda and self.world > 1:
+        if self.cuda and self.active:
             torch.cuda.current_stream(self.g.device).wait_stream(self.comm_stream)
 
 
@@ -107,7 +111,7 @@ class DataParallel(object):
             optimizer._dp = self
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
+        if self.reducer.active:
             dist.broadcast(self.core.params, src=src, group=self.reducer.pg)
             self.core.weights_dirty = True
 

@@ -118,3 +118,56 @@ def test_driver_under_two_ranks(tmp_path, model, accum):
     print("losses rank0 %.4f -> %.4f, rank1 %.4f -> %.4f" % (a["l0"], a["l1"], b["l0"], b["l1"]))
     for d in (a, b):
         assert d["l0"] == d["l0"] and d["l1"] < d["l0"] and d["vl"] == d["vl"], (d["l0"], d["l1"], d["vl"])
+
+
+_RCCL_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO_ROOT"]); sys.path.insert(0, os.path.join(os.environ["REPO_ROOT"], "tests"))
+from test_model_gpu import build, tb, weights, DEV
+from bert_multimodal_transformer_amd import AdamW, get_linear_schedule_with_warmup
+from bert_multimodal_transformer_amd.distributed import DataParallel
+from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
+torch.cuda.set_device(0)
+use_dp = os.environ["USE_DP"] == "1"
+if use_dp:
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))     # nccl == RCCL on ROCm
+m = build(layers=2, p_mag=0.0, hidden_p=0.0, attn_p=0.0).train()
+opt = AdamW(optimizer_grouped_parameters(m), lr=1e-3)
+sch = get_linear_schedule_with_warmup(opt, 0, 100)
+if use_dp:
+    dp = DataParallel(m, opt)
+    assert dp.reducer.active
+    dp.broadcast_parameters(0)
+with m.stream_scope():
+    for s in range(3):
+        ids, vis, aco, mask, seg, lab = tb(weights.synthetic_bert_batch(8, 50, 47, 74, seed=90 + s), DEV)
+        m.training_step(ids, vis, aco, mask, seg, lab)
+        opt.step(); sch.step(); opt.zero_grad()
+torch.cuda.synchronize()
+torch.save(m.flat_params.cpu(), os.environ["OUT"] + "." + os.environ["USE_DP"])
+if use_dp:
+    dist.barrier(); dist.destroy_process_group()
+print("OK")
+'''
+
+
+def test_rccl_call_path_single_rank(tmp_path):
+    """The RCCL (backend "nccl") call path of the product -- init with device_id, broadcast of the flat parameters, all-reduce
+    of flat gradient views on the comm stream hooked into the backward stages, the wait before AdamW, barrier -- on ONE GPU
+    with a 1-rank group (MB_DP_FORCE=1 issues the collectives although they are identities).  Result == plain single process."""
+    import torch
+    script = tmp_path / "r.py"
+    script.write_text(_RCCL_WORKER)
+    out = str(tmp_path / "rccl")
+    for use_dp in ("0", "1"):
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 1000),
+                   REPO_ROOT=ROOT, OUT=out, USE_DP=use_dp, MB_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode()[-3000:]
+    a, b = torch.load(out + ".0"), torch.load(out + ".1")
+    d = (a - b).abs()
+    frac = float((d > 2e-6).float().mean())
+    print("RCCL 1-rank DP vs plain: max |dparam| %.3e, moved fraction %.3e" % (float(d.max()), frac))
+    # same criterion as test_two_ranks_equal_one_process: Adam turns a ~0 gradient whose sign flips with the fp32 summation order
+    # into a +-lr move; a missing stream dependency would instead corrupt whole contiguous ranges
+    assert float(d.max()) <= 3 * 2 * 1e-3 * 1.1 and frac < 2e-2
