@@ -13,6 +13,8 @@ if [ "${1:-tests}" = "tests" ]; then
 fi
 (timeout 900 python bench.py 2>&1 | tail -5) > gpurun_out/bench_${TAG}.log 2>&1
 tail -2 gpurun_out/bench_${TAG}.log
+(timeout 600 python bench.py --model xlnet --cpu-steps 1 2>&1 | tail -2) > gpurun_out/bench_xlnet_${TAG}.log 2>&1
+tail -1 gpurun_out/bench_xlnet_${TAG}.log | cut -c1-400
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof && mkdir -p /tmp/prof
 (timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python $R/bench.py --steps 10 --warmup 3 --cpu-baseline 0 2>&1 | tail -3) > $R/gpurun_out/rocprof_${TAG}.log 2>&1
