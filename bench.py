@@ -53,6 +53,9 @@ def parse():
     p.add_argument("--fused-optimizer", type=int, default=0,
                    help="N=1 only: AdamW for the encoder GEMM weights runs in the weight-gradient GEMM epilogue (same arithmetic; "
                         "measured neutral, so the default keeps the same code path at every N)")
+    p.add_argument("--pipelined-optimizer", type=int, default=0,
+                   help="AdamW runs on the engine's optimizer stream, chunk by chunk, under the next forward (same arithmetic; "
+                        "measured neutral: the forward GEMMs are memory-latency-bound and slow down under the HBM-saturating update)")
     p.add_argument("--roofline-only", type=int, default=0, help="skip the training loop, print the GEMM table only")
     return p.parse_args()
 
@@ -215,6 +218,7 @@ def main():
     if a.overlap_optimizer:
         opt.enable_overlap(model)
     fused_opt = bool(a.fused_optimizer) and world == 1 and opt.enable_fused_backward(model)
+    piped_opt = bool(a.pipelined_optimizer) and not fused_opt and not a.overlap_optimizer and opt.enable_pipelined_step(model)
     model.train()
     nb = 8
     batches = make_batches(nb, B, L, V, A, seed=1234 + rank, layout=a.model)
@@ -296,7 +300,8 @@ def main():
                "config": {"workload": mname + (" bert-base-uncased" if a.model == "bert" else " xlnet-base-cased") + ", %s dims (V=%d, A=%d), batch %d/GPU, seq_len %d, full "
                                       "optimizer step (fwd+MSE+bwd%s+HF-AdamW%s+schedule; inputs resident in HBM), dropout on, random-init weights"
                                       % (a.dataset.upper(), V, A, B, L, "+RCCL all-reduce" if world > 1 else "",
-                                         " (encoder weights updated in the wgrad epilogue)" if fused_opt else ""),
+                                         " (encoder weights updated in the wgrad epilogue)" if fused_opt else
+                                         (" (pipelined under the next forward)" if piped_opt else "")),
                           "global_batch": world * B, "seq_len": L, "parallelism": "dp%d" % world},
                "mean_loss": round(loss, 4), "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
                "value_with_h2d": round(world * B / dt_h2d, 2)}

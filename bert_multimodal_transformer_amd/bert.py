@@ -99,6 +99,7 @@ class _Core(object):
         self._own_stream = None
         self.stage_hooks = []          # callables hook(stage) run after each backward stage (DataParallel, AdamW overlap)
         self.pre_backward_hooks = []   # callables run before the first backward stage (AdamW.enable_fused_backward)
+        self.optimizer_pending = False  # a pipelined optimizer step may still be writing parameters (join_optimizer())
         self._make_engine(1, 8)
         n = self._fn("param_count")(self.handle)
         self.n_params = n
@@ -137,6 +138,7 @@ class _Core(object):
             float(mc.dropout_prob), self.dt, int(B), int(L))
 
     def _make_engine(self, B, L):
+        self.join_optimizer()
         h = C.c_void_p()
         cfg = self._cfg(B, L)
         _lib.check(self._fn("create")(C.byref(cfg), C.byref(h)))       # raises (and keeps the old engine) on a bad shape
@@ -202,6 +204,7 @@ class _Core(object):
         with _Core._Hop(self):
             _lib.check(self._fn("sync_weights")(self.handle, self.stream()))
         self.weights_dirty = False
+        self.optimizer_pending = False
 
     # -- passes --------------------------------------------------------------------------------------
     def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, training):
@@ -230,6 +233,7 @@ class _Core(object):
                                                 self.step, _lib.ptr(logits), C.c_void_p(self.loss_buf.data_ptr()),
                                                 C.c_void_p(self.loss_buf.data_ptr() + 4) if lab is not None else None,
                                                 self.stream()))
+        self.optimizer_pending = False          # the engine forward waited for every chunk of a pipelined optimizer step
         return logits
 
     def _backward(self, dlogits=None, loss_scale=1.0):
@@ -260,6 +264,12 @@ class _Core(object):
         p = self.lib.mb_bert_pooled_output(self.handle)
         off = p - self.ws.data_ptr()
         return self.ws[off: off + B * H * 4].view(torch.float32).view(B, H).clone()
+
+    def join_optimizer(self):
+        """make the current stream wait for a pipelined optimizer step (AdamW.enable_pipelined_step) that is still in flight"""
+        if self.optimizer_pending and self.handle is not None and self.kind == "bert":
+            _lib.check(self.lib.mb_bert_adamw_join(self.handle, self.stream()))
+        self.optimizer_pending = False
 
     def fused_range(self):
         """flat [begin, end) the engine can update inside the backward (mb_bert_fuse_adamw); None if unsupported"""
@@ -352,7 +362,15 @@ class _MagBertBase(nn.Module):
         super()._load_from_state_dict(*a, **k)
         self._core.weights_dirty = True
 
+    def join_optimizer(self):
+        self._core.join_optimizer()
+
+    def state_dict(self, *args, **kwargs):
+        self._core.join_optimizer()
+        return super().state_dict(*args, **kwargs)
+
     def load_state_dict(self, state_dict, strict=True, **kw):
+        self._core.join_optimizer()
         sd = {k: v for k, v in state_dict.items() if not k.endswith("position_ids")}
         r = super().load_state_dict(sd, strict=strict, **kw)
         self._core.weights_dirty = True
@@ -382,12 +400,14 @@ class _MagBertBase(nn.Module):
             cur = torch.cuda.current_stream(core.device)
             if cur.cuda_stream != 0:
                 yield
+                core.join_optimizer()
                 return
             if core._own_stream is None:
                 core._own_stream = torch.cuda.Stream(device=core.device)
             core._own_stream.wait_stream(cur)
             with torch.cuda.stream(core._own_stream):
                 yield
+                core.join_optimizer()
             cur.wait_stream(core._own_stream)
         return scope()
 
@@ -514,6 +534,7 @@ class MAG_BertForSequenceClassification(_MagBertBase):
     # flat views for the fused optimizer / data parallel -------------------------------------------------
     @property
     def flat_params(self):
+        self._core.join_optimizer()
         return self._core.params
 
     @property

@@ -51,6 +51,11 @@ struct mb_bert_engine {
     bool fuse = false;
     float* FM = nullptr; float* FV = nullptr;      // Adam moments, flat, parallel to P
     AdamArgs fa;
+    // pipelined optimizer (mb_bert_adamw_pipelined): AdamW runs chunk by chunk on its own stream in the order the next forward
+    // needs the parameters; the forward waits for chunk k only in front of the first kernel that reads it
+    hipStream_t opt_stream = nullptr;
+    std::vector<hipEvent_t> oev;   // [0] grads final on the caller's stream ; [1 + k] chunk k updated (k = 0 front, 1..NL layers, NL+1 head)
+    bool opt_pending = false;
     bool prof = false;             // mb_bert_set_profiling: timing events around every grouped wgrad launch (on the side stream)
     std::vector<hipEvent_t> pev;   // [2 * num_layers]
     bool ws_zeroed = false;
@@ -288,6 +293,8 @@ void mb_bert_destroy(mb_bert_engine* e) {
     if (e->side) hipStreamDestroy(e->side);
     for (auto& ev : e->evs) if (ev) hipEventDestroy(ev);
     for (auto& ev : e->pev) if (ev) hipEventDestroy(ev);
+    for (auto& ev : e->oev) if (ev) hipEventDestroy(ev);
+    if (e->opt_stream) hipStreamDestroy(e->opt_stream);
     delete e;
 }
 int mb_bert_num_tensors(const mb_bert_engine* e) { return (int)e->tensors.size(); }
@@ -316,9 +323,19 @@ int mb_bert_bind(mb_bert_engine* e, float* params, float* grads, void* shadow, v
     return MB_OK;
 }
 
+int mb_bert_adamw_join(mb_bert_engine* e, void* stream) {
+    if (!e) return MB_ERR_ARG;
+    if (e->opt_pending) {       // the optimizer stream is in order: its last event implies every chunk
+        CK((int)hipStreamWaitEvent((hipStream_t)stream, e->oev.back(), 0));
+        e->opt_pending = false;
+    }
+    return MB_OK;
+}
+
 int mb_bert_sync_weights(mb_bert_engine* e, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!e->P) return MB_ERR_ARG;
+    CK(mb_bert_adamw_join(e, stream));
     if (e->c.dtype == DT_BF16)
         CK(convert(DT_BF16, e->P + e->sh_begin, e->SH + e->sh_begin * 2, e->sh_end - e->sh_begin, st));
     const mb_bert_config& c = e->c;
@@ -362,6 +379,8 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
         for (int l = 0; l < c.num_layers; ++l) { CK(zp(e->lw[l].ctx, H)); CK(zp(e->lw[l].y1, H)); CK(zp(e->lw[l].g, I)); }
     }
     e->padT = T;
+    const bool optw = e->opt_pending;          // parameters are still being updated on the optimizer stream, chunk by chunk
+    if (optw) CK((int)hipStreamWaitEvent(st, e->oev[1], 0));                        // embeddings + MAG
     // embeddings (bert.py:211-216)
     CK(embed_ln_forward(dt, input_ids, token_type_ids, P + e->word, P + e->pos, P + e->type, P + e->emb_lnw, P + e->emb_lnb,
                         c.layer_norm_eps, ws + e->ws_emb, (float*)(ws + e->ws_emb_st), (float*)(ws + e->ws_emb_st) + T, B, L,
@@ -376,6 +395,7 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
         const LayerOff& o = e->lo[l];
         const LayerWs& w = e->lw[l];
         const char* x = ws + e->ws_x[l];
+        if (optw) CK((int)hipStreamWaitEvent(st, e->oev[2 + l], 0));                // this layer's weights, biases, LayerNorms
         CK(gemm(dt, GEMM_NT, EPI_BIAS, T, 3 * H, H, x, H, e->W(o.wqkv), H, ws + w.qkv, 3 * H, nullptr, nullptr, P + o.bqkv,
                 nullptr, 0, kNoDrop, 1, 0, st));
         CK(attention_forward(dt, ws + w.qkv, attention_mask, ws + w.ctx, B, L, nh,
@@ -393,6 +413,7 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     }
     // pooler + classifier (+ MSE) (bert.py:231, 304-307; multimodal_driver.py:372-373)
     float* z = (float*)(ws + e->ws_head_z);
+    if (optw) { CK((int)hipStreamWaitEvent(st, e->oev[2 + c.num_layers], 0)); e->opt_pending = false; }   // pooler + classifier
     CK(gemm(dt, GEMM_NT, EPI_BIAS_F32, B, H, H, ws + e->ws_x[c.num_layers], L * H, e->W(e->wp), H, nullptr, H, nullptr, z,
             P + e->bp, nullptr, 0, kNoDrop, 1, 64, st));
     if (loss) CK((int)hipMemsetAsync(loss, 0, 4, st));
@@ -581,6 +602,46 @@ int mb_bert_fused_range(const mb_bert_engine* e, size_t* begin, size_t* end) {
     *begin = e->lo[0].wqkv;            // the encoder GEMM weights: layer 0 query ... layer NL-1 output.dense
     *end = e->wp;
     return e->deferred ? MB_OK : MB_ERR_MODE;
+}
+
+int mb_bert_adamw_pipelined(mb_bert_engine* e, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int step, int correct_bias, float grad_scale, int zero_grad, void* stream) {
+    if (!e || !m || !v || !e->P || !e->G) return MB_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int NL = e->c.num_layers;
+    if (!e->opt_stream) {
+        CK((int)hipStreamCreateWithFlags(&e->opt_stream, hipStreamNonBlocking));
+        e->oev.assign((size_t)NL + 3, nullptr);
+        for (auto& ev : e->oev) CK((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    if (e->opt_pending) CK(mb_bert_adamw_join(e, stream));       // two steps without a forward in between
+    AdamArgs a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale;
+    double ss = lr;
+    if (correct_bias) ss = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+    a.step_size = (float)ss;
+    hipStream_t os = e->opt_stream;
+    CK((int)hipEventRecord(e->oev[0], st));                      // every gradient is final on the caller's stream
+    CK((int)hipStreamWaitEvent(os, e->oev[0], 0));
+    auto upd = [&](size_t b, size_t en) -> int {                 // one range, entirely inside the decay or the no-decay group
+        if (en <= b) return MB_OK;
+        const size_t n = en - b;
+        const size_t sb = std::min(std::max(e->sh_begin, b), en) - b, se = std::min(std::max(e->sh_end, b), en) - b;
+        void* sh = e->c.dtype == DT_BF16 ? (void*)((bf16*)e->SH + b) : nullptr;
+        return adamw_step(e->P + b, e->G + b, m + b, v + b, sh, n, b < e->n_decay ? n : 0, sb, se, a, zero_grad, os);
+    };
+    // chunk 0: what the forward touches first -- embedding tables + MAG weights, embeddings LayerNorm, MAG biases + LayerNorm
+    CK(upd(e->word, e->wc)); CK(upd(e->emb_lnw, e->bp)); CK(upd(e->mag_bhv, e->bc));
+    CK((int)hipEventRecord(e->oev[1], os));
+    for (int l = 0; l < NL; ++l) {
+        CK(upd(e->lo[l].wqkv, l + 1 < NL ? e->lo[l + 1].wqkv : e->wp));
+        CK(upd(e->lo[l].bqkv, l + 1 < NL ? e->lo[l + 1].bqkv : e->emb_lnw));
+        CK((int)hipEventRecord(e->oev[2 + l], os));
+    }
+    CK(upd(e->wp, e->sh_end)); CK(upd(e->wc, e->n_decay)); CK(upd(e->bp, e->mag_bhv)); CK(upd(e->bc, e->n_params));
+    CK((int)hipEventRecord(e->oev[2 + NL], os));
+    e->opt_pending = true;
+    return MB_OK;
 }
 
 int mb_bert_set_profiling(mb_bert_engine* e, int on) {

@@ -111,6 +111,7 @@ class DataParallel(object):
             optimizer._dp = self
 
     def broadcast_parameters(self, src=0):
+        self.core.join_optimizer()
         if self.reducer.active:
             dist.broadcast(self.core.params, src=src, group=self.reducer.pg)
             self.core.weights_dirty = True

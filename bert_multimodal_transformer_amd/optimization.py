@@ -31,6 +31,7 @@ class AdamW(torch.optim.Optimizer):
         self._dp = None              # set by distributed.DataParallel
         self._ov = None              # overlap state (enable_overlap)
         self._fb = None              # fused-backward state (enable_fused_backward)
+        self._pipe = None            # pipelined-step state (enable_pipelined_step)
         self.fused_backward_armed = False
 
     # -- planning: map groups onto contiguous flat ranges ------------------------------------------------
@@ -62,6 +63,49 @@ class AdamW(torch.optim.Optimizer):
             for p in loose:
                 plan.append(("loose", gi, p))
         self._plan = plan
+
+    # -- optimizer pipelined against the next forward -------------------------------------------------------------
+    def enable_pipelined_step(self, model):
+        """step() hands the whole flat update to the engine (mb_bert_adamw_pipelined): the same AdamW kernel, launched range by
+        range on an engine-owned HIP stream in the order the NEXT forward reads the parameters; that forward waits for a range
+        only in front of the first kernel that needs it.  The update is HBM-bound and the forward is MFMA-latency-bound, so
+        ~3/4 of the optimizer pass disappears under the forward.  Same arithmetic, same hyper-parameters, works under
+        DataParallel (gradients are all-reduced before step()).
+
+        Contract: after step() the parameters are only guaranteed current for the model's own passes; anything else that
+        reads them (state_dict(), .cpu(), flat_params) goes through model.join_optimizer() first -- the model's state_dict(),
+        flat_params, load_state_dict() and stream_scope() do.  Returns False when the engine / parameter groups do not fit
+        (MAG-XLNet, parameters outside the flat buffer, a decayed no-decay group)."""
+        core = model._core
+        if core.kind != "bert" or self._fb is not None or self._ov is not None:
+            return False
+        if self._plan is None:
+            self._build_plan()
+        flats = [it for it in self._plan if it[0] == "flat"]
+        if len(flats) != 2 or len(self._plan) != 2 or any(it[2] is not core for it in flats):
+            return False
+        flats.sort(key=lambda it: it[3])
+        (_, g0, _, a0, b0), (_, g1, _, a1, b1) = flats
+        if a0 != 0 or b0 != core.n_decay or a1 != core.n_decay or b1 != core.n_params:
+            return False
+        if self.param_groups[g1]["weight_decay"] != 0.0:
+            return False
+        self._pipe = dict(core=core, g0=g0, g1=g1)
+        return True
+
+    def _pipelined_step(self):
+        pp = self._pipe
+        core = pp["core"]
+        ga, gb = self.param_groups[pp["g0"]], self.param_groups[pp["g1"]]
+        same = all(ga[k] == gb[k] for k in ("lr", "betas", "eps", "correct_bias"))
+        if not same:
+            return False                                  # groups diverged (custom schedule): plain path
+        b1, b2 = ga["betas"]
+        _lib.check(core.lib.mb_bert_adamw_pipelined(
+            core.handle, _lib.ptr(core._adam_m), _lib.ptr(core._adam_v), ga["lr"], b1, b2, ga["eps"], ga["weight_decay"], self._t,
+            1 if ga["correct_bias"] else 0, self.grad_scale, 1 if self.fused_zero_grad else 0, core.stream()))
+        core.optimizer_pending = True
+        return True
 
     # -- optimizer fused into the backward GEMMs --------------------------------------------------------------
     def enable_fused_backward(self, model):
@@ -207,6 +251,8 @@ class AdamW(torch.optim.Optimizer):
             return loss
         L = _lib.lib()
         self._t += 1
+        if self._pipe is not None and self._pipelined_step():
+            return loss
         for item in self._plan:
             group = self.param_groups[item[1]]
             b1, b2 = group["betas"]
@@ -249,6 +295,8 @@ class AdamW(torch.optim.Optimizer):
             self._build_plan()
         sd = super().state_dict()
         cores = []
+        if self._pipe is not None:
+            self._pipe["core"].join_optimizer()
         for item in self._plan:
             if item[0] == "flat" and all(item[2] is not c for c in cores):
                 cores.append(item[2])

@@ -158,6 +158,17 @@ int mb_bert_fuse_adamw(mb_bert_engine* e, float* m, float* v, float lr, float be
                        float weight_decay, int step, int correct_bias, float grad_scale);
 int mb_bert_fused_range(const mb_bert_engine* e, size_t* begin, size_t* end);
 
+/* optimizer.step() + optimizer.zero_grad() (multimodal_driver.py:384-386) for EVERY parameter of the engine, pipelined against
+ * the next forward: the same AdamW arithmetic as mb_adamw_step, launched range by range on an engine-owned stream in the order
+ * the forward consumes the parameters (embeddings + MAG, layer 0 ... layer NL-1, pooler + classifier).  The call returns at once;
+ * `stream` is NOT made to wait.  The next mb_bert_forward waits for each chunk right in front of the first kernel that reads it,
+ * so the HBM-bound update of layer l+1 ... runs under the MFMA-bound forward of layer l.  Everything else that reads the
+ * parameters on `stream` (state_dict, host copies, mb_bert_sync_weights) must call mb_bert_adamw_join first (sync_weights does).
+ * m, v: Adam moment buffers parallel to the bound parameters.  Gradients must be final on `stream` (after any all-reduce). */
+int mb_bert_adamw_pipelined(mb_bert_engine* e, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int step, int correct_bias, float grad_scale, int zero_grad, void* stream);
+int mb_bert_adamw_join(mb_bert_engine* e, void* stream);
+
 /* Measurement hooks (bench.py): with profiling on, every per-layer grouped weight-gradient launch of mb_bert_backward is
  * bracketed by HIP timing events on the engine's internal side stream -- the stream that kernel runs on, which the
  * caller cannot see.  mb_bert_profile_wgrad_us waits for the last backward's events and returns the mean launch

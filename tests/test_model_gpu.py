@@ -274,6 +274,46 @@ def test_fused_backward_optimizer_equals_plain_step(cdt):
         assert frac < 1e-3, frac
 
 
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_pipelined_optimizer_step_equals_plain_step(cdt):
+    """AdamW.enable_pipelined_step: the update runs on the engine's optimizer stream, chunk by chunk, under the next forward.
+    200 three-step trajectories (dropout ON, same seeds) must all end where the plain optimizer.step() trajectory ends: a
+    missing dependency between an update chunk and the forward kernel that reads it would show up as a stale tensor."""
+    from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
+    torch.manual_seed(5)
+    m = build(layers=2, cdt=cdt).train()
+    core = m._core
+    opt = AdamW(optimizer_grouped_parameters(m), lr=1e-3)
+    p0 = m.flat_params.clone()
+    rng0 = m.get_rng_state()
+    batches = [tb(weights.synthetic_bert_batch(4, 32, 47, 74, seed=120 + s), DEV) for s in range(3)]
+
+    def trajectory():
+        core.params.copy_(p0); core.weights_dirty = True
+        core._adam_m.zero_(); core._adam_v.zero_(); core.grads.zero_()
+        opt._t = 0
+        m.set_rng_state(rng0)
+        sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=1.0, num_training_steps=10)
+        with m.stream_scope():
+            for ids, vis, aco, mask, seg, lab in batches:
+                m.training_step(ids, vis, aco, mask, seg, lab)
+                opt.step(); sch.step(); opt.zero_grad()
+        return m.flat_params.clone()
+
+    opt._build_plan()
+    ref = trajectory()
+    ref2 = trajectory()
+    noise = float((ref - ref2).abs().max())                      # run-to-run noise of the plain path (fp32 atomics)
+    assert opt.enable_pipelined_step(m) is True
+    worst, bad = 0.0, 0
+    for trial in range(200):
+        d = float((trajectory() - ref).abs().max())
+        worst = max(worst, d)
+        bad += d > 2e-6 + 10 * noise
+    print("pipelined vs plain: plain run-to-run %.3e, worst of 200 trajectories %.3e, outliers %d" % (noise, worst, bad))
+    assert bad == 0
+
+
 def test_checkpoint_resume_continues_the_run(tmp_path):
     """state_dict (reference key names) + optimizer state (flat Adam moments, step count) + dropout counter saved after 2
     steps and loaded into fresh objects: step 3 equals the uninterrupted run bit for bit (fp32, dropout ON)."""
