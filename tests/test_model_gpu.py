@@ -314,6 +314,48 @@ def test_pipelined_optimizer_step_equals_plain_step(cdt):
     assert bad == 0
 
 
+@pytest.mark.parametrize("B,L", [(1, 8), (3, 127), (2, 128), (5, 33), (48, 1)])
+def test_edge_shapes_eval_fp32(B, L):
+    """smallest / odd / maximum sequence lengths, a single sample, a row without padding, a row that is only [CLS][SEP]"""
+    m = build(layers=2).eval()
+    o = oracle(layers=2).eval()
+    b = weights.synthetic_bert_batch(B, max(L, 8), 47, 74, seed=300 + L) if L >= 8 else None
+    if b is None:          # L = 1: a lone [CLS] token per sample
+        b = dict(input_ids=np.full((B, 1), 101, np.int64), visual=np.zeros((B, 1, 47), np.float32),
+                 acoustic=np.zeros((B, 1, 74), np.float32), input_mask=np.ones((B, 1), np.int64),
+                 segment_ids=np.zeros((B, 1), np.int64), label_ids=np.zeros((B,), np.float32))
+    else:
+        b["input_mask"][0, :] = 1                      # no padding in row 0
+        if B > 1:
+            b["input_mask"][1, 2:] = 0                 # only two real tokens in row 1
+            b["visual"][1, 2:] = 0; b["acoustic"][1, 2:] = 0
+    ids, vis, aco, mask, seg, _ = tb(b, DEV)
+    with torch.no_grad():
+        l1 = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0].cpu()
+        l0 = o(*tb(b)[:5])[0]
+    err = float((l1 - l0).abs().max())
+    print("B=%d L=%d max|err| %.3e" % (B, L, err))
+    assert err <= 1e-3
+
+
+def test_error_behaviour_matches_the_reference_conventions():
+    m = build(layers=1).eval()
+    ids, vis, aco, mask, seg, _ = tb(weights.synthetic_bert_batch(2, 16, 47, 74, seed=7), DEV)
+    with pytest.raises(ValueError):                                   # bert.py:158-168: neither input_ids nor inputs_embeds
+        m.bert(None, vis, aco)
+    with pytest.raises(ValueError):                                   # modality tensors of the wrong width
+        m(ids, vis[..., :40], aco, token_type_ids=seg, attention_mask=mask)
+    with pytest.raises(NotImplementedError):                          # optional paths the driver never takes
+        m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, head_mask=torch.ones(1, 12))
+    big = tb(weights.synthetic_bert_batch(1, 130, 47, 74, seed=8), DEV)
+    with pytest.raises(Exception) as ei:                              # L > 128: reported by the library, never re-routed
+        m(big[0], big[1], big[2], token_type_ids=big[4], attention_mask=big[3])
+    assert "shape" in str(ei.value).lower() or "magbert" in str(ei.value).lower()
+    # the model is still usable afterwards
+    with torch.no_grad():
+        assert torch.isfinite(m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0]).all()
+
+
 def test_checkpoint_resume_continues_the_run(tmp_path):
     """state_dict (reference key names) + optimizer state (flat Adam moments, step count) + dropout counter saved after 2
     steps and loaded into fresh objects: step 3 equals the uninterrupted run bit for bit (fp32, dropout ON)."""
