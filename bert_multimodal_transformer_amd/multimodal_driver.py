@@ -504,10 +504,10 @@ def train(model, train_dataloader, validation_dataloader, test_data_loader, opti
         print("epoch:{}, train_loss:{}, valid_loss:{}, test_acc:{}".format(epoch_i, train_loss, valid_loss, test_acc))
         valid_losses.append(valid_loss)
         test_accuracies.append(test_acc)
-        print(json.dumps({"train_loss": train_loss, "valid_loss": valid_loss, "test_acc": test_acc, "test_mae": test_mae,
-                          "test_corr": test_corr, "test_f_score": test_f_score, "best_valid_loss": min(valid_losses),
-                          "best_test_acc": max(test_accuracies),
-                          "train_samples_per_sec": len(train_dataloader.dataset) / dt}))
+        print(json.dumps({k: float(v) for k, v in {
+            "train_loss": train_loss, "valid_loss": valid_loss, "test_acc": test_acc, "test_mae": test_mae,
+            "test_corr": test_corr, "test_f_score": test_f_score, "best_valid_loss": min(valid_losses),
+            "best_test_acc": max(test_accuracies), "train_samples_per_sec": len(train_dataloader.dataset) / dt}.items()}))
 
 
 def main(argv=None):

@@ -407,6 +407,19 @@ def test_c5_shape_training_step_fp32():
     _grad_report(m, o, 2e-3)
 
 
+def test_driver_main_end_to_end(capsys):
+    """the bundled driver's main() with its CLI (synthetic data): train / eval / test for two epochs, one JSON record per epoch"""
+    import json
+    from bert_multimodal_transformer_amd import multimodal_driver as D
+    D.main(["--synthetic", "192", "--n_epochs", "2", "--seed", "3", "--train_batch_size", "48"])
+    out = capsys.readouterr().out
+    recs = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert len(recs) == 2
+    for r in recs:
+        assert all(np.isfinite(r[k]) for k in ("train_loss", "valid_loss", "test_mae")) and 0.0 <= r["test_acc"] <= 1.0
+        assert r["train_samples_per_sec"] > 0
+
+
 def test_optimizer_in_backward_overlap_is_close():
     """EXPERIMENTAL AdamW.enable_overlap (per-stage updates on a side stream during the backward).  Same arithmetic as
     optimizer.step(); usually bit-identical to the plain path, but a rare (1-2 % of runs) cross-stream hazard perturbs
