@@ -48,8 +48,6 @@ def parse():
     p.add_argument("--cpu-baseline", type=int, default=1)
     p.add_argument("--cpu-steps", type=int, default=2)
     p.add_argument("--roofline", type=int, default=1)
-    p.add_argument("--overlap-optimizer", type=int, default=0,
-                   help="EXPERIMENTAL: update each stage's parameters during the backward (see DESIGN.md, known issue)")
     p.add_argument("--fused-optimizer", type=int, default=0,
                    help="N=1 only: AdamW for the encoder GEMM weights runs in the weight-gradient GEMM epilogue (same arithmetic; "
                         "measured neutral, so the default keeps the same code path at every N)")
@@ -215,10 +213,8 @@ def main():
     if world > 1:
         dp = DataParallel(model, opt)
         dp.broadcast_parameters(0)
-    if a.overlap_optimizer:
-        opt.enable_overlap(model)
     fused_opt = bool(a.fused_optimizer) and world == 1 and opt.enable_fused_backward(model)
-    piped_opt = bool(a.pipelined_optimizer) and not fused_opt and not a.overlap_optimizer and opt.enable_pipelined_step(model)
+    piped_opt = bool(a.pipelined_optimizer) and not fused_opt and opt.enable_pipelined_step(model)
     model.train()
     nb = 8
     batches = make_batches(nb, B, L, V, A, seed=1234 + rank, layout=a.model)

@@ -97,7 +97,7 @@ class _Core(object):
         self.step = 0
         self.training_last = False
         self._own_stream = None
-        self.stage_hooks = []          # callables hook(stage) run after each backward stage (DataParallel, AdamW overlap)
+        self.stage_hooks = []          # callables hook(stage) run after each backward stage (DataParallel)
         self.pre_backward_hooks = []   # callables run before the first backward stage (AdamW.enable_fused_backward)
         self.optimizer_pending = False  # a pipelined optimizer step may still be writing parameters (join_optimizer())
         self._make_engine(1, 8)

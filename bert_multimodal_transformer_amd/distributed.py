@@ -102,7 +102,7 @@ class DataParallel(object):
         self.reducer = GradReducer(self.core.grads, process_group)
         self.world = self.reducer.world
         self.plan, self.tail = stage_plan(self.core)
-        self.core.stage_hooks.insert(0, self._on_stage)      # before any optimizer-overlap hook
+        self.core.stage_hooks.insert(0, self._on_stage)
         self.sync = True          # set False on gradient-accumulation micro-steps (multimodal_driver.py:383)
         if optimizer is not None:
             if getattr(optimizer, "_fb", None) is not None:
@@ -129,8 +129,7 @@ class DataParallel(object):
         self.reducer.reduce_ranges(self.plan[stage])
         if stage == len(self.plan) - 1:
             self.reducer.reduce_ranges([self.tail])
-            if not getattr(self, "defer_wait", False):
-                self.reducer.wait()
+            self.reducer.wait()
 
     def __getattr__(self, name):
         return getattr(self.model, name)

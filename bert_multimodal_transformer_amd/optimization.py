@@ -29,7 +29,6 @@ class AdamW(torch.optim.Optimizer):
         self._plan = None
         self._t = 0
         self._dp = None              # set by distributed.DataParallel
-        self._ov = None              # overlap state (enable_overlap)
         self._fb = None              # fused-backward state (enable_fused_backward)
         self._pipe = None            # pipelined-step state (enable_pipelined_step)
         self.fused_backward_armed = False
@@ -77,7 +76,7 @@ class AdamW(torch.optim.Optimizer):
         flat_params, load_state_dict() and stream_scope() do.  Returns False when the engine / parameter groups do not fit
         (MAG-XLNet, parameters outside the flat buffer, a decayed no-decay group)."""
         core = model._core
-        if core.kind != "bert" or self._fb is not None or self._ov is not None:
+        if core.kind != "bert" or self._fb is not None:
             return False
         if self._plan is None:
             self._build_plan()
@@ -159,96 +158,11 @@ class AdamW(torch.optim.Optimizer):
                                                group["eps"], group["weight_decay"], self._t + 1,
                                                1 if group["correct_bias"] else 0, self.grad_scale))
 
-    # -- optimizer-in-backward ---------------------------------------------------------------------------
-    def enable_overlap(self, model):
-        """Run the update of each backward stage's parameters as soon as that stage's gradients are final (and, under
-        data parallelism, all-reduced), on a side stream, while the backward of the earlier layers is still running.
-        AdamW is HBM-bound and the backward GEMMs are not, so ~80 % of the optimizer pass disappears from the step.
-        Exactly the same arithmetic as step(); step() then only joins the side stream.  Use with
-        gradient_accumulation_step == 1 (set optimizer.overlap_armed = False on non-final micro-steps).
-
-        EXPERIMENTAL / OFF BY DEFAULT.  Measured gain ~0.35 ms of a 6 ms step, but in ~1-2 % of multi-step runs the
-        trajectory differs from the plain path by the footprint of ONE stale small tensor (bias-sized) in the next
-        forward, although every stream hand-off is event-ordered on paper (tests/test_model_gpu.py::
-        test_optimizer_in_backward_overlap_is_close, scripts/exp/overlap_diag.py).  Root cause not found in round 1;
-        bench.py and the driver use the plain step()."""
-        if self._plan is None:
-            self._build_plan()
-        core = model._core
-        dev = core.device
-        self._ov = dict(core=core, pending=False,
-                        stream=(self._dp.reducer.comm_stream if self._dp is not None and self._dp.reducer.comm_stream is not None
-                                else torch.cuda.Stream(device=dev)))
-        self.overlap_armed = True
-        if self._dp is not None:
-            self._dp.defer_wait = True
-        core.stage_hooks.append(self._on_stage)
-
-    def _flat_update(self, core, a, b, stream):
-        """one fused launch over flat elements [a, b) (must not straddle the decay boundary)"""
-        L = _lib.lib()
-        gi = None
-        for item in self._plan:
-            if item[0] == "flat" and item[2] is core and item[3] <= a < item[4]:
-                gi = item[1]
-                break
-        if gi is None:
-            return
-        group = self.param_groups[gi]
-        b1, b2 = group["betas"]
-        sh = core.shadow if core.dt == _lib.DT_BF16 else None
-        sb = min(max(core.sh_begin, a), b) - a
-        se = min(max(core.sh_end, a), b) - a
-        _lib.check(L.mb_adamw_step(
-            core.params.data_ptr() + 4 * a, core.grads.data_ptr() + 4 * a, core._adam_m.data_ptr() + 4 * a,
-            core._adam_v.data_ptr() + 4 * a, (sh.data_ptr() + 2 * a) if sh is not None else None, b - a,
-            (b - a) if group["weight_decay"] > 0.0 else 0, sb, se, group["lr"], b1, b2, group["eps"],
-            group["weight_decay"], self._t_next, 1 if group["correct_bias"] else 0, self.grad_scale,
-            1 if self.fused_zero_grad else 0, stream))
-
-    def _on_stage(self, stage):
-        ov = self._ov
-        if ov is None or not self.overlap_armed:
-            return
-        core = ov["core"]
-        nstage = core.n_layers + 2
-        if stage == 0:
-            self._t_next = self._t + 1
-            ov["pending"] = True
-        ranges = self._dp.ready_ranges(stage) if self._dp is not None else core.stage_ranges(stage)
-        st = ov["stream"]
-        if self._dp is None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(core.device))
-            st.wait_event(ev)
-        # (under DP the comm stream already waited for this stage and holds its all-reduce: same-stream order)
-        for off, n in ranges:
-            a, b = off, off + n
-            cut = core.n_decay
-            pieces = [(a, b)] if not (a < cut < b) else [(a, cut), (cut, b)]
-            for x, y in pieces:
-                if y > x:
-                    self._flat_update(core, x, y, st.cuda_stream)
-        if stage == nstage - 1:
-            ov["done_stage"] = True
-
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         if self._plan is None:
             self._build_plan()
-        if self._ov is not None and self._ov["pending"]:
-            # every range was already updated stage by stage during the backward: join and advance the step count
-            core = self._ov["core"]
-            torch.cuda.current_stream(core.device).wait_stream(self._ov["stream"])
-            if core._own_stream is not None:
-                # the next pass hops from the (legacy NULL) default stream onto core._own_stream; a NULL stream that holds
-                # nothing but this wait was observed NOT to forward the dependency (ROCm 7.2) -> make the private stream
-                # wait on the optimizer stream directly
-                core._own_stream.wait_stream(self._ov["stream"])
-            self._ov["pending"] = False
-            self._t = self._t_next
-            return loss
         L = _lib.lib()
         self._t += 1
         if self._pipe is not None and self._pipelined_step():
