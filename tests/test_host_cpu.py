@@ -87,6 +87,56 @@ def test_flat_layout_matches_reference_state_dict(V):
     assert cover.min() == 1 and cover.max() == 1
 
 
+def test_xlnet_flat_layout_matches_reference_state_dict():
+    """MAG-XLNet engine layout (host-side, no GPU): reference names / shapes, the driver's decay rule (XLNet's `layer_norm.weight`
+    IS decayed, `r_*_bias` is not), `mask_emb` frozen, q|k|v contiguous, stage ranges tile the trainable part exactly once."""
+    from bert_multimodal_transformer_amd import _lib
+    from oracle import mag_xlnet_ref as X
+    L = _lib.lib()
+    cfg = _lib.XlnetEngineConfig(32000, 768, 12, 12, 3072, 1, 47, 74, 1, 1e-12, 1e-5, 1.0, 0.1, 0.1, 0.5, _lib.DT_BF16, 48, 50)
+    h = C.c_void_p()
+    _lib.check(L.mb_xlnet_create(C.byref(cfg), C.byref(h)))
+    name = C.create_string_buffer(160)
+    off, numel, ndim, decay = C.c_size_t(), C.c_size_t(), C.c_int(), C.c_int()
+    shape = (C.c_int64 * 4)()
+    rows = []
+    for i in range(L.mb_xlnet_num_tensors(h)):
+        _lib.check(L.mb_xlnet_tensor_info(h, i, name, 160, C.byref(off), C.byref(numel), C.byref(ndim), shape, C.byref(decay)))
+        rows.append((name.value.decode(), off.value, numel.value, tuple(shape[k] for k in range(ndim.value)), decay.value))
+    n_params, n_decay = L.mb_xlnet_param_count(h), L.mb_xlnet_decay_count(h)
+    ranges = []
+    for s in range(12 + 2):
+        offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+        k = L.mb_xlnet_stage_grad_ranges(h, s, offs, lens, 8)
+        assert 0 <= k <= 8
+        ranges += [(offs[i], lens[i]) for i in range(k)]
+    L.mb_xlnet_destroy(h)
+    ref = X.MAG_XLNetForSequenceClassification(X.XLNetConfigLite(), X.MultimodalConfig(1.0, 0.5), 47, 74)
+    assert {r[0]: r[3] for r in rows} == {n: tuple(p.shape) for n, p in ref.named_parameters()}
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    byname = {r[0]: r for r in rows}
+    for nme, o, n, shp, d in rows:
+        assert o % 64 == 0
+        if nme == "transformer.mask_emb":
+            assert d == 2                                     # never receives a gradient (xlnet.py:29): frozen slot
+            continue
+        assert bool(d) == (not any(nd in nme for nd in no_decay)), nme
+        assert (o < n_decay) == bool(d), nme
+    assert byname["transformer.layer.3.rel_attn.layer_norm.weight"][4] == 1 and byname["transformer.layer.3.rel_attn.r_r_bias"][4] == 0
+    for l in (0, 11):
+        q, k, v = (byname["transformer.layer.%d.rel_attn.%s" % (l, t)] for t in ("q", "k", "v"))
+        assert k[1] == q[1] + q[2] and v[1] == k[1] + k[2]
+    spans = sorted((r[1], r[1] + r[2]) for r in rows)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] <= n_params
+    cover = np.zeros(n_params, np.int8)
+    for o, n in ranges:
+        cover[o:o + n] += 1
+    for nme, o, n, shp, d in rows:
+        if d != 2:
+            assert cover[o:o + n].min() == 1 and cover[o:o + n].max() == 1, nme     # every trainable tensor reduced exactly once
+    assert cover.max() == 1
+
+
 def test_feature_conversion_matches_reference(golden):
     g = golden["g7g9_features_metrics"]
     from oracle import weights
