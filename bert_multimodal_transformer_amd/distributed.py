@@ -70,6 +70,14 @@ class GradReducer(object):
             for off, n in ranges:
                 dist.all_reduce(self.g[off: off + n], op=dist.ReduceOp.SUM, group=self.pg)
 
+    def mark(self):
+        """an event behind every piece enqueued so far (None on the host path, where reduce_ranges is synchronous)"""
+        if not (self.cuda and self.active):
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.comm_stream)
+        return ev
+
     def wait(self):
         """make the compute stream wait for every outstanding piece (call before optimizer.step())"""
         if self.cuda and self.active:
@@ -104,6 +112,9 @@ class DataParallel(object):
         self.plan, self.tail = stage_plan(self.core)
         self.core.stage_hooks.insert(0, self._on_stage)
         self.sync = True          # set False on gradient-accumulation micro-steps (multimodal_driver.py:383)
+        self.optimizer = optimizer
+        self.late_ranges = []
+        self.split_last = os.environ.get("MB_DP_SPLIT_LAST", "1") != "0"
         if optimizer is not None:
             if getattr(optimizer, "_fb", None) is not None:
                 raise RuntimeError("AdamW.enable_fused_backward() updates weights from local gradients: not usable with DataParallel")
@@ -126,10 +137,25 @@ class DataParallel(object):
     def _on_stage(self, stage):
         if not self.sync:
             return
+        if stage < len(self.plan) - 1:
+            self.reducer.reduce_ranges(self.plan[stage])
+            return
+        # last stage: its pieces (embeddings + MAG: 94 MB, and the small tail) are produced last and would be fully exposed.
+        # The compute stream only waits for everything BEFORE them; AdamW.step() updates the already-reduced ranges under this
+        # last all-reduce and calls finish() before it touches the late ranges (split_last = False: plain full wait here).
+        early = self.reducer.mark()
         self.reducer.reduce_ranges(self.plan[stage])
-        if stage == len(self.plan) - 1:
-            self.reducer.reduce_ranges([self.tail])
+        self.reducer.reduce_ranges([self.tail])
+        if self.split_last and early is not None and self.optimizer is not None:
+            torch.cuda.current_stream(self.core.grads.device).wait_event(early)
+            self.late_ranges = [r for r in list(self.plan[stage]) + [self.tail] if r[1] > 0]
+        else:
             self.reducer.wait()
+
+    def finish(self):
+        """full wait for the gradient exchange (AdamW.step() calls it before the late ranges; harmless to call twice)"""
+        self.reducer.wait()
+        self.late_ranges = []
 
     def __getattr__(self, name):
         return getattr(self.model, name)

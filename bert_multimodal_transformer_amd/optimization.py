@@ -165,23 +165,49 @@ class AdamW(torch.optim.Optimizer):
             self._build_plan()
         L = _lib.lib()
         self._t += 1
+        dp = self._dp
+        late = []
+        if dp is not None and getattr(dp, "late_ranges", None):
+            # data parallel: the all-reduce of the LAST backward stage (word embeddings: 94 MB, produced last) is still on the
+            # wire.  Everything else is already reduced (the stage hook made this stream wait for the "early" marker only), so
+            # the update of those ranges (~78 % of the parameters) runs under that last all-reduce; the late ranges follow after
+            # the full wait.  Plain path only: the pipelined / fused variants take the full wait first.
+            late = sorted(dp.late_ranges)
+            if self._pipe is not None or self._fb is not None:
+                dp.finish()
+                late = []
         if self._pipe is not None and self._pipelined_step():
             return loss
+
+        def launch(core, group, x, y):
+            if y <= x:
+                return
+            b1, b2 = group["betas"]
+            sh = core.shadow if core.dt == _lib.DT_BF16 else None
+            sb = min(max(core.sh_begin, x), y) - x
+            se = min(max(core.sh_end, x), y) - x
+            _lib.check(L.mb_adamw_step(
+                core.params.data_ptr() + 4 * x, core.grads.data_ptr() + 4 * x, core._adam_m.data_ptr() + 4 * x,
+                core._adam_v.data_ptr() + 4 * x, (sh.data_ptr() + 2 * x) if sh is not None else None, y - x,
+                (y - x) if group["weight_decay"] > 0.0 else 0, sb, se, group["lr"], b1, b2, group["eps"],
+                group["weight_decay"], self._t, 1 if group["correct_bias"] else 0, self.grad_scale,
+                1 if self.fused_zero_grad else 0, core.stream()))
+
+        deferred = []                      # (core, group, x, y) pieces that must wait for the last all-reduce
         for item in self._plan:
             group = self.param_groups[item[1]]
             b1, b2 = group["betas"]
             if item[0] == "flat":
                 _, _, core, a, b = item
-                st = core.stream()
-                sh = core.shadow if core.dt == _lib.DT_BF16 else None
-                sb = min(max(core.sh_begin, a), b) - a
-                se = min(max(core.sh_end, a), b) - a
-                _lib.check(L.mb_adamw_step(
-                    core.params.data_ptr() + 4 * a, core.grads.data_ptr() + 4 * a, core._adam_m.data_ptr() + 4 * a,
-                    core._adam_v.data_ptr() + 4 * a, (sh.data_ptr() + 2 * a) if sh is not None else None, b - a,
-                    (b - a) if group["weight_decay"] > 0.0 else 0, sb, se, group["lr"], b1, b2, group["eps"],
-                    group["weight_decay"], self._t, 1 if group["correct_bias"] else 0, self.grad_scale,
-                    1 if self.fused_zero_grad else 0, st))
+                cur = a
+                for lo, n in late:         # split [a, b) around the late ranges (sorted, disjoint, tensor-aligned)
+                    hi = lo + n
+                    if hi <= cur or lo >= b or core is not dp.core:
+                        continue
+                    launch(core, group, cur, max(cur, lo))
+                    deferred.append((core, group, max(cur, lo), min(b, hi)))
+                    cur = min(b, hi)
+                launch(core, group, cur, b)
             else:
                 p = item[2]
                 if p.grad is None:
@@ -199,6 +225,10 @@ class AdamW(torch.optim.Optimizer):
                                            0, 0, group["lr"], b1, b2, group["eps"], group["weight_decay"], self._t,
                                            1 if group["correct_bias"] else 0, self.grad_scale, 0,
                                            torch.cuda.current_stream(p.device).cuda_stream))
+        if late:
+            dp.finish()                    # this stream now waits for the last all-reduce
+            for core, group, x, y in deferred:
+                launch(core, group, x, y)
         return loss
 
     # -- checkpoint / resume ---------------------------------------------------------
