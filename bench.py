@@ -298,7 +298,8 @@ def main():
                                       % (a.dataset.upper(), V, A, B, L, "+RCCL all-reduce" if world > 1 else "",
                                          " (encoder weights updated in the wgrad epilogue)" if fused_opt else
                                          (" (pipelined under the next forward)" if piped_opt else "")),
-                          "global_batch": world * B, "seq_len": L, "parallelism": "dp%d" % world},
+                          "global_batch": world * B, "seq_len": L, "parallelism": "dp%d" % world,
+                          **({"grad_wire_dtype": "bf16" if dp.reducer.wire_dtype == torch.bfloat16 else "fp32"} if dp is not None else {})},
                "mean_loss": round(loss, 4), "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
                "value_with_h2d": round(world * B / dt_h2d, 2)}
         if gflop:

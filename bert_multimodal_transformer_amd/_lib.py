@@ -42,6 +42,8 @@ PROTOTYPES = {
     "mb_make_dropkey": (None, [_u64, _u64, _u32, _f, _dk]),
     "mb_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _dk, _i, _i, _vp]),
     "mb_gemm_grouped_wgrad": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mb_narrow": (_i, [_i, _vp, _vp, _sz, _vp]),
+    "mb_widen": (_i, [_i, _vp, _vp, _sz, _vp]),
     "mb_layernorm_forward": (_i, [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _dk, _vp]),
     "mb_layernorm_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _dk, _dk, _vp]),
     "mb_embed_forward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _dk, _vp]),

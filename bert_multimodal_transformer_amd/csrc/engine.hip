@@ -198,6 +198,16 @@ int mb_gemm_grouped_wgrad(int dtype, int count, const int* M, const int* N, int 
     return gemm_grouped_tn_launch(dtype, g, count, tile, (hipStream_t)stream);
 }
 
+int mb_narrow(int dtype, const float* src, void* dst, size_t n, void* stream) {
+    if (!src || !dst) return MB_ERR_ARG;
+    if (n % 4) return MB_ERR_SHAPE;
+    return convert(dtype, src, dst, n, (hipStream_t)stream);
+}
+int mb_widen(int dtype, const void* src, float* dst, size_t n, void* stream) {
+    if (!src || !dst) return MB_ERR_ARG;
+    return widen(dtype, src, dst, n, (hipStream_t)stream);
+}
+
 int mb_layernorm_forward(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
                          float* rstd, int rows, int H, const mb_dropkey* drop, void* stream) {
     return ln_forward(dtype, x, gamma, beta, eps, y, mean, rstd, rows, H, dk(drop), (hipStream_t)stream);

@@ -98,6 +98,7 @@ int colsum(int dtype, const void* x, int ldx, float* out, int rows, int cols, hi
 int pack_pad(int dtype, const float* src, int cols, void* dst, int cols_pad, int rows, hipStream_t st);
 // fp32 -> T contiguous conversion (n elements)
 int convert(int dtype, const float* src, void* dst, size_t n, hipStream_t st);
+int widen(int dtype, const void* src, float* dst, size_t n, hipStream_t st);       // dst fp32 <- src (dtype), n % 4 == 0
 
 // ------------------------------------------------------------------------------------------ MAG (mag.hip)
 struct MagDims { int T, H, V, A, Vp, Ap; };

@@ -327,6 +327,12 @@ __global__ void convert_kernel(const float* __restrict__ src, T* __restrict__ ds
         store4(dst + i * 4, *(const f32x4*)(src + i * 4));
 }
 
+template <class T>
+__global__ void widen_kernel(const T* __restrict__ src, float* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        *(f32x4*)(dst + i * 4) = load4(src + i * 4);
+}
+
 // ------------------------------------------------------------------------------------------ host launchers
 #define MB_DISPATCH_T(dtype, ...)                                  \
     if ((dtype) == DT_BF16) { typedef bf16 T; __VA_ARGS__ }        \
@@ -447,6 +453,16 @@ int convert(int dtype, const float* src, void* dst, size_t n, hipStream_t st) {
     unsigned grid = (unsigned)((n4 + 255) / 256);
     if (grid > 4096) grid = 4096;
     MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((convert_kernel<T>), dim3(grid), dim3(256), 0, st, src, (T*)dst, n4); })
+    return (int)hipGetLastError();
+}
+
+int widen(int dtype, const void* src, float* dst, size_t n, hipStream_t st) {
+    if (n == 0) return MB_OK;
+    if (n % 4) return MB_ERR_SHAPE;
+    const size_t n4 = n / 4;
+    unsigned grid = (unsigned)((n4 + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((widen_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)src, dst, n4); })
     return (int)hipGetLastError();
 }
 

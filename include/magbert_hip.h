@@ -51,6 +51,11 @@ int mb_gemm(int dtype, int layout, int epilogue, int M, int N, int K, const void
 int mb_gemm_grouped_wgrad(int dtype, int count, const int* M, const int* N, int K, const void* const* dY, const int* ldy,
                           const void* const* X, const int* ldx, float* const* dW, const int* ldw, int tile, void* stream);
 
+/* dst[i] = (dtype) src[i] and back, n % 4 == 0 -- the gradient wire format of the data-parallel exchange in bf16 perf mode
+ * (distributed.GradReducer: fp32 flat gradients -> bf16 staging -> RCCL all-reduce -> fp32).  New relative to the reference. */
+int mb_narrow(int dtype, const float* src, void* dst, size_t n, void* stream);
+int mb_widen(int dtype, const void* src, float* dst, size_t n, void* stream);
+
 /* LayerNorm (+ dropout on the output) forward / backward -- torch.nn.LayerNorm under BertSelfOutput/BertOutput. */
 int mb_layernorm_forward(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,
                          float* mean, float* rstd, int rows, int H, const mb_dropkey* drop, void* stream);
