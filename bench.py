@@ -176,7 +176,10 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the product path)")
     torch.cuda.set_device(local if torch.cuda.device_count() > local else 0)
     import torch.distributed as dist
-    if world > 1:
+    force_dp = world == 1 and os.environ.get("MB_DP_FORCE") == "1"     # 1-rank RCCL group: the whole DP code path on one GPU
+    if force_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("MB_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
                                 **({"device_id": torch.device("cuda", local)} if os.environ.get("MB_DIST_BACKEND", "nccl") == "nccl" else {}))
@@ -210,7 +213,7 @@ def main():
     total_steps = a.steps + a.warmup
     sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=0.1 * 1040, num_training_steps=1040)
     dp = None
-    if world > 1:
+    if world > 1 or force_dp:
         dp = DataParallel(model, opt)
         dp.broadcast_parameters(0)
     fused_opt = bool(a.fused_optimizer) and world == 1 and opt.enable_fused_backward(model)
@@ -344,7 +347,7 @@ def main():
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
 
