@@ -174,7 +174,7 @@ class _SeqReplay(torch.nn.Module):
         return x * mlt
 
 
-@pytest.mark.parametrize("cdt,tol_logit,tol_grad", [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 5e-2, 8e-2)])
+@pytest.mark.parametrize("cdt,tol_logit,tol_grad", [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 5e-2, 1e-1)])   # bf16 gradients: relative Frobenius error, dominated by relu / clamp flips in MAG (measured 7.7e-2 on W_hv)
 def test_train_mode_dropout_mask_replay(cdt, tol_logit, tol_grad):
     """Dropout ON at every site (0.1 hidden / attention / pos_emb / summary, MAG 0.5): device masks regenerated on the
     host and replayed inside the oracle (which works in the reference's [L, B, .] layout) -> exact train-mode parity."""
