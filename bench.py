@@ -5,14 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one full optimizer step of /root/reference/multimodal_driver.py:354-388 on one minibatch per GPU:
-H2D of the six batch tensors -> forward (embeddings, MAG, 12 encoder layers, pooler, classifier) -> MSE -> backward ->
-(N>1: RCCL all-reduce of the flat gradients, overlapped with the backward) -> HF-AdamW -> linear-warmup schedule ->
-zero_grad.  Workload = BASELINE.json configs[1]: bert-base-uncased MAG-BERT, MOSI dims (V=47, A=74), B=48/GPU, L=50,
+forward (embeddings, MAG, 12 encoder layers, pooler, classifier) -> MSE -> backward -> (N>1: RCCL all-reduce of the flat
+gradients, overlapped with the backward) -> HF-AdamW -> linear-warmup schedule -> zero_grad, with the six batch tensors
+already resident in HBM (`value`); the reference's per-step H2D (multimodal_driver.py:359) is timed separately
+(`value_with_h2d`).  Workload = BASELINE.json configs[1]: bert-base-uncased MAG-BERT, MOSI dims (V=47, A=74), B=48/GPU, L=50,
 bf16 MFMA with fp32 master weights, dropout ON (0.1/0.1/MAG 0.5), synthetic batches in prepare_bert_input's layout,
 random-init weights (no network).  Weak scaling: per-GPU batch fixed, global batch = 48*N.
 
 Prints ONE JSON line (rank 0) with the contract's keys plus
-  roofline     : the dominant kernel (MFMA GEMM) timed with HIP events on the launch stream
+  roofline     : the dominant kernel (the per-layer grouped weight-gradient GEMM) timed inside the step with HIP events on the
+                 stream it runs on, its HBM-side traffic from the committed PMC pass (profiles/r01_pmc_step.md)
   cpu_baseline : the CPU oracle (oracle/mag_bert_ref.py, kind "port") timed on this box's host cores, same step
 """
 import argparse
