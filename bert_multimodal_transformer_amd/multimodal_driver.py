@@ -321,8 +321,10 @@ def set_up_data_loader():
         train_dataloader = DataLoader(train_dataset, batch_sampler=sampler)
     else:
         train_dataloader = DataLoader(train_dataset, batch_size=args.train_batch_size, shuffle=True)
-    dev_dataloader = DataLoader(dev_dataset, batch_size=args.dev_batch_size, shuffle=True)
-    test_dataloader = DataLoader(test_dataset, batch_size=args.test_batch_size, shuffle=True)
+    # under DP the dev / test batches are dealt round-robin to the ranks (eval_epoch / test_epoch), so every rank must see the
+    # same batch order: no shuffle there (the metrics do not depend on the order)
+    dev_dataloader = DataLoader(dev_dataset, batch_size=args.dev_batch_size, shuffle=world == 1)
+    test_dataloader = DataLoader(test_dataset, batch_size=args.test_batch_size, shuffle=world == 1)
     return train_dataloader, dev_dataloader, test_dataloader, num_train_optimization_steps
 
 
@@ -439,8 +441,11 @@ def eval_epoch(model: nn.Module, dev_dataloader: DataLoader, optimizer):
     model.eval()
     dev_loss = torch.zeros((), device=_device())
     nb_dev_steps = 0
+    rank, world = _dist()
     with torch.no_grad(), model.stream_scope():
         for step, batch in enumerate(dev_dataloader):
+            if step % world != rank:          # data parallel: each rank evaluates its share of the batches
+                continue
             input_ids, visual, acoustic, input_mask, segment_ids, label_ids = _unpack(batch)
             outputs = model(input_ids, visual, acoustic, token_type_ids=segment_ids, attention_mask=input_mask, labels=None)
             logits = outputs[0]
@@ -449,6 +454,11 @@ def eval_epoch(model: nn.Module, dev_dataloader: DataLoader, optimizer):
                 loss = loss / args.gradient_accumulation_step
             dev_loss += loss
             nb_dev_steps += 1
+    if world > 1:
+        import torch.distributed as dist
+        acc = torch.stack([dev_loss.float(), torch.tensor(float(nb_dev_steps), device=dev_loss.device)])
+        dist.all_reduce(acc)                  # sum of the batch losses, number of batches
+        return float(acc[0].item()) / max(1.0, float(acc[1].item()))
     return float(dev_loss.item()) / max(1, nb_dev_steps)
 
 
@@ -456,14 +466,23 @@ def test_epoch(model: nn.Module, test_dataloader: DataLoader):
     """multimodal_driver.py:424-459."""
     model.eval()
     preds, labels = [], []
+    rank, world = _dist()
     with torch.no_grad():
-        for batch in test_dataloader:
+        for step, batch in enumerate(test_dataloader):
+            if step % world != rank:
+                continue
             input_ids, visual, acoustic, input_mask, segment_ids, label_ids = _unpack(batch)
             outputs = model(input_ids, visual, acoustic, token_type_ids=segment_ids, attention_mask=input_mask, labels=None)
             preds.append(outputs[0].detach().view(-1))
             labels.append(label_ids.detach().view(-1))
-    preds = torch.cat(preds).cpu().numpy()
-    labels = torch.cat(labels).cpu().numpy()
+    preds = torch.cat(preds).cpu().numpy() if preds else np.zeros((0,), np.float32)
+    labels = torch.cat(labels).cpu().numpy() if labels else np.zeros((0,), np.float32)
+    if world > 1:                             # every rank gets every prediction (order = by rank; the metrics are order-free)
+        import torch.distributed as dist
+        parts = [None] * world
+        dist.all_gather_object(parts, (preds, labels))
+        preds = np.concatenate([p for p, _ in parts])
+        labels = np.concatenate([l for _, l in parts])
     return preds, labels
 
 

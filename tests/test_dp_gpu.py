@@ -84,9 +84,12 @@ l0 = D.train_epoch(model, tr, opt, sch)
 for _ in range(4):
     l1 = D.train_epoch(model, tr, opt, sch)
 vl = D.eval_epoch(model, dev, opt)
+acc, mae, corr, f1 = D.test_score_model(model, te)
+npred = len(D.test_epoch(model, te)[0])
 torch.cuda.synchronize()
 rank = int(os.environ["RANK"])
-torch.save(dict(p=model.flat_params.cpu(), l0=l0, l1=l1, vl=vl, steps=len(tr), nsteps=nsteps), os.environ["OUT"] + ".%d" % rank)
+torch.save(dict(p=model.flat_params.cpu(), l0=l0, l1=l1, vl=vl, steps=len(tr), nsteps=nsteps, acc=float(acc), mae=float(mae), npred=npred,
+                ntest=len(te.dataset)), os.environ["OUT"] + ".%d" % rank)
 import torch.distributed as dist
 dist.barrier(); dist.destroy_process_group()
 print("OK", rank)
@@ -118,6 +121,9 @@ def test_driver_under_two_ranks(tmp_path, model, accum):
     print("losses rank0 %.4f -> %.4f, rank1 %.4f -> %.4f" % (a["l0"], a["l1"], b["l0"], b["l1"]))
     for d in (a, b):
         assert d["l0"] == d["l0"] and d["l1"] < d["l0"] and d["vl"] == d["vl"], (d["l0"], d["l1"], d["vl"])
+    # sharded evaluation: both ranks report the same dev loss and the same test metrics, computed over EVERY test sample
+    assert a["vl"] == b["vl"] and a["acc"] == b["acc"] and a["mae"] == b["mae"]
+    assert a["npred"] == b["npred"] == a["ntest"]
 
 
 _RCCL_WORKER = r'''
