@@ -156,11 +156,8 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
             for (int jt = 0; jt < NT; ++jt) {
                 const int j = jt * 16 + (lane >> 4) * 4;
                 f32x4 p = ac[jt] * inv;
-                if (psave != nullptr && i < L) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (j + r < L) psave[(size_t)rowidx + j + r] = from_f<T>(p[r]);
-                }
+                // saved probabilities: rows padded to LP columns -> one aligned 4-element store (columns >= L hold exact zeros)
+                if (psave != nullptr && i < L) store4(psave + ((size_t)blockIdx.x * LP + i) * LP + j, p);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p[r] *= drop_mult(drop, rowidx + j + r);
                 store4((T*)(Ps + (lane & 15) * SPIT) + j, p);
@@ -275,16 +272,19 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
             const uint32_t rowidx = ((uint32_t)blockIdx.x * L + (uint32_t)i) * L;
             f32x4 pv[NT];
             float dsum = 0.f;
+            const size_t prow = ((size_t)blockIdx.x * LP + (i < LP ? i : 0)) * LP;      // storage row (padded to LP columns)
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt)
+            for (int jt = 0; jt < NT; ++jt) {
+                const f32x4 pq = i < L ? load4(psave + prow + jt * 16 + (lane >> 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = jt * 16 + (lane >> 4) * 4 + r;
                     const bool ok = i < L && j < L;
-                    pv[jt][r] = ok ? to_f(psave[(size_t)rowidx + j]) : 0.f;
+                    pv[jt][r] = ok ? pq[r] : 0.f;
                     dp[jt][r] *= ok ? drop_mult(drop, rowidx + j) : 0.f;
                     dsum += dp[jt][r] * pv[jt][r];
                 }
+            }
             const float D = quad_sum(dsum);
             const int si = segv[i < LP ? i : 0];
 #pragma unroll
@@ -295,11 +295,11 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
                 for (int r = 0; r < 4; ++r) {
                     const int j = j0 + r;
                     if (i < L && j < L) {
-                        gsave[(size_t)rowidx + j] = from_f<T>(g[r]);
                         if (si == segv[j]) g0 += g[r]; else g1 += g[r];
                         *(T*)(Ss + (lane & 15) * GPIT + (L - i + j) * (int)sizeof(T)) = from_f<T>(g[r]);
                     } else g[r] = 0.f;
                 }
+                if (i < L) store4(gsave + prow + j0, g);          // same padded layout as psave
                 store4((T*)(Gs + (lane & 15) * SPIT) + j0, g);
             }
             g0 = quad_sum(g0);
@@ -363,7 +363,8 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv_kernel(const T* __rest
     for (int t = threadIdx.x; t < 128; t += NW * 64) bia[t] = t < 64 ? xp.r_w_bias[h * 64 + t] : xp.r_r_bias[h * 64 + t - 64];
     __syncthreads();
     char* St = strips + wave * 16 * SPIT;
-    const size_t pbase = (size_t)blockIdx.x * L * L;
+    const size_t pbase = (size_t)blockIdx.x * LP * LP;       // psave / gsave rows are padded to LP columns
+    const size_t dbase = (size_t)blockIdx.x * L * L;         // dropout element index space (unpadded)
     T* dq_base = dqkv + (size_t)b * L * ld + h * 64;
 
     // ---- key strips: dv, dk
@@ -382,8 +383,8 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv_kernel(const T* __rest
                 for (int r = 0; r < 4; ++r) {
                     const int i = i0 + r;
                     const bool ok = i < L && j < L;
-                    const size_t idx = pbase + (size_t)i * L + j;
-                    pd[r] = ok ? to_f(psave[idx]) * drop_mult(drop, (uint32_t)idx) : 0.f;
+                    const size_t idx = pbase + (size_t)i * LP + j;
+                    pd[r] = ok ? to_f(psave[idx]) * drop_mult(drop, (uint32_t)(dbase + (size_t)i * L + j)) : 0.f;
                     gt[it][r] = ok ? to_f(gsave[idx]) : 0.f;
                     csum += gt[it][r];
                 }
@@ -438,7 +439,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv_kernel(const T* __rest
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = i0 + r, j = p - L + i;
-                    g[r] = (i < L && j >= 0 && j < L) ? to_f(gsave[pbase + (size_t)i * L + j]) : 0.f;
+                    g[r] = (i < L && j >= 0 && j < L) ? to_f(gsave[pbase + (size_t)i * LP + j]) : 0.f;
                     csum += g[r];
                 }
                 store4((T*)(St + (lane & 15) * SPIT) + i0, g);

@@ -123,7 +123,7 @@ static void xl_build_layout(mb_xlnet_engine* e) {
     const size_t es = esize(c.dtype);
     const size_t T = align_up((size_t)c.max_batch * c.max_seq, 64);
     const size_t R = align_up((size_t)c.max_batch * 2 * c.max_seq, 64);
-    const size_t PP = (size_t)c.max_batch * nh * c.max_seq * c.max_seq;
+    const size_t PP = (size_t)c.max_batch * nh * 64 * 64;      // saved probabilities / score gradients: [B * heads][LP][LP], LP <= 64
     Carver w;
     e->mw.init(c.dtype, (int)T, (int)H, (int)V, (int)A);
     e->ws_mag = w.take(e->mw.bytes);
