@@ -34,6 +34,7 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md); f
 PEAK_F32_TFLOPS = 157.3
 # algorithmic FLOPs: forward 8.7234 GFLOP/sample at L=50, V=47; training = 3x
 TRAIN_GFLOP_PER_SAMPLE_L50 = 26.170
+TRAIN_GFLOP_PER_SAMPLE_C5 = 68.080      # MOSEI V=35, L=128
 
 
 def parse():
@@ -48,14 +49,11 @@ def parse():
     p.add_argument("--model", choices=["bert", "xlnet"], default="bert",
                    help="bert = the headline workload (BASELINE.json configs[1]); xlnet = configs[3] (MAG-XLNet), informational")
     p.add_argument("--cpu-baseline", type=int, default=1)
-    p.add_argument("--cpu-steps", type=int, default=2)
+    p.add_argument("--cpu-steps", type=int, default=5)
     p.add_argument("--roofline", type=int, default=1)
-    p.add_argument("--fused-optimizer", type=int, default=0,
-                   help="N=1 only: AdamW for the encoder GEMM weights runs in the weight-gradient GEMM epilogue (same arithmetic; "
-                        "measured neutral, so the default keeps the same code path at every N)")
-    p.add_argument("--pipelined-optimizer", type=int, default=0,
-                   help="AdamW runs on the engine's optimizer stream, chunk by chunk, under the next forward (same arithmetic; "
-                        "measured neutral: the forward GEMMs are memory-latency-bound and slow down under the HBM-saturating update)")
+    p.add_argument("--graph", type=int, default=1,
+                   help="1: each optimizer step is the step prologue + one replayed hipGraph where the engine supports it "
+                        "(MAG-BERT, single process); 0: every kernel launched from the host")
     p.add_argument("--roofline-only", type=int, default=0, help="skip the training loop, print the GEMM table only")
     return p.parse_args()
 
@@ -169,6 +167,80 @@ def gemm_roofline(dtype_name, T, reps=30):
     return res
 
 
+def hbm_roofline(dtype_name, B, L, V, A, reps=20):
+    """Achieved HBM GB/s of the row kernels (north_star: "rocprof reports achieved HBM GB/s on the MAG/LayerNorm kernels"):
+    each kernel is launched through the C ABI on synthetic operands and timed with HIP events on the launch stream,
+    back-to-back with rotating buffers larger than the L2s.  Bytes = algorithmic bytes."""
+    import ctypes as C
+    from bert_multimodal_transformer_amd import _lib
+    Lb = _lib.lib()
+    dt = _lib.DT_BF16 if dtype_name == "bf16" else _lib.DT_F32
+    tdt = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    es = 2 if dtype_name == "bf16" else 4
+    dev = torch.device("cuda", torch.cuda.current_device())
+    H, T = 768, B * L
+    st = torch.cuda.current_stream()
+    NB = 8                                   # rotate over 8 operand sets so the inputs are not L2-resident
+    xs = [(torch.randn(T, H, device=dev) * 0.5).to(tdt) for _ in range(NB)]
+    ys = [torch.empty(T, H, dtype=tdt, device=dev) for _ in range(NB)]
+    zs = [torch.empty(T, H, dtype=tdt, device=dev) for _ in range(NB)]
+    gamma, beta = torch.ones(H, device=dev), torch.zeros(H, device=dev)
+    mean, rstd = torch.zeros(T, device=dev), torch.ones(T, device=dev)
+    dg, db, dbias = torch.zeros(H, device=dev), torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    key = _lib.make_dropkey(1, 1, 17, 0.1)
+    nokey = _lib.no_drop()
+    out = []
+
+    def timed(name, nbytes, fn):
+        for i in range(3):
+            fn(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for i in range(reps):
+            fn(i)
+        e1.record(st)
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        out.append({"kernel": name, "bytes": int(nbytes), "avg_us": round(us, 2), "tb_per_s": round(nbytes / us * 1e-6, 3),
+                    "frac_of_8tbs": round(nbytes / us * 1e-6 / 8.0, 4)})
+
+    timed("ln_fwd (LayerNorm, BertSelfOutput/BertOutput)", 2 * T * H * es, lambda i: _lib.check(Lb.mb_layernorm_forward(
+        dt, _lib.ptr(xs[i % NB]), _lib.ptr(gamma), _lib.ptr(beta), 1e-12, _lib.ptr(ys[i % NB]), _lib.ptr(mean), _lib.ptr(rstd),
+        T, H, C.byref(nokey), st.cuda_stream)))
+    timed("ln_bwd (+dropout backward, dgamma/dbeta/dbias)", 4 * T * H * es, lambda i: _lib.check(Lb.mb_layernorm_backward(
+        dt, _lib.ptr(xs[i % NB]), _lib.ptr(ys[i % NB]), _lib.ptr(gamma), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(zs[i % NB]),
+        _lib.ptr(ys[(i + 1) % NB]), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dbias), T, H, C.byref(nokey), C.byref(key), st.cuda_stream)))
+    # MAG: the whole operator (3 GEMMs + gate kernel) and AdamW over a 100 M-parameter flat buffer
+    from bert_multimodal_transformer_amd import MAG
+    n = 110_853_184
+    p_, g_, m_, v_ = (torch.zeros(n, device=dev) for _ in range(4))
+    sh = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    timed("adamw (p,g,m,v read; p,m,v,g=0 + bf16 shadow written)", n * 34, lambda i: _lib.check(Lb.mb_adamw_step(
+        p_.data_ptr(), g_.data_ptr(), m_.data_ptr(), v_.data_ptr(), sh.data_ptr(), n, n, 0, n, 1e-5, 0.9, 0.999, 1e-6, 0.01, i + 1, 1,
+        1.0, 1, st.cuda_stream)))
+    del p_, g_, m_, v_, sh
+    return out
+
+
+def cpu_info():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    phys = None
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False)
+    except Exception:
+        pass
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "physical_cores": phys}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,6 +271,7 @@ def main():
     from bert_multimodal_transformer_amd.distributed import DataParallel
     from bert_multimodal_transformer_amd.global_configs import DATASET_DIMS
     from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
+    from bert_multimodal_transformer_amd.prefetch import DevicePrefetcher
 
     V, A = DATASET_DIMS[a.dataset]["visual_dim"], DATASET_DIMS[a.dataset]["acoustic_dim"]
     B, L = a.batch, a.seq
@@ -218,25 +291,28 @@ def main():
     if world > 1 or force_dp:
         dp = DataParallel(model, opt)
         dp.broadcast_parameters(0)
-    fused_opt = bool(a.fused_optimizer) and world == 1 and opt.enable_fused_backward(model)
-    piped_opt = bool(a.pipelined_optimizer) and not fused_opt and opt.enable_pipelined_step(model)
     model.train()
     nb = 8
-    batches = make_batches(nb, B, L, V, A, seed=1234 + rank, layout=a.model)
+    batches = make_batches(nb, B, L, V, A, seed=1234 + rank, layout=a.model)      # pinned host tensors, as a DataLoader yields them
     dev = torch.device("cuda", torch.cuda.current_device())
+    use_graph = None if a.graph else False
+    graph_on = bool(a.graph) and model._core.graph_blocker() is None and opt.flat_step_args(model._core) is not None
 
-    # `value` is quoted with the inputs already resident in HBM; the H2D-inclusive rate (the reference moves every batch
-    # inside the loop, multimodal_driver.py:359) is measured by a second, shorter loop and reported as value_with_h2d
-    resident = [tuple(t.to(dev) for t in b) for b in batches]
+    def host_batches(n, start=0):
+        for i in range(n):
+            yield batches[(start + i) % nb]
 
-    def step(i, h2d=False):
-        if h2d:
-            batch = tuple(t.to(dev, non_blocking=True) for t in batches[i % nb])
-        else:
-            batch = resident[i % nb]
-        ids, vis, aco, mask, seg, lab = batch
-        model.training_step(ids, vis, aco, mask, seg, lab)
-        opt.step(); sch.step(); opt.zero_grad()
+    def run(n, start, events=None):
+        """n optimizer steps exactly as train_epoch runs them: the batch comes from the HOST (one asynchronous H2D per step on
+        the copy stream, multimodal_driver.py:359), forward + MSE + backward (+ all-reduce) + AdamW + schedule + zero_grad."""
+        for batch in DevicePrefetcher(host_batches(n, start), dev):
+            ids, vis, aco, mask, seg, lab = batch
+            model.train_step(ids, vis, aco, mask, seg, lab, optimizer=opt, graph=use_graph)
+            sch.step()
+            if events is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream())
+                events.append(ev)
 
     def fence():
         torch.cuda.synchronize()
@@ -246,67 +322,87 @@ def main():
 
     scope = model.stream_scope()          # the whole loop on one private HIP stream (see _MagBertBase.stream_scope)
     scope.__enter__()
-    for i in range(a.warmup):
-        step(i)
+    run(a.warmup, 0)
     fence()
+    evs = [torch.cuda.Event(enable_timing=True)]
+    evs[0].record(torch.cuda.current_stream())
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i)
+    run(a.steps, a.warmup, evs)
     t_host = time.perf_counter() - t0          # host done enqueueing; the GPU may still be running
     fence()
     dt = time.perf_counter() - t0
-    n2 = max(2, a.steps // 4)
+    per_step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1))
+    # secondary figure: the same steps with the batch tensors already resident in HBM (no per-step H2D at all)
+    resident = [tuple(t.to(dev) for t in b) for b in batches]
+    n2 = max(4, a.steps // 2)
+    fence()
     t1 = time.perf_counter()
     for i in range(n2):
-        step(a.warmup + a.steps + i, h2d=True)
+        ids, vis, aco, mask, seg, lab = resident[i % nb]
+        model.train_step(ids, vis, aco, mask, seg, lab, optimizer=opt, graph=use_graph)
+        sch.step()
     fence()
-    dt_h2d = (time.perf_counter() - t1) / n2
+    dt_res = (time.perf_counter() - t1) / n2
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     # in-step duration of the dominant kernel (grouped weight-gradient GEMM): HIP events on the engine's side stream
+    # (profiling events cannot live inside a captured graph: these steps run the same kernels launch by launch)
     wgrad_in_step_us = None
+    comm_exposed_ms = None
+    n3 = 0
     try:
         import ctypes as C
         from bert_multimodal_transformer_amd import _lib
         core = model._core
         if core.kind != "bert":
-            raise RuntimeError("the MAG-XLNet engine launches its weight gradients one by one on the main stream")
+            raise RuntimeError("the MAG-XLNet engine has no timing hooks around its grouped weight-gradient launch")
         _lib.check(_lib.lib().mb_bert_set_profiling(core.handle, 1))
         acc = []
         for i in range(6):
-            step(i)
+            ids, vis, aco, mask, seg, lab = resident[i % nb]
+            model.train_step(ids, vis, aco, mask, seg, lab, optimizer=opt, graph=use_graph)
+            sch.step()
             torch.cuda.synchronize()
             v = C.c_float()
             _lib.check(_lib.lib().mb_bert_profile_wgrad_us(core.handle, C.byref(v)))
             acc.append(v.value)
         _lib.check(_lib.lib().mb_bert_set_profiling(core.handle, 0))
         wgrad_in_step_us = float(np.mean(acc[1:]))
-        n2 += 6
+        n3 = 6
     except Exception as ex:          # MB_GROUP_WGRAD=0 (four separate launches): no grouped kernel to time
         print("note: in-step wgrad timing unavailable (%s)" % ex, file=sys.stderr)
+    if dp is not None:
+        comm_exposed_ms = dp.exposed_ms()
     scope.__exit__(None, None, None)
-    loss = float(model.loss_running().item()) / max(1, total_steps + n2)
+    loss = float(model.loss_running().item()) / max(1, total_steps + n2 + n3)
     value = world * B * a.steps / dt
 
     out = None
     if rank == 0:
         gflop = TRAIN_GFLOP_PER_SAMPLE_L50 if (L == 50 and V == 47 and a.model == "bert") else None
+        if L == 128 and V == 35 and a.model == "bert":
+            gflop = TRAIN_GFLOP_PER_SAMPLE_C5
         mname = "MAG-BERT" if a.model == "bert" else "MAG-XLNet"
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
-        out = {"metric": "train samples/sec %s MOSI seq_len=%d" % (mname, L), "value": round(value, 2), "unit": "samples/s",
+        q = lambda f: round(per_step_ms[min(len(per_step_ms) - 1, int(f * len(per_step_ms)))], 3)
+        out = {"metric": "train samples/sec %s %s seq_len=%d" % (mname, a.dataset.upper(), L), "value": round(value, 2), "unit": "samples/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": mname + (" bert-base-uncased" if a.model == "bert" else " xlnet-base-cased") + ", %s dims (V=%d, A=%d), batch %d/GPU, seq_len %d, full "
-                                      "optimizer step (fwd+MSE+bwd%s+HF-AdamW%s+schedule; inputs resident in HBM), dropout on, random-init weights"
-                                      % (a.dataset.upper(), V, A, B, L, "+RCCL all-reduce" if world > 1 else "",
-                                         " (encoder weights updated in the wgrad epilogue)" if fused_opt else
-                                         (" (pipelined under the next forward)" if piped_opt else "")),
+                                      "optimizer step (per-step H2D of the batch + fwd+MSE+bwd%s+HF-AdamW+schedule+zero_grad), dropout on, "
+                                      "random-init weights" % (a.dataset.upper(), V, A, B, L, "+RCCL all-reduce" if world > 1 else ""),
                           "global_batch": world * B, "seq_len": L, "parallelism": "dp%d" % world,
+                          "step_graph": bool(graph_on), "h2d": "one pinned block per batch, copy stream, prefetched one step ahead",
                           **({"grad_wire_dtype": "bf16" if dp.reducer.wire_dtype == torch.bfloat16 else "fp32"} if dp is not None else {})},
                "mean_loss": round(loss, 4), "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
-               "value_with_h2d": round(world * B / dt_h2d, 2)}
+               "step_ms_median": q(0.5), "step_ms_p10": q(0.1), "step_ms_p90": q(0.9),
+               "value_inputs_resident": round(world * B / dt_res, 2)}
+        if comm_exposed_ms is not None:
+            out["comm_exposed_ms"] = round(comm_exposed_ms, 4)
+        if graph_on:
+            out["graph_captures_replays"] = list(model._core.graph_stats())
         if gflop:
             out["step_tflops_algorithmic"] = round(value * gflop * 1e-3, 1)
             out["step_mfma_frac"] = round(value * gflop * 1e-3 * 0.984 / (peak * world), 4)
@@ -324,16 +420,16 @@ def main():
                            "avg_us": round(us, 2), "avg_us_standalone": dom["avg_us"], "flop_per_launch": dom["flop"],
                            "timing": "HIP events on the launch stream, in-step" if us is not dom["avg_us"] else
                                      "HIP events on the launch stream, back-to-back launches"}
-        # HBM-side bytes per launch of that kernel: PMC counters cannot be collected from inside this process; the figure
-        # comes from the committed rocprofv3 --pmc passes over this same command (profiles/r01_pmc_step.md), else null
+        # HBM-side bytes per launch of that kernel and the in-step per-kernel table: PMC counters / kernel traces cannot be
+        # collected from inside this process; they come from the committed rocprofv3 passes over this same command
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 pm = json.load(fh)
             if dom["kernel"].startswith(pm["kernel"]) and a.dtype == "bf16" and B == 48 and L == 50 and a.model == "bert":
                 out["roofline"]["traffic"] = pm["fetch_bytes"] + pm["write_bytes"]
                 out["roofline"]["traffic_unit"] = "bytes/launch"
                 out["roofline"]["traffic_source"] = pm["source"]
-                out["roofline"]["algorithmic_bytes"] = 116391936
+                out["roofline"]["algorithmic_bytes"] = pm.get("algorithmic_bytes", 116391936)
         except Exception:
             pass
         if a.model != "bert":
@@ -342,10 +438,20 @@ def main():
         tot_us = sum(r["avg_us"] for r in rl)
         tot_fl = sum(r["flop"] for r in rl)
         out["roofline_gemms"] = {"per_layer_us": round(tot_us, 1), "aggregate_tflops": round(tot_fl / tot_us * 1e-6, 1),
-                                 "frac": round(tot_fl / tot_us * 1e-6 / peak, 4),
+                                 "frac": round(tot_fl / tot_us * 1e-6 / peak, 4), "timing": "back-to-back launches (warm caches: an upper bound)",
                                  "kernels": [{k: r[k] for k in ("kernel", "avg_us", "tflops")} for r in rl]}
+        out["roofline_hbm"] = {"peak_tb_per_s": 8.0, "timing": "HIP events, back-to-back launches over rotating operand sets",
+                               "kernels": hbm_roofline(a.dtype, B, L, V, A)}
+        try:       # in-step per-kernel table (rocprofv3 --kernel-trace over this command), committed with the round's profiles
+            with open(os.path.join(ROOT, "profiles", "instep_kernels.json")) as fh:
+                ik = json.load(fh)
+            if ik.get("workload") == "%s B=%d L=%d %s" % (a.model, B, L, a.dtype):
+                out["instep_kernels"] = ik
+        except Exception:
+            pass
     if a.cpu_baseline and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(B, L, V, A, a.cpu_steps, a.model)
+        out["cpu_baseline"].update(cpu_info())
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(out))

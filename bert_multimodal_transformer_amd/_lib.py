@@ -71,10 +71,9 @@ PROTOTYPES = {
     "mb_bert_sequence_output": (_vp, [_vp]),
     "mb_bert_pooled_output": (_vp, [_vp]),
     "mb_bert_stage_grad_ranges": (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz), _i]),
-    "mb_bert_fuse_adamw": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _i, _f]),
-    "mb_bert_fused_range": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
-    "mb_bert_adamw_pipelined": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _i, _f, _i, _vp]),
-    "mb_bert_adamw_join": (_i, [_vp, _vp]),
+    "mb_bert_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f,
+                                _i, _i, _f, _f, _i, _vp]),
+    "mb_bert_graph_stats": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "mb_bert_set_profiling": (_i, [_vp, _i]),
     "mb_bert_profile_wgrad_us": (_i, [_vp, C.POINTER(_f)]),
     "mb_xlnet_create": (_i, [C.POINTER(XlnetEngineConfig), C.POINTER(_vp)]),

@@ -98,8 +98,6 @@ class _Core(object):
         self.training_last = False
         self._own_stream = None
         self.stage_hooks = []          # callables hook(stage) run after each backward stage (DataParallel)
-        self.pre_backward_hooks = []   # callables run before the first backward stage (AdamW.enable_fused_backward)
-        self.optimizer_pending = False  # a pipelined optimizer step may still be writing parameters (join_optimizer())
         self._make_engine(1, 8)
         n = self._fn("param_count")(self.handle)
         self.n_params = n
@@ -138,7 +136,6 @@ class _Core(object):
             float(mc.dropout_prob), self.dt, int(B), int(L))
 
     def _make_engine(self, B, L):
-        self.join_optimizer()
         h = C.c_void_p()
         cfg = self._cfg(B, L)
         _lib.check(self._fn("create")(C.byref(cfg), C.byref(h)))       # raises (and keeps the old engine) on a bad shape
@@ -204,7 +201,6 @@ class _Core(object):
         with _Core._Hop(self):
             _lib.check(self._fn("sync_weights")(self.handle, self.stream()))
         self.weights_dirty = False
-        self.optimizer_pending = False
 
     # -- passes --------------------------------------------------------------------------------------
     def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, training):
@@ -213,15 +209,7 @@ class _Core(object):
         self._ensure(B, L)
         if self.weights_dirty:
             self.sync_weights()
-        ids = input_ids.to(dev, torch.int64).contiguous()
-        msk = attention_mask.to(dev, torch.int64).contiguous()
-        seg = token_type_ids.to(dev, torch.int64).contiguous()
-        vis = visual.to(dev, torch.float32).contiguous()
-        aco = acoustic.to(dev, torch.float32).contiguous()
-        if vis.shape != (B, L, self.V) or aco.shape != (B, L, self.A):
-            raise ValueError("visual/acoustic must be [B, L, %d] / [B, L, %d], got %s / %s" %
-                             (self.V, self.A, tuple(vis.shape), tuple(aco.shape)))
-        lab = None if labels is None else labels.to(dev, torch.float32).contiguous().view(-1)
+        ids, msk, seg, vis, aco, lab = self._inputs(input_ids, visual, acoustic, attention_mask, token_type_ids, labels)
         logits = torch.empty(B, self.config.num_labels, dtype=torch.float32, device=dev)
         if training:
             self.step += 1
@@ -233,7 +221,6 @@ class _Core(object):
                                                 self.step, _lib.ptr(logits), C.c_void_p(self.loss_buf.data_ptr()),
                                                 C.c_void_p(self.loss_buf.data_ptr() + 4) if lab is not None else None,
                                                 self.stream()))
-        self.optimizer_pending = False          # the engine forward waited for every chunk of a pipelined optimizer step
         return logits
 
     def _backward(self, dlogits=None, loss_scale=1.0):
@@ -242,14 +229,71 @@ class _Core(object):
         if dlogits is None and lab is None:
             raise ValueError("fused backward needs the labels passed to forward()")
         with _Core._Hop(self):
-            for hook in self.pre_backward_hooks:
-                hook()
             for s in range(nstage):
                 _lib.check(self._fn("backward")(self.handle, _lib.ptr(dlogits),
                                                      _lib.ptr(lab) if dlogits is None else None, float(loss_scale), s, s + 1,
                                                      self.stream()))
                 for hook in self.stage_hooks:
                     hook(s)
+
+    def _inputs(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels):
+        B, L = input_ids.shape
+        dev = self.device
+        ids = input_ids.to(dev, torch.int64).contiguous()
+        msk = attention_mask.to(dev, torch.int64).contiguous()
+        seg = token_type_ids.to(dev, torch.int64).contiguous()
+        vis = visual.to(dev, torch.float32).contiguous()
+        aco = acoustic.to(dev, torch.float32).contiguous()
+        if vis.shape != (B, L, self.V) or aco.shape != (B, L, self.A):
+            raise ValueError("visual/acoustic must be [B, L, %d] / [B, L, %d], got %s / %s" %
+                             (self.V, self.A, tuple(vis.shape), tuple(aco.shape)))
+        lab = None if labels is None else labels.to(dev, torch.float32).contiguous().view(-1)
+        return ids, msk, seg, vis, aco, lab
+
+    def graph_blocker(self):
+        """why the whole-step hipGraph (mb_bert_train_step) cannot run this model's steps, or None"""
+        if os.environ.get("MB_STEP_GRAPH", "1") == "0":
+            return "MB_STEP_GRAPH=0"
+        if self.kind != "bert":
+            return "the MAG-XLNet engine has no captured step yet"
+        if self.stage_hooks:
+            return "backward stage hooks are installed (data parallel: the gradient exchange is issued between stages)"
+        return None
+
+    def train_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, opt, loss_scale=1.0, mode=1):
+        """One optimizer step as the step prologue + one replayed hipGraph (include/magbert_hip.h: mb_bert_train_step).
+        opt: None (gradient-accumulation micro-step, no update) or the dict AdamW.flat_step_args() returns."""
+        B, L = input_ids.shape
+        self._ensure(B, L)
+        if self.weights_dirty:
+            self.sync_weights()
+        ids, msk, seg, vis, aco, lab = self._inputs(input_ids, visual, acoustic, attention_mask, token_type_ids, labels)
+        if lab is None:
+            raise ValueError("the fused step needs label_ids")
+        if not hasattr(self, "_logit_bufs"):
+            self._logit_bufs = {}
+        logits = self._logit_bufs.get(B)
+        if logits is None:          # one persistent buffer per batch size: its address is part of the captured graph
+            logits = self._logit_bufs[B] = torch.empty(B, self.config.num_labels, dtype=torch.float32, device=self.device)
+        self.step += 1
+        self._keep = (ids, msk, seg, vis, aco, lab, logits)
+        self.training_last = True
+        o = opt or {}
+        with _Core._Hop(self):
+            _lib.check(self.lib.mb_bert_train_step(
+                self.handle, _lib.ptr(ids), _lib.ptr(vis), _lib.ptr(aco), _lib.ptr(msk), _lib.ptr(seg), _lib.ptr(lab), B, L,
+                self.seed & (2 ** 64 - 1), self.step, _lib.ptr(logits), C.c_void_p(self.loss_buf.data_ptr()),
+                C.c_void_p(self.loss_buf.data_ptr() + 4), _lib.ptr(o.get("m")), _lib.ptr(o.get("v")), o.get("lr", 0.0),
+                o.get("beta1", 0.9), o.get("beta2", 0.999), o.get("eps", 1e-6), o.get("weight_decay", 0.0), int(o.get("t", 1)),
+                1 if o.get("correct_bias", True) else 0, o.get("grad_scale", 1.0), float(loss_scale), int(mode), self.stream()))
+        return logits
+
+    def graph_stats(self):
+        cap, rep = C.c_size_t(), C.c_size_t()
+        if self.kind != "bert":
+            return 0, 0
+        _lib.check(self.lib.mb_bert_graph_stats(self.handle, C.byref(cap), C.byref(rep)))
+        return cap.value, rep.value
 
     def sequence_output(self, B, L):
         H = self.config.hidden_size
@@ -264,21 +308,6 @@ class _Core(object):
         p = self.lib.mb_bert_pooled_output(self.handle)
         off = p - self.ws.data_ptr()
         return self.ws[off: off + B * H * 4].view(torch.float32).view(B, H).clone()
-
-    def join_optimizer(self):
-        """make the current stream wait for a pipelined optimizer step (AdamW.enable_pipelined_step) that is still in flight"""
-        if self.optimizer_pending and self.handle is not None and self.kind == "bert":
-            _lib.check(self.lib.mb_bert_adamw_join(self.handle, self.stream()))
-        self.optimizer_pending = False
-
-    def fused_range(self):
-        """flat [begin, end) the engine can update inside the backward (mb_bert_fuse_adamw); None if unsupported"""
-        if self.kind != "bert":
-            return None
-        b, e = C.c_size_t(), C.c_size_t()
-        if self.lib.mb_bert_fused_range(self.handle, C.byref(b), C.byref(e)) != 0:
-            return None
-        return b.value, e.value
 
     def stage_ranges(self, stage):
         offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
@@ -362,15 +391,7 @@ class _MagBertBase(nn.Module):
         super()._load_from_state_dict(*a, **k)
         self._core.weights_dirty = True
 
-    def join_optimizer(self):
-        self._core.join_optimizer()
-
-    def state_dict(self, *args, **kwargs):
-        self._core.join_optimizer()
-        return super().state_dict(*args, **kwargs)
-
     def load_state_dict(self, state_dict, strict=True, **kw):
-        self._core.join_optimizer()
         sd = {k: v for k, v in state_dict.items() if not k.endswith("position_ids")}
         r = super().load_state_dict(sd, strict=strict, **kw)
         self._core.weights_dirty = True
@@ -400,14 +421,12 @@ class _MagBertBase(nn.Module):
             cur = torch.cuda.current_stream(core.device)
             if cur.cuda_stream != 0:
                 yield
-                core.join_optimizer()
                 return
             if core._own_stream is None:
                 core._own_stream = torch.cuda.Stream(device=core.device)
             core._own_stream.wait_stream(cur)
             with torch.cuda.stream(core._own_stream):
                 yield
-                core.join_optimizer()
             cur.wait_stream(core._own_stream)
         return scope()
 
@@ -444,6 +463,68 @@ class _MagBertBase(nn.Module):
         return model
 
 
+class _FusedStep(object):
+    """Fused training surface shared by MAG_BertForSequenceClassification and MAG_XLNetForSequenceClassification
+    (what the bundled driver's train_epoch and bench.py call instead of the reference's five-line step)."""
+
+    def training_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, loss_scale=1.0):
+        """forward + MSE (multimodal_driver.py:372-373) + backward in two C calls, no host sync.
+        Returns the device scalar holding this step's loss (running sum is in .loss_running())."""
+        if self.num_labels != 1:
+            raise NotImplementedError("fused loss is the regression MSE of the driver (num_labels == 1)")
+        core = self._core
+        core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, True)
+        core._backward(None, loss_scale)
+        return core.loss_buf[0]
+
+    def train_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, optimizer=None,
+                   loss_scale=1.0, graph=None):
+        """One iteration of train_epoch's loop body (multimodal_driver.py:359-386): forward, MSE, backward and -- when
+        `optimizer` is given -- optimizer.step() + optimizer.zero_grad().  scheduler.step() stays with the caller.
+
+        Where it can (MAG-BERT, single process, the driver's two parameter groups on this model's flat buffer) the whole
+        iteration is the step prologue + ONE replayed hipGraph; otherwise the same kernels are launched one by one
+        (training_step + optimizer.step()).  graph=False forces the launch-by-launch path, graph=True raises if the graph
+        cannot be used.  Pass optimizer=None on gradient-accumulation micro-steps.  Returns the device loss scalar."""
+        if self.num_labels != 1:
+            raise NotImplementedError("fused loss is the regression MSE of the driver (num_labels == 1)")
+        core = self._core
+        why = core.graph_blocker()
+        opt = None
+        if why is None and optimizer is not None:
+            opt = optimizer.flat_step_args(core) if hasattr(optimizer, "flat_step_args") else None
+            if opt is None:
+                why = "the optimizer is not the two-group AdamW over this model's flat buffer"
+        if graph is True and why is not None:
+            raise _lib.MagbertError("whole-step graph unavailable: " + why)
+        if why is not None or graph is False:
+            self.training_step(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, loss_scale=loss_scale)
+            if optimizer is not None:
+                optimizer.step()
+                optimizer.zero_grad()
+            return core.loss_buf[0]
+        if optimizer is not None:
+            optimizer._t += 1
+            opt["t"] = optimizer._t
+        core.train_step(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, opt, loss_scale=loss_scale)
+        return core.loss_buf[0]
+
+    def loss_running(self, reset=False):
+        v = self._core.loss_buf[1].clone()
+        if reset:
+            self._core.loss_buf[1].zero_()
+        return v
+
+    # flat views for the fused optimizer / data parallel -------------------------------------------------
+    @property
+    def flat_params(self):
+        return self._core.params
+
+    @property
+    def flat_grads(self):
+        return self._core.grads
+
+
 class MAG_BertModel(_MagBertBase):
     """bert.py:76-237.  forward -> (sequence_output, pooled_output).  Outputs are fp32 copies of engine activations
     (not differentiable; the trainable surface is MAG_BertForSequenceClassification, which is what the driver uses)."""
@@ -478,7 +559,7 @@ class MAG_BertModel(_MagBertBase):
         return self._core.sequence_output(B, L), self._core.pooled_output(B)
 
 
-class MAG_BertForSequenceClassification(_MagBertBase):
+class MAG_BertForSequenceClassification(_FusedStep, _MagBertBase):
     """bert.py:240-324."""
 
     def __init__(self, config, multimodal_config, visual_dim=VISUAL_DIM, acoustic_dim=ACOUSTIC_DIM,
@@ -513,30 +594,3 @@ class MAG_BertForSequenceClassification(_MagBertBase):
                 loss = torch.nn.functional.cross_entropy(logits.view(-1, self.num_labels), labels.to(logits.device).view(-1))
             outputs = (loss,) + outputs
         return outputs
-
-    # fused fast path (what the bundled driver / bench use) ----------------------------------------------
-    def training_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, loss_scale=1.0):
-        """forward + MSE (multimodal_driver.py:372-373) + backward in two C calls, no host sync.
-        Returns the device scalar holding this step's loss (running sum is in .loss_running())."""
-        if self.num_labels != 1:
-            raise NotImplementedError("fused loss is the regression MSE of the driver (num_labels == 1)")
-        core = self._core
-        core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, True)
-        core._backward(None, loss_scale)
-        return core.loss_buf[0]
-
-    def loss_running(self, reset=False):
-        v = self._core.loss_buf[1].clone()
-        if reset:
-            self._core.loss_buf[1].zero_()
-        return v
-
-    # flat views for the fused optimizer / data parallel -------------------------------------------------
-    @property
-    def flat_params(self):
-        self._core.join_optimizer()
-        return self._core.params
-
-    @property
-    def flat_grads(self):
-        return self._core.grads

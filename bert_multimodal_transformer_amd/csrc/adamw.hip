@@ -11,7 +11,8 @@ namespace mb {
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16* __restrict__ shadow, size_t n4,
                                                     size_t n_decay, size_t sh_begin, size_t sh_end, AdamArgs a,
-                                                    int zero_grad) {
+                                                    const AdamArgs* __restrict__ dyn, int zero_grad) {
+    if (dyn) a = *dyn;                  // replayed step graph: this step's lr / step size / gradient scale live in device memory
     const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
     const float decay = a.lr * a.weight_decay;
     for (size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * 256) {
@@ -34,7 +35,8 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float
 
 // scalar tail (n % 4 elements) -- only hit by stand-alone tensors, the engine's flat buffers are 64-aligned
 __global__ void adamw_tail_kernel(float* p, float* g, float* m, float* v, size_t begin, size_t n, size_t n_decay, AdamArgs a,
-                                  int zero_grad) {
+                                  const AdamArgs* dyn, int zero_grad) {
+    if (dyn) a = *dyn;
     const size_t i = begin + threadIdx.x;
     if (i >= n) return;
     const float gv = g[i] * a.grad_scale;
@@ -47,7 +49,7 @@ __global__ void adamw_tail_kernel(float* p, float* g, float* m, float* v, size_t
 }
 
 int adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, size_t n_decay, size_t sh_begin,
-               size_t sh_end, AdamArgs a, int zero_grad, hipStream_t st) {
+               size_t sh_end, AdamArgs a, int zero_grad, hipStream_t st, const AdamArgs* dyn) {
     if (n == 0) return MB_OK;
     if ((n_decay % 4 && n_decay < n) || (sh_begin % 4) || (sh_end % 4)) return MB_ERR_SHAPE;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return MB_ERR_SHAPE;
@@ -56,9 +58,9 @@ int adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, s
         unsigned grid = (unsigned)((n4 + 255) / 256);
         if (grid > 256 * 16) grid = 256 * 16;
         hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16*)shadow, n4, n_decay, sh_begin,
-                           sh_end, a, zero_grad);
+                           sh_end, a, dyn, zero_grad);
     }
-    if (n % 4) hipLaunchKernelGGL(adamw_tail_kernel, dim3(1), dim3(64), 0, st, p, g, m, v, n4 * 4, n, n_decay, a, zero_grad);
+    if (n % 4) hipLaunchKernelGGL(adamw_tail_kernel, dim3(1), dim3(64), 0, st, p, g, m, v, n4 * 4, n, n_decay, a, dyn, zero_grad);
     return (int)hipGetLastError();
 }
 

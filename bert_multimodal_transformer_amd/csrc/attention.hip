@@ -24,6 +24,7 @@ namespace mb {
 template <class T, int LP, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                            T* __restrict__ ctx, int L, int nh, DropKey drop) {
+    drop.resolve();
     typedef AttnCfg<T> C;
     constexpr int PIT = C::ROWB + 16;                 // image pitch (bytes)
     constexpr int SPIT = LP * (int)sizeof(T) + 16;    // strip pitch
@@ -113,6 +114,7 @@ template <class T, int LP, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                            const T* __restrict__ dctx, T* __restrict__ dqkv,
                                                            float* __restrict__ dbias, int L, int nh, DropKey drop) {
+    drop.resolve();
     typedef AttnCfg<T> C;
     constexpr int PIT = C::ROWB + 16;
     constexpr int SPIT = LP * (int)sizeof(T) + 16;

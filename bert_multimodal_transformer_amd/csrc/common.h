@@ -41,6 +41,13 @@ struct DropKey {
     uint32_t k0, k1;      // per-site, per-step key (host: splitmix64(seed, step, site))
     uint32_t thresh;      // drop if hash < thresh ; thresh = round(p * 2^32) ; 0 => dropout off
     float scale;          // 1/(1-p)
+    // Replayed step graphs cannot carry a per-step value in their kernel arguments: there (k0, k1) of this site live in
+    // device memory (written by step_prologue_kernel ahead of the graph launch) and every kernel fetches them once, at
+    // entry, with two scalar loads.  nullptr = keys by value (eager launches, operator-level C ABI).
+    const uint32_t* dyn;
+    __device__ __forceinline__ void resolve() {
+        if (dyn != nullptr && thresh != 0u) { k0 = dyn[0]; k1 = dyn[1]; }
+    }
 };
 __device__ __forceinline__ uint32_t hash32(uint32_t idx, uint32_t k0, uint32_t k1) {
     uint32_t x = idx * 0x9E3779B1u + k0;

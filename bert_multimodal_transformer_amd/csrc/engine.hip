@@ -47,20 +47,23 @@ struct mb_bert_engine {
     int overlap_wgrad = 1;
     int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128), 0 = four launches
     bool deferred = false;         // grouped launch on the side stream, joined one stage later
-    // optimizer-in-backward (mb_bert_fuse_adamw): the grouped wgrad applies HF AdamW to the encoder GEMM weights in its epilogue
-    bool fuse = false;
-    float* FM = nullptr; float* FV = nullptr;      // Adam moments, flat, parallel to P
-    AdamArgs fa;
-    // pipelined optimizer (mb_bert_adamw_pipelined): AdamW runs chunk by chunk on its own stream in the order the next forward
-    // needs the parameters; the forward waits for chunk k only in front of the first kernel that reads it
-    hipStream_t opt_stream = nullptr;
-    std::vector<hipEvent_t> oev;   // [0] grads final on the caller's stream ; [1 + k] chunk k updated (k = 0 front, 1..NL layers, NL+1 head)
-    bool opt_pending = false;
     bool prof = false;             // mb_bert_set_profiling: timing events around every grouped wgrad launch (on the side stream)
     std::vector<hipEvent_t> pev;   // [2 * num_layers]
     bool ws_zeroed = false;
     uint64_t seed = 0, step = 0;
     float* logits = nullptr;
+    // whole-step hipGraph (mb_bert_train_step): per-step scalars live in the workspace (ws_state: AdamArgs[2] + keys[nsites][2]),
+    // the batch is gathered into fixed staging buffers (ws_in_*), one instantiated graph per (shape, output pointers)
+    bool dyn = false;              // dropout keys / AdamW scalars are read from device memory (set while a train step is built)
+    bool capturing = false;        // the stream is in capture mode: nothing outside the captured sequence may be waited for
+    int nsites = 0;
+    size_t ws_state = 0, ws_in_ids = 0, ws_in_seg = 0, ws_in_mask = 0, ws_in_vis = 0, ws_in_aco = 0, ws_in_lab = 0;
+    struct StepGraph {
+        int B, L, with_opt; const void *logits, *loss, *loss_run, *m, *v; float loss_scale; hipStream_t st;
+        hipGraph_t graph; hipGraphExec_t exec;
+    };
+    std::vector<StepGraph> graphs;
+    size_t graph_launches = 0, graph_captures = 0;
 
     size_t add(const std::string& name, std::vector<int64_t> shape, int decay, size_t& cursor) {
         TensorInfo t;
@@ -75,7 +78,15 @@ struct mb_bert_engine {
     const void* W(size_t off) const {   // GEMM operand view of a weight (bf16 shadow in perf mode, master in fp32 mode)
         return c.dtype == DT_BF16 ? (const void*)(SH + off * 2) : (const void*)(P + off);
     }
-    DropKey key(uint32_t site, float p) const { return training ? make_key(seed, step, site, p) : kNoDrop; }
+    AdamArgs* adam_state() const { return (AdamArgs*)(ws + ws_state); }
+    uint32_t* key_state() const { return (uint32_t*)(ws + ws_state + 2 * sizeof(AdamArgs)); }
+    DropKey key(uint32_t site, float p) const {
+        if (!training) return kNoDrop;
+        if (!dyn) return make_key(seed, step, site, p);
+        DropKey k = make_key(0, 0, site, p);          // thresh / scale of this site; (k0, k1) come from the device table
+        if (k.thresh) { k.k0 = k.k1 = 0u; k.dyn = key_state() + 2 * (size_t)site; }
+        return k;
+    }
 };
 
 static void build_layout(mb_bert_engine* e) {
@@ -158,7 +169,57 @@ static void build_layout(mb_bert_engine* e) {
     }
     e->ws_dctx = w.take(T * H * es); e->ws_dsum = w.take(T * H * 4); e->ws_dz = w.take((size_t)c.max_batch * H * es);
     e->ws_lnp_a = w.take(ln_partials_floats((int)T, (int)H) * 4); e->ws_lnp_b = w.take(ln_partials_floats((int)T, (int)H) * 4);
+    e->nsites = SITE_LAYER0 + 4 * c.num_layers;
+    e->ws_state = w.take(2 * sizeof(AdamArgs) + (size_t)e->nsites * 8);
+    e->ws_in_ids = w.take(T * 8); e->ws_in_seg = w.take(T * 8); e->ws_in_mask = w.take(T * 8);
+    e->ws_in_vis = w.take(T * (size_t)V * 4); e->ws_in_aco = w.take(T * (size_t)A * 4);
+    e->ws_in_lab = w.take((size_t)c.max_batch * c.num_labels * 4);
     e->ws_bytes = w.off;
+}
+
+// the internal side stream + its fork / join events (created once, outside any stream capture)
+static int ensure_side(mb_bert_engine* e) {
+    if (e->side || !e->overlap_wgrad) return MB_OK;
+    // MB_SIDE_PRIORITY=1: lowest dispatch priority for the weight-gradient stream (the dgrad chain is the critical
+    // path).  Measured: no effect -- resident wgrad blocks keep their LDS slots for a whole K = T loop, priority
+    // only orders NEW workgroups -- so the default stays the normal priority.
+    int least = 0, greatest = 0;
+    CK((int)hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const char* pv = getenv("MB_SIDE_PRIORITY");
+    const int prio = (pv && atoi(pv) != 0) ? least : 0;
+    CK((int)hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio));
+    e->evs.assign((size_t)e->c.num_layers * 5, nullptr);
+    for (auto& ev : e->evs) CK((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    return MB_OK;
+}
+
+// State the next pass relies on but that is not part of the pass itself (kept out of captured step graphs): outstanding
+// side-stream work of an unfinished backward, the one-time clearing of the workspace, zero pad rows for this token count.
+static int prepare_pass(mb_bert_engine* e, int T, hipStream_t st) {
+    const mb_bert_config& c = e->c;
+    const int H = c.hidden_size, I = c.intermediate_size, dt = c.dtype;
+    char* ws = e->ws;
+    const int Tp = (int)align_up((size_t)T, 64);
+    if (e->deferred && e->side)       // a backward that was not run to its last stage may still have weight-gradient GEMMs reading activations
+        for (size_t l = 0; l < 2 && l * 5 + 4 < e->evs.size(); ++l) CK((int)hipStreamWaitEvent(st, e->evs[l * 5 + 4], 0));
+    if (!e->ws_zeroed) { CK((int)hipMemsetAsync(ws, 0, e->ws_bytes, st)); e->ws_zeroed = true; e->padT = T; }
+    if (e->padT != T && Tp > T) {
+        // a different batch shape ran before: rows [T, Tp) of every buffer that feeds a wgrad as the k-major operand
+        // may hold stale tokens -> clear them (kernels never write rows >= T)
+        const size_t es = esize(dt);
+        auto zp = [&](size_t off, size_t cols) {
+            return (int)hipMemsetAsync(ws + off + (size_t)T * cols * es, 0, (size_t)(Tp - T) * cols * es, st);
+        };
+        CK(zp(e->ws_emb, H));
+        for (int k = 0; k < 2; ++k) {
+            CK(zp(e->ws_ds[k], H)); CK(zp(e->ws_dzd[k], H)); CK(zp(e->ws_ds2[k], H)); CK(zp(e->ws_dzd2[k], H));
+            CK(zp(e->ws_du[k], I)); CK(zp(e->ws_dqkv[k], 3 * H));
+        }
+        for (int l = 0; l <= c.num_layers; ++l) CK(zp(e->ws_x[l], H));
+        for (int l = 0; l < c.num_layers; ++l) { CK(zp(e->lw[l].ctx, H)); CK(zp(e->lw[l].y1, H)); CK(zp(e->lw[l].g, I)); }
+    }
+    e->padT = T;
+    return MB_OK;
 }
 
 extern "C" {
@@ -303,8 +364,7 @@ void mb_bert_destroy(mb_bert_engine* e) {
     if (e->side) hipStreamDestroy(e->side);
     for (auto& ev : e->evs) if (ev) hipEventDestroy(ev);
     for (auto& ev : e->pev) if (ev) hipEventDestroy(ev);
-    for (auto& ev : e->oev) if (ev) hipEventDestroy(ev);
-    if (e->opt_stream) hipStreamDestroy(e->opt_stream);
+    for (auto& g : e->graphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
     delete e;
 }
 int mb_bert_num_tensors(const mb_bert_engine* e) { return (int)e->tensors.size(); }
@@ -330,22 +390,14 @@ int mb_bert_bind(mb_bert_engine* e, float* params, float* grads, void* shadow, v
     if (e->c.dtype == DT_BF16 && !shadow) return MB_ERR_ARG;
     e->P = params; e->G = grads; e->SH = (char*)shadow; e->ws = (char*)workspace;
     e->ws_zeroed = false; e->padT = -1;
-    return MB_OK;
-}
-
-int mb_bert_adamw_join(mb_bert_engine* e, void* stream) {
-    if (!e) return MB_ERR_ARG;
-    if (e->opt_pending) {       // the optimizer stream is in order: its last event implies every chunk
-        CK((int)hipStreamWaitEvent((hipStream_t)stream, e->oev.back(), 0));
-        e->opt_pending = false;
-    }
+    for (auto& g : e->graphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }      // captured against the old buffers
+    e->graphs.clear();
     return MB_OK;
 }
 
 int mb_bert_sync_weights(mb_bert_engine* e, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!e->P) return MB_ERR_ARG;
-    CK(mb_bert_adamw_join(e, stream));
     if (e->c.dtype == DT_BF16)
         CK(convert(DT_BF16, e->P + e->sh_begin, e->SH + e->sh_begin * 2, e->sh_end - e->sh_begin, st));
     const mb_bert_config& c = e->c;
@@ -369,28 +421,7 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     e->B = B; e->L = L; e->training = training; e->seed = seed; e->step = step; e->logits = logits;
     float* P = e->P;
     char* ws = e->ws;
-    const int Tp = (int)align_up((size_t)T, 64);
-    if (e->deferred && e->side)       // a backward that was not run to its last stage may still have weight-gradient GEMMs reading activations
-        for (size_t l = 0; l < 2 && l * 5 + 4 < e->evs.size(); ++l) CK((int)hipStreamWaitEvent(st, e->evs[l * 5 + 4], 0));
-    if (!e->ws_zeroed) { CK((int)hipMemsetAsync(ws, 0, e->ws_bytes, st)); e->ws_zeroed = true; e->padT = T; }
-    if (e->padT != T && Tp > T) {
-        // a different batch shape ran before: rows [T, Tp) of every buffer that feeds a wgrad as the k-major operand
-        // may hold stale tokens -> clear them (kernels never write rows >= T)
-        const size_t es = esize(dt);
-        auto zp = [&](size_t off, size_t cols) {
-            return (int)hipMemsetAsync(ws + off + (size_t)T * cols * es, 0, (size_t)(Tp - T) * cols * es, st);
-        };
-        CK(zp(e->ws_emb, H));
-        for (int k = 0; k < 2; ++k) {
-            CK(zp(e->ws_ds[k], H)); CK(zp(e->ws_dzd[k], H)); CK(zp(e->ws_ds2[k], H)); CK(zp(e->ws_dzd2[k], H));
-            CK(zp(e->ws_du[k], I)); CK(zp(e->ws_dqkv[k], 3 * H));
-        }
-        for (int l = 0; l <= c.num_layers; ++l) CK(zp(e->ws_x[l], H));
-        for (int l = 0; l < c.num_layers; ++l) { CK(zp(e->lw[l].ctx, H)); CK(zp(e->lw[l].y1, H)); CK(zp(e->lw[l].g, I)); }
-    }
-    e->padT = T;
-    const bool optw = e->opt_pending;          // parameters are still being updated on the optimizer stream, chunk by chunk
-    if (optw) CK((int)hipStreamWaitEvent(st, e->oev[1], 0));                        // embeddings + MAG
+    if (!e->capturing) CK(prepare_pass(e, T, st));
     // embeddings (bert.py:211-216)
     CK(embed_ln_forward(dt, input_ids, token_type_ids, P + e->word, P + e->pos, P + e->type, P + e->emb_lnw, P + e->emb_lnb,
                         c.layer_norm_eps, ws + e->ws_emb, (float*)(ws + e->ws_emb_st), (float*)(ws + e->ws_emb_st) + T, B, L,
@@ -405,7 +436,6 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
         const LayerOff& o = e->lo[l];
         const LayerWs& w = e->lw[l];
         const char* x = ws + e->ws_x[l];
-        if (optw) CK((int)hipStreamWaitEvent(st, e->oev[2 + l], 0));                // this layer's weights, biases, LayerNorms
         CK(gemm(dt, GEMM_NT, EPI_BIAS, T, 3 * H, H, x, H, e->W(o.wqkv), H, ws + w.qkv, 3 * H, nullptr, nullptr, P + o.bqkv,
                 nullptr, 0, kNoDrop, 1, 0, st));
         CK(attention_forward(dt, ws + w.qkv, attention_mask, ws + w.ctx, B, L, nh,
@@ -423,7 +453,6 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     }
     // pooler + classifier (+ MSE) (bert.py:231, 304-307; multimodal_driver.py:372-373)
     float* z = (float*)(ws + e->ws_head_z);
-    if (optw) { CK((int)hipStreamWaitEvent(st, e->oev[2 + c.num_layers], 0)); e->opt_pending = false; }   // pooler + classifier
     CK(gemm(dt, GEMM_NT, EPI_BIAS_F32, B, H, H, ws + e->ws_x[c.num_layers], L * H, e->W(e->wp), H, nullptr, H, nullptr, z,
             P + e->bp, nullptr, 0, kNoDrop, 1, 64, st));
     if (loss) CK((int)hipMemsetAsync(loss, 0, 4, st));
@@ -475,18 +504,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             // dgrad chain; dY buffers are per-LayerNorm (A/B) and the stage ends with a join, which keeps them race-free.
             hipStream_t ss = st;
             if (e->overlap_wgrad) {
-                if (!e->side) {
-                    // MB_SIDE_PRIORITY=1: lowest dispatch priority for the weight-gradient stream (the dgrad chain is the critical
-                    // path).  Measured: no effect -- resident wgrad blocks keep their LDS slots for a whole K = T loop, priority
-                    // only orders NEW workgroups -- so the default stays the normal priority.
-                    int least = 0, greatest = 0;
-                    CK((int)hipDeviceGetStreamPriorityRange(&least, &greatest));
-                    const char* pv = getenv("MB_SIDE_PRIORITY");
-                    const int prio = (pv && atoi(pv) != 0) ? least : 0;
-                    CK((int)hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio));
-                    e->evs.assign((size_t)NL * 5, nullptr);
-                    for (auto& ev : e->evs) CK((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-                }
+                CK(ensure_side(e));
                 ss = e->side;
             }
             hipEvent_t* sev = e->overlap_wgrad ? &e->evs[(size_t)l * 5] : nullptr;
@@ -510,14 +528,6 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                               wgrad_args(3 * H, H, Tk, dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H)};
             const bool grouped = e->deferred;
             if (grouped && !gemm_grouped_tn_ok(dt, wg, 4, e->group_wgrad)) return MB_ERR_SHAPE;
-            const bool fused = grouped && e->fuse;
-            if (fused)
-                for (GemmArgs& a : wg) {
-                    const size_t off = (size_t)(a.Cf - G);
-                    a.ad_p = P + off; a.ad_m = e->FM + off; a.ad_v = e->FV + off;
-                    a.ad_sh = dt == DT_BF16 ? (void*)((bf16*)e->SH + off) : nullptr;
-                    a.adam = e->fa;
-                }
             if (!grouped) {
             CK(fork(0));
             CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, ss));
@@ -550,20 +560,17 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             auto launch_group = [&]() -> int {
                 CK(fork(3));
                 if (e->prof) CK((int)hipEventRecord(e->pev[2 * l], ss));
-                CK(gemm_grouped_tn_launch(dt, wg, 4, e->group_wgrad, ss, fused ? EPI_ADAMW : EPI_ACCUM_F32));
+                CK(gemm_grouped_tn_launch(dt, wg, 4, e->group_wgrad, ss));
                 if (e->prof) CK((int)hipEventRecord(e->pev[2 * l + 1], ss));
                 return (int)hipEventRecord(sev[4], ss);       // "weight gradients (or updated weights) of layer l are final"
             };
-            if (grouped && !fused) CK(launch_group());
+            if (grouped) CK(launch_group());
             if (!grouped) {
                 CK(fork(3));
                 CK(wgrad(dt, 3 * H, H, Tk, dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H, ss));
             }
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, 3 * H, dqkv, 3 * H, e->W(o.wqkv), H, dx, H, nullptr, nullptr,
                     nullptr, dsB, H, kNoDrop, 1, 0, st));
-            // fused optimizer: the launch rewrites this layer's weights, so it may only start once the layer's last reader
-            // (the dgrad above) has been enqueued in front of the fork event
-            if (fused) CK(launch_group());
             if (ss != st && !grouped) {      // join: the stage's gradients are complete (and dY buffers reusable) once main passes this
                 CK((int)hipEventRecord(sev[4], ss));
                 CK((int)hipStreamWaitEvent(st, sev[4], 0));
@@ -575,7 +582,6 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
         } else {
             // ---- MAG + embeddings
             if (e->deferred && e->side) CK((int)hipStreamWaitEvent(st, e->evs[4], 0));      // weight gradients of layer 0
-            e->fuse = false;                                                                  // one-shot: re-arm every step
             char* dx = ws + e->ws_dxa;
             char* de = ws + e->ws_dxb;
             CK(mag_bwd_impl(dt, dx, ws + e->ws_emb, P + e->mag_bhv, P + e->mag_bha, P + e->mag_bv, P + e->mag_ba,
@@ -592,65 +598,105 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
     return MB_OK;
 }
 
-int mb_bert_fuse_adamw(mb_bert_engine* e, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay,
-                       int step, int correct_bias, float grad_scale) {
-    if (!e) return MB_ERR_ARG;
-    if (!m || !v) { e->fuse = false; return MB_OK; }
-    if (!e->deferred) return MB_ERR_MODE;
-    e->FM = m; e->FV = v;
-    AdamArgs& a = e->fa;
-    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale;
-    double ss = lr;
-    if (correct_bias) ss = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
-    a.step_size = (float)ss;
-    e->fuse = true;
+// ------------------------------------------------------------------------------------------------ whole step
+// One optimizer step of train_epoch (/root/reference/multimodal_driver.py:354-388: batch -> forward -> MSE -> backward ->
+// optimizer.step() -> optimizer.zero_grad()) as two launches: the step prologue (this step's batch, dropout keys and AdamW
+// scalars into device memory) and a replayed hipGraph holding every other kernel of the step, including the side-stream
+// fork / join of the weight-gradient launches.  mode 1 = graph replay (captured on first use per shape), mode 2 = the same
+// kernel sequence launched one by one (A/B reference for the graph; also what runs while profiling events are on).
+static int enqueue_step(mb_bert_engine* e, int B, int L, float* logits, float* loss, float* loss_run, float* m, float* v,
+                        float loss_scale, hipStream_t st) {
+    char* ws = e->ws;
+    const float* lab = (const float*)(ws + e->ws_in_lab);
+    CK(mb_bert_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
+                       (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
+                       loss_run, st));
+    CK(mb_bert_backward(e, nullptr, lab, loss_scale, 0, e->c.num_layers + 2, st));
+    if (m && v) {
+        const AdamArgs none = {};
+        const size_t nd = e->n_decay, n = e->n_params;
+        void* sh = e->c.dtype == DT_BF16 ? (void*)e->SH : nullptr;
+        CK(adamw_step(e->P, e->G, m, v, sh, nd, nd, e->sh_begin, e->sh_end, none, 1, st, e->adam_state()));
+        CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state() + 1));
+    }
     return MB_OK;
 }
 
-int mb_bert_fused_range(const mb_bert_engine* e, size_t* begin, size_t* end) {
-    if (!e || !begin || !end) return MB_ERR_ARG;
-    *begin = e->lo[0].wqkv;            // the encoder GEMM weights: layer 0 query ... layer NL-1 output.dense
-    *end = e->wp;
-    return e->deferred ? MB_OK : MB_ERR_MODE;
+int mb_bert_train_step(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                       const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                       uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, float* m, float* v, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int opt_step, int correct_bias, float grad_scale,
+                       float loss_scale, int mode, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!e || !e->P || !e->G || !e->ws) return MB_ERR_ARG;
+    const mb_bert_config& c = e->c;
+    if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
+    if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !labels || !logits || !loss) return MB_ERR_ARG;
+    if ((m == nullptr) != (v == nullptr) || (mode != 1 && mode != 2)) return MB_ERR_ARG;
+    const int T = B * L;
+    char* ws = e->ws;
+    CK(ensure_side(e));
+    e->training = 1;
+    CK(prepare_pass(e, T, st));
+    // ---- this step's values -> device memory
+    PrologueArgs pa = {};
+    auto cp = [&](const void* src, size_t off, size_t bytes) {
+        pa.src[pa.ncopies] = (const uint32_t*)src; pa.dst[pa.ncopies] = (uint32_t*)(ws + off); pa.dwords[pa.ncopies] = (uint32_t)(bytes / 4);
+        ++pa.ncopies;
+    };
+    cp(input_ids, e->ws_in_ids, (size_t)T * 8); cp(token_type_ids, e->ws_in_seg, (size_t)T * 8); cp(attention_mask, e->ws_in_mask, (size_t)T * 8);
+    cp(visual, e->ws_in_vis, (size_t)T * c.visual_dim * 4); cp(acoustic, e->ws_in_aco, (size_t)T * c.acoustic_dim * 4);
+    cp(labels, e->ws_in_lab, (size_t)B * c.num_labels * 4);
+    pa.seed = seed; pa.step = step; pa.keys = e->key_state(); pa.nsites = e->nsites;
+    if (m) {
+        double ss = lr;
+        if (correct_bias) ss = (double)lr * sqrt(1.0 - pow((double)beta2, (double)opt_step)) / (1.0 - pow((double)beta1, (double)opt_step));
+        AdamArgs a;
+        a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.step_size = (float)ss;
+        a.grad_scale = grad_scale;
+        pa.adam[0] = a;
+        a.weight_decay = 0.f;
+        pa.adam[1] = a;
+        pa.adam_dst = e->adam_state();
+    }
+    CK(step_prologue(pa, st));
+    if (mode == 2 || e->prof) {
+        e->dyn = true;
+        const int r = enqueue_step(e, B, L, logits, loss, loss_run, m, v, loss_scale, st);
+        e->dyn = false;
+        return r;
+    }
+    mb_bert_engine::StepGraph* g = nullptr;
+    for (auto& x : e->graphs)
+        if (x.B == B && x.L == L && x.with_opt == (m != nullptr) && x.logits == logits && x.loss == loss && x.loss_run == loss_run &&
+            x.m == m && x.v == v && x.loss_scale == loss_scale && x.st == st) { g = &x; break; }
+    if (!g) {
+        if (e->graphs.size() >= 32) {          // callers that keep changing output pointers: do not grow without bound
+            hipGraphExecDestroy(e->graphs.front().exec); hipGraphDestroy(e->graphs.front().graph);
+            e->graphs.erase(e->graphs.begin());
+        }
+        mb_bert_engine::StepGraph ng = {B, L, m != nullptr, logits, loss, loss_run, m, v, loss_scale, st, nullptr, nullptr};
+        CK((int)hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        e->dyn = true; e->capturing = true;
+        const int r = enqueue_step(e, B, L, logits, loss, loss_run, m, v, loss_scale, st);
+        e->dyn = false; e->capturing = false;
+        const int r2 = (int)hipStreamEndCapture(st, &ng.graph);
+        if (r) { if (ng.graph) hipGraphDestroy(ng.graph); return r; }
+        CK(r2);
+        CK((int)hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0));
+        e->graphs.push_back(ng);
+        g = &e->graphs.back();
+        ++e->graph_captures;
+    }
+    CK((int)hipGraphLaunch(g->exec, st));
+    ++e->graph_launches;
+    return MB_OK;
 }
 
-int mb_bert_adamw_pipelined(mb_bert_engine* e, float* m, float* v, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, int step, int correct_bias, float grad_scale, int zero_grad, void* stream) {
-    if (!e || !m || !v || !e->P || !e->G) return MB_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const int NL = e->c.num_layers;
-    if (!e->opt_stream) {
-        CK((int)hipStreamCreateWithFlags(&e->opt_stream, hipStreamNonBlocking));
-        e->oev.assign((size_t)NL + 3, nullptr);
-        for (auto& ev : e->oev) CK((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
-    if (e->opt_pending) CK(mb_bert_adamw_join(e, stream));       // two steps without a forward in between
-    AdamArgs a;
-    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale;
-    double ss = lr;
-    if (correct_bias) ss = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
-    a.step_size = (float)ss;
-    hipStream_t os = e->opt_stream;
-    CK((int)hipEventRecord(e->oev[0], st));                      // every gradient is final on the caller's stream
-    CK((int)hipStreamWaitEvent(os, e->oev[0], 0));
-    auto upd = [&](size_t b, size_t en) -> int {                 // one range, entirely inside the decay or the no-decay group
-        if (en <= b) return MB_OK;
-        const size_t n = en - b;
-        const size_t sb = std::min(std::max(e->sh_begin, b), en) - b, se = std::min(std::max(e->sh_end, b), en) - b;
-        void* sh = e->c.dtype == DT_BF16 ? (void*)((bf16*)e->SH + b) : nullptr;
-        return adamw_step(e->P + b, e->G + b, m + b, v + b, sh, n, b < e->n_decay ? n : 0, sb, se, a, zero_grad, os);
-    };
-    // chunk 0: what the forward touches first -- embedding tables + MAG weights, embeddings LayerNorm, MAG biases + LayerNorm
-    CK(upd(e->word, e->wc)); CK(upd(e->emb_lnw, e->bp)); CK(upd(e->mag_bhv, e->bc));
-    CK((int)hipEventRecord(e->oev[1], os));
-    for (int l = 0; l < NL; ++l) {
-        CK(upd(e->lo[l].wqkv, l + 1 < NL ? e->lo[l + 1].wqkv : e->wp));
-        CK(upd(e->lo[l].bqkv, l + 1 < NL ? e->lo[l + 1].bqkv : e->emb_lnw));
-        CK((int)hipEventRecord(e->oev[2 + l], os));
-    }
-    CK(upd(e->wp, e->sh_end)); CK(upd(e->wc, e->n_decay)); CK(upd(e->bp, e->mag_bhv)); CK(upd(e->bc, e->n_params));
-    CK((int)hipEventRecord(e->oev[2 + NL], os));
-    e->opt_pending = true;
+int mb_bert_graph_stats(const mb_bert_engine* e, size_t* captures, size_t* launches) {
+    if (!e) return MB_ERR_ARG;
+    if (captures) *captures = e->graph_captures;
+    if (launches) *launches = e->graph_launches;
     return MB_OK;
 }
 

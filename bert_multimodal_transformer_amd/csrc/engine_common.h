@@ -5,6 +5,8 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
+#include <algorithm>
 #include "kernels.h"
 #include "../../include/magbert_hip.h"
 
@@ -31,6 +33,7 @@ inline uint64_t splitmix64(uint64_t x) {
 
 inline DropKey make_key(uint64_t seed, uint64_t step, uint32_t site, float p) {
     DropKey k;
+    k.dyn = nullptr;
     if (!(p > 0.f)) { k.k0 = k.k1 = k.thresh = 0; k.scale = 1.f; return k; }
     const uint64_t h = splitmix64(splitmix64(seed) ^ splitmix64(step * 0x100000001B3ull + site));
     k.k0 = (uint32_t)h;
@@ -41,10 +44,10 @@ inline DropKey make_key(uint64_t seed, uint64_t step, uint32_t site, float p) {
     k.scale = 1.0f / (1.0f - p);
     return k;
 }
-const DropKey kNoDrop = {0u, 0u, 0u, 1.0f};
+const DropKey kNoDrop = {0u, 0u, 0u, 1.0f, nullptr};
 inline DropKey dk(const mb_dropkey* d) {
     if (!d) return kNoDrop;
-    DropKey k = {d->k0, d->k1, d->thresh, d->scale};
+    DropKey k = {d->k0, d->k1, d->thresh, d->scale, nullptr};
     return k;
 }
 
@@ -100,7 +103,6 @@ inline GemmArgs wgrad_args(int Mo, int No, int rows, const void* dY, int ldy, co
     a.A = dY; a.B = X; a.M = Mo; a.N = No; a.K = rows; a.lda = ldy; a.ldb = ldx;
     a.C = nullptr; a.ldc = ldw; a.C2 = nullptr; a.Cf = dW; a.bias = nullptr; a.colsum = nullptr; a.R = nullptr; a.ldr = 0;
     a.alpha = 1.0f; a.drop = kNoDrop; a.kchunk = rows; a.dbg = 0; a.reg_m = a.reg_n = a.tpr_m = a.tpr_n = 0;
-    a.ad_p = a.ad_m = a.ad_v = nullptr; a.ad_sh = nullptr; a.adam = AdamArgs{};
     return a;
 }
 

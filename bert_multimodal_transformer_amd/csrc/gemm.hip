@@ -171,51 +171,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         if (p.bias && n < p.N) Vec8<float>::load(p.bias + n, bias8);
     }
     T* __restrict__ C = (T*)p.C;
-    if constexpr (MODE == EPI_ADAMW) {
-        // optimizer-in-backward: the fp32 accumulator is the complete gradient of these weights (the gradient buffer is not
-        // touched and stays zero).  p / m / v come cold from HBM: the loads of CH rows (12 x 32 B per thread) are issued
-        // before the first use so the epilogue is bandwidth- and not latency-bound.  Same operation order as adamw_kernel.
-        constexpr int CH = 4;
-        const float omb1 = 1.0f - p.adam.beta1, omb2 = 1.0f - p.adam.beta2, decay = p.adam.lr * p.adam.weight_decay;
-        for (int r0 = tid / TPR; r0 < BM; r0 += RPP * CH) {
-            float pv[CH][8], mv[CH][8], vv[CH][8];
-            bool ok[CH];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const int r = r0 + k * RPP, m = m0 + r;
-                ok[k] = r < BM && m < p.M && n < p.N;
-                if (ok[k]) {
-                    const size_t off = (size_t)m * p.ldc + n;
-                    Vec8<float>::load(p.ad_p + off, pv[k]);
-                    Vec8<float>::load(p.ad_m + off, mv[k]);
-                    Vec8<float>::load(p.ad_v + off, vv[k]);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                if (!ok[k]) continue;
-                const int r = r0 + k * RPP;
-                const size_t off = (size_t)(m0 + r) * p.ldc + n;
-                const int ch = c >> 2;
-                const f32x4 a = *(const f32x4*)(smem + r * RBY + ((ch ^ (r & 7)) << 4));
-                const f32x4 b = *(const f32x4*)(smem + r * RBY + (((ch + 1) ^ (r & 7)) << 4));
-                const float gr[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float g = gr[q] * p.adam.grad_scale;
-                    mv[k][q] = p.adam.beta1 * mv[k][q] + omb1 * g;
-                    vv[k][q] = p.adam.beta2 * vv[k][q] + omb2 * g * g;
-                    pv[k][q] -= p.adam.step_size * (mv[k][q] / (sqrtf(vv[k][q]) + p.adam.eps));
-                    if (decay > 0.f) pv[k][q] -= decay * pv[k][q];
-                }
-                Vec8<float>::store(p.ad_p + off, pv[k]);
-                Vec8<float>::store(p.ad_m + off, mv[k]);
-                Vec8<float>::store(p.ad_v + off, vv[k]);
-                if (p.ad_sh) Vec8<bf16>::store((bf16*)p.ad_sh + off, pv[k]);
-            }
-        }
-        return;
-    }
+    DropKey dkey = p.drop;
+    dkey.resolve();
 #pragma unroll 2
     for (int r = tid / TPR; r < BM; r += RPP) {
         const int m = m0 + r;
@@ -238,7 +195,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
             float g[8];
             const uint32_t gidx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;   // XLNet drops the activation (modeling_xlnet FF)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { v[q] += bias8[q]; g[q] = gelu_f(v[q]) * drop_mult(p.drop, gidx + q); }
+            for (int q = 0; q < 8; ++q) { v[q] += bias8[q]; g[q] = gelu_f(v[q]) * drop_mult(dkey, gidx + q); }
             Vec8<T>::store(C + off, v);
             Vec8<T>::store((T*)p.C2 + off, g);
         } else if constexpr (MODE == EPI_BIAS_DROP_RES) {
@@ -246,7 +203,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
             Vec8<T>::load((const T*)p.R + (size_t)m * p.ldr + n, res);
             const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = (v[q] + bias8[q]) * drop_mult(p.drop, idx + q) + res[q];
+            for (int q = 0; q < 8; ++q) v[q] = (v[q] + bias8[q]) * drop_mult(dkey, idx + q) + res[q];
             Vec8<T>::store(C + off, v);
         } else if constexpr (MODE == EPI_ADD_RES) {
             if (p.R) {
@@ -261,7 +218,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
             Vec8<T>::load((const T*)p.R + (size_t)m * p.ldr + n, u);
             const uint32_t gidx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { v[q] *= dgelu_f(u[q]) * drop_mult(p.drop, gidx + q); cs[q] += v[q]; }
+            for (int q = 0; q < 8; ++q) { v[q] *= dgelu_f(u[q]) * drop_mult(dkey, gidx + q); cs[q] += v[q]; }
             Vec8<T>::store(C + off, v);
         } else if constexpr (MODE == EPI_ACCUM_F32) {
             float* dst = p.Cf + off;
@@ -375,7 +332,16 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) char*)(p))
 
-template <int RB> __device__ __forceinline__ int kswz(int k) { return RB >= 256 ? ((k & 3) << 1) : (((k >> 1) & 1) << 1); }
+// XOR applied to the 16-byte chunk index of k-row k of a kmaj image (bit 0 stays clear: the 32-byte block a 16-lane group
+// of ds_read_b64_tr_b16 reads stays contiguous).  A half-wave of the transpose read touches 8 k-rows -- k0 + {0,1,2,3} and
+// k0 + 8 + {0,1,2,3} -- at the same columns, so the swizzle must send those 8 rows to the 8 different 32-byte windows of the
+// 256-byte bank line: bits (k & 3, k >> 3 & 1) for 256-byte rows, (k >> 1 & 1, k >> 3 & 1) for 128-byte rows (two rows per
+// bank line, k & 1 already separates them).  The round-1 form ignored k >> 3: rows k and k + 8 collided (2-way conflict on
+// every transpose read = the 33-50 % conflict cycles of profiles/r01_gemm_pmc.md); MB_GEMM_DBG & 8 selects it for A/B runs.
+template <class T, int RB> __device__ __forceinline__ int kswz(int k, bool r1 = false) {
+    if (sizeof(T) != 2 || r1) return RB >= 256 ? ((k & 3) << 1) : (((k >> 1) & 1) << 1);
+    return RB >= 256 ? (((k & 3) | (((k >> 3) & 1) << 2)) << 1) : ((((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1);
+}
 
 // KB = bytes of k per stage row (128 or 64).  A smaller KB halves the stage, so twice as many stages (bytes in flight)
 // fit next to the stage being multiplied -- the fill rate of a CU is latency x bytes-in-flight bound.
@@ -392,7 +358,7 @@ struct Dma {
     static __device__ __forceinline__ int rswz(int lc, int r) { return KB == 128 ? (lc ^ (r & 7)) : (lc ^ ((r >> 1) & 3)); }
 
     static __device__ __forceinline__ void issue(const T* __restrict__ base, int ld, int row0, int nrows, int k0,
-                                                 char* lds, int lane, int wave) {
+                                                 char* lds, int lane, int wave, bool r1) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int blk = i * 4 + wave;
@@ -407,7 +373,7 @@ struct Dma {
                 constexpr int RPK = 1024 / RB;
                 const int kl = blk * RPK + (lane * 16) / RB;
                 const int pc = ((lane * 16) % RB) >> 4;
-                const int lc = pc ^ kswz<RB>(kl);
+                const int lc = pc ^ kswz<T, RB>(kl, r1);
                 src = base + (size_t)(k0 + kl) * ld + row0 + lc * EPV;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -416,7 +382,7 @@ struct Dma {
     }
 
     // fragment for image rows rbase + (lane & 15), k-slab s (64 bytes of k)
-    static __device__ __forceinline__ frag_t frag(const char* lds, int rbase, int s, int lane) {
+    static __device__ __forceinline__ frag_t frag(const char* lds, int rbase, int s, int lane, bool r1) {
         if constexpr (!KMAJ) {
             const int r = rbase + (lane & 15);
             const int lc = s * 4 + (lane >> 4);
@@ -428,7 +394,7 @@ struct Dma {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = s * 32 + (lane >> 4) * 8 + h * 4 + (i >> 2);
-                const int pc = (colb >> 4) ^ kswz<RB>(k);
+                const int pc = (colb >> 4) ^ kswz<T, RB>(k, r1);
                 u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (__attribute__((address_space(3))) s16x4*)LDS_PTR(lds + k * RB + (pc << 4) + (colb & 15)));
             }
@@ -439,7 +405,7 @@ struct Dma {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = s * 16 + (lane >> 4) * 4 + j;
-                const int pc = (colb >> 4) ^ kswz<RB>(k);
+                const int pc = (colb >> 4) ^ kswz<T, RB>(k, r1);
                 v[j] = *(const float*)(lds + k * RB + (pc << 4) + (colb & 15));
             }
             return v;
@@ -480,11 +446,12 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int bid, con
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const bool r1 = (p.dbg & 8) != 0;
     auto issue = [&](int t) {
         if (p.dbg & 1) return;
         char* st = smem + (t % NSTAGE) * STAGE;
-        DA::issue(A, p.lda, m0, p.M, kbeg + t * BKE, st, lane, wave);
-        DB::issue(B, p.ldb, n0, p.N, kbeg + t * BKE, st + BM * KB, lane, wave);
+        DA::issue(A, p.lda, m0, p.M, kbeg + t * BKE, st, lane, wave, r1);
+        DB::issue(B, p.ldb, n0, p.N, kbeg + t * BKE, st + BM * KB, lane, wave, r1);
     };
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
@@ -505,9 +472,9 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int bid, con
             frag_t a[MT], b[NT];
             if (!(p.dbg & 4)) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = DA::frag(cur, wr * (BM / 2) + i * 16, s, lane);
+                for (int i = 0; i < MT; ++i) a[i] = DA::frag(cur, wr * (BM / 2) + i * 16, s, lane, r1);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = DB::frag(cur + BM * KB, wc * (BN / 2) + j * 16, s, lane);
+                for (int j = 0; j < NT; ++j) b[j] = DB::frag(cur + BM * KB, wc * (BN / 2) + j * 16, s, lane, r1);
             } else {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) asm volatile("" : "=v"(a[i]));
@@ -540,7 +507,7 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const GemmArgs p) {
 // gradients alone is at most ~2 blocks per CU (one under-filled round whose duration is set by the K = T loop latency,
 // not by its size); launched together they are one grid of ~7 blocks per CU that keeps every CU's LDS ring full.
 // Problem g owns blocks [first[g], first[g+1]) (multiples of 8, so block -> XCD mapping is unchanged).
-template <class T, int BM, int BN, int NSTAGE, int KB, int MODE>
+template <class T, int BM, int BN, int NSTAGE, int KB>
 __global__ void __launch_bounds__(256) gemm2_grouped_tn_kernel(const GroupedGemmArgs ga) {
     __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB>::BYTES];
     // (A persistent variant that holds only one LDS slot per CU -- MB_GROUP_GRID = 128 / 256 / 384 blocks looping over the 432
@@ -550,7 +517,7 @@ __global__ void __launch_bounds__(256) gemm2_grouped_tn_kernel(const GroupedGemm
     for (int i = 1; i < MB_MAX_GROUP; ++i)
         if (i < ga.count && (int)blockIdx.x >= ga.first[i]) g = i;
     g = __builtin_amdgcn_readfirstlane(g);
-    gemm2_body<T, BM, BN, true, true, MODE, NSTAGE, KB>(ga.g[g], (int)blockIdx.x - ga.first[g], 0, smem);
+    gemm2_body<T, BM, BN, true, true, EPI_ACCUM_F32, NSTAGE, KB>(ga.g[g], (int)blockIdx.x - ga.first[g], 0, smem);
 }
 
 // ---------------------------------------------------------------------------------------------- host
@@ -660,7 +627,7 @@ static int launch_T(const GemmArgs& a, int layout, int mode, int splits, int til
 }
 
 template <class T, int BM, int BN>
-static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st, int mode) {
+static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
     constexpr int BKE = 128 / sizeof(T);
     constexpr int EPV = 16 / sizeof(T);
     GroupedGemmArgs ga;
@@ -676,20 +643,17 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st, int 
         ga.first[i] = total;
         total += choose_regions<BM, BN>(p);
         p.kchunk = p.K;
-        p.dbg = 0;
+        if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
+        p.dbg = g_dbg & 8;
     }
     ga.first[count] = total;
     static int g_gstages = -1;       // MB_GROUP_STAGES: ring depth of the grouped kernel (2 | 3)
     if (g_gstages < 0) g_gstages = env_int("MB_GROUP_STAGES", 2);
     const int grid = total;
-    if (mode == EPI_ADAMW) {
-        for (int i = 0; i < count; ++i)
-            if (!ga.g[i].ad_p || !ga.g[i].ad_m || !ga.g[i].ad_v) return MB_ERR_ARG;
-        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128, EPI_ADAMW>), dim3(grid), dim3(256), 0, st, ga);
-    } else if (g_gstages >= 3) {
-        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 3, 128, EPI_ACCUM_F32>), dim3(grid), dim3(256), 0, st, ga);
+    if (g_gstages >= 3) {
+        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 3, 128>), dim3(grid), dim3(256), 0, st, ga);
     } else {
-        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128, EPI_ACCUM_F32>), dim3(grid), dim3(256), 0, st, ga);
+        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128>), dim3(grid), dim3(256), 0, st, ga);
     }
     return (int)hipGetLastError();
 }
@@ -706,11 +670,10 @@ int gemm_grouped_tn_ok(int dtype, const GemmArgs* probs, int count, int tile) {
     return 1;
 }
 
-int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st, int mode) {
+int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st) {
     if (count < 1 || count > MB_MAX_GROUP) return MB_ERR_ARG;
-    if (mode != EPI_ACCUM_F32 && mode != EPI_ADAMW) return MB_ERR_MODE;
-    if (dtype == DT_BF16) return tile == 128 ? launch_grouped<bf16, 128, 128>(probs, count, st, mode) : launch_grouped<bf16, 64, 64>(probs, count, st, mode);
-    if (dtype == DT_F32) return tile == 128 ? launch_grouped<float, 128, 128>(probs, count, st, mode) : launch_grouped<float, 64, 64>(probs, count, st, mode);
+    if (dtype == DT_BF16) return tile == 128 ? launch_grouped<bf16, 128, 128>(probs, count, st) : launch_grouped<bf16, 64, 64>(probs, count, st);
+    if (dtype == DT_F32) return tile == 128 ? launch_grouped<float, 128, 128>(probs, count, st) : launch_grouped<float, 64, 64>(probs, count, st);
     return MB_ERR_DTYPE;
 }
 

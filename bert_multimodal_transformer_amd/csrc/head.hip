@@ -12,6 +12,7 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ bc, const float* __restrict__ labels,
                                                        float* __restrict__ pooled, float* __restrict__ logits, float* loss,
                                                        float* loss_run, int B, int nl, DropKey drop) {
+    drop.resolve();
     constexpr int H = CH * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
@@ -54,6 +55,7 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ pooled, const float* __restrict__ Wc,
                                                        T* __restrict__ dz, float* dWc, float* dbc, int B, int nl,
                                                        DropKey drop) {
+    drop.resolve();
     constexpr int H = CH * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;

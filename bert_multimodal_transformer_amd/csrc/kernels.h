@@ -23,8 +23,7 @@ enum { EPI_BIAS = 0,          // C = alpha*acc + bias                           
        EPI_ADD_RES = 3,       // C = acc (+ R)                                          (T out)
        EPI_DGELU = 4,         // C = acc * gelu'(R)                                     (T out)
        EPI_ACCUM_F32 = 5,     // Cf += acc   (atomic when split-K)                      (fp32 out)
-       EPI_BIAS_F32 = 6,      // Cf = alpha*acc + bias                                  (fp32 out)
-       EPI_ADAMW = 7 };       // grouped wgrad only: acc IS the gradient -> HF AdamW applied to (ad_p, ad_m, ad_v) in place
+       EPI_BIAS_F32 = 6 };    // Cf = alpha*acc + bias                                  (fp32 out)
 
 struct AdamArgs {
     float lr, beta1, beta2, eps, weight_decay, step_size;   // step_size = lr*sqrt(1-b2^t)/(1-b1^t)
@@ -45,9 +44,6 @@ struct GemmArgs {
     int kchunk;                // filled by the launcher
     int dbg;                   // ablation switches (MB_GEMM_DBG): 1 = no DMA issue, 2 = no MFMA, 4 = no LDS fragment reads
     int reg_m, reg_n, tpr_m, tpr_n;   // XCD regions (filled by the launcher): reg_m*reg_n == 8, tiles per region
-    // EPI_ADAMW: parameter master / Adam moments (fp32) and optional bf16 operand shadow, same [M][ldc] layout as Cf
-    float* ad_p; float* ad_m; float* ad_v; void* ad_sh;
-    AdamArgs adam;
 };
 
 // tile: 0 = auto, 64 or 128.  splits: split-K factor (only EPI_ACCUM_F32).
@@ -62,7 +58,7 @@ struct GroupedGemmArgs {
     int count;
 };
 int gemm_grouped_tn_ok(int dtype, const GemmArgs* probs, int count, int tile);
-int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st, int mode = EPI_ACCUM_F32);
+int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------ row kernels (rowops.hip)
 // LayerNorm over the last dim H (H % 256 == 0, H <= 1024): y = (x-mean)*rstd*gamma + beta ; optional dropout on y.
@@ -162,7 +158,23 @@ int head_backward(int dtype, const float* dlogits, const float* logits, const fl
 // ------------------------------------------------------------------------------------------ optimizer (adamw.hip)
 // transformers 3.0.2 AdamW over flat fp32 buffers; elements [0, n_decay) use weight_decay, the rest 0.
 // shadow (bf16, may be null): shadow[i] = bf16(p[i]) for i in [sh_begin, sh_end). zero_grad: g <- 0 after use.
+// dyn (device pointer, may be null): when set, the hyper-parameters are read from *dyn instead of `a` (replayed step graphs)
 int adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, size_t n_decay,
-               size_t sh_begin, size_t sh_end, AdamArgs a, int zero_grad, hipStream_t st);
+               size_t sh_begin, size_t sh_end, AdamArgs a, int zero_grad, hipStream_t st, const AdamArgs* dyn = nullptr);
+
+// ------------------------------------------------------------------------------------------ step prologue (rowops.hip)
+// Everything that changes from one optimizer step to the next, moved into device memory by ONE small launch so that the rest
+// of the step can be a replayed hipGraph: the six batch tensors (gathered into the engine's fixed staging buffers), the
+// dropout keys of every site for (seed, step) -- same derivation as make_key() on the host -- and the AdamW scalars of the
+// two parameter groups (lr, bias-corrected step size, gradient scale).
+#define MB_PROLOGUE_MAX_COPIES 8
+struct PrologueArgs {
+    const uint32_t* src[MB_PROLOGUE_MAX_COPIES]; uint32_t* dst[MB_PROLOGUE_MAX_COPIES]; uint32_t dwords[MB_PROLOGUE_MAX_COPIES];
+    int ncopies;
+    uint64_t seed, step;
+    uint32_t* keys; int nsites;            // keys[2 * site + {0, 1}]
+    AdamArgs adam[2]; AdamArgs* adam_dst;  // may be null
+};
+int step_prologue(const PrologueArgs& a, hipStream_t st);
 
 }  // namespace mb

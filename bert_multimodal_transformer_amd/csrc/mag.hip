@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(256) mag_gate_fwd_kernel(const T* __restrict__
                                                            const float* __restrict__ beta, float ln_eps, float beta_shift,
                                                            T* __restrict__ out, float* mean, float* rstd, int rows,
                                                            DropKey drop) {
+    drop.resolve();
     constexpr int H = CH * 256;
     constexpr float invH = 1.0f / H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,6 +153,7 @@ __global__ void __launch_bounds__(256) mag_gate_bwd_kernel(const T* __restrict__
                                                            T* __restrict__ dZv, T* __restrict__ dZa, float* db_hv,
                                                            float* db_ha, float* db_v, float* db_a, float* dgamma,
                                                            float* dbeta, int rows, DropKey drop) {
+    drop.resolve();
     constexpr int H = CH * 256;
     constexpr float invH = 1.0f / H;
     __shared__ float lds[4 * 6 * H];

@@ -37,6 +37,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
                                                      const float* __restrict__ beta, float eps, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                      DropKey drop) {
+    drop.resolve();
     constexpr int H = CH * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
@@ -85,6 +86,8 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
                                                      T* __restrict__ dx_drop, float* dgamma, float* dbeta, float* dbias,
                                                      int rows, DropKey drop_out, DropKey drop_in) {
+    drop_out.resolve();
+    drop_in.resolve();
     constexpr int H = CH * 256;
     constexpr float invH = 1.0f / H;
     __shared__ float lds[4 * 3 * H];
@@ -186,6 +189,7 @@ __global__ void __launch_bounds__(256) embed_fwd_kernel(const int64_t* __restric
                                                         const float* __restrict__ beta, float eps, T* __restrict__ out,
                                                         float* __restrict__ mean, float* __restrict__ rstd, int rows, int L,
                                                         DropKey drop) {
+    drop.resolve();
     constexpr int H = CH * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
@@ -221,6 +225,7 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
                                                         const float* __restrict__ rstd, float* __restrict__ dsum_ws,
                                                         float* dword, float* dgamma, float* dbeta, int rows, int L,
                                                         int pad_id, DropKey drop) {
+    drop.resolve();
     constexpr int H = CH * 256;
     constexpr float invH = 1.0f / H;
     __shared__ float lds[4 * 2 * H];
@@ -463,6 +468,55 @@ int widen(int dtype, const void* src, float* dst, size_t n, hipStream_t st) {
     unsigned grid = (unsigned)((n4 + 255) / 256);
     if (grid > 4096) grid = 4096;
     MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((widen_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)src, dst, n4); })
+    return (int)hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------ step prologue
+// Device twin of make_key() (engine_common.h): k = splitmix64(splitmix64(seed) ^ splitmix64(step * FNV + site)).
+__device__ __forceinline__ uint64_t splitmix64_dev(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void __launch_bounds__(256) step_prologue_kernel(const PrologueArgs a) {
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+    if (blockIdx.x == 0) {
+        for (int s = threadIdx.x; s < a.nsites; s += 256) {
+            const uint64_t h = splitmix64_dev(splitmix64_dev(a.seed) ^ splitmix64_dev(a.step * 0x100000001B3ull + (uint64_t)s));
+            a.keys[2 * s] = (uint32_t)h;
+            a.keys[2 * s + 1] = (uint32_t)(h >> 32);
+        }
+        if (a.adam_dst && threadIdx.x < 2) a.adam_dst[threadIdx.x] = a.adam[threadIdx.x];
+    }
+#pragma unroll 1
+    for (int c = 0; c < a.ncopies; ++c) {
+        const uint32_t* __restrict__ src = a.src[c];
+        uint32_t* __restrict__ dst = a.dst[c];
+        const size_t n = a.dwords[c];
+        if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+            const size_t n4 = n / 4;
+            for (size_t i = tid; i < n4; i += nth) ((u32x4*)dst)[i] = ((const u32x4*)src)[i];
+            for (size_t i = n4 * 4 + tid; i < n; i += nth) dst[i] = src[i];
+        } else {
+            for (size_t i = tid; i < n; i += nth) dst[i] = src[i];
+        }
+    }
+}
+
+int step_prologue(const PrologueArgs& a, hipStream_t st) {
+    if (a.ncopies < 0 || a.ncopies > MB_PROLOGUE_MAX_COPIES || a.nsites < 0 || (a.nsites > 0 && !a.keys)) return MB_ERR_ARG;
+    size_t most = 0;
+    for (int c = 0; c < a.ncopies; ++c) {
+        if (a.dwords[c] && (!a.src[c] || !a.dst[c])) return MB_ERR_ARG;
+        if (a.dwords[c] > most) most = a.dwords[c];
+    }
+    unsigned grid = (unsigned)((most / 4 + 255) / 256);
+    if (grid < 1) grid = 1;
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(step_prologue_kernel, dim3(grid), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 

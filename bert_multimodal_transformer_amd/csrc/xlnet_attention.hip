@@ -33,6 +33,7 @@ template <class T, int LP, int NW>
 __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ kr,
                                                               XlParams xp, T* __restrict__ vec, T* __restrict__ psave,
                                                               int L, int nh, DropKey drop) {
+    drop.resolve();
     typedef AttnCfg<T> C;
     constexpr int RP = 2 * LP;
     constexpr int PIT = C::ROWB + 16;
@@ -207,6 +208,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
                                                                 T* __restrict__ gsave, T* __restrict__ dqkv, float* d_rwb,
                                                                 float* d_rrb, float* d_rsb, float* d_seg, int L, int nh,
                                                                 DropKey drop) {
+    drop.resolve();
     typedef AttnCfg<T> C;
     constexpr int RP = 2 * LP;
     constexpr int PIT = C::ROWB + 16;
@@ -344,6 +346,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv_kernel(const T* __rest
                                                                  const T* __restrict__ gsave, const T* __restrict__ dvec,
                                                                  T* __restrict__ dqkv, T* __restrict__ dkr, int L, int nh,
                                                                  DropKey drop) {
+    drop.resolve();
     typedef AttnCfg<T> C;
     constexpr int PIT = C::ROWB + 16;
     constexpr int SPIT = LP * (int)sizeof(T) + 16;

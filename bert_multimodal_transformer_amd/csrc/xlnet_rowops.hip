@@ -7,6 +7,7 @@ namespace mb {
 template <class T>
 __global__ void __launch_bounds__(256) gather_drop_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
                                                               T* __restrict__ out, int rows, int H, DropKey drop) {
+    drop.resolve();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
@@ -27,6 +28,7 @@ __global__ void __launch_bounds__(256) gather_drop_fwd_kernel(const int64_t* __r
 template <class T, int RC>
 __global__ void __launch_bounds__(256) gather_drop_bwd_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids,
                                                               float* dword, int rows, int H, DropKey drop) {
+    drop.resolve();
     const int col = blockIdx.y * 256 + threadIdx.x;
     if (col >= H) return;
     const int r0 = blockIdx.x * RC, r1 = min(rows, r0 + RC);
@@ -48,6 +50,7 @@ __global__ void __launch_bounds__(256) gather_drop_bwd_kernel(const T* __restric
 // pos_seq = arange(L, -L, -1): row p <-> position L - p ; freq d in [0, H/2): inv = 10000^(-2d/H) ; [sin | cos]
 template <class T>
 __global__ void __launch_bounds__(256) pos_emb_kernel(T* __restrict__ out, int B, int L, int H, DropKey drop) {
+    drop.resolve();
     const size_t total = (size_t)B * 2 * L * H;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % H);
@@ -66,6 +69,7 @@ __global__ void __launch_bounds__(256) pos_emb_kernel(T* __restrict__ out, int B
 
 template <class T>
 __global__ void last_token_fwd_kernel(const T* __restrict__ x, T* __restrict__ xs, int B, int L, int H, DropKey drop) {
+    drop.resolve();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * H) return;
     const int b = i / H, c = i % H;
@@ -74,6 +78,7 @@ __global__ void last_token_fwd_kernel(const T* __restrict__ x, T* __restrict__ x
 }
 template <class T>
 __global__ void last_token_bwd_kernel(const T* __restrict__ dxs, T* __restrict__ dx, int B, int L, int H, DropKey drop) {
+    drop.resolve();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * H) return;
     const int b = i / H, c = i % H;

@@ -100,21 +100,33 @@ class GradReducer(object):
             torch.cuda.current_stream(self.g.device).wait_stream(self.comm_stream)
 
 
+def complement(ranges, n):
+    """sorted disjoint (off, len) pieces of [0, n) that no range in `ranges` covers"""
+    out, cur = [], 0
+    for off, ln in sorted(ranges):
+        if off > cur:
+            out.append((cur, off - cur))
+        cur = max(cur, off + ln)
+    if cur < n:
+        out.append((cur, n - cur))
+    return out
+
+
 def stage_plan(core):
-    """[(stage, [large ranges])] + the final small range, from the engine's layout."""
+    """([large ranges of stage s] for every backward stage, [the rest]) from the engine's layout.  The rest -- small tensors
+    that no stage reports as a large range: biases, LayerNorms, the classifier -- is whatever the large ranges leave uncovered,
+    so every trainable element is reduced exactly once whatever the engine reports (MAG-XLNet hands over its whole no-decay
+    block as one large range of its last stage; MAG-BERT's per-layer no-decay spans are small and end up here)."""
     nstage = core.n_layers + 2
-    small_begin = None
     plan = []
     for s in range(nstage):
-        big = []
-        for off, n in core.stage_ranges(s):
-            if n >= (1 << 16):
-                big.append((off, n))
-        plan.append(big)
-    # everything that is not in a big range: classifier weight + the whole no-decay group live at the tail
-    covered_end = max(off + n for big in plan for off, n in big if off < core.n_decay)
-    small_begin = covered_end
-    return plan, (small_begin, core.n_params - small_begin)
+        plan.append([(off, n) for off, n in core.stage_ranges(s) if n >= (1 << 16)])
+    seen = [r for big in plan for r in big]
+    for i, (o1, n1) in enumerate(sorted(seen)):
+        for o2, n2 in sorted(seen)[i + 1:]:
+            if o2 < o1 + n1:
+                raise RuntimeError("engine stage ranges overlap: (%d,%d) and (%d,%d)" % (o1, n1, o2, n2))
+    return plan, complement(seen, core.n_params)
 
 
 class DataParallel(object):
@@ -140,14 +152,14 @@ class DataParallel(object):
         self.optimizer = optimizer
         self.late_ranges = []
         self.split_last = os.environ.get("MB_DP_SPLIT_LAST", "1") != "0"
+        # exposed communication: timing events around the two places where the compute stream waits for the comm stream
+        self._tev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.core.grads.is_cuda else None
+        self._tev_used = [False, False]
         if optimizer is not None:
-            if getattr(optimizer, "_fb", None) is not None:
-                raise RuntimeError("AdamW.enable_fused_backward() updates weights from local gradients: not usable with DataParallel")
             optimizer.grad_scale = 1.0 / self.world
             optimizer._dp = self
 
     def broadcast_parameters(self, src=0):
-        self.core.join_optimizer()
         if self.reducer.active:
             dist.broadcast(self.core.params, src=src, group=self.reducer.pg)
             self.core.weights_dirty = True
@@ -156,7 +168,7 @@ class DataParallel(object):
         """flat gradient ranges whose all-reduce has been enqueued once `stage` is done"""
         r = list(self.plan[stage])
         if stage == len(self.plan) - 1:
-            r.append(self.tail)
+            r.extend(self.tail)
         return r
 
     def _on_stage(self, stage):
@@ -170,16 +182,43 @@ class DataParallel(object):
         # last all-reduce and calls finish() before it touches the late ranges (split_last = False: plain full wait here).
         early = self.reducer.mark()
         self.reducer.reduce_ranges(self.plan[stage])
-        self.reducer.reduce_ranges([self.tail])
+        self.reducer.reduce_ranges(self.tail)
         if self.split_last and early is not None and self.optimizer is not None:
-            torch.cuda.current_stream(self.core.grads.device).wait_event(early)
-            self.late_ranges = [r for r in list(self.plan[stage]) + [self.tail] if r[1] > 0]
+            self._timed_wait(0, lambda cs: cs.wait_event(early))
+            self.late_ranges = [r for r in list(self.plan[stage]) + list(self.tail) if r[1] > 0]
         else:
-            self.reducer.wait()
+            self._timed_wait(0, lambda cs: self.reducer.wait())
+            self._tev_used[1] = False
+
+    def _timed_wait(self, k, wait):
+        """run `wait` (which makes the compute stream wait for gradient pieces) between two timing events on that stream"""
+        cs = torch.cuda.current_stream(self.core.grads.device) if self.core.grads.is_cuda else None
+        if self._tev is None or not self.reducer.active:
+            wait(cs)
+            return
+        self._tev[2 * k].record(cs)
+        wait(cs)
+        self._tev[2 * k + 1].record(cs)
+        self._tev_used[k] = True
+
+    def exposed_ms(self):
+        """Time the compute stream of the LAST step spent stalled on the gradient exchange (both waits: before the early
+        AdamW ranges and before the late ones); synchronises.  0 when every piece had landed by the time it was needed."""
+        if self._tev is None:
+            return 0.0
+        total = 0.0
+        for k in range(2):
+            if self._tev_used[k]:
+                self._tev[2 * k + 1].synchronize()
+                total += self._tev[2 * k].elapsed_time(self._tev[2 * k + 1])
+        return total
 
     def finish(self):
         """full wait for the gradient exchange (AdamW.step() calls it before the late ranges; harmless to call twice)"""
-        self.reducer.wait()
+        if self.late_ranges:
+            self._timed_wait(1, lambda cs: self.reducer.wait())
+        else:
+            self.reducer.wait()
         self.late_ranges = []
 
     def __getattr__(self, name):

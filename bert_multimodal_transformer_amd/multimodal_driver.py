@@ -88,8 +88,10 @@ def get_parser():
     parser.add_argument("--synthetic", type=int, default=0, help="use N synthetic training samples (no .pkl needed)")
     parser.add_argument("--compute_dtype", choices=["bf16", "fp32"], default="bf16")
     parser.add_argument("--reference_loop", type=str2bool, default=False)
-    parser.add_argument("--fused_optimizer", type=str2bool, default=False,
-                        help="single process, gradient_accumulation_step 1: AdamW for the encoder weights runs inside the backward GEMMs")
+    parser.add_argument("--step_graph", type=str2bool, default=True,
+                        help="fused loop, single process: run each optimizer step as one replayed hipGraph (mb_bert_train_step)")
+    parser.add_argument("--prefetch", type=str2bool, default=True,
+                        help="fused loop: stage batch i+1 on a copy stream while step i computes (prefetch.DevicePrefetcher)")
     parser.add_argument("--pretrained", type=str, default="", help="local checkpoint dir/file (offline)")
     return parser
 
@@ -124,37 +126,35 @@ def _dims():
 
 
 # ------------------------------------------------------------------------------------------------- features
+def _wordpieces(words, tokenizer):
+    """wordpieces of a word list + for every piece the index of the word it came from"""
+    pieces, owner = [], []
+    for w, word in enumerate(words):
+        sub = tokenizer.tokenize(word)
+        pieces += sub
+        owner += [w] * len(sub)
+    return pieces, np.asarray(owner, dtype=np.int64)
+
+
 def convert_to_features(examples, max_seq_length, tokenizer):
-    """multimodal_driver.py:82-140: per-word features repeated per wordpiece, truncated to L-2, then padded."""
-    features = []
-    for (ex_index, example) in enumerate(examples):
-        (words, visual, acoustic), label_id, segment = example
-        tokens, inversions = [], []
-        for idx, word in enumerate(words):
-            tokenized = tokenizer.tokenize(word)
-            tokens.extend(tokenized)
-            inversions.extend([idx] * len(tokenized))
-        assert len(tokens) == len(inversions)
-        inv = np.asarray(inversions, dtype=np.int64)
-        visual = np.asarray(visual)[inv] if len(inv) else np.zeros((0, np.asarray(visual).shape[1]))
-        acoustic = np.asarray(acoustic)[inv] if len(inv) else np.zeros((0, np.asarray(acoustic).shape[1]))
-        if len(tokens) > max_seq_length - 2:
-            tokens = tokens[: max_seq_length - 2]
-            acoustic = acoustic[: max_seq_length - 2]
-            visual = visual[: max_seq_length - 2]
-        if args.model == "bert-base-uncased":
-            prepare_input = prepare_bert_input
-        elif args.model == "xlnet-base-cased":
-            prepare_input = prepare_xlnet_input
-        input_ids, visual, acoustic, input_mask, segment_ids = prepare_input(tokens, visual, acoustic, tokenizer)
-        assert len(input_ids) == args.max_seq_length
-        assert len(input_mask) == args.max_seq_length
-        assert len(segment_ids) == args.max_seq_length
-        assert acoustic.shape[0] == args.max_seq_length
-        assert visual.shape[0] == args.max_seq_length
-        features.append(InputFeatures(input_ids=input_ids, input_mask=input_mask, segment_ids=segment_ids, visual=visual,
-                                      acoustic=acoustic, label_id=label_id))
-    return features
+    """Feature conversion with the semantics of multimodal_driver.py:82-140: every wordpiece inherits the visual / acoustic
+    row of the word it belongs to (a gather by owner index), the sequence is cut to max_seq_length - 2 pieces, and the
+    model-specific layout (special tokens, padding side, segment ids) is applied by prepare_bert_input / prepare_xlnet_input."""
+    layout = {"bert-base-uncased": prepare_bert_input, "xlnet-base-cased": prepare_xlnet_input}[args.model]
+    room = max_seq_length - 2
+    out = []
+    for (words, visual, acoustic), label_id, _segment in examples:
+        pieces, owner = _wordpieces(words, tokenizer)
+        visual, acoustic = np.asarray(visual), np.asarray(acoustic)
+        owner = owner[:room]
+        vis = visual[owner] if owner.size else np.zeros((0, visual.shape[1]))
+        aco = acoustic[owner] if owner.size else np.zeros((0, acoustic.shape[1]))
+        input_ids, vis, aco, input_mask, segment_ids = layout(pieces[:room], vis, aco, tokenizer)
+        if not (len(input_ids) == len(input_mask) == len(segment_ids) == vis.shape[0] == aco.shape[0] == args.max_seq_length):
+            raise AssertionError("feature rows must all have max_seq_length = %d entries" % args.max_seq_length)
+        out.append(InputFeatures(input_ids=input_ids, visual=vis, acoustic=aco, input_mask=input_mask, segment_ids=segment_ids,
+                                 label_id=label_id))
+    return out
 
 
 def prepare_bert_input(tokens, visual, acoustic, tokenizer):
@@ -381,8 +381,6 @@ def prep_for_training(num_train_optimization_steps: int):
         from .distributed import DataParallel
         model._dp = DataParallel(model, optimizer)          # hooks the backward stages: RCCL all-reduce during the backward
         model._dp.broadcast_parameters(0)
-    if getattr(args, "fused_optimizer", False) and world == 1 and args.gradient_accumulation_step == 1:
-        optimizer.enable_fused_backward(model)        # no-op (False) where the engine has no grouped wgrad launch
     return model, optimizer, scheduler
 
 
@@ -421,19 +419,30 @@ def train_epoch(model: nn.Module, train_dataloader: DataLoader, optimizer, sched
         return tr_loss / max(1, nb_tr_steps)
     with model.stream_scope():                        # one private HIP stream for the whole epoch (no NULL-stream hops)
         model.loss_running(reset=True)
-        for step, batch in enumerate(train_dataloader):
-            input_ids, visual, acoustic, input_mask, segment_ids, label_ids = _unpack(batch)
+        if getattr(args, "prefetch", True):
+            from .prefetch import DevicePrefetcher      # batch i+1 crosses PCIe as one copy while step i computes
+            batches = DevicePrefetcher(train_dataloader, _device())
+        else:
+            batches = (_unpack(b) for b in train_dataloader)
+        use_graph = None if getattr(args, "step_graph", True) else False
+        for step, batch in enumerate(batches):
+            input_ids, visual, acoustic, input_mask, segment_ids, label_ids = batch
+            update = (step + 1) % accum == 0
             if dp is not None:
-                dp.sync = (step + 1) % accum == 0           # all-reduce only on the micro-step that is followed by step()
-            model.training_step(input_ids, visual, acoustic, input_mask, segment_ids, label_ids, loss_scale=1.0 / accum)
+                dp.sync = update                          # all-reduce only on the micro-step that is followed by step()
+            # forward + MSE + backward (+ optimizer.step() + zero_grad()): one replayed hipGraph where the engine can
+            model.train_step(input_ids, visual, acoustic, input_mask, segment_ids, label_ids,
+                             optimizer=optimizer if update else None, loss_scale=1.0 / accum, graph=use_graph)
             nb_tr_steps += 1
-            if (step + 1) % accum == 0:
-                optimizer.step()
+            if update:
                 scheduler.step()
-                optimizer.zero_grad()
         running = model.loss_running(reset=True)
-    total = float(running.item()) / accum             # the only host sync of the epoch
-    return total / max(1, nb_tr_steps)
+    stats = torch.stack([running.double() / accum, torch.tensor(float(nb_tr_steps), dtype=torch.float64, device=running.device)])
+    if dp is not None and _dist()[1] > 1:
+        import torch.distributed as dist
+        dist.all_reduce(stats)                        # the epoch's loss covers every rank's shard, like valid_loss
+    stats = stats.cpu()                               # the only host sync of the epoch
+    return float(stats[0]) / max(1.0, float(stats[1]))
 
 
 def eval_epoch(model: nn.Module, dev_dataloader: DataLoader, optimizer):
@@ -487,18 +496,16 @@ def test_epoch(model: nn.Module, test_dataloader: DataLoader):
 
 
 def score_predictions(preds, y_test, use_zero=False):
-    """The metric block of test_score_model (multimodal_driver.py:465-480)."""
+    """Metrics of test_score_model (multimodal_driver.py:465-480) on the samples whose label is non-zero (all of them with
+    use_zero): binary accuracy and weighted F1 of the sign (>= 0), mean absolute error, Pearson correlation."""
     from sklearn.metrics import accuracy_score, f1_score
-    non_zeros = np.array([i for i, e in enumerate(y_test) if e != 0 or use_zero])
-    preds = preds[non_zeros]
-    y_test = y_test[non_zeros]
-    mae = np.mean(np.absolute(preds - y_test))
-    corr = np.corrcoef(preds, y_test)[0][1]
-    preds = preds >= 0
-    y_test = y_test >= 0
-    f_score = f1_score(y_test, preds, average="weighted")
-    acc = accuracy_score(y_test, preds)
-    return acc, mae, corr, f_score
+    preds, y_test = np.asarray(preds), np.asarray(y_test)
+    keep = np.flatnonzero(np.ones_like(y_test, dtype=bool) if use_zero else (y_test != 0))
+    p, y = preds[keep], y_test[keep]
+    mae = np.abs(p - y).mean()
+    corr = np.corrcoef(p, y)[0, 1]
+    p_pos, y_pos = p >= 0, y >= 0
+    return accuracy_score(y_pos, p_pos), mae, corr, f1_score(y_pos, p_pos, average="weighted")
 
 
 def test_score_model(model: nn.Module, test_dataloader: DataLoader, use_zero=False):
@@ -532,6 +539,14 @@ def train(model, train_dataloader, validation_dataloader, test_data_loader, opti
 def main(argv=None):
     global args
     args = parse_args(argv)
+    rank, world = _dist()
+    if world > 1:
+        # `--seed random` (the default) draws in every process: the ranks must agree, the sharded sampler cuts ONE global
+        # permutation (distributed.shard_indices) and the replicas must start from the same weights
+        import torch.distributed as dist
+        box = [args.seed]
+        dist.broadcast_object_list(box, src=0)
+        args.seed = int(box[0])
     set_random_seed(args.seed)
     train_data_loader, dev_data_loader, test_data_loader, num_train_optimization_steps = set_up_data_loader()
     model, optimizer, scheduler = prep_for_training(num_train_optimization_steps)

@@ -29,9 +29,6 @@ class AdamW(torch.optim.Optimizer):
         self._plan = None
         self._t = 0
         self._dp = None              # set by distributed.DataParallel
-        self._fb = None              # fused-backward state (enable_fused_backward)
-        self._pipe = None            # pipelined-step state (enable_pipelined_step)
-        self.fused_backward_armed = False
 
     # -- planning: map groups onto contiguous flat ranges ------------------------------------------------
     def _build_plan(self):
@@ -63,100 +60,26 @@ class AdamW(torch.optim.Optimizer):
                 plan.append(("loose", gi, p))
         self._plan = plan
 
-    # -- optimizer pipelined against the next forward -------------------------------------------------------------
-    def enable_pipelined_step(self, model):
-        """step() hands the whole flat update to the engine (mb_bert_adamw_pipelined): the same AdamW kernel, launched range by
-        range on an engine-owned HIP stream in the order the NEXT forward reads the parameters; that forward waits for a range
-        only in front of the first kernel that needs it.  The update is HBM-bound and the forward is MFMA-latency-bound, so
-        ~3/4 of the optimizer pass disappears under the forward.  Same arithmetic, same hyper-parameters, works under
-        DataParallel (gradients are all-reduced before step()).
-
-        Contract: after step() the parameters are only guaranteed current for the model's own passes; anything else that
-        reads them (state_dict(), .cpu(), flat_params) goes through model.join_optimizer() first -- the model's state_dict(),
-        flat_params, load_state_dict() and stream_scope() do.  Returns False when the engine / parameter groups do not fit
-        (MAG-XLNet, parameters outside the flat buffer, a decayed no-decay group)."""
-        core = model._core
-        if core.kind != "bert" or self._fb is not None:
-            return False
+    def flat_step_args(self, core):
+        """Hyper-parameters of step() as ONE whole-buffer update, when this optimizer is exactly the driver's two parameter
+        groups (multimodal_driver.py:329-343) over `core`'s flat buffer: [0, n_decay) decayed, the rest not, same lr / betas /
+        eps / bias correction in both.  None otherwise (loose tensors, more groups, diverged groups, data parallel): the caller
+        then runs step() as usual.  Used by the whole-step graph (mb_bert_train_step), which applies the update itself."""
+        if self._dp is not None or not self.fused_zero_grad:
+            return None
         if self._plan is None:
             self._build_plan()
-        flats = [it for it in self._plan if it[0] == "flat"]
-        if len(flats) != 2 or len(self._plan) != 2 or any(it[2] is not core for it in flats):
-            return False
-        flats.sort(key=lambda it: it[3])
-        (_, g0, _, a0, b0), (_, g1, _, a1, b1) = flats
-        if a0 != 0 or b0 != core.n_decay or a1 != core.n_decay or b1 != core.n_params:
-            return False
-        if self.param_groups[g1]["weight_decay"] != 0.0:
-            return False
-        self._pipe = dict(core=core, g0=g0, g1=g1)
-        return True
-
-    def _pipelined_step(self):
-        pp = self._pipe
-        core = pp["core"]
-        ga, gb = self.param_groups[pp["g0"]], self.param_groups[pp["g1"]]
-        same = all(ga[k] == gb[k] for k in ("lr", "betas", "eps", "correct_bias"))
-        if not same:
-            return False                                  # groups diverged (custom schedule): plain path
-        b1, b2 = ga["betas"]
-        _lib.check(core.lib.mb_bert_adamw_pipelined(
-            core.handle, _lib.ptr(core._adam_m), _lib.ptr(core._adam_v), ga["lr"], b1, b2, ga["eps"], ga["weight_decay"], self._t,
-            1 if ga["correct_bias"] else 0, self.grad_scale, 1 if self.fused_zero_grad else 0, core.stream()))
-        core.optimizer_pending = True
-        return True
-
-    # -- optimizer fused into the backward GEMMs --------------------------------------------------------------
-    def enable_fused_backward(self, model):
-        """Apply this optimizer's update to the encoder GEMM weights (77 % of the parameters) INSIDE the backward: the
-        engine's per-layer grouped weight-gradient GEMM runs the AdamW arithmetic in its epilogue on the fp32 accumulators
-        (mb_bert_fuse_adamw), so those gradients are never stored, re-read or zeroed; step() then only updates the rest
-        (embeddings, MAG, pooler, classifier, biases, LayerNorms).  Same arithmetic and the same hyper-parameters
-        (lr of the current scheduler state, betas, eps, weight decay, bias correction) as step().
-
-        Contract: every backward after this call IS an optimizer step for that range -- use it only where each
-        backward is followed by step() (gradient_accumulation_step == 1), in a single process (no gradient all-reduce),
-        and do not expect `.grad` of the encoder weights to hold anything but zeros.  Returns False (and changes
-        nothing) when the engine cannot do it (MAG-XLNet, MB_GROUP_WGRAD=0)."""
-        if self._dp is not None:
-            raise _lib.MagbertError("fused backward needs the full gradient locally: not available under DataParallel")
-        core = model._core
-        rng = core.fused_range()
-        if rng is None:
-            return False
-        if self._plan is None:
-            self._build_plan()
-        a, b = rng
-        plan, owner = [], None
-        for item in self._plan:
-            if item[0] == "flat" and item[2] is core and item[3] < b and a < item[4]:
-                if not (item[3] <= a and b <= item[4]):
-                    raise _lib.MagbertError("the fused range straddles parameter groups")
-                owner = item[1]
-                if item[3] < a:
-                    plan.append(("flat", item[1], core, item[3], a))
-                if b < item[4]:
-                    plan.append(("flat", item[1], core, b, item[4]))
-            else:
-                plan.append(item)
-        if owner is None:
-            return False
-        self._plan = plan
-        self._fb = dict(core=core, group=owner)
-        self.fused_backward_armed = True          # set False for a backward that must not update (then call step_skipped())
-        core.pre_backward_hooks.append(self._arm_fused)
-        return True
-
-    def _arm_fused(self):
-        fb = self._fb
-        core, group = fb["core"], self.param_groups[fb["group"]]
-        if not self.fused_backward_armed:
-            _lib.check(core.lib.mb_bert_fuse_adamw(core.handle, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 1, 0, 1.0))
-            return
-        b1, b2 = group["betas"]
-        _lib.check(core.lib.mb_bert_fuse_adamw(core.handle, _lib.ptr(core._adam_m), _lib.ptr(core._adam_v), group["lr"], b1, b2,
-                                               group["eps"], group["weight_decay"], self._t + 1,
-                                               1 if group["correct_bias"] else 0, self.grad_scale))
+        if len(self._plan) != 2 or any(it[0] != "flat" or it[2] is not core for it in self._plan):
+            return None
+        (_, g0, _, a0, b0), (_, g1, _, a1, b1) = sorted(self._plan, key=lambda it: it[3])
+        if (a0, b0, a1, b1) != (0, core.n_decay, core.n_decay, core.n_params):
+            return None
+        ga, gb = self.param_groups[g0], self.param_groups[g1]
+        if any(ga[k] != gb[k] for k in ("lr", "betas", "eps", "correct_bias")) or gb["weight_decay"] != 0.0:
+            return None
+        return dict(m=core._adam_m, v=core._adam_v, lr=float(ga["lr"]), beta1=float(ga["betas"][0]), beta2=float(ga["betas"][1]),
+                    eps=float(ga["eps"]), weight_decay=float(ga["weight_decay"]), correct_bias=bool(ga["correct_bias"]),
+                    grad_scale=float(self.grad_scale))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -171,13 +94,8 @@ class AdamW(torch.optim.Optimizer):
             # data parallel: the all-reduce of the LAST backward stage (word embeddings: 94 MB, produced last) is still on the
             # wire.  Everything else is already reduced (the stage hook made this stream wait for the "early" marker only), so
             # the update of those ranges (~78 % of the parameters) runs under that last all-reduce; the late ranges follow after
-            # the full wait.  Plain path only: the pipelined / fused variants take the full wait first.
+            # the full wait.
             late = sorted(dp.late_ranges)
-            if self._pipe is not None or self._fb is not None:
-                dp.finish()
-                late = []
-        if self._pipe is not None and self._pipelined_step():
-            return loss
 
         def launch(core, group, x, y):
             if y <= x:
@@ -239,8 +157,6 @@ class AdamW(torch.optim.Optimizer):
             self._build_plan()
         sd = super().state_dict()
         cores = []
-        if self._pipe is not None:
-            self._pipe["core"].join_optimizer()
         for item in self._plan:
             if item[0] == "flat" and all(item[2] is not c for c in cores):
                 cores.append(item[2])
@@ -254,8 +170,6 @@ class AdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._plan = None
         self._build_plan()
-        if self._fb is not None:
-            raise _lib.MagbertError("load_state_dict() before enable_fused_backward(), not after")
         if extra is not None:
             self._t = int(extra["t"])
             cores = []

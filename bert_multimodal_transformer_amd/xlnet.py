@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .bert import _Core, _EngineFn, _MagBertBase, _attach_parameters, _init_weights
+from .bert import _Core, _EngineFn, _FusedStep, _MagBertBase, _attach_parameters, _init_weights
 from .global_configs import ACOUSTIC_DIM, VISUAL_DIM, XLNET_INJECTION_INDEX
 
 
@@ -98,7 +98,7 @@ class MAG_XLNetModel(_XlBase):
         return (self._core.sequence_output(B, L),)
 
 
-class MAG_XLNetForSequenceClassification(_XlBase):
+class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
     """xlnet.py:432-527."""
 
     def __init__(self, config, multimodal_config, visual_dim=VISUAL_DIM, acoustic_dim=ACOUSTIC_DIM,
@@ -136,25 +136,3 @@ class MAG_XLNetForSequenceClassification(_XlBase):
                 loss = torch.nn.functional.cross_entropy(logits.view(-1, self.num_labels), labels.to(logits.device).view(-1))
             outputs = (loss,) + outputs
         return outputs
-
-    def training_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, loss_scale=1.0):
-        if self.num_labels != 1:
-            raise NotImplementedError("fused loss is the regression MSE of the driver (num_labels == 1)")
-        core = self._core
-        core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, True)
-        core._backward(None, loss_scale)
-        return core.loss_buf[0]
-
-    def loss_running(self, reset=False):
-        v = self._core.loss_buf[1].clone()
-        if reset:
-            self._core.loss_buf[1].zero_()
-        return v
-
-    @property
-    def flat_params(self):
-        return self._core.params
-
-    @property
-    def flat_grads(self):
-        return self._core.grads

@@ -150,29 +150,28 @@ const float* mb_bert_pooled_output(const mb_bert_engine* e);    /* [B][H] fp32 (
 /* gradient buckets for data parallelism: range r of stage s covers flat elements [off, off+len) */
 int mb_bert_stage_grad_ranges(const mb_bert_engine* e, int stage, size_t* offs, size_t* lens, int cap);
 
-/* Optimizer-in-backward for the encoder GEMM weights (77 % of the parameters).  Arms the NEXT mb_bert_backward: the
- * grouped weight-gradient launch of every layer applies transformers-3.0.2 AdamW (same arithmetic as mb_adamw_step:
- * moments, eps outside the sqrt, decoupled decay after the update, bf16 operand shadow) to its four weights in the GEMM
- * epilogue, straight from the fp32 accumulators.  Replaces, for flat range mb_bert_fused_range = [begin, end),
- * `loss.backward()` gradient stores + `optimizer.step()` + `optimizer.zero_grad()` (multimodal_driver.py:378-386): the
- * gradient buffer of that range is neither written nor read (it stays zero), which removes 16 B/param of HBM traffic.
- * m, v: Adam moment buffers parallel to the bound parameter buffer; m == NULL disarms.  One-shot (re-arm every step).
- * Only valid when nothing else needs those gradients: single process (no all-reduce), gradient_accumulation_step == 1.
- * MB_ERR_MODE when the engine does not run the grouped launch (MB_GROUP_WGRAD=0 / MB_OVERLAP_WGRAD=0). */
-int mb_bert_fuse_adamw(mb_bert_engine* e, float* m, float* v, float lr, float beta1, float beta2, float eps,
-                       float weight_decay, int step, int correct_bias, float grad_scale);
-int mb_bert_fused_range(const mb_bert_engine* e, size_t* begin, size_t* end);
-
-/* optimizer.step() + optimizer.zero_grad() (multimodal_driver.py:384-386) for EVERY parameter of the engine, pipelined against
- * the next forward: the same AdamW arithmetic as mb_adamw_step, launched range by range on an engine-owned stream in the order
- * the forward consumes the parameters (embeddings + MAG, layer 0 ... layer NL-1, pooler + classifier).  The call returns at once;
- * `stream` is NOT made to wait.  The next mb_bert_forward waits for each chunk right in front of the first kernel that reads it,
- * so the HBM-bound update of layer l+1 ... runs under the MFMA-bound forward of layer l.  Everything else that reads the
- * parameters on `stream` (state_dict, host copies, mb_bert_sync_weights) must call mb_bert_adamw_join first (sync_weights does).
- * m, v: Adam moment buffers parallel to the bound parameters.  Gradients must be final on `stream` (after any all-reduce). */
-int mb_bert_adamw_pipelined(mb_bert_engine* e, float* m, float* v, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, int step, int correct_bias, float grad_scale, int zero_grad, void* stream);
-int mb_bert_adamw_join(mb_bert_engine* e, void* stream);
+/* One whole optimizer step of train_epoch (multimodal_driver.py:354-388): `batch = tuple(t.to(DEVICE) ...)` staging, forward,
+ * MSE (`:372-373`), loss.backward() (`:378`), optimizer.step() + optimizer.zero_grad() (`:384-386`) -- as TWO launches:
+ *   1. a step prologue kernel that gathers the six batch tensors (device pointers, e.g. the landing buffer of an asynchronous
+ *      H2D prefetch) into the engine's fixed staging buffers and writes this step's dropout keys (seed, step) and AdamW
+ *      scalars (lr, bias-corrected step size from opt_step, grad_scale) into device memory;
+ *   2. a replayed hipGraph with every other kernel of the step (captured on first use for each (B, L, output pointers);
+ *      the internal side-stream fork / join of the weight-gradient launches is part of the graph).
+ * Same kernels, same arithmetic, same dropout masks as mb_bert_forward + mb_bert_backward + 2 x mb_adamw_step with the same
+ * (seed, step).  m, v: Adam moments parallel to the bound parameters; both NULL = no optimizer update (a gradient-accumulation
+ * micro-step: gradients are accumulated, nothing is cleared).  With an update the gradient buffer is cleared in the same pass.
+ * The two parameter groups of multimodal_driver.py:329-343 are [0, decay_count) with `weight_decay` and the rest with 0.
+ * loss[0] = this step's MSE, loss_run (optional) += it.  mode: 1 = graph replay, 2 = the same sequence launched kernel by
+ * kernel (reference for tests / profiling).  Pass the same logits / loss / m / v pointers every step: they are baked into the
+ * captured graph (a new combination is captured again).  Not for data parallel runs: the gradient exchange is interleaved
+ * with the backward stages from the host (mb_bert_backward + mb_bert_stage_grad_ranges). */
+int mb_bert_train_step(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                       const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                       uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, float* m, float* v, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int opt_step, int correct_bias, float grad_scale,
+                       float loss_scale, int mode, void* stream);
+/* number of graphs captured / replays launched so far (tests, bench) */
+int mb_bert_graph_stats(const mb_bert_engine* e, size_t* captures, size_t* launches);
 
 /* Measurement hooks (bench.py): with profiling on, every per-layer grouped weight-gradient launch of mb_bert_backward is
  * bracketed by HIP timing events on the engine's internal side stream -- the stream that kernel runs on, which the

@@ -235,83 +235,104 @@ def test_driver_epoch_runs_and_learns():
     assert np.isfinite(l_ref)
 
 
-@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
-def test_fused_backward_optimizer_equals_plain_step(cdt):
-    """AdamW.enable_fused_backward: the encoder GEMM weights are updated inside the grouped weight-gradient GEMM epilogue.
-    Same arithmetic as optimizer.step() -> parameters, Adam moments and the bf16 operand shadow follow the plain path
-    (differences only from fp contraction order: measured 7e-7 absolute on O(0.05) weights after 3 steps), dropout ON."""
+def _trajectory(cdt, mode, nsteps=4, accum=1, layers=3, shapes=((5, 40), (5, 40), (3, 24), (5, 40))):
+    """nsteps optimizer steps (dropout ON, lr schedule moving) through model.train_step; mode: False = kernels launched one by
+    one (training_step + optimizer.step()), True = step prologue + replayed hipGraph, 2 = prologue + the same sequence eagerly"""
     from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
-    runs = []
-    for fused in (False, True):
-        torch.manual_seed(77)
-        m = build(layers=3, cdt=cdt).train()
-        opt = AdamW(optimizer_grouped_parameters(m), lr=1e-3)
-        sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=1.0, num_training_steps=10)
-        if fused:
-            assert opt.enable_fused_backward(m) is True
-        a, b = m._core.fused_range()
-        for s in range(3):
-            ids, vis, aco, mask, seg, lab = tb(weights.synthetic_bert_batch(5, 40, 47, 74, seed=90 + s), DEV)
-            m.training_step(ids, vis, aco, mask, seg, lab)
-            if fused:
-                assert float(m.flat_grads[a:b].abs().max()) == 0.0          # never written
-                assert float(m.flat_grads[b:].abs().max()) > 0.0             # the rest still goes through step()
-            opt.step(); sch.step(); opt.zero_grad()
-        m.eval()
-        ids, vis, aco, mask, seg, lab = tb(weights.synthetic_bert_batch(4, 40, 47, 74, seed=99), DEV)
-        with torch.no_grad():
-            logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0].clone()
-        torch.cuda.synchronize()
-        runs.append((m.flat_params.clone(), m._core._adam_m.clone(), m._core._adam_v.clone(), logits, m._core.shadow.clone()))
-    (p0, m0, v0, l0, s0), (p1, m1, v1, l1, s1) = runs
-    dp, dm, dv = float((p0 - p1).abs().max()), float((m0 - m1).abs().max()), float((v0 - v1).abs().max())
-    print("fused vs plain: max |dparam| %.3e |dm| %.3e |dv| %.3e |dlogit| %.3e" % (dp, dm, dv, float((l0 - l1).abs().max())))
-    tol = 1e-5 if cdt == torch.float32 else 2e-5       # lr 1e-3 * Adam's m/(sqrt(v)+eps) amplifies 1-ulp gradient differences (seen: up to 2.5e-6); bf16: a 1-ulp fp32 difference can flip a bf16 rounding of the shadow
-    assert dp <= tol and dm <= tol and dv <= tol
-    assert float((l0 - l1).abs().max()) <= (1e-5 if cdt == torch.float32 else 2e-2)
-    if cdt == torch.bfloat16:
-        frac = float((s0 != s1).float().mean())
-        assert frac < 1e-3, frac
-
-
-@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
-def test_pipelined_optimizer_step_equals_plain_step(cdt):
-    """AdamW.enable_pipelined_step: the update runs on the engine's optimizer stream, chunk by chunk, under the next forward.
-    200 three-step trajectories (dropout ON, same seeds) must all end where the plain optimizer.step() trajectory ends: a
-    missing dependency between an update chunk and the forward kernel that reads it would show up as a stale tensor."""
-    from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
-    torch.manual_seed(5)
-    m = build(layers=2, cdt=cdt).train()
-    core = m._core
+    torch.manual_seed(77)
+    m = build(layers=layers, cdt=cdt).train()
     opt = AdamW(optimizer_grouped_parameters(m), lr=1e-3)
-    p0 = m.flat_params.clone()
-    rng0 = m.get_rng_state()
-    batches = [tb(weights.synthetic_bert_batch(4, 32, 47, 74, seed=120 + s), DEV) for s in range(3)]
+    sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=1.0, num_training_steps=10)
+    losses = []
+    with m.stream_scope():
+        for s in range(nsteps * accum):
+            B, L = shapes[s % len(shapes)]
+            ids, vis, aco, mask, seg, lab = tb(weights.synthetic_bert_batch(B, L, 47, 74, seed=90 + s), DEV)
+            update = (s + 1) % accum == 0
+            if mode == 2:
+                core = m._core
+                o = opt.flat_step_args(core) if update else None
+                if update:
+                    opt._t += 1
+                    o["t"] = opt._t
+                core.train_step(ids, vis, aco, mask, seg, lab, o, loss_scale=1.0 / accum, mode=2)
+            else:
+                m.train_step(ids, vis, aco, mask, seg, lab, optimizer=opt if update else None, loss_scale=1.0 / accum, graph=mode)
+            losses.append(m._core.loss_buf[0].clone())
+            if update:
+                sch.step()
+    m.eval()
+    ids, vis, aco, mask, seg, lab = tb(weights.synthetic_bert_batch(4, 40, 47, 74, seed=99), DEV)
+    with torch.no_grad():
+        logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0].clone()
+    torch.cuda.synchronize()
+    return dict(p=m.flat_params.clone(), m=m._core._adam_m.clone(), v=m._core._adam_v.clone(), g=m.flat_grads.clone(), logits=logits,
+                shadow=m._core.shadow.clone(), losses=torch.stack(losses).cpu(), stats=m._core.graph_stats(), running=float(m.loss_running()))
 
-    def trajectory():
-        core.params.copy_(p0); core.weights_dirty = True
-        core._adam_m.zero_(); core._adam_v.zero_(); core.grads.zero_()
-        opt._t = 0
-        m.set_rng_state(rng0)
-        sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=1.0, num_training_steps=10)
-        with m.stream_scope():
-            for ids, vis, aco, mask, seg, lab in batches:
-                m.training_step(ids, vis, aco, mask, seg, lab)
-                opt.step(); sch.step(); opt.zero_grad()
-        return m.flat_params.clone()
 
-    opt._build_plan()
-    ref = trajectory()
-    ref2 = trajectory()
-    noise = float((ref - ref2).abs().max())                      # run-to-run noise of the plain path (fp32 atomics)
-    assert opt.enable_pipelined_step(m) is True
-    worst, bad = 0.0, 0
-    for trial in range(200):
-        d = float((trajectory() - ref).abs().max())
-        worst = max(worst, d)
-        bad += d > 1e-5 + 10 * noise          # a stale tensor moves parameters by ~lr = 1e-3; atomics noise stays below 3e-6
-    print("pipelined vs plain: plain run-to-run %.3e, worst of 200 trajectories %.3e, outliers %d" % (noise, worst, bad))
-    assert bad == 0
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_step_graph_equals_launch_by_launch(cdt):
+    """mb_bert_train_step: the replayed whole-step hipGraph (dropout keys, lr and bias correction read from device memory,
+    batch gathered by the step prologue, side-stream fork / join captured) ends every step exactly where the kernels launched
+    one by one end it: same dropout masks, same losses, same parameters / Adam moments / bf16 shadow, gradients cleared.
+    Shapes change inside the run (a second graph is captured and the first one is replayed again afterwards)."""
+    ref = _trajectory(cdt, False)
+    ref2 = _trajectory(cdt, False)
+    noise = float((ref["p"] - ref2["p"]).abs().max())                  # fp32 atomics: run-to-run noise of the plain path
+    eager = _trajectory(cdt, 2)
+    graph = _trajectory(cdt, True)
+    assert ref["stats"] == (0, 0) and graph["stats"][0] == 2 and graph["stats"][1] == 4, (ref["stats"], graph["stats"])
+    for name, run in (("prologue+eager", eager), ("graph", graph)):
+        dp = float((run["p"] - ref["p"]).abs().max())
+        dm = float((run["m"] - ref["m"]).abs().max())
+        dv = float((run["v"] - ref["v"]).abs().max())
+        dl = float((run["losses"] - ref["losses"]).abs().max())
+        print("%s vs launch-by-launch: |dparam| %.3e |dm| %.3e |dv| %.3e |dloss| %.3e (plain run-to-run %.3e)" % (name, dp, dm, dv, dl, noise))
+        tol = 1e-5 + 10 * noise         # a wrong mask / stale lr moves parameters by ~lr = 1e-3
+        assert dp <= tol and dm <= tol and dv <= tol
+        assert dl <= (1e-5 if cdt == torch.float32 else 2e-3)
+        assert float(run["g"].abs().max()) == 0.0                      # zero_grad() happened inside the step
+        assert abs(run["running"] - ref["running"]) <= 1e-3
+        assert float((run["logits"] - ref["logits"]).abs().max()) <= (1e-5 if cdt == torch.float32 else 2e-2)
+        if cdt == torch.bfloat16:
+            assert float((run["shadow"] != ref["shadow"]).float().mean()) < 1e-3
+
+
+def test_step_graph_gradient_accumulation_and_replay_stability():
+    """accumulation micro-steps replay a graph WITHOUT the optimizer (gradients accumulate, nothing is cleared), the closing
+    micro-step one with it; 30 replayed trajectories all end where the launch-by-launch path ends (a missing dependency in the
+    captured fork / join would show up as a stale tensor in some of them)."""
+    ref = _trajectory(torch.bfloat16, False, nsteps=3, accum=2, layers=2, shapes=((4, 32),))
+    noise = float((ref["p"] - _trajectory(torch.bfloat16, False, nsteps=3, accum=2, layers=2, shapes=((4, 32),))["p"]).abs().max())
+    worst = 0.0
+    for trial in range(30):
+        run = _trajectory(torch.bfloat16, True, nsteps=3, accum=2, layers=2, shapes=((4, 32),))
+        assert run["stats"] == (2, 6)                              # one graph with, one without the update
+        worst = max(worst, float((run["p"] - ref["p"]).abs().max()))
+    print("graph with accumulation: worst |dparam| over 30 trajectories %.3e (plain run-to-run %.3e)" % (worst, noise))
+    assert worst <= 1e-5 + 10 * noise
+
+
+def test_prefetcher_yields_the_batches_bit_exactly():
+    """prefetch.DevicePrefetcher: every batch arrives as `t.to(DEVICE)` would deliver it, in order, also when the consumer is
+    slower or faster than the copies and the batch shape changes (last batch of an epoch)."""
+    from bert_multimodal_transformer_amd.prefetch import DevicePrefetcher
+    host = []
+    for s, (B, L) in enumerate([(6, 20), (6, 20), (6, 20), (6, 20), (6, 20), (6, 20), (2, 20)]):
+        b = weights.synthetic_bert_batch(B, L, 47, 74, seed=500 + s)
+        t = tb(b)
+        host.append((t[0], t[1].unsqueeze(1), t[2].unsqueeze(1), t[3], t[4], t[5]))      # [B,1,L,V] like a TensorDataset of features
+    seen = 0
+    for i, dev_batch in enumerate(DevicePrefetcher(host, DEV)):
+        if i % 2:
+            torch.cuda.synchronize()
+        ref = host[i]
+        assert dev_batch[1].shape == ref[1].squeeze(1).shape
+        for k, (d, h) in enumerate(zip(dev_batch, ref)):
+            h = h.squeeze(1) if k in (1, 2) else h
+            assert d.is_cuda and d.dtype == h.dtype and torch.equal(d.cpu(), h), (i, k)
+        seen += 1
+    assert seen == len(host)
 
 
 @pytest.mark.parametrize("B,L", [(1, 8), (3, 127), (2, 128), (5, 33), (48, 1)])
