@@ -51,9 +51,9 @@ def parse():
     p.add_argument("--cpu-baseline", type=int, default=1)
     p.add_argument("--cpu-steps", type=int, default=5)
     p.add_argument("--roofline", type=int, default=1)
-    p.add_argument("--graph", type=int, default=1,
-                   help="1: each optimizer step is the step prologue + one replayed hipGraph where the engine supports it "
-                        "(MAG-BERT, single process); 0: every kernel launched from the host")
+    p.add_argument("--graph", type=int, default=0,
+                   help="1: replay each optimizer step as one hipGraph (mb_bert_train_step mode 1; MAG-BERT, single process). "
+                        "Default 0 = the same single engine call launching the kernels on the stream: measured 4-6 %% faster on ROCm 7.2")
     p.add_argument("--roofline-only", type=int, default=0, help="skip the training loop, print the GEMM table only")
     return p.parse_args()
 
@@ -271,7 +271,7 @@ def main():
     from bert_multimodal_transformer_amd.distributed import DataParallel
     from bert_multimodal_transformer_amd.global_configs import DATASET_DIMS
     from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
-    from bert_multimodal_transformer_amd.prefetch import DevicePrefetcher
+    from bert_multimodal_transformer_amd.prefetch import PinnedBatchRing
 
     V, A = DATASET_DIMS[a.dataset]["visual_dim"], DATASET_DIMS[a.dataset]["acoustic_dim"]
     B, L = a.batch, a.seq
@@ -295,17 +295,19 @@ def main():
     nb = 8
     batches = make_batches(nb, B, L, V, A, seed=1234 + rank, layout=a.model)      # pinned host tensors, as a DataLoader yields them
     dev = torch.device("cuda", torch.cuda.current_device())
-    use_graph = None if a.graph else False
-    graph_on = bool(a.graph) and model._core.graph_blocker() is None and opt.flat_step_args(model._core) is not None
+    single_call = model._core.fused_step_blocker() is None and opt.flat_step_args(model._core) is not None
+    use_graph = True if (a.graph and single_call) else None
+    graph_on = use_graph is True
 
     def host_batches(n, start=0):
         for i in range(n):
             yield batches[(start + i) % nb]
 
     def run(n, start, events=None):
-        """n optimizer steps exactly as train_epoch runs them: the batch comes from the HOST (one asynchronous H2D per step on
-        the copy stream, multimodal_driver.py:359), forward + MSE + backward (+ all-reduce) + AdamW + schedule + zero_grad."""
-        for batch in DevicePrefetcher(host_batches(n, start), dev):
+        """n optimizer steps exactly as train_epoch runs them: the batch comes from the HOST (packed into a pinned block that
+        the step's gather launch reads across PCIe: multimodal_driver.py:359), forward + MSE + backward (+ all-reduce) + AdamW +
+        schedule + zero_grad."""
+        for batch in PinnedBatchRing(host_batches(n, start), dev):
             ids, vis, aco, mask, seg, lab = batch
             model.train_step(ids, vis, aco, mask, seg, lab, optimizer=opt, graph=use_graph)
             sch.step()
@@ -394,7 +396,8 @@ def main():
                                       "optimizer step (per-step H2D of the batch + fwd+MSE+bwd%s+HF-AdamW+schedule+zero_grad), dropout on, "
                                       "random-init weights" % (a.dataset.upper(), V, A, B, L, "+RCCL all-reduce" if world > 1 else ""),
                           "global_batch": world * B, "seq_len": L, "parallelism": "dp%d" % world,
-                          "step_graph": bool(graph_on), "h2d": "one pinned block per batch, copy stream, prefetched one step ahead",
+                          "step_call": ("mb_bert_train_step, " + ("hipGraph replay" if graph_on else "stream launches")) if single_call else "passes driven from Python",
+                          "h2d": "batch packed into one pinned host block, gathered across PCIe by the step's first launch",
                           **({"grad_wire_dtype": "bf16" if dp.reducer.wire_dtype == torch.bfloat16 else "fp32"} if dp is not None else {})},
                "mean_loss": round(loss, 4), "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
                "step_ms_median": q(0.5), "step_ms_p10": q(0.1), "step_ms_p90": q(0.9),

@@ -203,85 +203,115 @@ class _Core(object):
         self.weights_dirty = False
 
     # -- passes --------------------------------------------------------------------------------------
+    def _pinned_batch(self, tensors, B, L):
+        """True when the batch can be read by the GPU where it is: six pinned, contiguous host tensors of the engine's dtypes
+        (what prefetch.PinnedBatchRing yields).  Anything else goes through torch's .to(device)."""
+        if self.kind != "bert":
+            return False
+        want = (torch.int64, torch.float32, torch.float32, torch.int64, torch.int64, torch.float32)
+        shapes = ((B, L), (B, L, self.V), (B, L, self.A), (B, L), (B, L), None)
+        for t, dt, shp in zip(tensors, want, shapes):
+            if t is None:
+                continue
+            if t.is_cuda or t.dtype != dt or not t.is_contiguous() or (shp is not None and tuple(t.shape) != shp) or not t.is_pinned():
+                return False
+        return True
+
+    def _inputs(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, gather_in_step=False):
+        """-> (pointers in the C ABI's order: ids, vis, aco, mask, seg, labels ; objects to keep alive).
+        Pinned host batches are never copied by torch: mb_bert_train_step's prologue gathers them across PCIe itself
+        (gather_in_step), the other passes get them through ONE gather launch (mb_bert_load_batch) into the engine's staging
+        buffers.  Device / pageable tensors take the reference's route, `t.to(DEVICE)` (multimodal_driver.py:359)."""
+        B, L = input_ids.shape
+        dev = self.device
+        lab_in = None if labels is None else labels.reshape(-1)
+        six = (input_ids, visual, acoustic, attention_mask, token_type_ids, lab_in)
+        if self._pinned_batch(six, B, L):
+            ptrs = [None if t is None else C.c_void_p(t.data_ptr()) for t in six]
+            if gather_in_step:
+                return ptrs, six
+            staged = (C.c_void_p * 6)()
+            with _Core._Hop(self):
+                _lib.check(self.lib.mb_bert_load_batch(self.handle, ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5], B, L, staged,
+                                                       self.stream()))
+            return [C.c_void_p(staged[i]) if staged[i] else None for i in range(6)], six
+        nb = not input_ids.is_cuda and input_ids.is_pinned()      # pinned host tensors: asynchronous copies on this stream
+        ids = input_ids.to(dev, torch.int64, non_blocking=nb).contiguous()
+        msk = attention_mask.to(dev, torch.int64, non_blocking=nb).contiguous()
+        seg = token_type_ids.to(dev, torch.int64, non_blocking=nb).contiguous()
+        vis = visual.to(dev, torch.float32, non_blocking=nb).contiguous()
+        aco = acoustic.to(dev, torch.float32, non_blocking=nb).contiguous()
+        if vis.shape != (B, L, self.V) or aco.shape != (B, L, self.A):
+            raise ValueError("visual/acoustic must be [B, L, %d] / [B, L, %d], got %s / %s" %
+                             (self.V, self.A, tuple(vis.shape), tuple(aco.shape)))
+        lab = None if labels is None else labels.to(dev, torch.float32, non_blocking=nb).contiguous().view(-1)
+        keep = (ids, vis, aco, msk, seg, lab)
+        return [_lib.ptr(t) for t in keep], keep
+
     def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, training):
         B, L = input_ids.shape
         dev = self.device
         self._ensure(B, L)
         if self.weights_dirty:
             self.sync_weights()
-        ids, msk, seg, vis, aco, lab = self._inputs(input_ids, visual, acoustic, attention_mask, token_type_ids, labels)
+        ptr, keep = self._inputs(input_ids, visual, acoustic, attention_mask, token_type_ids, labels)
         logits = torch.empty(B, self.config.num_labels, dtype=torch.float32, device=dev)
         if training:
             self.step += 1
-        self._keep = (ids, msk, seg, vis, aco, lab, logits)      # engine keeps raw pointers until the backward
+        self._keep = (keep, logits)                 # the engine keeps raw pointers until the backward
+        self._lab_ptr = ptr[5]
         self.training_last = bool(training)
         with _Core._Hop(self):
-            _lib.check(self._fn("forward")(self.handle, _lib.ptr(ids), _lib.ptr(vis), _lib.ptr(aco), _lib.ptr(msk),
-                                                _lib.ptr(seg), _lib.ptr(lab), B, L, 1 if training else 0, self.seed,
-                                                self.step, _lib.ptr(logits), C.c_void_p(self.loss_buf.data_ptr()),
-                                                C.c_void_p(self.loss_buf.data_ptr() + 4) if lab is not None else None,
-                                                self.stream()))
+            _lib.check(self._fn("forward")(self.handle, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5], B, L, 1 if training else 0,
+                                           self.seed & (2 ** 64 - 1), self.step, _lib.ptr(logits), C.c_void_p(self.loss_buf.data_ptr()),
+                                           C.c_void_p(self.loss_buf.data_ptr() + 4) if ptr[5] is not None else None,
+                                           self.stream()))
         return logits
 
     def _backward(self, dlogits=None, loss_scale=1.0):
         nstage = self.n_layers + 2
-        lab = self._keep[5]
+        lab = self._lab_ptr
         if dlogits is None and lab is None:
             raise ValueError("fused backward needs the labels passed to forward()")
         with _Core._Hop(self):
             for s in range(nstage):
-                _lib.check(self._fn("backward")(self.handle, _lib.ptr(dlogits),
-                                                     _lib.ptr(lab) if dlogits is None else None, float(loss_scale), s, s + 1,
-                                                     self.stream()))
+                _lib.check(self._fn("backward")(self.handle, _lib.ptr(dlogits), lab if dlogits is None else None,
+                                                float(loss_scale), s, s + 1, self.stream()))
                 for hook in self.stage_hooks:
                     hook(s)
 
-    def _inputs(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels):
-        B, L = input_ids.shape
-        dev = self.device
-        ids = input_ids.to(dev, torch.int64).contiguous()
-        msk = attention_mask.to(dev, torch.int64).contiguous()
-        seg = token_type_ids.to(dev, torch.int64).contiguous()
-        vis = visual.to(dev, torch.float32).contiguous()
-        aco = acoustic.to(dev, torch.float32).contiguous()
-        if vis.shape != (B, L, self.V) or aco.shape != (B, L, self.A):
-            raise ValueError("visual/acoustic must be [B, L, %d] / [B, L, %d], got %s / %s" %
-                             (self.V, self.A, tuple(vis.shape), tuple(aco.shape)))
-        lab = None if labels is None else labels.to(dev, torch.float32).contiguous().view(-1)
-        return ids, msk, seg, vis, aco, lab
-
-    def graph_blocker(self):
-        """why the whole-step hipGraph (mb_bert_train_step) cannot run this model's steps, or None"""
-        if os.environ.get("MB_STEP_GRAPH", "1") == "0":
-            return "MB_STEP_GRAPH=0"
+    def fused_step_blocker(self):
+        """why one optimizer step cannot be ONE engine call (mb_bert_train_step), or None"""
         if self.kind != "bert":
-            return "the MAG-XLNet engine has no captured step yet"
+            return "the MAG-XLNet engine has no single-call step yet"
         if self.stage_hooks:
             return "backward stage hooks are installed (data parallel: the gradient exchange is issued between stages)"
         return None
 
-    def train_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, opt, loss_scale=1.0, mode=1):
-        """One optimizer step as the step prologue + one replayed hipGraph (include/magbert_hip.h: mb_bert_train_step).
-        opt: None (gradient-accumulation micro-step, no update) or the dict AdamW.flat_step_args() returns."""
+    def train_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, opt, loss_scale=1.0, mode=2):
+        """One optimizer step as ONE engine call (include/magbert_hip.h: mb_bert_train_step): the step prologue (batch gather,
+        dropout keys, AdamW scalars -> device memory) followed by every kernel of the step, launched one by one (mode 2) or as
+        a replayed hipGraph (mode 1).  opt: None (gradient-accumulation micro-step, no update) or AdamW.flat_step_args()."""
         B, L = input_ids.shape
         self._ensure(B, L)
         if self.weights_dirty:
             self.sync_weights()
-        ids, msk, seg, vis, aco, lab = self._inputs(input_ids, visual, acoustic, attention_mask, token_type_ids, labels)
-        if lab is None:
+        if labels is None:
             raise ValueError("the fused step needs label_ids")
+        ptr, keep = self._inputs(input_ids, visual, acoustic, attention_mask, token_type_ids, labels, gather_in_step=True)
         if not hasattr(self, "_logit_bufs"):
             self._logit_bufs = {}
         logits = self._logit_bufs.get(B)
-        if logits is None:          # one persistent buffer per batch size: its address is part of the captured graph
+        if logits is None:          # one persistent buffer per batch size: its address is part of a captured graph
             logits = self._logit_bufs[B] = torch.empty(B, self.config.num_labels, dtype=torch.float32, device=self.device)
         self.step += 1
-        self._keep = (ids, msk, seg, vis, aco, lab, logits)
+        self._keep = (keep, logits)
+        self._lab_ptr = None        # the engine's own staging copy: a later stand-alone backward needs a new forward
         self.training_last = True
         o = opt or {}
         with _Core._Hop(self):
             _lib.check(self.lib.mb_bert_train_step(
-                self.handle, _lib.ptr(ids), _lib.ptr(vis), _lib.ptr(aco), _lib.ptr(msk), _lib.ptr(seg), _lib.ptr(lab), B, L,
+                self.handle, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5], B, L,
                 self.seed & (2 ** 64 - 1), self.step, _lib.ptr(logits), C.c_void_p(self.loss_buf.data_ptr()),
                 C.c_void_p(self.loss_buf.data_ptr() + 4), _lib.ptr(o.get("m")), _lib.ptr(o.get("v")), o.get("lr", 0.0),
                 o.get("beta1", 0.9), o.get("beta2", 0.999), o.get("eps", 1e-6), o.get("weight_decay", 0.0), int(o.get("t", 1)),
@@ -479,24 +509,30 @@ class _FusedStep(object):
 
     def train_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, optimizer=None,
                    loss_scale=1.0, graph=None):
-        """One iteration of train_epoch's loop body (multimodal_driver.py:359-386): forward, MSE, backward and -- when
-        `optimizer` is given -- optimizer.step() + optimizer.zero_grad().  scheduler.step() stays with the caller.
+        """One iteration of train_epoch's loop body (multimodal_driver.py:359-386): batch staging, forward, MSE, backward
+        and -- when `optimizer` is given -- optimizer.step() + optimizer.zero_grad().  scheduler.step() stays with the caller.
 
         Where it can (MAG-BERT, single process, the driver's two parameter groups on this model's flat buffer) the whole
-        iteration is the step prologue + ONE replayed hipGraph; otherwise the same kernels are launched one by one
-        (training_step + optimizer.step()).  graph=False forces the launch-by-launch path, graph=True raises if the graph
-        cannot be used.  Pass optimizer=None on gradient-accumulation micro-steps.  Returns the device loss scalar."""
+        iteration is ONE engine call, mb_bert_train_step: a step prologue that gathers the batch (straight from pinned host
+        memory if that is where it is) and puts this step's dropout keys / lr / bias correction into device memory, then every
+        kernel of the step -- launched one after the other (default), or as one replayed hipGraph with graph=True or
+        MB_STEP_GRAPH=1 (measured on ROCm 7.2: the two-stream graph replays 4-6 % SLOWER than the stream launches, see
+        DESIGN.md, so it is opt-in).  Otherwise (MAG-XLNet, data parallel, foreign optimizers) the passes are driven from
+        here: training_step + optimizer.step().  graph=False forces that path.  Pass optimizer=None on gradient-accumulation
+        micro-steps.  Returns the device loss scalar."""
         if self.num_labels != 1:
             raise NotImplementedError("fused loss is the regression MSE of the driver (num_labels == 1)")
         core = self._core
-        why = core.graph_blocker()
+        why = core.fused_step_blocker()
         opt = None
         if why is None and optimizer is not None:
             opt = optimizer.flat_step_args(core) if hasattr(optimizer, "flat_step_args") else None
             if opt is None:
                 why = "the optimizer is not the two-group AdamW over this model's flat buffer"
+        if graph is None and os.environ.get("MB_STEP_GRAPH", "0") == "1":
+            graph = True
         if graph is True and why is not None:
-            raise _lib.MagbertError("whole-step graph unavailable: " + why)
+            raise _lib.MagbertError("single-call step unavailable: " + why)
         if why is not None or graph is False:
             self.training_step(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, loss_scale=loss_scale)
             if optimizer is not None:
@@ -506,8 +542,17 @@ class _FusedStep(object):
         if optimizer is not None:
             optimizer._t += 1
             opt["t"] = optimizer._t
-        core.train_step(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, opt, loss_scale=loss_scale)
+            optimizer._opt_called = True          # the update happens inside the step: lr schedulers see an optimizer step
+        core.train_step(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, opt, loss_scale=loss_scale,
+                        mode=1 if graph is True else 2)
         return core.loss_buf[0]
+
+    def eval_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids):
+        """forward in the module's current mode with the fused MSE of eval_epoch (multimodal_driver.py:405-411): the batch
+        loss is added to loss_running() on the device.  Returns the logits."""
+        if self.num_labels != 1:
+            raise NotImplementedError("fused loss is the regression MSE of the driver (num_labels == 1)")
+        return self._core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, self.training)
 
     def loss_running(self, reset=False):
         v = self._core.loss_buf[1].clone()

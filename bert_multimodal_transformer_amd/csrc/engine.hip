@@ -693,6 +693,30 @@ int mb_bert_train_step(mb_bert_engine* e, const int64_t* input_ids, const float*
     return MB_OK;
 }
 
+int mb_bert_load_batch(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                       const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                       const void** staged6, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!e || !e->ws || !staged6) return MB_ERR_ARG;
+    const mb_bert_config& c = e->c;
+    if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
+    if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids) return MB_ERR_ARG;
+    const int T = B * L;
+    char* ws = e->ws;
+    PrologueArgs pa = {};
+    auto cp = [&](const void* src, size_t off, size_t bytes) {
+        pa.src[pa.ncopies] = (const uint32_t*)src; pa.dst[pa.ncopies] = (uint32_t*)(ws + off); pa.dwords[pa.ncopies] = (uint32_t)(bytes / 4);
+        ++pa.ncopies;
+    };
+    cp(input_ids, e->ws_in_ids, (size_t)T * 8); cp(token_type_ids, e->ws_in_seg, (size_t)T * 8); cp(attention_mask, e->ws_in_mask, (size_t)T * 8);
+    cp(visual, e->ws_in_vis, (size_t)T * c.visual_dim * 4); cp(acoustic, e->ws_in_aco, (size_t)T * c.acoustic_dim * 4);
+    if (labels) cp(labels, e->ws_in_lab, (size_t)B * c.num_labels * 4);
+    CK(step_prologue(pa, st));
+    staged6[0] = ws + e->ws_in_ids; staged6[1] = ws + e->ws_in_vis; staged6[2] = ws + e->ws_in_aco; staged6[3] = ws + e->ws_in_mask;
+    staged6[4] = ws + e->ws_in_seg; staged6[5] = labels ? ws + e->ws_in_lab : nullptr;
+    return MB_OK;
+}
+
 int mb_bert_graph_stats(const mb_bert_engine* e, size_t* captures, size_t* launches) {
     if (!e) return MB_ERR_ARG;
     if (captures) *captures = e->graph_captures;

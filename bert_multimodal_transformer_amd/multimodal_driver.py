@@ -88,10 +88,12 @@ def get_parser():
     parser.add_argument("--synthetic", type=int, default=0, help="use N synthetic training samples (no .pkl needed)")
     parser.add_argument("--compute_dtype", choices=["bf16", "fp32"], default="bf16")
     parser.add_argument("--reference_loop", type=str2bool, default=False)
-    parser.add_argument("--step_graph", type=str2bool, default=True,
-                        help="fused loop, single process: run each optimizer step as one replayed hipGraph (mb_bert_train_step)")
+    parser.add_argument("--step_graph", type=str2bool, default=False,
+                        help="fused loop, single process: replay each optimizer step as one hipGraph (mb_bert_train_step mode 1; "
+                             "measured 4-6 %% slower than the default stream launches on ROCm 7.2)")
     parser.add_argument("--prefetch", type=str2bool, default=True,
-                        help="fused loop: stage batch i+1 on a copy stream while step i computes (prefetch.DevicePrefetcher)")
+                        help="pack every batch into a pinned host block the GPU reads in place (prefetch.PinnedBatchRing) instead of "
+                             "six t.to(DEVICE) copies per step")
     parser.add_argument("--pretrained", type=str, default="", help="local checkpoint dir/file (offline)")
     return parser
 
@@ -392,6 +394,16 @@ def _unpack(batch):
     return input_ids, visual, acoustic, input_mask, segment_ids, label_ids
 
 
+def _batches(dataloader):
+    """The loop's `batch = tuple(t.to(DEVICE) for t in batch)` (multimodal_driver.py:359-362): by default every batch is
+    packed into a pinned host block that the engine's gather launch reads in place (prefetch.PinnedBatchRing); with
+    --prefetch false the six copies of the reference."""
+    if getattr(args, "prefetch", True):
+        from .prefetch import PinnedBatchRing
+        return PinnedBatchRing(dataloader, _device())
+    return (_unpack(b) for b in dataloader)
+
+
 def train_epoch(model: nn.Module, train_dataloader: DataLoader, optimizer, scheduler):
     """multimodal_driver.py:354-388.  Returns the mean training loss of the epoch."""
     model.train()
@@ -419,12 +431,8 @@ def train_epoch(model: nn.Module, train_dataloader: DataLoader, optimizer, sched
         return tr_loss / max(1, nb_tr_steps)
     with model.stream_scope():                        # one private HIP stream for the whole epoch (no NULL-stream hops)
         model.loss_running(reset=True)
-        if getattr(args, "prefetch", True):
-            from .prefetch import DevicePrefetcher      # batch i+1 crosses PCIe as one copy while step i computes
-            batches = DevicePrefetcher(train_dataloader, _device())
-        else:
-            batches = (_unpack(b) for b in train_dataloader)
-        use_graph = None if getattr(args, "step_graph", True) else False
+        batches = _batches(train_dataloader)
+        use_graph = True if getattr(args, "step_graph", False) else None
         for step, batch in enumerate(batches):
             input_ids, visual, acoustic, input_mask, segment_ids, label_ids = batch
             update = (step + 1) % accum == 0
@@ -446,23 +454,22 @@ def train_epoch(model: nn.Module, train_dataloader: DataLoader, optimizer, sched
 
 
 def eval_epoch(model: nn.Module, dev_dataloader: DataLoader, optimizer):
-    """multimodal_driver.py:391-421."""
+    """multimodal_driver.py:391-421: mean over the dev batches of MSELoss(logits, labels) (divided by the accumulation
+    factor like the reference).  The per-batch loss is the engine's fused MSE, summed on the device: one host sync."""
     model.eval()
-    dev_loss = torch.zeros((), device=_device())
     nb_dev_steps = 0
     rank, world = _dist()
     with torch.no_grad(), model.stream_scope():
-        for step, batch in enumerate(dev_dataloader):
+        model.loss_running(reset=True)
+        for step, batch in enumerate(_batches(dev_dataloader)):
             if step % world != rank:          # data parallel: each rank evaluates its share of the batches (SURVEY section 8 f-2)
                 continue
-            input_ids, visual, acoustic, input_mask, segment_ids, label_ids = _unpack(batch)
-            outputs = model(input_ids, visual, acoustic, token_type_ids=segment_ids, attention_mask=input_mask, labels=None)
-            logits = outputs[0]
-            loss = MSELoss()(logits.view(-1), label_ids.view(-1))
-            if args.gradient_accumulation_step > 1:
-                loss = loss / args.gradient_accumulation_step
-            dev_loss += loss
+            input_ids, visual, acoustic, input_mask, segment_ids, label_ids = batch
+            model.eval_step(input_ids, visual, acoustic, input_mask, segment_ids, label_ids)
             nb_dev_steps += 1
+        dev_loss = model.loss_running(reset=True)
+    if args.gradient_accumulation_step > 1:
+        dev_loss = dev_loss / args.gradient_accumulation_step
     if world > 1:
         import torch.distributed as dist
         acc = torch.stack([dev_loss.float(), torch.tensor(float(nb_dev_steps), device=dev_loss.device)])
@@ -476,16 +483,16 @@ def test_epoch(model: nn.Module, test_dataloader: DataLoader):
     model.eval()
     preds, labels = [], []
     rank, world = _dist()
-    with torch.no_grad():
-        for step, batch in enumerate(test_dataloader):
+    with torch.no_grad(), model.stream_scope():
+        for step, batch in enumerate(_batches(test_dataloader)):
             if step % world != rank:
                 continue
-            input_ids, visual, acoustic, input_mask, segment_ids, label_ids = _unpack(batch)
+            input_ids, visual, acoustic, input_mask, segment_ids, label_ids = batch
             outputs = model(input_ids, visual, acoustic, token_type_ids=segment_ids, attention_mask=input_mask, labels=None)
             preds.append(outputs[0].detach().view(-1))
-            labels.append(label_ids.detach().view(-1))
-    preds = torch.cat(preds).cpu().numpy() if preds else np.zeros((0,), np.float32)
-    labels = torch.cat(labels).cpu().numpy() if labels else np.zeros((0,), np.float32)
+            labels.append(label_ids.detach().view(-1).cpu().clone())      # (the ring recycles its pinned blocks)
+        preds = torch.cat(preds).cpu().numpy() if preds else np.zeros((0,), np.float32)
+    labels = torch.cat(labels).numpy() if labels else np.zeros((0,), np.float32)
     if world > 1:                             # every rank gets every prediction (order = by rank; the metrics are order-free)
         import torch.distributed as dist
         parts = [None] * world

@@ -170,6 +170,15 @@ int mb_bert_train_step(mb_bert_engine* e, const int64_t* input_ids, const float*
                        uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, float* m, float* v, float lr,
                        float beta1, float beta2, float eps, float weight_decay, int opt_step, int correct_bias, float grad_scale,
                        float loss_scale, int mode, void* stream);
+/* `batch = tuple(t.to(DEVICE) for t in batch)` (multimodal_driver.py:359, :396, :429) for callers that drive the passes
+ * themselves (evaluation, data parallel): ONE gather launch copies the six batch tensors into the engine's staging buffers.
+ * The sources may be pinned HOST memory (hipHostMalloc / torch pin_memory: the kernel reads it across PCIe, no copy engine, no
+ * extra stream) or device memory.  labels may be NULL.  staged6 receives the device pointers to hand to mb_bert_forward /
+ * mb_bert_backward in the order input_ids, visual, acoustic, attention_mask, token_type_ids, labels.  mb_bert_train_step
+ * does this gather itself (its sources may be pinned host memory too). */
+int mb_bert_load_batch(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                       const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                       const void** staged6, void* stream);
 /* number of graphs captured / replays launched so far (tests, bench) */
 int mb_bert_graph_stats(const mb_bert_engine* e, size_t* captures, size_t* launches);
 

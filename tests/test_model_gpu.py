@@ -261,13 +261,14 @@ def _trajectory(cdt, mode, nsteps=4, accum=1, layers=3, shapes=((5, 40), (5, 40)
             losses.append(m._core.loss_buf[0].clone())
             if update:
                 sch.step()
+    stats = m._core.graph_stats()           # (the eval forward below may need a larger engine, which starts from zero)
     m.eval()
     ids, vis, aco, mask, seg, lab = tb(weights.synthetic_bert_batch(4, 40, 47, 74, seed=99), DEV)
     with torch.no_grad():
         logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0].clone()
     torch.cuda.synchronize()
     return dict(p=m.flat_params.clone(), m=m._core._adam_m.clone(), v=m._core._adam_v.clone(), g=m.flat_grads.clone(), logits=logits,
-                shadow=m._core.shadow.clone(), losses=torch.stack(losses).cpu(), stats=m._core.graph_stats(), running=float(m.loss_running()))
+                shadow=m._core.shadow.clone(), losses=torch.stack(losses).cpu(), stats=stats, running=float(m.loss_running()))
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
@@ -313,24 +314,40 @@ def test_step_graph_gradient_accumulation_and_replay_stability():
     assert worst <= 1e-5 + 10 * noise
 
 
-def test_prefetcher_yields_the_batches_bit_exactly():
-    """prefetch.DevicePrefetcher: every batch arrives as `t.to(DEVICE)` would deliver it, in order, also when the consumer is
-    slower or faster than the copies and the batch shape changes (last batch of an epoch)."""
-    from bert_multimodal_transformer_amd.prefetch import DevicePrefetcher
+def test_pinned_batches_are_gathered_in_place_bit_exactly():
+    """prefetch.PinnedBatchRing + the engine's gather launch: a batch handed over as pinned HOST tensors gives exactly the
+    logits / loss / gradients of the same batch handed over as device tensors (`t.to(DEVICE)`), through every entry: eval
+    forward (mb_bert_load_batch), the Python-driven training step, and the single-call step (prologue gather).  The ring
+    recycles its blocks (7 batches through 3 blocks, the last one smaller)."""
+    from bert_multimodal_transformer_amd.prefetch import PinnedBatchRing
+    from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
     host = []
     for s, (B, L) in enumerate([(6, 20), (6, 20), (6, 20), (6, 20), (6, 20), (6, 20), (2, 20)]):
-        b = weights.synthetic_bert_batch(B, L, 47, 74, seed=500 + s)
-        t = tb(b)
+        t = tb(weights.synthetic_bert_batch(B, L, 47, 74, seed=500 + s))
         host.append((t[0], t[1].unsqueeze(1), t[2].unsqueeze(1), t[3], t[4], t[5]))      # [B,1,L,V] like a TensorDataset of features
+    torch.manual_seed(3)
+    m = build(layers=2, p_mag=0.0, hidden_p=0.0, attn_p=0.0)
     seen = 0
-    for i, dev_batch in enumerate(DevicePrefetcher(host, DEV)):
-        if i % 2:
-            torch.cuda.synchronize()
-        ref = host[i]
-        assert dev_batch[1].shape == ref[1].squeeze(1).shape
-        for k, (d, h) in enumerate(zip(dev_batch, ref)):
-            h = h.squeeze(1) if k in (1, 2) else h
-            assert d.is_cuda and d.dtype == h.dtype and torch.equal(d.cpu(), h), (i, k)
+    for i, pb in enumerate(PinnedBatchRing(host, DEV, blocks=3)):
+        ref = [h.squeeze(1) if k in (1, 2) else h for k, h in enumerate(host[i])]
+        for d, h in zip(pb, ref):
+            assert (not d.is_cuda) and d.is_pinned() and d.dtype == h.dtype and torch.equal(d, h)
+        dev = [h.to(DEV) for h in ref]
+        m.eval()
+        with torch.no_grad():
+            l_pin = m(pb[0], pb[1], pb[2], token_type_ids=pb[4], attention_mask=pb[3])[0].clone()
+            l_dev = m(dev[0], dev[1], dev[2], token_type_ids=dev[4], attention_mask=dev[3])[0].clone()
+        assert torch.equal(l_pin, l_dev), i
+        m.train()
+        grads = []
+        for batch, graph in ((pb, False), (dev, False), (pb, None), (dev, None)):
+            m.zero_grad()
+            m.train_step(*batch, optimizer=None, graph=graph)
+            grads.append((m.flat_grads.clone(), m._core.loss_buf[0].clone()))
+        torch.cuda.synchronize()
+        for g, l in grads[1:]:
+            assert float((l - grads[0][1]).abs()) <= 1e-6
+            assert float((g - grads[0][0]).abs().max()) <= 1e-5 * max(1.0, float(grads[0][0].abs().max()))      # fp32 atomics only
         seen += 1
     assert seen == len(host)
 

@@ -5,7 +5,9 @@
 // plain C++ process, so a GPU-box visit costs seconds instead of a Python/torch start-up, and rocprofv3 can wrap it.
 //
 //   step_bench [--steps K] [--warmup W] [--batch B] [--seq L] [--dtype bf16|fp32] [--visual V] [--layers N]
-//              [--graph 0|1] [--h2d 0|1] [--nbatch n] [--check 0|1]
+//              [--graph 0|1|2] [--h2d 0|1|2] [--nbatch n]
+//   --graph: 0 forward/backward/AdamW calls, 1 mb_bert_train_step hipGraph replay, 2 mb_bert_train_step stream launches
+//   --h2d:   0 batch resident in HBM, 1 hipMemcpyAsync per step, 2 batch read in place from pinned host memory by the prologue
 //
 // Prints one line per run: ms/step (HIP events around the K timed steps), host enqueue ms/step, samples/s, final loss.
 #include <hip/hip_runtime.h>
@@ -98,7 +100,8 @@ int main(int argc, char** argv) {
     int t_opt = 0;
     auto step = [&](int i) {
         char* src = db[i % nbatch];
-        if (h2d) HCK(hipMemcpyAsync(src, hb[i % nbatch], bytes, hipMemcpyHostToDevice, st));
+        if (h2d == 1) HCK(hipMemcpyAsync(src, hb[i % nbatch], bytes, hipMemcpyHostToDevice, st));     // copy engine, same stream
+        if (h2d == 2) src = hb[i % nbatch];       // zero-copy: the step prologue gathers the batch out of pinned host memory (--graph 1|2)
         Batch b = view(src);
         ++t_opt;
         if (graph) {
