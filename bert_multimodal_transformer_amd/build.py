@@ -65,21 +65,24 @@ def build(force=False, verbose=True):
 
 
 def build_tools(force=False):
-    """tools/step_bench: torch-free C++ driver of the step engine through the C ABI (measurement tooling)."""
+    """tools/*.cpp: torch-free C++ drivers of the C ABI (measurement tooling): step_bench (whole optimizer steps), gemm_bench."""
     root = os.path.dirname(HERE)
-    src = os.path.join(root, "tools", "step_bench.cpp")
-    if not os.path.exists(src):
-        return None
     outdir = os.path.join(root, "tools", "bin")
-    os.makedirs(outdir, exist_ok=True)
-    out = os.path.join(outdir, "step_bench")
-    if force or _stale(out, [src, LIB, os.path.join(root, "include", "magbert_hip.h")]):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", src, "-o", out, "-L" + LIBDIR, "-lmagbert_hip",
-               "-Wl,-rpath,$ORIGIN/../../bert_multimodal_transformer_amd/lib"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
-    return out
+    outs = []
+    for name in ("step_bench", "gemm_bench"):
+        src = os.path.join(root, "tools", name + ".cpp")
+        if not os.path.exists(src):
+            continue
+        os.makedirs(outdir, exist_ok=True)
+        out = os.path.join(outdir, name)
+        if force or _stale(out, [src, LIB, os.path.join(root, "include", "magbert_hip.h")]):
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", src, "-o", out, "-L" + LIBDIR, "-lmagbert_hip",
+                   "-Wl,-rpath,$ORIGIN/../../bert_multimodal_transformer_amd/lib"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        outs.append(out)
+    return outs
 
 
 if __name__ == "__main__":

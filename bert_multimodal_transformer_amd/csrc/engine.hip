@@ -44,9 +44,11 @@ struct mb_bert_engine {
     // weight-gradient GEMMs run on an internal side stream, concurrently with the dgrad chain of the same layer
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> evs;      // 5 events per encoder stage (4 forks + 1 join), never reused within a backward
-    int overlap_wgrad = 1;
+    int overlap_wgrad = 0;         // MB_OVERLAP_WGRAD=1: weight-gradient launches on the internal side stream (round-1 default; measured equal
+                                   // to the in-line grouped launch, which keeps the step a single-stream sequence -- and its hipGraph a fast one)
     int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128), 0 = four launches
-    bool deferred = false;         // grouped launch on the side stream, joined one stage later
+    bool grouped = false;          // the layer's four weight gradients are ONE launch
+    bool deferred = false;         // ... on the side stream, joined one stage later (MB_OVERLAP_WGRAD=0: on the caller's stream, in line)
     bool prof = false;             // mb_bert_set_profiling: timing events around every grouped wgrad launch (on the side stream)
     std::vector<hipEvent_t> pev;   // [2 * num_layers]
     bool ws_zeroed = false;
@@ -247,6 +249,7 @@ int mb_gemm(int dtype, int layout, int epilogue, int M, int N, int K, const void
     GemmArgs a = {};
     a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.C = C; a.ldc = ldc; a.C2 = C2; a.Cf = Cf;
     a.bias = bias; a.R = R; a.ldr = ldr; a.alpha = alpha; a.drop = dk(drop); a.kchunk = K; a.colsum = nullptr;
+    if (epilogue == EPI_DGELU) { a.colsum = Cf; a.Cf = nullptr; }       // epilogue 4: the fp32 pointer is the fused bias gradient
     return gemm_launch(dtype, layout, epilogue, a, splits, tile, (hipStream_t)stream);
 }
 
@@ -353,8 +356,10 @@ int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
     e->c = *cfg;
     if (const char* v = getenv("MB_OVERLAP_WGRAD")) e->overlap_wgrad = atoi(v);
     if (const char* v = getenv("MB_GROUP_WGRAD")) e->group_wgrad = atoi(v);
-    e->deferred = e->overlap_wgrad && (e->group_wgrad == 64 || e->group_wgrad == 128) &&
-                  cfg->hidden_size % e->group_wgrad == 0 && cfg->intermediate_size % e->group_wgrad == 0;
+    e->grouped = (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->hidden_size % e->group_wgrad == 0 &&
+                 cfg->intermediate_size % e->group_wgrad == 0;
+    e->deferred = e->overlap_wgrad && e->grouped;
+
     build_layout(e);
     *out = e;
     return MB_OK;
@@ -526,7 +531,8 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                               wgrad_args(I, H, Tk, du, I, ws + w.y1, H, G + o.w1, H),
                               wgrad_args(H, H, Tk, dzdB, H, ws + w.ctx, H, G + o.wo, H),
                               wgrad_args(3 * H, H, Tk, dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H)};
-            const bool grouped = e->deferred;
+            const bool grouped = e->grouped;
+            const bool inl = grouped && !e->deferred;         // grouped launch in line on the caller's stream (no overlap)
             if (grouped && !gemm_grouped_tn_ok(dt, wg, 4, e->group_wgrad)) return MB_ERR_SHAPE;
             if (!grouped) {
             CK(fork(0));
@@ -558,6 +564,12 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, dqkv, G + o.bqkv, B, L, nh,
                                   e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st));
             auto launch_group = [&]() -> int {
+                if (inl) {
+                    if (e->prof) CK((int)hipEventRecord(e->pev[2 * l], st));
+                    CK(gemm_grouped_tn_launch(dt, wg, 4, e->group_wgrad, st));
+                    if (e->prof) CK((int)hipEventRecord(e->pev[2 * l + 1], st));
+                    return MB_OK;
+                }
                 CK(fork(3));
                 if (e->prof) CK((int)hipEventRecord(e->pev[2 * l], ss));
                 CK(gemm_grouped_tn_launch(dt, wg, 4, e->group_wgrad, ss));
@@ -578,7 +590,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             // deferred join: the grouped wgrad of layer l keeps running under the dgrad chain of layer l-1; main only
             // waits for layer l+1's (whose dY buffers, same parity as l-1, are written next).  What is final on `st` when
             // this stage returns is therefore: weights of layer l+1, biases / LayerNorm of layer l (mb_bert_stage_grad_ranges)
-            if (grouped && l + 1 < NL) CK((int)hipStreamWaitEvent(st, e->evs[(size_t)(l + 1) * 5 + 4], 0));
+            if (e->deferred && l + 1 < NL) CK((int)hipStreamWaitEvent(st, e->evs[(size_t)(l + 1) * 5 + 4], 0));
         } else {
             // ---- MAG + embeddings
             if (e->deferred && e->side) CK((int)hipStreamWaitEvent(st, e->evs[4], 0));      // weight gradients of layer 0
@@ -703,6 +715,7 @@ int mb_bert_load_batch(mb_bert_engine* e, const int64_t* input_ids, const float*
     if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids) return MB_ERR_ARG;
     const int T = B * L;
     char* ws = e->ws;
+    CK(prepare_pass(e, T, st));          // the one-time clearing of the workspace must not land on top of the staged batch
     PrologueArgs pa = {};
     auto cp = [&](const void* src, size_t off, size_t bytes) {
         pa.src[pa.ncopies] = (const uint32_t*)src; pa.dst[pa.ncopies] = (uint32_t*)(ws + off); pa.dwords[pa.ncopies] = (uint32_t)(bytes / 4);
@@ -735,7 +748,7 @@ int mb_bert_set_profiling(mb_bert_engine* e, int on) {
 }
 
 int mb_bert_profile_wgrad_us(mb_bert_engine* e, float* avg_us) {
-    if (!e || !avg_us || !e->prof || !e->deferred) return MB_ERR_ARG;
+    if (!e || !avg_us || !e->prof || !e->grouped) return MB_ERR_ARG;
     double sum = 0.0;
     for (int l = 0; l < e->c.num_layers; ++l) {
         float ms = 0.f;

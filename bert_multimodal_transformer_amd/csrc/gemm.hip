@@ -145,13 +145,19 @@ template <> struct Vec8<float> {
     }
 };
 
-template <class T, int BM, int BN, int MODE>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0, int wr,
-                                              int wc, int lane, char* smem) {
-    constexpr int MT = BM / 32, NT = BN / 32;
+// KS (k-split waves): every wave holds a partial sum of the WHOLE tile (its quarter of every k-stage); the four partial tiles
+// are staged side by side and added in the row-major pass.
+template <class T, int BM, int BN, int MODE, bool KS>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS ? BM / 16 : BM / 32][KS ? BN / 16 : BN / 32],
+                                              int m0, int n0, int wave, int lane, char* smem) {
+    constexpr int MT = KS ? BM / 16 : BM / 32, NT = KS ? BN / 16 : BN / 32;
     constexpr int RBY = BN * 4;                     // staged row bytes (fp32)
+    constexpr int REG = BM * RBY;                   // one staged tile
+    constexpr int NSUM = KS ? 4 : 1;
     constexpr int TPR = BN / 8;                     // threads per row in the row-major pass
     constexpr int RPP = 256 / TPR;                  // rows per pass
+    const int wr = KS ? 0 : (wave >> 1), wc = KS ? 0 : (wave & 1);
+    char* stage = smem + (KS ? wave * REG : 0);
     __syncthreads();                                // every wave is done with the operand stages
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -159,7 +165,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         for (int j = 0; j < NT; ++j) {
             const int r = wr * (BM / 2) + i * 16 + (lane & 15);
             const int ch = (wc * (BN / 2) + j * 16 + (lane >> 4) * 4) >> 2;
-            *(f32x4*)(smem + r * RBY + ((ch ^ (r & 7)) << 4)) = acc[i][j];
+            *(f32x4*)(stage + r * RBY + ((ch ^ (r & 7)) << 4)) = acc[i][j];
         }
     __syncthreads();
     const int tid = threadIdx.x;
@@ -180,8 +186,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         float v[8];
         {
             const int ch = c >> 2;
-            const f32x4 a = *(const f32x4*)(smem + r * RBY + ((ch ^ (r & 7)) << 4));
-            const f32x4 b = *(const f32x4*)(smem + r * RBY + (((ch + 1) ^ (r & 7)) << 4));
+            f32x4 a = *(const f32x4*)(smem + r * RBY + ((ch ^ (r & 7)) << 4));
+            f32x4 b = *(const f32x4*)(smem + r * RBY + (((ch + 1) ^ (r & 7)) << 4));
+#pragma unroll
+            for (int w = 1; w < NSUM; ++w) {
+                a += *(const f32x4*)(smem + w * REG + r * RBY + ((ch ^ (r & 7)) << 4));
+                b += *(const f32x4*)(smem + w * REG + r * RBY + (((ch + 1) ^ (r & 7)) << 4));
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) { v[q] = a[q]; v[4 + q] = b[q]; }
         }
@@ -195,7 +206,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
             float g[8];
             const uint32_t gidx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;   // XLNet drops the activation (modeling_xlnet FF)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { v[q] += bias8[q]; g[q] = gelu_f(v[q]) * drop_mult(dkey, gidx + q); }
+            // C keeps gelu'(u), not u: the backward (EPI_DGELU) only ever needs u through gelu', and here u is still the fp32
+            // accumulator (bf16 mode: the derivative of the unrounded pre-activation; fp32 mode: bit-identical to computing it later)
+            for (int q = 0; q < 8; ++q) {
+                const float u = v[q] + bias8[q];
+                g[q] = gelu_f(u) * drop_mult(dkey, gidx + q);
+                v[q] = dgelu_f(u);
+            }
             Vec8<T>::store(C + off, v);
             Vec8<T>::store((T*)p.C2 + off, g);
         } else if constexpr (MODE == EPI_BIAS_DROP_RES) {
@@ -218,7 +235,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
             Vec8<T>::load((const T*)p.R + (size_t)m * p.ldr + n, u);
             const uint32_t gidx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { v[q] *= dgelu_f(u[q]) * drop_mult(dkey, gidx + q); cs[q] += v[q]; }
+            for (int q = 0; q < 8; ++q) { v[q] *= u[q] * drop_mult(dkey, gidx + q); cs[q] += v[q]; }      // R = gelu'(u) saved by EPI_BIAS_GELU
             Vec8<T>::store(C + off, v);
         } else if constexpr (MODE == EPI_ACCUM_F32) {
             float* dst = p.Cf + off;
@@ -236,7 +253,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
     }
     if constexpr (MODE == EPI_DGELU) {
         // fused bias gradient: this thread summed its rows; lanes that share the column group differ by TPR in lane id
-        if (p.colsum) {
+        if (p.colsum && !(p.dbg & 16)) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float s = cs[q];
@@ -314,7 +331,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
-    gemm_epilogue<T, BM, BN, MODE>(p, acc, m0, n0, wr, wc, lane, smem);
+    gemm_epilogue<T, BM, BN, MODE, false>(p, acc, m0, n0, wave, lane, smem);
 }
 
 
@@ -355,7 +372,9 @@ struct Dma {
     typedef typename Frag<T>::type frag_t;
 
     // physical chunk of logical chunk lc in row r of the row image (conflict-free ds_read_b128)
-    static __device__ __forceinline__ int rswz(int lc, int r) { return KB == 128 ? (lc ^ (r & 7)) : (lc ^ ((r >> 1) & 3)); }
+    static __device__ __forceinline__ int rswz(int lc, int r) {
+        return KB == 256 ? (lc ^ (r & 15)) : KB == 128 ? (lc ^ (r & 7)) : (lc ^ ((r >> 1) & 3));
+    }
 
     static __device__ __forceinline__ void issue(const T* __restrict__ base, int ld, int row0, int nrows, int k0,
                                                  char* lds, int lane, int wave, bool r1) {
@@ -415,14 +434,21 @@ struct Dma {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NSTAGE, int KB>
+template <int BM, int BN, int NSTAGE, int KB, bool KS = false>
 struct Gemm2Smem { static constexpr int STAGE = (BM + BN) * KB;
-                   static constexpr int BYTES = NSTAGE * STAGE > BM * BN * 4 ? NSTAGE * STAGE : BM * BN * 4; };   // ring, reused by the epilogue tile
+                   static constexpr int EPI = BM * BN * 4 * (KS ? 4 : 1);
+                   static constexpr int BYTES = NSTAGE * STAGE > EPI ? NSTAGE * STAGE : EPI; };   // ring, reused by the epilogue tile(s)
 
-template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB>
+// KS = k-split waves (KB = 256 only): instead of a quarter of the tile for every k, each of the four waves owns the WHOLE
+// BM x BN tile for one 64-byte k-slab of every stage.  A 64 x 64 tile cut four ways leaves a wave 32 x 32: four fragment reads
+// (1 KB of LDS traffic) per MFMA pair -- ~240 B/clk per CU at full MFMA rate, i.e. the LDS port itself.  With the whole tile per
+// wave it is half that, there is one barrier per 256 bytes of k instead of per 128, and the tile count (the only way a
+// [2432 x 768] output fills 256 CUs) stays the same.  The four partial tiles meet in the LDS-staged epilogue.
+template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB, bool KS = false>
 __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int bid, const int ky, char* smem) {
+    static_assert(!KS || KB == 256, "k-split waves: four 64-byte slabs per stage");
     constexpr int BKE = KB / sizeof(T);
-    constexpr int MT = BM / 32, NT = BN / 32;
+    constexpr int MT = KS ? BM / 16 : BM / 32, NT = KS ? BN / 16 : BN / 32;
     constexpr int STAGE = (BM + BN) * KB;
     typedef typename Frag<T>::type frag_t;
     typedef Dma<T, BM, AK, KB> DA;
@@ -431,7 +457,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int bid, con
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = KS ? 0 : (wave >> 1), wc = KS ? 0 : (wave & 1);
     int m0, n0;
     if (!tile_origin<BM, BN>(p, m0, n0, bid)) return;
     const int kbeg = ky * p.kchunk;
@@ -468,7 +494,8 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int bid, con
         if (t + NSTAGE - 1 < nt) issue(t + NSTAGE - 1);
         const char* cur = smem + (t % NSTAGE) * STAGE;
 #pragma unroll
-        for (int s = 0; s < KB / 64; ++s) {
+        for (int s0 = 0; s0 < (KS ? 1 : KB / 64); ++s0) {
+            const int s = KS ? wave : s0;
             frag_t a[MT], b[NT];
             if (!(p.dbg & 4)) {
 #pragma unroll
@@ -494,13 +521,13 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int bid, con
             }
         }
     }
-    gemm_epilogue<T, BM, BN, MODE>(p, acc, m0, n0, wr, wc, lane, smem);
+    gemm_epilogue<T, BM, BN, MODE, KS>(p, acc, m0, n0, wave, lane, smem);
 }
 
-template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB>
+template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB, bool KS = false>
 __global__ void __launch_bounds__(256) gemm2_kernel(const GemmArgs p) {
-    __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB>::BYTES];
-    gemm2_body<T, BM, BN, AK, BK, MODE, NSTAGE, KB>(p, blockIdx.x, blockIdx.y, smem);
+    __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB, KS>::BYTES];
+    gemm2_body<T, BM, BN, AK, BK, MODE, NSTAGE, KB, KS>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 // Grouped wgrad: up to MB_MAX_GROUP independent dW += dY^T X problems in ONE launch.  Each of a layer's four weight
@@ -566,6 +593,16 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
         if (g_stages > 0) { kb = (g_stages / 10 == 2) ? 64 : 128; ns = g_stages % 10; }
         if (kb == 64 && (p.kchunk % (64 / (int)sizeof(T)) != 0)) kb = 128;
 #define MB_LAUNCH2(NS, KBV) hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, NS, KBV>), grid, dim3(256), 0, st, p)
+        static int g_ks = -1;             // MB_GEMM_KSPLIT: 1 (default) = k-split waves for the 64 x 64 bf16 tiles, 0 = round-1 quarter tiles
+        if (g_ks < 0) g_ks = env_int("MB_GEMM_KSPLIT", 1);
+        if constexpr (BM == 64 && BN == 64 && sizeof(T) == 2) {
+            // each k-split block holds 64 KB of LDS (2 per CU): worth it while the whole grid is co-resident; beyond that
+            // (T = 4096: 768 tiles) the 32 KB quarter-tile kernel's higher residency wins (measured: 7.30 vs 7.97 ms per step)
+            if (g_ks && g_stages <= 0 && p.kchunk % 128 == 0 && splits == 1 && tiles <= 512) {
+                hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, 2, 256, true>), grid, dim3(256), 0, st, p);
+                return (int)hipGetLastError();
+            }
+        }
         if (kb == 128) {
             if (BM == 128) { if (ns <= 2) MB_LAUNCH2(2, 128); else MB_LAUNCH2(3, 128); }
             else { if (ns <= 2) MB_LAUNCH2(2, 128); else if (ns == 3) MB_LAUNCH2(3, 128); else MB_LAUNCH2(4, 128); }

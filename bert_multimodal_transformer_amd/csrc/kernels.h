@@ -18,10 +18,10 @@ enum { GEMM_NT = 0,   // A [M][K] row, B [N][K] row      : Y = X W^T            
        GEMM_TN = 2 }; // A [K][M] kmaj, B [K][N] kmaj    : dW = dY^T X          (wgrad)
 
 enum { EPI_BIAS = 0,          // C = alpha*acc + bias                                   (T out)
-       EPI_BIAS_GELU = 1,     // C = acc + bias ; C2 = gelu(C)                          (T out x2)
+       EPI_BIAS_GELU = 1,     // u = acc + bias ; C = gelu'(u) ; C2 = gelu(u) [* dropout]  (T out x2)
        EPI_BIAS_DROP_RES = 2, // C = dropout(acc + bias) + R                            (T out)
        EPI_ADD_RES = 3,       // C = acc (+ R)                                          (T out)
-       EPI_DGELU = 4,         // C = acc * gelu'(R)                                     (T out)
+       EPI_DGELU = 4,         // C = acc * R [* dropout], R = gelu'(u) saved by mode 1  (T out)
        EPI_ACCUM_F32 = 5,     // Cf += acc   (atomic when split-K)                      (fp32 out)
        EPI_BIAS_F32 = 6 };    // Cf = alpha*acc + bias                                  (fp32 out)
 

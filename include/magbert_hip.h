@@ -39,8 +39,9 @@ void mb_make_dropkey(uint64_t seed, uint64_t step, uint32_t site, float p, mb_dr
  * layout 0 (NT): A[M][K], B[N][K]          forward  Y = X W^T
  * layout 1 (NN): A[M][K], B[K][N]          dgrad    dX = dY W
  * layout 2 (TN): A[K][M], B[K][N]          wgrad    dW += dY^T X   (fp32 accumulate, split-K)
- * epilogue: 0 C=alpha*acc+bias | 1 C=acc+bias, C2=gelu(C) | 2 C=dropout(acc+bias)+R | 3 C=acc+R | 4 C=acc*gelu'(R)
- *           5 Cf+=acc (fp32) | 6 Cf=alpha*acc+bias (fp32)                                                        */
+ * epilogue: 0 C=alpha*acc+bias | 1 u=acc+bias: C=gelu'(u), C2=gelu(u) | 2 C=dropout(acc+bias)+R | 3 C=acc+R | 4 C=acc*R (R = the gelu'(u) saved by 1)
+ *           5 Cf+=acc (fp32) | 6 Cf=alpha*acc+bias (fp32)
+ * With epilogue 4, Cf (fp32 [N], may be NULL) receives += the column sums of C: the bias gradient of the Linear in front. */
 int mb_gemm(int dtype, int layout, int epilogue, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
             void* C, int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, float alpha,
             const mb_dropkey* drop, int splits, int tile, void* stream);

@@ -42,7 +42,7 @@ def loop(name, n, graph, pre):
     print("%-28s %6.3f ms/step  host %6.3f ms/step | next(batch): mean %.3f max %.3f | train_step: mean %.3f max %.3f" %
           (name, dt / n * 1e3, t_host / n * 1e3, m[:, 0].mean(), m[:, 0].max(), m[:, 1].mean(), m[:, 1].max()), flush=True)
 
-for rep in range(2):
+for rep in range(1):
     loop("python-driven, resident", 30, False, False)
     loop("single call, resident", 30, None, False)
     loop("graph, resident", 30, True, False)

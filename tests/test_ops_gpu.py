@@ -75,10 +75,11 @@ def test_gemm_nt_epilogues(dt, tdt, M, N, K, tile):
     ref = A.double() @ B.double().t()
     c, _, _ = gemm(dt, tdt, _lib.GEMM_NT, _lib.EPI_BIAS, M, N, K, A, B, bias=bias, alpha=0.5, tile=tile)
     close(c, (0.5 * ref + bias.double()).float(), dt, "bias")
-    u, g, _ = gemm(dt, tdt, _lib.GEMM_NT, _lib.EPI_BIAS_GELU, M, N, K, A, B, bias=bias, tile=tile)
-    uref = (ref + bias.double()).float()
-    close(u, uref, dt, "gelu.u")
-    close(g, torch.nn.functional.gelu(uref.to(tdt).float() if dt else uref), dt, "gelu.g", 2.0)
+    d, g, _ = gemm(dt, tdt, _lib.GEMM_NT, _lib.EPI_BIAS_GELU, M, N, K, A, B, bias=bias, tile=tile)
+    uref = (ref + bias.double())
+    dref = 0.5 * (1 + torch.erf(uref / 2 ** 0.5)) + uref * torch.exp(-0.5 * uref * uref) / (2 * np.pi) ** 0.5
+    close(d, dref.float(), dt, "gelu.dgelu(u)")        # C = gelu'(acc + bias): what the backward's EPI_DGELU multiplies by
+    close(g, torch.nn.functional.gelu(uref.float()), dt, "gelu.g", 2.0)
     key = _lib.make_dropkey(11, 3, 17, 0.1)
     mask = torch.from_numpy(rng.keep_mult(M * N, rng.make_key(11, 3, 17, 0.1))).view(M, N)
     c, _, _ = gemm(dt, tdt, _lib.GEMM_NT, _lib.EPI_BIAS_DROP_RES, M, N, K, A, B, bias=bias, R=R, drop=key, tile=tile)
@@ -97,9 +98,7 @@ def test_gemm_nn_dgrad(dt, tdt, M, N, K, tile):
     c, _, _ = gemm(dt, tdt, _lib.GEMM_NN, _lib.EPI_ADD_RES, M, N, K, A, B, R=R, tile=tile)
     close(c, (ref + R.double()).float(), dt, "add_res")
     c, _, _ = gemm(dt, tdt, _lib.GEMM_NN, _lib.EPI_DGELU, M, N, K, A, B, R=R, tile=tile)
-    x = R.double()
-    dgelu = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * np.pi) ** 0.5
-    close(c, (ref * dgelu).float(), dt, "dgelu")
+    close(c, (ref * R.double()).float(), dt, "dgelu")      # R = gelu'(u) as saved by the forward's EPI_BIAS_GELU
 
 
 @pytest.mark.parametrize("dt,tdt", DTS)

@@ -1,0 +1,112 @@
+// gemm_bench -- torch-free timing of the encoder's GEMM launches through the C ABI (mb_gemm / mb_gemm_grouped_wgrad).
+// Measurement tooling (not product).  Every case runs `reps` launches over `nset` rotating operand sets (so that operands
+// come from HBM / Infinity Cache like inside a training step, not from a warm L2) between two HIP events.
+//
+//   gemm_bench [--T tokens] [--reps n] [--nset n] [--only substring]
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../include/magbert_hip.h"
+
+#define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(_e)); exit(2); } } while (0)
+#define MCK(x) do { int _e = (x); if (_e) { fprintf(stderr, "%s:%d magbert error %d: %s\n", __FILE__, __LINE__, _e, mb_error_string(_e)); exit(3); } } while (0)
+
+static void* dev_rand(size_t n_bf16, uint32_t seed) {
+    std::vector<uint16_t> h(n_bf16);
+    uint32_t s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n_bf16; ++i) {
+        s = s * 1664525u + 1013904223u;
+        const float v = ((int)((s >> 9) & 0x7FFF) - 16384) * (0.05f / 16384.f);        // uniform in [-0.05, 0.05)
+        uint32_t b; memcpy(&b, &v, 4);
+        h[i] = (uint16_t)(b >> 16);
+    }
+    void* d; HCK(hipMalloc(&d, n_bf16 * 2)); HCK(hipMemcpy(d, h.data(), n_bf16 * 2, hipMemcpyHostToDevice));
+    return d;
+}
+
+int main(int argc, char** argv) {
+    int T = 2400, reps = 48, nset = 6;
+    std::string only;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        std::string k = argv[i];
+        if (k == "--T") T = atoi(argv[i + 1]); else if (k == "--reps") reps = atoi(argv[i + 1]);
+        else if (k == "--nset") nset = atoi(argv[i + 1]); else if (k == "--only") only = argv[i + 1];
+    }
+    const int H = 768, I = 3072;
+    const int Tp = (T + 63) / 64 * 64;
+    hipStream_t st; HCK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    std::vector<void*> xh(nset), xi(nset), x3(nset), oi(nset), oi2(nset), o3(nset);
+    for (int s = 0; s < nset; ++s) {
+        xh[s] = dev_rand((size_t)Tp * H, 10 + s); xi[s] = dev_rand((size_t)Tp * I, 20 + s); x3[s] = dev_rand((size_t)Tp * 3 * H, 30 + s);
+        HCK(hipMalloc(&oi[s], (size_t)Tp * I * 2)); HCK(hipMalloc(&oi2[s], (size_t)Tp * I * 2)); HCK(hipMalloc(&o3[s], (size_t)Tp * 3 * H * 2));
+    }
+    void *wqkv = dev_rand((size_t)3 * H * H, 1), *wo = dev_rand((size_t)H * H, 2), *w1 = dev_rand((size_t)I * H, 3), *w2 = dev_rand((size_t)H * I, 4);
+    float *bias, *colsum, *gW[4];
+    HCK(hipMalloc(&bias, (size_t)I * 4)); HCK(hipMemset(bias, 0, (size_t)I * 4));
+    HCK(hipMalloc(&colsum, (size_t)I * 4)); HCK(hipMemset(colsum, 0, (size_t)I * 4));
+    const int gM[4] = {H, I, H, 3 * H}, gN[4] = {I, H, H, H};
+    for (int g = 0; g < 4; ++g) { HCK(hipMalloc(&gW[g], (size_t)gM[g] * gN[g] * 4)); HCK(hipMemset(gW[g], 0, (size_t)gM[g] * gN[g] * 4)); }
+    mb_dropkey key; mb_make_dropkey(1, 1, 17, 0.1f, &key);
+    enum { NT = 0, NN = 1 };
+    struct Case { const char* name; int layout, epi, M, N, K; int a, b, r, c; };     // operand selectors: 0 xh, 1 xi, 2 x3 ; weights 0 qkv 1 o 2 w1 3 w2
+    const Case cases[] = {
+        {"fwd qkv   [T,768]x[2304,768]^T +bias", NT, 0, T, 3 * H, H, 0, 0, -1, 2},
+        {"fwd out   [T,768]x[768,768]^T +bias+drop+res", NT, 2, T, H, H, 0, 1, 0, 0},
+        {"fwd ffn1  [T,768]x[3072,768]^T +bias+gelu", NT, 1, T, I, H, 0, 2, -1, 1},
+        {"fwd ffn2  [T,3072]x[768,3072]^T +bias+drop+res", NT, 2, T, H, I, 1, 3, 0, 0},
+        {"dgrad ffn2 [T,768]x[768,3072] *gelu' +colsum", NN, 4, T, I, H, 0, 3, 1, 1},
+        {"dgrad ffn1 [T,3072]x[3072,768] +res", NN, 3, T, H, I, 1, 2, 0, 0},
+        {"dgrad out  [T,768]x[768,768]", NN, 3, T, H, H, 0, 1, -1, 0},
+        {"dgrad qkv  [T,2304]x[2304,768] +res", NN, 3, T, H, 3 * H, 2, 0, 0, 0},
+    };
+    void* W[4] = {wqkv, wo, w1, w2};
+    const int ldw[4] = {H, H, H, I};
+    hipEvent_t e0, e1; HCK(hipEventCreate(&e0)); HCK(hipEventCreate(&e1));
+    double tot_us = 0, tot_fl = 0;
+    auto sel = [&](int which, int s) -> void* { return which == 0 ? xh[s] : which == 1 ? xi[s] : x3[s]; };
+    auto ld = [&](int which) { return which == 0 ? H : which == 1 ? I : 3 * H; };
+    for (const Case& c : cases) {
+        if (!only.empty() && !strstr(c.name, only.c_str())) continue;
+        auto launch = [&](int i) {
+            const int s = i % nset;
+            void* out = c.c == 0 ? o3[s] : c.c == 1 ? oi[s] : o3[s];
+            // NN: B is the weight as stored [K][N] (ldb = N); NT: B [N][K] (ldb = K)
+            const int ldb = c.layout == NN ? c.N : c.K;
+            (void)ldw;
+            MCK(mb_gemm(MB_DT_BF16, c.layout, c.epi, c.M, c.N, c.K, sel(c.a, s), ld(c.a), W[c.b], ldb, out, c.N, oi2[s],
+                        c.epi == 4 ? colsum : nullptr, bias, c.r >= 0 ? sel(c.r, (s + 1) % nset) : nullptr, c.r >= 0 ? ld(c.r) : 0, 1.0f, &key, 1, 0, st));
+        };
+        for (int i = 0; i < 4; ++i) launch(i);
+        HCK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) launch(i);
+        HCK(hipEventRecord(e1, st)); HCK(hipEventSynchronize(e1));
+        float ms; HCK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / reps, fl = 2.0 * c.M * c.N * c.K;
+        printf("%-52s %8.2f us %8.1f TF/s\n", c.name, us, fl / us * 1e-6);
+        tot_us += us; tot_fl += fl;
+    }
+    if (only.empty() || strstr("wgrad", only.c_str())) {
+        auto launch = [&](int i) {
+            const int s = i % nset;
+            const void* dY[4] = {xh[s], xi[s], xh[(s + 1) % nset], x3[s]};
+            const void* X[4] = {xi[(s + 2) % nset], xh[(s + 2) % nset], xh[(s + 3) % nset], xh[(s + 4) % nset]};
+            const int ldy[4] = {H, I, H, 3 * H}, ldx[4] = {I, H, H, H};
+            MCK(mb_gemm_grouped_wgrad(MB_DT_BF16, 4, gM, gN, Tp, dY, ldy, X, ldx, gW, gN, 128, st));
+        };
+        for (int i = 0; i < 4; ++i) launch(i);
+        HCK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) launch(i);
+        HCK(hipEventRecord(e1, st)); HCK(hipEventSynchronize(e1));
+        float ms; HCK(hipEventElapsedTime(&ms, e0, e1));
+        double fl = 0; for (int g = 0; g < 4; ++g) fl += 2.0 * gM[g] * gN[g] * Tp;
+        const double us = ms * 1e3 / reps;
+        printf("%-52s %8.2f us %8.1f TF/s\n", "wgrad x4 grouped [768x3072|3072x768|768x768|2304x768]", us, fl / us * 1e-6);
+        tot_us += us; tot_fl += fl;
+    }
+    printf("per-layer GEMM time %.1f us, aggregate %.1f TF/s (T=%d, bf16, %d rotating operand sets)\n", tot_us, tot_fl / tot_us * 1e-6, T, nset);
+    return 0;
+}
