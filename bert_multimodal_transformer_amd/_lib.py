@@ -70,6 +70,9 @@ PROTOTYPES = {
     "mb_bert_backward": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp]),
     "mb_bert_sequence_output": (_vp, [_vp]),
     "mb_bert_pooled_output": (_vp, [_vp]),
+    "mb_bert_hidden_state": (_vp, [_vp, _i]),
+    "mb_bert_set_attention_output": (_i, [_vp, _vp]),
+    "mb_bert_backward_outputs": (_i, [_vp, _vp, _vp, _vp]),
     "mb_bert_stage_grad_ranges": (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz), _i]),
     "mb_bert_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f,
                                 _i, _i, _f, _f, _i, _vp]),
@@ -91,6 +94,7 @@ PROTOTYPES = {
     "mb_xlnet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64, _vp, _vp, _vp, _vp]),
     "mb_xlnet_backward": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp]),
     "mb_xlnet_sequence_output": (_vp, [_vp]),
+    "mb_xlnet_hidden_state": (_vp, [_vp, _i]),
     "mb_xlnet_stage_grad_ranges": (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz), _i]),
 }
 

@@ -75,6 +75,28 @@ class _EngineFn(torch.autograd.Function):
         return torch.zeros((), device=dlogits.device), None, None
 
 
+class _BaseFn(torch.autograd.Function):
+    """(sequence_output, pooled_output) = MAG_BertModel(batch) with an autograd edge (bert.py:233-237 returns autograd tensors):
+    the forward was already enqueued; backward turns (d_sequence_output, d_pooled_output) into the engine's entry gradients and
+    runs the encoder / MAG / embedding stages, accumulating into the flat gradient buffer (p.grad are views of it)."""
+
+    @staticmethod
+    def forward(ctx, anchor, seq, pooled, core):
+        ctx.core = core
+        ctx.save_for_backward(pooled)
+        return seq.view_as(seq), pooled.view_as(pooled)
+
+    @staticmethod
+    def backward(ctx, d_seq, d_pooled):
+        core = ctx.core
+        (pooled,) = ctx.saved_tensors
+        cd = core.compute_dtype
+        ds = None if d_seq is None else d_seq.to(cd).contiguous()
+        dz = None if d_pooled is None else (d_pooled.float() * (1.0 - pooled * pooled)).to(cd).contiguous()    # tanh'
+        core.backward_outputs(ds, dz)
+        return torch.zeros((), device=core.device), None, None, None
+
+
 class _Core(object):
     """Flat parameter/gradient storage + engine handle shared by the model classes."""
 
@@ -234,6 +256,8 @@ class _Core(object):
             with _Core._Hop(self):
                 _lib.check(self.lib.mb_bert_load_batch(self.handle, ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5], B, L, staged,
                                                        self.stream()))
+            off = staged[0] - self.ws.data_ptr()
+            self._ids_dev = self.ws[off: off + B * L * 8].view(torch.int64)          # the engine's staging copy of input_ids
             return [C.c_void_p(staged[i]) if staged[i] else None for i in range(6)], six
         nb = not input_ids.is_cuda and input_ids.is_pinned()      # pinned host tensors: asynchronous copies on this stream
         ids = input_ids.to(dev, torch.int64, non_blocking=nb).contiguous()
@@ -246,6 +270,7 @@ class _Core(object):
                              (self.V, self.A, tuple(vis.shape), tuple(aco.shape)))
         lab = None if labels is None else labels.to(dev, torch.float32, non_blocking=nb).contiguous().view(-1)
         keep = (ids, vis, aco, msk, seg, lab)
+        self._ids_dev = ids.reshape(-1)
         return [_lib.ptr(t) for t in keep], keep
 
     def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, training):
@@ -279,6 +304,10 @@ class _Core(object):
                                                 float(loss_scale), s, s + 1, self.stream()))
                 for hook in self.stage_hooks:
                     hook(s)
+
+    def batch_ids(self):
+        """device tensor of the token ids of the last forward (data parallel: the rows of the word-embedding gradient)"""
+        return self._ids_dev
 
     def fused_step_blocker(self):
         """why one optimizer step cannot be ONE engine call (mb_bert_train_step), or None"""
@@ -325,13 +354,45 @@ class _Core(object):
         _lib.check(self.lib.mb_bert_graph_stats(self.handle, C.byref(cap), C.byref(rep)))
         return cap.value, rep.value
 
-    def sequence_output(self, B, L):
+    def _act(self, ptr, B, L):
+        """fp32 copy of a [B*L][H] activation of the last forward (workspace pointer -> tensor)"""
         H = self.config.hidden_size
-        p = self._fn("sequence_output")(self.handle)
         es = 2 if self.dt == _lib.DT_BF16 else 4
-        off = p - self.ws.data_ptr()
-        raw = self.ws[off: off + B * L * H * es]
-        return raw.view(self.compute_dtype).view(B, L, H).float()
+        off = ptr - self.ws.data_ptr()
+        return self.ws[off: off + B * L * H * es].view(self.compute_dtype).view(B, L, H).float()
+
+    def hidden_states(self, B, L):
+        """all_hidden_states of the last forward: n_layers + 1 tensors [B, L, H] (bert.py:227-237 / xlnet.py:363-392)"""
+        return tuple(self._act(self._fn("hidden_state")(self.handle, i), B, L) for i in range(self.n_layers + 1))
+
+    def attention_buffer(self, B, L):
+        """arms the next forward to write every layer's attention probabilities (MAG-BERT); returns the buffer"""
+        if self.kind != "bert":
+            raise NotImplementedError("output_attentions is built for MAG-BERT only")
+        nh = self.config.num_attention_heads
+        buf = torch.empty(self.n_layers, B, nh, L, L, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mb_bert_set_attention_output(self.handle, _lib.ptr(buf)))
+        return buf
+
+    def attention_done(self):
+        if self.kind == "bert":
+            _lib.check(self.lib.mb_bert_set_attention_output(self.handle, None))
+
+    def backward_outputs(self, d_seq, d_pre):
+        """backward of the base model from the gradients of (sequence_output, pooler pre-activation): mb_bert_backward_outputs,
+        then the encoder / MAG / embedding stages"""
+        nstage = self.n_layers + 2
+        with _Core._Hop(self):
+            _lib.check(self.lib.mb_bert_backward_outputs(self.handle, _lib.ptr(d_seq), _lib.ptr(d_pre), self.stream()))
+            for hook in self.stage_hooks:
+                hook(0)
+            for s in range(1, nstage):
+                _lib.check(self.lib.mb_bert_backward(self.handle, None, None, 1.0, s, s + 1, self.stream()))
+                for hook in self.stage_hooks:
+                    hook(s)
+
+    def sequence_output(self, B, L):
+        return self._act(self._fn("sequence_output")(self.handle), B, L)
 
     def pooled_output(self, B):
         H = self.config.hidden_size
@@ -394,6 +455,59 @@ def _init_weights(core):
                     H = shape[1]
                     v[core.config.pad_token_id * H:(core.config.pad_token_id + 1) * H].zero_()
     core.weights_dirty = True
+
+
+def load_pretrained_state_dict(model, state_dict, base_prefix, source="checkpoint"):
+    """The key handling of transformers 3.0.2 PreTrainedModel.from_pretrained (what multimodal_driver.py:317-323 relies on):
+      * legacy LayerNorm names: `gamma` -> `weight`, `beta` -> `bias` (the published bert-base-uncased file uses them);
+      * base-model prefix: a checkpoint saved from the bare BertModel / XLNetModel loads into `model.<base_prefix>`; a
+        checkpoint saved from a model with a head loads into the bare model with the prefix stripped;
+      * `*.position_ids` buffers of newer transformers are ignored;
+      * everything of the checkpoint that has no home here is reported as unexpected (e.g. `cls.predictions.*`), every
+        parameter of the model the checkpoint does not provide as missing (it keeps its fresh init: `bert.MAG.*`,
+        `classifier.*`, ...); a tensor with the wrong shape is an error, as in transformers.
+    Nothing is dropped silently: both lists are logged (logging.WARNING, same wording as transformers) and returned."""
+    import logging
+    log = logging.getLogger(__name__)
+    sd = {}
+    for k, v in state_dict.items():
+        nk = k.replace("gamma", "weight") if "gamma" in k else k
+        nk = nk.replace("beta", "bias") if "beta" in nk else nk
+        if nk.endswith("position_ids"):
+            continue
+        sd[nk] = v
+    own = dict(model.state_dict())
+    pre = base_prefix + "."
+    model_has = any(k.startswith(pre) for k in own)
+    ckpt_has = any(k.startswith(pre) for k in sd)
+    if model_has and not ckpt_has:
+        sd = {pre + k: v for k, v in sd.items()}
+    elif not model_has and ckpt_has:
+        sd = {(k[len(pre):] if k.startswith(pre) else k): v for k, v in sd.items()}
+    missing = [k for k in own if k not in sd]
+    unexpected = [k for k in sd if k not in own]
+    errors = ["size mismatch for %s: copying a param with shape %s from checkpoint, the shape in current model is %s." %
+              (k, tuple(sd[k].shape), tuple(own[k].shape)) for k in own if k in sd and tuple(sd[k].shape) != tuple(own[k].shape)]
+    if errors:
+        raise RuntimeError("Error(s) in loading state_dict for %s:\n\t%s" % (model.__class__.__name__, "\n\t".join(errors)))
+    nn.Module.load_state_dict(model, {k: v for k, v in sd.items() if k in own}, strict=False)
+    model._core.weights_dirty = True
+    name = model.__class__.__name__
+    if unexpected:
+        log.warning("Some weights of the model checkpoint at %s were not used when initializing %s: %s", source, name, unexpected)
+    if missing:
+        log.warning("Some weights of %s were not initialized from the model checkpoint at %s and are newly initialized: %s",
+                    name, source, missing)
+    return {"missing_keys": missing, "unexpected_keys": unexpected, "error_msgs": []}
+
+
+def _pretrained_file(path, cls_name):
+    if os.path.isdir(path):
+        path = os.path.join(path, "pytorch_model.bin")
+    if not os.path.isfile(path):
+        raise OSError("from_pretrained(%r): no local checkpoint (offline build; pass a directory holding pytorch_model.bin or a "
+                      "state-dict file, or construct %s(config, multimodal_config) and load_state_dict yourself)" % (path, cls_name))
+    return path
 
 
 class _MagBertBase(nn.Module):
@@ -468,29 +582,29 @@ class _MagBertBase(nn.Module):
         """call after editing parameters in place (bf16 mode keeps an operand shadow of the GEMM weights)"""
         self._core.sync_weights()
 
+    base_model_prefix = "bert"
+
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, **kwargs):
-        """multimodal_driver.py:317-319.  There is no network here: the argument must be a local directory
-        (or file) holding a `pytorch_model.bin`-style state dict; missing keys (bert.MAG.*, classifier.*) keep
-        their fresh init exactly like the reference."""
+        """multimodal_driver.py:317-319.  There is no network here: the argument must be a local directory (or file) holding
+        a `pytorch_model.bin`-style state dict, e.g. the published bert-base-uncased file.  Keys are mapped the way
+        transformers 3.0.2 maps them (load_pretrained_state_dict: legacy gamma / beta names, base-model prefix); parameters
+        the checkpoint lacks (bert.MAG.*, classifier.*) keep their fresh init exactly like in the reference, and both the
+        missing and the unused keys are logged and kept in `model.loading_info` (`output_loading_info=True` returns them)."""
         multimodal_config = kwargs.pop("multimodal_config", model_args[0] if model_args else None)
         num_labels = kwargs.pop("num_labels", 1)
-        config = config or BertConfig(num_labels=num_labels)
+        want_info = kwargs.pop("output_loading_info", False)
+        config = config or cls._default_config(num_labels)
         config.num_labels = num_labels
         model = cls(config, multimodal_config, **kwargs)
-        path = pretrained_model_name_or_path
-        if os.path.isdir(path):
-            path = os.path.join(path, "pytorch_model.bin")
-        if not os.path.isfile(path):
-            raise OSError("from_pretrained(%r): no local checkpoint (offline build; pass a directory or state-dict file, "
-                          "or construct %s(config, multimodal_config) and load_state_dict yourself)" %
-                          (pretrained_model_name_or_path, cls.__name__))
+        path = _pretrained_file(pretrained_model_name_or_path, cls.__name__)
         sd = torch.load(path, map_location="cpu")
-        own = model.state_dict().keys()
-        if not any(k in own for k in sd):          # plain BertModel checkpoint: keys lack the "bert." prefix
-            sd = {"bert." + k: v for k, v in sd.items()}
-        model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
-        return model
+        model.loading_info = load_pretrained_state_dict(model, sd, cls.base_model_prefix, source=path)
+        return (model, model.loading_info) if want_info else model
+
+    @staticmethod
+    def _default_config(num_labels):
+        return BertConfig(num_labels=num_labels)
 
 
 class _FusedStep(object):
@@ -515,11 +629,11 @@ class _FusedStep(object):
         Where it can (MAG-BERT, single process, the driver's two parameter groups on this model's flat buffer) the whole
         iteration is ONE engine call, mb_bert_train_step: a step prologue that gathers the batch (straight from pinned host
         memory if that is where it is) and puts this step's dropout keys / lr / bias correction into device memory, then every
-        kernel of the step -- launched one after the other (default), or as one replayed hipGraph with graph=True or
-        MB_STEP_GRAPH=1 (measured on ROCm 7.2: the two-stream graph replays 4-6 % SLOWER than the stream launches, see
-        DESIGN.md, so it is opt-in).  Otherwise (MAG-XLNet, data parallel, foreign optimizers) the passes are driven from
-        here: training_step + optimizer.step().  graph=False forces that path.  Pass optimizer=None on gradient-accumulation
-        micro-steps.  Returns the device loss scalar."""
+        kernel of the step as ONE replayed hipGraph (the step is a single-stream kernel sequence: replay costs ~12 us of host
+        time and runs as fast as the stream launches).  graph="launches" (or MB_STEP_GRAPH=0) keeps the single call but launches
+        the kernels one by one.  Otherwise (MAG-XLNet, data parallel, foreign optimizers) the passes are driven from here:
+        training_step + optimizer.step(); graph=False forces that path, graph=True raises if the single call is unavailable.
+        Pass optimizer=None on gradient-accumulation micro-steps.  Returns the device loss scalar."""
         if self.num_labels != 1:
             raise NotImplementedError("fused loss is the regression MSE of the driver (num_labels == 1)")
         core = self._core
@@ -529,8 +643,6 @@ class _FusedStep(object):
             opt = optimizer.flat_step_args(core) if hasattr(optimizer, "flat_step_args") else None
             if opt is None:
                 why = "the optimizer is not the two-group AdamW over this model's flat buffer"
-        if graph is None and os.environ.get("MB_STEP_GRAPH", "0") == "1":
-            graph = True
         if graph is True and why is not None:
             raise _lib.MagbertError("single-call step unavailable: " + why)
         if why is not None or graph is False:
@@ -543,8 +655,9 @@ class _FusedStep(object):
             optimizer._t += 1
             opt["t"] = optimizer._t
             optimizer._opt_called = True          # the update happens inside the step: lr schedulers see an optimizer step
+        launches = graph == "launches" or (graph is None and os.environ.get("MB_STEP_GRAPH", "1") == "0")
         core.train_step(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, opt, loss_scale=loss_scale,
-                        mode=1 if graph is True else 2)
+                        mode=2 if launches else 1)
         return core.loss_buf[0]
 
     def eval_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids):
@@ -590,9 +703,15 @@ class MAG_BertModel(_MagBertBase):
     def forward(self, input_ids, visual, acoustic, attention_mask=None, token_type_ids=None, position_ids=None,
                 head_mask=None, inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 output_attentions=None, output_hidden_states=None):
+        """-> (sequence_output, pooled_output, (hidden_states), (attentions)) like bert.py:233-237.  sequence_output and
+        pooled_output carry an autograd edge into the engine (a head built on top of this model trains the whole stack);
+        hidden_states / attentions are detached fp32 copies.  head_mask, inputs_embeds, non-default position_ids and the
+        decoder arguments are not built on the HIP path and raise."""
         self._unsupported(position_ids=position_ids, head_mask=head_mask, inputs_embeds=inputs_embeds,
-                          encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask,
-                          output_attentions=output_attentions, output_hidden_states=output_hidden_states)
+                          encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask)
+        output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
+        output_hidden_states = (output_hidden_states if output_hidden_states is not None
+                                else getattr(self.config, "output_hidden_states", False))
         if input_ids is None:
             raise ValueError("You have to specify either input_ids or inputs_embeds")      # bert.py:166-168
         if attention_mask is None:
@@ -600,8 +719,25 @@ class MAG_BertModel(_MagBertBase):
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)                                     # bert.py:175-177
         B, L = input_ids.shape
-        self._core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training)
-        return self._core.sequence_output(B, L), self._core.pooled_output(B)
+        core = self._core
+        probs = None
+        if output_attentions:
+            core._ensure(B, L)
+            probs = core.attention_buffer(B, L)
+        try:
+            core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training)
+        finally:
+            if output_attentions:
+                core.attention_done()
+        seq, pooled = core.sequence_output(B, L), core.pooled_output(B)
+        if torch.is_grad_enabled():
+            seq, pooled = _BaseFn.apply(core.anchor, seq, pooled, core)
+        outputs = (seq, pooled)
+        if output_hidden_states:
+            outputs = outputs + (core.hidden_states(B, L),)
+        if output_attentions:
+            outputs = outputs + (tuple(probs[l] for l in range(core.n_layers)),)
+        return outputs
 
 
 class MAG_BertForSequenceClassification(_FusedStep, _MagBertBase):
@@ -621,17 +757,32 @@ class MAG_BertForSequenceClassification(_FusedStep, _MagBertBase):
     # reference API ------------------------------------------------------------------------------------
     def forward(self, input_ids, visual, acoustic, attention_mask=None, token_type_ids=None, position_ids=None,
                 head_mask=None, inputs_embeds=None, labels=None, output_attentions=None, output_hidden_states=None):
-        self._unsupported(position_ids=position_ids, head_mask=head_mask, inputs_embeds=inputs_embeds,
-                          output_attentions=output_attentions, output_hidden_states=output_hidden_states)
+        self._unsupported(position_ids=position_ids, head_mask=head_mask, inputs_embeds=inputs_embeds)
+        output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
+        output_hidden_states = (output_hidden_states if output_hidden_states is not None
+                                else getattr(self.config, "output_hidden_states", False))
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         core = self._core
-        logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training)
+        B, L = input_ids.shape
+        probs = None
+        if output_attentions:
+            core._ensure(B, L)
+            probs = core.attention_buffer(B, L)
+        try:
+            logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training)
+        finally:
+            if output_attentions:
+                core.attention_done()
         if torch.is_grad_enabled():
             logits = _EngineFn.apply(core.anchor, logits, core)
-        outputs = (logits,)
+        outputs = (logits,)                                           # bert.py:309-311: (logits,) + outputs[2:]
+        if output_hidden_states:
+            outputs = outputs + (core.hidden_states(B, L),)
+        if output_attentions:
+            outputs = outputs + (tuple(probs[l] for l in range(core.n_layers)),)
         if labels is not None:                                        # bert.py:313-322
             if self.num_labels == 1:
                 loss = torch.nn.functional.mse_loss(logits.view(-1), labels.to(logits.device).float().view(-1))

@@ -23,7 +23,8 @@ namespace mb {
 // =============================================================================================== forward
 template <class T, int LP, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
-                                                           T* __restrict__ ctx, int L, int nh, DropKey drop) {
+                                                           T* __restrict__ ctx, float* __restrict__ probs, int L, int nh,
+                                                           DropKey drop) {
     drop.resolve();
     typedef AttnCfg<T> C;
     constexpr int PIT = C::ROWB + 16;                 // image pitch (bytes)
@@ -89,6 +90,11 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p[r] *= drop_mult(drop, rowidx + j + r);
                 store4((T*)(Ps + (lane & 15) * SPIT) + j, p);
+                if (probs && i < L) {           // output_attentions (bert.py:147-151): the probabilities after dropout, fp32
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (j + r < L) probs[(size_t)rowidx + j + r] = p[r];
+                }
             }
         }
         __syncthreads();
@@ -323,8 +329,9 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
 
 // =============================================================================================== host
 template <class T, int LP, int NW>
-static int launch_fwd(const void* qkv, const int64_t* mask, void* ctx, int B, int L, int nh, DropKey drop, hipStream_t st) {
-    hipLaunchKernelGGL((attn_fwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, mask, (T*)ctx, L,
+static int launch_fwd(const void* qkv, const int64_t* mask, void* ctx, float* probs, int B, int L, int nh, DropKey drop,
+                      hipStream_t st) {
+    hipLaunchKernelGGL((attn_fwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, mask, (T*)ctx, probs, L,
                        nh, drop);
     return (int)hipGetLastError();
 }
@@ -337,22 +344,22 @@ static int launch_bwd(const void* qkv, const int64_t* mask, const void* dctx, vo
 }
 
 int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx, int B, int L, int nh, DropKey drop,
-                      hipStream_t st) {
+                      hipStream_t st, float* probs) {
     if (L < 1 || L > 128) return MB_ERR_SHAPE;
     const int LP = (L + 31) / 32 * 32;
     if (dtype == DT_BF16) {
         switch (LP) {
-            case 32: return launch_fwd<bf16, 32, 2>(qkv, mask, ctx, B, L, nh, drop, st);
-            case 64: return launch_fwd<bf16, 64, 4>(qkv, mask, ctx, B, L, nh, drop, st);
-            case 96: return launch_fwd<bf16, 96, 4>(qkv, mask, ctx, B, L, nh, drop, st);
-            default: return launch_fwd<bf16, 128, 4>(qkv, mask, ctx, B, L, nh, drop, st);
+            case 32: return launch_fwd<bf16, 32, 2>(qkv, mask, ctx, probs, B, L, nh, drop, st);
+            case 64: return launch_fwd<bf16, 64, 4>(qkv, mask, ctx, probs, B, L, nh, drop, st);
+            case 96: return launch_fwd<bf16, 96, 4>(qkv, mask, ctx, probs, B, L, nh, drop, st);
+            default: return launch_fwd<bf16, 128, 4>(qkv, mask, ctx, probs, B, L, nh, drop, st);
         }
     } else if (dtype == DT_F32) {
         switch (LP) {
-            case 32: return launch_fwd<float, 32, 2>(qkv, mask, ctx, B, L, nh, drop, st);
-            case 64: return launch_fwd<float, 64, 4>(qkv, mask, ctx, B, L, nh, drop, st);
-            case 96: return launch_fwd<float, 96, 4>(qkv, mask, ctx, B, L, nh, drop, st);
-            default: return launch_fwd<float, 128, 4>(qkv, mask, ctx, B, L, nh, drop, st);
+            case 32: return launch_fwd<float, 32, 2>(qkv, mask, ctx, probs, B, L, nh, drop, st);
+            case 64: return launch_fwd<float, 64, 4>(qkv, mask, ctx, probs, B, L, nh, drop, st);
+            case 96: return launch_fwd<float, 96, 4>(qkv, mask, ctx, probs, B, L, nh, drop, st);
+            default: return launch_fwd<float, 128, 4>(qkv, mask, ctx, probs, B, L, nh, drop, st);
         }
     }
     return MB_ERR_DTYPE;

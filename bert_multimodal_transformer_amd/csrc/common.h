@@ -106,10 +106,21 @@ __device__ __forceinline__ void mma16(f32x4& acc, f32x4 x, f32x4 y) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[3], y[3], acc, 0, 0, 0);
 }
 
-// erf-GELU (transformers 3.0.2 ACT2FN["gelu"]) and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float dgelu_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+// erf-GELU (transformers 3.0.2 ACT2FN["gelu"]: x * 0.5 * (1 + erf(x / sqrt(2)))) and its derivative.
+// Both need Phi(x) = 0.5 (1 + erf(x / sqrt 2)) and phi-like e = exp(-x^2 / 2); erf comes from Abramowitz-Stegun 7.1.26,
+// erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), |error| <= 1.5e-7 -- and with z = x / sqrt 2 its exponential
+// IS e, so one v_exp + one v_rcp + a Horner chain serve gelu and gelu' together (libm's erff is two branchy ranges per call;
+// these sit in the epilogues of the two widest GEMMs).  1.5e-7 absolute on Phi is below fp32 rounding of the products it
+// enters, far inside the 1e-3 logit contract of the fp32 parity mode.
+__device__ __forceinline__ void gelu_parts(float x, float& Phi, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    e = __expf(-0.5f * x * x);
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float half_erfc = 0.5f * poly * e;            // 0.5 * erfc(|x| / sqrt 2)
+    Phi = x >= 0.f ? 1.0f - half_erfc : half_erfc;
 }
+__device__ __forceinline__ float gelu_f(float x) { float P, e; gelu_parts(x, P, e); return x * P; }
+__device__ __forceinline__ float dgelu_f(float x) { float P, e; gelu_parts(x, P, e); return P + x * 0.39894228040143268f * e; }
 
 }  // namespace mb

@@ -51,6 +51,7 @@ struct mb_bert_engine {
     bool deferred = false;         // ... on the side stream, joined one stage later (MB_OVERLAP_WGRAD=0: on the caller's stream, in line)
     bool prof = false;             // mb_bert_set_profiling: timing events around every grouped wgrad launch (on the side stream)
     std::vector<hipEvent_t> pev;   // [2 * num_layers]
+    float* attn_out = nullptr;     // mb_bert_set_attention_output: [num_layers][B][nh][L][L] fp32, filled by the next forwards
     bool ws_zeroed = false;
     uint64_t seed = 0, step = 0;
     float* logits = nullptr;
@@ -444,7 +445,8 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
         CK(gemm(dt, GEMM_NT, EPI_BIAS, T, 3 * H, H, x, H, e->W(o.wqkv), H, ws + w.qkv, 3 * H, nullptr, nullptr, P + o.bqkv,
                 nullptr, 0, kNoDrop, 1, 0, st));
         CK(attention_forward(dt, ws + w.qkv, attention_mask, ws + w.ctx, B, L, nh,
-                             e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st));
+                             e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st,
+                             e->attn_out ? e->attn_out + (size_t)l * B * nh * L * L : nullptr));
         CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, T, H, H, ws + w.ctx, H, e->W(o.wo), H, ws + w.s1, H, nullptr, nullptr,
                 P + o.bo, x, H, e->key(SITE_LAYER0 + 4 * l + 1, c.hidden_dropout), 1, 0, st));
         CK(ln_forward(dt, ws + w.s1, P + o.ln1w, P + o.ln1b, c.layer_norm_eps, ws + w.y1, (float*)(ws + w.st1),
@@ -620,6 +622,9 @@ static int enqueue_step(mb_bert_engine* e, int B, int L, float* logits, float* l
                         float loss_scale, hipStream_t st) {
     char* ws = e->ws;
     const float* lab = (const float*)(ws + e->ws_in_lab);
+    float* keep_attn = e->attn_out;
+    e->attn_out = nullptr;                      // optional outputs belong to explicit forwards, never to a (captured) training step
+    struct Restore { mb_bert_engine* e; float* p; ~Restore() { e->attn_out = p; } } restore{e, keep_attn};
     CK(mb_bert_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
                        (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
                        loss_run, st));
@@ -757,6 +762,37 @@ int mb_bert_profile_wgrad_us(mb_bert_engine* e, float* avg_us) {
         sum += ms;
     }
     *avg_us = (float)(sum * 1e3 / e->c.num_layers);
+    return MB_OK;
+}
+
+// ---- optional outputs and the autograd edge of the base model (bert.py:147-156, 227-237)
+const void* mb_bert_hidden_state(const mb_bert_engine* e, int i) {
+    if (!e || !e->ws || i < 0 || i > e->c.num_layers) return nullptr;
+    return e->ws + e->ws_x[i];
+}
+int mb_bert_set_attention_output(mb_bert_engine* e, float* probs) {
+    if (!e) return MB_ERR_ARG;
+    e->attn_out = probs;
+    return MB_OK;
+}
+int mb_bert_backward_outputs(mb_bert_engine* e, const void* d_sequence_output, const void* d_pooler_preact, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!e || !e->G || !e->ids) return MB_ERR_ARG;
+    const mb_bert_config& c = e->c;
+    const int dt = c.dtype, H = c.hidden_size, B = e->B, L = e->L, T = B * L, NL = c.num_layers;
+    char* ws = e->ws;
+    const size_t bytes = (size_t)T * H * esize(dt);
+    if (d_sequence_output) CK((int)hipMemcpyAsync(ws + e->ws_dxa, d_sequence_output, bytes, hipMemcpyDeviceToDevice, st));
+    else CK((int)hipMemsetAsync(ws + e->ws_dxa, 0, bytes, st));
+    if (d_pooler_preact) {
+        // pooler Linear (bert.py:230-231 -> BertPooler): weight / bias gradients, then its input gradient lands on the [CLS] rows
+        const char* xf = ws + e->ws_x[NL];
+        CK(gemm(dt, GEMM_TN, EPI_ACCUM_F32, H, H, B, d_pooler_preact, H, xf, L * H, nullptr, H, nullptr, e->G + e->wp, nullptr, nullptr, 0,
+                kNoDrop, 1, 64, st));
+        CK(colsum(dt, d_pooler_preact, H, e->G + e->bp, B, H, st));
+        CK(gemm(dt, GEMM_NN, EPI_ADD_RES, B, H, H, d_pooler_preact, H, e->W(e->wp), H, ws + e->ws_dxa, L * H, nullptr, nullptr, nullptr,
+                ws + e->ws_dxa, L * H, kNoDrop, 1, 64, st));
+    }
     return MB_OK;
 }
 

@@ -252,15 +252,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
         }
     }
     if constexpr (MODE == EPI_DGELU) {
-        // fused bias gradient: this thread summed its rows; lanes that share the column group differ by TPR in lane id
+        // fused bias gradient: this thread summed its rows; lanes that share the column group differ by TPR in lane id.  The
+        // four waves' sums meet in LDS so that a block issues ONE atomic per column (measured: with one per wave the atomics
+        // alone were 15 us of the 39 us dgrad-ffn2 launch -- 233 K atomics on 3072 addresses).
         if (p.colsum && !(p.dbg & 16)) {
+            __syncthreads();                            // the row pass is done with the staged tile
+            float* red = (float*)smem;                  // [4 waves][BN]
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float s = cs[q];
 #pragma unroll
                 for (int o = TPR; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
-                if (lane < TPR && n < p.N) atomicAdd(p.colsum + n + q, s);
+                if (lane < TPR) red[wave * BN + lane * 8 + q] = s;
             }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.N)
+                atomicAdd(p.colsum + n0 + tid, (red[tid] + red[BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]));
         }
     }
 }
@@ -596,9 +603,10 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
         static int g_ks = -1;             // MB_GEMM_KSPLIT: 1 (default) = k-split waves for the 64 x 64 bf16 tiles, 0 = round-1 quarter tiles
         if (g_ks < 0) g_ks = env_int("MB_GEMM_KSPLIT", 1);
         if constexpr (BM == 64 && BN == 64 && sizeof(T) == 2) {
-            // each k-split block holds 64 KB of LDS (2 per CU): worth it while the whole grid is co-resident; beyond that
+            // each k-split block holds 64 KB of LDS (2 per CU): worth it while the whole grid is co-resident and the k loop is long
+            // enough to amortise the four-tile epilogue (K = 768: 3 stages, measured 10.8 vs 9.8 us); beyond that
             // (T = 4096: 768 tiles) the 32 KB quarter-tile kernel's higher residency wins (measured: 7.30 vs 7.97 ms per step)
-            if (g_ks && g_stages <= 0 && p.kchunk % 128 == 0 && splits == 1 && tiles <= 512) {
+            if (g_ks && g_stages <= 0 && p.kchunk % 128 == 0 && p.kchunk >= 1024 && splits == 1 && tiles <= 512) {
                 hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, 2, 256, true>), grid, dim3(256), 0, st, p);
                 return (int)hipGetLastError();
             }

@@ -120,8 +120,9 @@ int mag_gate_backward(int dtype, const void* dout, const void* e, const void* Ze
 // ------------------------------------------------------------------------------------------ attention (attention.hip)
 // qkv: [B*L][3H] token-major (q | k | v, head h at columns h*64..), mask: int64 [B][L] (1 = attend),
 // ctx: [B*L][H].  softmax(QK^T/sqrt(dh) + (1-mask)*-10000) -> dropout -> . V   (dh = 64, L <= 128)
+// probs (fp32 [B][nh][L][L], may be null): the attention probabilities after dropout (output_attentions)
 int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx, int B, int L, int nh,
-                      DropKey drop, hipStream_t st);
+                      DropKey drop, hipStream_t st, float* probs = nullptr);
 // dbias (fp32 [3H], may be null): += column sums of dqkv (bias grads of the fused QKV Linear)
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx,
                        void* dqkv, float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st);

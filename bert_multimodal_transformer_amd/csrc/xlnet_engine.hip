@@ -392,6 +392,10 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
     return MB_OK;
 }
 
+const void* mb_xlnet_hidden_state(const mb_xlnet_engine* e, int i) {      // input of layer i (before the MAG injection), i = n_layer: last output
+    if (!e || !e->ws || i < 0 || i > e->c.n_layer) return nullptr;
+    return e->ws + e->ws_x[i];
+}
 const void* mb_xlnet_sequence_output(const mb_xlnet_engine* e) { return e->ws ? e->ws + e->ws_x[e->c.n_layer] : nullptr; }
 
 int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap) {

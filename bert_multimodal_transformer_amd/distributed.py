@@ -100,6 +100,35 @@ class GradReducer(object):
             torch.cuda.current_stream(self.g.device).wait_stream(self.comm_stream)
 
 
+def exchange_embedding_rows(grad_table, ids, capacity, group=None):
+    """Sum over the ranks of a word-embedding gradient [V, H] of which every rank touched at most `capacity` rows (the token
+    ids of its minibatch), moving only those rows: 2 all-gathers of capacity x (8 + 4H) bytes instead of a dense all-reduce
+    of V x H x 4 (bert-base: 7.4 MB instead of 93.8 MB at 2,400 tokens per rank).  In place; the result is the dense sum.
+
+    Every rank sends its sorted ids and the matching gradient rows (a repeated id sends its row once, the repeats send zeros;
+    the tail up to `capacity` repeats the last id with zeros), then clears every row any rank touched and adds the
+    contributions in rank order -- the same additions in the same order everywhere, so the replicas stay bit-identical."""
+    world = dist.get_world_size(group)
+    flat = ids.reshape(-1).to(grad_table.device)
+    n = flat.numel()
+    if n > capacity:
+        raise RuntimeError("exchange_embedding_rows: %d ids exceed the agreed capacity %d" % (n, capacity))
+    srt, _ = torch.sort(flat)
+    if n < capacity:
+        srt = torch.cat([srt, srt[-1:].expand(capacity - n)])
+    first = torch.ones(capacity, dtype=torch.bool, device=srt.device)
+    first[1:] = srt[1:] != srt[:-1]
+    vals = grad_table.index_select(0, srt) * first.unsqueeze(1).to(grad_table.dtype)
+    rows_all = [torch.empty_like(srt) for _ in range(world)]
+    vals_all = [torch.empty_like(vals) for _ in range(world)]
+    dist.all_gather(rows_all, srt, group=group)
+    dist.all_gather(vals_all, vals, group=group)
+    grad_table.index_fill_(0, torch.cat(rows_all), 0.0)
+    for r in range(world):
+        grad_table.index_add_(0, rows_all[r], vals_all[r])
+    return grad_table
+
+
 def complement(ranges, n):
     """sorted disjoint (off, len) pieces of [0, n) that no range in `ranges` covers"""
     out, cur = [], 0
@@ -152,6 +181,20 @@ class DataParallel(object):
         self.optimizer = optimizer
         self.late_ranges = []
         self.split_last = os.environ.get("MB_DP_SPLIT_LAST", "1") != "0"
+        # The word-embedding gradient (30,522 x 768 fp32 = 94 MB, 21 % of the payload, produced LAST) has at most B*L non-zero
+        # rows: it is exchanged row-wise (exchange_embedding_rows).  MB_DP_SPARSE_EMB=0 keeps it in the dense last piece.
+        self.word = None
+        if os.environ.get("MB_DP_SPARSE_EMB", "1") != "0" and self.reducer.active:
+            for name, off, numel, shape, decay in self.core.tensors:
+                if name.endswith("word_embeddings.weight") or name.endswith("word_embedding.weight"):
+                    self.word = (off, numel, tuple(shape))
+        self.word_capacity = None           # rows per rank, agreed over the group at the first exchange
+        self._micro_since_sync = 0
+        # every rank draws its own dropout masks (the reference is single-process: nothing to be faithful to; identical masks on
+        # every shard would correlate the regularisation noise).  The mixed seed is what get_rng_state() saves.
+        if self.reducer.active and self.reducer.world > 1:
+            rank = dist.get_rank(process_group)
+            self.core.seed = (self.core.seed ^ ((0x9E3779B97F4A7C15 * (rank + 1)) & ((1 << 63) - 1))) & ((1 << 63) - 1)
         # exposed communication: timing events around the two places where the compute stream waits for the comm stream
         self._tev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.core.grads.is_cuda else None
         self._tev_used = [False, False]
@@ -171,8 +214,45 @@ class DataParallel(object):
             r.extend(self.tail)
         return r
 
+    def _split_word(self, ranges):
+        """ranges minus the word-embedding table (handled by the row exchange)"""
+        if self.word is None:
+            return list(ranges), False
+        w0, wn, _ = self.word
+        out, hit = [], False
+        for off, n in ranges:
+            if off <= w0 and w0 + wn <= off + n:
+                hit = True
+                if w0 > off:
+                    out.append((off, w0 - off))
+                if off + n > w0 + wn:
+                    out.append((w0 + wn, off + n - (w0 + wn)))
+            else:
+                out.append((off, n))
+        return out, hit
+
+    def _exchange_word_rows(self):
+        red = self.reducer
+        w0, wn, shape = self.word
+        ids = self.core.batch_ids()
+        if self.word_capacity is None:          # one-time agreement on the per-rank row capacity (largest engine of the group)
+            cap = torch.tensor([self.core.max_B * self.core.max_L], dtype=torch.int64, device=ids.device if red.cuda else "cpu")
+            dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=red.pg)
+            self.word_capacity = int(cap.item())
+        table = self.core.grads[w0: w0 + wn].view(shape)
+        if red.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.core.grads.device))
+            with torch.cuda.stream(red.comm_stream):
+                red.comm_stream.wait_event(ev)
+                exchange_embedding_rows(table, ids, self.word_capacity, red.pg)
+        else:
+            exchange_embedding_rows(table, ids, self.word_capacity, red.pg)
+
     def _on_stage(self, stage):
         if not self.sync:
+            if stage == 0:
+                self._micro_since_sync += 1
             return
         if stage < len(self.plan) - 1:
             self.reducer.reduce_ranges(self.plan[stage])
@@ -181,7 +261,12 @@ class DataParallel(object):
         # The compute stream only waits for everything BEFORE them; AdamW.step() updates the already-reduced ranges under this
         # last all-reduce and calls finish() before it touches the late ranges (split_last = False: plain full wait here).
         early = self.reducer.mark()
-        self.reducer.reduce_ranges(self.plan[stage])
+        # with accumulated micro-steps the touched rows are the union over the micro-steps: dense exchange for that step
+        dense, sparse = self._split_word(self.plan[stage]) if self._micro_since_sync == 0 else (list(self.plan[stage]), False)
+        self._micro_since_sync = 0
+        self.reducer.reduce_ranges(dense)
+        if sparse:
+            self._exchange_word_rows()
         self.reducer.reduce_ranges(self.tail)
         if self.split_last and early is not None and self.optimizer is not None:
             self._timed_wait(0, lambda cs: cs.wait_event(early))

@@ -88,9 +88,9 @@ def get_parser():
     parser.add_argument("--synthetic", type=int, default=0, help="use N synthetic training samples (no .pkl needed)")
     parser.add_argument("--compute_dtype", choices=["bf16", "fp32"], default="bf16")
     parser.add_argument("--reference_loop", type=str2bool, default=False)
-    parser.add_argument("--step_graph", type=str2bool, default=False,
-                        help="fused loop, single process: replay each optimizer step as one hipGraph (mb_bert_train_step mode 1; "
-                             "measured 4-6 %% slower than the default stream launches on ROCm 7.2)")
+    parser.add_argument("--step_graph", type=str2bool, default=True,
+                        help="fused loop, single process: each optimizer step = step prologue + one replayed hipGraph "
+                             "(mb_bert_train_step); false = the same engine call launching the kernels one by one")
     parser.add_argument("--prefetch", type=str2bool, default=True,
                         help="pack every batch into a pinned host block the GPU reads in place (prefetch.PinnedBatchRing) instead of "
                              "six t.to(DEVICE) copies per step")
@@ -432,7 +432,7 @@ def train_epoch(model: nn.Module, train_dataloader: DataLoader, optimizer, sched
     with model.stream_scope():                        # one private HIP stream for the whole epoch (no NULL-stream hops)
         model.loss_running(reset=True)
         batches = _batches(train_dataloader)
-        use_graph = True if getattr(args, "step_graph", False) else None
+        use_graph = None if getattr(args, "step_graph", True) else "launches"
         for step, batch in enumerate(batches):
             input_ids, visual, acoustic, input_mask, segment_ids, label_ids = batch
             update = (step + 1) % accum == 0

@@ -45,23 +45,11 @@ class XLNetConfig(object):
 
 
 class _XlBase(_MagBertBase):
-    @classmethod
-    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, **kwargs):
-        import os
-        multimodal_config = kwargs.pop("multimodal_config", model_args[0] if model_args else None)
-        num_labels = kwargs.pop("num_labels", 1)
-        config = config or XLNetConfig(num_labels=num_labels)
-        config.num_labels = num_labels
-        model = cls(config, multimodal_config, **kwargs)
-        path = pretrained_model_name_or_path
-        if os.path.isdir(path):
-            path = os.path.join(path, "pytorch_model.bin")
-        if not os.path.isfile(path):
-            raise OSError("from_pretrained(%r): no local checkpoint (offline build)" % (pretrained_model_name_or_path,))
-        sd = torch.load(path, map_location="cpu")
-        own = model.state_dict().keys()
-        model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
-        return model
+    base_model_prefix = "transformer"          # from_pretrained (bert._MagBertBase) maps keys exactly like transformers 3.0.2
+
+    @staticmethod
+    def _default_config(num_labels):
+        return XLNetConfig(num_labels=num_labels)
 
 
 class MAG_XLNetModel(_XlBase):
@@ -85,8 +73,9 @@ class MAG_XLNetModel(_XlBase):
                 token_type_ids=None, input_mask=None, head_mask=None, inputs_embeds=None, use_cache=True,
                 output_attentions=None, output_hidden_states=None):
         self._unsupported(mems=mems, perm_mask=perm_mask, target_mapping=target_mapping, input_mask=input_mask,
-                          head_mask=head_mask, inputs_embeds=inputs_embeds, output_attentions=output_attentions,
-                          output_hidden_states=output_hidden_states)
+                          head_mask=head_mask, inputs_embeds=inputs_embeds, output_attentions=output_attentions)
+        output_hidden_states = (output_hidden_states if output_hidden_states is not None
+                                else getattr(self.config, "output_hidden_states", False))
         if input_ids is None:
             raise ValueError("You have to specify either input_ids or inputs_embeds")          # xlnet.py:211-213
         if attention_mask is None:
@@ -95,7 +84,10 @@ class MAG_XLNetModel(_XlBase):
             token_type_ids = torch.zeros_like(input_ids)
         B, L = input_ids.shape
         self._core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training)
-        return (self._core.sequence_output(B, L),)
+        outputs = (self._core.sequence_output(B, L),)
+        if output_hidden_states:               # xlnet.py:363-392: the input of every layer (before the MAG injection) + the last output
+            outputs = outputs + (self._core.hidden_states(B, L),)
+        return outputs
 
 
 class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
@@ -118,8 +110,9 @@ class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
                 token_type_ids=None, input_mask=None, head_mask=None, inputs_embeds=None, use_cache=True, labels=None,
                 output_attentions=None, output_hidden_states=None):
         self._unsupported(mems=mems, perm_mask=perm_mask, target_mapping=target_mapping, input_mask=input_mask,
-                          head_mask=head_mask, inputs_embeds=inputs_embeds, output_attentions=output_attentions,
-                          output_hidden_states=output_hidden_states)
+                          head_mask=head_mask, inputs_embeds=inputs_embeds, output_attentions=output_attentions)
+        output_hidden_states = (output_hidden_states if output_hidden_states is not None
+                                else getattr(self.config, "output_hidden_states", False))
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         if token_type_ids is None:
@@ -129,6 +122,8 @@ class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
         if torch.is_grad_enabled():
             logits = _EngineFn.apply(core.anchor, logits, core)
         outputs = (logits,)
+        if output_hidden_states:
+            outputs = outputs + (core.hidden_states(input_ids.shape[0], input_ids.shape[1]),)
         if labels is not None:                                        # xlnet.py:515-524
             if self.num_labels == 1:
                 loss = torch.nn.functional.mse_loss(logits.view(-1), labels.to(logits.device).float().view(-1))

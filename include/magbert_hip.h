@@ -148,6 +148,19 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
 /* activations for API parity (device pointers into the workspace, valid until the next forward) */
 const void* mb_bert_sequence_output(const mb_bert_engine* e);   /* [B*L][H] in dtype */
 const float* mb_bert_pooled_output(const mb_bert_engine* e);    /* [B][H] fp32 (pre-dropout) */
+/* Optional outputs of MAG_BertModel.forward (bert.py:147-156, 227-237).
+ * hidden_state(i), i in [0, num_layers]: the encoder's all_hidden_states entry i -- i = 0 is the fused embedding MAG returns,
+ * i = l + 1 the output of layer l -- [B*L][H] in dtype, valid until the next forward (they are the activations saved for
+ * the backward anyway).  set_attention_output: the next forwards also write every layer's attention probabilities AFTER
+ * dropout (what BertSelfAttention returns with output_attentions) to probs [num_layers][B][nh][L][L] fp32; NULL turns it off. */
+const void* mb_bert_hidden_state(const mb_bert_engine* e, int i);
+int mb_bert_set_attention_output(mb_bert_engine* e, float* probs);
+/* Backward entry of the BASE model, for heads that live outside the engine: replaces stage 0 of mb_bert_backward.
+ * d_sequence_output [B*L][H] (dtype; NULL = zero) is the gradient of outputs[0]; d_pooler_preact [B][H] (dtype; NULL = the
+ * pooled output is unused) is the gradient of the pooler's PRE-activation, i.e. d_pooled * (1 - pooled^2) (pooled =
+ * mb_bert_pooled_output).  Accumulates the pooler's weight / bias gradients; continue with mb_bert_backward(e, NULL, NULL,
+ * 1.f, 1, num_layers + 2, stream). */
+int mb_bert_backward_outputs(mb_bert_engine* e, const void* d_sequence_output, const void* d_pooler_preact, void* stream);
 /* gradient buckets for data parallelism: range r of stage s covers flat elements [off, off+len) */
 int mb_bert_stage_grad_ranges(const mb_bert_engine* e, int stage, size_t* offs, size_t* lens, int cap);
 
@@ -225,6 +238,8 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
 int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* labels, float loss_scale, int stage_begin,
                       int stage_end, void* stream);
 const void* mb_xlnet_sequence_output(const mb_xlnet_engine* e);
+/* input of layer i as XLNetModel collects it with output_hidden_states (xlnet.py:363-392; before the MAG injection), i = n_layer: the last output */
+const void* mb_xlnet_hidden_state(const mb_xlnet_engine* e, int i);
 int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap);
 
 #ifdef __cplusplus

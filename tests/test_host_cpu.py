@@ -254,6 +254,94 @@ def test_grad_reducer_gloo_world2(tmp_path):
         assert p.returncode == 0, out.decode()[-2000:]
 
 
+def _stub_core(kind):
+    """engine layout through the C ABI (host-only calls) wrapped like bert._Core, for distributed.stage_plan"""
+    from bert_multimodal_transformer_amd import _lib
+    L = _lib.lib()
+    h = C.c_void_p()
+    if kind == "bert":
+        cfg = _lib.BertEngineConfig(30522, 768, 12, 12, 3072, 512, 2, 1, 47, 74, 0, 1e-12, 1e-5, 1.0, 0.1, 0.1, 0.5, _lib.DT_BF16, 4, 50)
+        _lib.check(L.mb_bert_create(C.byref(cfg), C.byref(h)))
+    else:
+        cfg = _lib.XlnetEngineConfig(32000, 768, 12, 12, 3072, 1, 47, 74, 1, 1e-12, 1e-5, 1.0, 0.1, 0.1, 0.5, _lib.DT_BF16, 4, 50)
+        _lib.check(L.mb_xlnet_create(C.byref(cfg), C.byref(h)))
+    fn = lambda n: getattr(L, "mb_%s_%s" % (kind, n))
+
+    class Core(object):
+        n_layers = 12
+        n_params = fn("param_count")(h)
+        n_decay = fn("decay_count")(h)
+
+        def stage_ranges(self, stage):
+            offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+            k = fn("stage_grad_ranges")(h, stage, offs, lens, 8)
+            return [(offs[i], lens[i]) for i in range(k)]
+
+    name = C.create_string_buffer(160)
+    off, numel, ndim, decay = C.c_size_t(), C.c_size_t(), C.c_int(), C.c_int()
+    shape = (C.c_int64 * 4)()
+    rows = []
+    for i in range(fn("num_tensors")(h)):
+        _lib.check(fn("tensor_info")(h, i, name, 160, C.byref(off), C.byref(numel), C.byref(ndim), shape, C.byref(decay)))
+        rows.append((name.value.decode(), off.value, numel.value, decay.value))
+    return Core(), rows
+
+
+@pytest.mark.parametrize("kind", ["bert", "xlnet"])
+def test_dp_plan_reduces_every_trainable_element_exactly_once(kind):
+    """distributed.stage_plan: the per-stage large ranges plus the remainder cover every trainable element ONCE for both
+    engines (MAG-XLNet reports its whole no-decay block as one large range of its last stage: round 1 reduced it twice)."""
+    from bert_multimodal_transformer_amd.distributed import stage_plan
+    core, rows = _stub_core(kind)
+    plan, tail = stage_plan(core)
+    assert len(plan) == 14
+    cover = np.zeros(core.n_params, np.int16)
+    for rng_ in [r for big in plan for r in big] + list(tail):
+        cover[rng_[0]: rng_[0] + rng_[1]] += 1
+    for name, off, numel, decay in rows:
+        want_min = 0 if decay == 2 else 1               # frozen slots (XLNet mask_emb) may or may not travel; never twice
+        assert cover[off: off + numel].min() >= want_min and cover[off: off + numel].max() <= 1, name
+    assert cover.max() == 1
+
+
+_ROWS_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO_ROOT"])
+from bert_multimodal_transformer_amd.distributed import exchange_embedding_rows
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+V, H, cap = 997, 24, 64
+for trial in range(4):
+    g = torch.Generator().manual_seed(100 * trial + rank)
+    n = cap if trial % 2 == 0 else cap - 7 - rank           # also fewer ids than the agreed capacity (ragged last batch)
+    ids = torch.randint(0, 40 if trial < 2 else V, (n,), generator=g)      # many repeats / almost none
+    table = torch.zeros(V, H)
+    table.index_add_(0, ids, torch.randn(n, H, generator=g))                # what the embedding backward leaves: rows of ids only
+    dense = table.clone()
+    dist.all_reduce(dense)
+    got = exchange_embedding_rows(table.clone(), ids, cap)
+    assert torch.allclose(got, dense, rtol=0, atol=1e-6), float((got - dense).abs().max())
+    both = [torch.empty_like(got) for _ in range(world)]
+    dist.all_gather(both, got)
+    assert torch.equal(both[0], both[1])                                    # replicas bit-identical
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_embedding_row_exchange_equals_dense_allreduce_gloo_world2(tmp_path):
+    script = tmp_path / "rows.py"
+    script.write_text(_ROWS_WORKER)
+    port = 29400 + os.getpid() % 500
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), REPO_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()[-2000:]
+
+
 def test_no_cpu_fallback():
     from bert_multimodal_transformer_amd import MAG, _lib
     if torch.cuda.is_available():
