@@ -4,10 +4,12 @@
 //  not torch.optim.AdamW).  HBM-bound: reads p,g,m,v and writes p,m,v = 28 B/param, + 4 B/param to zero the
 //  gradient in place (replaces optimizer.zero_grad()) + 2 B/param for the bf16 operand shadow of GEMM weights.
 // The flat layout puts every weight-decayed tensor first: elements [0, n_decay) decay, the rest do not.
+#include <cstdlib>
 #include "kernels.h"
 
 namespace mb {
 
+template <bool NT>
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16* __restrict__ shadow, size_t n4,
                                                     size_t n_decay, size_t sh_begin, size_t sh_end, AdamArgs a,
@@ -17,18 +19,30 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float
     const float decay = a.lr * a.weight_decay;
     for (size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * 256) {
         const size_t i = i4 * 4;
-        f32x4 pv = *(const f32x4*)(p + i), gv = *(const f32x4*)(g + i), mv = *(const f32x4*)(m + i),
-              vv = *(const f32x4*)(v + i);
+        f32x4 pv, gv, mv, vv;
+        if constexpr (NT) {          // streamed once per step, never re-read before it is rewritten: keep it out of the caches
+            pv = __builtin_nontemporal_load((const f32x4*)(p + i)); gv = __builtin_nontemporal_load((const f32x4*)(g + i));
+            mv = __builtin_nontemporal_load((const f32x4*)(m + i)); vv = __builtin_nontemporal_load((const f32x4*)(v + i));
+        } else {
+            pv = *(const f32x4*)(p + i); gv = *(const f32x4*)(g + i); mv = *(const f32x4*)(m + i); vv = *(const f32x4*)(v + i);
+        }
         gv *= a.grad_scale;
         mv = a.beta1 * mv + omb1 * gv;
         vv = a.beta2 * vv + omb2 * gv * gv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) pv[r] -= a.step_size * (mv[r] / (sqrtf(vv[r]) + a.eps));
         if (i < n_decay && decay > 0.f) pv -= decay * pv;
-        *(f32x4*)(p + i) = pv;
-        *(f32x4*)(m + i) = mv;
-        *(f32x4*)(v + i) = vv;
-        if (zero_grad) *(f32x4*)(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (NT) {
+            __builtin_nontemporal_store(pv, (f32x4*)(p + i));
+            __builtin_nontemporal_store(mv, (f32x4*)(m + i));
+            __builtin_nontemporal_store(vv, (f32x4*)(v + i));
+            if (zero_grad) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, (f32x4*)(g + i));
+        } else {
+            *(f32x4*)(p + i) = pv;
+            *(f32x4*)(m + i) = mv;
+            *(f32x4*)(v + i) = vv;
+            if (zero_grad) *(f32x4*)(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         if (shadow && i >= sh_begin && i < sh_end) store4(shadow + i, pv);
     }
 }
@@ -57,8 +71,12 @@ int adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, s
     if (n4) {
         unsigned grid = (unsigned)((n4 + 255) / 256);
         if (grid > 256 * 16) grid = 256 * 16;
-        hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16*)shadow, n4, n_decay, sh_begin,
-                           sh_end, a, dyn, zero_grad);
+        static int nt = -1;          // MB_ADAMW_NT=0: plain loads / stores (non-temporal measured 1.1 % faster per step: 4.86 vs 4.91 ms)
+        if (nt < 0) { const char* e = getenv("MB_ADAMW_NT"); nt = e ? atoi(e) : 1; }
+        if (nt) hipLaunchKernelGGL(adamw_kernel<true>, dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16*)shadow, n4, n_decay, sh_begin,
+                                   sh_end, a, dyn, zero_grad);
+        else hipLaunchKernelGGL(adamw_kernel<false>, dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16*)shadow, n4, n_decay, sh_begin,
+                                sh_end, a, dyn, zero_grad);
     }
     if (n % 4) hipLaunchKernelGGL(adamw_tail_kernel, dim3(1), dim3(64), 0, st, p, g, m, v, n4 * 4, n, n_decay, a, dyn, zero_grad);
     return (int)hipGetLastError();

@@ -462,7 +462,7 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     float* z = (float*)(ws + e->ws_head_z);
     CK(gemm(dt, GEMM_NT, EPI_BIAS_F32, B, H, H, ws + e->ws_x[c.num_layers], L * H, e->W(e->wp), H, nullptr, H, nullptr, z,
             P + e->bp, nullptr, 0, kNoDrop, 1, 64, st));
-    if (loss) CK((int)hipMemsetAsync(loss, 0, 4, st));
+    if (loss) CK(zero_fill(loss, 4, st));
     CK(head_forward(z, P + e->wc, P + e->bc, labels, (float*)(ws + e->ws_head_pooled), logits, loss, loss_run, B, H,
                     c.num_labels, e->key(SITE_HEAD, c.hidden_dropout), st));
     return MB_OK;
@@ -491,7 +491,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             CK(gemm(dt, GEMM_TN, EPI_ACCUM_F32, H, H, B, ws + e->ws_dz, H, xf, L * H, nullptr, H, nullptr, G + e->wp, nullptr,
                     nullptr, 0, kNoDrop, 1, 64, st));
             CK(colsum(dt, ws + e->ws_dz, H, G + e->bp, B, H, st));
-            CK((int)hipMemsetAsync(ws + e->ws_dxa, 0, (size_t)T * H * esize(dt), st));
+            CK(zero_fill(ws + e->ws_dxa, (size_t)T * H * esize(dt), st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, B, H, H, ws + e->ws_dz, H, e->W(e->wp), H, ws + e->ws_dxa, L * H, nullptr,
                     nullptr, nullptr, nullptr, 0, kNoDrop, 1, 64, st));
         } else if (stage <= NL) {
@@ -783,7 +783,7 @@ int mb_bert_backward_outputs(mb_bert_engine* e, const void* d_sequence_output, c
     char* ws = e->ws;
     const size_t bytes = (size_t)T * H * esize(dt);
     if (d_sequence_output) CK((int)hipMemcpyAsync(ws + e->ws_dxa, d_sequence_output, bytes, hipMemcpyDeviceToDevice, st));
-    else CK((int)hipMemsetAsync(ws + e->ws_dxa, 0, bytes, st));
+    else CK(zero_fill(ws + e->ws_dxa, bytes, st));
     if (d_pooler_preact) {
         // pooler Linear (bert.py:230-231 -> BertPooler): weight / bias gradients, then its input gradient lands on the [CLS] rows
         const char* xf = ws + e->ws_x[NL];

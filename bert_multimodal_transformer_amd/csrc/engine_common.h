@@ -138,8 +138,8 @@ inline int mag_fwd_impl(int dtype, const void* text, const float* visual, const 
         const int Tp = (int)align_up((size_t)T, 64);
         const size_t es = esize(dtype);
         if (Tp > T) {
-            CK((int)hipMemsetAsync(ws + w.vp + (size_t)T * w.Vp * es, 0, (size_t)(Tp - T) * w.Vp * es, st));
-            CK((int)hipMemsetAsync(ws + w.ap + (size_t)T * w.Ap * es, 0, (size_t)(Tp - T) * w.Ap * es, st));
+            CK(zero_fill(ws + w.vp + (size_t)T * w.Vp * es, (size_t)(Tp - T) * w.Vp * es, st));
+            CK(zero_fill(ws + w.ap + (size_t)T * w.Ap * es, (size_t)(Tp - T) * w.Ap * es, st));
         }
     }
     CK(gemm(dtype, GEMM_NT, EPI_BIAS, T, 2 * H, H, text, H, ws + w.We, H, ws + w.Ze, 2 * H, nullptr, nullptr, nullptr,
@@ -162,17 +162,17 @@ inline int mag_bwd_impl(int dtype, const void* d_out, const void* text, const fl
     const int Tp = (int)align_up((size_t)T, 64);      // zero-padded token rows of the workspace operands
     const size_t es = esize(dtype);
     if (Tp > T) {                                     // keep the pad rows of this call's k-major operands zero
-        CK((int)hipMemsetAsync(ws + w.dZe + (size_t)T * 2 * H * es, 0, (size_t)(Tp - T) * 2 * H * es, st));
-        CK((int)hipMemsetAsync(ws + w.dZv + (size_t)T * 2 * H * es, 0, (size_t)(Tp - T) * 2 * H * es, st));
-        CK((int)hipMemsetAsync(ws + w.dZa + (size_t)T * 2 * H * es, 0, (size_t)(Tp - T) * 2 * H * es, st));
+        CK(zero_fill(ws + w.dZe + (size_t)T * 2 * H * es, (size_t)(Tp - T) * 2 * H * es, st));
+        CK(zero_fill(ws + w.dZv + (size_t)T * 2 * H * es, (size_t)(Tp - T) * 2 * H * es, st));
+        CK(zero_fill(ws + w.dZa + (size_t)T * 2 * H * es, (size_t)(Tp - T) * 2 * H * es, st));
     }
     CK(mag_gate_backward(dtype, d_out, text, ws + w.Ze, ws + w.Zv, ws + w.Za, b_hv, b_ha, b_v, b_a, ln_w,
                          (const float*)(ws + w.mean), (const float*)(ws + w.rstd), beta_shift, ws + w.dep, ws + w.dZe,
                          ws + w.dZv, ws + w.dZa, db_hv, db_ha, db_v, db_a, dln_w, dln_b, d, drop, st));
     // packed weight grads (dWe, dWv, dWa are contiguous in the workspace up to alignment: clear each)
-    CK((int)hipMemsetAsync(ws + w.dWe, 0, (size_t)2 * H * H * 4, st));
-    CK((int)hipMemsetAsync(ws + w.dWv, 0, (size_t)2 * H * w.Vp * 4, st));
-    CK((int)hipMemsetAsync(ws + w.dWa, 0, (size_t)2 * H * w.Ap * 4, st));
+    CK(zero_fill(ws + w.dWe, (size_t)2 * H * H * 4, st));
+    CK(zero_fill(ws + w.dWv, (size_t)2 * H * w.Vp * 4, st));
+    CK(zero_fill(ws + w.dWa, (size_t)2 * H * w.Ap * 4, st));
     CK(wgrad(dtype, 2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H, st));
     CK(wgrad(dtype, 2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp, st));
     CK(wgrad(dtype, 2 * H, w.Ap, Tp, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap, st));

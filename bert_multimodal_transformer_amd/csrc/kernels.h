@@ -177,5 +177,7 @@ struct PrologueArgs {
     AdamArgs adam[2]; AdamArgs* adam_dst;  // may be null
 };
 int step_prologue(const PrologueArgs& a, hipStream_t st);
+// p[0, bytes) = 0 as a kernel launch (bytes and p multiples of 4)
+int zero_fill(void* p, size_t bytes, hipStream_t st);
 
 }  // namespace mb

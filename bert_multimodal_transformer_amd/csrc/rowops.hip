@@ -276,11 +276,13 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
     block_colsum_atomic<CH, 2>(part, dst, lds);
 }
 
-// position / token-type table grads: block l sums dsum over the batch (sole owner of dpos[l]).
+// position / token-type table grads: block (l, c) sums 256 columns of dsum over the batch (sole owner of that piece of dpos[l]).
 __global__ void __launch_bounds__(256) embed_pos_type_kernel(const float* __restrict__ dsum_ws, const int64_t* __restrict__ seg,
                                                              float* dpos, float* dtype_, int B, int L, int H) {
     const int l = blockIdx.x;
-    for (int col = threadIdx.x; col < H; col += 256) {
+    {
+        const int col = blockIdx.y * 256 + threadIdx.x;
+        if (col >= H) return;
         float ap = 0.f, a0 = 0.f, a1 = 0.f;
         for (int b = 0; b < B; ++b) {
             const int t = b * L + l;
@@ -421,7 +423,7 @@ int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int
                            (const T*)dout, ids, seg, word, pos, type, gamma, mean, rstd, dsum_ws, dword, dgamma, dbeta,
                            rows, L, pad_id, drop);
     }))
-    hipLaunchKernelGGL(embed_pos_type_kernel, dim3(L), dim3(256), 0, st, dsum_ws, seg, dpos, dtype_, B, L, H);
+    hipLaunchKernelGGL(embed_pos_type_kernel, dim3(L, (H + 255) / 256), dim3(256), 0, st, dsum_ws, seg, dpos, dtype_, B, L, H);
     return (int)hipGetLastError();
 }
 
@@ -471,6 +473,32 @@ int widen(int dtype, const void* src, float* dst, size_t n, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------ zero fill
+// The passes clear their scratch (packed MAG weight gradients, pad rows, the [CLS]-only pooler gradient slab, the loss word)
+// with this launch instead of hipMemsetAsync: a captured step then consists of kernel nodes only (memset nodes of a replayed
+// graph were the one thing that did not reproduce the eager result on ROCm 7.2: stale packed MAG gradients on replays).
+__global__ void __launch_bounds__(256) zero_fill_kernel(uint32_t* __restrict__ p, size_t ndw) {
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+    if (((uintptr_t)p & 15) == 0) {
+        const size_t n4 = ndw / 4;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (size_t i = tid; i < n4; i += nth) ((u32x4*)p)[i] = z;
+        for (size_t i = n4 * 4 + tid; i < ndw; i += nth) p[i] = 0u;
+    } else {
+        for (size_t i = tid; i < ndw; i += nth) p[i] = 0u;
+    }
+}
+int zero_fill(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return MB_OK;
+    if (!p || (bytes & 3) || ((uintptr_t)p & 3)) return MB_ERR_ARG;
+    const size_t ndw = bytes / 4;
+    unsigned grid = (unsigned)((ndw / 4 + 255) / 256);
+    if (grid < 1) grid = 1;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(256), 0, st, (uint32_t*)p, ndw);
+    return (int)hipGetLastError();
+}
 
 // ------------------------------------------------------------------------------------------ step prologue
 // Device twin of make_key() (engine_common.h): k = splitmix64(splitmix64(seed) ^ splitmix64(step * FNV + site)).

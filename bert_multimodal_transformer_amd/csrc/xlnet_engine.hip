@@ -269,7 +269,7 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
     float* z = (float*)(ws + e->ws_head_z);
     CK(gemm(dt, GEMM_NT, EPI_BIAS_F32, B, H, H, ws + e->ws_xs, H, e->W(e->wsum), H, nullptr, H, nullptr, z, P + e->bsum, nullptr, 0,
             kNoDrop, 1, 64, st));
-    if (loss) CK((int)hipMemsetAsync(loss, 0, 4, st));
+    if (loss) CK(zero_fill(loss, 4, st));
     CK(head_forward(z, P + e->wc, P + e->bc, labels, (float*)(ws + e->ws_head_pooled), logits, loss, loss_run, B, H, c.num_labels,
                     e->key(XS_HEAD, c.summary_last_dropout), st));
     return MB_OK;
@@ -298,7 +298,7 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
             CK(colsum(dt, ws + e->ws_dz, H, G + e->bsum, B, H, st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, B, H, H, ws + e->ws_dz, H, e->W(e->wsum), H, ws + e->ws_dxs, H, nullptr, nullptr, nullptr,
                     nullptr, 0, kNoDrop, 1, 64, st));
-            CK((int)hipMemsetAsync(ws + e->ws_dxa, 0, (size_t)T * H * es, st));
+            CK(zero_fill(ws + e->ws_dxa, (size_t)T * H * es, st));
             CK(last_token_backward(dt, ws + e->ws_dxs, ws + e->ws_dxa, B, L, H, e->key(XS_FINAL, pd), st));
         } else if (stage <= NL) {
             const int l = NL - stage;

@@ -89,7 +89,8 @@ class BertEmbeddings(nn.Module):
 
     def __init__(self, c):
         super().__init__()
-        self.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size)
+        # 3.0.2: nn.Embedding(vocab, hidden, padding_idx=config.pad_token_id): the [PAD] row (id 0) never receives a gradient
+        self.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size, padding_idx=getattr(c, "pad_token_id", 0))
         self.position_embeddings = nn.Embedding(c.max_position_embeddings, c.hidden_size)
         self.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
         self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
