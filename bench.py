@@ -4,18 +4,24 @@
     python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one full optimizer step of /root/reference/multimodal_driver.py:354-388 on one minibatch per GPU:
-forward (embeddings, MAG, 12 encoder layers, pooler, classifier) -> MSE -> backward -> (N>1: RCCL all-reduce of the flat
-gradients, overlapped with the backward) -> HF-AdamW -> linear-warmup schedule -> zero_grad, with the six batch tensors
-already resident in HBM (`value`); the reference's per-step H2D (multimodal_driver.py:359) is timed separately
-(`value_with_h2d`).  Workload = BASELINE.json configs[1]: bert-base-uncased MAG-BERT, MOSI dims (V=47, A=74), B=48/GPU, L=50,
-bf16 MFMA with fp32 master weights, dropout ON (0.1/0.1/MAG 0.5), synthetic batches in prepare_bert_input's layout,
-random-init weights (no network).  Weak scaling: per-GPU batch fixed, global batch = 48*N.
+One "step" = one full iteration of train_epoch (/root/reference/multimodal_driver.py:354-388) on one minibatch per GPU: the
+batch comes from HOST memory every step (`batch = tuple(t.to(DEVICE) ...)`, :359 -- here one pinned block the step's first
+launch gathers across PCIe), forward (embeddings, MAG, 12 encoder layers, pooler, classifier) -> MSE -> backward -> (N>1: RCCL
+all-reduce of the flat gradients, overlapped with the backward) -> HF-AdamW -> linear-warmup schedule -> zero_grad.  `value`
+INCLUDES that per-step host-to-device transfer; the same loop with the batch tensors already resident in HBM is reported as
+`value_inputs_resident` (the two coincide: the gather costs ~5 us).  Workload = BASELINE.json configs[1]: bert-base-uncased
+MAG-BERT, MOSI dims (V=47, A=74), B=48/GPU, L=50, bf16 MFMA with fp32 master weights, dropout ON (0.1/0.1/MAG 0.5), synthetic
+batches in prepare_bert_input's layout, random-init weights (no network).  Weak scaling: per-GPU batch fixed, global batch = 48*N.
+At N=1 the whole iteration is ONE engine call (mb_bert_train_step: step prologue + one replayed hipGraph).
 
 Prints ONE JSON line (rank 0) with the contract's keys plus
-  roofline     : the dominant kernel (the per-layer grouped weight-gradient GEMM) timed inside the step with HIP events on the
-                 stream it runs on, its HBM-side traffic from the committed PMC pass (profiles/r01_pmc_step.md)
-  cpu_baseline : the CPU oracle (oracle/mag_bert_ref.py, kind "port") timed on this box's host cores, same step
+  step_ms_median / p10 / p90 : per-step GPU time from HIP events recorded after every step
+  roofline       : the dominant kernel (the per-layer grouped weight-gradient GEMM) timed INSIDE the step with HIP events on
+                   the stream it runs on; its HBM-side traffic from the committed PMC pass (profiles/pmc_traffic.json)
+  roofline_gemms : the nine GEMM launches of a layer, back-to-back (warm caches: an upper bound)
+  roofline_hbm   : achieved HBM TB/s of the LayerNorm / AdamW row kernels (north_star), HIP events, rotating operands
+  instep_kernels : per-kernel in-step table from the committed rocprofv3 kernel trace of this command (profiles/)
+  cpu_baseline   : the CPU oracle (oracle/mag_bert_ref.py, kind "port") timed on this box's host cores, same step
 """
 import argparse
 import json
@@ -210,8 +216,19 @@ def hbm_roofline(dtype_name, B, L, V, A, reps=20):
     timed("ln_bwd (+dropout backward, dgamma/dbeta/dbias)", 4 * T * H * es, lambda i: _lib.check(Lb.mb_layernorm_backward(
         dt, _lib.ptr(xs[i % NB]), _lib.ptr(ys[i % NB]), _lib.ptr(gamma), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(zs[i % NB]),
         _lib.ptr(ys[(i + 1) % NB]), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dbias), T, H, C.byref(nokey), C.byref(key), st.cuda_stream)))
-    # MAG: the whole operator (3 GEMMs + gate kernel) and AdamW over a 100 M-parameter flat buffer
-    from bert_multimodal_transformer_amd import MAG
+    # MAG forward, the whole operator as the engine runs it (weight pack + modality pack + 3 MFMA GEMMs + the gate / norm-ratio /
+    # LayerNorm / dropout row kernel): algorithmic bytes = read e, v, a + write out per token
+    mag_ws = torch.empty(Lb.mb_mag_workspace_bytes(dt, T, H, V, A), dtype=torch.uint8, device=dev)
+    vis = [torch.randn(T, V, device=dev) for _ in range(NB)]
+    aco = [torch.randn(T, A, device=dev) for _ in range(NB)]
+    mp = [torch.randn(H, V + H, device=dev) * 0.02, torch.zeros(H, device=dev), torch.randn(H, A + H, device=dev) * 0.02,
+          torch.zeros(H, device=dev), torch.randn(H, V, device=dev) * 0.02, torch.zeros(H, device=dev),
+          torch.randn(H, A, device=dev) * 0.02, torch.zeros(H, device=dev), gamma, beta]
+    mkey = _lib.make_dropkey(1, 1, 1, 0.5)
+    timed("mag_forward (modeling.py:25-51: pack + 3 GEMMs + gate/LN/dropout kernel)", T * (2 * H * es + 4 * V + 4 * A),
+          lambda i: _lib.check(Lb.mb_mag_forward(dt, _lib.ptr(xs[i % NB]), _lib.ptr(vis[i % NB]), _lib.ptr(aco[i % NB]),
+                                                 *[_lib.ptr(t) for t in mp], 1.0, C.byref(mkey), _lib.ptr(ys[i % NB]), _lib.ptr(mag_ws),
+                                                 T, H, V, A, st.cuda_stream)))
     n = 110_853_184
     p_, g_, m_, v_ = (torch.zeros(n, device=dev) for _ in range(4))
     sh = torch.zeros(n, dtype=torch.bfloat16, device=dev)

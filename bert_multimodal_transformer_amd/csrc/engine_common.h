@@ -173,9 +173,20 @@ inline int mag_bwd_impl(int dtype, const void* d_out, const void* text, const fl
     CK(zero_fill(ws + w.dWe, (size_t)2 * H * H * 4, st));
     CK(zero_fill(ws + w.dWv, (size_t)2 * H * w.Vp * 4, st));
     CK(zero_fill(ws + w.dWa, (size_t)2 * H * w.Ap * 4, st));
-    CK(wgrad(dtype, 2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H, st));
-    CK(wgrad(dtype, 2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp, st));
-    CK(wgrad(dtype, 2 * H, w.Ap, Tp, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap, st));
+    {
+        // the three packed weight gradients as ONE grouped launch (like a layer's four): alone, the two modality problems are
+        // 24 / 48 tiles whose duration is the K = T loop latency (three launches of ~34 us each)
+        GemmArgs wg[3] = {wgrad_args(2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H),
+                          wgrad_args(2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp),
+                          wgrad_args(2 * H, w.Ap, Tp, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap)};
+        if (text_padded && gemm_grouped_tn_ok(dtype, wg, 3, 64)) {
+            CK(gemm_grouped_tn_launch(dtype, wg, 3, 64, st));
+        } else {
+            CK(wgrad(dtype, 2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H, st));
+            CK(wgrad(dtype, 2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp, st));
+            CK(wgrad(dtype, 2 * H, w.Ap, Tp, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap, st));
+        }
+    }
     CK(mag_unpack_wgrads((const float*)(ws + w.dWe), (const float*)(ws + w.dWv), (const float*)(ws + w.dWa), dW_hv, dW_ha,
                          dW_v, dW_a, d, st));
     // d_text = dZe . We + (ds + d||e|| term)

@@ -59,13 +59,20 @@ class GradReducer(object):
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("MB_DP_FORCE") == "1")
         self.cuda = flat_grads.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grads.device) if self.cuda else None
-        self.pending = []
+        # fork / mark events are created once and re-recorded (32 > pieces per step): no per-step event churn
+        self._events = [torch.cuda.Event() for _ in range(32)] if self.cuda else []
+        self._next_event = 0
+
+    def _event(self):
+        ev = self._events[self._next_event]
+        self._next_event = (self._next_event + 1) % len(self._events)
+        return ev
 
     def reduce_ranges(self, ranges):
         if not self.active or not ranges:
             return
         if self.cuda:
-            ev = torch.cuda.Event()
+            ev = self._event()
             ev.record(torch.cuda.current_stream(self.g.device))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
@@ -90,7 +97,7 @@ class GradReducer(object):
         """an event behind every piece enqueued so far (None on the host path, where reduce_ranges is synchronous)"""
         if not (self.cuda and self.active):
             return None
-        ev = torch.cuda.Event()
+        ev = self._event()
         ev.record(self.comm_stream)
         return ev
 
@@ -241,7 +248,7 @@ class DataParallel(object):
             self.word_capacity = int(cap.item())
         table = self.core.grads[w0: w0 + wn].view(shape)
         if red.cuda:
-            ev = torch.cuda.Event()
+            ev = red._event()
             ev.record(torch.cuda.current_stream(self.core.grads.device))
             with torch.cuda.stream(red.comm_stream):
                 red.comm_stream.wait_event(ev)
