@@ -1,0 +1,55 @@
+#!/bin/bash
+# round artefacts: bench lines (headline, C5 shape, MAG-XLNet), rocprofv3 kernel stats, in-step kernel table, PMC passes.
+# usage: bash scripts/gpu_artifacts.sh r02     (every command under its own timeout)
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r02}
+O=$R/gpurun_out/$TAG; mkdir -p $O
+cd $R
+SB=$R/tools/bin/step_bench
+export TMPDIR=/tmp
+# ---- 1. in-step kernel table + idle, graph replay (what bench.py runs) and PMC passes, torch-free
+( cd /tmp && rm -rf /tmp/p_tr && timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_tr -o sb -- $SB --graph 1 --h2d 2 --steps 20 --warmup 5 2>&1 | grep step_bench ) > $O/step_bench_traced.txt
+f=$(find /tmp/p_tr -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 scripts/exp/instep_json.py $f 8 "bert B=48 L=50 bf16" $O/instep_kernels.json > $O/instep_kernels.txt
+f=$(find /tmp/p_tr -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/step_kernel_stats.csv
+for set in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && rm -rf /tmp/p_$set && timeout 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/p_$set -o p -- $SB --graph 2 --h2d 2 --steps 6 --warmup 2 > /dev/null 2>&1 )
+  f=$(find /tmp/p_$set -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 scripts/exp/pmc_reduce.py $f $set > $O/pmc_$set.txt
+done
+( cd /tmp && rm -rf /tmp/p_sq && timeout 120 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d /tmp/p_sq -o p -- $SB --graph 2 --h2d 2 --steps 6 --warmup 2 > /dev/null 2>&1 )
+f=$(find /tmp/p_sq -name "*counter_collection.csv" | head -1)
+[ -n "$f" ] && python3 - "$f" > $O/pmc_SQ.txt <<'PY'
+import csv, sys
+agg = {}
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        d = agg.setdefault(r["Kernel_Name"][:90], {})
+        a = d.setdefault(r["Counter_Name"], [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
+rows = []
+for k, d in agg.items():
+    g = lambda n: d.get(n, [1, 0.0])[1] / max(1, d.get(n, [1, 0.0])[0])
+    wc = g("SQ_WAVE_CYCLES")
+    if wc > 0:
+        rows.append((d["SQ_WAVE_CYCLES"][1], k, d["SQ_WAVE_CYCLES"][0], g("SQ_WAVES"), wc, g("SQ_VALU_MFMA_BUSY_CYCLES"), g("SQ_INSTS_VALU_MFMA_MOPS_BF16"),
+                     g("SQ_WAIT_ANY") / wc, g("SQ_WAIT_INST_ANY") / wc, g("SQ_ACTIVE_INST_ANY") / wc))
+print("# per launch: kernel, launches, waves, wave quad-cycles, MFMA busy cycles, MFMA MOPS(bf16), wait_any/wave_cyc, wait_inst/wave_cyc, active_inst/wave_cyc")
+for _, k, n, w, wc, mb, mo, wa, wi, ai in sorted(rows, reverse=True)[:14]:
+    print("%-90s %5d %7.0f %12.0f %12.0f %12.0f %5.2f %5.2f %5.2f" % (k, n, w, wc, mb, mo, wa, wi, ai))
+PY
+timeout 60 tools/bin/gemm_bench > $O/gemm_bench.txt 2>&1
+timeout 60 tools/bin/gemm_bench --T 4096 > $O/gemm_bench_T4096.txt 2>&1
+# ---- 2. C5 shape and a second headline timing from the C++ driver
+{ timeout 60 $SB --graph 1 --h2d 2 --steps 40 --warmup 8; timeout 60 $SB --graph 1 --h2d 2 --batch 32 --seq 128 --visual 35 --steps 30 --warmup 6; } > $O/step_bench.txt 2>&1
+( cd /tmp && rm -rf /tmp/p_c5 && timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c5 -o sb -- $SB --graph 1 --h2d 2 --batch 32 --seq 128 --visual 35 --steps 12 --warmup 4 > /dev/null 2>&1 )
+f=$(find /tmp/p_c5 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c5_kernel_stats.csv
+f=$(find /tmp/p_c5 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 scripts/exp/instep_json.py $f 6 "bert B=32 L=128 bf16 (MOSEI V=35)" $O/instep_kernels_c5.json > $O/instep_kernels_c5.txt
+# ---- 3. bench.py lines
+cp $O/instep_kernels.json profiles/instep_kernels.json 2>/dev/null
+(timeout 400 python bench.py 2>&1 | tail -2) > $O/bench_line.log 2>&1
+(timeout 300 python bench.py --dataset mosei --seq 128 --batch 32 --cpu-baseline 0 --steps 30 --warmup 6 2>&1 | tail -2) > $O/bench_line_c5.log 2>&1
+(timeout 300 python bench.py --model xlnet --cpu-steps 2 --steps 30 --warmup 6 2>&1 | tail -2) > $O/bench_line_xlnet.log 2>&1
+( cd /tmp && rm -rf /tmp/p_b && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_b -o b -- python $R/bench.py --steps 10 --warmup 3 --cpu-baseline 0 --roofline 0 > /dev/null 2>&1 )
+f=$(find /tmp/p_b -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_kernel_stats.csv
+( cd /tmp && rm -rf /tmp/p_x && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_x -o b -- python $R/bench.py --model xlnet --steps 10 --warmup 3 --cpu-baseline 0 --roofline 0 > /dev/null 2>&1 )
+f=$(find /tmp/p_x -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/xlnet_kernel_stats.csv
+for f in bench_line bench_line_c5 bench_line_xlnet; do tail -1 $O/$f.log | cut -c1-420; done
+cat $O/instep_kernels.txt | head -24
+cat $O/step_bench.txt
