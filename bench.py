@@ -320,18 +320,19 @@ def main():
         for i in range(n):
             yield batches[(start + i) % nb]
 
+    ring = PinnedBatchRing(None, dev)            # one ring (4 pinned blocks) for the whole run
+
     def run(n, start, events=None):
         """n optimizer steps exactly as train_epoch runs them: the batch comes from the HOST (packed into a pinned block that
         the step's gather launch reads across PCIe: multimodal_driver.py:359), forward + MSE + backward (+ all-reduce) + AdamW +
         schedule + zero_grad."""
-        for batch in PinnedBatchRing(host_batches(n, start), dev):
+        ring.loader = host_batches(n, start)
+        for i, batch in enumerate(ring):
             ids, vis, aco, mask, seg, lab = batch
             model.train_step(ids, vis, aco, mask, seg, lab, optimizer=opt, graph=use_graph)
             sch.step()
             if events is not None:
-                ev = torch.cuda.Event(enable_timing=True)
-                ev.record(torch.cuda.current_stream())
-                events.append(ev)
+                events[i + 1].record(torch.cuda.current_stream())
 
     def fence():
         torch.cuda.synchronize()
@@ -343,7 +344,10 @@ def main():
     scope.__enter__()
     run(a.warmup, 0)
     fence()
-    evs = [torch.cuda.Event(enable_timing=True)]
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]      # created (and warmed) before the timed region
+    for ev in evs:
+        ev.record(torch.cuda.current_stream())
+    fence()
     evs[0].record(torch.cuda.current_stream())
     t0 = time.perf_counter()
     run(a.steps, a.warmup, evs)

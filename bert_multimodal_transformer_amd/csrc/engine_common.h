@@ -138,8 +138,10 @@ inline int mag_fwd_impl(int dtype, const void* text, const float* visual, const 
         const int Tp = (int)align_up((size_t)T, 64);
         const size_t es = esize(dtype);
         if (Tp > T) {
-            CK(zero_fill(ws + w.vp + (size_t)T * w.Vp * es, (size_t)(Tp - T) * w.Vp * es, st));
-            CK(zero_fill(ws + w.ap + (size_t)T * w.Ap * es, (size_t)(Tp - T) * w.Ap * es, st));
+            ZeroRanges z = {};
+            z.add(ws + w.vp + (size_t)T * w.Vp * es, (size_t)(Tp - T) * w.Vp * es);
+            z.add(ws + w.ap + (size_t)T * w.Ap * es, (size_t)(Tp - T) * w.Ap * es);
+            CK(zero_fill_ranges(z, st));
         }
     }
     CK(gemm(dtype, GEMM_NT, EPI_BIAS, T, 2 * H, H, text, H, ws + w.We, H, ws + w.Ze, 2 * H, nullptr, nullptr, nullptr,
@@ -161,18 +163,22 @@ inline int mag_bwd_impl(int dtype, const void* d_out, const void* text, const fl
     MagDims d = {T, H, V, A, w.Vp, w.Ap};
     const int Tp = (int)align_up((size_t)T, 64);      // zero-padded token rows of the workspace operands
     const size_t es = esize(dtype);
-    if (Tp > T) {                                     // keep the pad rows of this call's k-major operands zero
-        CK(zero_fill(ws + w.dZe + (size_t)T * 2 * H * es, (size_t)(Tp - T) * 2 * H * es, st));
-        CK(zero_fill(ws + w.dZv + (size_t)T * 2 * H * es, (size_t)(Tp - T) * 2 * H * es, st));
-        CK(zero_fill(ws + w.dZa + (size_t)T * 2 * H * es, (size_t)(Tp - T) * 2 * H * es, st));
+    {
+        // one launch clears the pad rows of this call's k-major operands and the packed weight-gradient accumulators
+        ZeroRanges z = {};
+        if (Tp > T) {
+            z.add(ws + w.dZe + (size_t)T * 2 * H * es, (size_t)(Tp - T) * 2 * H * es);
+            z.add(ws + w.dZv + (size_t)T * 2 * H * es, (size_t)(Tp - T) * 2 * H * es);
+            z.add(ws + w.dZa + (size_t)T * 2 * H * es, (size_t)(Tp - T) * 2 * H * es);
+        }
+        z.add(ws + w.dWe, (size_t)2 * H * H * 4);
+        z.add(ws + w.dWv, (size_t)2 * H * w.Vp * 4);
+        z.add(ws + w.dWa, (size_t)2 * H * w.Ap * 4);
+        CK(zero_fill_ranges(z, st));
     }
     CK(mag_gate_backward(dtype, d_out, text, ws + w.Ze, ws + w.Zv, ws + w.Za, b_hv, b_ha, b_v, b_a, ln_w,
                          (const float*)(ws + w.mean), (const float*)(ws + w.rstd), beta_shift, ws + w.dep, ws + w.dZe,
                          ws + w.dZv, ws + w.dZa, db_hv, db_ha, db_v, db_a, dln_w, dln_b, d, drop, st));
-    // packed weight grads (dWe, dWv, dWa are contiguous in the workspace up to alignment: clear each)
-    CK(zero_fill(ws + w.dWe, (size_t)2 * H * H * 4, st));
-    CK(zero_fill(ws + w.dWv, (size_t)2 * H * w.Vp * 4, st));
-    CK(zero_fill(ws + w.dWa, (size_t)2 * H * w.Ap * 4, st));
     {
         // the three packed weight gradients as ONE grouped launch (like a layer's four): alone, the two modality problems are
         // 24 / 48 tiles whose duration is the K = T loop latency (three launches of ~34 us each)

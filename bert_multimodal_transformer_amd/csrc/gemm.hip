@@ -20,6 +20,7 @@
 // The accumulator is computed transposed (mma16(acc, Bfrag, Afrag)) so that a lane owns 4 CONSECUTIVE
 // columns n of one row m: epilogue loads/stores are 8/16-byte vectors and bias is one float4.
 #include <cstdlib>
+#include <algorithm>
 #include "kernels.h"
 
 namespace mb {
@@ -452,7 +453,7 @@ struct Gemm2Smem { static constexpr int STAGE = (BM + BN) * KB;
 // wave it is half that, there is one barrier per 256 bytes of k instead of per 128, and the tile count (the only way a
 // [2432 x 768] output fills 256 CUs) stays the same.  The four partial tiles meet in the LDS-staged epilogue.
 template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB, bool KS = false>
-__device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int bid, const int ky, char* smem) {
+__device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, const int n0, const int ky, char* smem) {
     static_assert(!KS || KB == 256, "k-split waves: four 64-byte slabs per stage");
     constexpr int BKE = KB / sizeof(T);
     constexpr int MT = KS ? BM / 16 : BM / 32, NT = KS ? BN / 16 : BN / 32;
@@ -465,8 +466,6 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int bid, con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = KS ? 0 : (wave >> 1), wc = KS ? 0 : (wave & 1);
-    int m0, n0;
-    if (!tile_origin<BM, BN>(p, m0, n0, bid)) return;
     const int kbeg = ky * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nt = (kend - kbeg) / BKE;
@@ -534,7 +533,9 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int bid, con
 template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB, bool KS = false>
 __global__ void __launch_bounds__(256) gemm2_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB, KS>::BYTES];
-    gemm2_body<T, BM, BN, AK, BK, MODE, NSTAGE, KB, KS>(p, blockIdx.x, blockIdx.y, smem);
+    int m0, n0;
+    if (!tile_origin<BM, BN>(p, m0, n0, blockIdx.x)) return;
+    gemm2_body<T, BM, BN, AK, BK, MODE, NSTAGE, KB, KS>(p, m0, n0, blockIdx.y, smem);
 }
 
 // Grouped wgrad: up to MB_MAX_GROUP independent dW += dY^T X problems in ONE launch.  Each of a layer's four weight
@@ -546,12 +547,41 @@ __global__ void __launch_bounds__(256) gemm2_grouped_tn_kernel(const GroupedGemm
     __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB>::BYTES];
     // (A persistent variant that holds only one LDS slot per CU -- MB_GROUP_GRID = 128 / 256 / 384 blocks looping over the 432
     //  tiles -- was measured: no gain at 384, slower below; the launch is needed at full width to finish inside its layer.)
-    int g = 0;
+    int g = 0, m0, n0;
+    if (ga.chunk > 0) {
+        // XCD-compact placement across the WHOLE group: all tiles of all problems form one list in "strip" order (strips of
+        // `reg_n` tiles across the longer side of a problem, row-major inside a strip); XCD x (= blockIdx % 8) owns the x-th run
+        // of `chunk` consecutive tiles.  A run is ~one strip: ~(short side + strip width) operand panels per XCD instead of the
+        // (rows + columns) of eight separate regions in EVERY problem -- the panels cross the fabric ~2x less often.
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int lin = xcd * ga.chunk + j;
+        if (j >= ga.chunk || lin >= ga.first[ga.count]) return;
 #pragma unroll
-    for (int i = 1; i < MB_MAX_GROUP; ++i)
-        if (i < ga.count && (int)blockIdx.x >= ga.first[i]) g = i;
-    g = __builtin_amdgcn_readfirstlane(g);
-    gemm2_body<T, BM, BN, true, true, EPI_ACCUM_F32, NSTAGE, KB>(ga.g[g], (int)blockIdx.x - ga.first[g], 0, smem);
+        for (int i = 1; i < MB_MAX_GROUP; ++i)
+            if (i < ga.count && lin >= ga.first[i]) g = i;
+        g = __builtin_amdgcn_readfirstlane(g);
+        const GemmArgs& p = ga.g[g];
+        const int local = lin - ga.first[g];
+        const int W = p.reg_n, tm_n = p.tpr_m, tn_n = p.tpr_n;
+        int tm, tn;
+        if (p.reg_m == 0) {                          // strips across n
+            const int strip = local / (tm_n * W), r = local - strip * tm_n * W;
+            const int w = min(W, tn_n - strip * W);
+            tm = r / w; tn = strip * W + r - tm * w;
+        } else {                                     // strips across m
+            const int strip = local / (tn_n * W), r = local - strip * tn_n * W;
+            const int h = min(W, tm_n - strip * W);
+            tn = r / h; tm = strip * W + r - tn * h;
+        }
+        m0 = tm * BM; n0 = tn * BN;
+    } else {
+#pragma unroll
+        for (int i = 1; i < MB_MAX_GROUP; ++i)
+            if (i < ga.count && (int)blockIdx.x >= ga.first[i]) g = i;
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (!tile_origin<BM, BN>(ga.g[g], m0, n0, (int)blockIdx.x - ga.first[g])) return;
+    }
+    gemm2_body<T, BM, BN, true, true, EPI_ACCUM_F32, NSTAGE, KB>(ga.g[g], m0, n0, 0, smem);
 }
 
 // ---------------------------------------------------------------------------------------------- host
@@ -677,6 +707,8 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
     constexpr int EPV = 16 / sizeof(T);
     GroupedGemmArgs ga;
     ga.count = count;
+    static int g_map = -1;           // MB_GROUP_MAP=0: round-1 placement (eight XCD regions inside every problem)
+    if (g_map < 0) g_map = env_int("MB_GROUP_MAP", 1);
     int total = 0;
     for (int i = 0; i < count; ++i) {
         GemmArgs& p = ga.g[i];
@@ -686,7 +718,13 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
             (((uintptr_t)p.A | (uintptr_t)p.B) % 16))
             return MB_ERR_SHAPE;
         ga.first[i] = total;
-        total += choose_regions<BM, BN>(p);
+        if (g_map) {
+            p.tpr_m = p.M / BM; p.tpr_n = p.N / BN;
+            p.reg_m = p.tpr_n >= p.tpr_m ? 0 : 1;               // strips run across the longer side
+            total += p.tpr_m * p.tpr_n;
+        } else {
+            total += choose_regions<BM, BN>(p);
+        }
         p.kchunk = p.K;
         if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
         p.dbg = g_dbg & 8;
@@ -694,7 +732,13 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
     ga.first[count] = total;
     static int g_gstages = -1;       // MB_GROUP_STAGES: ring depth of the grouped kernel (2 | 3)
     if (g_gstages < 0) g_gstages = env_int("MB_GROUP_STAGES", 2);
-    const int grid = total;
+    ga.chunk = g_map ? (total + 7) / 8 : 0;
+    if (g_map)
+        for (int i = 0; i < count; ++i) {       // strip width: one strip ~ one XCD's share (chunk) of the list
+            const int shortside = std::min(ga.g[i].tpr_m, ga.g[i].tpr_n);
+            ga.g[i].reg_n = std::max(1, (ga.chunk + shortside / 2) / shortside);
+        }
+    const int grid = g_map ? 8 * ga.chunk : total;
     if (g_gstages >= 3) {
         hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 3, 128>), dim3(grid), dim3(256), 0, st, ga);
     } else {

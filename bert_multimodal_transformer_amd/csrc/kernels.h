@@ -54,8 +54,9 @@ int gemm_launch(int dtype, int layout, int mode, const GemmArgs& a, int splits, 
 #define MB_MAX_GROUP 8
 struct GroupedGemmArgs {
     GemmArgs g[MB_MAX_GROUP];
-    int first[MB_MAX_GROUP + 1];
+    int first[MB_MAX_GROUP + 1];    // first block (region placement) or first tile of the group-wide list (chunk > 0) of every problem
     int count;
+    int chunk;                      // > 0: tiles per XCD of the group-wide XCD-compact placement (gemm.hip); 0: per-problem regions
 };
 int gemm_grouped_tn_ok(int dtype, const GemmArgs* probs, int count, int tile);
 int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st);
@@ -177,7 +178,13 @@ struct PrologueArgs {
     AdamArgs adam[2]; AdamArgs* adam_dst;  // may be null
 };
 int step_prologue(const PrologueArgs& a, hipStream_t st);
-// p[0, bytes) = 0 as a kernel launch (bytes and p multiples of 4)
+// p[0, bytes) = 0 as a kernel launch (bytes and p multiples of 4); up to MB_ZERO_MAX ranges in one launch
+#define MB_ZERO_MAX 8
+struct ZeroRanges {
+    uint32_t* p[MB_ZERO_MAX]; size_t ndw[MB_ZERO_MAX]; int n;
+    void add(void* ptr, size_t bytes) { if (bytes && n < MB_ZERO_MAX) { p[n] = (uint32_t*)ptr; ndw[n] = bytes / 4; ++n; } }
+};
 int zero_fill(void* p, size_t bytes, hipStream_t st);
+int zero_fill_ranges(const ZeroRanges& z, hipStream_t st);
 
 }  // namespace mb

@@ -478,26 +478,45 @@ int widen(int dtype, const void* src, float* dst, size_t n, hipStream_t st) {
 // The passes clear their scratch (packed MAG weight gradients, pad rows, the [CLS]-only pooler gradient slab, the loss word)
 // with this launch instead of hipMemsetAsync: a captured step then consists of kernel nodes only (memset nodes of a replayed
 // graph were the one thing that did not reproduce the eager result on ROCm 7.2: stale packed MAG gradients on replays).
-__global__ void __launch_bounds__(256) zero_fill_kernel(uint32_t* __restrict__ p, size_t ndw) {
+__global__ void __launch_bounds__(256) zero_fill_kernel(const ZeroRanges z) {
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
-    if (((uintptr_t)p & 15) == 0) {
-        const size_t n4 = ndw / 4;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        for (size_t i = tid; i < n4; i += nth) ((u32x4*)p)[i] = z;
-        for (size_t i = n4 * 4 + tid; i < ndw; i += nth) p[i] = 0u;
-    } else {
-        for (size_t i = tid; i < ndw; i += nth) p[i] = 0u;
+#pragma unroll 1
+    for (int r = 0; r < z.n; ++r) {
+        uint32_t* __restrict__ p = z.p[r];
+        const size_t ndw = z.ndw[r];
+        if (((uintptr_t)p & 15) == 0) {
+            const size_t n4 = ndw / 4;
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            for (size_t i = tid; i < n4; i += nth) ((u32x4*)p)[i] = zero;
+            for (size_t i = n4 * 4 + tid; i < ndw; i += nth) p[i] = 0u;
+        } else {
+            for (size_t i = tid; i < ndw; i += nth) p[i] = 0u;
+        }
     }
+}
+int zero_fill_ranges(const ZeroRanges& z, hipStream_t st) {
+    if (z.n < 0 || z.n > MB_ZERO_MAX) return MB_ERR_ARG;
+    size_t most = 0;
+    ZeroRanges c = {};
+    for (int r = 0; r < z.n; ++r) {
+        if (z.ndw[r] == 0) continue;
+        if (!z.p[r] || ((uintptr_t)z.p[r] & 3)) return MB_ERR_ARG;
+        c.p[c.n] = z.p[r]; c.ndw[c.n] = z.ndw[r]; ++c.n;
+        if (z.ndw[r] > most) most = z.ndw[r];
+    }
+    if (c.n == 0) return MB_OK;
+    unsigned grid = (unsigned)((most / 4 + 255) / 256);
+    if (grid < 1) grid = 1;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(256), 0, st, c);
+    return (int)hipGetLastError();
 }
 int zero_fill(void* p, size_t bytes, hipStream_t st) {
     if (bytes == 0) return MB_OK;
-    if (!p || (bytes & 3) || ((uintptr_t)p & 3)) return MB_ERR_ARG;
-    const size_t ndw = bytes / 4;
-    unsigned grid = (unsigned)((ndw / 4 + 255) / 256);
-    if (grid < 1) grid = 1;
-    if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(256), 0, st, (uint32_t*)p, ndw);
-    return (int)hipGetLastError();
+    if (!p || (bytes & 3)) return MB_ERR_ARG;
+    ZeroRanges z = {};
+    z.n = 1; z.p[0] = (uint32_t*)p; z.ndw[0] = bytes / 4;
+    return zero_fill_ranges(z, st);
 }
 
 // ------------------------------------------------------------------------------------------ step prologue

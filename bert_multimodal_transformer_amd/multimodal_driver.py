@@ -400,8 +400,15 @@ def _batches(dataloader):
     --prefetch false the six copies of the reference."""
     if getattr(args, "prefetch", True):
         from .prefetch import PinnedBatchRing
-        return PinnedBatchRing(dataloader, _device())
+        ring = _RINGS.get(str(_device()))
+        if ring is None:                       # one ring (four pinned blocks) per device for the whole run
+            ring = _RINGS[str(_device())] = PinnedBatchRing(None, _device())
+        ring.loader = dataloader
+        return ring
     return (_unpack(b) for b in dataloader)
+
+
+_RINGS = {}
 
 
 def train_epoch(model: nn.Module, train_dataloader: DataLoader, optimizer, scheduler):
