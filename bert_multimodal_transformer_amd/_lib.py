@@ -95,6 +95,11 @@ PROTOTYPES = {
     "mb_xlnet_backward": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp]),
     "mb_xlnet_sequence_output": (_vp, [_vp]),
     "mb_xlnet_hidden_state": (_vp, [_vp, _i]),
+    "mb_xlnet_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f,
+                                 _i, _i, _f, _f, _i, _vp]),
+    "mb_xlnet_load_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_vp), _vp]),
+    "mb_xlnet_graph_stats": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
+    "mb_xlnet_trainable_count": (_sz, [_vp]),
     "mb_xlnet_stage_grad_ranges": (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz), _i]),
 }
 

@@ -124,6 +124,8 @@ class _Core(object):
         n = self._fn("param_count")(self.handle)
         self.n_params = n
         self.n_decay = self._fn("decay_count")(self.handle)
+        # end of the flat range the optimizer updates: MAG-XLNet keeps a frozen slot (transformer.mask_emb) behind it
+        self.n_update_end = n if kind == "bert" else self.lib.mb_xlnet_trainable_count(self.handle)
         b, e = C.c_size_t(), C.c_size_t()
         self._fn("shadow_range")(self.handle, C.byref(b), C.byref(e))
         self.sh_begin, self.sh_end = b.value, e.value
@@ -228,8 +230,6 @@ class _Core(object):
     def _pinned_batch(self, tensors, B, L):
         """True when the batch can be read by the GPU where it is: six pinned, contiguous host tensors of the engine's dtypes
         (what prefetch.PinnedBatchRing yields).  Anything else goes through torch's .to(device)."""
-        if self.kind != "bert":
-            return False
         want = (torch.int64, torch.float32, torch.float32, torch.int64, torch.int64, torch.float32)
         shapes = ((B, L), (B, L, self.V), (B, L, self.A), (B, L), (B, L), None)
         for t, dt, shp in zip(tensors, want, shapes):
@@ -254,8 +254,8 @@ class _Core(object):
                 return ptrs, six
             staged = (C.c_void_p * 6)()
             with _Core._Hop(self):
-                _lib.check(self.lib.mb_bert_load_batch(self.handle, ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5], B, L, staged,
-                                                       self.stream()))
+                _lib.check(self._fn("load_batch")(self.handle, ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5], B, L, staged,
+                                                   self.stream()))
             off = staged[0] - self.ws.data_ptr()
             self._ids_dev = self.ws[off: off + B * L * 8].view(torch.int64)          # the engine's staging copy of input_ids
             return [C.c_void_p(staged[i]) if staged[i] else None for i in range(6)], six
@@ -311,8 +311,6 @@ class _Core(object):
 
     def fused_step_blocker(self):
         """why one optimizer step cannot be ONE engine call (mb_bert_train_step), or None"""
-        if self.kind != "bert":
-            return "the MAG-XLNet engine has no single-call step yet"
         if self.stage_hooks:
             return "backward stage hooks are installed (data parallel: the gradient exchange is issued between stages)"
         return None
@@ -339,7 +337,7 @@ class _Core(object):
         self.training_last = True
         o = opt or {}
         with _Core._Hop(self):
-            _lib.check(self.lib.mb_bert_train_step(
+            _lib.check(self._fn("train_step")(
                 self.handle, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5], B, L,
                 self.seed & (2 ** 64 - 1), self.step, _lib.ptr(logits), C.c_void_p(self.loss_buf.data_ptr()),
                 C.c_void_p(self.loss_buf.data_ptr() + 4), _lib.ptr(o.get("m")), _lib.ptr(o.get("v")), o.get("lr", 0.0),
@@ -349,9 +347,7 @@ class _Core(object):
 
     def graph_stats(self):
         cap, rep = C.c_size_t(), C.c_size_t()
-        if self.kind != "bert":
-            return 0, 0
-        _lib.check(self.lib.mb_bert_graph_stats(self.handle, C.byref(cap), C.byref(rep)))
+        _lib.check(self._fn("graph_stats")(self.handle, C.byref(cap), C.byref(rep)))
         return cap.value, rep.value
 
     def _act(self, ptr, B, L):

@@ -19,7 +19,7 @@
 struct LayerOff { size_t wqkv, wo, w1, w2, bqkv, bo, ln1w, ln1b, b1, b2, ln2w, ln2b; };
 struct LayerWs { size_t qkv, ctx, s1, st1, y1, u, g, s2, st2; };
 
-struct mb_bert_engine {
+struct mb_bert_engine : StepMixin {
     mb_bert_config c;
     std::vector<TensorInfo> tensors;
     std::vector<LayerOff> lo;
@@ -55,18 +55,7 @@ struct mb_bert_engine {
     bool ws_zeroed = false;
     uint64_t seed = 0, step = 0;
     float* logits = nullptr;
-    // whole-step hipGraph (mb_bert_train_step): per-step scalars live in the workspace (ws_state: AdamArgs[2] + keys[nsites][2]),
-    // the batch is gathered into fixed staging buffers (ws_in_*), one instantiated graph per (shape, output pointers)
-    bool dyn = false;              // dropout keys / AdamW scalars are read from device memory (set while a train step is built)
-    bool capturing = false;        // the stream is in capture mode: nothing outside the captured sequence may be waited for
-    int nsites = 0;
-    size_t ws_state = 0, ws_in_ids = 0, ws_in_seg = 0, ws_in_mask = 0, ws_in_vis = 0, ws_in_aco = 0, ws_in_lab = 0;
-    struct StepGraph {
-        int B, L, with_opt; const void *logits, *loss, *loss_run, *m, *v; float loss_scale; hipStream_t st;
-        hipGraph_t graph; hipGraphExec_t exec;
-    };
-    std::vector<StepGraph> graphs;
-    size_t graph_launches = 0, graph_captures = 0;
+    // (whole-step machinery: StepMixin -- staging buffers, device-resident step state, graph cache)
 
     size_t add(const std::string& name, std::vector<int64_t> shape, int decay, size_t& cursor) {
         TensorInfo t;
@@ -81,15 +70,7 @@ struct mb_bert_engine {
     const void* W(size_t off) const {   // GEMM operand view of a weight (bf16 shadow in perf mode, master in fp32 mode)
         return c.dtype == DT_BF16 ? (const void*)(SH + off * 2) : (const void*)(P + off);
     }
-    AdamArgs* adam_state() const { return (AdamArgs*)(ws + ws_state); }
-    uint32_t* key_state() const { return (uint32_t*)(ws + ws_state + 2 * sizeof(AdamArgs)); }
-    DropKey key(uint32_t site, float p) const {
-        if (!training) return kNoDrop;
-        if (!dyn) return make_key(seed, step, site, p);
-        DropKey k = make_key(0, 0, site, p);          // thresh / scale of this site; (k0, k1) come from the device table
-        if (k.thresh) { k.k0 = k.k1 = 0u; k.dyn = key_state() + 2 * (size_t)site; }
-        return k;
-    }
+    DropKey key(uint32_t site, float p) const { return step_key(ws, training != 0, seed, step, site, p); }
 };
 
 static void build_layout(mb_bert_engine* e) {
@@ -172,11 +153,7 @@ static void build_layout(mb_bert_engine* e) {
     }
     e->ws_dctx = w.take(T * H * es); e->ws_dsum = w.take(T * H * 4); e->ws_dz = w.take((size_t)c.max_batch * H * es);
     e->ws_lnp_a = w.take(ln_partials_floats((int)T, (int)H) * 4); e->ws_lnp_b = w.take(ln_partials_floats((int)T, (int)H) * 4);
-    e->nsites = SITE_LAYER0 + 4 * c.num_layers;
-    e->ws_state = w.take(2 * sizeof(AdamArgs) + (size_t)e->nsites * 8);
-    e->ws_in_ids = w.take(T * 8); e->ws_in_seg = w.take(T * 8); e->ws_in_mask = w.take(T * 8);
-    e->ws_in_vis = w.take(T * (size_t)V * 4); e->ws_in_aco = w.take(T * (size_t)A * 4);
-    e->ws_in_lab = w.take((size_t)c.max_batch * c.num_labels * 4);
+    e->carve_step(w, T, (int)V, (int)A, c.max_batch, c.num_labels, SITE_LAYER0 + 4 * c.num_layers);
     e->ws_bytes = w.off;
 }
 
@@ -370,7 +347,7 @@ void mb_bert_destroy(mb_bert_engine* e) {
     if (e->side) hipStreamDestroy(e->side);
     for (auto& ev : e->evs) if (ev) hipEventDestroy(ev);
     for (auto& ev : e->pev) if (ev) hipEventDestroy(ev);
-    for (auto& g : e->graphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
+    e->drop_graphs();
     delete e;
 }
 int mb_bert_num_tensors(const mb_bert_engine* e) { return (int)e->tensors.size(); }
@@ -396,8 +373,7 @@ int mb_bert_bind(mb_bert_engine* e, float* params, float* grads, void* shadow, v
     if (e->c.dtype == DT_BF16 && !shadow) return MB_ERR_ARG;
     e->P = params; e->G = grads; e->SH = (char*)shadow; e->ws = (char*)workspace;
     e->ws_zeroed = false; e->padT = -1;
-    for (auto& g : e->graphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }      // captured against the old buffers
-    e->graphs.clear();
+    e->drop_graphs();                         // captured against the old buffers
     return MB_OK;
 }
 
@@ -633,8 +609,8 @@ static int enqueue_step(mb_bert_engine* e, int B, int L, float* logits, float* l
         const AdamArgs none = {};
         const size_t nd = e->n_decay, n = e->n_params;
         void* sh = e->c.dtype == DT_BF16 ? (void*)e->SH : nullptr;
-        CK(adamw_step(e->P, e->G, m, v, sh, nd, nd, e->sh_begin, e->sh_end, none, 1, st, e->adam_state()));
-        CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state() + 1));
+        CK(adamw_step(e->P, e->G, m, v, sh, nd, nd, e->sh_begin, e->sh_end, none, 1, st, e->adam_state(ws)));
+        CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
     }
     return MB_OK;
 }
@@ -655,59 +631,12 @@ int mb_bert_train_step(mb_bert_engine* e, const int64_t* input_ids, const float*
     CK(ensure_side(e));
     e->training = 1;
     CK(prepare_pass(e, T, st));
-    // ---- this step's values -> device memory
-    PrologueArgs pa = {};
-    auto cp = [&](const void* src, size_t off, size_t bytes) {
-        pa.src[pa.ncopies] = (const uint32_t*)src; pa.dst[pa.ncopies] = (uint32_t*)(ws + off); pa.dwords[pa.ncopies] = (uint32_t)(bytes / 4);
-        ++pa.ncopies;
-    };
-    cp(input_ids, e->ws_in_ids, (size_t)T * 8); cp(token_type_ids, e->ws_in_seg, (size_t)T * 8); cp(attention_mask, e->ws_in_mask, (size_t)T * 8);
-    cp(visual, e->ws_in_vis, (size_t)T * c.visual_dim * 4); cp(acoustic, e->ws_in_aco, (size_t)T * c.acoustic_dim * 4);
-    cp(labels, e->ws_in_lab, (size_t)B * c.num_labels * 4);
-    pa.seed = seed; pa.step = step; pa.keys = e->key_state(); pa.nsites = e->nsites;
-    if (m) {
-        double ss = lr;
-        if (correct_bias) ss = (double)lr * sqrt(1.0 - pow((double)beta2, (double)opt_step)) / (1.0 - pow((double)beta1, (double)opt_step));
-        AdamArgs a;
-        a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.step_size = (float)ss;
-        a.grad_scale = grad_scale;
-        pa.adam[0] = a;
-        a.weight_decay = 0.f;
-        pa.adam[1] = a;
-        pa.adam_dst = e->adam_state();
-    }
-    CK(step_prologue(pa, st));
-    if (mode == 2 || e->prof) {
-        e->dyn = true;
-        const int r = enqueue_step(e, B, L, logits, loss, loss_run, m, v, loss_scale, st);
-        e->dyn = false;
-        return r;
-    }
-    mb_bert_engine::StepGraph* g = nullptr;
-    for (auto& x : e->graphs)
-        if (x.B == B && x.L == L && x.with_opt == (m != nullptr) && x.logits == logits && x.loss == loss && x.loss_run == loss_run &&
-            x.m == m && x.v == v && x.loss_scale == loss_scale && x.st == st) { g = &x; break; }
-    if (!g) {
-        if (e->graphs.size() >= 32) {          // callers that keep changing output pointers: do not grow without bound
-            hipGraphExecDestroy(e->graphs.front().exec); hipGraphDestroy(e->graphs.front().graph);
-            e->graphs.erase(e->graphs.begin());
-        }
-        mb_bert_engine::StepGraph ng = {B, L, m != nullptr, logits, loss, loss_run, m, v, loss_scale, st, nullptr, nullptr};
-        CK((int)hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-        e->dyn = true; e->capturing = true;
-        const int r = enqueue_step(e, B, L, logits, loss, loss_run, m, v, loss_scale, st);
-        e->dyn = false; e->capturing = false;
-        const int r2 = (int)hipStreamEndCapture(st, &ng.graph);
-        if (r) { if (ng.graph) hipGraphDestroy(ng.graph); return r; }
-        CK(r2);
-        CK((int)hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0));
-        e->graphs.push_back(ng);
-        g = &e->graphs.back();
-        ++e->graph_captures;
-    }
-    CK((int)hipGraphLaunch(g->exec, st));
-    ++e->graph_launches;
-    return MB_OK;
+    return train_step_impl(e, ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
+                           labels, B, L, seed, step, logits, loss, loss_run, m, v, lr, beta1, beta2, eps, weight_decay, opt_step,
+                           correct_bias, grad_scale, loss_scale, mode, e->prof, st,
+                           [&](float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
+                               return enqueue_step(e, B, L, lg, ls, lr_, m_, v_, sc, s);
+                           });
 }
 
 int mb_bert_load_batch(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
@@ -722,16 +651,10 @@ int mb_bert_load_batch(mb_bert_engine* e, const int64_t* input_ids, const float*
     char* ws = e->ws;
     CK(prepare_pass(e, T, st));          // the one-time clearing of the workspace must not land on top of the staged batch
     PrologueArgs pa = {};
-    auto cp = [&](const void* src, size_t off, size_t bytes) {
-        pa.src[pa.ncopies] = (const uint32_t*)src; pa.dst[pa.ncopies] = (uint32_t*)(ws + off); pa.dwords[pa.ncopies] = (uint32_t)(bytes / 4);
-        ++pa.ncopies;
-    };
-    cp(input_ids, e->ws_in_ids, (size_t)T * 8); cp(token_type_ids, e->ws_in_seg, (size_t)T * 8); cp(attention_mask, e->ws_in_mask, (size_t)T * 8);
-    cp(visual, e->ws_in_vis, (size_t)T * c.visual_dim * 4); cp(acoustic, e->ws_in_aco, (size_t)T * c.acoustic_dim * 4);
-    if (labels) cp(labels, e->ws_in_lab, (size_t)B * c.num_labels * 4);
+    e->fill_copies(pa, ws, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, B, L, c.visual_dim, c.acoustic_dim,
+                   c.num_labels);
     CK(step_prologue(pa, st));
-    staged6[0] = ws + e->ws_in_ids; staged6[1] = ws + e->ws_in_vis; staged6[2] = ws + e->ws_in_aco; staged6[3] = ws + e->ws_in_mask;
-    staged6[4] = ws + e->ws_in_seg; staged6[5] = labels ? ws + e->ws_in_lab : nullptr;
+    e->staged(ws, labels != nullptr, staged6);
     return MB_OK;
 }
 

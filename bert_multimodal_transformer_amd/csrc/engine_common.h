@@ -125,6 +125,116 @@ inline int wgrad(int dtype, int Mo, int No, int rows, const void* dY, int ldy, c
                 kNoDrop, splits, tile, st);
 }
 
+// ------------------------------------------------------------------------------------------------ whole-step machinery
+// Shared by both engines (mb_bert_train_step / mb_xlnet_train_step, mb_*_load_batch): everything that changes from one optimizer
+// step to the next lives in the workspace -- staging buffers for the six batch tensors, the dropout keys of every site, the AdamW
+// scalars of the two parameter groups -- written by ONE prologue launch; the rest of the step is a fixed kernel sequence that can
+// be replayed as a hipGraph.
+struct StepGraph {
+    int B, L, with_opt; const void *logits, *loss, *loss_run, *m, *v; float loss_scale; hipStream_t st;
+    hipGraph_t graph; hipGraphExec_t exec;
+};
+
+struct StepMixin {
+    bool dyn = false;              // dropout keys / AdamW scalars are read from device memory (set while a train step is built)
+    bool capturing = false;        // the stream is in capture mode: nothing outside the captured sequence may be waited for
+    int nsites = 0;
+    size_t ws_state = 0, ws_in_ids = 0, ws_in_seg = 0, ws_in_mask = 0, ws_in_vis = 0, ws_in_aco = 0, ws_in_lab = 0;
+    std::vector<StepGraph> graphs;
+    size_t graph_launches = 0, graph_captures = 0;
+
+    void carve_step(Carver& w, size_t Tpad, int V, int A, int max_batch, int num_labels, int nsites_) {
+        nsites = nsites_;
+        ws_state = w.take(2 * sizeof(AdamArgs) + (size_t)nsites * 8);
+        ws_in_ids = w.take(Tpad * 8); ws_in_seg = w.take(Tpad * 8); ws_in_mask = w.take(Tpad * 8);
+        ws_in_vis = w.take(Tpad * (size_t)V * 4); ws_in_aco = w.take(Tpad * (size_t)A * 4);
+        ws_in_lab = w.take((size_t)max_batch * num_labels * 4);
+    }
+    void drop_graphs() {
+        for (auto& g : graphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
+        graphs.clear();
+    }
+    AdamArgs* adam_state(char* ws) const { return (AdamArgs*)(ws + ws_state); }
+    uint32_t* key_state(char* ws) const { return (uint32_t*)(ws + ws_state + 2 * sizeof(AdamArgs)); }
+    DropKey step_key(char* ws, bool training, uint64_t seed, uint64_t step, uint32_t site, float p) const {
+        if (!training) return kNoDrop;
+        if (!dyn) return make_key(seed, step, site, p);
+        DropKey k = make_key(0, 0, site, p);          // thresh / scale of this site; (k0, k1) come from the device table
+        if (k.thresh) { k.k0 = k.k1 = 0u; k.dyn = key_state(ws) + 2 * (size_t)site; }
+        return k;
+    }
+    void fill_copies(PrologueArgs& pa, char* ws, const void* ids, const void* vis, const void* aco, const void* mask, const void* seg,
+                     const void* lab, int B, int L, int V, int A, int num_labels) const {
+        const size_t T = (size_t)B * L;
+        auto cp = [&](const void* src, size_t off, size_t bytes) {
+            pa.src[pa.ncopies] = (const uint32_t*)src; pa.dst[pa.ncopies] = (uint32_t*)(ws + off); pa.dwords[pa.ncopies] = (uint32_t)(bytes / 4);
+            ++pa.ncopies;
+        };
+        cp(ids, ws_in_ids, T * 8); cp(seg, ws_in_seg, T * 8); cp(mask, ws_in_mask, T * 8);
+        cp(vis, ws_in_vis, T * V * 4); cp(aco, ws_in_aco, T * A * 4);
+        if (lab) cp(lab, ws_in_lab, (size_t)B * num_labels * 4);
+    }
+    void staged(char* ws, bool with_labels, const void** six) const {
+        six[0] = ws + ws_in_ids; six[1] = ws + ws_in_vis; six[2] = ws + ws_in_aco; six[3] = ws + ws_in_mask; six[4] = ws + ws_in_seg;
+        six[5] = with_labels ? ws + ws_in_lab : nullptr;
+    }
+};
+
+// enqueue(logits, loss, loss_run, m, v, loss_scale, st): forward (reading the staged batch) + backward + AdamW of one engine
+template <class E, class Enqueue>
+inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const void* ids, const void* vis, const void* aco, const void* mask,
+                           const void* seg, const void* labels, int B, int L, uint64_t seed, uint64_t step, float* logits, float* loss,
+                           float* loss_run, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay,
+                           int opt_step, int correct_bias, float grad_scale, float loss_scale, int mode, bool force_launches,
+                           hipStream_t st, Enqueue enqueue) {
+    PrologueArgs pa = {};
+    e->fill_copies(pa, ws, ids, vis, aco, mask, seg, labels, B, L, V, A, num_labels);
+    pa.seed = seed; pa.step = step; pa.keys = e->key_state(ws); pa.nsites = e->nsites;
+    if (m) {
+        double ss = lr;
+        if (correct_bias) ss = (double)lr * sqrt(1.0 - pow((double)beta2, (double)opt_step)) / (1.0 - pow((double)beta1, (double)opt_step));
+        AdamArgs a;
+        a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.step_size = (float)ss;
+        a.grad_scale = grad_scale;
+        pa.adam[0] = a;
+        a.weight_decay = 0.f;
+        pa.adam[1] = a;
+        pa.adam_dst = e->adam_state(ws);
+    }
+    CK(step_prologue(pa, st));
+    if (mode == 2 || force_launches) {
+        e->dyn = true;
+        const int r = enqueue(logits, loss, loss_run, m, v, loss_scale, st);
+        e->dyn = false;
+        return r;
+    }
+    StepGraph* g = nullptr;
+    for (auto& x : e->graphs)
+        if (x.B == B && x.L == L && x.with_opt == (m != nullptr) && x.logits == logits && x.loss == loss && x.loss_run == loss_run &&
+            x.m == m && x.v == v && x.loss_scale == loss_scale && x.st == st) { g = &x; break; }
+    if (!g) {
+        if (e->graphs.size() >= 32) {          // callers that keep changing output pointers: do not grow without bound
+            hipGraphExecDestroy(e->graphs.front().exec); hipGraphDestroy(e->graphs.front().graph);
+            e->graphs.erase(e->graphs.begin());
+        }
+        StepGraph ng = {B, L, m != nullptr, logits, loss, loss_run, m, v, loss_scale, st, nullptr, nullptr};
+        CK((int)hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        e->dyn = true; e->capturing = true;
+        const int r = enqueue(logits, loss, loss_run, m, v, loss_scale, st);
+        e->dyn = false; e->capturing = false;
+        const int r2 = (int)hipStreamEndCapture(st, &ng.graph);
+        if (r) { if (ng.graph) hipGraphDestroy(ng.graph); return r; }
+        CK(r2);
+        CK((int)hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0));
+        e->graphs.push_back(ng);
+        g = &e->graphs.back();
+        ++e->graph_captures;
+    }
+    CK((int)hipGraphLaunch(g->exec, st));
+    ++e->graph_launches;
+    return MB_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ MAG operator
 inline int mag_fwd_impl(int dtype, const void* text, const float* visual, const float* acoustic, const float* W_hv,
                  const float* b_hv, const float* W_ha, const float* b_ha, const float* W_v, const float* b_v,

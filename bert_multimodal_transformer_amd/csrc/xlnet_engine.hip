@@ -19,7 +19,7 @@
 struct XlLayerOff { size_t q, k, v, o, r, w1, w2, seg, ralnw, fflnw, rrb, rsb, rwb, ralnb, fflnb, b1, b2; };
 struct XlLayerWs { size_t qkv, kr, vec, psave, s1, st1, y1, u, g, s2, st2; };
 
-struct mb_xlnet_engine {
+struct mb_xlnet_engine : StepMixin {
     mb_xlnet_config c;
     std::vector<TensorInfo> tensors;
     std::vector<XlLayerOff> lo;
@@ -37,8 +37,9 @@ struct mb_xlnet_engine {
     const int64_t* ids = nullptr; const int64_t* seg = nullptr; const int64_t* mask = nullptr;
     int B = 0, L = 0, training = 0, padT = -1;
     int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped weight-gradient launch (64 | 128), 0 = one by one
-    // the grouped launch of layer l runs on an internal side stream under the dgrad chain of layer l-1 (as in the MAG-BERT engine)
-    int overlap_wgrad = 1;
+    // MB_OVERLAP_WGRAD=1: the grouped launch of layer l runs on an internal side stream under the dgrad chain of layer l-1 (round-1
+    // default; measured equal to the in-line launch on the MAG-BERT engine, which keeps the step one in-order, graph-friendly sequence)
+    int overlap_wgrad = 0;
     bool deferred = false;
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> evs;   // [2 * n_layer]: fork, done
@@ -57,7 +58,7 @@ struct mb_xlnet_engine {
         return t.off;
     }
     const void* W(size_t off) const { return c.dtype == DT_BF16 ? (const void*)(SH + off * 2) : (const void*)(P + off); }
-    DropKey key(uint32_t site, float p) const { return training ? make_key(seed, step, site, p) : kNoDrop; }
+    DropKey key(uint32_t site, float p) const { return step_key(ws, training != 0, seed, step, site, p); }
 };
 
 // dropout sites: 0 word embedding, 1 MAG, 2 summary-last, 3 final output, 4 pos_emb ; layer l: 16+8l+{0 attn probs, 1 attn out,
@@ -150,7 +151,20 @@ static void xl_build_layout(mb_xlnet_engine* e) {
     e->ws_dvec = w.take(T * H * es); e->ws_gsave = w.take(PP * es);
     e->ws_dz = w.take((size_t)c.max_batch * H * es); e->ws_dxs = w.take((size_t)c.max_batch * H * es);
     e->ws_lnp_a = w.take(ln_partials_floats((int)T, (int)H) * 4); e->ws_lnp_b = w.take(ln_partials_floats((int)T, (int)H) * 4);
+    e->carve_step(w, T, (int)V, (int)A, c.max_batch, c.num_labels, XS_LAYER0 + 8 * c.n_layer);
     e->ws_bytes = w.off;
+}
+
+// state the next pass relies on but that is not part of the pass itself (kept out of captured step graphs)
+static int xl_prepare_pass(mb_xlnet_engine* e, int T, hipStream_t st) {
+    if (e->deferred && e->side)      // a backward that was not run to its last stage may still have weight-gradient GEMMs in flight
+        for (size_t l = 0; l < 2 && 2 * l + 1 < e->evs.size(); ++l) CK((int)hipStreamWaitEvent(st, e->evs[2 * l + 1], 0));
+    if (!e->ws_zeroed || e->padT != T) {      // pad rows of every k-major wgrad operand must be zero
+        CK((int)hipMemsetAsync(e->ws, 0, e->ws_bytes, st));
+        e->ws_zeroed = true;
+    }
+    e->padT = T;
+    return MB_OK;
 }
 
 extern "C" {
@@ -175,6 +189,7 @@ void mb_xlnet_destroy(mb_xlnet_engine* e) {
     if (!e) return;
     if (e->side) hipStreamDestroy(e->side);
     for (auto& ev : e->evs) if (ev) hipEventDestroy(ev);
+    e->drop_graphs();
     delete e;
 }
 int mb_xlnet_num_tensors(const mb_xlnet_engine* e) { return (int)e->tensors.size(); }
@@ -199,6 +214,7 @@ int mb_xlnet_bind(mb_xlnet_engine* e, float* params, float* grads, void* shadow,
     if (e->c.dtype == DT_BF16 && !shadow) return MB_ERR_ARG;
     e->P = params; e->G = grads; e->SH = (char*)shadow; e->ws = (char*)workspace;
     e->ws_zeroed = false; e->padT = -1;
+    e->drop_graphs();
     return MB_OK;
 }
 int mb_xlnet_sync_weights(mb_xlnet_engine* e, void* stream) {
@@ -222,13 +238,7 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
     e->B = B; e->L = L; e->training = training; e->seed = seed; e->step = step; e->logits = logits;
     float* P = e->P;
     char* ws = e->ws;
-    if (e->deferred && e->side)      // a backward that was not run to its last stage may still have weight-gradient GEMMs in flight
-        for (size_t l = 0; l < 2 && 2 * l + 1 < e->evs.size(); ++l) CK((int)hipStreamWaitEvent(st, e->evs[2 * l + 1], 0));
-    if (!e->ws_zeroed || e->padT != T) {      // pad rows of every k-major wgrad operand must be zero
-        CK((int)hipMemsetAsync(ws, 0, e->ws_bytes, st));
-        e->ws_zeroed = true;
-    }
-    e->padT = T;
+    if (!e->capturing) CK(xl_prepare_pass(e, T, st));
     const float pd = c.dropout;
     CK(gather_drop_forward(dt, input_ids, P + e->word, ws + e->ws_x[0], T, H, e->key(XS_EMB, pd), st));            // xlnet.py:304-305
     CK(xlnet_pos_emb(dt, ws + e->ws_pos, B, L, H, e->key(XS_POS, pd), st));                                         // xlnet.py:332-333
@@ -380,7 +390,11 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                                 nullptr, G + e->mag_whv, G + e->mag_bhv, G + e->mag_wha, G + e->mag_bha, G + e->mag_wv, G + e->mag_bv,
                                 G + e->mag_wa, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb, T, H, c.visual_dim, c.acoustic_dim, true,
                                 st));
-                CK((int)hipMemcpyAsync(dx, t1, (size_t)T * H * es, hipMemcpyDeviceToDevice, st));
+                {   // dx <- t1 as a kernel (a captured step holds kernel nodes only)
+                    PrologueArgs cp = {};
+                    cp.src[0] = (const uint32_t*)t1; cp.dst[0] = (uint32_t*)dx; cp.dwords[0] = (uint32_t)((size_t)T * H * es / 4); cp.ncopies = 1;
+                    CK(step_prologue(cp, st));
+                }
             }
             // deferred join: main waits for layer l+1's launch only now (its dY buffers have the parity of layer l-1, written next)
             if (grouped && e->deferred && l + 1 < NL) CK((int)hipStreamWaitEvent(st, e->evs[2 * (l + 1) + 1], 0));
@@ -391,6 +405,72 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
     }
     return MB_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ whole step (as mb_bert_train_step)
+static int xl_enqueue_step(mb_xlnet_engine* e, int B, int L, float* logits, float* loss, float* loss_run, float* m, float* v,
+                           float loss_scale, hipStream_t st) {
+    char* ws = e->ws;
+    const float* lab = (const float*)(ws + e->ws_in_lab);
+    CK(mb_xlnet_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
+                        (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
+                        loss_run, st));
+    CK(mb_xlnet_backward(e, nullptr, lab, loss_scale, 0, e->c.n_layer + 2, st));
+    if (m && v) {
+        const AdamArgs none = {};
+        const size_t nd = e->n_decay, n = e->n_trainable;        // the frozen mask_emb slot behind n_trainable is never updated
+        void* sh = e->c.dtype == DT_BF16 ? (void*)e->SH : nullptr;
+        CK(adamw_step(e->P, e->G, m, v, sh, nd, nd, e->sh_begin, e->sh_end, none, 1, st, e->adam_state(ws)));
+        CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
+    }
+    return MB_OK;
+}
+
+int mb_xlnet_train_step(mb_xlnet_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                        const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                        uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, float* m, float* v, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int opt_step, int correct_bias, float grad_scale,
+                        float loss_scale, int mode, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!e || !e->P || !e->G || !e->ws) return MB_ERR_ARG;
+    const mb_xlnet_config& c = e->c;
+    if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
+    if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !labels || !logits || !loss) return MB_ERR_ARG;
+    if ((m == nullptr) != (v == nullptr) || (mode != 1 && mode != 2)) return MB_ERR_ARG;
+    if (e->deferred) return MB_ERR_MODE;          // MB_OVERLAP_WGRAD=1: the side-stream scheme is driven stage by stage (mb_xlnet_backward)
+    e->training = 1;
+    CK(xl_prepare_pass(e, B * L, st));
+    return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
+                           labels, B, L, seed, step, logits, loss, loss_run, m, v, lr, beta1, beta2, eps, weight_decay, opt_step,
+                           correct_bias, grad_scale, loss_scale, mode, false, st,
+                           [&](float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
+                               return xl_enqueue_step(e, B, L, lg, ls, lr_, m_, v_, sc, s);
+                           });
+}
+
+int mb_xlnet_load_batch(mb_xlnet_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                        const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                        const void** staged6, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!e || !e->ws || !staged6) return MB_ERR_ARG;
+    const mb_xlnet_config& c = e->c;
+    if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
+    if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids) return MB_ERR_ARG;
+    CK(xl_prepare_pass(e, B * L, st));
+    PrologueArgs pa = {};
+    e->fill_copies(pa, e->ws, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, B, L, c.visual_dim, c.acoustic_dim,
+                   c.num_labels);
+    CK(step_prologue(pa, st));
+    e->staged(e->ws, labels != nullptr, staged6);
+    return MB_OK;
+}
+
+int mb_xlnet_graph_stats(const mb_xlnet_engine* e, size_t* captures, size_t* launches) {
+    if (!e) return MB_ERR_ARG;
+    if (captures) *captures = e->graph_captures;
+    if (launches) *launches = e->graph_launches;
+    return MB_OK;
+}
+size_t mb_xlnet_trainable_count(const mb_xlnet_engine* e) { return e->n_trainable; }
 
 const void* mb_xlnet_hidden_state(const mb_xlnet_engine* e, int i) {      // input of layer i (before the MAG injection), i = n_layer: last output
     if (!e || !e->ws || i < 0 || i > e->c.n_layer) return nullptr;

@@ -69,10 +69,14 @@ class AdamW(torch.optim.Optimizer):
             return None
         if self._plan is None:
             self._build_plan()
-        if len(self._plan) != 2 or any(it[0] != "flat" or it[2] is not core for it in self._plan):
+        flats = [it for it in self._plan if it[0] == "flat"]
+        loose = [it for it in self._plan if it[0] != "flat"]
+        if any(it[2].grad is not None for it in loose):           # grad-less parameters (MAG-XLNet's frozen mask_emb) are skipped by step() too
             return None
-        (_, g0, _, a0, b0), (_, g1, _, a1, b1) = sorted(self._plan, key=lambda it: it[3])
-        if (a0, b0, a1, b1) != (0, core.n_decay, core.n_decay, core.n_params):
+        if len(flats) != 2 or any(it[2] is not core for it in flats):
+            return None
+        (_, g0, _, a0, b0), (_, g1, _, a1, b1) = sorted(flats, key=lambda it: it[3])
+        if (a0, b0, a1, b1) != (0, core.n_decay, core.n_decay, getattr(core, "n_update_end", core.n_params)):
             return None
         ga, gb = self.param_groups[g0], self.param_groups[g1]
         if any(ga[k] != gb[k] for k in ("lr", "betas", "eps", "correct_bias")) or gb["weight_decay"] != 0.0:

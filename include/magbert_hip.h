@@ -241,6 +241,20 @@ const void* mb_xlnet_sequence_output(const mb_xlnet_engine* e);
 /* input of layer i as XLNetModel collects it with output_hidden_states (xlnet.py:363-392; before the MAG injection), i = n_layer: the last output */
 const void* mb_xlnet_hidden_state(const mb_xlnet_engine* e, int i);
 int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap);
+/* the MAG-XLNet counterparts of mb_bert_train_step / mb_bert_load_batch / mb_bert_graph_stats (same contracts; one iteration of
+ * train_epoch, multimodal_driver.py:359-386, for the xlnet-base-cased model).  The two parameter groups are [0, decay_count) and
+ * [decay_count, trainable_count); the frozen transformer.mask_emb slot behind them is never updated (HF AdamW skips grad-less
+ * parameters).  MB_ERR_MODE when the engine was created with MB_OVERLAP_WGRAD=1 (side-stream weight gradients). */
+int mb_xlnet_train_step(mb_xlnet_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                        const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                        uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, float* m, float* v, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int opt_step, int correct_bias, float grad_scale,
+                        float loss_scale, int mode, void* stream);
+int mb_xlnet_load_batch(mb_xlnet_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                        const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                        const void** staged6, void* stream);
+int mb_xlnet_graph_stats(const mb_xlnet_engine* e, size_t* captures, size_t* launches);
+size_t mb_xlnet_trainable_count(const mb_xlnet_engine* e);
 
 #ifdef __cplusplus
 }

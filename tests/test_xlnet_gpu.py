@@ -267,3 +267,43 @@ def test_driver_epoch_xlnet_runs_and_learns():
     assert np.isfinite(vl) and 0.0 <= acc <= 1.0 and np.isfinite(mae)
     D.args.reference_loop = True
     assert np.isfinite(D.train_epoch(model, tr, opt, sch))
+
+
+def _xl_trajectory(mode, cdt=torch.float32, nsteps=4, shapes=((5, 40), (5, 40), (3, 24), (5, 40))):
+    """nsteps optimizer steps (dropout ON) through model.train_step; mode False = passes driven from Python, True = step prologue +
+    replayed hipGraph (mb_xlnet_train_step), "launches" = the same single call launching the kernels one by one"""
+    from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
+    torch.manual_seed(77)
+    m = build(layers=3, cdt=cdt).train()
+    opt = AdamW(optimizer_grouped_parameters(m), lr=1e-3)
+    sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=1.0, num_training_steps=10)
+    losses = []
+    with m.stream_scope():
+        for s in range(nsteps):
+            B, L = shapes[s % len(shapes)]
+            ids, vis, aco, mask, seg, lab = tb(weights.synthetic_xlnet_batch(B, L, 47, 74, seed=90 + s), DEV)
+            m.train_step(ids, vis, aco, mask, seg, lab, optimizer=opt, graph=mode)
+            losses.append(m._core.loss_buf[0].clone())
+            sch.step()
+    stats = m._core.graph_stats()
+    torch.cuda.synchronize()
+    return dict(p=m.flat_params.clone(), g=m.flat_grads.clone(), losses=torch.stack(losses).cpu(), stats=stats,
+                frozen=m.transformer.mask_emb.detach().clone())
+
+
+def test_xlnet_single_call_step_equals_python_driven_passes():
+    """mb_xlnet_train_step (step prologue + replayed hipGraph, or the same call launching kernel by kernel) ends every step where
+    the passes driven from Python end it: same dropout masks, losses, parameters; gradients cleared; the frozen mask_emb slot
+    untouched.  Shapes change inside the run (two graphs, replays)."""
+    ref = _xl_trajectory(False)
+    noise = float((ref["p"] - _xl_trajectory(False)["p"]).abs().max())
+    assert ref["stats"] == (0, 0)
+    for name, mode in (("launches", "launches"), ("graph", True)):
+        run = _xl_trajectory(mode)
+        dp = float((run["p"] - ref["p"]).abs().max())
+        dl = float((run["losses"] - ref["losses"]).abs().max())
+        print("xlnet single call (%s) vs python-driven: |dparam| %.3e |dloss| %.3e (run-to-run %.3e) graphs %s" % (name, dp, dl, noise, run["stats"]))
+        assert dp <= 1e-5 + 10 * noise and dl <= 1e-5
+        assert float(run["g"].abs().max()) == 0.0
+        assert torch.equal(run["frozen"], ref["frozen"])
+        assert run["stats"] == ((2, 4) if mode is True else (0, 0))
