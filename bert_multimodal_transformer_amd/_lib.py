@@ -72,6 +72,9 @@ PROTOTYPES = {
     "mb_bert_pooled_output": (_vp, [_vp]),
     "mb_bert_hidden_state": (_vp, [_vp, _i]),
     "mb_bert_set_attention_output": (_i, [_vp, _vp]),
+    "mb_bert_set_head_mask": (_i, [_vp, _vp]),
+    "mb_bert_set_inputs_embeds": (_i, [_vp, _vp]),
+    "mb_bert_inputs_embeds_grad": (_vp, [_vp]),
     "mb_bert_backward_outputs": (_i, [_vp, _vp, _vp, _vp]),
     "mb_bert_stage_grad_ranges": (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz), _i]),
     "mb_bert_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f,

@@ -13,8 +13,9 @@ Different by design (MI355X-first):
   * forward/backward are single C calls that enqueue the whole pass on the current HIP stream;
   * `compute_dtype=torch.bfloat16` (perf mode) keeps bf16 activations + a bf16 operand shadow of the GEMM weights;
     `torch.float32` (parity mode) runs exact-fp32 MFMA and matches the CPU reference logits to < 1e-3;
-  * options the driver never uses (head_mask, inputs_embeds, position_ids, output_attentions/hidden_states,
-    encoder_hidden_states) raise NotImplementedError instead of silently taking a slow path.
+  * the optional arguments of forward are built on the HIP path too (head_mask, inputs_embeds, output_attentions,
+    output_hidden_states); what is not (non-default position_ids, the decoder's encoder_hidden_states) raises
+    NotImplementedError instead of silently taking a slow path.
 """
 import ctypes as C
 import os
@@ -65,14 +66,15 @@ class _EngineFn(torch.autograd.Function):
     accumulates into the flat gradient buffer (p.grad are views of it)."""
 
     @staticmethod
-    def forward(ctx, anchor, logits, core):
+    def forward(ctx, anchor, logits, core, inputs_embeds=None):
         ctx.core = core
+        ctx.want_emb = inputs_embeds is not None
         return logits.view_as(logits)
 
     @staticmethod
     def backward(ctx, dlogits):
         ctx.core._backward(dlogits.contiguous().float())
-        return torch.zeros((), device=dlogits.device), None, None
+        return torch.zeros((), device=dlogits.device), None, None, ctx.core.inputs_embeds_grad() if ctx.want_emb else None
 
 
 class _BaseFn(torch.autograd.Function):
@@ -81,8 +83,9 @@ class _BaseFn(torch.autograd.Function):
     runs the encoder / MAG / embedding stages, accumulating into the flat gradient buffer (p.grad are views of it)."""
 
     @staticmethod
-    def forward(ctx, anchor, seq, pooled, core):
+    def forward(ctx, anchor, seq, pooled, core, inputs_embeds=None):
         ctx.core = core
+        ctx.want_emb = inputs_embeds is not None
         ctx.save_for_backward(pooled)
         return seq.view_as(seq), pooled.view_as(pooled)
 
@@ -94,7 +97,7 @@ class _BaseFn(torch.autograd.Function):
         ds = None if d_seq is None else d_seq.to(cd).contiguous()
         dz = None if d_pooled is None else (d_pooled.float() * (1.0 - pooled * pooled)).to(cd).contiguous()    # tanh'
         core.backward_outputs(ds, dz)
-        return torch.zeros((), device=core.device), None, None, None
+        return torch.zeros((), device=core.device), None, None, None, core.inputs_embeds_grad() if ctx.want_emb else None
 
 
 class _Core(object):
@@ -137,6 +140,7 @@ class _Core(object):
         self.anchor = torch.zeros((), device=self.device, requires_grad=True)
         self.weights_dirty = True
         self.loss_buf = torch.zeros(2, dtype=torch.float32, device=self.device)   # [last step, running sum]
+        self._optional = (None, None)
 
     # -- engine lifecycle ---------------------------------------------------------------------------
     def _fn(self, name):
@@ -167,6 +171,7 @@ class _Core(object):
             self._fn("destroy")(self.handle)
             self.ws = None
         self.handle = h
+        self._optional = (None, None)          # a new engine starts without head_mask / inputs_embeds
         self.max_B, self.max_L = B, L
 
     def _ensure(self, B, L):
@@ -273,12 +278,56 @@ class _Core(object):
         self._ids_dev = ids.reshape(-1)
         return [_lib.ptr(t) for t in keep], keep
 
-    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, training):
-        B, L = input_ids.shape
+    def _set_optional(self, head_mask=None, inputs_embeds=None):
+        """head_mask [n_layers][n_heads] / inputs_embeds [B*L][H] (fp32 device tensors or None) -> engine state; sticky in the
+        engine, so every pass states what it wants (the single-call step refuses to run with either set)."""
+        if self.kind != "bert":
+            if head_mask is not None or inputs_embeds is not None:
+                raise NotImplementedError("head_mask / inputs_embeds are built for MAG-BERT only")
+            return
+        if head_mask is None and inputs_embeds is None and self._optional == (None, None):
+            return
+        _lib.check(self.lib.mb_bert_set_head_mask(self.handle, _lib.ptr(head_mask)))
+        _lib.check(self.lib.mb_bert_set_inputs_embeds(self.handle, _lib.ptr(inputs_embeds)))
+        self._optional = (head_mask, inputs_embeds)          # kept alive: the engine holds raw pointers through the backward
+
+    def head_mask_table(self, head_mask):
+        """transformers get_head_mask (bert.py:206-207): [n_heads] (every layer) or [n_layers][n_heads] (or the broadcast
+        5-D form of it) -> fp32 [n_layers][n_heads] on the device.  Masks that differ per sample or per position are not built."""
+        if head_mask is None:
+            return None
+        NL, nh = self.n_layers, self.config.num_attention_heads
+        hm = torch.as_tensor(head_mask).to(self.device, torch.float32)
+        if hm.dim() == 1 and hm.numel() == nh:
+            hm = hm[None].expand(NL, nh)
+        elif hm.numel() == NL * nh and (hm.dim() == 2 or tuple(hm.shape) == (NL, 1, nh, 1, 1)):
+            hm = hm.reshape(NL, nh)
+        else:
+            raise NotImplementedError("head_mask must be [num_heads] or [num_layers, num_heads], got %s" % (tuple(hm.shape),))
+        return hm.contiguous()
+
+    def inputs_embeds_grad(self):
+        """gradient of the inputs_embeds of the last forward, after its backward: fp32 [B, L, H] (a copy)"""
+        p = self.lib.mb_bert_inputs_embeds_grad(self.handle)
+        B, L, H = self._emb_shape
+        off = p - self.ws.data_ptr()
+        return self.ws[off: off + B * L * H * 4].view(torch.float32).view(B, L, H).clone()
+
+    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, training, head_mask=None,
+                inputs_embeds=None):
         dev = self.device
+        if inputs_embeds is not None:               # bert.py:158-168: shapes come from the embeddings, the ids are not read
+            inputs_embeds = inputs_embeds.detach().to(dev, torch.float32).contiguous()
+            B, L, H = inputs_embeds.shape
+            if H != self.config.hidden_size:
+                raise ValueError("inputs_embeds must be [B, L, %d]" % self.config.hidden_size)
+            self._emb_shape = (B, L, H)
+            input_ids = torch.zeros(B, L, dtype=torch.int64, device=dev)
+        B, L = input_ids.shape
         self._ensure(B, L)
         if self.weights_dirty:
             self.sync_weights()
+        self._set_optional(self.head_mask_table(head_mask), inputs_embeds)
         ptr, keep = self._inputs(input_ids, visual, acoustic, attention_mask, token_type_ids, labels)
         logits = torch.empty(B, self.config.num_labels, dtype=torch.float32, device=dev)
         if training:
@@ -325,6 +374,7 @@ class _Core(object):
             self.sync_weights()
         if labels is None:
             raise ValueError("the fused step needs label_ids")
+        self._set_optional(None, None)
         ptr, keep = self._inputs(input_ids, visual, acoustic, attention_mask, token_type_ids, labels, gather_in_step=True)
         if not hasattr(self, "_logit_bufs"):
             self._logit_bufs = {}
@@ -507,6 +557,24 @@ def _pretrained_file(path, cls_name):
 
 
 class _MagBertBase(nn.Module):
+    def _front(self, input_ids, inputs_embeds, attention_mask, token_type_ids, position_ids):
+        """argument checks and defaults of MAG_BertModel.forward (bert.py:158-177) -> (B, L, attention_mask, token_type_ids)"""
+        if input_ids is not None and inputs_embeds is not None:
+            raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+        if input_ids is None and inputs_embeds is None:
+            raise ValueError("You have to specify either input_ids or inputs_embeds")
+        B, L = input_ids.shape if input_ids is not None else inputs_embeds.shape[:-1]
+        dev = self._core.device
+        if position_ids is not None:      # only the default arange (BertEmbeddings) is built: the position is the row index
+            want = torch.arange(L, device=position_ids.device).expand(position_ids.shape[0], L)
+            if tuple(position_ids.shape[-1:]) != (L,) or not torch.equal(position_ids.reshape(-1, L), want):
+                raise NotImplementedError("position_ids other than arange(seq_len) are not supported by the HIP path")
+        if attention_mask is None:
+            attention_mask = torch.ones(B, L, dtype=torch.int64, device=dev)       # bert.py:173-174
+        if token_type_ids is None:
+            token_type_ids = torch.zeros(B, L, dtype=torch.int64, device=dev)      # bert.py:175-177
+        return B, L, attention_mask, token_type_ids
+
     def _unsupported(self, **kw):
         for k, v in kw.items():
             if v is not None and v is not False:
@@ -700,34 +768,29 @@ class MAG_BertModel(_MagBertBase):
                 head_mask=None, inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 output_attentions=None, output_hidden_states=None):
         """-> (sequence_output, pooled_output, (hidden_states), (attentions)) like bert.py:233-237.  sequence_output and
-        pooled_output carry an autograd edge into the engine (a head built on top of this model trains the whole stack);
-        hidden_states / attentions are detached fp32 copies.  head_mask, inputs_embeds, non-default position_ids and the
-        decoder arguments are not built on the HIP path and raise."""
-        self._unsupported(position_ids=position_ids, head_mask=head_mask, inputs_embeds=inputs_embeds,
-                          encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask)
+        pooled_output carry an autograd edge into the engine (a head built on top of this model trains the whole stack, and
+        inputs_embeds receives its gradient); hidden_states / attentions are detached fp32 copies.  head_mask: [num_heads] or
+        [num_layers, num_heads].  Non-default position_ids and the decoder arguments are not built on the HIP path and raise."""
+        self._unsupported(encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
-        if input_ids is None:
-            raise ValueError("You have to specify either input_ids or inputs_embeds")      # bert.py:166-168
-        if attention_mask is None:
-            attention_mask = torch.ones_like(input_ids)                                      # bert.py:173-174
-        if token_type_ids is None:
-            token_type_ids = torch.zeros_like(input_ids)                                     # bert.py:175-177
-        B, L = input_ids.shape
+        B, L, attention_mask, token_type_ids = self._front(input_ids, inputs_embeds, attention_mask, token_type_ids, position_ids)
         core = self._core
         probs = None
         if output_attentions:
             core._ensure(B, L)
             probs = core.attention_buffer(B, L)
         try:
-            core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training)
+            core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, head_mask=head_mask,
+                         inputs_embeds=inputs_embeds)
         finally:
             if output_attentions:
                 core.attention_done()
         seq, pooled = core.sequence_output(B, L), core.pooled_output(B)
         if torch.is_grad_enabled():
-            seq, pooled = _BaseFn.apply(core.anchor, seq, pooled, core)
+            emb_edge = inputs_embeds if inputs_embeds is not None and inputs_embeds.requires_grad else None
+            seq, pooled = _BaseFn.apply(core.anchor, seq, pooled, core, emb_edge)
         outputs = (seq, pooled)
         if output_hidden_states:
             outputs = outputs + (core.hidden_states(B, L),)
@@ -753,27 +816,24 @@ class MAG_BertForSequenceClassification(_FusedStep, _MagBertBase):
     # reference API ------------------------------------------------------------------------------------
     def forward(self, input_ids, visual, acoustic, attention_mask=None, token_type_ids=None, position_ids=None,
                 head_mask=None, inputs_embeds=None, labels=None, output_attentions=None, output_hidden_states=None):
-        self._unsupported(position_ids=position_ids, head_mask=head_mask, inputs_embeds=inputs_embeds)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
-        if attention_mask is None:
-            attention_mask = torch.ones_like(input_ids)
-        if token_type_ids is None:
-            token_type_ids = torch.zeros_like(input_ids)
+        B, L, attention_mask, token_type_ids = self._front(input_ids, inputs_embeds, attention_mask, token_type_ids, position_ids)
         core = self._core
-        B, L = input_ids.shape
         probs = None
         if output_attentions:
             core._ensure(B, L)
             probs = core.attention_buffer(B, L)
         try:
-            logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training)
+            logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training,
+                                  head_mask=head_mask, inputs_embeds=inputs_embeds)
         finally:
             if output_attentions:
                 core.attention_done()
         if torch.is_grad_enabled():
-            logits = _EngineFn.apply(core.anchor, logits, core)
+            emb_edge = inputs_embeds if inputs_embeds is not None and inputs_embeds.requires_grad else None
+            logits = _EngineFn.apply(core.anchor, logits, core, emb_edge)
         outputs = (logits,)                                           # bert.py:309-311: (logits,) + outputs[2:]
         if output_hidden_states:
             outputs = outputs + (core.hidden_states(B, L),)

@@ -23,7 +23,8 @@ namespace mb {
 // =============================================================================================== forward
 template <class T, int LP, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
-                                                           T* __restrict__ ctx, float* __restrict__ probs, int L, int nh,
+                                                           T* __restrict__ ctx, float* __restrict__ probs,
+                                                           const float* __restrict__ head_scale, int L, int nh,
                                                            DropKey drop) {
     drop.resolve();
     typedef AttnCfg<T> C;
@@ -53,6 +54,8 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
 
     char* Ps = strips + wave * 16 * SPIT;
     const float scale = 0.125f;
+    // head_mask (bert.py:196-209 -> BertSelfAttention): the dropped probabilities of head h are multiplied by head_scale[h]
+    const float hs = head_scale ? head_scale[h] : 1.0f;
     for (int s0 = 0; s0 < NT; s0 += NW) {
         const int strip = s0 + wave;
         const bool active = strip < NT;
@@ -88,7 +91,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
                 const int j = jt * 16 + (lane >> 4) * 4;
                 f32x4 p = acc[jt] * inv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p[r] *= drop_mult(drop, rowidx + j + r);
+                for (int r = 0; r < 4; ++r) p[r] *= drop_mult(drop, rowidx + j + r) * hs;
                 store4((T*)(Ps + (lane & 15) * SPIT) + j, p);
                 if (probs && i < L) {           // output_attentions (bert.py:147-151): the probabilities after dropout, fp32
 #pragma unroll
@@ -119,7 +122,8 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
 template <class T, int LP, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                            const T* __restrict__ dctx, T* __restrict__ dqkv,
-                                                           float* __restrict__ dbias, int L, int nh, DropKey drop) {
+                                                           float* __restrict__ dbias,
+                                                           const float* __restrict__ head_scale, int L, int nh, DropKey drop) {
     drop.resolve();
     typedef AttnCfg<T> C;
     constexpr int PIT = C::ROWB + 16;
@@ -178,6 +182,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
 
     char* St = strips + wave * 16 * SPIT;
     const float scale = 0.125f;
+    // head_mask: ctx_h = head_scale[h] * (dropped P) V, so dQ, dK and dV of the head are the unmasked ones times head_scale[h]
+    const float hs = head_scale ? head_scale[h] : 1.0f;
     T* dq_base = dqkv + (size_t)b * L * ld + h * 64;
 
     // ------------------------------------------------------------------ sweep A: query strips -> dQ, row stats
@@ -243,6 +249,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
                 for (int sl = 0; sl < LSL; ++sl)
                     mma16(o, frag_kmaj(Ki, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
                           frag_nat<T>(St, SPIT, lane & 15, sl, lane));
+                o = o * hs;
                 const int i = strip * 16 + (lane & 15);
                 if (i < L) store4(dq_base + (size_t)i * ld + dt * 16 + (lane >> 4) * 4, o);
                 if (i < L) cq[dt] += o;
@@ -298,6 +305,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
                 for (int sl = 0; sl < LSL; ++sl)
                     mma16(o, frag_kmaj(Oi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
                           frag_nat<T>(St, SPIT, lane & 15, sl, lane));
+                o = o * hs;
                 if (j < L) store4(dq_base + (size_t)j * ld + 2 * H + dt * 16 + (lane >> 4) * 4, o);
                 if (j < L) cv[dt] += o;
             }
@@ -317,6 +325,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
                 for (int sl = 0; sl < LSL; ++sl)
                     mma16(o, frag_kmaj(Qi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
                           frag_nat<T>(St, SPIT, lane & 15, sl, lane));
+                o = o * hs;
                 if (j < L) store4(dq_base + (size_t)j * ld + H + dt * 16 + (lane >> 4) * 4, o);
                 if (j < L) ck[dt] += o;
             }
@@ -329,60 +338,60 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
 
 // =============================================================================================== host
 template <class T, int LP, int NW>
-static int launch_fwd(const void* qkv, const int64_t* mask, void* ctx, float* probs, int B, int L, int nh, DropKey drop,
-                      hipStream_t st) {
-    hipLaunchKernelGGL((attn_fwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, mask, (T*)ctx, probs, L,
-                       nh, drop);
+static int launch_fwd(const void* qkv, const int64_t* mask, void* ctx, float* probs, const float* hsc, int B, int L, int nh,
+                      DropKey drop, hipStream_t st) {
+    hipLaunchKernelGGL((attn_fwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, mask, (T*)ctx, probs, hsc,
+                       L, nh, drop);
     return (int)hipGetLastError();
 }
 template <class T, int LP, int NW>
-static int launch_bwd(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, float* dbias, int B, int L, int nh,
-                      DropKey drop, hipStream_t st) {
+static int launch_bwd(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, float* dbias, const float* hsc, int B,
+                      int L, int nh, DropKey drop, hipStream_t st) {
     hipLaunchKernelGGL((attn_bwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, mask,
-                       (const T*)dctx, (T*)dqkv, dbias, L, nh, drop);
+                       (const T*)dctx, (T*)dqkv, dbias, hsc, L, nh, drop);
     return (int)hipGetLastError();
 }
 
 int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx, int B, int L, int nh, DropKey drop,
-                      hipStream_t st, float* probs) {
+                      hipStream_t st, float* probs, const float* head_scale) {
     if (L < 1 || L > 128) return MB_ERR_SHAPE;
     const int LP = (L + 31) / 32 * 32;
     if (dtype == DT_BF16) {
         switch (LP) {
-            case 32: return launch_fwd<bf16, 32, 2>(qkv, mask, ctx, probs, B, L, nh, drop, st);
-            case 64: return launch_fwd<bf16, 64, 4>(qkv, mask, ctx, probs, B, L, nh, drop, st);
-            case 96: return launch_fwd<bf16, 96, 4>(qkv, mask, ctx, probs, B, L, nh, drop, st);
-            default: return launch_fwd<bf16, 128, 4>(qkv, mask, ctx, probs, B, L, nh, drop, st);
+            case 32: return launch_fwd<bf16, 32, 2>(qkv, mask, ctx, probs, head_scale, B, L, nh, drop, st);
+            case 64: return launch_fwd<bf16, 64, 4>(qkv, mask, ctx, probs, head_scale, B, L, nh, drop, st);
+            case 96: return launch_fwd<bf16, 96, 4>(qkv, mask, ctx, probs, head_scale, B, L, nh, drop, st);
+            default: return launch_fwd<bf16, 128, 4>(qkv, mask, ctx, probs, head_scale, B, L, nh, drop, st);
         }
     } else if (dtype == DT_F32) {
         switch (LP) {
-            case 32: return launch_fwd<float, 32, 2>(qkv, mask, ctx, probs, B, L, nh, drop, st);
-            case 64: return launch_fwd<float, 64, 4>(qkv, mask, ctx, probs, B, L, nh, drop, st);
-            case 96: return launch_fwd<float, 96, 4>(qkv, mask, ctx, probs, B, L, nh, drop, st);
-            default: return launch_fwd<float, 128, 4>(qkv, mask, ctx, probs, B, L, nh, drop, st);
+            case 32: return launch_fwd<float, 32, 2>(qkv, mask, ctx, probs, head_scale, B, L, nh, drop, st);
+            case 64: return launch_fwd<float, 64, 4>(qkv, mask, ctx, probs, head_scale, B, L, nh, drop, st);
+            case 96: return launch_fwd<float, 96, 4>(qkv, mask, ctx, probs, head_scale, B, L, nh, drop, st);
+            default: return launch_fwd<float, 128, 4>(qkv, mask, ctx, probs, head_scale, B, L, nh, drop, st);
         }
     }
     return MB_ERR_DTYPE;
 }
 
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx, void* dqkv,
-                       float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st) {
+                       float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale) {
     (void)ctx;   // D_i is recomputed as sum_j dP_ij P_ij, the forward output is not needed
     if (L < 1 || L > 128) return MB_ERR_SHAPE;
     const int LP = (L + 31) / 32 * 32;
     if (dtype == DT_BF16) {
         switch (LP) {
-            case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
-            case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
-            case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
-            default: return launch_bwd<bf16, 128, 4>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
+            case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
+            case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
+            case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
+            default: return launch_bwd<bf16, 128, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
         }
     } else if (dtype == DT_F32) {
         switch (LP) {
-            case 32: return launch_bwd<float, 32, 2>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
-            case 64: return launch_bwd<float, 64, 4>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
-            case 96: return launch_bwd<float, 96, 2>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);
-            default: return launch_bwd<float, 128, 2>(qkv, mask, dctx, dqkv, dbias, B, L, nh, drop, st);   // 2 waves: LDS budget
+            case 32: return launch_bwd<float, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
+            case 64: return launch_bwd<float, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
+            case 96: return launch_bwd<float, 96, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
+            default: return launch_bwd<float, 128, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);   // 2 waves: LDS budget
         }
     }
     return MB_ERR_DTYPE;

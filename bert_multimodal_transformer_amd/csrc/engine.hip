@@ -52,6 +52,9 @@ struct mb_bert_engine : StepMixin {
     bool prof = false;             // mb_bert_set_profiling: timing events around every grouped wgrad launch (on the side stream)
     std::vector<hipEvent_t> pev;   // [2 * num_layers]
     float* attn_out = nullptr;     // mb_bert_set_attention_output: [num_layers][B][nh][L][L] fp32, filled by the next forwards
+    const float* head_mask = nullptr;   // mb_bert_set_head_mask: [num_layers][num_heads] fp32 (caller-owned device memory)
+    const float* emb_in = nullptr;      // mb_bert_set_inputs_embeds: [B*L][H] fp32 word embeddings given instead of input_ids
+    bool ran_forward = false;
     bool ws_zeroed = false;
     uint64_t seed = 0, step = 0;
     float* logits = nullptr;
@@ -397,15 +400,16 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     const mb_bert_config& c = e->c;
     if (!e->P || !e->ws) return MB_ERR_ARG;
     if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
-    if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !logits) return MB_ERR_ARG;
+    if ((!input_ids && !e->emb_in) || !visual || !acoustic || !attention_mask || !token_type_ids || !logits) return MB_ERR_ARG;
     const int dt = c.dtype, H = c.hidden_size, I = c.intermediate_size, T = B * L, nh = c.num_heads;
-    e->ids = input_ids; e->seg = token_type_ids; e->mask = attention_mask;
+    if (e->emb_in) input_ids = nullptr;           // inputs_embeds given: the word-table gather (and its gradient scatter) is skipped
+    e->ids = input_ids; e->seg = token_type_ids; e->mask = attention_mask; e->ran_forward = true;
     e->B = B; e->L = L; e->training = training; e->seed = seed; e->step = step; e->logits = logits;
     float* P = e->P;
     char* ws = e->ws;
     if (!e->capturing) CK(prepare_pass(e, T, st));
     // embeddings (bert.py:211-216)
-    CK(embed_ln_forward(dt, input_ids, token_type_ids, P + e->word, P + e->pos, P + e->type, P + e->emb_lnw, P + e->emb_lnb,
+    CK(embed_ln_forward(dt, input_ids, token_type_ids, e->emb_in ? e->emb_in : P + e->word, P + e->pos, P + e->type, P + e->emb_lnw, P + e->emb_lnb,
                         c.layer_norm_eps, ws + e->ws_emb, (float*)(ws + e->ws_emb_st), (float*)(ws + e->ws_emb_st) + T, B, L,
                         H, e->key(SITE_EMB, c.hidden_dropout), st));
     // MAG (bert.py:219): packed weights are refreshed every pass (5.5 MB, one launch) so optimizer steps are seen
@@ -422,7 +426,8 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
                 nullptr, 0, kNoDrop, 1, 0, st));
         CK(attention_forward(dt, ws + w.qkv, attention_mask, ws + w.ctx, B, L, nh,
                              e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st,
-                             e->attn_out ? e->attn_out + (size_t)l * B * nh * L * L : nullptr));
+                             e->attn_out ? e->attn_out + (size_t)l * B * nh * L * L : nullptr,
+                             e->head_mask ? e->head_mask + (size_t)l * nh : nullptr));
         CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, T, H, H, ws + w.ctx, H, e->W(o.wo), H, ws + w.s1, H, nullptr, nullptr,
                 P + o.bo, x, H, e->key(SITE_LAYER0 + 4 * l + 1, c.hidden_dropout), 1, 0, st));
         CK(ln_forward(dt, ws + w.s1, P + o.ln1w, P + o.ln1b, c.layer_norm_eps, ws + w.y1, (float*)(ws + w.st1),
@@ -448,7 +453,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                      int stage_end, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const mb_bert_config& c = e->c;
-    if (!e->G || !e->ids) return MB_ERR_ARG;
+    if (!e->G || !e->ran_forward) return MB_ERR_ARG;
     const int dt = c.dtype, H = c.hidden_size, I = c.intermediate_size, B = e->B, L = e->L, T = B * L, nh = c.num_heads;
     const int NL = c.num_layers;
     const int Tk = (int)align_up((size_t)T, 64);      // zero-padded reduction length of the wgrad GEMMs
@@ -540,7 +545,8 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                     nullptr, 0, kNoDrop, 1, 0, st));
             // attention backward; the fused-QKV bias gradient (column sums of dqkv) is accumulated inside the kernel
             CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, dqkv, G + o.bqkv, B, L, nh,
-                                  e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st));
+                                  e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st,
+                                  e->head_mask ? e->head_mask + (size_t)l * nh : nullptr));
             auto launch_group = [&]() -> int {
                 if (inl) {
                     if (e->prof) CK((int)hipEventRecord(e->pev[2 * l], st));
@@ -579,9 +585,9 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                             nullptr, G + e->mag_whv, G + e->mag_bhv, G + e->mag_wha, G + e->mag_bha, G + e->mag_wv,
                             G + e->mag_bv, G + e->mag_wa, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb, T, H, c.visual_dim,
                             c.acoustic_dim, true, st));
-            CK(embed_ln_backward(dt, de, e->ids, e->seg, P + e->word, P + e->pos, P + e->type, P + e->emb_lnw,
+            CK(embed_ln_backward(dt, de, e->ids, e->seg, e->ids ? P + e->word : e->emb_in, P + e->pos, P + e->type, P + e->emb_lnw,
                                  (const float*)(ws + e->ws_emb_st), (const float*)(ws + e->ws_emb_st) + T,
-                                 (float*)(ws + e->ws_dsum), G + e->word, G + e->pos, G + e->type, G + e->emb_lnw,
+                                 (float*)(ws + e->ws_dsum), e->ids ? G + e->word : nullptr, G + e->pos, G + e->type, G + e->emb_lnw,
                                  G + e->emb_lnb, B, L, H, c.pad_token_id, e->key(SITE_EMB, c.hidden_dropout), st));
         }
     }
@@ -601,6 +607,7 @@ static int enqueue_step(mb_bert_engine* e, int B, int L, float* logits, float* l
     float* keep_attn = e->attn_out;
     e->attn_out = nullptr;                      // optional outputs belong to explicit forwards, never to a (captured) training step
     struct Restore { mb_bert_engine* e; float* p; ~Restore() { e->attn_out = p; } } restore{e, keep_attn};
+    if (e->head_mask || e->emb_in) return MB_ERR_MODE;     // head_mask / inputs_embeds are arguments of explicit forwards only
     CK(mb_bert_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
                        (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
                        loss_run, st));
@@ -698,9 +705,23 @@ int mb_bert_set_attention_output(mb_bert_engine* e, float* probs) {
     e->attn_out = probs;
     return MB_OK;
 }
+int mb_bert_set_head_mask(mb_bert_engine* e, const float* head_mask) {
+    if (!e) return MB_ERR_ARG;
+    e->head_mask = head_mask;
+    return MB_OK;
+}
+int mb_bert_set_inputs_embeds(mb_bert_engine* e, const float* inputs_embeds) {
+    if (!e) return MB_ERR_ARG;
+    e->emb_in = inputs_embeds;
+    return MB_OK;
+}
+const float* mb_bert_inputs_embeds_grad(const mb_bert_engine* e) {
+    if (!e || !e->ws || !e->ran_forward) return nullptr;
+    return (const float*)(e->ws + e->ws_dsum);
+}
 int mb_bert_backward_outputs(mb_bert_engine* e, const void* d_sequence_output, const void* d_pooler_preact, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (!e || !e->G || !e->ids) return MB_ERR_ARG;
+    if (!e || !e->G || !e->ran_forward) return MB_ERR_ARG;
     const mb_bert_config& c = e->c;
     const int dt = c.dtype, H = c.hidden_size, B = e->B, L = e->L, T = B * L, NL = c.num_layers;
     char* ws = e->ws;

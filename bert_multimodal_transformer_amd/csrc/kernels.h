@@ -121,12 +121,14 @@ int mag_gate_backward(int dtype, const void* dout, const void* e, const void* Ze
 // ------------------------------------------------------------------------------------------ attention (attention.hip)
 // qkv: [B*L][3H] token-major (q | k | v, head h at columns h*64..), mask: int64 [B][L] (1 = attend),
 // ctx: [B*L][H].  softmax(QK^T/sqrt(dh) + (1-mask)*-10000) -> dropout -> . V   (dh = 64, L <= 128)
-// probs (fp32 [B][nh][L][L], may be null): the attention probabilities after dropout (output_attentions)
+// probs (fp32 [B][nh][L][L], may be null): the attention probabilities after dropout and head mask (output_attentions)
+// head_scale (fp32 [nh], may be null): head_mask of this layer -- the dropped probabilities of head h are multiplied by it
 int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx, int B, int L, int nh,
-                      DropKey drop, hipStream_t st, float* probs = nullptr);
+                      DropKey drop, hipStream_t st, float* probs = nullptr, const float* head_scale = nullptr);
 // dbias (fp32 [3H], may be null): += column sums of dqkv (bias grads of the fused QKV Linear)
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx,
-                       void* dqkv, float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st);
+                       void* dqkv, float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st,
+                       const float* head_scale = nullptr);
 
 // ------------------------------------------------------------------------------------------ XLNet (xlnet_attention.hip, xlnet_rowops.hip)
 // relative attention core, L <= 64.  qkv [T][3H] token-major, kr [B][2L][H], psave/gsave [B][nh][L][L].

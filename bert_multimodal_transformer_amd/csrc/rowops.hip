@@ -194,7 +194,8 @@ __global__ void __launch_bounds__(256) embed_fwd_kernel(const int64_t* __restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
-    const size_t id = (size_t)ids[row], sg = (size_t)seg[row], l = (size_t)(row % L);
+    // ids == nullptr: inputs_embeds (bert.py:185-195) -- `word` is then the [rows][H] fp32 embedding of each token itself
+    const size_t id = ids ? (size_t)ids[row] : (size_t)row, sg = (size_t)seg[row], l = (size_t)(row % L);
     f32x4 v[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -238,7 +239,7 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
     for (int i = 0; i < RPW; ++i) {
         const int row = (blockIdx.x * 4 + wave) * RPW + i;
         if (row >= rows) break;
-        const size_t id = (size_t)ids[row], sg = (size_t)seg[row], l = (size_t)(row % L);
+        const size_t id = ids ? (size_t)ids[row] : (size_t)row, sg = (size_t)seg[row], l = (size_t)(row % L);
         const float mu = mean[row], rs = rstd[row];
         f32x4 dyv[CH], xh[CH], gg[CH];
         float s1 = 0.f, s2 = 0.f;
@@ -264,7 +265,8 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
             const int col = (c * 64 + lane) * 4;
             const f32x4 d = (dyv[c] * gg[c] - m1 - xh[c] * m2) * rs;
             *(f32x4*)(dsum_ws + (size_t)row * H + col) = d;
-            if ((int)id != pad_id) {      // nn.Embedding(padding_idx=pad_token_id): no gradient for the pad row
+            // dword == nullptr (inputs_embeds): the gradient of the given embeddings is dsum_ws itself
+            if (dword != nullptr && (int)id != pad_id) {      // nn.Embedding(padding_idx=pad_token_id): no gradient for the pad row
 #pragma unroll
                 for (int r = 0; r < 4; ++r) atomicAdd(dword + id * H + col + r, d[r]);
             }

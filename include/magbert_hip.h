@@ -155,6 +155,17 @@ const float* mb_bert_pooled_output(const mb_bert_engine* e);    /* [B][H] fp32 (
  * dropout (what BertSelfAttention returns with output_attentions) to probs [num_layers][B][nh][L][L] fp32; NULL turns it off. */
 const void* mb_bert_hidden_state(const mb_bert_engine* e, int i);
 int mb_bert_set_attention_output(mb_bert_engine* e, float* probs);
+/* Optional INPUTS of MAG_BertModel.forward (bert.py:160, 185-209).  Both are sticky until reset with NULL, apply to
+ * mb_bert_forward / mb_bert_backward only (mb_bert_train_step returns MB_ERR_MODE while one is set), and point at caller-owned
+ * device memory that must stay valid through the backward.
+ * set_head_mask: fp32 [num_layers][num_heads]; the attention probabilities of head h in layer l are multiplied by
+ *   head_mask[l][h] after dropout (BertSelfAttention; what get_head_mask broadcasts a 1-D or 2-D mask to).
+ * set_inputs_embeds: fp32 [B*L][H] word embeddings used instead of the word_embeddings[input_ids] gather (input_ids may then
+ *   be NULL); the word table receives no gradient, and after the backward inputs_embeds_grad returns the gradient of the
+ *   given embeddings, fp32 [B*L][H] (workspace memory, valid until the next backward). */
+int mb_bert_set_head_mask(mb_bert_engine* e, const float* head_mask);
+int mb_bert_set_inputs_embeds(mb_bert_engine* e, const float* inputs_embeds);
+const float* mb_bert_inputs_embeds_grad(const mb_bert_engine* e);
 /* Backward entry of the BASE model, for heads that live outside the engine: replaces stage 0 of mb_bert_backward.
  * d_sequence_output [B*L][H] (dtype; NULL = zero) is the gradient of outputs[0]; d_pooler_preact [B][H] (dtype; NULL = the
  * pooled output is unused) is the gradient of the pooler's PRE-activation, i.e. d_pooled * (1 - pooled^2) (pooled =

@@ -96,10 +96,12 @@ class BertEmbeddings(nn.Module):
         self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
         self.dropout = nn.Dropout(c.hidden_dropout_prob)
 
-    def forward(self, input_ids, token_type_ids):
-        L = input_ids.shape[1]
-        pos = torch.arange(L, dtype=torch.long, device=input_ids.device).unsqueeze(0).expand_as(input_ids)
-        e = self.word_embeddings(input_ids) + self.position_embeddings(pos) + self.token_type_embeddings(token_type_ids)
+    def forward(self, input_ids, token_type_ids, inputs_embeds=None):
+        # inputs_embeds (bert.py:211-216 passes it through): used in place of word_embeddings(input_ids)
+        L = token_type_ids.shape[1]
+        pos = torch.arange(L, dtype=torch.long, device=token_type_ids.device).unsqueeze(0).expand_as(token_type_ids)
+        words = self.word_embeddings(input_ids) if inputs_embeds is None else inputs_embeds
+        e = words + self.position_embeddings(pos) + self.token_type_embeddings(token_type_ids)
         return self.dropout(self.LayerNorm(e))
 
 
@@ -119,11 +121,14 @@ class BertSelfAttention(nn.Module):
         B, L, _ = x.shape
         return x.view(B, L, self.nh, self.dh).permute(0, 2, 1, 3)
 
-    def forward(self, x, ext_mask):
+    def forward(self, x, ext_mask, head_mask=None):
         q, k, v = self._split(self.query(x)), self._split(self.key(x)), self._split(self.value(x))
         s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(self.dh)
         s = s + ext_mask
         p = self.dropout(F.softmax(s, dim=-1))
+        if head_mask is not None:          # 3.0.2: attention_probs = attention_probs * head_mask, after the dropout
+            p = p * head_mask
+        self.last_probs = p                # what output_attentions returns
         ctx = torch.matmul(p, v).permute(0, 2, 1, 3).contiguous()
         return ctx.view(x.shape[0], x.shape[1], self.nh * self.dh)
 
@@ -145,8 +150,8 @@ class BertAttention(nn.Module):
         self.self = BertSelfAttention(c)
         self.output = BertSelfOutput(c)
 
-    def forward(self, x, ext_mask):
-        return self.output(self.self(x, ext_mask), x)
+    def forward(self, x, ext_mask, head_mask=None):
+        return self.output(self.self(x, ext_mask, head_mask), x)
 
 
 class BertIntermediate(nn.Module):
@@ -176,8 +181,8 @@ class BertLayer(nn.Module):
         self.intermediate = BertIntermediate(c)
         self.output = BertOutput(c)
 
-    def forward(self, x, ext_mask):
-        a = self.attention(x, ext_mask)
+    def forward(self, x, ext_mask, head_mask=None):
+        a = self.attention(x, ext_mask, head_mask)
         return self.output(self.intermediate(a), a)
 
 
@@ -186,9 +191,9 @@ class BertEncoder(nn.Module):
         super().__init__()
         self.layer = nn.ModuleList([BertLayer(c) for _ in range(c.num_hidden_layers)])
 
-    def forward(self, x, ext_mask):
-        for lyr in self.layer:
-            x = lyr(x, ext_mask)
+    def forward(self, x, ext_mask, head_mask=None):
+        for i, lyr in enumerate(self.layer):
+            x = lyr(x, ext_mask, None if head_mask is None else head_mask[i])
         return x
 
 
@@ -215,16 +220,25 @@ class MAG_BertModel(nn.Module):
         self.MAG = MAG(config.hidden_size, multimodal_config.beta_shift, multimodal_config.dropout_prob,
                        visual_dim, acoustic_dim)                 # bert.py:84-88
 
-    def forward(self, input_ids, visual, acoustic, attention_mask=None, token_type_ids=None):
+    def forward(self, input_ids, visual, acoustic, attention_mask=None, token_type_ids=None, head_mask=None,
+                inputs_embeds=None):
+        shape = input_ids.shape if input_ids is not None else inputs_embeds.shape[:-1]      # bert.py:158-168
+        dev = visual.device
         if attention_mask is None:
-            attention_mask = torch.ones_like(input_ids)          # bert.py:173-174
+            attention_mask = torch.ones(shape, dtype=torch.long, device=dev)     # bert.py:173-174
         if token_type_ids is None:
-            token_type_ids = torch.zeros_like(input_ids)         # bert.py:175-177
+            token_type_ids = torch.zeros(shape, dtype=torch.long, device=dev)    # bert.py:175-177
+        if head_mask is not None:
+            # 3.0.2 get_head_mask (bert.py:206-207): [nh] -> every layer, [NL][nh] as is; broadcast over [B][nh][L][L]
+            head_mask = head_mask.to(torch.float32)
+            if head_mask.dim() == 1:
+                head_mask = head_mask[None].expand(self.config.num_hidden_layers, -1)
+            head_mask = head_mask[:, None, :, None, None]
         # 3.0.2 get_extended_attention_mask (bert.py:180-182): (1 - mask)[:,None,None,:] * -10000.0
         ext = (1.0 - attention_mask[:, None, None, :].to(torch.float32)) * -10000.0
-        emb = self.embeddings(input_ids, token_type_ids)         # bert.py:211-216
+        emb = self.embeddings(input_ids, token_type_ids, inputs_embeds)     # bert.py:211-216
         fused = self.MAG(emb, visual, acoustic)                  # bert.py:219
-        seq = self.encoder(fused, ext)                           # bert.py:221-229
+        seq = self.encoder(fused, ext, head_mask)                # bert.py:221-229
         pooled = self.pooler(seq)                                # bert.py:231
         return seq, pooled
 
@@ -239,8 +253,9 @@ class MAG_BertForSequenceClassification(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)               # bert.py:246
         self.classifier = nn.Linear(config.hidden_size, config.num_labels)  # bert.py:247
 
-    def forward(self, input_ids, visual, acoustic, attention_mask=None, token_type_ids=None, labels=None):
-        seq, pooled = self.bert(input_ids, visual, acoustic, attention_mask, token_type_ids)
+    def forward(self, input_ids, visual, acoustic, attention_mask=None, token_type_ids=None, labels=None, head_mask=None,
+                inputs_embeds=None):
+        seq, pooled = self.bert(input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask, inputs_embeds)
         logits = self.classifier(self.dropout(pooled))                      # bert.py:304-307
         outputs = (logits,)
         if labels is not None:                                              # bert.py:313-322

@@ -233,16 +233,11 @@ def test_optional_outputs_and_trainable_base_model_fp32():
     b = weights.synthetic_bert_batch(B, L, 47, 74, seed=81)
     ids, vis, aco, mask, seg, lab = tb(b, DEV)
     i2, v2, a2, m2, s2, l2 = tb(b)
-    ref_h, ref_p = [], []
+    ref_h = []
     hooks = [o.bert.encoder.register_forward_pre_hook(lambda mod, args: ref_h.append(args[0].detach()))]
     for lyr in o.bert.encoder.layer:
         hooks.append(lyr.register_forward_hook(lambda mod, args, out: ref_h.append(out.detach())))
 
-        def probs(mod, args):
-            x, ext = args
-            q, k = mod._split(mod.query(x)), mod._split(mod.key(x))
-            ref_p.append(torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / 8.0 + ext, dim=-1).detach())
-        hooks.append(lyr.attention.self.register_forward_pre_hook(probs))
     base.train()
     seq, pooled, hs, att = base(ids, vis, aco, attention_mask=mask, token_type_ids=seg, output_hidden_states=True, output_attentions=True)
     assert seq.requires_grad and pooled.requires_grad
@@ -254,6 +249,7 @@ def test_optional_outputs_and_trainable_base_model_fp32():
     (((so * w_seq.cpu()).sum(-1).mean()) + 3.0 * (po * w_pool.cpu()).sum(-1).mean()).backward()
     for h in hooks:
         h.remove()
+    ref_p = [lyr.attention.self.last_probs.detach() for lyr in o.bert.encoder.layer]       # dropout p = 0: the softmax itself
     torch.cuda.synchronize()
     assert float((seq.detach().cpu() - so.detach()).abs().max()) <= 1e-4 and float((pooled.detach().cpu() - po.detach()).abs().max()) <= 1e-4
     assert len(hs) == layers + 1 and len(att) == layers
@@ -279,9 +275,75 @@ def test_optional_outputs_and_trainable_base_model_fp32():
         assert float((h.cpu() - r).abs().max()) <= 1e-4
     # options that are not built raise instead of being ignored
     with pytest.raises(NotImplementedError):
-        m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, head_mask=torch.ones(12, device=DEV))
+        m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, position_ids=torch.arange(L, device=DEV).flip(0)[None].expand(B, L))
     with pytest.raises(NotImplementedError):
-        base(None, vis, aco, inputs_embeds=torch.zeros(B, L, 768, device=DEV))
+        base(ids, vis, aco, encoder_hidden_states=torch.zeros(B, L, 768, device=DEV))
+    m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, position_ids=torch.arange(L, device=DEV)[None].expand(B, L))   # the default is fine
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_head_mask_and_inputs_embeds_vs_oracle(cdt):
+    """f-4: the optional INPUTS of forward (bert.py:147-168, 206-216).  head_mask scales the attention probabilities of
+    (layer, head) AFTER the attention dropout (masks replayed in the oracle), inputs_embeds replaces the word-table gather and
+    receives its own gradient; the word table then gets none.  Logits, attention probabilities, every parameter gradient and
+    d(inputs_embeds) against the oracle; then the state does not leak into a plain forward or the single-call step."""
+    layers, B, L, V, nh, H = 2, 3, 24, 47, 12, 768
+    fp32 = cdt == torch.float32
+    torch.manual_seed(7)
+    m = build(V, layers, cdt, p_mag=0.0, hidden_p=0.0, attn_p=0.1).train()
+    o = R.set_dropout(oracle(V, layers, p_mag=0.0), 0.0, 0.1, 0.0).train()
+    core = m._core
+    b = weights.synthetic_bert_batch(B, L, V, 74, seed=43)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    i2, v2, a2, m2, s2, l2 = tb(b)
+    hm = torch.ones(layers, nh)
+    hm[0, 3] = 0.0; hm[0, 7] = 0.5; hm[1, 0] = 0.0; hm[1, 11] = 2.0
+    emb_cpu = (o.bert.embeddings.word_embeddings(i2).detach() + 0.05 * torch.from_numpy(weights.make_param("probe.emb", (B, L, H), "test"))).requires_grad_(True)
+    emb = emb_cpu.detach().to(DEV).requires_grad_(True)
+    out = m(None, vis, aco, token_type_ids=seg, attention_mask=mask, head_mask=hm.to(DEV), inputs_embeds=emb, output_attentions=True)
+    logits, att = out[0], out[1]
+    torch.nn.MSELoss()(logits.view(-1), lab.view(-1)).backward()
+    seed, step = core.seed, core.step
+    for l, lyr in enumerate(o.bert.encoder.layer):
+        lyr.attention.self.dropout = _Replay(torch.from_numpy(rng.keep_mult(B * nh * L * L, rng.make_key(seed, step, rng.SITE_LAYER0 + 4 * l, 0.1))))
+    lo = o(None, v2, a2, m2, s2, head_mask=hm, inputs_embeds=emb_cpu)[0]
+    torch.nn.functional.mse_loss(lo.view(-1), l2.view(-1)).backward()
+    torch.cuda.synchronize()
+    err = float((logits.detach().cpu() - lo.detach()).abs().max())
+    perr = max(float((att[l].cpu() - o.bert.encoder.layer[l].attention.self.last_probs.detach()).abs().max()) for l in range(layers))
+    ge = emb.grad.cpu() - emb_cpu.grad
+    gerr = float(ge.norm() / emb_cpu.grad.norm())
+    print("head_mask + inputs_embeds (%s): logits %.2e, probabilities %.2e, d(inputs_embeds) rel. Frobenius %.2e" % (cdt, err, perr, gerr))
+    assert err <= (1e-3 if fp32 else 1e-2)
+    assert perr <= (1e-5 if fp32 else 2e-2)
+    assert float(att[0][:, 3].abs().max()) == 0.0 and float(att[1][:, 0].abs().max()) == 0.0        # masked heads output zeros
+    assert gerr <= (2e-3 if fp32 else 3e-2)
+    word = dict(m.named_parameters())["bert.embeddings.word_embeddings.weight"]
+    assert float(word.grad.abs().max()) == 0.0 and o.bert.embeddings.word_embeddings.weight.grad is None
+    o.bert.embeddings.word_embeddings.weight.grad = torch.zeros_like(o.bert.embeddings.word_embeddings.weight)
+    _grad_report(m, o, 5e-3 if fp32 else 3e-2, frobenius=not fp32, loose=LOOSE_BF16 + ("classifier.bias",), tol_loose=1e-1, show=3)
+    # both arguments at once / neither: the reference's errors (bert.py:158-168)
+    with pytest.raises(ValueError):
+        m(ids, vis, aco, inputs_embeds=emb)
+    with pytest.raises(ValueError):
+        m(None, vis, aco)
+    with pytest.raises(NotImplementedError):
+        m(ids, vis, aco, head_mask=torch.ones(B, nh, device=DEV)[:, :5])
+    # nothing sticks: a plain eval forward equals a fresh model's, and the single-call step runs
+    m.eval()
+    o = oracle(V, layers, p_mag=0.0).eval()           # a fresh one: the mask-replay modules above multiply in eval mode too
+    with torch.no_grad():
+        plain = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0]
+        ref = o(i2, v2, a2, m2, s2)[0]
+        one = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, head_mask=hm[0].to(DEV))[0]          # 1-D: every layer
+        ref1 = o(i2, v2, a2, m2, s2, head_mask=hm[0])[0]
+    assert float((plain.cpu() - ref).abs().max()) <= (1e-3 if fp32 else 2e-2)
+    assert float((one.cpu() - ref1).abs().max()) <= (1e-3 if fp32 else 2e-2)
+    m.train()
+    m.zero_grad()
+    m.train_step(ids, vis, aco, mask, seg, lab, optimizer=None)
+    torch.cuda.synchronize()
+    assert float(word.grad.abs().max()) > 0.0
 
 
 def test_from_pretrained_maps_huggingface_checkpoints(tmp_path):
