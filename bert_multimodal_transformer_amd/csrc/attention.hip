@@ -45,9 +45,12 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
     const int H = nh * 64;
     const size_t ld = (size_t)3 * H;
     const T* base = qkv + (size_t)b * L * ld + h * 64;
-    stage_head<T, LP, NW * 64>(Qi, PIT, base, ld, L);
-    stage_head<T, LP, NW * 64>(Ki, PIT, base + H, ld, L);
-    stage_head<T, LP, NW * 64>(Vi, PIT, base + 2 * H, ld, L);
+    {
+        char* const img[3] = {Qi, Ki, Vi};
+        const T* const src[3] = {base, base + H, base + 2 * H};
+        const size_t lds[3] = {ld, ld, ld};
+        stage_heads<T, LP, NW * 64, 3>(img, PIT, src, lds, L);
+    }
     for (int j = threadIdx.x; j < LP; j += NW * 64)
         mbias[j] = j < L ? (1.0f - (float)mask[(size_t)b * L + j]) * kMaskNeg : kPadNeg;
     __syncthreads();
@@ -123,7 +126,12 @@ template <class T, int LP, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                            const T* __restrict__ dctx, T* __restrict__ dqkv,
                                                            float* __restrict__ dbias,
-                                                           const float* __restrict__ head_scale, int L, int nh, DropKey drop) {
+                                                           const float* __restrict__ head_scale, int L, int nh, DropKey drop,
+                                                           unsigned long long* __restrict__ trace) {
+    // MB_ATTN_TRACE=1: phase stamps of every block (100 MHz wall clock): 0 entry, 1 operands staged, 2 query sweep done,
+    // 3 dQ bias flushed, 4 key sweep done, 5 exit
+    auto stamp = [&](int k) { if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * 8 + k] = wall_clock64(); };
+    stamp(0);
     drop.resolve();
     typedef AttnCfg<T> C;
     constexpr int PIT = C::ROWB + 16;
@@ -131,7 +139,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
     constexpr int NT = LP / 16;
     constexpr int DSL = 64 / C::SLAB;
     constexpr int LSL = LP / C::SLAB;
-    __shared__ __attribute__((aligned(16))) char smem[4 * LP * PIT + NW * 16 * SPIT + 4 * LP * 4 + NW * 64 * 4];
+    __shared__ __attribute__((aligned(16))) char smem[4 * LP * PIT + NW * 16 * SPIT + 4 * LP * 4];
     char* Qi = smem;
     char* Ki = smem + LP * PIT;
     char* Vi = smem + 2 * LP * PIT;
@@ -141,17 +149,18 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
     float* rmax = mbias + LP;
     float* rinv = rmax + LP;
     float* rD = rinv + LP;
-    float* csum = rD + LP;                   // [NW][64] scratch for the fused QKV bias gradient (column sums of dqkv)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x / nh, h = blockIdx.x % nh;
     const int H = nh * 64;
     const size_t ld = (size_t)3 * H;
     const T* base = qkv + (size_t)b * L * ld + h * 64;
-    stage_head<T, LP, NW * 64>(Qi, PIT, base, ld, L);
-    stage_head<T, LP, NW * 64>(Ki, PIT, base + H, ld, L);
-    stage_head<T, LP, NW * 64>(Vi, PIT, base + 2 * H, ld, L);
-    stage_head<T, LP, NW * 64>(Oi, PIT, dctx + (size_t)b * L * H + h * 64, (size_t)H, L);
+    {
+        char* const img[4] = {Qi, Ki, Vi, Oi};
+        const T* const src[4] = {base, base + H, base + 2 * H, dctx + (size_t)b * L * H + h * 64};
+        const size_t lds[4] = {ld, ld, ld, (size_t)H};
+        stage_heads<T, LP, NW * 64, 4>(img, PIT, src, lds, L);
+    }
     for (int j = threadIdx.x; j < LP; j += NW * 64)
         mbias[j] = j < L ? (1.0f - (float)mask[(size_t)b * L + j]) * kMaskNeg : kPadNeg;
     // per-lane running column sums of the dQ / dK / dV tiles this wave produces (its own row only; rows >= L excluded);
@@ -159,26 +168,36 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
     f32x4 cq[4], ck[4], cv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) cq[dt] = ck[dt] = cv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float* csw = csum;                       // [NW][64] scratch, reused per flush
-    auto flush = [&](f32x4 (&c4)[4], int which) {    // called by every thread of the block (uniform)
+    // Fused QKV bias gradient: ONE reduction + one atomic per column per block, at the very end (the strips are free then).
+    // Flushed after each sweep, the barrier behind every batch of atomics waited for their round trip to L2 -- 8 of the 25 us
+    // of a launch (profiles/r02_attention_phases.txt).
+    auto flush_all = [&]() {                 // called by every thread of the block (uniform), after the last strip barrier
         if (dbias == nullptr) return;
+        float* csw = (float*)strips;         // [3][NW][64]
+        static_assert(NW * 16 * SPIT >= 3 * NW * 64 * 4, "the strip buffers hold the three column-sum tiles");
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int which = 0; which < 3; ++which) {
+            f32x4 (&c4)[4] = which == 0 ? cq : which == 1 ? ck : cv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float sred = group16_sum(c4[dt][r]);
-                if ((lane & 15) == 0) csw[wave * 64 + dt * 16 + (lane >> 4) * 4 + r] = sred;
-            }
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sred = row16_sum_to_lane15(c4[dt][r]);
+                    if ((lane & 15) == 15) csw[(which * NW + wave) * 64 + dt * 16 + (lane >> 4) * 4 + r] = sred;
+                }
+        }
+        stamp(6);
         __syncthreads();
-        for (int j = threadIdx.x; j < 64; j += NW * 64) {
+        for (int j = threadIdx.x; j < 192; j += NW * 64) {
+            const int which = j >> 6, col = j & 63;
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) t += csw[w * 64 + j];
-            atomicAdd(dbias + (size_t)which * H + h * 64 + j, t);
+            for (int w = 0; w < NW; ++w) t += csw[(which * NW + w) * 64 + col];
+            atomicAdd(dbias + (size_t)which * H + h * 64 + col, t);
         }
-        __syncthreads();
     };
     __syncthreads();
+    stamp(1);
 
     char* St = strips + wave * 16 * SPIT;
     const float scale = 0.125f;
@@ -258,7 +277,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
         __syncthreads();
     }
 
-    flush(cq, 0);
+    stamp(2);
+    stamp(3);
 
     // ------------------------------------------------------------------ sweep B: key strips -> dV, dK
     for (int s0 = 0; s0 < NT; s0 += NW) {
@@ -332,11 +352,31 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
         }
         __syncthreads();
     }
-    flush(ck, 1);
-    flush(cv, 2);
+    stamp(4);
+    flush_all();
+    stamp(5);
 }
 
 // =============================================================================================== host
+static unsigned long long* g_attn_trace = nullptr;      // MB_ATTN_TRACE=1 (measurement tooling): [blocks][8] stamps of the last backward
+static int g_attn_trace_on = -1, g_attn_trace_blocks = 0;
+static unsigned long long* attn_trace_buffer(int blocks) {
+    if (g_attn_trace_on < 0) {
+        const char* v = getenv("MB_ATTN_TRACE");
+        g_attn_trace_on = v ? atoi(v) : 0;
+        if (g_attn_trace_on && hipMalloc(&g_attn_trace, (size_t)8192 * 8 * sizeof(unsigned long long)) != hipSuccess) g_attn_trace_on = 0;
+    }
+    if (!g_attn_trace_on || blocks > 8192) return nullptr;
+    g_attn_trace_blocks = blocks;
+    return g_attn_trace;
+}
+int attention_trace_fetch(unsigned long long* host_out, int max_blocks) {
+    if (!g_attn_trace || !host_out) return 0;
+    const int n = g_attn_trace_blocks < max_blocks ? g_attn_trace_blocks : max_blocks;
+    if (hipDeviceSynchronize() != hipSuccess) return 0;
+    if (hipMemcpy(host_out, g_attn_trace, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
 template <class T, int LP, int NW>
 static int launch_fwd(const void* qkv, const int64_t* mask, void* ctx, float* probs, const float* hsc, int B, int L, int nh,
                       DropKey drop, hipStream_t st) {
@@ -348,7 +388,7 @@ template <class T, int LP, int NW>
 static int launch_bwd(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, float* dbias, const float* hsc, int B,
                       int L, int nh, DropKey drop, hipStream_t st) {
     hipLaunchKernelGGL((attn_bwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, mask,
-                       (const T*)dctx, (T*)dqkv, dbias, hsc, L, nh, drop);
+                       (const T*)dctx, (T*)dqkv, dbias, hsc, L, nh, drop, attn_trace_buffer(B * nh));
     return (int)hipGetLastError();
 }
 
@@ -384,7 +424,7 @@ int attention_backward(int dtype, const void* qkv, const int64_t* mask, const vo
             case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
             case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
             case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
-            default: return launch_bwd<bf16, 128, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
+            default: return launch_bwd<bf16, 128, 8>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);   // 8 waves: all eight strips of a sweep at once
         }
     } else if (dtype == DT_F32) {
         switch (LP) {

@@ -38,6 +38,30 @@ __device__ __forceinline__ void stage_head(char* img, int pitch, const T* __rest
     }
 }
 
+// The same for N heads at once, every global load issued before the first LDS store: staged one after the other, each image
+// was its own memory round trip (measured: 3.5 us of a 17 us attention backward before the first MFMA).
+template <class T, int LP, int NTHR, int N>
+__device__ __forceinline__ void stage_heads(char* const (&img)[N], int pitch, const T* const (&src)[N], const size_t (&ld)[N], int L) {
+    constexpr int CPR = AttnCfg<T>::ROWB / 16;
+    constexpr int IT = (LP * CPR + NTHR - 1) / NTHR;
+    u32x4 v[N][IT];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int id = threadIdx.x + it * NTHR, row = id / CPR, c = id % CPR;
+            v[n][it] = u32x4{0u, 0u, 0u, 0u};
+            if (id < LP * CPR && row < L) v[n][it] = *(const u32x4*)((const char*)(src[n] + (size_t)row * ld[n]) + c * 16);
+        }
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int id = threadIdx.x + it * NTHR, row = id / CPR, c = id % CPR;
+            if (id < LP * CPR) *(u32x4*)(img[n] + row * pitch + c * 16) = v[n][it];
+        }
+}
+
 // row-wise reduction across the 4 lanes {i, i+16, i+32, i+48} that share a query/key row
 __device__ __forceinline__ float quad_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 16, 64));

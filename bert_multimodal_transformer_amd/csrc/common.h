@@ -63,10 +63,20 @@ __device__ __forceinline__ float drop_mult(const DropKey& d, uint32_t idx) {
 }
 
 // ---------------------------------------------------------------- reductions
+// Sum over the 64 lanes, returned in every lane.  DPP adds (plain VALU): an inclusive scan inside each 16-lane row (row_shr
+// 1, 2, 4, 8), the row totals chained with row_bcast15 / row_bcast31, the grand total read from lane 63 -- seven instructions
+// instead of six ds_bpermute round trips through the LDS crossbar (the row kernels do one or two of these per row on their
+// critical path).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+#define MB_DPP(x, ctrl, rmask, bc) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rmask, 0xf, bc))
+    v += MB_DPP(v, 0x111, 0xf, true);       // row_shr:1
+    v += MB_DPP(v, 0x112, 0xf, true);       // row_shr:2
+    v += MB_DPP(v, 0x114, 0xf, true);       // row_shr:4
+    v += MB_DPP(v, 0x118, 0xf, true);       // row_shr:8   -> lane 15 of every row holds the row total
+    v += MB_DPP(v, 0x142, 0xa, false);      // row_bcast15 -> rows 1 and 3 add the total of the row before
+    v += MB_DPP(v, 0x143, 0xc, false);      // row_bcast31 -> rows 2 and 3 add lane 31 (rows 0 + 1): lane 63 holds everything
+#undef MB_DPP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -77,6 +87,18 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float group16_sum(float v) {
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// Sum over the 16 lanes of a DPP row (lanes that share lane >> 4), valid in lane 15 of the row only: an inclusive scan with four
+// v_add_f32 row_shr steps (out-of-row sources read 0) -- plain VALU, no LDS crossbar traffic like the ds_bpermute behind
+// __shfl_xor.  For reductions whose result one lane per row writes out.
+__device__ __forceinline__ float row16_sum_to_lane15(float v) {
+#define MB_ROW_SHR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + (n), 0xf, 0xf, true))
+    v += MB_ROW_SHR(v, 1);
+    v += MB_ROW_SHR(v, 2);
+    v += MB_ROW_SHR(v, 4);
+    v += MB_ROW_SHR(v, 8);
+#undef MB_ROW_SHR
     return v;
 }
 __device__ __forceinline__ float group16_max(float v) {
@@ -115,12 +137,35 @@ __device__ __forceinline__ void mma16(f32x4& acc, f32x4 x, f32x4 y) {
 __device__ __forceinline__ void gelu_parts(float x, float& Phi, float& e) {
     const float z = fabsf(x) * 0.70710678118654752f;
     e = __expf(-0.5f * x * x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);       // v_rcp_f32 (1 ulp); an IEEE division here is ten instructions
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float half_erfc = 0.5f * poly * e;            // 0.5 * erfc(|x| / sqrt 2)
     Phi = x >= 0.f ? 1.0f - half_erfc : half_erfc;
 }
 __device__ __forceinline__ float gelu_f(float x) { float P, e; gelu_parts(x, P, e); return x * P; }
 __device__ __forceinline__ float dgelu_f(float x) { float P, e; gelu_parts(x, P, e); return P + x * 0.39894228040143268f * e; }
+
+// Two elements per instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: packed fp32 runs at twice the scalar VALU rate;
+// only the two transcendentals and the sign transfer stay per element).  Same formula as gelu_parts, evaluated pairwise --
+// the GELU epilogue of the [T x 3072] GEMM was 9 us of VALU time per launch with the scalar form.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_pair(f32x2 x, f32x2& g, f32x2& dg) {
+    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    const f32x2 d = ax * 0.23164190455f + 1.0f;                 // 1 + p |x| / sqrt 2
+    const f32x2 q = x * x * -0.72134752044f;                    // -x^2 / 2 * log2(e)
+    const f32x2 e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+    const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    // 0.5 * (a1 t + ... + a5 t^5): the halved A&S coefficients
+    f32x2 poly = t * 0.5307027145f + -0.7265760135f;
+    poly = poly * t + 0.7107068705f;
+    poly = poly * t + -0.142248368f;
+    poly = poly * t + 0.127414796f;
+    const f32x2 h = poly * t * e;                               // 0.5 erfc(|x| / sqrt 2)
+    const f32x2 u = 0.5f - h;                                   // Phi = 0.5 + sign(x) (0.5 - h)
+    const f32x2 su = {__builtin_copysignf(u.x, x.x), __builtin_copysignf(u.y, x.y)};
+    const f32x2 Phi = su + 0.5f;
+    g = x * Phi;
+    dg = x * 0.39894228040143268f * e + Phi;
+}
 
 }  // namespace mb

@@ -234,6 +234,8 @@ int mb_gemm(int dtype, int layout, int epilogue, int M, int N, int K, const void
     return gemm_launch(dtype, layout, epilogue, a, splits, tile, (hipStream_t)stream);
 }
 
+int mb_debug_gemm_trace(unsigned long long* host_out, int max_blocks) { return gemm_trace_fetch(host_out, max_blocks); }
+int mb_debug_attention_trace(unsigned long long* host_out, int max_blocks) { return attention_trace_fetch(host_out, max_blocks); }
 int mb_gemm_grouped_wgrad(int dtype, int count, const int* M, const int* N, int K, const void* const* dY, const int* ldy,
                           const void* const* X, const int* ldx, float* const* dW, const int* ldw, int tile, void* stream) {
     if (count < 1 || count > MB_MAX_GROUP || !M || !N || !dY || !X || !dW || !ldy || !ldx || !ldw) return MB_ERR_ARG;
@@ -282,7 +284,17 @@ int mb_attention_forward(int dtype, const void* qkv, const int64_t* mask, void* 
 }
 int mb_attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L,
                           int nh, const mb_dropkey* drop, void* stream) {
-    return attention_backward(dtype, qkv, mask, nullptr, dctx, dqkv, nullptr, B, L, nh, dk(drop), (hipStream_t)stream);
+    // MB_ATTN_TRACE=1 (tools/attn_bench): the traced launch also produces the fused QKV bias gradient, as inside the engine
+    static float* trace_dbias = nullptr;
+    static int trace_on = -1;
+    if (trace_on < 0) {
+        const char* v = getenv("MB_ATTN_TRACE");
+        trace_on = v ? atoi(v) : 0;
+        if (trace_on && (hipMalloc(&trace_dbias, (size_t)3 * 64 * 64 * sizeof(float)) != hipSuccess ||
+                         hipMemset(trace_dbias, 0, (size_t)3 * 64 * 64 * sizeof(float)) != hipSuccess)) trace_dbias = nullptr;
+    }
+    return attention_backward(dtype, qkv, mask, nullptr, dctx, dqkv, (trace_on && nh <= 64) ? trace_dbias : nullptr, B, L, nh, dk(drop),
+                              (hipStream_t)stream);
 }
 
 size_t mb_mag_workspace_bytes(int dtype, int T, int H, int V, int A) {

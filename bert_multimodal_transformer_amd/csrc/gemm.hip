@@ -146,17 +146,52 @@ template <> struct Vec8<float> {
     }
 };
 
+// What an epilogue reads from global memory -- the residual / gelu' rows of this thread, the bias, the dropout key of a
+// replayed step graph -- is requested BEFORE the k loop (EpiPre::fetch): issued inside the row pass, each of these loads was a
+// full memory round trip on the critical path of a tile whose MFMA work is already over (measured per launch: 1.7 us for the
+// residual epilogues, 6 us for the gelu' one, whose rows were read two at a time).  bf16 only: eight fp32 rows would be 64 VGPRs.
+template <class T, int BM, int BN, int MODE, int NW>
+struct EpiPre {
+    static constexpr int TPR = BN / 8;                    // threads per row in the row-major pass
+    static constexpr int RPP = NW * 64 / TPR;             // rows per pass
+    static constexpr int NR = BM / RPP;                   // rows per thread
+    static constexpr bool HAS_R = sizeof(T) == 2 && (MODE == EPI_BIAS_DROP_RES || MODE == EPI_ADD_RES || MODE == EPI_DGELU);
+    bf16x8 r[HAS_R ? NR : 1];
+    float bias8[8];
+    DropKey key;
+    __device__ __forceinline__ void fetch(const GemmArgs& p, int m0, int n0, int tid) {
+        key = p.drop;
+        key.resolve();
+        const int n = n0 + (tid % TPR) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bias8[q] = 0.f;
+        if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_F32 || MODE == EPI_BIAS_GELU || MODE == EPI_BIAS_DROP_RES) {
+            if (p.bias && n < p.N) Vec8<float>::load(p.bias + n, bias8);
+        }
+        if constexpr (HAS_R) {
+#pragma unroll
+            for (int it = 0; it < NR; ++it) {
+                const int m = m0 + tid / TPR + it * RPP;
+                r[it] = bf16x8{};
+                if (p.R && m < p.M && n < p.N) r[it] = *(const bf16x8*)((const bf16*)p.R + (size_t)m * p.ldr + n);
+            }
+        }
+    }
+};
+
 // KS (k-split waves): every wave holds a partial sum of the WHOLE tile (its quarter of every k-stage); the four partial tiles
 // are staged side by side and added in the row-major pass.
-template <class T, int BM, int BN, int MODE, bool KS>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS ? BM / 16 : BM / 32][KS ? BN / 16 : BN / 32],
-                                              int m0, int n0, int wave, int lane, char* smem) {
-    constexpr int MT = KS ? BM / 16 : BM / 32, NT = KS ? BN / 16 : BN / 32;
+template <class T, int BM, int BN, int MODE, bool KS, int NW = 4>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS ? BM / 16 : BM / (8 * NW)][KS ? BN / 16 : BN / 32],
+                                              int m0, int n0, int wave, int lane, char* smem,
+                                              const EpiPre<T, BM, BN, MODE, NW>& pre) {
+    typedef EpiPre<T, BM, BN, MODE, NW> Pre;
+    constexpr int WM = NW / 2;                      // waves along m (each wave: BM / WM rows x BN / 2 columns)
+    constexpr int MT = KS ? BM / 16 : BM / (16 * WM), NT = KS ? BN / 16 : BN / 32;
     constexpr int RBY = BN * 4;                     // staged row bytes (fp32)
     constexpr int REG = BM * RBY;                   // one staged tile
     constexpr int NSUM = KS ? 4 : 1;
-    constexpr int TPR = BN / 8;                     // threads per row in the row-major pass
-    constexpr int RPP = 256 / TPR;                  // rows per pass
+    constexpr int TPR = Pre::TPR, RPP = Pre::RPP, NR = Pre::NR;
     const int wr = KS ? 0 : (wave >> 1), wc = KS ? 0 : (wave & 1);
     char* stage = smem + (KS ? wave * REG : 0);
     __syncthreads();                                // every wave is done with the operand stages
@@ -164,7 +199,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int r = wr * (BM / 2) + i * 16 + (lane & 15);
+            const int r = wr * (BM / WM) + i * 16 + (lane & 15);
             const int ch = (wc * (BN / 2) + j * 16 + (lane >> 4) * 4) >> 2;
             *(f32x4*)(stage + r * RBY + ((ch ^ (r & 7)) << 4)) = acc[i][j];
         }
@@ -173,15 +208,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
     const int c = (tid % TPR) * 8;
     const int n = n0 + c;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_F32 || MODE == EPI_BIAS_GELU || MODE == EPI_BIAS_DROP_RES) {
-        if (p.bias && n < p.N) Vec8<float>::load(p.bias + n, bias8);
-    }
+    const float (&bias8)[8] = pre.bias8;
     T* __restrict__ C = (T*)p.C;
-    DropKey dkey = p.drop;
-    dkey.resolve();
-#pragma unroll 2
-    for (int r = tid / TPR; r < BM; r += RPP) {
+    const DropKey& dkey = pre.key;
+#pragma unroll
+    for (int it = 0; it < NR; ++it) {
+        const int r = tid / TPR + it * RPP;
         const int m = m0 + r;
         if (m >= p.M || n >= p.N) continue;
         float v[8];
@@ -197,6 +229,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
 #pragma unroll
             for (int q = 0; q < 4; ++q) { v[q] = a[q]; v[4 + q] = b[q]; }
         }
+        // the residual / gelu' row: prefetched (bf16) or read here (fp32)
+        float res[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE == EPI_BIAS_DROP_RES || MODE == EPI_ADD_RES || MODE == EPI_DGELU) {
+            if constexpr (Pre::HAS_R) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) res[q] = (float)pre.r[it][q];
+            } else {
+                if (p.R) Vec8<T>::load((const T*)p.R + (size_t)m * p.ldr + n, res);
+            }
+        }
         const size_t off = (size_t)m * p.ldc + n;
         if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_F32) {
 #pragma unroll
@@ -206,37 +248,37 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
         } else if constexpr (MODE == EPI_BIAS_GELU) {
             float g[8];
             const uint32_t gidx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;   // XLNet drops the activation (modeling_xlnet FF)
-#pragma unroll
             // C keeps gelu'(u), not u: the backward (EPI_DGELU) only ever needs u through gelu', and here u is still the fp32
             // accumulator (bf16 mode: the derivative of the unrounded pre-activation; fp32 mode: bit-identical to computing it later)
-            for (int q = 0; q < 8; ++q) {
-                const float u = v[q] + bias8[q];
-                g[q] = gelu_f(u) * drop_mult(dkey, gidx + q);
-                v[q] = dgelu_f(u);
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                const f32x2 u = {v[q] + bias8[q], v[q + 1] + bias8[q + 1]};
+                f32x2 gg, dg;
+                gelu_pair(u, gg, dg);
+                g[q] = gg.x;
+                g[q + 1] = gg.y;
+                v[q] = dg.x;
+                v[q + 1] = dg.y;
+            }
+            if (dkey.thresh != 0u) {               // activation dropout (MAG-XLNet only): one uniform branch per row
+#pragma unroll
+                for (int q = 0; q < 8; ++q) g[q] *= drop_mult(dkey, gidx + q);
             }
             Vec8<T>::store(C + off, v);
             Vec8<T>::store((T*)p.C2 + off, g);
         } else if constexpr (MODE == EPI_BIAS_DROP_RES) {
-            float res[8];
-            Vec8<T>::load((const T*)p.R + (size_t)m * p.ldr + n, res);
             const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = (v[q] + bias8[q]) * drop_mult(dkey, idx + q) + res[q];
             Vec8<T>::store(C + off, v);
         } else if constexpr (MODE == EPI_ADD_RES) {
-            if (p.R) {
-                float res[8];
-                Vec8<T>::load((const T*)p.R + (size_t)m * p.ldr + n, res);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += res[q];
-            }
+            for (int q = 0; q < 8; ++q) v[q] += res[q];
             Vec8<T>::store(C + off, v);
         } else if constexpr (MODE == EPI_DGELU) {
-            float u[8];
-            Vec8<T>::load((const T*)p.R + (size_t)m * p.ldr + n, u);
             const uint32_t gidx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { v[q] *= u[q] * drop_mult(dkey, gidx + q); cs[q] += v[q]; }      // R = gelu'(u) saved by EPI_BIAS_GELU
+            for (int q = 0; q < 8; ++q) { v[q] *= res[q] * drop_mult(dkey, gidx + q); cs[q] += v[q]; }      // R = gelu'(u) saved by EPI_BIAS_GELU
             Vec8<T>::store(C + off, v);
         } else if constexpr (MODE == EPI_ACCUM_F32) {
             float* dst = p.Cf + off;
@@ -258,7 +300,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
         // alone were 15 us of the 39 us dgrad-ffn2 launch -- 233 K atomics on 3072 addresses).
         if (p.colsum && !(p.dbg & 16)) {
             __syncthreads();                            // the row pass is done with the staged tile
-            float* red = (float*)smem;                  // [4 waves][BN]
+            float* red = (float*)smem;                  // [NW waves][BN]
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float s = cs[q];
@@ -267,8 +309,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
                 if (lane < TPR) red[wave * BN + lane * 8 + q] = s;
             }
             __syncthreads();
-            if (tid < BN && n0 + tid < p.N)
-                atomicAdd(p.colsum + n0 + tid, (red[tid] + red[BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]));
+            if (tid < BN && n0 + tid < p.N) {
+                float t = (red[tid] + red[BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]);
+                if constexpr (NW == 8) t += (red[4 * BN + tid] + red[5 * BN + tid]) + (red[6 * BN + tid] + red[7 * BN + tid]);
+                atomicAdd(p.colsum + n0 + tid, t);
+            }
         }
     }
 }
@@ -339,7 +384,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
-    gemm_epilogue<T, BM, BN, MODE, false>(p, acc, m0, n0, wave, lane, smem);
+    EpiPre<T, BM, BN, MODE, 4> pre;
+    pre.fetch(p, m0, n0, threadIdx.x);
+    gemm_epilogue<T, BM, BN, MODE, false>(p, acc, m0, n0, wave, lane, smem, pre);
 }
 
 
@@ -370,13 +417,14 @@ template <class T, int RB> __device__ __forceinline__ int kswz(int k, bool r1 = 
 
 // KB = bytes of k per stage row (128 or 64).  A smaller KB halves the stage, so twice as many stages (bytes in flight)
 // fit next to the stage being multiplied -- the fill rate of a CU is latency x bytes-in-flight bound.
-template <class T, int BROWS, bool KMAJ, int KB>
+template <class T, int BROWS, bool KMAJ, int KB, int NW = 4>
 struct Dma {
     static constexpr int EPV = 16 / sizeof(T);
     static constexpr int RB = BROWS * (int)sizeof(T);      // kmaj image row bytes
     static constexpr int CPR = KB / 16;                    // 16-B chunks per row-image row (8 or 4)
     static constexpr int RPI = 64 / CPR;                   // row-image rows per 1-KB DMA piece (8 or 16)
-    static constexpr int NI = BROWS * KB / 4096;           // 1-KB pieces per wave per stage
+    static constexpr int NI = BROWS * KB / (1024 * NW);    // 1-KB pieces per wave per stage
+    static_assert(NI * 1024 * NW == BROWS * KB, "a stage image is a whole number of 1-KB pieces per wave");
     typedef typename Frag<T>::type frag_t;
 
     // physical chunk of logical chunk lc in row r of the row image (conflict-free ds_read_b128)
@@ -388,7 +436,7 @@ struct Dma {
                                                  char* lds, int lane, int wave, bool r1) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int blk = i * 4 + wave;
+            const int blk = i * NW + wave;
             const T* src;
             if constexpr (!KMAJ) {
                 const int r = blk * RPI + lane / CPR;
@@ -452,15 +500,23 @@ struct Gemm2Smem { static constexpr int STAGE = (BM + BN) * KB;
 // (1 KB of LDS traffic) per MFMA pair -- ~240 B/clk per CU at full MFMA rate, i.e. the LDS port itself.  With the whole tile per
 // wave it is half that, there is one barrier per 256 bytes of k instead of per 128, and the tile count (the only way a
 // [2432 x 768] output fills 256 CUs) stays the same.  The four partial tiles meet in the LDS-staged epilogue.
-template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB, bool KS = false>
+//
+// NW = 8 (BM = 256 only, never with KS): eight waves as 4 x 2, each still a 64 x 64 quarter of a 128-row half -- the register
+// picture of the 128 x 128 kernel, two waves per SIMD from ONE block.  One 256 x 128 tile per CU moves 25 % fewer operand bytes
+// through the CU's 64 B/clk fill port than two co-resident 128 x 128 tiles, keeps 96 KB of loads in flight instead of 64 KB
+// (3-deep ring of 48-KB stages) and turns a [2400 x 3072] output into 240 tiles: one balanced round on 256 CUs instead of 456
+// tiles of which the slowest CU runs two.
+template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB, bool KS = false, int NW = 4>
 __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, const int n0, const int ky, char* smem) {
     static_assert(!KS || KB == 256, "k-split waves: four 64-byte slabs per stage");
+    static_assert(NW == 4 || (NW == 8 && !KS), "4 waves (2 x 2) or 8 waves (4 x 2)");
     constexpr int BKE = KB / sizeof(T);
-    constexpr int MT = KS ? BM / 16 : BM / 32, NT = KS ? BN / 16 : BN / 32;
+    constexpr int WM = NW / 2;
+    constexpr int MT = KS ? BM / 16 : BM / (16 * WM), NT = KS ? BN / 16 : BN / 32;
     constexpr int STAGE = (BM + BN) * KB;
     typedef typename Frag<T>::type frag_t;
-    typedef Dma<T, BM, AK, KB> DA;
-    typedef Dma<T, BN, BK, KB> DB;
+    typedef Dma<T, BM, AK, KB, NW> DA;
+    typedef Dma<T, BN, BK, KB, NW> DB;
     constexpr int G = DA::NI + DB::NI;            // DMA instructions per wave per stage
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -479,6 +535,13 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const bool r1 = (p.dbg & 8) != 0;
+    // phase stamps of this block (0 entry, 1 first stage landed, 2 k loop done, 3 epilogue issued, 4 its stores completed)
+    auto stamp = [&](int k) {
+        if (p.trace && tid == 0) p.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = wall_clock64();
+    };
+    stamp(0);
+    EpiPre<T, BM, BN, MODE, NW> pre;
+    pre.fetch(p, m0, n0, tid);                   // in flight under the whole k loop (oldest loads: counted out first by vmcnt)
     auto issue = [&](int t) {
         if (p.dbg & 1) return;
         char* st = smem + (t % NSTAGE) * STAGE;
@@ -497,6 +560,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
         else if (NSTAGE >= 3 && younger >= 1) wait_vmcnt<G>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();            // everyone's piece of stage t landed; everyone left stage t-1
+        if (t == 0) stamp(1);
         if (t + NSTAGE - 1 < nt) issue(t + NSTAGE - 1);
         const char* cur = smem + (t % NSTAGE) * STAGE;
 #pragma unroll
@@ -505,7 +569,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
             frag_t a[MT], b[NT];
             if (!(p.dbg & 4)) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = DA::frag(cur, wr * (BM / 2) + i * 16, s, lane, r1);
+                for (int i = 0; i < MT; ++i) a[i] = DA::frag(cur, wr * (BM / WM) + i * 16, s, lane, r1);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) b[j] = DB::frag(cur + BM * KB, wc * (BN / 2) + j * 16, s, lane, r1);
             } else {
@@ -527,15 +591,21 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
             }
         }
     }
-    gemm_epilogue<T, BM, BN, MODE, KS>(p, acc, m0, n0, wave, lane, smem);
+    stamp(2);
+    gemm_epilogue<T, BM, BN, MODE, KS, NW>(p, acc, m0, n0, wave, lane, smem, pre);
+    if (p.trace) {
+        stamp(3);
+        wait_vmcnt<0>();
+        stamp(4);
+    }
 }
 
-template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB, bool KS = false>
-__global__ void __launch_bounds__(256) gemm2_kernel(const GemmArgs p) {
+template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB, bool KS = false, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) gemm2_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB, KS>::BYTES];
     int m0, n0;
     if (!tile_origin<BM, BN>(p, m0, n0, blockIdx.x)) return;
-    gemm2_body<T, BM, BN, AK, BK, MODE, NSTAGE, KB, KS>(p, m0, n0, blockIdx.y, smem);
+    gemm2_body<T, BM, BN, AK, BK, MODE, NSTAGE, KB, KS, NW>(p, m0, n0, blockIdx.y, smem);
 }
 
 // Grouped wgrad: up to MB_MAX_GROUP independent dW += dY^T X problems in ONE launch.  Each of a layer's four weight
@@ -589,6 +659,27 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
+static unsigned long long* g_trace = nullptr;       // MB_GEMM_TRACE=1: device buffer of phase stamps, [kTraceBlocks][8]
+static int g_trace_on = -1, g_trace_blocks = 0;
+constexpr int kTraceBlocks = 8192;
+static unsigned long long* trace_buffer(int blocks, hipStream_t st) {
+    if (g_trace_on < 0) {
+        const char* v = getenv("MB_GEMM_TRACE");
+        g_trace_on = v ? atoi(v) : 0;
+        if (g_trace_on && hipMalloc(&g_trace, (size_t)kTraceBlocks * 8 * sizeof(unsigned long long)) != hipSuccess) g_trace_on = 0;
+    }
+    if (!g_trace_on || blocks > kTraceBlocks) return nullptr;
+    g_trace_blocks = blocks;
+    (void)hipMemsetAsync(g_trace, 0, (size_t)blocks * 8 * sizeof(unsigned long long), st);
+    return g_trace;
+}
+int gemm_trace_fetch(unsigned long long* host_out, int max_blocks) {
+    if (!g_trace || !host_out) return 0;
+    const int n = g_trace_blocks < max_blocks ? g_trace_blocks : max_blocks;
+    if (hipDeviceSynchronize() != hipSuccess) return 0;
+    if (hipMemcpy(host_out, g_trace, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
 static int g_impl = -1, g_stages = -1, g_dbg = 0;      // MB_GEMM_IMPL: 0 auto, 1 = register-staged v1, 2 = LDS-DMA v2 ; MB_GEMM_STAGES: 2|3|4
 
 // choose the 8-region (one per XCD) decomposition with the smallest per-XCD panel footprint; returns the padded grid size
@@ -619,11 +710,22 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
     dim3 grid(tiles, splits);
     if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
     p.dbg = g_dbg;
+    p.trace = (g_trace_on != 0) ? trace_buffer(tiles * splits, st) : nullptr;
     // v2 preconditions (see the kernel header)
     bool v2ok = (p.K % BKE == 0) && (p.lda % EPV == 0) && (p.ldb % EPV == 0) && (((uintptr_t)p.A | (uintptr_t)p.B) % 16 == 0);
     if (AK) v2ok = v2ok && (p.M % BM == 0);
     if (BK) v2ok = v2ok && (p.N % BN == 0);
     if (g_impl == 1) v2ok = false;
+    if constexpr (BM == 256) {
+        // 8-wave single-round kernel (bf16, row-major A): anything it cannot take goes to the 128 x 128 configuration
+        if constexpr (sizeof(T) == 2 && !AK && BN == 128) {
+            if (v2ok && splits == 1) {
+                hipLaunchKernelGGL((gemm2_kernel<T, 256, 128, AK, BK, MODE, 3, 128, false, 8>), grid, dim3(512), 0, st, p);
+                return (int)hipGetLastError();
+            }
+        }
+        return launch_cfg<T, 128, 128, AK, BK, MODE>(a, splits, st);
+    } else
     if (v2ok) {
         // (KB, NSTAGE) per tile: MB_GEMM_STAGES = 10*KBsel + stages overrides (KBsel 1 -> 128-byte rows, 2 -> 64-byte rows)
         int ns = 2, kb = 128;      // measured best (per-layer GEMM 290 us): deeper rings / 64-byte rows do not pay
@@ -642,7 +744,7 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
             }
         }
         if (kb == 128) {
-            if (BM == 128) { if (ns <= 2) MB_LAUNCH2(2, 128); else MB_LAUNCH2(3, 128); }
+            if (BM == 128) { if (ns <= 2) MB_LAUNCH2(2, 128); else if (ns == 3) MB_LAUNCH2(3, 128); else MB_LAUNCH2(4, 128); }
             else { if (ns <= 2) MB_LAUNCH2(2, 128); else if (ns == 3) MB_LAUNCH2(3, 128); else MB_LAUNCH2(4, 128); }
         } else {
             if (ns <= 3) MB_LAUNCH2(3, 64); else if (ns == 4) MB_LAUNCH2(4, 64); else MB_LAUNCH2(5, 64);
@@ -655,14 +757,23 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
 }
 
 static int g_tile_n768 = -1;       // MB_GEMM_TILE_N768: tile code for auto-selected narrow GEMMs (64 | 12864 | 128)
+static int g_tile_big = -1;        // MB_GEMM_TILE_BIG: 1 = 256 x 128 eight-wave tiles where they make ONE round on the chip (default 0: measured slower)
 
 template <class T, bool AK, bool BK, int MODE>
 static int launch_tile(const GemmArgs& a, int splits, int tile, hipStream_t st) {
     if (tile == 0) {   // heuristic: fill >= ~1 wave of the 256 CUs
         const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (splits < 1 ? 1 : splits);
         if (g_tile_n768 < 0) g_tile_n768 = env_int("MB_GEMM_TILE_N768", 64);
+        if (g_tile_big < 0) g_tile_big = env_int("MB_GEMM_TILE_BIG", 0);
         tile = (t128 >= 224) ? 128 : g_tile_n768;
+        // one 256 x 128 tile per CU: taken when the whole output is a single, reasonably full round of the 256 CUs
+        const long t256 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+        if (g_tile_big && sizeof(T) == 2 && !AK && splits <= 1 && t256 <= 256 && t256 >= 168) tile = 256;
     }
+    if constexpr (sizeof(T) == 2 && !AK) {
+        if (tile == 256) return launch_cfg<T, 256, 128, AK, BK, MODE>(a, splits, st);
+    }
+    if (tile == 256) tile = 128;
     if (tile == 128) return launch_cfg<T, 128, 128, AK, BK, MODE>(a, splits, st);
     if (tile == 12864) return launch_cfg<T, 128, 64, AK, BK, MODE>(a, splits, st);
     return launch_cfg<T, 64, 64, AK, BK, MODE>(a, splits, st);

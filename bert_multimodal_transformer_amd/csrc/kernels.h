@@ -44,7 +44,10 @@ struct GemmArgs {
     int kchunk;                // filled by the launcher
     int dbg;                   // ablation switches (MB_GEMM_DBG): 1 = no DMA issue, 2 = no MFMA, 4 = no LDS fragment reads
     int reg_m, reg_n, tpr_m, tpr_n;   // XCD regions (filled by the launcher): reg_m*reg_n == 8, tiles per region
+    unsigned long long* trace;        // MB_GEMM_TRACE=1: [blocks][8] wall-clock stamps (100 MHz) of the phases of every block, else null
 };
+// copies the stamps of the last traced launch to the host (measurement tooling: tools/gemm_bench --trace); returns the block count
+int gemm_trace_fetch(unsigned long long* host_out, int max_blocks);
 
 // tile: 0 = auto, 64 or 128.  splits: split-K factor (only EPI_ACCUM_F32).
 int gemm_launch(int dtype, int layout, int mode, const GemmArgs& a, int splits, int tile, hipStream_t st);
@@ -129,6 +132,7 @@ int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx,
                        void* dqkv, float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st,
                        const float* head_scale = nullptr);
+int attention_trace_fetch(unsigned long long* host_out, int max_blocks);     // MB_ATTN_TRACE=1: stamps of the last attention_backward
 
 // ------------------------------------------------------------------------------------------ XLNet (xlnet_attention.hip, xlnet_rowops.hip)
 // relative attention core, L <= 64.  qkv [T][3H] token-major, kr [B][2L][H], psave/gsave [B][nh][L][L].

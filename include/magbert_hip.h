@@ -46,6 +46,15 @@ int mb_gemm(int dtype, int layout, int epilogue, int M, int N, int K, const void
             void* C, int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, float alpha,
             const mb_dropkey* drop, int splits, int tile, void* stream);
 
+/* Measurement hook (tools/gemm_bench --trace; not used by the product path): with MB_GEMM_TRACE=1 in the environment every
+ * block of an mb_gemm launch stamps the 100 MHz wall clock at 0 entry, 1 first operand stage landed, 2 k loop done,
+ * 3 epilogue issued, 4 its stores completed.  Copies the [blocks][8] stamps of the LAST launch to host_out (blocks that
+ * exited without a tile stay 0) and returns the block count (0 when tracing is off). */
+int mb_debug_gemm_trace(unsigned long long* host_out, int max_blocks);
+/* same for mb_attention_backward with MB_ATTN_TRACE=1: 0 entry, 1 operands staged, 2 query sweep done, 3 dQ bias flushed,
+ * 4 key sweep done, 5 exit */
+int mb_debug_attention_trace(unsigned long long* host_out, int max_blocks);
+
 /* `count` (<= 4) weight gradients dW_g[M_g][N_g] += dY_g[K][M_g]^T X_g[K][N_g] in ONE launch (fp32 accumulate) -- the
  * four torch.nn.Linear weight gradients autograd produces per BertLayer (mm_backward under loss.backward(),
  * multimodal_driver.py:378).  Every M_g, N_g must be a multiple of `tile` (64 | 128) and K a multiple of 128 bytes. */

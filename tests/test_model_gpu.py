@@ -637,7 +637,7 @@ def test_error_behaviour_matches_the_reference_conventions():
     with pytest.raises(ValueError):                                   # modality tensors of the wrong width
         m(ids, vis[..., :40], aco, token_type_ids=seg, attention_mask=mask)
     with pytest.raises(NotImplementedError):                          # optional paths the driver never takes
-        m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, head_mask=torch.ones(1, 12))
+        m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, head_mask=torch.ones(2, 5))          # neither [num_heads] nor [num_layers, num_heads]
     big = tb(weights.synthetic_bert_batch(1, 130, 47, 74, seed=8), DEV)
     with pytest.raises(Exception) as ei:                              # L > 128: reported by the library, never re-routed
         m(big[0], big[1], big[2], token_type_ids=big[4], attention_mask=big[3])

@@ -67,7 +67,8 @@ def gemm(dt, tdt, layout, epi, M, N, K, A, B, bias=None, R=None, alpha=1.0, drop
 
 
 @pytest.mark.parametrize("dt,tdt", DTS)
-@pytest.mark.parametrize("M,N,K,tile", [(150, 192, 128, 64), (2400, 768, 768, 0), (300, 256, 3072, 128), (48, 768, 768, 64)])
+@pytest.mark.parametrize("M,N,K,tile", [(150, 192, 128, 64), (2400, 768, 768, 0), (300, 256, 3072, 128), (48, 768, 768, 64),
+                                        (2400, 3072, 768, 0), (2400, 2304, 768, 256), (300, 136, 192, 256)])   # 256 = eight-wave 256 x 128 tiles (bf16; fp32 falls back to 128)
 def test_gemm_nt_epilogues(dt, tdt, M, N, K, tile):
     A, B = rnd((M, K), 1, tdt), rnd((N, K), 2, tdt, 0.1)     # asymmetric operands: a transposed C-write cannot pass
     bias = rnd((N,), 3, torch.float32)
@@ -90,15 +91,16 @@ def test_gemm_nt_epilogues(dt, tdt, M, N, K, tile):
 
 @pytest.mark.parametrize("dt,tdt", DTS)
 @pytest.mark.parametrize("M,N,K,tile", [(150, 192, 128, 64), (2400, 768, 3072, 0), (2400, 3072, 768, 128), (2400, 768, 2304, 64),
-                                        (100, 128, 64, 128), (2400, 768, 768, 128)])
+                                        (100, 128, 64, 128), (2400, 768, 768, 128), (2400, 3072, 768, 0), (500, 384, 192, 256)])
 def test_gemm_nn_dgrad(dt, tdt, M, N, K, tile):
     A, B = rnd((M, K), 5, tdt), rnd((K, N), 6, tdt, 0.1)     # B stored [K][N]
     R = rnd((M, N), 7, tdt)
     ref = A.double() @ B.double()
     c, _, _ = gemm(dt, tdt, _lib.GEMM_NN, _lib.EPI_ADD_RES, M, N, K, A, B, R=R, tile=tile)
     close(c, (ref + R.double()).float(), dt, "add_res")
-    c, _, _ = gemm(dt, tdt, _lib.GEMM_NN, _lib.EPI_DGELU, M, N, K, A, B, R=R, tile=tile)
+    c, _, cf = gemm(dt, tdt, _lib.GEMM_NN, _lib.EPI_DGELU, M, N, K, A, B, R=R, tile=tile)
     close(c, (ref * R.double()).float(), dt, "dgelu")      # R = gelu'(u) as saved by the forward's EPI_BIAS_GELU
+    close(cf.view(-1)[:N], (ref * R.double()).sum(0).float(), dt, "dgelu.colsum")      # fused bias gradient: column sums of the fp32 values
 
 
 @pytest.mark.parametrize("dt,tdt", DTS)

@@ -2,7 +2,8 @@
 // Measurement tooling (not product).  Every case runs `reps` launches over `nset` rotating operand sets (so that operands
 // come from HBM / Infinity Cache like inside a training step, not from a warm L2) between two HIP events.
 //
-//   gemm_bench [--T tokens] [--reps n] [--nset n] [--only substring]
+//   gemm_bench [--T tokens] [--reps n] [--nset n] [--only substring] [--trace 1]
+//   --trace 1 (with MB_GEMM_TRACE=1): after timing a case, one more launch whose per-block phase stamps are summarised
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -10,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include "../include/magbert_hip.h"
 
 #define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(_e)); exit(2); } } while (0)
@@ -29,12 +31,13 @@ static void* dev_rand(size_t n_bf16, uint32_t seed) {
 }
 
 int main(int argc, char** argv) {
-    int T = 2400, reps = 48, nset = 6;
+    int T = 2400, reps = 48, nset = 6, trace = 0;
     std::string only;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i];
         if (k == "--T") T = atoi(argv[i + 1]); else if (k == "--reps") reps = atoi(argv[i + 1]);
         else if (k == "--nset") nset = atoi(argv[i + 1]); else if (k == "--only") only = argv[i + 1];
+        else if (k == "--trace") trace = atoi(argv[i + 1]);
     }
     const int H = 768, I = 3072;
     const int Tp = (T + 63) / 64 * 64;
@@ -88,6 +91,26 @@ int main(int argc, char** argv) {
         const double us = ms * 1e3 / reps, fl = 2.0 * c.M * c.N * c.K;
         printf("%-52s %8.2f us %8.1f TF/s\n", c.name, us, fl / us * 1e-6);
         tot_us += us; tot_fl += fl;
+        if (trace) {
+            // phase picture of ONE launch in steady state (the queue is kept busy by the launches in front of it)
+            for (int i = 0; i < 8; ++i) launch(i);
+            std::vector<unsigned long long> tr((size_t)8192 * 8);
+            const int nb = mb_debug_gemm_trace(tr.data(), 8192);
+            std::vector<double> ph[5];
+            unsigned long long t00 = ~0ull;
+            for (int b = 0; b < nb; ++b) if (tr[(size_t)b * 8]) t00 = std::min(t00, tr[(size_t)b * 8]);
+            for (int b = 0; b < nb; ++b) {
+                if (!tr[(size_t)b * 8]) continue;
+                for (int k = 0; k < 5; ++k) ph[k].push_back((double)(tr[(size_t)b * 8 + k] - t00) * 0.01);
+            }
+            static const char* nm[5] = {"entry", "stage 0 landed", "k loop done", "epilogue issued", "stores done"};
+            printf("    %d blocks with a tile of %d launched; us after the first block's entry  (min / median / max)\n", (int)ph[0].size(), nb);
+            for (int k = 0; k < 5; ++k) {
+                if (ph[k].empty()) continue;
+                std::sort(ph[k].begin(), ph[k].end());
+                printf("    %-16s %7.2f %7.2f %7.2f\n", nm[k], ph[k].front(), ph[k][ph[k].size() / 2], ph[k].back());
+            }
+        }
     }
     if (only.empty() || strstr("wgrad", only.c_str())) {
         auto launch = [&](int i) {
