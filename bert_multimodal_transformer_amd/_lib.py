@@ -74,6 +74,8 @@ PROTOTYPES = {
     "mb_bert_set_attention_output": (_i, [_vp, _vp]),
     "mb_debug_gemm_trace": (_i, [_vp, _i]),
     "mb_debug_attention_trace": (_i, [_vp, _i]),
+    "mb_bert_mark_grads_zero": (_i, [_vp, _i]),
+    "mb_xlnet_mark_grads_zero": (_i, [_vp, _i]),
     "mb_bert_set_head_mask": (_i, [_vp, _vp]),
     "mb_bert_set_inputs_embeds": (_i, [_vp, _vp]),
     "mb_bert_inputs_embeds_grad": (_vp, [_vp]),

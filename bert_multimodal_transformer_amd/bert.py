@@ -141,6 +141,7 @@ class _Core(object):
         self.weights_dirty = True
         self.loss_buf = torch.zeros(2, dtype=torch.float32, device=self.device)   # [last step, running sum]
         self._optional = (None, None)
+        self._gz = True             # the flat gradient buffer holds zeros (mirror of the engine's flag: survives a re-created engine)
 
     # -- engine lifecycle ---------------------------------------------------------------------------
     def _fn(self, name):
@@ -183,6 +184,7 @@ class _Core(object):
                                              _lib.ptr(self.shadow) if self.dt == _lib.DT_BF16 else None,
                                              _lib.ptr(self.ws), nbytes))
             self.weights_dirty = True
+            _lib.check(self._fn("mark_grads_zero")(self.handle, 1 if self._gz else 0))
 
     def _tensor_table(self):
         out = []
@@ -291,6 +293,14 @@ class _Core(object):
         _lib.check(self.lib.mb_bert_set_inputs_embeds(self.handle, _lib.ptr(inputs_embeds)))
         self._optional = (head_mask, inputs_embeds)          # kept alive: the engine holds raw pointers through the backward
 
+    def mark_grads_zero(self, known_zero=True):
+        """tells the engine the flat gradient buffer holds zeros (it then stores, instead of accumulating, the layer weight
+        gradients of the next backward -- include/magbert_hip.h: mb_bert_mark_grads_zero).  Called by everything of ours that
+        zeroes the buffer; code that writes into `.grad` tensors by hand between a zero_grad() and a backward must pass False."""
+        self._gz = bool(known_zero)
+        if self.handle is not None:
+            _lib.check(self._fn("mark_grads_zero")(self.handle, 1 if known_zero else 0))
+
     def head_mask_table(self, head_mask):
         """transformers get_head_mask (bert.py:206-207): [n_heads] (every layer) or [n_layers][n_heads] (or the broadcast
         5-D form of it) -> fp32 [n_layers][n_heads] on the device.  Masks that differ per sample or per position are not built."""
@@ -348,6 +358,7 @@ class _Core(object):
         if dlogits is None and lab is None:
             raise ValueError("fused backward needs the labels passed to forward()")
         with _Core._Hop(self):
+            self._gz = False                    # (the engine consumed its flag at stage 0)
             for s in range(nstage):
                 _lib.check(self._fn("backward")(self.handle, _lib.ptr(dlogits), lab if dlogits is None else None,
                                                 float(loss_scale), s, s + 1, self.stream()))
@@ -393,6 +404,7 @@ class _Core(object):
                 C.c_void_p(self.loss_buf.data_ptr() + 4), _lib.ptr(o.get("m")), _lib.ptr(o.get("v")), o.get("lr", 0.0),
                 o.get("beta1", 0.9), o.get("beta2", 0.999), o.get("eps", 1e-6), o.get("weight_decay", 0.0), int(o.get("t", 1)),
                 1 if o.get("correct_bias", True) else 0, o.get("grad_scale", 1.0), float(loss_scale), int(mode), self.stream()))
+        self._gz = opt is not None          # the fused AdamW left the gradients zeroed / a micro-step left them populated
         return logits
 
     def graph_stats(self):
@@ -428,6 +440,7 @@ class _Core(object):
         """backward of the base model from the gradients of (sequence_output, pooler pre-activation): mb_bert_backward_outputs,
         then the encoder / MAG / embedding stages"""
         nstage = self.n_layers + 2
+        self._gz = False
         with _Core._Hop(self):
             _lib.check(self.lib.mb_bert_backward_outputs(self.handle, _lib.ptr(d_seq), _lib.ptr(d_pre), self.stream()))
             for hook in self.stage_hooks:
@@ -641,6 +654,7 @@ class _MagBertBase(nn.Module):
     def zero_grad(self, set_to_none=False):
         # p.grad are views of the flat gradient buffer the engine accumulates into: clear it in place
         self._core.grads.zero_()
+        self._core.mark_grads_zero(True)
 
     def sync_weights(self):
         """call after editing parameters in place (bf16 mode keeps an operand shadow of the GEMM weights)"""

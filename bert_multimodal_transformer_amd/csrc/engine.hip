@@ -349,6 +349,7 @@ int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
     e->c = *cfg;
     if (const char* v = getenv("MB_OVERLAP_WGRAD")) e->overlap_wgrad = atoi(v);
     if (const char* v = getenv("MB_GROUP_WGRAD")) e->group_wgrad = atoi(v);
+    if (const char* v = getenv("MB_WGRAD_OVERWRITE")) e->ow_enable = atoi(v);
     e->grouped = (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->hidden_size % e->group_wgrad == 0 &&
                  cfg->intermediate_size % e->group_wgrad == 0;
     e->deferred = e->overlap_wgrad && e->grouped;
@@ -471,6 +472,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
     const int Tk = (int)align_up((size_t)T, 64);      // zero-padded reduction length of the wgrad GEMMs
     if (stage_begin < 0) stage_begin = 0;
     if (stage_end > NL + 2) stage_end = NL + 2;
+    if (stage_begin == 0) e->begin_backward_pass();
     float* P = e->P; float* G = e->G;
     char* ws = e->ws;
     const bool hd = e->training && c.hidden_dropout > 0.f;
@@ -527,6 +529,8 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                               wgrad_args(H, H, Tk, dzdB, H, ws + w.ctx, H, G + o.wo, H),
                               wgrad_args(3 * H, H, Tk, dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H)};
             const bool grouped = e->grouped;
+            if (grouped)
+                for (GemmArgs& a : wg) a.overwrite = e->ow_pass ? 1 : 0;       // whole-tile, no split-K launches only
             const bool inl = grouped && !e->deferred;         // grouped launch in line on the caller's stream (no overlap)
             if (grouped && !gemm_grouped_tn_ok(dt, wg, 4, e->group_wgrad)) return MB_ERR_SHAPE;
             if (!grouped) {
@@ -717,6 +721,11 @@ int mb_bert_set_attention_output(mb_bert_engine* e, float* probs) {
     e->attn_out = probs;
     return MB_OK;
 }
+int mb_bert_mark_grads_zero(mb_bert_engine* e, int known_zero) {
+    if (!e) return MB_ERR_ARG;
+    e->grads_zero = known_zero != 0;
+    return MB_OK;
+}
 int mb_bert_set_head_mask(mb_bert_engine* e, const float* head_mask) {
     if (!e) return MB_ERR_ARG;
     e->head_mask = head_mask;
@@ -734,6 +743,7 @@ const float* mb_bert_inputs_embeds_grad(const mb_bert_engine* e) {
 int mb_bert_backward_outputs(mb_bert_engine* e, const void* d_sequence_output, const void* d_pooler_preact, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!e || !e->G || !e->ran_forward) return MB_ERR_ARG;
+    e->begin_backward_pass();
     const mb_bert_config& c = e->c;
     const int dt = c.dtype, H = c.hidden_size, B = e->B, L = e->L, T = B * L, NL = c.num_layers;
     char* ws = e->ws;

@@ -131,7 +131,7 @@ inline int wgrad(int dtype, int Mo, int No, int rows, const void* dY, int ldy, c
 // scalars of the two parameter groups -- written by ONE prologue launch; the rest of the step is a fixed kernel sequence that can
 // be replayed as a hipGraph.
 struct StepGraph {
-    int B, L, with_opt; const void *logits, *loss, *loss_run, *m, *v; float loss_scale; hipStream_t st;
+    int B, L, with_opt, overwrite; const void *logits, *loss, *loss_run, *m, *v; float loss_scale; hipStream_t st;
     hipGraph_t graph; hipGraphExec_t exec;
 };
 
@@ -142,6 +142,19 @@ struct StepMixin {
     size_t ws_state = 0, ws_in_ids = 0, ws_in_seg = 0, ws_in_mask = 0, ws_in_vis = 0, ws_in_aco = 0, ws_in_lab = 0;
     std::vector<StepGraph> graphs;
     size_t graph_launches = 0, graph_captures = 0;
+    // Known-zero gradients.  The fused AdamW leaves the flat gradient buffer zeroed (optimizer.zero_grad()); when nothing has
+    // written to it since, the layer weight gradients of the next backward are STORED instead of accumulated: the read half of
+    // a 340 MB read-modify-write per step (28 MB per layer, straight from HBM: AdamW streamed the zeros out non-temporally).
+    // grads_zero: set by a step that ran the optimizer and by mb_*_mark_grads_zero (the host zeroed the buffer itself);
+    // consumed -- and cleared -- by the first stage of the next backward.  A false "known zero" is the only way this can go
+    // wrong, so everything that is not the engine's own zeroing leaves it false.  MB_WGRAD_OVERWRITE=0 turns it off.
+    bool grads_zero = false, ow_pass = false, in_step = false;
+    int ow_enable = 1;
+    void begin_backward_pass() {
+        if (in_step) return;                 // the single-call step decided already (and replays a graph captured for that decision)
+        ow_pass = grads_zero && ow_enable;
+        grads_zero = false;
+    }
 
     void carve_step(Carver& w, size_t Tpad, int V, int A, int max_batch, int num_labels, int nsites_) {
         nsites = nsites_;
@@ -186,7 +199,17 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
                            const void* seg, const void* labels, int B, int L, uint64_t seed, uint64_t step, float* logits, float* loss,
                            float* loss_run, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay,
                            int opt_step, int correct_bias, float grad_scale, float loss_scale, int mode, bool force_launches,
-                           hipStream_t st, Enqueue enqueue) {
+                           hipStream_t st, Enqueue enqueue_inner) {
+    // what this step's backward may assume about the gradient buffer -- part of the graph's identity -- and what it leaves behind
+    const int ow = (e->grads_zero && e->ow_enable) ? 1 : 0;
+    struct Flags {
+        E* e; bool after;
+        ~Flags() { e->in_step = false; e->grads_zero = after; }
+    } flags{e, m != nullptr};
+    e->in_step = true; e->ow_pass = ow != 0;
+    auto enqueue = [&](float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
+        return enqueue_inner(lg, ls, lr_, m_, v_, sc, s);
+    };
     PrologueArgs pa = {};
     e->fill_copies(pa, ws, ids, vis, aco, mask, seg, labels, B, L, V, A, num_labels);
     pa.seed = seed; pa.step = step; pa.keys = e->key_state(ws); pa.nsites = e->nsites;
@@ -210,14 +233,14 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
     }
     StepGraph* g = nullptr;
     for (auto& x : e->graphs)
-        if (x.B == B && x.L == L && x.with_opt == (m != nullptr) && x.logits == logits && x.loss == loss && x.loss_run == loss_run &&
+        if (x.B == B && x.L == L && x.with_opt == (m != nullptr) && x.overwrite == ow && x.logits == logits && x.loss == loss && x.loss_run == loss_run &&
             x.m == m && x.v == v && x.loss_scale == loss_scale && x.st == st) { g = &x; break; }
     if (!g) {
         if (e->graphs.size() >= 32) {          // callers that keep changing output pointers: do not grow without bound
             hipGraphExecDestroy(e->graphs.front().exec); hipGraphDestroy(e->graphs.front().graph);
             e->graphs.erase(e->graphs.begin());
         }
-        StepGraph ng = {B, L, m != nullptr, logits, loss, loss_run, m, v, loss_scale, st, nullptr, nullptr};
+        StepGraph ng = {B, L, m != nullptr, ow, logits, loss, loss_run, m, v, loss_scale, st, nullptr, nullptr};
         CK((int)hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
         e->dyn = true; e->capturing = true;
         const int r = enqueue(logits, loss, loss_run, m, v, loss_scale, st);

@@ -285,6 +285,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
             if (gridDim.y > 1) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) atomicAdd(dst + q, v[q]);
+            } else if (p.overwrite) {                  // the gradient buffer is known to hold zeros: no read-modify-write
+                Vec8<float>::store(dst, v);
             } else {
                 float o[8];
                 Vec8<float>::load(dst, o);

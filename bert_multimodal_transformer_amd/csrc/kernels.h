@@ -44,6 +44,7 @@ struct GemmArgs {
     int kchunk;                // filled by the launcher
     int dbg;                   // ablation switches (MB_GEMM_DBG): 1 = no DMA issue, 2 = no MFMA, 4 = no LDS fragment reads
     int reg_m, reg_n, tpr_m, tpr_n;   // XCD regions (filled by the launcher): reg_m*reg_n == 8, tiles per region
+    int overwrite;                    // EPI_ACCUM_F32 without split-K: Cf = acc instead of Cf += acc (the caller knows Cf holds zeros)
     unsigned long long* trace;        // MB_GEMM_TRACE=1: [blocks][8] wall-clock stamps (100 MHz) of the phases of every block, else null
 };
 // copies the stamps of the last traced launch to the host (measurement tooling: tools/gemm_bench --trace); returns the block count

@@ -178,6 +178,7 @@ int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out) {
     mb_xlnet_engine* e = new mb_xlnet_engine();
     if (const char* v = getenv("MB_GROUP_WGRAD")) e->group_wgrad = atoi(v);
     if (const char* v = getenv("MB_OVERLAP_WGRAD")) e->overlap_wgrad = atoi(v);
+    if (const char* v = getenv("MB_WGRAD_OVERWRITE")) e->ow_enable = atoi(v);
     e->deferred = e->overlap_wgrad && (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->d_inner % e->group_wgrad == 0 &&
                   cfg->d_model % e->group_wgrad == 0;
     e->c = *cfg;
@@ -295,6 +296,7 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
     const size_t es = esize(dt);
     if (stage_begin < 0) stage_begin = 0;
     if (stage_end > NL + 2) stage_end = NL + 2;
+    if (stage_begin == 0) e->begin_backward_pass();
     float* P = e->P; float* G = e->G;
     char* ws = e->ws;
     const float pd = c.dropout;
@@ -340,6 +342,8 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                               wgrad_args(H, H, Tk, xin, H, dqkv + (size_t)H * es, 3 * H, G + o.k, H),
                               wgrad_args(H, H, Tk, xin, H, dqkv + (size_t)2 * H * es, 3 * H, G + o.v, H)};
             const bool grouped = e->group_wgrad > 0 && gemm_grouped_tn_ok(dt, wg, 7, e->group_wgrad);
+            if (grouped)
+                for (GemmArgs& a : wg) a.overwrite = e->ow_pass ? 1 : 0;
             if (!grouped) CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, st));
             CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, du, I, nullptr, G + o.b1, nullptr, ws + w.u, I,
                     e->key(XS_LAYER0 + 8 * l + 2, pd), 1, 0, st));
@@ -445,6 +449,12 @@ int mb_xlnet_train_step(mb_xlnet_engine* e, const int64_t* input_ids, const floa
                            [&](float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
                                return xl_enqueue_step(e, B, L, lg, ls, lr_, m_, v_, sc, s);
                            });
+}
+
+int mb_xlnet_mark_grads_zero(mb_xlnet_engine* e, int known_zero) {
+    if (!e) return MB_ERR_ARG;
+    e->grads_zero = known_zero != 0;
+    return MB_OK;
 }
 
 int mb_xlnet_load_batch(mb_xlnet_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,

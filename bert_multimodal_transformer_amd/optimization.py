@@ -59,6 +59,25 @@ class AdamW(torch.optim.Optimizer):
             for p in loose:
                 plan.append(("loose", gi, p))
         self._plan = plan
+        # cores whose GEMM-weight range [sh_begin, sh_end) is updated -- hence zeroed -- entirely by this optimizer: after a
+        # fused step their layer weight gradients are known to be zero (mb_bert_mark_grads_zero: the next backward stores them)
+        self._covers = {}
+        spans = {}
+        for it in plan:
+            if it[0] == "flat":
+                spans.setdefault(id(it[2]), (it[2], []))[1].append((it[3], it[4]))
+        for cid, (core, sp) in spans.items():
+            sp.sort()
+            reach = core.sh_begin
+            for a, b in sp:
+                if a <= reach:
+                    reach = max(reach, b)
+            self._covers[cid] = (core, reach >= core.sh_end)
+
+    def _mark_zero(self):
+        for core, covered in self._covers.values():
+            if covered:
+                core.mark_grads_zero(True)
 
     def flat_step_args(self, core):
         """Hyper-parameters of step() as ONE whole-buffer update, when this optimizer is exactly the driver's two parameter
@@ -151,6 +170,8 @@ class AdamW(torch.optim.Optimizer):
             dp.finish()                    # this stream now waits for the last all-reduce
             for core, group, x, y in deferred:
                 launch(core, group, x, y)
+        if self.fused_zero_grad:
+            self._mark_zero()              # every gradient the update consumed is zero again
         return loss
 
     # -- checkpoint / resume ---------------------------------------------------------
@@ -195,6 +216,7 @@ class AdamW(torch.optim.Optimizer):
                 core = item[2]
                 if not self.fused_zero_grad and id(core) not in done:
                     core.grads.zero_()
+                    core.mark_grads_zero(True)
                     done.add(id(core))
             else:
                 p = item[2]

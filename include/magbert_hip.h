@@ -184,6 +184,13 @@ int mb_bert_backward_outputs(mb_bert_engine* e, const void* d_sequence_output, c
 /* gradient buckets for data parallelism: range r of stage s covers flat elements [off, off+len) */
 int mb_bert_stage_grad_ranges(const mb_bert_engine* e, int stage, size_t* offs, size_t* lens, int cap);
 
+/* Known-zero gradients.  A step that runs the fused AdamW leaves the flat gradient buffer zeroed (the reference's
+ * optimizer.zero_grad(), multimodal_driver.py:386); the next backward then STORES the layer weight gradients instead of adding
+ * to them (no read of 28 MB per layer).  A host that zeroes the bound gradient buffer itself (model.zero_grad(), a stand-alone
+ * mb_adamw_step with zero_grad) says so with known_zero = 1; anything else that writes gradients must leave / set it 0.  The
+ * flag is consumed by the first stage of the next backward.  MB_WGRAD_OVERWRITE=0 disables the optimisation. */
+int mb_bert_mark_grads_zero(mb_bert_engine* e, int known_zero);
+
 /* One whole optimizer step of train_epoch (multimodal_driver.py:354-388): `batch = tuple(t.to(DEVICE) ...)` staging, forward,
  * MSE (`:372-373`), loss.backward() (`:378`), optimizer.step() + optimizer.zero_grad() (`:384-386`) -- as TWO launches:
  *   1. a step prologue kernel that gathers the six batch tensors (device pointers, e.g. the landing buffer of an asynchronous
@@ -261,6 +268,7 @@ const void* mb_xlnet_sequence_output(const mb_xlnet_engine* e);
 /* input of layer i as XLNetModel collects it with output_hidden_states (xlnet.py:363-392; before the MAG injection), i = n_layer: the last output */
 const void* mb_xlnet_hidden_state(const mb_xlnet_engine* e, int i);
 int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap);
+int mb_xlnet_mark_grads_zero(mb_xlnet_engine* e, int known_zero);      /* as mb_bert_mark_grads_zero */
 /* the MAG-XLNet counterparts of mb_bert_train_step / mb_bert_load_batch / mb_bert_graph_stats (same contracts; one iteration of
  * train_epoch, multimodal_driver.py:359-386, for the xlnet-base-cased model).  The two parameter groups are [0, decay_count) and
  * [decay_count, trainable_count); the frozen transformer.mask_emb slot behind them is never updated (HF AdamW skips grad-less

@@ -555,6 +555,57 @@ def test_step_graph_gradient_accumulation_and_replay_stability():
     assert worst <= 1e-5 + 10 * noise
 
 
+def test_known_zero_gradients_are_stored_not_accumulated(monkeypatch):
+    """After a step that ran the fused AdamW (which zeroes the gradients) the next backward STORES the layer weight gradients
+    instead of adding to them.  Storing into zeros and adding to zeros are the same fp32 numbers, so a model with
+    MB_WGRAD_OVERWRITE=0 must follow the same trajectory (to the 1e-7 run-to-run noise of the fp32 atomics in the bias / LayerNorm
+    gradients; a stale or double-counted gradient is an O(1) relative error) through every way of stepping: single-call steps,
+    accumulation micro-steps, Python-driven passes, model.zero_grad(); a hand-edited gradient (flag withdrawn) is accumulated onto."""
+    from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
+
+    def run(overwrite):
+        monkeypatch.setenv("MB_WGRAD_OVERWRITE", "1" if overwrite else "0")
+        torch.manual_seed(5)
+        m = build(layers=2, cdt=torch.float32, p_mag=0.0, hidden_p=0.0, attn_p=0.0).train()     # no dropout: batch 6 twice = same gradient
+        opt = AdamW(optimizer_grouped_parameters(m), lr=1e-3)
+        snaps = []
+        batches = [tb(weights.synthetic_bert_batch(4, 32, 47, 74, seed=700 + s), DEV) for s in range(8)]
+        with m.stream_scope():
+            # deterministic column-sum atomics are not guaranteed: compare the GEMM weight gradients (one writer per element)
+            wname = "bert.encoder.layer.1.intermediate.dense.weight"
+            w = dict(m.named_parameters())[wname]
+            m.train_step(*batches[0], optimizer=opt)                       # fresh zeros -> stored; AdamW zeroes
+            snaps.append(w.detach().clone())
+            m.train_step(*batches[1], optimizer=None)                      # known zero -> stored
+            snaps.append(w.grad.clone())
+            m.train_step(*batches[2], optimizer=None)                      # populated -> accumulated
+            snaps.append(w.grad.clone())
+            m.train_step(*batches[3], optimizer=opt)                       # accumulated, then updated and zeroed
+            snaps.append(w.detach().clone())
+            assert float(m.flat_grads.abs().max()) == 0.0
+            m.train_step(*batches[4], optimizer=opt, graph=False)          # Python-driven passes + optimizer.step()
+            snaps.append(w.detach().clone())
+            m.training_step(*batches[5])                                   # after step(): known zero -> stored
+            snaps.append(w.grad.clone())
+            m.zero_grad()
+            w.grad.add_(1.0)                                               # a gradient written by hand ...
+            m._core.mark_grads_zero(False)                                 # ... withdraws the promise
+            m.training_step(*batches[6])
+            snaps.append(w.grad.clone())
+            m.zero_grad()
+            m.training_step(*batches[6])
+            snaps.append(w.grad.clone())
+        torch.cuda.synchronize()
+        return snaps
+
+    a, b = run(True), run(False)
+    for i, (x, y) in enumerate(zip(a, b)):
+        err, ref = float((x - y).abs().max()), float(y.abs().max())
+        assert err <= 2e-5 * ref + 1e-8, "snapshot %d differs by %.3e (max %.3e)" % (i, err, ref)
+    assert float((a[6] - a[7] - 1.0).abs().max()) <= 1e-6                  # the hand-written +1 survived the backward
+    assert float((a[2] - a[1]).abs().max()) > 0.0                          # the second micro-step added something
+
+
 def test_pinned_batches_are_gathered_in_place_bit_exactly():
     """prefetch.PinnedBatchRing + the engine's gather launch: a batch handed over as pinned HOST tensors gives exactly the
     logits / loss / gradients of the same batch handed over as device tensors (`t.to(DEVICE)`), through every entry: eval
