@@ -62,6 +62,31 @@ __device__ __forceinline__ void stage_heads(char* const (&img)[N], int pitch, co
         }
 }
 
+// N images with their own row counts (allocated rows RA[n], valid rows rows[n]); RMAX = max RA: MAG-XLNet stages the 2L-row
+// relative-position keys next to the L-row q / k / v images.
+template <class T, int NTHR, int N, int RMAX>
+__device__ __forceinline__ void stage_heads_var(char* const (&img)[N], int pitch, const T* const (&src)[N], const size_t (&ld)[N],
+                                                const int (&ralloc)[N], const int (&rows)[N]) {
+    constexpr int CPR = AttnCfg<T>::ROWB / 16;
+    constexpr int IT = (RMAX * CPR + NTHR - 1) / NTHR;
+    u32x4 v[N][IT];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int id = threadIdx.x + it * NTHR, row = id / CPR, c = id % CPR;
+            v[n][it] = u32x4{0u, 0u, 0u, 0u};
+            if (id < ralloc[n] * CPR && row < rows[n]) v[n][it] = *(const u32x4*)((const char*)(src[n] + (size_t)row * ld[n]) + c * 16);
+        }
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int id = threadIdx.x + it * NTHR, row = id / CPR, c = id % CPR;
+            if (id < ralloc[n] * CPR) *(u32x4*)(img[n] + row * pitch + c * 16) = v[n][it];
+        }
+}
+
 // row-wise reduction across the 4 lanes {i, i+16, i+32, i+48} that share a query/key row
 __device__ __forceinline__ float quad_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 16, 64));

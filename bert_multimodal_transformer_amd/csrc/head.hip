@@ -7,6 +7,8 @@
 
 namespace mb {
 
+// Atomics on ONE address serialise at the L2 (measured: 48 samples x 2 atomics = most of a 15 us launch), so the four waves of
+// a block meet in LDS first: one loss atomic per block, one classifier-gradient atomic per column per block.
 template <int CH>
 __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ z, const float* __restrict__ Wc,
                                                        const float* __restrict__ bc, const float* __restrict__ labels,
@@ -14,38 +16,49 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__
                                                        float* loss_run, int B, int nl, DropKey drop) {
     drop.resolve();
     constexpr int H = CH * 256;
+    __shared__ float lsum[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
-    if (b >= B) return;
-    f32x4 pd[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int col = (c * 64 + lane) * 4;
-        f32x4 t = *(const f32x4*)(z + (size_t)b * H + col);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = tanhf(t[r]);
-        *(f32x4*)(pooled + (size_t)b * H + col) = t;
-        const uint32_t idx = (uint32_t)b * H + col;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pd[c][r] = t[r] * drop_mult(drop, idx + r);
-    }
-    for (int k = 0; k < nl; ++k) {
-        float s = 0.f;
+    const bool valid = b < B;
+    float mine = 0.f;
+    if (valid) {
+        f32x4 pd[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const f32x4 w = *(const f32x4*)(Wc + (size_t)k * H + (c * 64 + lane) * 4);
-            const f32x4 t = pd[c] * w;
-            s += (t[0] + t[1]) + (t[2] + t[3]);
+            const int col = (c * 64 + lane) * 4;
+            f32x4 t = *(const f32x4*)(z + (size_t)b * H + col);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = tanhf(t[r]);
+            *(f32x4*)(pooled + (size_t)b * H + col) = t;
+            const uint32_t idx = (uint32_t)b * H + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pd[c][r] = t[r] * drop_mult(drop, idx + r);
         }
-        s = wave_sum(s) + bc[k];
-        if (lane == 0) {
-            logits[(size_t)b * nl + k] = s;
-            if (labels) {
-                const float d = s - labels[(size_t)b * nl + k];
-                if (loss) atomicAdd(loss, d * d / (float)(B * nl));
-                if (loss_run) atomicAdd(loss_run, d * d / (float)(B * nl));
+        for (int k = 0; k < nl; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const f32x4 w = *(const f32x4*)(Wc + (size_t)k * H + (c * 64 + lane) * 4);
+                const f32x4 t = pd[c] * w;
+                s += (t[0] + t[1]) + (t[2] + t[3]);
+            }
+            s = wave_sum(s) + bc[k];
+            if (lane == 0) {
+                logits[(size_t)b * nl + k] = s;
+                if (labels) {
+                    const float d = s - labels[(size_t)b * nl + k];
+                    mine += d * d / (float)(B * nl);
+                }
             }
         }
+    }
+    if (labels == nullptr || (loss == nullptr && loss_run == nullptr)) return;      // uniform
+    if (lane == 0) lsum[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+        if (loss) atomicAdd(loss, t);
+        if (loss_run) atomicAdd(loss_run, t);
     }
 }
 
@@ -57,34 +70,45 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__
                                                        DropKey drop) {
     drop.resolve();
     constexpr int H = CH * 256;
+    __shared__ float wsum[4][H];
+    __shared__ float bsum[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
-    if (b >= B) return;
+    const bool valid = b < B;
+    const int bb = valid ? b : 0;
     f32x4 dpd[CH], pl[CH], dm[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int col = (c * 64 + lane) * 4;
         dpd[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        pl[c] = *(const f32x4*)(pooled + (size_t)b * H + col);
-        const uint32_t idx = (uint32_t)b * H + col;
+        pl[c] = *(const f32x4*)(pooled + (size_t)bb * H + col);
+        const uint32_t idx = (uint32_t)bb * H + col;
 #pragma unroll
         for (int r = 0; r < 4; ++r) dm[c][r] = drop_mult(drop, idx + r);
     }
     for (int k = 0; k < nl; ++k) {
-        float dl;
-        if (dlogits) dl = dlogits[(size_t)b * nl + k];
-        else dl = 2.0f * (logits[(size_t)b * nl + k] - labels[(size_t)b * nl + k]) / (float)(B * nl) * loss_scale;
+        float dl = 0.f;
+        if (valid) {
+            if (dlogits) dl = dlogits[(size_t)b * nl + k];
+            else dl = 2.0f * (logits[(size_t)b * nl + k] - labels[(size_t)b * nl + k]) / (float)(B * nl) * loss_scale;
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int col = (c * 64 + lane) * 4;
             dpd[c] += dl * *(const f32x4*)(Wc + (size_t)k * H + col);
-            if (dWc) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(dWc + (size_t)k * H + col + r, dl * pl[c][r] * dm[c][r]);
-            }
+            if (dWc) *(f32x4*)(&wsum[wave][col]) = dl * pl[c] * dm[c];
         }
-        if (dbc && lane == 0) atomicAdd(dbc + k, dl);
+        if (lane == 0) bsum[wave] = dl;
+        if (dWc || dbc) {                 // uniform
+            __syncthreads();
+            if (dWc)
+                for (int col = threadIdx.x; col < H; col += 256)
+                    atomicAdd(dWc + (size_t)k * H + col, (wsum[0][col] + wsum[1][col]) + (wsum[2][col] + wsum[3][col]));
+            if (dbc && threadIdx.x == 0) atomicAdd(dbc + k, (bsum[0] + bsum[1]) + (bsum[2] + bsum[3]));
+            __syncthreads();
+        }
     }
+    if (!valid) return;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int col = (c * 64 + lane) * 4;

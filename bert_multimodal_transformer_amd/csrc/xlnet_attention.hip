@@ -63,10 +63,13 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
     const int H = nh * 64;
     const size_t ld = (size_t)3 * H;
     const T* base = qkv + (size_t)b * L * ld + h * 64;
-    stage_head<T, LP, NW * 64>(Qi, PIT, base, ld, L);
-    stage_head<T, LP, NW * 64>(Ki, PIT, base + H, ld, L);
-    stage_head<T, LP, NW * 64>(Vi, PIT, base + 2 * H, ld, L);
-    stage_head<T, RP, NW * 64>(Ri, PIT, kr + (size_t)b * 2 * L * H + h * 64, (size_t)H, 2 * L);
+    {
+        char* const img[4] = {Qi, Ki, Vi, Ri};
+        const T* const src[4] = {base, base + H, base + 2 * H, kr + (size_t)b * 2 * L * H + h * 64};
+        const size_t lds[4] = {ld, ld, ld, (size_t)H};
+        const int ra[4] = {LP, LP, LP, RP}, rv[4] = {L, L, L, 2 * L};
+        stage_heads_var<T, NW * 64, 4, RP>(img, PIT, src, lds, ra, rv);       // every load in flight before the first LDS store
+    }
     for (int t = threadIdx.x; t < 16 * 64; t += NW * 64) {
         const int row = t >> 6, d = t & 63;
         *(T*)(Si + row * PIT + d * (int)sizeof(T)) = from_f<T>(row < 2 ? xp.seg_embed[((size_t)row * nh + h) * 64 + d] : 0.f);
@@ -181,24 +184,29 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
     }
 }
 
-// block-level column-sum flush: per-lane partials (own row only) -> 16-row shuffle tree -> waves summed in LDS -> atomics
-template <int NW>
-__device__ __forceinline__ void flush_colsum(f32x4 (&c4)[4], float* dst64, float* scratch, int lane, int wave) {
+// block-level column-sum flush of N [4][4] per-lane tiles at once: per-lane partials (own row only) -> 16-row DPP reduction ->
+// waves summed in LDS -> ONE atomic per column.  `scratch` holds N * NW * 64 floats and must be free (call after a barrier).
+// One pass for all five bias / segment-embedding gradients: flushed one tile at a time, each flush ended in a barrier that
+// waited for its atomics' round trip to L2.
+template <int NW, int N>
+__device__ __forceinline__ void flush_colsums(f32x4 (* const (&c4)[N])[4], float* const (&dst64)[N], float* scratch, int lane, int wave) {
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int n = 0; n < N; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float s = group16_sum(c4[dt][r]);
-            if ((lane & 15) == 0) scratch[wave * 64 + dt * 16 + (lane >> 4) * 4 + r] = s;
-        }
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = row16_sum_to_lane15((*c4[n])[dt][r]);
+                if ((lane & 15) == 15) scratch[(n * NW + wave) * 64 + dt * 16 + (lane >> 4) * 4 + r] = s;
+            }
     __syncthreads();
-    for (int j = threadIdx.x; j < 64; j += NW * 64) {
+    for (int j = threadIdx.x; j < N * 64; j += NW * 64) {
+        const int n = j >> 6, col = j & 63;
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) t += scratch[w * 64 + j];
-        atomicAdd(dst64 + j, t);
+        for (int w = 0; w < NW; ++w) t += scratch[(n * NW + w) * 64 + col];
+        atomicAdd(dst64[n] + col, t);
     }
-    __syncthreads();
 }
 
 // ================================================================================================ backward, query side
@@ -234,10 +242,13 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
     const int H = nh * 64;
     const size_t ld = (size_t)3 * H;
     const T* base = qkv + (size_t)b * L * ld + h * 64;
-    stage_head<T, LP, NW * 64>(Ki, PIT, base + H, ld, L);
-    stage_head<T, LP, NW * 64>(Vi, PIT, base + 2 * H, ld, L);
-    stage_head<T, LP, NW * 64>(Oi, PIT, dvec + (size_t)b * L * H + h * 64, (size_t)H, L);
-    stage_head<T, RP, NW * 64>(Ri, PIT, kr + (size_t)b * 2 * L * H + h * 64, (size_t)H, 2 * L);
+    {
+        char* const img[4] = {Ki, Vi, Oi, Ri};
+        const T* const src[4] = {base + H, base + 2 * H, dvec + (size_t)b * L * H + h * 64, kr + (size_t)b * 2 * L * H + h * 64};
+        const size_t lds[4] = {ld, ld, (size_t)H, (size_t)H};
+        const int ra[4] = {LP, LP, LP, RP}, rv[4] = {L, L, L, 2 * L};
+        stage_heads_var<T, NW * 64, 4, RP>(img, PIT, src, lds, ra, rv);
+    }
     for (int t = threadIdx.x; t < 192; t += NW * 64)
         sef[t] = t < 128 ? xp.seg_embed[((size_t)(t >> 6) * nh + h) * 64 + (t & 63)] : xp.r_s_bias[h * 64 + (t & 63)];
     for (int j = threadIdx.x; j < LP; j += NW * 64) {
@@ -333,11 +344,13 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
         }
         __syncthreads();
     }
-    flush_colsum<NW>(cw, d_rwb + h * 64, scratch, lane, wave);
-    flush_colsum<NW>(cr, d_rrb + h * 64, scratch, lane, wave);
-    flush_colsum<NW>(cs, d_rsb + h * 64, scratch, lane, wave);
-    flush_colsum<NW>(d0, d_seg + (size_t)h * 64, scratch, lane, wave);
-    flush_colsum<NW>(d1, d_seg + ((size_t)nh + h) * 64, scratch, lane, wave);
+    {
+        // the strip buffers are free after the last strip barrier: 5 * NW * 64 floats fit (NW * 16 * (SPIT + GPIT) bytes)
+        static_assert(NW * 16 * (SPIT + GPIT) >= 5 * NW * 64 * 4, "strip buffers hold the five column-sum tiles");
+        f32x4 (* const tiles[5])[4] = {&cw, &cr, &cs, &d0, &d1};
+        float* const dst[5] = {d_rwb + h * 64, d_rrb + h * 64, d_rsb + h * 64, d_seg + (size_t)h * 64, d_seg + ((size_t)nh + h) * 64};
+        flush_colsums<NW, 5>(tiles, dst, (float*)gstr, lane, wave);
+    }
 }
 
 // ================================================================================================ backward, key / position side
@@ -361,8 +374,12 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv_kernel(const T* __rest
     const int b = blockIdx.x / nh, h = blockIdx.x % nh;
     const int H = nh * 64;
     const size_t ld = (size_t)3 * H;
-    stage_head<T, LP, NW * 64>(Qi, PIT, qkv + (size_t)b * L * ld + h * 64, ld, L);
-    stage_head<T, LP, NW * 64>(Oi, PIT, dvec + (size_t)b * L * H + h * 64, (size_t)H, L);
+    {
+        char* const img[2] = {Qi, Oi};
+        const T* const src[2] = {qkv + (size_t)b * L * ld + h * 64, dvec + (size_t)b * L * H + h * 64};
+        const size_t lds[2] = {ld, (size_t)H};
+        stage_heads<T, LP, NW * 64, 2>(img, PIT, src, lds, L);
+    }
     for (int t = threadIdx.x; t < 128; t += NW * 64) bia[t] = t < 64 ? xp.r_w_bias[h * 64 + t] : xp.r_r_bias[h * 64 + t - 64];
     __syncthreads();
     char* St = strips + wave * 16 * SPIT;
