@@ -36,6 +36,10 @@ for _, k, n, w, wc, mb, mo, wa, wi, ai in sorted(rows, reverse=True)[:14]:
 PY
 timeout 60 tools/bin/gemm_bench > $O/gemm_bench.txt 2>&1
 timeout 60 tools/bin/gemm_bench --T 4096 > $O/gemm_bench_T4096.txt 2>&1
+# per-block phase stamps (100 MHz wall clock) of the GEMM launches and of the attention backward; launch floor
+MB_GEMM_TRACE=1 timeout 60 tools/bin/gemm_bench --trace 1 > $O/gemm_phases.txt 2>&1
+{ MB_ATTN_TRACE=1 timeout 60 tools/bin/attn_bench; MB_ATTN_TRACE=1 timeout 60 tools/bin/attn_bench --batch 32 --seq 128; timeout 60 tools/bin/attn_bench; } > $O/attention_phases.txt 2>&1
+timeout 60 tools/bin/launch_floor > $O/launch_floor.txt 2>&1
 # ---- 2. C5 shape and a second headline timing from the C++ driver
 { timeout 60 $SB --graph 1 --h2d 2 --steps 40 --warmup 8; timeout 60 $SB --graph 1 --h2d 2 --batch 32 --seq 128 --visual 35 --steps 30 --warmup 6; } > $O/step_bench.txt 2>&1
 ( cd /tmp && rm -rf /tmp/p_c5 && timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c5 -o sb -- $SB --graph 1 --h2d 2 --batch 32 --seq 128 --visual 35 --steps 12 --warmup 4 > /dev/null 2>&1 )
