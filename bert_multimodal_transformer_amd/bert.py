@@ -423,6 +423,28 @@ class _Core(object):
         """all_hidden_states of the last forward: n_layers + 1 tensors [B, L, H] (bert.py:227-237 / xlnet.py:363-392)"""
         return tuple(self._act(self._fn("hidden_state")(self.handle, i), B, L) for i in range(self.n_layers + 1))
 
+    def xl_attentions(self, B, L, training):
+        """MAG-XLNet output_attentions (xlnet.py:387-427): n_layers tensors [B, n_head, L, L] fp32, the attention probabilities
+        after dropout -- the probabilities the forward saved for its backward times, in train mode, the counter-hash dropout mask
+        of the layer's site (regenerated on the host: an optional debugging output, not a hot path)."""
+        from . import rng
+        nh, p = self.config.n_head, float(self.config.dropout)
+        es = 2 if self.dt == _lib.DT_BF16 else 4
+        out = []
+        for l in range(self.n_layers):
+            lp = C.c_int()
+            ptr = self.lib.mb_xlnet_attention_probs(self.handle, l, C.byref(lp))
+            if not ptr:
+                raise _lib.MagbertError("no forward has run")
+            LP = lp.value
+            off = ptr - self.ws.data_ptr()
+            a = self.ws[off: off + B * nh * LP * LP * es].view(self.compute_dtype).view(B, nh, LP, LP)[:, :, :L, :L].float()
+            if training and p > 0.0:
+                key = rng.make_key(self.seed, self.step, rng.XS_LAYER0 + 8 * l, p)
+                a = a * torch.from_numpy(rng.keep_mult(B * nh * L * L, key)).view(B, nh, L, L).to(a.device)
+            out.append(a.contiguous())
+        return tuple(out)
+
     def attention_buffer(self, B, L):
         """arms the next forward to write every layer's attention probabilities (MAG-BERT); returns the buffer"""
         if self.kind != "bert":

@@ -486,6 +486,11 @@ const void* mb_xlnet_hidden_state(const mb_xlnet_engine* e, int i) {      // inp
     if (!e || !e->ws || i < 0 || i > e->c.n_layer) return nullptr;
     return e->ws + e->ws_x[i];
 }
+const void* mb_xlnet_attention_probs(const mb_xlnet_engine* e, int layer, int* padded_len) {
+    if (!e || !e->ws || !e->ids || layer < 0 || layer >= e->c.n_layer) return nullptr;
+    if (padded_len) *padded_len = (e->L + 31) / 32 * 32;
+    return e->ws + e->lw[layer].psave;
+}
 const void* mb_xlnet_sequence_output(const mb_xlnet_engine* e) { return e->ws ? e->ws + e->ws_x[e->c.n_layer] : nullptr; }
 
 int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap) {

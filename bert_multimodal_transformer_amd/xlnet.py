@@ -6,7 +6,8 @@ Same class names, constructor `(config, multimodal_config)`, forward argument or
 r_w_bias,seg_embed,layer_norm.*}, transformer.layer.{i}.ff.{layer_norm,layer_1,layer_2}.*, transformer.MAG.*,
 sequence_summary.summary.*, logits_proj.*).  Built for the configuration the reference driver runs
 (multimodal_driver.py:363-370: attention_mask + token_type_ids, no mems / perm_mask / target_mapping / input_mask /
-head_mask / inputs_embeds; those raise NotImplementedError), sequence length <= 64, MAG injected in front of layer
+head_mask / inputs_embeds; those raise NotImplementedError; output_hidden_states / output_attentions are served from the
+activations the engine keeps for its backward), sequence length <= 64, MAG injected in front of layer
 XLNET_INJECTION_INDEX (global_configs.py:19, xlnet.py:371-372).
 """
 import torch
@@ -73,7 +74,8 @@ class MAG_XLNetModel(_XlBase):
                 token_type_ids=None, input_mask=None, head_mask=None, inputs_embeds=None, use_cache=True,
                 output_attentions=None, output_hidden_states=None):
         self._unsupported(mems=mems, perm_mask=perm_mask, target_mapping=target_mapping, input_mask=input_mask,
-                          head_mask=head_mask, inputs_embeds=inputs_embeds, output_attentions=output_attentions)
+                          head_mask=head_mask, inputs_embeds=inputs_embeds)
+        output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
         if input_ids is None:
@@ -87,6 +89,8 @@ class MAG_XLNetModel(_XlBase):
         outputs = (self._core.sequence_output(B, L),)
         if output_hidden_states:               # xlnet.py:363-392: the input of every layer (before the MAG injection) + the last output
             outputs = outputs + (self._core.hidden_states(B, L),)
+        if output_attentions:                  # xlnet.py:387-427: per layer [B, n_head, L, L], after the attention dropout
+            outputs = outputs + (self._core.xl_attentions(B, L, self.training),)
         return outputs
 
 
@@ -110,7 +114,8 @@ class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
                 token_type_ids=None, input_mask=None, head_mask=None, inputs_embeds=None, use_cache=True, labels=None,
                 output_attentions=None, output_hidden_states=None):
         self._unsupported(mems=mems, perm_mask=perm_mask, target_mapping=target_mapping, input_mask=input_mask,
-                          head_mask=head_mask, inputs_embeds=inputs_embeds, output_attentions=output_attentions)
+                          head_mask=head_mask, inputs_embeds=inputs_embeds)
+        output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
         if attention_mask is None:
@@ -124,6 +129,8 @@ class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
         outputs = (logits,)
         if output_hidden_states:
             outputs = outputs + (core.hidden_states(input_ids.shape[0], input_ids.shape[1]),)
+        if output_attentions:
+            outputs = outputs + (core.xl_attentions(input_ids.shape[0], input_ids.shape[1], self.training),)
         if labels is not None:                                        # xlnet.py:515-524
             if self.num_labels == 1:
                 loss = torch.nn.functional.mse_loss(logits.view(-1), labels.to(logits.device).float().view(-1))

@@ -267,6 +267,11 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
 const void* mb_xlnet_sequence_output(const mb_xlnet_engine* e);
 /* input of layer i as XLNetModel collects it with output_hidden_states (xlnet.py:363-392; before the MAG injection), i = n_layer: the last output */
 const void* mb_xlnet_hidden_state(const mb_xlnet_engine* e, int i);
+/* output_attentions (xlnet.py:387-427): the softmax probabilities the last forward saved for its backward, layer `layer`:
+ * [B * n_head][LP][LP] in the engine's dtype, LP = *padded_len = L rounded up to 32 (entries beyond L are zero), BEFORE the
+ * attention dropout (the host multiplies the counter-hash mask of site XS_LAYER0 + 8 * layer in train mode).  Valid until the
+ * next forward. */
+const void* mb_xlnet_attention_probs(const mb_xlnet_engine* e, int layer, int* padded_len);
 int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap);
 int mb_xlnet_mark_grads_zero(mb_xlnet_engine* e, int known_zero);      /* as mb_bert_mark_grads_zero */
 /* the MAG-XLNet counterparts of mb_bert_train_step / mb_bert_load_batch / mb_bert_graph_stats (same contracts; one iteration of

@@ -68,6 +68,7 @@ class XLNetRelativeAttention(nn.Module):
         score = (ac + bd + ef) * self.scale
         score = score - 1e30 * torch.einsum("ijbn->bnij", attn_mask)
         p = self.dropout(F.softmax(score, dim=3))
+        self.last_probs = p                 # what output_attentions returns (xlnet.py:387-427): [B, n_head, L, L], after the dropout
         vec = torch.einsum("bnij,jbnd->ibnd", p, v)
         out = self.dropout(torch.einsum("ibnd,hnd->ibh", vec, self.o))
         return self.layer_norm(out + h)

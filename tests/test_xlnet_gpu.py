@@ -126,6 +126,31 @@ def test_base_model_sequence_output_fp32():
     assert err <= 1e-3
 
 
+def test_output_attentions_and_hidden_states_fp32():
+    """f-4 for MAG-XLNet (xlnet.py:363-427): output_attentions = the probabilities the forward keeps for its backward, one
+    [B, n_head, L, L] tensor per layer, on the base model and passed through by the classification model (eval mode here; the
+    train-mode tensors -- after the attention dropout -- are compared in test_train_mode_dropout_mask_replay)."""
+    layers, B, L, nh = 2, 3, 40, 12
+    m = MAG_XLNetForSequenceClassification(XLNetConfig(n_layer=layers), MultimodalConfig(1.0, 0.5), 47, 74).eval()
+    m.load_state_dict({n: torch.from_numpy(weights.make_param(n, tuple(q.shape), "test")) for n, q in m.named_parameters()})
+    o = X.load_deterministic(X.MAG_XLNetForSequenceClassification(X.XLNetConfigLite(n_layer=layers), X.MultimodalConfig(1.0, 0.5), 47, 74)).eval()
+    b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=83)
+    ids, vis, aco, mask, seg, _ = tb(b, DEV)
+    with torch.no_grad():
+        out = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, output_attentions=True, output_hidden_states=True)
+        o(*tb(b)[:5])
+        base = m.transformer(ids, vis, aco, token_type_ids=seg, attention_mask=mask, output_attentions=True)
+    assert len(out) == 3 and len(out[1]) == layers + 1 and len(out[2]) == layers
+    for l in range(layers):
+        a, r = out[2][l].cpu(), o.transformer.layer[l].rel_attn.last_probs
+        assert tuple(a.shape) == (B, nh, L, L)
+        err = float((a - r).abs().max())
+        print("layer %d attention probabilities max|err| %.3e" % (l, err))
+        assert err <= 1e-5
+        assert float((a.sum(-1) - 1.0).abs().max()) <= 1e-4
+    assert len(base) == 2 and float((base[1][0] - out[2][0]).abs().max()) == 0.0
+
+
 def test_gradients_match_oracle_fp32(golden):
     """train mode, every dropout p = 0: loss and all parameter gradients vs the oracle (and the golden loss)."""
     m = build(p_mag=0.0, p=0.0).train()
@@ -184,7 +209,8 @@ def test_train_mode_dropout_mask_replay(cdt, tol_logit, tol_grad):
     core = m._core
     b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=41)
     ids, vis, aco, mask, seg, lab = tb(b, DEV)
-    logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
+    out = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None, output_attentions=True)
+    logits, att = out[0], out[1]
     torch.nn.MSELoss()(logits.view(-1), lab.view(-1)).backward()
     seed, step = core.seed, core.step
     mult = lambda site, p, n: torch.from_numpy(rng.keep_mult(n, rng.make_key(seed, step, site, p)))
@@ -204,6 +230,10 @@ def test_train_mode_dropout_mask_replay(cdt, tol_logit, tol_grad):
     err = float((logits.detach().cpu() - lo.detach()).abs().max())
     print("xlnet train-mode logits max|err|:", err)
     assert err <= tol_logit
+    # output_attentions in train mode: the probabilities AFTER the (replayed) attention dropout
+    perr = max(float((att[l].cpu() - lyr.rel_attn.last_probs.detach()).abs().max()) for l, lyr in enumerate(o.transformer.layer))
+    print("xlnet train-mode attention probabilities max|err|:", perr)
+    assert perr <= (1e-5 if cdt == torch.float32 else 2e-2)
     _grad_report(m, o, tol_grad, frobenius=(cdt == torch.bfloat16))
 
 
