@@ -83,12 +83,6 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
-// reduce across the 16 lanes that share (lane >> 4)
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 // Sum over the 16 lanes of a DPP row (lanes that share lane >> 4), valid in lane 15 of the row only: an inclusive scan with four
 // v_add_f32 row_shr steps (out-of-row sources read 0) -- plain VALU, no LDS crossbar traffic like the ds_bpermute behind
 // __shfl_xor.  For reductions whose result one lane per row writes out.
@@ -99,11 +93,6 @@ __device__ __forceinline__ float row16_sum_to_lane15(float v) {
     v += MB_ROW_SHR(v, 4);
     v += MB_ROW_SHR(v, 8);
 #undef MB_ROW_SHR
-    return v;
-}
-__device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 
@@ -134,20 +123,9 @@ __device__ __forceinline__ void mma16(f32x4& acc, f32x4 x, f32x4 y) {
 // IS e, so one v_exp + one v_rcp + a Horner chain serve gelu and gelu' together (libm's erff is two branchy ranges per call;
 // these sit in the epilogues of the two widest GEMMs).  1.5e-7 absolute on Phi is below fp32 rounding of the products it
 // enters, far inside the 1e-3 logit contract of the fp32 parity mode.
-__device__ __forceinline__ void gelu_parts(float x, float& Phi, float& e) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    e = __expf(-0.5f * x * x);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);       // v_rcp_f32 (1 ulp); an IEEE division here is ten instructions
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float half_erfc = 0.5f * poly * e;            // 0.5 * erfc(|x| / sqrt 2)
-    Phi = x >= 0.f ? 1.0f - half_erfc : half_erfc;
-}
-__device__ __forceinline__ float gelu_f(float x) { float P, e; gelu_parts(x, P, e); return x * P; }
-__device__ __forceinline__ float dgelu_f(float x) { float P, e; gelu_parts(x, P, e); return P + x * 0.39894228040143268f * e; }
-
-// Two elements per instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: packed fp32 runs at twice the scalar VALU rate;
-// only the two transcendentals and the sign transfer stay per element).  Same formula as gelu_parts, evaluated pairwise --
-// the GELU epilogue of the [T x 3072] GEMM was 9 us of VALU time per launch with the scalar form.
+// Evaluated two elements per instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: packed fp32 runs at twice the scalar VALU
+// rate; only the two transcendentals -- v_exp_f32, v_rcp_f32, no IEEE division -- and the sign transfer stay per element): the
+// GELU epilogue of the [T x 3072] GEMM was 9 us of VALU time per launch in scalar form.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gelu_pair(f32x2 x, f32x2& g, f32x2& dg) {
     const f32x2 ax = {fabsf(x.x), fabsf(x.y)};

@@ -225,15 +225,14 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
     constexpr int NT = LP / 16, DSL = 64 / C::SLAB, LSL = LP / C::SLAB, RSL = RP / C::SLAB;
     // Q is not staged: it is only read once per row at the end (q_i + r_s_bias for the segment-embedding gradient), straight from
     // HBM/L2.  Without its image the block needs 75 KB of LDS instead of 84 KB -> two blocks per CU (576 blocks: 2 rounds, not 3).
-    __shared__ __attribute__((aligned(16))) char smem[(3 * LP + RP) * PIT + NW * 16 * (SPIT + GPIT) + (NW * 64 + 192 + 2 * LP) * 4];
+    __shared__ __attribute__((aligned(16))) char smem[(3 * LP + RP) * PIT + NW * 16 * (SPIT + GPIT) + (192 + 2 * LP) * 4];
     char* Ki = smem;
     char* Vi = Ki + LP * PIT;
     char* Oi = Vi + LP * PIT;                          // dvec image
     char* Ri = Oi + LP * PIT;
     char* gstr = Ri + RP * PIT;
     char* sstr = gstr + NW * 16 * SPIT;
-    float* scratch = (float*)(sstr + NW * 16 * GPIT);
-    float* sef = scratch + NW * 64;                    // se0[64] | se1[64] | rsb[64]
+    float* sef = (float*)(sstr + NW * 16 * GPIT);     // se0[64] | se1[64] | rsb[64]
     int* segv = (int*)(sef + 192);
     int* padf = segv + LP;
 
