@@ -388,6 +388,7 @@ int mb_bert_bind(mb_bert_engine* e, float* params, float* grads, void* shadow, v
     if (!params || !workspace || ws_bytes < e->ws_bytes) return MB_ERR_ARG;
     if (e->c.dtype == DT_BF16 && !shadow) return MB_ERR_ARG;
     e->P = params; e->G = grads; e->SH = (char*)shadow; e->ws = (char*)workspace;
+    e->grads_zero = false;                 // a newly bound gradient buffer: nothing is known about its contents
     e->ws_zeroed = false; e->padT = -1;
     e->drop_graphs();                         // captured against the old buffers
     return MB_OK;
