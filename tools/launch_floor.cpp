@@ -69,5 +69,38 @@ int main() {
     timeit("load+store 3.7 MB each", st, reps, [&](int i) { hipLaunchKernelGGL(k_load_store, dim3(456), dim3(256), 0, st, in[i % nset], out[i % nset], 2); });
     timeit("load+store 29.9 MB each", st, reps, [&](int i) { hipLaunchKernelGGL(k_load_store, dim3(456), dim3(256), 0, st, in[i % nset], out[i % nset], 16); });
     timeit("load+store 29.9 MB each, 1824 blocks x 4", st, reps, [&](int i) { hipLaunchKernelGGL(k_load_store, dim3(1824), dim3(256), 0, st, in[i % nset], out[i % nset], 4); });
+    // what ONE fork / join costs a replayed graph: 200 small kernels in a chain vs the same chain with kernels 100..119 on a second
+    // stream next to kernels 120..139 (event fork + event join captured as graph dependencies)
+    {
+        hipStream_t s2; HCK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        hipEvent_t f, j, e0, e1; HCK(hipEventCreateWithFlags(&f, hipEventDisableTiming)); HCK(hipEventCreateWithFlags(&j, hipEventDisableTiming));
+        HCK(hipEventCreate(&e0)); HCK(hipEventCreate(&e1));
+        for (int branches = 0; branches <= 12; branches = branches ? branches * 12 : 1) {
+            hipGraph_t g; hipGraphExec_t ge;
+            HCK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int per = branches ? 200 / branches : 200;
+            for (int i = 0; i < 200; ++i) {
+                const bool fork_here = branches && (i % per) == per / 2;
+                if (fork_here) {
+                    HCK(hipEventRecord(f, st)); HCK(hipStreamWaitEvent(s2, f, 0));
+                    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(k_store, dim3(456), dim3(256), 0, s2, out[1], 2);
+                    HCK(hipEventRecord(j, s2));
+                }
+                hipLaunchKernelGGL(k_store, dim3(456), dim3(256), 0, st, out[0], 2);
+                if (branches && (i % per) == per / 2 + 4) HCK(hipStreamWaitEvent(st, j, 0));
+            }
+            HCK(hipStreamEndCapture(st, &g));
+            HCK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            for (int w = 0; w < 3; ++w) HCK(hipGraphLaunch(ge, st));
+            HCK(hipStreamSynchronize(st));
+            HCK(hipEventRecord(e0, st));
+            for (int r = 0; r < 10; ++r) HCK(hipGraphLaunch(ge, st));
+            HCK(hipEventRecord(e1, st)); HCK(hipEventSynchronize(e1));
+            float ms; HCK(hipEventElapsedTime(&ms, e0, e1));
+            printf("graph of 200 chained 3.7-MB store kernels, %2d fork/join(s) with 4 extra kernels each on a second stream: %8.1f us per replay\n",
+                   branches, ms * 100.0);
+            HCK(hipGraphExecDestroy(ge)); HCK(hipGraphDestroy(g));
+        }
+    }
     return 0;
 }
