@@ -33,6 +33,8 @@ struct mb_bert_engine : StepMixin {
     std::vector<LayerWs> lw;
     size_t ws_ds[2], ws_dzd[2], ws_ds2[2], ws_dzd2[2], ws_du[2], ws_dqkv[2];   // dY operands of the wgrads: ping-pong by layer parity
     size_t ws_dxa, ws_dxb, ws_dctx, ws_dsum, ws_dz, ws_lnp_a, ws_lnp_b;
+    size_t lnp_stride = 0;         // floats per layer in each of the two LayerNorm partial buffers
+    int lnp_nblk = 0;              // slabs per layer written by the current backward
     size_t ws_ids, ws_seg, ws_mask, ws_labels;    // (inputs are caller pointers; kept for the backward)
     size_t ws_bytes;
     // bound buffers
@@ -155,7 +157,9 @@ static void build_layout(mb_bert_engine* e) {
         e->ws_dzd2[k] = w.take(T * H * es); e->ws_du[k] = w.take(T * I * es); e->ws_dqkv[k] = w.take(T * 3 * H * es);
     }
     e->ws_dctx = w.take(T * H * es); e->ws_dsum = w.take(T * H * 4); e->ws_dz = w.take((size_t)c.max_batch * H * es);
-    e->ws_lnp_a = w.take(ln_partials_floats((int)T, (int)H) * 4); e->ws_lnp_b = w.take(ln_partials_floats((int)T, (int)H) * 4);
+    // LayerNorm partial slabs of EVERY layer (2 x 2.8 MB per layer at T = 2400): the single-call step reduces them in one launch
+    e->lnp_stride = ln_partials_floats((int)T, (int)H);
+    e->ws_lnp_a = w.take(e->lnp_stride * 4 * c.num_layers); e->ws_lnp_b = w.take(e->lnp_stride * 4 * c.num_layers);
     e->carve_step(w, T, (int)V, (int)A, c.max_batch, c.num_labels, SITE_LAYER0 + 4 * c.num_layers);
     e->ws_bytes = w.off;
 }
@@ -518,8 +522,10 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                 return (int)hipStreamWaitEvent(ss, sev[k], 0);
             };
             int nblk = 0;
-            float* lnp_a = (float*)(ws + e->ws_lnp_a);
-            float* lnp_b = (float*)(ws + e->ws_lnp_b);
+            float* lnp_a = (float*)(ws + e->ws_lnp_a) + (size_t)l * e->lnp_stride;
+            float* lnp_b = (float*)(ws + e->ws_lnp_b) + (size_t)l * e->lnp_stride;
+            // single-call step: nobody needs this layer's LayerNorm / bias gradients before AdamW -> all layers reduced at once
+            const bool defer_ln = e->in_step && NL <= MB_LN_MAX_LAYERS;
             // LN2 + dropout backward (column sums -> per-block partial slabs, reduced once per layer below)
             CK(ln_backward_partials(dt, dx, ws + w.s2, P + o.ln2w, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, dsA,
                                     hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(SITE_LAYER0 + 4 * l + 2, c.hidden_dropout), st));
@@ -554,9 +560,19 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             CK(fork(2));
             CK(wgrad(dt, H, H, Tk, dzdB, H, ws + w.ctx, H, G + o.wo, H, ss));
             }
-            {
+            e->lnp_nblk = nblk;
+            if (!defer_ln) {
                 float* const dst6[6] = {G + o.ln2w, G + o.ln2b, G + o.b2, G + o.ln1w, G + o.ln1b, G + o.bo};
                 CK(ln_reduce_partials(lnp_a, lnp_b, nblk, H, dst6, st));
+            } else if (l == 0) {
+                LnReduceDst dst = {};
+                for (int k = 0; k < NL; ++k) {
+                    const LayerOff& ok = e->lo[k];
+                    float* const d6[6] = {G + ok.ln2w, G + ok.ln2b, G + ok.b2, G + ok.ln1w, G + ok.ln1b, G + ok.bo};
+                    for (int q = 0; q < 6; ++q) dst.d[k][q] = d6[q];
+                }
+                CK(ln_reduce_partials_layers((const float*)(ws + e->ws_lnp_a), (const float*)(ws + e->ws_lnp_b), e->lnp_stride, NL, nblk, H,
+                                             dst, st));
             }
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.wo), H, ws + e->ws_dctx, H, nullptr, nullptr, nullptr,
                     nullptr, 0, kNoDrop, 1, 0, st));

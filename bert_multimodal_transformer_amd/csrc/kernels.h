@@ -82,6 +82,13 @@ size_t ln_partials_floats(int rows, int H);
 int ln_backward_partials(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                          void* dx, void* dx_drop, float* partials, int* nblk, int rows, int H, DropKey drop_in, hipStream_t st);
 int ln_reduce_partials(const float* partials_a, const float* partials_b, int nblk, int H, float* const* dst6, hipStream_t st);
+// The same for `layers` layers in ONE launch: layer l's slabs start at partials_x + l * layer_stride floats, its six destinations
+// are dst[l][0..5].  (A single-process step has no use for a layer's LayerNorm / bias gradients before AdamW: twelve 5-us
+// launches become one.)
+#define MB_LN_MAX_LAYERS 32
+struct LnReduceDst { float* d[MB_LN_MAX_LAYERS][6]; };
+int ln_reduce_partials_layers(const float* partials_a, const float* partials_b, size_t layer_stride, int layers, int nblk, int H,
+                              const LnReduceDst& dst, hipStream_t st);
 
 // BertEmbeddings: e = dropout(LN(word[ids] + pos[l] + type[seg])).
 int embed_ln_forward(int dtype, const int64_t* ids, const int64_t* seg, const float* word, const float* pos,

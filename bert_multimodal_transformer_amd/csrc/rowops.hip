@@ -183,6 +183,28 @@ __global__ void __launch_bounds__(256) ln_reduce_kernel(const float* __restrict_
         atomicAdd(dst + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// all layers at once: blockIdx.z = layer * 8 + slab octant
+__global__ void __launch_bounds__(256) ln_reduce_layers_kernel(const float* __restrict__ pa, const float* __restrict__ pb,
+                                                               size_t layer_stride, int nblk, int H, LnReduceDst dst) {
+    const int q = blockIdx.y;
+    const int layer = blockIdx.z >> 3;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = (threadIdx.x >> 6) + 4 * (blockIdx.z & 7);
+    constexpr int nparts = 32;
+    __shared__ float red[4][64];
+    float* out = dst.d[layer][q];
+    const float* src = (q < 3 ? pa : pb) + (size_t)layer * layer_stride;
+    float s = 0.f;
+    if (out != nullptr && col < H) {
+        const int qq = q % 3;
+        for (int b = part; b < nblk; b += nparts) s += src[((size_t)b * 3 + qq) * H + col];
+    }
+    red[threadIdx.x >> 6][threadIdx.x & 63] = s;
+    __syncthreads();
+    if ((threadIdx.x >> 6) == 0 && out != nullptr && col < H)
+        atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // ------------------------------------------------------------------------------------------ embeddings
 template <class T, int CH>
 __global__ void __launch_bounds__(256) embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
@@ -411,6 +433,14 @@ int ln_reduce_partials(const float* pa, const float* pb, int nblk, int H, float*
     if (nblk <= 0) return MB_OK;
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((H + 63) / 64, 6, 8), dim3(256), 0, st, pa, pb, nblk, H, d[0], d[1], d[2], d[3], d[4],
                        d[5]);
+    return (int)hipGetLastError();
+}
+
+int ln_reduce_partials_layers(const float* pa, const float* pb, size_t layer_stride, int layers, int nblk, int H,
+                              const LnReduceDst& dst, hipStream_t st) {
+    if (nblk <= 0 || layers <= 0) return MB_OK;
+    if (layers > MB_LN_MAX_LAYERS) return MB_ERR_SHAPE;
+    hipLaunchKernelGGL(ln_reduce_layers_kernel, dim3((H + 63) / 64, 6, 8 * layers), dim3(256), 0, st, pa, pb, layer_stride, nblk, H, dst);
     return (int)hipGetLastError();
 }
 
