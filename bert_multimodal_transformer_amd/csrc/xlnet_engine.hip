@@ -32,6 +32,7 @@ struct mb_xlnet_engine : StepMixin {
     std::vector<XlLayerWs> lw;
     size_t ws_dsa[2], ws_dzda[2], ws_dsb[2], ws_dzdb[2], ws_du[2], ws_dqkv[2], ws_dkr[2];   // dY operands of the weight gradients: ping-pong by layer parity
     size_t ws_dxa, ws_dxb, ws_dvec, ws_gsave, ws_dz, ws_dxs, ws_lnp_a, ws_lnp_b;
+    size_t lnp_stride = 0;         // floats per layer in each of the two LayerNorm partial buffers
     size_t ws_bytes;
     float* P = nullptr; float* G = nullptr; char* SH = nullptr; char* ws = nullptr;
     const int64_t* ids = nullptr; const int64_t* seg = nullptr; const int64_t* mask = nullptr;
@@ -150,7 +151,8 @@ static void xl_build_layout(mb_xlnet_engine* e) {
     }
     e->ws_dvec = w.take(T * H * es); e->ws_gsave = w.take(PP * es);
     e->ws_dz = w.take((size_t)c.max_batch * H * es); e->ws_dxs = w.take((size_t)c.max_batch * H * es);
-    e->ws_lnp_a = w.take(ln_partials_floats((int)T, (int)H) * 4); e->ws_lnp_b = w.take(ln_partials_floats((int)T, (int)H) * 4);
+    e->lnp_stride = ln_partials_floats((int)T, (int)H);        // per-layer slabs: the single-call step reduces all layers at once
+    e->ws_lnp_a = w.take(e->lnp_stride * 4 * c.n_layer); e->ws_lnp_b = w.take(e->lnp_stride * 4 * c.n_layer);
     e->carve_step(w, T, (int)V, (int)A, c.max_batch, c.num_labels, XS_LAYER0 + 8 * c.n_layer);
     e->ws_bytes = w.off;
 }
@@ -328,8 +330,9 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
             char* du = ws + e->ws_du[par];
             char* dkr = ws + e->ws_dkr[par];
             int nblk = 0;
-            float* lnp_a = (float*)(ws + e->ws_lnp_a);
-            float* lnp_b = (float*)(ws + e->ws_lnp_b);
+            float* lnp_a = (float*)(ws + e->ws_lnp_a) + (size_t)l * e->lnp_stride;
+            float* lnp_b = (float*)(ws + e->ws_lnp_b) + (size_t)l * e->lnp_stride;
+            const bool defer_ln = e->in_step && NL <= MB_LN_MAX_LAYERS;      // as in engine.hip: one reduction launch for all layers
             // ---- feed-forward block
             CK(ln_backward_partials(dt, dx, ws + w.s2, P + o.fflnw, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, dsA,
                                     hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(XS_LAYER0 + 8 * l + 3, pd), st));
@@ -354,9 +357,18 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
             // ---- relative attention block
             CK(ln_backward_partials(dt, t1, ws + w.s1, P + o.ralnw, (const float*)(ws + w.st1), (const float*)(ws + w.st1) + T, dsB,
                                     hd ? dzdB : nullptr, lnp_b, &nblk, T, H, e->key(XS_LAYER0 + 8 * l + 1, pd), st));
-            {
+            if (!defer_ln) {
                 float* const dst6[6] = {G + o.fflnw, G + o.fflnb, G + o.b2, G + o.ralnw, G + o.ralnb, nullptr};
                 CK(ln_reduce_partials(lnp_a, lnp_b, nblk, H, dst6, st));
+            } else if (l == 0) {
+                LnReduceDst dst = {};
+                for (int k = 0; k < NL; ++k) {
+                    const XlLayerOff& ok = e->lo[k];
+                    float* const d6[6] = {G + ok.fflnw, G + ok.fflnb, G + ok.b2, G + ok.ralnw, G + ok.ralnb, nullptr};
+                    for (int q = 0; q < 6; ++q) dst.d[k][q] = d6[q];
+                }
+                CK(ln_reduce_partials_layers((const float*)(ws + e->ws_lnp_a), (const float*)(ws + e->ws_lnp_b), e->lnp_stride, NL, nblk, H,
+                                             dst, st));
             }
             if (!grouped) CK(wgrad(dt, H, H, Tk, dzdB, H, ws + w.vec, H, G + o.o, H, st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.o), H, ws + e->ws_dvec, H, nullptr, nullptr, nullptr, nullptr, 0,
