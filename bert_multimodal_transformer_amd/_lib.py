@@ -75,6 +75,7 @@ PROTOTYPES = {
     "mb_debug_gemm_trace": (_i, [_vp, _i]),
     "mb_debug_attention_trace": (_i, [_vp, _i]),
     "mb_xlnet_attention_probs": (_vp, [_vp, _i, C.POINTER(_i)]),
+    "mb_xlnet_set_head_mask": (_i, [_vp, _vp]),
     "mb_bert_mark_grads_zero": (_i, [_vp, _i]),
     "mb_xlnet_mark_grads_zero": (_i, [_vp, _i]),
     "mb_bert_set_head_mask": (_i, [_vp, _vp]),

@@ -284,8 +284,12 @@ class _Core(object):
         """head_mask [n_layers][n_heads] / inputs_embeds [B*L][H] (fp32 device tensors or None) -> engine state; sticky in the
         engine, so every pass states what it wants (the single-call step refuses to run with either set)."""
         if self.kind != "bert":
-            if head_mask is not None or inputs_embeds is not None:
-                raise NotImplementedError("head_mask / inputs_embeds are built for MAG-BERT only")
+            if inputs_embeds is not None:
+                raise NotImplementedError("inputs_embeds is built for MAG-BERT only")
+            if head_mask is None and self._optional == (None, None):
+                return
+            _lib.check(self.lib.mb_xlnet_set_head_mask(self.handle, _lib.ptr(head_mask)))
+            self._optional = (head_mask, None)
             return
         if head_mask is None and inputs_embeds is None and self._optional == (None, None):
             return
@@ -306,7 +310,7 @@ class _Core(object):
         5-D form of it) -> fp32 [n_layers][n_heads] on the device.  Masks that differ per sample or per position are not built."""
         if head_mask is None:
             return None
-        NL, nh = self.n_layers, self.config.num_attention_heads
+        NL, nh = self.n_layers, (self.config.num_attention_heads if self.kind == "bert" else self.config.n_head)
         hm = torch.as_tensor(head_mask).to(self.device, torch.float32)
         if hm.dim() == 1 and hm.numel() == nh:
             hm = hm[None].expand(NL, nh)
@@ -442,6 +446,8 @@ class _Core(object):
             if training and p > 0.0:
                 key = rng.make_key(self.seed, self.step, rng.XS_LAYER0 + 8 * l, p)
                 a = a * torch.from_numpy(rng.keep_mult(B * nh * L * L, key)).view(B, nh, L, L).to(a.device)
+            if self._optional[0] is not None:            # head_mask: attn_prob * head_mask (xlnet.py:383)
+                a = a * self._optional[0][l].view(1, nh, 1, 1)
             out.append(a.contiguous())
         return tuple(out)
 

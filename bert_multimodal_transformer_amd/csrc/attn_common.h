@@ -87,6 +87,16 @@ __device__ __forceinline__ void stage_heads_var(char* const (&img)[N], int pitch
         }
 }
 
+// multiplies rows [0, LP) x 64 elements of a staged image by s (head_mask: every gradient of a head is linear in the head's dvec,
+// so scaling the staged dvec image scales them all).  Call between two barriers.
+template <class T, int LP, int NTHR>
+__device__ __forceinline__ void scale_image(char* img, int pitch, float s) {
+    for (int id = threadIdx.x; id < LP * 64; id += NTHR) {
+        T* p = (T*)(img + (id >> 6) * pitch) + (id & 63);
+        *p = from_f<T>(to_f(*p) * s);
+    }
+}
+
 // row-wise reduction across the 4 lanes {i, i+16, i+32, i+48} that share a query/key row
 __device__ __forceinline__ float quad_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 16, 64));

@@ -146,11 +146,12 @@ int attention_trace_fetch(unsigned long long* host_out, int max_blocks);     // 
 // relative attention core, L <= 64.  qkv [T][3H] token-major, kr [B][2L][H], psave/gsave [B][nh][L][L].
 int xlnet_attention_forward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
                             const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask, void* vec,
-                            void* psave, int B, int L, int nh, DropKey drop, hipStream_t st);
+                            void* psave, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale = nullptr);
 int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
                              const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask,
                              const void* psave, const void* dvec, void* gsave, void* dqkv, void* dkr, float* d_rwb,
-                             float* d_rrb, float* d_rsb, float* d_seg, int B, int L, int nh, DropKey drop, hipStream_t st);
+                             float* d_rrb, float* d_rsb, float* d_seg, int B, int L, int nh, DropKey drop, hipStream_t st,
+                             const float* head_scale = nullptr);     // head_scale [nh] or null: head_mask of the layer
 // out[t] = dropout(word[ids[t]])  (xlnet.py:304-305) ; backward scatter-adds into dword
 int gather_drop_forward(int dtype, const int64_t* ids, const float* word, void* out, int rows, int H, DropKey drop, hipStream_t st);
 int gather_drop_backward(int dtype, const void* dout, const int64_t* ids, float* dword, int rows, int H, DropKey drop, hipStream_t st);

@@ -22,6 +22,7 @@ struct XlParams {
     const float* r_w_bias; const float* r_r_bias; const float* r_s_bias;   // [nh][64]
     const float* seg_embed;                                                // [2][nh][64]
     const int64_t* seg; const int64_t* mask;                               // [B][L]
+    const float* head_scale;                                               // [nh] or null: head_mask of this layer (xlnet.py:383)
 };
 
 template <class T> __device__ __forceinline__ float ldT(const char* img, int pitch, int row, int d) {
@@ -177,6 +178,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
                     mma16(o, frag_kmaj(Vi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
                           frag_nat<T>(Ps, SPIT, lane & 15, sl, lane));
                 const int i = strip * 16 + (lane & 15);
+                if (xp.head_scale) o = o * xp.head_scale[h];      // attn_prob * head_mask, applied to the head's output (same product)
                 if (i < L) store4(vec + ((size_t)b * L + i) * H + h * 64 + dt * 16 + (lane >> 4) * 4, o);
             }
         }
@@ -255,6 +257,10 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
         padf[j] = 0;
     }
     __syncthreads();
+    if (xp.head_scale) {                 // head_mask: every gradient of this head is linear in its dvec
+        scale_image<T, LP, NW * 64>(Oi, PIT, xp.head_scale[h]);
+        __syncthreads();
+    }
 
     f32x4 cw[4], cr[4], cs[4], d0[4], d1[4];
 #pragma unroll
@@ -381,6 +387,10 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv_kernel(const T* __rest
     }
     for (int t = threadIdx.x; t < 128; t += NW * 64) bia[t] = t < 64 ? xp.r_w_bias[h * 64 + t] : xp.r_r_bias[h * 64 + t - 64];
     __syncthreads();
+    if (xp.head_scale) {
+        scale_image<T, LP, NW * 64>(Oi, PIT, xp.head_scale[h]);
+        __syncthreads();
+    }
     char* St = strips + wave * 16 * SPIT;
     const size_t pbase = (size_t)blockIdx.x * LP * LP;       // psave / gsave rows are padded to LP columns
     const size_t dbase = (size_t)blockIdx.x * L * L;         // dropout element index space (unpadded)
@@ -496,8 +506,8 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv_kernel(const T* __rest
 
 int xlnet_attention_forward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
                             const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask, void* vec,
-                            void* psave, int B, int L, int nh, DropKey drop, hipStream_t st) {
-    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask};
+                            void* psave, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale) {
+    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale};
     XL_DISPATCH({
         hipLaunchKernelGGL((xl_attn_fwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, (const T*)kr, xp,
                            (T*)vec, (T*)psave, L, nh, drop);
@@ -507,8 +517,9 @@ int xlnet_attention_forward(int dtype, const void* qkv, const void* kr, const fl
 int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
                              const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask,
                              const void* psave, const void* dvec, void* gsave, void* dqkv, void* dkr, float* d_rwb,
-                             float* d_rrb, float* d_rsb, float* d_seg, int B, int L, int nh, DropKey drop, hipStream_t st) {
-    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask};
+                             float* d_rrb, float* d_rsb, float* d_seg, int B, int L, int nh, DropKey drop, hipStream_t st,
+                             const float* head_scale) {
+    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale};
     XL_DISPATCH({
         hipLaunchKernelGGL((xl_attn_bwd_q_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, (const T*)kr,
                            xp, (const T*)psave, (const T*)dvec, (T*)gsave, (T*)dqkv, d_rwb, d_rrb, d_rsb, d_seg, L, nh, drop);

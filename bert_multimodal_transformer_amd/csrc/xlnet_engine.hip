@@ -33,6 +33,7 @@ struct mb_xlnet_engine : StepMixin {
     size_t ws_dsa[2], ws_dzda[2], ws_dsb[2], ws_dzdb[2], ws_du[2], ws_dqkv[2], ws_dkr[2];   // dY operands of the weight gradients: ping-pong by layer parity
     size_t ws_dxa, ws_dxb, ws_dvec, ws_gsave, ws_dz, ws_dxs, ws_lnp_a, ws_lnp_b;
     size_t lnp_stride = 0;         // floats per layer in each of the two LayerNorm partial buffers
+    const float* head_mask = nullptr;   // mb_xlnet_set_head_mask: [n_layer][n_head] fp32 (caller-owned device memory)
     size_t ws_bytes;
     float* P = nullptr; float* G = nullptr; char* SH = nullptr; char* ws = nullptr;
     const int64_t* ids = nullptr; const int64_t* seg = nullptr; const int64_t* mask = nullptr;
@@ -264,7 +265,8 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
         CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, xin, H, e->W(o.v), H, qkv + (size_t)2 * H * es, 3 * H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
         CK(gemm(dt, GEMM_NN, EPI_ADD_RES, R, H, H, ws + e->ws_pos, H, e->W(o.r), H, ws + w.kr, H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
         CK(xlnet_attention_forward(dt, qkv, ws + w.kr, P + o.rwb, P + o.rrb, P + o.rsb, P + o.seg, token_type_ids, attention_mask,
-                                   ws + w.vec, ws + w.psave, B, L, nh, e->key(XS_LAYER0 + 8 * l + 0, pd), st));
+                                   ws + w.vec, ws + w.psave, B, L, nh, e->key(XS_LAYER0 + 8 * l + 0, pd), st,
+                                   e->head_mask ? e->head_mask + (size_t)l * nh : nullptr));
         // post_attention: dropout(vec . o^T) + h -> LayerNorm
         CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, T, H, H, ws + w.vec, H, e->W(o.o), H, ws + w.s1, H, nullptr, nullptr, nullptr, xin, H,
                 e->key(XS_LAYER0 + 8 * l + 1, pd), 1, 0, st));
@@ -375,7 +377,8 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                     kNoDrop, 1, 0, st));
             CK(xlnet_attention_backward(dt, ws + w.qkv, ws + w.kr, P + o.rwb, P + o.rrb, P + o.rsb, P + o.seg, e->seg, e->mask,
                                         ws + w.psave, ws + e->ws_dvec, ws + e->ws_gsave, dqkv, dkr, G + o.rwb, G + o.rrb,
-                                        G + o.rsb, G + o.seg, B, L, nh, e->key(XS_LAYER0 + 8 * l + 0, pd), st));
+                                        G + o.rsb, G + o.seg, B, L, nh, e->key(XS_LAYER0 + 8 * l + 0, pd), st,
+                                        e->head_mask ? e->head_mask + (size_t)l * nh : nullptr));
             if (grouped && e->deferred) {
                 if (!e->side) {
                     CK((int)hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
@@ -454,6 +457,7 @@ int mb_xlnet_train_step(mb_xlnet_engine* e, const int64_t* input_ids, const floa
     if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !labels || !logits || !loss) return MB_ERR_ARG;
     if ((m == nullptr) != (v == nullptr) || (mode != 1 && mode != 2)) return MB_ERR_ARG;
     if (e->deferred) return MB_ERR_MODE;          // MB_OVERLAP_WGRAD=1: the side-stream scheme is driven stage by stage (mb_xlnet_backward)
+    if (e->head_mask) return MB_ERR_MODE;         // head_mask is an argument of explicit forwards only
     e->training = 1;
     CK(xl_prepare_pass(e, B * L, st));
     return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
@@ -464,6 +468,11 @@ int mb_xlnet_train_step(mb_xlnet_engine* e, const int64_t* input_ids, const floa
                            });
 }
 
+int mb_xlnet_set_head_mask(mb_xlnet_engine* e, const float* head_mask) {
+    if (!e) return MB_ERR_ARG;
+    e->head_mask = head_mask;
+    return MB_OK;
+}
 int mb_xlnet_mark_grads_zero(mb_xlnet_engine* e, int known_zero) {
     if (!e) return MB_ERR_ARG;
     e->grads_zero = known_zero != 0;

@@ -6,8 +6,8 @@ Same class names, constructor `(config, multimodal_config)`, forward argument or
 r_w_bias,seg_embed,layer_norm.*}, transformer.layer.{i}.ff.{layer_norm,layer_1,layer_2}.*, transformer.MAG.*,
 sequence_summary.summary.*, logits_proj.*).  Built for the configuration the reference driver runs
 (multimodal_driver.py:363-370: attention_mask + token_type_ids, no mems / perm_mask / target_mapping / input_mask /
-head_mask / inputs_embeds; those raise NotImplementedError; output_hidden_states / output_attentions are served from the
-activations the engine keeps for its backward), sequence length <= 64, MAG injected in front of layer
+inputs_embeds; those raise NotImplementedError; output_hidden_states / output_attentions are served from the activations the
+engine keeps for its backward, head_mask scales each head's attention output inside the kernels), sequence length <= 64, MAG injected in front of layer
 XLNET_INJECTION_INDEX (global_configs.py:19, xlnet.py:371-372).
 """
 import torch
@@ -74,7 +74,7 @@ class MAG_XLNetModel(_XlBase):
                 token_type_ids=None, input_mask=None, head_mask=None, inputs_embeds=None, use_cache=True,
                 output_attentions=None, output_hidden_states=None):
         self._unsupported(mems=mems, perm_mask=perm_mask, target_mapping=target_mapping, input_mask=input_mask,
-                          head_mask=head_mask, inputs_embeds=inputs_embeds)
+                          inputs_embeds=inputs_embeds)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
@@ -85,7 +85,7 @@ class MAG_XLNetModel(_XlBase):
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         B, L = input_ids.shape
-        self._core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training)
+        self._core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, head_mask=head_mask)
         outputs = (self._core.sequence_output(B, L),)
         if output_hidden_states:               # xlnet.py:363-392: the input of every layer (before the MAG injection) + the last output
             outputs = outputs + (self._core.hidden_states(B, L),)
@@ -114,7 +114,7 @@ class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
                 token_type_ids=None, input_mask=None, head_mask=None, inputs_embeds=None, use_cache=True, labels=None,
                 output_attentions=None, output_hidden_states=None):
         self._unsupported(mems=mems, perm_mask=perm_mask, target_mapping=target_mapping, input_mask=input_mask,
-                          head_mask=head_mask, inputs_embeds=inputs_embeds)
+                          inputs_embeds=inputs_embeds)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
@@ -123,7 +123,7 @@ class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         core = self._core
-        logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training)
+        logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, head_mask=head_mask)
         if torch.is_grad_enabled():
             logits = _EngineFn.apply(core.anchor, logits, core)
         outputs = (logits,)

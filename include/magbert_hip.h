@@ -272,6 +272,10 @@ const void* mb_xlnet_hidden_state(const mb_xlnet_engine* e, int i);
  * attention dropout (the host multiplies the counter-hash mask of site XS_LAYER0 + 8 * layer in train mode).  Valid until the
  * next forward. */
 const void* mb_xlnet_attention_probs(const mb_xlnet_engine* e, int layer, int* padded_len);
+/* head_mask (xlnet.py:340-353, 383): fp32 [n_layer][n_head] device memory, sticky until reset with NULL; head h of layer l
+ * contributes head_mask[l][h] times its attention output (attn_prob * head_mask after the dropout).  Explicit forwards /
+ * backwards only: mb_xlnet_train_step returns MB_ERR_MODE while it is set. */
+int mb_xlnet_set_head_mask(mb_xlnet_engine* e, const float* head_mask);
 int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap);
 int mb_xlnet_mark_grads_zero(mb_xlnet_engine* e, int known_zero);      /* as mb_bert_mark_grads_zero */
 /* the MAG-XLNet counterparts of mb_bert_train_step / mb_bert_load_batch / mb_bert_graph_stats (same contracts; one iteration of

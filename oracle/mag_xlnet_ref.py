@@ -56,7 +56,7 @@ class XLNetRelativeAttention(nn.Module):
         x = x.reshape(s[0], s[1], s[2], s[3] - 1)
         return x[:, :, :, :klen]          # => bd[i, j] = raw[i, L - i + j]
 
-    def forward(self, h, attn_mask, r, seg_mat):
+    def forward(self, h, attn_mask, r, seg_mat, head_mask=None):
         q = torch.einsum("ibh,hnd->ibnd", h, self.q)
         k = torch.einsum("ibh,hnd->ibnd", h, self.k)
         v = torch.einsum("ibh,hnd->ibnd", h, self.v)
@@ -68,6 +68,8 @@ class XLNetRelativeAttention(nn.Module):
         score = (ac + bd + ef) * self.scale
         score = score - 1e30 * torch.einsum("ijbn->bnij", attn_mask)
         p = self.dropout(F.softmax(score, dim=3))
+        if head_mask is not None:           # xlnet.py:383 -> rel_attn_core: attn_prob = attn_prob * head_mask, after the dropout
+            p = p * head_mask.view(1, -1, 1, 1)
         self.last_probs = p                 # what output_attentions returns (xlnet.py:387-427): [B, n_head, L, L], after the dropout
         vec = torch.einsum("bnij,jbnd->ibnd", p, v)
         out = self.dropout(torch.einsum("ibnd,hnd->ibh", vec, self.o))
@@ -94,8 +96,8 @@ class XLNetLayer(nn.Module):
         self.rel_attn = XLNetRelativeAttention(c)
         self.ff = XLNetFeedForward(c)
 
-    def forward(self, h, attn_mask, r, seg_mat):
-        return self.ff(self.rel_attn(h, attn_mask, r, seg_mat))
+    def forward(self, h, attn_mask, r, seg_mat, head_mask=None):
+        return self.ff(self.rel_attn(h, attn_mask, r, seg_mat, head_mask))
 
 
 class MAG_XLNetModel(nn.Module):
@@ -119,7 +121,11 @@ class MAG_XLNetModel(nn.Module):
         pos_emb = torch.cat([torch.sin(sinusoid), torch.cos(sinusoid)], dim=-1)
         return pos_emb[:, None, :].expand(-1, bsz, -1)
 
-    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids):
+    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask=None):
+        if head_mask is not None:            # xlnet.py:340-353: [n_head] -> every layer, [n_layer][n_head] as is
+            head_mask = head_mask.to(torch.float32)
+            if head_mask.dim() == 1:
+                head_mask = head_mask[None].expand(self.n_layer, -1)
         ids = input_ids.transpose(0, 1).contiguous()                                    # xlnet.py:206
         L, B = ids.shape
         visual = visual.transpose(0, 1).contiguous()                                    # xlnet.py:215-216
@@ -135,7 +141,7 @@ class MAG_XLNetModel(nn.Module):
         for i, layer in enumerate(self.layer):
             if i == self.injection_index:
                 h = self.MAG(h, visual, acoustic)                                       # xlnet.py:371-372
-            h = layer(h, non_tgt, pos_emb, seg_mat)                                     # xlnet.py:374-385
+            h = layer(h, non_tgt, pos_emb, seg_mat, None if head_mask is None else head_mask[i])     # xlnet.py:374-385
         return self.dropout(h).permute(1, 0, 2).contiguous()                            # xlnet.py:396-399
 
 
@@ -161,8 +167,8 @@ class MAG_XLNetForSequenceClassification(nn.Module):
         self.sequence_summary = SequenceSummary(config)
         self.logits_proj = nn.Linear(config.d_model, config.num_labels)
 
-    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels=None):
-        out = self.transformer(input_ids, visual, acoustic, attention_mask, token_type_ids)
+    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels=None, head_mask=None):
+        out = self.transformer(input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask)
         logits = self.logits_proj(self.sequence_summary(out))                           # xlnet.py:506-509
         outputs = (logits,)
         if labels is not None:

@@ -151,6 +151,43 @@ def test_output_attentions_and_hidden_states_fp32():
     assert len(base) == 2 and float((base[1][0] - out[2][0]).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_head_mask_vs_oracle(cdt):
+    """f-4 for MAG-XLNet (xlnet.py:336-353, 383): head_mask [n_layer][n_head] (and the 1-D form) scales attn_prob after the
+    dropout.  Train mode, every dropout p = 0: logits, the returned attention probabilities and every parameter gradient against
+    the oracle; afterwards a plain forward is unaffected and the single-call step runs."""
+    layers, B, L, nh = 2, 3, 24, 12
+    fp32 = cdt == torch.float32
+    m = build(layers, cdt, p_mag=0.0, p=0.0).train()
+    o = X.set_dropout(oracle(layers, p_mag=0.0), 0.0, 0.0).train()
+    b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=47)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    hm = torch.ones(layers, nh)
+    hm[0, 2] = 0.0; hm[0, 9] = 0.5; hm[1, 0] = 0.0; hm[1, 5] = 2.0
+    out = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, head_mask=hm.to(DEV), output_attentions=True)
+    logits, att = out[0], out[1]
+    torch.nn.MSELoss()(logits.view(-1), lab.view(-1)).backward()
+    i2, v2, a2, m2, s2, l2 = tb(b)
+    lo = o(i2, v2, a2, m2, s2, head_mask=hm)[0]
+    torch.nn.functional.mse_loss(lo.view(-1), l2.view(-1)).backward()
+    torch.cuda.synchronize()
+    err = float((logits.detach().cpu() - lo.detach()).abs().max())
+    perr = max(float((att[l].cpu() - lyr.rel_attn.last_probs.detach()).abs().max()) for l, lyr in enumerate(o.transformer.layer))
+    print("xlnet head_mask (%s): logits %.2e, probabilities %.2e" % (cdt, err, perr))
+    assert err <= (1e-3 if fp32 else 5e-2) and perr <= (1e-5 if fp32 else 2e-2)
+    assert float(att[0][:, 2].abs().max()) == 0.0 and float(att[1][:, 0].abs().max()) == 0.0
+    _grad_report(m, o, 5e-3 if fp32 else 1e-1, frobenius=not fp32)
+    m.eval(); o.eval()
+    with torch.no_grad():
+        plain = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0].cpu()
+        one = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, head_mask=hm[0].to(DEV))[0].cpu()       # 1-D: every layer
+        assert float((plain - o(i2, v2, a2, m2, s2)[0]).abs().max()) <= (1e-3 if fp32 else 5e-2)
+        assert float((one - o(i2, v2, a2, m2, s2, head_mask=hm[0])[0]).abs().max()) <= (1e-3 if fp32 else 5e-2)
+    m.train(); m.zero_grad()
+    m.train_step(ids, vis, aco, mask, seg, lab, optimizer=None)
+    torch.cuda.synchronize()
+
+
 def test_gradients_match_oracle_fp32(golden):
     """train mode, every dropout p = 0: loss and all parameter gradients vs the oracle (and the golden loss)."""
     m = build(p_mag=0.0, p=0.0).train()
