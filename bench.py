@@ -213,7 +213,8 @@ def hbm_roofline(dtype_name, B, L, V, A, reps=20):
     timed("ln_fwd (LayerNorm, BertSelfOutput/BertOutput)", 2 * T * H * es, lambda i: _lib.check(Lb.mb_layernorm_forward(
         dt, _lib.ptr(xs[i % NB]), _lib.ptr(gamma), _lib.ptr(beta), 1e-12, _lib.ptr(ys[i % NB]), _lib.ptr(mean), _lib.ptr(rstd),
         T, H, C.byref(nokey), st.cuda_stream)))
-    timed("ln_bwd (+dropout backward, dgamma/dbeta/dbias)", 4 * T * H * es, lambda i: _lib.check(Lb.mb_layernorm_backward(
+    # (the operator-level launch: column sums by atomics.  Inside the step the partial-sum variant runs -- instep_kernels: ~8 us)
+    timed("ln_bwd operator (+dropout backward, dgamma/dbeta/dbias by atomics)", 4 * T * H * es, lambda i: _lib.check(Lb.mb_layernorm_backward(
         dt, _lib.ptr(xs[i % NB]), _lib.ptr(ys[i % NB]), _lib.ptr(gamma), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(zs[i % NB]),
         _lib.ptr(ys[(i + 1) % NB]), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dbias), T, H, C.byref(nokey), C.byref(key), st.cuda_stream)))
     # MAG forward, the whole operator as the engine runs it (weight pack + modality pack + 3 MFMA GEMMs + the gate / norm-ratio /
