@@ -21,6 +21,7 @@
 // columns n of one row m: epilogue loads/stores are 8/16-byte vectors and bias is one float4.
 #include <cstdlib>
 #include <algorithm>
+#include <type_traits>
 #include "kernels.h"
 
 namespace mb {
@@ -472,8 +473,13 @@ struct Dma {
             for (int h = 0; h < 2; ++h) {
                 const int k = s * 32 + (lane >> 4) * 8 + h * 4 + (i >> 2);
                 const int pc = (colb >> 4) ^ kswz<T, RB>(k, r1);
-                u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)LDS_PTR(lds + k * RB + (pc << 4) + (colb & 15)));
+                // inline asm, not __builtin_amdgcn_ds_read_tr16_b64_v4i16: hipcc (ROCm 7.2) orders the builtin behind EVERY pending
+                // LDS-DMA of the wave (s_waitcnt vmcnt(0) in front of the first transpose read of a stage) -- the loads of stage
+                // t + 1 issued a few instructions earlier were waited for before stage t was multiplied, i.e. no overlap of fill and
+                // MFMA inside a block in any kernel with a k-major operand (dgrads, wgrads).  The asm is invisible to that pass; what
+                // it must do itself is wait for the data (lds_fence below) before the first MFMA reads the registers.
+                const uint32_t addr = (uint32_t)(size_t)LDS_PTR(lds + k * RB + (pc << 4) + (colb & 15));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.h[h]) : "v"(addr) : "memory");
             }
             return u.v;
         } else {
@@ -488,9 +494,101 @@ struct Dma {
             return v;
         }
     }
+
+    // ------------------------------------------------------------------ bf16 main loop (gemm2_body): what the phase and
+    // per-iteration stamps of round 3 showed is that a wave never waits for its stage -- it is busy ISSUING: ~65 clocks per
+    // global_load_lds (64-bit address arithmetic per piece and stage) and a full LDS round trip in front of every 16 MFMAs.
+    //   * DMA by buffer_load ... lds: the lane's byte offset inside the operand is loop invariant (one VGPR per piece), the
+    //     stage advance is ONE scalar offset: a piece is s_mov m0 + buffer_load, no vector arithmetic at all;
+    //   * fragment reads as inline asm from loop-invariant base addresses + immediate offsets, all slabs of a stage issued
+    //     before the DMA of the next stage (whose issue then hides their latency), counted out with s_waitcnt lgkmcnt.
+    // byte offset of this lane's 16 bytes of piece i from the operand base, at k = 0
+    static __device__ __forceinline__ uint32_t dma_voff(int i, int ld, int row0, int nrows, int lane, int wave) {
+        const int blk = i * NW + wave;
+        if constexpr (!KMAJ) {
+            const int r = blk * RPI + lane / CPR;
+            const int lc = rswz(lane % CPR, r);
+            int g = row0 + r;
+            g = g < nrows ? g : nrows - 1;
+            return ((uint32_t)g * (uint32_t)ld + (uint32_t)(lc * EPV)) * (uint32_t)sizeof(T);
+        } else {
+            constexpr int RPK = 1024 / RB;
+            const int kl = blk * RPK + (lane * 16) / RB;
+            const int pc = ((lane * 16) % RB) >> 4;
+            const int lc = pc ^ kswz<T, RB>(kl);
+            return ((uint32_t)kl * (uint32_t)ld + (uint32_t)(row0 + lc * EPV)) * (uint32_t)sizeof(T);
+        }
+    }
+    // bytes the operand advances per k element
+    static __device__ __forceinline__ uint32_t k_stride_bytes(int ld) { return (KMAJ ? (uint32_t)ld : 1u) * (uint32_t)sizeof(T); }
+    static __device__ __forceinline__ void issue_buf(__amdgpu_buffer_rsrc_t rs, const uint32_t (&voff)[NI], uint32_t soff, char* lds, int wave) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)LDS_PTR(lds + (i * NW + wave) * 1024), 16,
+                                                     (int)voff[i], (int)soff, 0, 0);
+    }
+    // Fragment reader of one wave: NB loop-invariant LDS byte addresses (stage 0) -- row images: one per k-slab of the stage
+    // (the XOR swizzle moves with the slab, the 16-row step of fragment i is an immediate); k-major images: one per fragment
+    // (the swizzle moves with the column group, the k-slab and the two halves of the transpose read are immediates).
+    template <int NF, int NSLAB> struct Reader {
+        static constexpr int NB = KMAJ ? NF : NSLAB;
+        uint32_t base[NB];
+        // img: LDS address of the operand image in stage 0; rbase: first image row of the wave; slab0: first slab of the wave
+        __device__ __forceinline__ void init(uint32_t img, int rbase, int slab0, int lane) {
+            const int l15 = lane & 15, q = lane >> 4;
+            if constexpr (!KMAJ) {
+                const int r = rbase + l15;
+#pragma unroll
+                for (int s = 0; s < NSLAB; ++s) base[s] = img + (uint32_t)(r * KB + (rswz((slab0 + s) * 4 + q, r) << 4));
+            } else {
+                const int kl = q * 8 + (l15 >> 2);            // + slab * 32 + h * 4: neither term reaches the swizzle bits
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const int colb = (rbase + j * 16 + (l15 & 3) * 4) * 2;
+                    const int pc = (colb >> 4) ^ kswz<T, RB>(kl);
+                    base[j] = img + (uint32_t)((slab0 * 32 + kl) * RB + (pc << 4) + (colb & 15));
+                }
+            }
+        }
+        // fragment f of slab s (relative to slab0) in the stage at byte offset `st`
+        template <int F, int S> __device__ __forceinline__ bf16x8 read(uint32_t st) const {
+            union { s16x4 h[2]; bf16x8 v; } u;
+            if constexpr (!KMAJ) {
+                const uint32_t a = base[S] + st;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(u.v) : "v"(a), "n"(F * 16 * KB) : "memory");
+            } else {
+                const uint32_t a = base[F] + st;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u.h[0]) : "v"(a), "n"(S * 32 * RB) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u.h[1]) : "v"(a), "n"((S * 32 + 4) * RB) : "memory");
+            }
+            return u.v;
+        }
+        static constexpr int READS_PER_FRAG = KMAJ ? 2 : 1;
+    };
 };
 
+// -DMB_GEMM_LOOPTRACE (measurement builds only, scripts/exp/r3): wave 0 of every block keeps shader-clock stamps of the first
+// kLtIters k-loop iterations in LDS (top of the iteration / stage landed / barrier passed / DMA issued / MFMAs issued) and copies
+// them behind the five phase stamps of the block: kTraceStride u64 per block instead of 8.
+#ifdef MB_GEMM_LOOPTRACE
+constexpr int kLtIters = 24, kLtPoints = 5, kTraceStride = 128;
+#else
+constexpr int kTraceStride = 8;
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// All LDS reads issued so far (the asm transpose reads included, which the compiler's own s_waitcnt bookkeeping does not see) have
+// returned; `touch` pins a fragment behind the wait (an MFMA consuming it cannot be scheduled in front of the s_waitcnt).
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// at most N LDS reads still outstanding (LDS returns in order; the counter has 4 bits).  Only meaningful while no scalar load is
+// in flight (those return out of order): the k loop of gemm2_body holds none -- tests/test_host_cpu.py checks the ISA for that.
+template <int N> __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N < 15 ? N : 15) : "memory"); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+template <class F> __device__ __forceinline__ void touch(F& f) { asm volatile("" : "+v"(f)); }
 
 template <int BM, int BN, int NSTAGE, int KB, bool KS = false>
 struct Gemm2Smem { static constexpr int STAGE = (BM + BN) * KB;
@@ -536,60 +634,129 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const bool r1 = (p.dbg & 8) != 0;
     // phase stamps of this block (0 entry, 1 first stage landed, 2 k loop done, 3 epilogue issued, 4 its stores completed)
     auto stamp = [&](int k) {
-        if (p.trace && tid == 0) p.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = wall_clock64();
+        if (p.trace && tid == 0) p.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kTraceStride + k] = wall_clock64();
     };
+#ifdef MB_GEMM_LOOPTRACE
+    __shared__ uint32_t lt[kLtIters * kLtPoints];
+#define MB_LT(t, j) do { if (p.trace && (t) < kLtIters && tid == 0) lt[(t) * kLtPoints + (j)] = (uint32_t)__builtin_readcyclecounter(); } while (0)
+#else
+#define MB_LT(t, j) do { } while (0)
+#endif
     stamp(0);
     EpiPre<T, BM, BN, MODE, NW> pre;
     pre.fetch(p, m0, n0, tid);                   // in flight under the whole k loop (oldest loads: counted out first by vmcnt)
-    auto issue = [&](int t) {
-        if (p.dbg & 1) return;
-        char* st = smem + (t % NSTAGE) * STAGE;
-        DA::issue(A, p.lda, m0, p.M, kbeg + t * BKE, st, lane, wave, r1);
-        DB::issue(B, p.ldb, n0, p.N, kbeg + t * BKE, st + BM * KB, lane, wave, r1);
-    };
-#pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nt) issue(s);
-
-    for (int t = 0; t < nt; ++t) {
-        // stage t must have landed; up to NSTAGE-2 younger stages may stay in flight
+    auto wait_stage = [&](int t) {               // stage t must have landed; up to NSTAGE-2 younger stages may stay in flight
         const int younger = min(NSTAGE - 2, nt - 1 - t);
         if (NSTAGE >= 5 && younger >= 3) wait_vmcnt<3 * G>();
         else if (NSTAGE >= 4 && younger >= 2) wait_vmcnt<2 * G>();
         else if (NSTAGE >= 3 && younger >= 1) wait_vmcnt<G>();
         else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();            // everyone's piece of stage t landed; everyone left stage t-1
-        if (t == 0) stamp(1);
-        if (t + NSTAGE - 1 < nt) issue(t + NSTAGE - 1);
-        const char* cur = smem + (t % NSTAGE) * STAGE;
+    };
+    if constexpr (sizeof(T) == 2) {
+        // ------------------------------------------------------------------ bf16: buffer-addressed DMA, asm fragment reads
+        constexpr int NSLAB = KS ? 1 : KB / 64;              // 64-byte k-slabs of a stage this wave multiplies
+        typedef typename DA::template Reader<MT, NSLAB> RA;
+        typedef typename DB::template Reader<NT, NSLAB> RB_;
+        constexpr int RPS = MT * RA::READS_PER_FRAG + NT * RB_::READS_PER_FRAG;      // LDS read instructions per slab
+        RA ra;
+        RB_ rb;
+        const uint32_t lds0 = (uint32_t)(size_t)LDS_PTR(smem);
+        ra.init(lds0, wr * (BM / WM), KS ? wave : 0, lane);
+        rb.init(lds0 + BM * KB, wc * (BN / 2), KS ? wave : 0, lane);
+        uint32_t va[DA::NI], vb[DB::NI];
 #pragma unroll
-        for (int s0 = 0; s0 < (KS ? 1 : KB / 64); ++s0) {
-            const int s = KS ? wave : s0;
-            frag_t a[MT], b[NT];
-            if (!(p.dbg & 4)) {
+        for (int i = 0; i < DA::NI; ++i) va[i] = DA::dma_voff(i, p.lda, m0, p.M, lane, wave);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = DA::frag(cur, wr * (BM / WM) + i * 16, s, lane, r1);
+        for (int i = 0; i < DB::NI; ++i) vb[i] = DB::dma_voff(i, p.ldb, n0, p.N, lane, wave);
+        const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, -1, 0x00020000);
+        const uint32_t ksa = DA::k_stride_bytes(p.lda) * BKE, ksb = DB::k_stride_bytes(p.ldb) * BKE;      // operand bytes per stage
+        uint32_t soa = DA::k_stride_bytes(p.lda) * (uint32_t)kbeg, sob = DB::k_stride_bytes(p.ldb) * (uint32_t)kbeg;
+        auto issue = [&](int slot) {                 // the next stage in k order goes to ring slot `slot`
+#ifdef MB_GEMM_ABLATE
+            if (p.dbg & 1) return;
+#endif
+            DA::issue_buf(rsa, va, soa, smem + slot * STAGE, wave);
+            DB::issue_buf(rsb, vb, sob, smem + slot * STAGE + BM * KB, wave);
+            soa += ksa; sob += ksb;
+        };
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = DB::frag(cur + BM * KB, wc * (BN / 2) + j * 16, s, lane, r1);
-            } else {
+        for (int s = 0; s < NSTAGE - 1; ++s)
+            if (s < nt) issue(s);
+        for (int t = 0; t < nt; ++t) {
+            MB_LT(t, 0);
+            wait_stage(t);
+            MB_LT(t, 1);
+            __builtin_amdgcn_s_barrier();            // everyone's piece of stage t landed; everyone left stage t-1
+            MB_LT(t, 2);
+            if (t == 0) stamp(1);
+            const uint32_t st = (uint32_t)((t % NSTAGE) * STAGE);
+            bf16x8 a[NSLAB][MT], b[NSLAB][NT];
+#ifdef MB_GEMM_ABLATE
+            const bool no_reads = (p.dbg & 4) != 0, no_mfma = (p.dbg & 2) != 0;
+#else
+            constexpr bool no_reads = false, no_mfma = false;
+#endif
+            // every fragment of the stage is requested first ...
+            static_for<NSLAB>([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                static_for<MT>([&](auto ic) { constexpr int I = decltype(ic)::value; if (!no_reads) a[S][I] = ra.template read<I, S>(st); else asm volatile("" : "=v"(a[S][I])); });
+                static_for<NT>([&](auto jc) { constexpr int J = decltype(jc)::value; if (!no_reads) b[S][J] = rb.template read<J, S>(st); else asm volatile("" : "=v"(b[S][J])); });
+            });
+            // ... then the DMA of the stage NSTAGE-1 ahead (into the slot everyone left at the barrier): its issue hides the LDS latency
+            if (t + NSTAGE - 1 < nt) issue((t + NSTAGE - 1) % NSTAGE);
+            MB_LT(t, 3);
+            static_for<NSLAB>([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+#ifdef MB_GEMM_LOOPTRACE
+                lds_wait<0>();                        // (the stamps are scalar memory reads: no counting next to them)
+#else
+                lds_wait<(NSLAB - 1 - S) * RPS>();    // slab S has returned, the younger slabs may still be in flight
+#endif
 #pragma unroll
-                for (int i = 0; i < MT; ++i) asm volatile("" : "=v"(a[i]));
+                for (int i = 0; i < MT; ++i) touch(a[S][i]);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) asm volatile("" : "=v"(b[j]));
-            }
-            if (!(p.dbg & 2)) {
+                for (int j = 0; j < NT; ++j) touch(b[S][j]);
+                if (!no_mfma) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) mma16(acc[i][j], b[S][j], a[S][i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);    // the MFMAs of slab S stay in front of the wait for slab S + 1
+            });
+            MB_LT(t, 4);
+        }
+    } else {
+        // ------------------------------------------------------------------ fp32 parity mode: global_load_lds + compiler-visible reads
+        auto issue = [&](int t) {
+            char* st = smem + (t % NSTAGE) * STAGE;
+            DA::issue(A, p.lda, m0, p.M, kbeg + t * BKE, st, lane, wave, false);
+            DB::issue(B, p.ldb, n0, p.N, kbeg + t * BKE, st + BM * KB, lane, wave, false);
+        };
+#pragma unroll
+        for (int s = 0; s < NSTAGE - 1; ++s)
+            if (s < nt) issue(s);
+        for (int t = 0; t < nt; ++t) {
+            wait_stage(t);
+            __builtin_amdgcn_s_barrier();
+            if (t == 0) stamp(1);
+            if (t + NSTAGE - 1 < nt) issue(t + NSTAGE - 1);
+            const char* cur = smem + (t % NSTAGE) * STAGE;
+#pragma unroll
+            for (int s0 = 0; s0 < (KS ? 1 : KB / 64); ++s0) {
+                const int s = KS ? wave : s0;
+                frag_t a[MT], b[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[i] = DA::frag(cur, wr * (BM / WM) + i * 16, s, lane, false);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = DB::frag(cur + BM * KB, wc * (BN / 2) + j * 16, s, lane, false);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) mma16(acc[i][j], b[j], a[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(a[i]));
-#pragma unroll
-                for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(b[j]));
             }
         }
     }
@@ -599,7 +766,14 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
         stamp(3);
         wait_vmcnt<0>();
         stamp(4);
+#ifdef MB_GEMM_LOOPTRACE
+        if (tid == 0) {
+            unsigned long long* dst = p.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kTraceStride + 8;
+            for (int i = 0; i < kLtIters * kLtPoints; ++i) dst[i] = lt[i];
+        }
+#endif
     }
+#undef MB_LT
 }
 
 template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB, bool KS = false, int NW = 4>
@@ -663,24 +837,24 @@ static int env_int(const char* name, int dflt) {
 }
 static unsigned long long* g_trace = nullptr;       // MB_GEMM_TRACE=1: device buffer of phase stamps, [kTraceBlocks][8]
 static int g_trace_on = -1, g_trace_blocks = 0;
-constexpr int kTraceBlocks = 8192;
+constexpr int kTraceBlocks = 8192 * 8 / kTraceStride;
 static unsigned long long* trace_buffer(int blocks, hipStream_t st) {
     if (g_trace_on < 0) {
         const char* v = getenv("MB_GEMM_TRACE");
         g_trace_on = v ? atoi(v) : 0;
-        if (g_trace_on && hipMalloc(&g_trace, (size_t)kTraceBlocks * 8 * sizeof(unsigned long long)) != hipSuccess) g_trace_on = 0;
+        if (g_trace_on && hipMalloc(&g_trace, (size_t)kTraceBlocks * kTraceStride * sizeof(unsigned long long)) != hipSuccess) g_trace_on = 0;
     }
     if (!g_trace_on || blocks > kTraceBlocks) return nullptr;
     g_trace_blocks = blocks;
-    (void)hipMemsetAsync(g_trace, 0, (size_t)blocks * 8 * sizeof(unsigned long long), st);
+    (void)hipMemsetAsync(g_trace, 0, (size_t)blocks * kTraceStride * sizeof(unsigned long long), st);
     return g_trace;
 }
 int gemm_trace_fetch(unsigned long long* host_out, int max_blocks) {
     if (!g_trace || !host_out) return 0;
     const int n = g_trace_blocks < max_blocks ? g_trace_blocks : max_blocks;
     if (hipDeviceSynchronize() != hipSuccess) return 0;
-    if (hipMemcpy(host_out, g_trace, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    return n;
+    if (hipMemcpy(host_out, g_trace, (size_t)n * kTraceStride * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;        // (a -DMB_GEMM_LOOPTRACE build hands out kTraceStride = 128 u64 per block: the caller sizes host_out for that)
 }
 static int g_impl = -1, g_stages = -1, g_dbg = 0;      // MB_GEMM_IMPL: 0 auto, 1 = register-staged v1, 2 = LDS-DMA v2 ; MB_GEMM_STAGES: 2|3|4
 
@@ -840,10 +1014,10 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
         }
         p.kchunk = p.K;
         if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
-        p.dbg = g_dbg & 8;
+        p.dbg = g_dbg;
     }
     ga.first[count] = total;
-    static int g_gstages = -1;       // MB_GROUP_STAGES: ring depth of the grouped kernel (2 | 3)
+    static int g_gstages = -1;       // MB_GROUP_STAGES: ring of the grouped kernel: 2 | 3 stages of 128-byte k rows, 24 | 25 = 4 | 5 stages of 64-byte k rows
     if (g_gstages < 0) g_gstages = env_int("MB_GROUP_STAGES", 2);
     ga.chunk = g_map ? (total + 7) / 8 : 0;
     if (g_map)
@@ -852,7 +1026,15 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
             ga.g[i].reg_n = std::max(1, (ga.chunk + shortside / 2) / shortside);
         }
     const int grid = g_map ? 8 * ga.chunk : total;
-    if (g_gstages >= 3) {
+    if (g_trace_on != 0) {
+        unsigned long long* tr = trace_buffer(grid, st);
+        for (int i = 0; i < count; ++i) ga.g[i].trace = tr;
+    }
+    if (g_gstages == 24) {
+        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 4, 64>), dim3(grid), dim3(256), 0, st, ga);
+    } else if (g_gstages == 25) {
+        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 5, 64>), dim3(grid), dim3(256), 0, st, ga);
+    } else if (g_gstages >= 3) {
         hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 3, 128>), dim3(grid), dim3(256), 0, st, ga);
     } else {
         hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128>), dim3(grid), dim3(256), 0, st, ga);

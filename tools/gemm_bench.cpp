@@ -31,13 +31,14 @@ static void* dev_rand(size_t n_bf16, uint32_t seed) {
 }
 
 int main(int argc, char** argv) {
-    int T = 2400, reps = 48, nset = 6, trace = 0;
+    int T = 2400, reps = 48, nset = 6, trace = 0, looptrace = 0;
     std::string only;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i];
         if (k == "--T") T = atoi(argv[i + 1]); else if (k == "--reps") reps = atoi(argv[i + 1]);
         else if (k == "--nset") nset = atoi(argv[i + 1]); else if (k == "--only") only = argv[i + 1];
         else if (k == "--trace") trace = atoi(argv[i + 1]);
+        else if (k == "--looptrace") { looptrace = atoi(argv[i + 1]); trace = trace || looptrace; }   // library built with -DMB_GEMM_LOOPTRACE
     }
     const int H = 768, I = 3072;
     const int Tp = (T + 63) / 64 * 64;
@@ -72,6 +73,48 @@ int main(int argc, char** argv) {
     double tot_us = 0, tot_fl = 0;
     auto sel = [&](int which, int s) -> void* { return which == 0 ? xh[s] : which == 1 ? xi[s] : x3[s]; };
     auto ld = [&](int which) { return which == 0 ? H : which == 1 ? I : 3 * H; };
+    auto trace_summary = [&]() {
+        // phase picture of ONE launch in steady state (the queue is kept busy by the launches in front of it)
+        const size_t S = looptrace ? 128 : 8;          // u64 per block
+        std::vector<unsigned long long> tr((size_t)8192 * 8);
+        const int nb = mb_debug_gemm_trace(tr.data(), (int)(8192 * 8 / S));
+        std::vector<double> ph[5];
+        unsigned long long t00 = ~0ull;
+        for (int b = 0; b < nb; ++b) if (tr[(size_t)b * S]) t00 = std::min(t00, tr[(size_t)b * S]);
+        for (int b = 0; b < nb; ++b) {
+            if (!tr[(size_t)b * S]) continue;
+            for (int k = 0; k < 5; ++k) ph[k].push_back((double)(tr[(size_t)b * S + k] - t00) * 0.01);
+        }
+        if (looptrace) {
+            // shader-clock stamps of wave 0, iterations 4 .. 22 of every block: where an iteration of the k loop goes
+            static const char* pn[5] = {"wait for the stage (vmcnt)", "barrier", "DMA issue", "fragment reads + MFMA issue", "whole iteration"};
+            std::vector<double> d[5];
+            for (int b = 0; b < nb; ++b) {
+                if (!tr[(size_t)b * S]) continue;
+                const unsigned long long* lt = &tr[(size_t)b * S + 8];
+                for (int t = 4; t < 22; ++t) {
+                    if (!lt[(t + 1) * 5]) break;
+                    auto df = [&](int i1, int i0) { return (double)(uint32_t)((uint32_t)lt[i1] - (uint32_t)lt[i0]); };
+                    d[0].push_back(df(t * 5 + 1, t * 5)); d[1].push_back(df(t * 5 + 2, t * 5 + 1)); d[2].push_back(df(t * 5 + 3, t * 5 + 2));
+                    d[3].push_back(df(t * 5 + 4, t * 5 + 3)); d[4].push_back(df((t + 1) * 5, t * 5));
+                }
+            }
+            printf("    k-loop iteration of wave 0, shader clocks (p10 / median / p90 / mean over %d samples)\n", (int)d[0].size());
+            for (int k = 0; k < 5; ++k) {
+                if (d[k].empty()) continue;
+                std::sort(d[k].begin(), d[k].end());
+                double m = 0; for (double x : d[k]) m += x;
+                printf("    %-28s %7.0f %7.0f %7.0f %7.0f\n", pn[k], d[k][d[k].size() / 10], d[k][d[k].size() / 2], d[k][d[k].size() * 9 / 10], m / d[k].size());
+            }
+        }
+        static const char* nm[5] = {"entry", "stage 0 landed", "k loop done", "epilogue issued", "stores done"};
+        printf("    %d blocks with a tile of %d launched; us after the first block's entry  (min / median / max)\n", (int)ph[0].size(), nb);
+        for (int k = 0; k < 5; ++k) {
+            if (ph[k].empty()) continue;
+            std::sort(ph[k].begin(), ph[k].end());
+            printf("    %-16s %7.2f %7.2f %7.2f\n", nm[k], ph[k].front(), ph[k][ph[k].size() / 2], ph[k].back());
+        }
+    };
     for (const Case& c : cases) {
         if (!only.empty() && !strstr(c.name, only.c_str())) continue;
         auto launch = [&](int i) {
@@ -91,26 +134,7 @@ int main(int argc, char** argv) {
         const double us = ms * 1e3 / reps, fl = 2.0 * c.M * c.N * c.K;
         printf("%-52s %8.2f us %8.1f TF/s\n", c.name, us, fl / us * 1e-6);
         tot_us += us; tot_fl += fl;
-        if (trace) {
-            // phase picture of ONE launch in steady state (the queue is kept busy by the launches in front of it)
-            for (int i = 0; i < 8; ++i) launch(i);
-            std::vector<unsigned long long> tr((size_t)8192 * 8);
-            const int nb = mb_debug_gemm_trace(tr.data(), 8192);
-            std::vector<double> ph[5];
-            unsigned long long t00 = ~0ull;
-            for (int b = 0; b < nb; ++b) if (tr[(size_t)b * 8]) t00 = std::min(t00, tr[(size_t)b * 8]);
-            for (int b = 0; b < nb; ++b) {
-                if (!tr[(size_t)b * 8]) continue;
-                for (int k = 0; k < 5; ++k) ph[k].push_back((double)(tr[(size_t)b * 8 + k] - t00) * 0.01);
-            }
-            static const char* nm[5] = {"entry", "stage 0 landed", "k loop done", "epilogue issued", "stores done"};
-            printf("    %d blocks with a tile of %d launched; us after the first block's entry  (min / median / max)\n", (int)ph[0].size(), nb);
-            for (int k = 0; k < 5; ++k) {
-                if (ph[k].empty()) continue;
-                std::sort(ph[k].begin(), ph[k].end());
-                printf("    %-16s %7.2f %7.2f %7.2f\n", nm[k], ph[k].front(), ph[k][ph[k].size() / 2], ph[k].back());
-            }
-        }
+        if (trace) { for (int i = 0; i < 8; ++i) launch(i); trace_summary(); }
     }
     if (only.empty() || strstr("wgrad", only.c_str())) {
         auto launch = [&](int i) {
@@ -129,6 +153,7 @@ int main(int argc, char** argv) {
         const double us = ms * 1e3 / reps;
         printf("%-52s %8.2f us %8.1f TF/s\n", "wgrad x4 grouped [768x3072|3072x768|768x768|2304x768]", us, fl / us * 1e-6);
         tot_us += us; tot_fl += fl;
+        if (trace) { for (int i = 0; i < 8; ++i) launch(i); trace_summary(); }
     }
     printf("per-layer GEMM time %.1f us, aggregate %.1f TF/s (T=%d, bf16, %d rotating operand sets)\n", tot_us, tot_fl / tot_us * 1e-6, T, nset);
     return 0;
