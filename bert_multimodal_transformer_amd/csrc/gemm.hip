@@ -564,6 +564,17 @@ struct Dma {
             return u.v;
         }
         static constexpr int READS_PER_FRAG = KMAJ ? 2 : 1;
+        // read instruction R (of NF * READS_PER_FRAG) of slab S into the fragment set dst
+        template <int R, int S, class FR> __device__ __forceinline__ void emit(FR (&dst)[NF], uint32_t st) const {
+            if constexpr (!KMAJ) {
+                const uint32_t a = base[S] + st;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[R].v) : "v"(a), "n"(R * 16 * KB) : "memory");
+            } else {
+                constexpr int F = R / 2, H = R % 2;
+                const uint32_t a = base[F] + st;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst[F].h[H]) : "v"(a), "n"((S * 32 + H * 4) * RB) : "memory");
+            }
+        }
     };
 };
 
@@ -582,6 +593,13 @@ __device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt
 // at most N LDS reads still outstanding (LDS returns in order; the counter has 4 bits).  Only meaningful while no scalar load is
 // in flight (those return out of order): the k loop of gemm2_body holds none -- tests/test_host_cpu.py checks the ISA for that.
 template <int N> __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N < 15 ? N : 15) : "memory"); }
+union FragU { bf16x8 v; s16x4 h[2]; };     // an MFMA operand fragment; a transpose read fills one half
+// acc += X Y^T as a pinned instruction: volatile asm statements keep their order, which is what lets the k loop place the LDS
+// reads and DMA issues of the NEXT slab between the MFMAs of this one (a builtin MFMA is free to move; hipcc put all 32 of a
+// stage behind the last wait).  vDst == SrcC: consecutive accumulations into one tile need no wait states.
+__device__ __forceinline__ void mma16_pinned(f32x4& acc, const bf16x8& x, const bf16x8& y) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y));
+}
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (N > 0) {
         static_for<N - 1>(f);
@@ -654,7 +672,149 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
         else if (NSTAGE >= 3 && younger >= 1) wait_vmcnt<G>();
         else wait_vmcnt<0>();
     };
-    if constexpr (sizeof(T) == 2) {
+#ifdef MB_GEMM_PLAIN_LOOP      // A/B builds (scripts/build_variant.py): the un-pipelined bf16 loop below for two ring slots as well
+    constexpr bool kPipelined = false;
+#else
+    constexpr bool kPipelined = true;
+#endif
+    if constexpr (sizeof(T) == 2 && NSTAGE == 2 && kPipelined) {
+        // ------------------------------------------------------------------ bf16, two ring slots: software-pipelined slab stream
+        // Round-3 stamps (profiles/r03_gemm_looptrace.txt): a wave never waits for its stage, it is busy issuing -- per iteration
+        // ~600 clocks of DMA issue, an exposed LDS round trip per slab, and only then 16 MFMAs.  Here every MFMA is a pinned asm
+        // statement and the work for the NEXT slab rides between them: the fragments of slab sigma + 1 are read into the second
+        // register set while slab sigma is multiplied, and the stage two ahead is requested from the same gaps.  Because a stage
+        // lives in registers while it is multiplied, its ring slot is free as soon as everybody has READ it: two slots carry
+        // "being read" + "in flight".  One barrier per stage; every wait is a full drain (no counting next to scalar loads).
+        //   two slabs per stage:  A: MFMA(t, 0) | reads(t, 1)          sync: stage t+1 landed, reads done, barrier
+        //                         B: MFMA(t, 1) | reads(t+1, 0), DMA(t+2 -> slot of t)
+        //   one slab per stage (k-split waves, 64-byte rows): every step is a B step, register sets alternate per stage
+        constexpr int NSLAB = KS ? 1 : KB / 64;
+        typedef typename DA::template Reader<MT, NSLAB> RA;
+        typedef typename DB::template Reader<NT, NSLAB> RB_;
+        constexpr int NRA = MT * RA::READS_PER_FRAG, NRD = NRA + NT * RB_::READS_PER_FRAG;      // LDS read instructions per slab
+        constexpr int NM = MT * NT;
+        RA ra;
+        RB_ rb;
+        const uint32_t lds0 = (uint32_t)(size_t)LDS_PTR(smem);
+        ra.init(lds0, wr * (BM / WM), KS ? wave : 0, lane);
+        rb.init(lds0 + BM * KB, wc * (BN / 2), KS ? wave : 0, lane);
+        uint32_t va[DA::NI], vb[DB::NI];
+#pragma unroll
+        for (int i = 0; i < DA::NI; ++i) va[i] = DA::dma_voff(i, p.lda, m0, p.M, lane, wave);
+#pragma unroll
+        for (int i = 0; i < DB::NI; ++i) vb[i] = DB::dma_voff(i, p.ldb, n0, p.N, lane, wave);
+        const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, -1, 0x00020000);
+        const uint32_t ksa = DA::k_stride_bytes(p.lda) * BKE, ksb = DB::k_stride_bytes(p.ldb) * BKE;      // operand bytes per stage
+        uint32_t soa = DA::k_stride_bytes(p.lda) * (uint32_t)kbeg, sob = DB::k_stride_bytes(p.ldb) * (uint32_t)kbeg;
+#ifdef MB_GEMM_ABLATE
+        const bool no_dma = (p.dbg & 1) != 0, no_reads = (p.dbg & 4) != 0, no_mfma = (p.dbg & 2) != 0;
+#else
+        constexpr bool no_dma = false, no_reads = false, no_mfma = false;
+#endif
+        // DMA piece I of the next stage in k order into the ring slot at byte offset `slot`
+        auto dma_piece = [&](auto ic, uint32_t slot) {
+            constexpr int I = decltype(ic)::value;
+            if (no_dma) return;
+            if constexpr (I < DA::NI)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (__attribute__((address_space(3))) void*)LDS_PTR(smem + slot + (I * NW + wave) * 1024),
+                                                         16, (int)va[I], (int)soa, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (__attribute__((address_space(3))) void*)LDS_PTR(smem + slot + BM * KB + ((I - DA::NI) * NW + wave) * 1024),
+                                                         16, (int)vb[I - DA::NI], (int)sob, 0, 0);
+        };
+        auto issue_stage = [&](uint32_t slot) {
+            static_for<G>([&](auto ic) { dma_piece(ic, slot); });
+            soa += ksa; sob += ksb;
+        };
+        FragU fa[2][MT], fb[2][NT];
+        // read instruction R of slab S of the stage at `st` into register set BUF
+        auto read_one = [&](auto rc, auto sc, auto bc, uint32_t st) {
+            constexpr int R = decltype(rc)::value, S = decltype(sc)::value, BUF = decltype(bc)::value;
+            if (no_reads) return;
+            if constexpr (R < NRA) ra.template emit<R, S>(fa[BUF], st);
+            else rb.template emit<R - NRA, S>(fb[BUF], st);
+        };
+        // one step of the stream: the MFMAs of register set BUF, with RD ? the reads of (stage at st_next, slab S_NEXT) into the
+        // other set : nothing, and DMA ? the pieces of the next stage into slot_dma : nothing, spread over the gaps (reads first:
+        // they are needed at the next step, the stage has a whole iteration to land)
+        auto step = [&](auto bc, auto snc, auto rdc, auto dmac, uint32_t st_next, uint32_t slot_dma) {
+            constexpr int BUF = decltype(bc)::value, S_NEXT = decltype(snc)::value;
+            constexpr bool RD = decltype(rdc)::value, DMA = decltype(dmac)::value;
+            constexpr int NF = (RD ? NRD : 0) + (DMA ? G : 0);
+            static_for<NM>([&](auto mc) {
+                constexpr int M = decltype(mc)::value;
+                if (!no_mfma) mma16_pinned(acc[M / NT][M % NT], fb[BUF][M % NT].v, fa[BUF][M / NT].v);
+                constexpr int f0 = M * NF / NM, f1 = (M + 1) * NF / NM;
+                static_for<f1 - f0>([&](auto fc) {
+                    constexpr int F = f0 + decltype(fc)::value;
+                    if constexpr (RD && F < NRD) read_one(std::integral_constant<int, F>{}, snc, std::integral_constant<int, BUF ^ 1>{}, st_next);
+                    else dma_piece(std::integral_constant<int, F - (RD ? NRD : 0)>{}, slot_dma);
+                });
+            });
+            if constexpr (DMA) { soa += ksa; sob += ksb; }
+        };
+        typedef std::integral_constant<int, 0> I0;
+        typedef std::integral_constant<int, 1> I1;
+        typedef std::true_type Y;
+        typedef std::false_type N_;
+        issue_stage(0);
+        issue_stage(STAGE);
+        wait_vmcnt<G>();
+        __builtin_amdgcn_s_barrier();
+        stamp(1);
+        static_for<NRD>([&](auto rc) { read_one(rc, I0{}, I0{}, 0u); });      // the only exposed fragment read of the tile
+        // The loop body is ONE path (the accumulators and both fragment sets are loop-carried through tied asm operands: a
+        // branch between step variants inside the loop costs a register copy of all of them per iteration); the last two
+        // stages, which request / read nothing further, are peeled.  nt >= 2 (the launcher sends shorter k ranges elsewhere).
+        if constexpr (NSLAB == 2) {
+            auto stage = [&](int t, auto rdc, auto dmac, bool more) {
+                const uint32_t cur = (t & 1) ? (uint32_t)STAGE : 0u, nxt = (uint32_t)STAGE - cur;
+                MB_LT(t, 0);
+                lds_wait_all();
+                step(I0{}, I1{}, Y{}, N_{}, cur, 0u);                // A: MFMA(t, 0) | reads(t, 1)
+                MB_LT(t, 1);
+                if (more) wait_vmcnt<0>();                          // stage t + 1 has landed (the stage after it is not requested yet)
+                lds_wait_all();
+                MB_LT(t, 2);
+                __builtin_amdgcn_s_barrier();                       // ... for everybody, and everybody has read stage t out of its slot
+                MB_LT(t, 3);
+                step(I1{}, I0{}, rdc, dmac, nxt, cur);               // B: MFMA(t, 1) | reads(t+1, 0), DMA(t+2)
+                MB_LT(t, 4);
+            };
+            int t = 0;
+            for (; t + 2 < nt; ++t) stage(t, Y{}, Y{}, true);
+            stage(t, Y{}, N_{}, true);
+            stage(t + 1, N_{}, N_{}, false);
+        } else {
+            auto one = [&](auto bc, int t, auto rdc, auto dmac, bool more) {
+                constexpr int BUF = decltype(bc)::value;
+                constexpr uint32_t cur = BUF ? (uint32_t)STAGE : 0u, nxt = (uint32_t)STAGE - cur;      // even stages live in slot 0
+                MB_LT(t, 0);
+                if (more) wait_vmcnt<0>();
+                lds_wait_all();
+                MB_LT(t, 2);
+                __builtin_amdgcn_s_barrier();
+                MB_LT(t, 3);
+                step(bc, I0{}, rdc, dmac, nxt, cur);
+                MB_LT(t, 4);
+            };
+            int t = 0;
+            for (; t + 3 < nt; t += 2) {
+                one(I0{}, t, Y{}, Y{}, true);
+                one(I1{}, t + 1, Y{}, Y{}, true);
+            }
+            if (nt - t == 3) {
+                one(I0{}, t, Y{}, Y{}, true);
+                one(I1{}, t + 1, Y{}, N_{}, true);
+                one(I0{}, t + 2, N_{}, N_{}, false);
+            } else {
+                one(I0{}, t, Y{}, N_{}, true);
+                one(I1{}, t + 1, N_{}, N_{}, false);
+            }
+        }
+        wait_vmcnt<0>();
+    } else if constexpr (sizeof(T) == 2) {
         // ------------------------------------------------------------------ bf16: buffer-addressed DMA, asm fragment reads
         constexpr int NSLAB = KS ? 1 : KB / 64;              // 64-byte k-slabs of a stage this wave multiplies
         typedef typename DA::template Reader<MT, NSLAB> RA;
@@ -907,6 +1067,9 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
         int ns = 2, kb = 128;      // measured best (per-layer GEMM 290 us): deeper rings / 64-byte rows do not pay
         if (g_stages > 0) { kb = (g_stages / 10 == 2) ? 64 : 128; ns = g_stages % 10; }
         if (kb == 64 && (p.kchunk % (64 / (int)sizeof(T)) != 0)) kb = 128;
+        // the two-slot bf16 loop is a software pipeline with its last two stages peeled: a k range of a single stage takes the
+        // three-slot kernel (plain loop)
+        if (sizeof(T) == 2 && ns <= 2 && p.kchunk / (kb / (int)sizeof(T)) < 2) ns = 3;
 #define MB_LAUNCH2(NS, KBV) hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, NS, KBV>), grid, dim3(256), 0, st, p)
         static int g_ks = -1;             // MB_GEMM_KSPLIT: 1 (default) = k-split waves for the 64 x 64 bf16 tiles, 0 = round-1 quarter tiles
         if (g_ks < 0) g_ks = env_int("MB_GEMM_KSPLIT", 1);
@@ -1030,11 +1193,13 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
         unsigned long long* tr = trace_buffer(grid, st);
         for (int i = 0; i < count; ++i) ga.g[i].trace = tr;
     }
-    if (g_gstages == 24) {
+    int gst = g_gstages;
+    if (sizeof(T) == 2 && gst == 2 && ga.g[0].K / BKE < 2) gst = 3;      // (all problems of a group share K) single-stage k range: plain loop
+    if (gst == 24) {
         hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 4, 64>), dim3(grid), dim3(256), 0, st, ga);
-    } else if (g_gstages == 25) {
+    } else if (gst == 25) {
         hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 5, 64>), dim3(grid), dim3(256), 0, st, ga);
-    } else if (g_gstages >= 3) {
+    } else if (gst >= 3) {
         hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 3, 128>), dim3(grid), dim3(256), 0, st, ga);
     } else {
         hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128>), dim3(grid), dim3(256), 0, st, ga);
