@@ -78,6 +78,10 @@ PROTOTYPES = {
     "mb_xlnet_set_head_mask": (_i, [_vp, _vp]),
     "mb_bert_mark_grads_zero": (_i, [_vp, _i]),
     "mb_xlnet_mark_grads_zero": (_i, [_vp, _i]),
+    "mb_bert_materialize_grads": (_i, [_vp, _vp]),
+    "mb_xlnet_materialize_grads": (_i, [_vp, _vp]),
+    "mb_bert_grads_stale": (_i, [_vp]),
+    "mb_xlnet_grads_stale": (_i, [_vp]),
     "mb_bert_set_head_mask": (_i, [_vp, _vp]),
     "mb_bert_set_inputs_embeds": (_i, [_vp, _vp]),
     "mb_bert_inputs_embeds_grad": (_vp, [_vp]),

@@ -73,6 +73,8 @@ class _EngineFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits):
+        # autograd may already have accumulated other loss terms into the p.grad views: this node adds to the buffer, never stores
+        ctx.core.mark_grads_zero(False)
         ctx.core._backward(dlogits.contiguous().float())
         return torch.zeros((), device=dlogits.device), None, None, ctx.core.inputs_embeds_grad() if ctx.want_emb else None
 
@@ -96,6 +98,7 @@ class _BaseFn(torch.autograd.Function):
         cd = core.compute_dtype
         ds = None if d_seq is None else d_seq.to(cd).contiguous()
         dz = None if d_pooled is None else (d_pooled.float() * (1.0 - pooled * pooled)).to(cd).contiguous()    # tanh'
+        core.mark_grads_zero(False)           # as in _EngineFn: a node of somebody else's graph accumulates
         core.backward_outputs(ds, dz)
         return torch.zeros((), device=core.device), None, None, None, core.inputs_embeds_grad() if ctx.want_emb else None
 
@@ -301,9 +304,19 @@ class _Core(object):
         """tells the engine the flat gradient buffer holds zeros (it then stores, instead of accumulating, the layer weight
         gradients of the next backward -- include/magbert_hip.h: mb_bert_mark_grads_zero).  Called by everything of ours that
         zeroes the buffer; code that writes into `.grad` tensors by hand between a zero_grad() and a backward must pass False."""
+        if not known_zero:
+            self.materialize_grads()          # whatever the caller is about to add to: real zeros where a fused step skipped them
         self._gz = bool(known_zero)
         if self.handle is not None:
             _lib.check(self._fn("mark_grads_zero")(self.handle, 1 if known_zero else 0))
+
+    def materialize_grads(self):
+        """A single-call step that ends with the optimizer does not write the zeros of optimizer.zero_grad() over the layers'
+        GEMM weight gradients (the next backward overwrites them: include/magbert_hip.h, mb_bert_materialize_grads).  Everything
+        that is about to read the flat gradient buffer calls this first; a no-op when nothing is stale."""
+        if self.handle is not None and self.ws is not None and self._fn("grads_stale")(self.handle):
+            with _Core._Hop(self):
+                _lib.check(self._fn("materialize_grads")(self.handle, self.stream()))
 
     def head_mask_table(self, head_mask):
         """transformers get_head_mask (bert.py:206-207): [n_heads] (every layer) or [n_layers][n_heads] (or the broadcast
@@ -377,6 +390,8 @@ class _Core(object):
         """why one optimizer step cannot be ONE engine call (mb_bert_train_step), or None"""
         if self.stage_hooks:
             return "backward stage hooks are installed (data parallel: the gradient exchange is issued between stages)"
+        if self.kind == "xlnet" and os.environ.get("MB_OVERLAP_WGRAD", "0") not in ("", "0"):
+            return "MB_OVERLAP_WGRAD=1: the side-stream weight gradients of MAG-XLNet are driven stage by stage"
         return None
 
     def train_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, opt, loss_scale=1.0, mode=2):
@@ -786,7 +801,13 @@ class _FusedStep(object):
 
     @property
     def flat_grads(self):
+        self._core.materialize_grads()
         return self._core.grads
+
+    def materialize_grads(self):
+        """after a fused train_step with an optimizer the `.grad` views of the encoder's GEMM weights hold stale values instead of
+        the zeros of optimizer.zero_grad() until something needs them (_Core.materialize_grads); call this before reading them"""
+        self._core.materialize_grads()
 
 
 class MAG_BertModel(_MagBertBase):

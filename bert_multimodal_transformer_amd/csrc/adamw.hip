@@ -9,6 +9,71 @@
 
 namespace mb {
 
+// one quad of four consecutive parameters
+struct AdamQuad { f32x4 p, g, m, v; };
+template <bool NT> __device__ __forceinline__ AdamQuad adam_load(const float* p, const float* g, const float* m, const float* v, size_t i) {
+    AdamQuad q;
+    if constexpr (NT) {          // streamed once per step, never re-read before it is rewritten: keep it out of the caches
+        q.p = __builtin_nontemporal_load((const f32x4*)(p + i)); q.g = __builtin_nontemporal_load((const f32x4*)(g + i));
+        q.m = __builtin_nontemporal_load((const f32x4*)(m + i)); q.v = __builtin_nontemporal_load((const f32x4*)(v + i));
+    } else {
+        q.p = *(const f32x4*)(p + i); q.g = *(const f32x4*)(g + i); q.m = *(const f32x4*)(m + i); q.v = *(const f32x4*)(v + i);
+    }
+    return q;
+}
+template <bool NT> __device__ __forceinline__ void adam_update_store(AdamQuad q, float* p, float* g, float* m, float* v, bf16* shadow, size_t i,
+                                                                     const AdamArgs& a, float omb1, float omb2, float decay, size_t n_decay,
+                                                                     size_t sh_begin, size_t sh_end, size_t keep_begin, size_t keep_end, int zero_grad) {
+    q.g *= a.grad_scale;
+    q.m = a.beta1 * q.m + omb1 * q.g;
+    q.v = a.beta2 * q.v + omb2 * q.g * q.g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q.p[r] -= a.step_size * (q.m[r] / (sqrtf(q.v[r]) + a.eps));
+    if (i < n_decay && decay > 0.f) q.p -= decay * q.p;
+    const bool zg = zero_grad && !(i >= keep_begin && i < keep_end);
+    if constexpr (NT) {
+        __builtin_nontemporal_store(q.p, (f32x4*)(p + i));
+        __builtin_nontemporal_store(q.m, (f32x4*)(m + i));
+        __builtin_nontemporal_store(q.v, (f32x4*)(v + i));
+        if (zg) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, (f32x4*)(g + i));
+    } else {
+        *(f32x4*)(p + i) = q.p;
+        *(f32x4*)(m + i) = q.m;
+        *(f32x4*)(v + i) = q.v;
+        if (zg) *(f32x4*)(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (shadow && i >= sh_begin && i < sh_end) store4(shadow + i, q.p);
+}
+
+// Variant kernel for experiments (MB_ADAMW_VAR): UNR quads in flight per thread, CHUNK: every block owns one contiguous range
+template <bool NT, int UNR, bool CHUNK>
+__global__ void __launch_bounds__(256) adamw_var_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, bf16* __restrict__ shadow, size_t n4, size_t n_decay,
+                                                        size_t sh_begin, size_t sh_end, size_t keep_begin, size_t keep_end, AdamArgs a,
+                                                        const AdamArgs* __restrict__ dyn, int zero_grad) {
+    if (dyn) a = *dyn;
+    const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
+    const float decay = a.lr * a.weight_decay;
+    size_t begin, end, stride;
+    if constexpr (CHUNK) {
+        const size_t per = ((n4 + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+        begin = (size_t)blockIdx.x * per + threadIdx.x; end = min(n4, (size_t)(blockIdx.x + 1) * per); stride = 256;
+    } else {
+        begin = (size_t)blockIdx.x * 256 + threadIdx.x; end = n4; stride = (size_t)gridDim.x * 256;
+    }
+    for (size_t i4 = begin; i4 < end; i4 += stride * UNR) {
+        AdamQuad q[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (i4 + u * stride < end) q[u] = adam_load<NT>(p, g, m, v, (i4 + u * stride) * 4);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (i4 + u * stride < end)
+                adam_update_store<NT>(q[u], p, g, m, v, shadow, (i4 + u * stride) * 4, a, omb1, omb2, decay, n_decay, sh_begin, sh_end, keep_begin,
+                                      keep_end, zero_grad);
+    }
+}
+
 template <bool NT>
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16* __restrict__ shadow, size_t n4,
@@ -63,9 +128,9 @@ __global__ void adamw_tail_kernel(float* p, float* g, float* m, float* v, size_t
 }
 
 int adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, size_t n_decay, size_t sh_begin,
-               size_t sh_end, AdamArgs a, int zero_grad, hipStream_t st, const AdamArgs* dyn) {
+               size_t sh_end, AdamArgs a, int zero_grad, hipStream_t st, const AdamArgs* dyn, size_t keep_begin, size_t keep_end) {
     if (n == 0) return MB_OK;
-    if ((n_decay % 4 && n_decay < n) || (sh_begin % 4) || (sh_end % 4)) return MB_ERR_SHAPE;
+    if ((n_decay % 4 && n_decay < n) || (sh_begin % 4) || (sh_end % 4) || (keep_begin % 4) || (keep_end % 4)) return MB_ERR_SHAPE;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return MB_ERR_SHAPE;
     const size_t n4 = n / 4;
     if (n4) {
@@ -73,6 +138,17 @@ int adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, s
         if (grid > 256 * 16) grid = 256 * 16;
         static int nt = -1;          // MB_ADAMW_NT=0: plain loads / stores (non-temporal measured 1.1 % faster per step: 4.86 vs 4.91 ms)
         if (nt < 0) { const char* e = getenv("MB_ADAMW_NT"); nt = e ? atoi(e) : 1; }
+        // MB_ADAMW_VAR: 3 (default) = every block owns ONE contiguous range of each of the seven streams and keeps two quads in
+        // flight (round 3, tools/adamw_bench: 5.38 vs 5.10 TB/s for the grid-strided kernel); 0 = that grid-strided kernel;
+        // 1 / 2 / 4 / 5 = the other combinations measured (profiles/r03_adamw_variants.txt).  MB_ADAMW_GRID caps the grid.
+        static int var = -1, vgrid = 0;
+        if (var < 0) { const char* e = getenv("MB_ADAMW_VAR"); var = e ? atoi(e) : 3; const char* g2 = getenv("MB_ADAMW_GRID"); vgrid = g2 ? atoi(g2) : 0; }
+        if (vgrid > 0 && (unsigned)vgrid < grid) grid = (unsigned)vgrid;
+        const size_t kb = keep_begin, ke = keep_end;
+        if (var == 0 && ke > kb) var = 3;       // (the grid-strided kernel has no keep range)
+#define MB_AV(U, C) hipLaunchKernelGGL((adamw_var_kernel<true, U, C>), dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16*)shadow, n4, n_decay, sh_begin, sh_end, kb, ke, a, dyn, zero_grad)
+        if (var == 1) MB_AV(2, false); else if (var == 2) MB_AV(1, true); else if (var == 3) MB_AV(2, true); else if (var == 4) MB_AV(4, false); else if (var == 5) MB_AV(4, true); else
+#undef MB_AV
         if (nt) hipLaunchKernelGGL(adamw_kernel<true>, dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16*)shadow, n4, n_decay, sh_begin,
                                    sh_end, a, dyn, zero_grad);
         else hipLaunchKernelGGL(adamw_kernel<false>, dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16*)shadow, n4, n_decay, sh_begin,

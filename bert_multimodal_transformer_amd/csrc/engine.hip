@@ -354,11 +354,15 @@ int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
     if (const char* v = getenv("MB_OVERLAP_WGRAD")) e->overlap_wgrad = atoi(v);
     if (const char* v = getenv("MB_GROUP_WGRAD")) e->group_wgrad = atoi(v);
     if (const char* v = getenv("MB_WGRAD_OVERWRITE")) e->ow_enable = atoi(v);
+    if (const char* v = getenv("MB_ADAMW_KEEP")) e->keep_enable = atoi(v);
     e->grouped = (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->hidden_size % e->group_wgrad == 0 &&
                  cfg->intermediate_size % e->group_wgrad == 0;
     e->deferred = e->overlap_wgrad && e->grouped;
 
     build_layout(e);
+    // lazy zeroing: the range the grouped launches of all layers store into = every layer's four GEMM weights (contiguous)
+    e->ow_covers = e->grouped;
+    e->stale_begin = e->lo[0].wqkv; e->stale_end = e->wp;
     *out = e;
     return MB_OK;
 }
@@ -477,7 +481,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
     const int Tk = (int)align_up((size_t)T, 64);      // zero-padded reduction length of the wgrad GEMMs
     if (stage_begin < 0) stage_begin = 0;
     if (stage_end > NL + 2) stage_end = NL + 2;
-    if (stage_begin == 0) e->begin_backward_pass();
+    if (stage_begin == 0) CK(e->begin_backward_pass(e->G, st));
     float* P = e->P; float* G = e->G;
     char* ws = e->ws;
     const bool hd = e->training && c.hidden_dropout > 0.f;
@@ -630,9 +634,10 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
 // ------------------------------------------------------------------------------------------------ whole step
 // One optimizer step of train_epoch (/root/reference/multimodal_driver.py:354-388: batch -> forward -> MSE -> backward ->
 // optimizer.step() -> optimizer.zero_grad()) as two launches: the step prologue (this step's batch, dropout keys and AdamW
-// scalars into device memory) and a replayed hipGraph holding every other kernel of the step, including the side-stream
-// fork / join of the weight-gradient launches.  mode 1 = graph replay (captured on first use per shape), mode 2 = the same
-// kernel sequence launched one by one (A/B reference for the graph; also what runs while profiling events are on).
+// scalars into device memory) and a replayed hipGraph holding every other kernel of the step -- ONE in-order kernel sequence
+// (the grouped weight-gradient launches run in line: a graph with a side-stream fork / join replays on a slow path).
+// mode 1 = graph replay (captured on first use per shape), mode 2 = the same kernel sequence launched one by one (A/B
+// reference for the graph; also what runs while profiling events are on).
 static int enqueue_step(mb_bert_engine* e, int B, int L, float* logits, float* loss, float* loss_run, float* m, float* v,
                         float loss_scale, hipStream_t st) {
     char* ws = e->ws;
@@ -649,7 +654,9 @@ static int enqueue_step(mb_bert_engine* e, int B, int L, float* logits, float* l
         const AdamArgs none = {};
         const size_t nd = e->n_decay, n = e->n_params;
         void* sh = e->c.dtype == DT_BF16 ? (void*)e->SH : nullptr;
-        CK(adamw_step(e->P, e->G, m, v, sh, nd, nd, e->sh_begin, e->sh_end, none, 1, st, e->adam_state(ws)));
+        const bool keep = e->keep_in_step();          // the layers' GEMM weight gradients: overwritten by the next backward, not zeroed
+        CK(adamw_step(e->P, e->G, m, v, sh, nd, nd, e->sh_begin, e->sh_end, none, 1, st, e->adam_state(ws), keep ? e->stale_begin : 0,
+                      keep ? e->stale_end : 0));
         CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
     }
     return MB_OK;
@@ -741,8 +748,14 @@ int mb_bert_set_attention_output(mb_bert_engine* e, float* probs) {
 int mb_bert_mark_grads_zero(mb_bert_engine* e, int known_zero) {
     if (!e) return MB_ERR_ARG;
     e->grads_zero = known_zero != 0;
+    if (known_zero) e->grads_stale = false;       // the caller zeroed the whole buffer itself
     return MB_OK;
 }
+int mb_bert_materialize_grads(mb_bert_engine* e, void* stream) {
+    if (!e) return MB_ERR_ARG;
+    return e->materialize_grads(e->G, (hipStream_t)stream);
+}
+int mb_bert_grads_stale(const mb_bert_engine* e) { return e && e->grads_stale ? 1 : 0; }
 int mb_bert_set_head_mask(mb_bert_engine* e, const float* head_mask) {
     if (!e) return MB_ERR_ARG;
     e->head_mask = head_mask;
@@ -760,7 +773,7 @@ const float* mb_bert_inputs_embeds_grad(const mb_bert_engine* e) {
 int mb_bert_backward_outputs(mb_bert_engine* e, const void* d_sequence_output, const void* d_pooler_preact, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!e || !e->G || !e->ran_forward) return MB_ERR_ARG;
-    e->begin_backward_pass();
+    CK(e->begin_backward_pass(e->G, st));
     const mb_bert_config& c = e->c;
     const int dt = c.dtype, H = c.hidden_size, B = e->B, L = e->L, T = B * L, NL = c.num_layers;
     char* ws = e->ws;

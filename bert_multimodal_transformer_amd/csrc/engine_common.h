@@ -150,10 +150,27 @@ struct StepMixin {
     // wrong, so everything that is not the engine's own zeroing leaves it false.  MB_WGRAD_OVERWRITE=0 turns it off.
     bool grads_zero = false, ow_pass = false, in_step = false;
     int ow_enable = 1;
-    void begin_backward_pass() {
-        if (in_step) return;                 // the single-call step decided already (and replays a graph captured for that decision)
+    // Lazy zeroing (round 3).  The zeros the fused AdamW writes over the layers' GEMM weight gradients (340 MB per step) are only
+    // ever overwritten by the next backward, so a single-call step that ends with the optimizer leaves that range as it is:
+    // "logically zero, physically stale" (grads_stale, [stale_begin, stale_end)).  Whoever else is about to look at it gets real
+    // zeros first: a backward that accumulates (begin_backward_pass / train_step_impl), mb_*_materialize_grads (called by the
+    // Python mirror before optimizer.step(), flat_grads, mark_grads_zero(False)).  MB_ADAMW_KEEP=0 turns it off.
+    bool grads_stale = false, ow_covers = false;       // ow_covers: the overwriting (grouped) launch covers [stale_begin, stale_end)
+    size_t stale_begin = 0, stale_end = 0;
+    int keep_enable = 1;
+    bool keep_in_step() const { return keep_enable && ow_enable && ow_covers && stale_end > stale_begin; }
+    int materialize_grads(float* G, hipStream_t st) {
+        if (grads_stale && G) CK(zero_fill(G + stale_begin, (stale_end - stale_begin) * sizeof(float), st));
+        grads_stale = false;
+        return MB_OK;
+    }
+    int begin_backward_pass(float* G, hipStream_t st) {
+        if (in_step) return MB_OK;           // the single-call step decided already (and replays a graph captured for that decision)
         ow_pass = grads_zero && ow_enable;
         grads_zero = false;
+        if (!(ow_pass && ow_covers)) CK(materialize_grads(G, st));      // this pass adds onto the range: it needs the zeros
+        grads_stale = false;                 // (else: every layer stage of the pass stores its gradients over the stale values)
+        return MB_OK;
     }
 
     void carve_step(Carver& w, size_t Tpad, int V, int A, int max_batch, int num_labels, int nsites_) {
@@ -202,10 +219,17 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
                            hipStream_t st, Enqueue enqueue_inner) {
     // what this step's backward may assume about the gradient buffer -- part of the graph's identity -- and what it leaves behind
     const int ow = (e->grads_zero && e->ow_enable) ? 1 : 0;
+    if (!(ow && e->ow_covers)) CK(e->materialize_grads(e->G, st));      // an accumulating backward needs the zeros that were skipped
+    const bool stale_before = e->grads_stale;
+    // what the step leaves behind is only known once everything was enqueued: an early error return leaves "nothing known"
     struct Flags {
-        E* e; bool after;
-        ~Flags() { e->in_step = false; e->grads_zero = after; }
-    } flags{e, m != nullptr};
+        E* e; bool ok, with_opt, stale_before;
+        ~Flags() {
+            e->in_step = false;
+            e->grads_zero = ok && with_opt;
+            e->grads_stale = ok ? (with_opt && e->keep_in_step()) : stale_before;
+        }
+    } flags{e, false, m != nullptr, stale_before};
     e->in_step = true; e->ow_pass = ow != 0;
     auto enqueue = [&](float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
         return enqueue_inner(lg, ls, lr_, m_, v_, sc, s);
@@ -229,6 +253,7 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
         e->dyn = true;
         const int r = enqueue(logits, loss, loss_run, m, v, loss_scale, st);
         e->dyn = false;
+        flags.ok = r == MB_OK;
         return r;
     }
     StepGraph* g = nullptr;
@@ -255,6 +280,7 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
     }
     CK((int)hipGraphLaunch(g->exec, st));
     ++e->graph_launches;
+    flags.ok = true;
     return MB_OK;
 }
 

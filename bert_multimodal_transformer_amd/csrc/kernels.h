@@ -176,8 +176,11 @@ int head_backward(int dtype, const float* dlogits, const float* logits, const fl
 // transformers 3.0.2 AdamW over flat fp32 buffers; elements [0, n_decay) use weight_decay, the rest 0.
 // shadow (bf16, may be null): shadow[i] = bf16(p[i]) for i in [sh_begin, sh_end). zero_grad: g <- 0 after use.
 // dyn (device pointer, may be null): when set, the hyper-parameters are read from *dyn instead of `a` (replayed step graphs)
+// keep range [keep_begin, keep_end) (elements, multiples of 4; empty by default): g is NOT zeroed there -- the caller knows the next
+// backward overwrites that range (the layers' GEMM weight gradients of a single-call step: 340 MB of zeros per step nobody reads)
 int adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, size_t n_decay,
-               size_t sh_begin, size_t sh_end, AdamArgs a, int zero_grad, hipStream_t st, const AdamArgs* dyn = nullptr);
+               size_t sh_begin, size_t sh_end, AdamArgs a, int zero_grad, hipStream_t st, const AdamArgs* dyn = nullptr,
+               size_t keep_begin = 0, size_t keep_end = 0);
 
 // ------------------------------------------------------------------------------------------ step prologue (rowops.hip)
 // Everything that changes from one optimizer step to the next, moved into device memory by ONE small launch so that the rest

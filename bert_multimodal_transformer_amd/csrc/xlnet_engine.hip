@@ -162,9 +162,24 @@ static void xl_build_layout(mb_xlnet_engine* e) {
 static int xl_prepare_pass(mb_xlnet_engine* e, int T, hipStream_t st) {
     if (e->deferred && e->side)      // a backward that was not run to its last stage may still have weight-gradient GEMMs in flight
         for (size_t l = 0; l < 2 && 2 * l + 1 < e->evs.size(); ++l) CK((int)hipStreamWaitEvent(st, e->evs[2 * l + 1], 0));
-    if (!e->ws_zeroed || e->padT != T) {      // pad rows of every k-major wgrad operand must be zero
-        CK((int)hipMemsetAsync(e->ws, 0, e->ws_bytes, st));
-        e->ws_zeroed = true;
+    if (!e->ws_zeroed) { CK((int)hipMemsetAsync(e->ws, 0, e->ws_bytes, st)); e->ws_zeroed = true; e->padT = T; }
+    if (e->padT != T) {
+        // another batch shape ran before: the pad rows [T, Tp) / [2T, Rp) of every buffer a weight gradient reads as its k-major
+        // operand may hold stale tokens (kernels never write rows past the batch) -> clear those rows, not the whole workspace
+        const mb_xlnet_config& c = e->c;
+        const size_t es = esize(c.dtype), H = c.d_model, I = c.d_inner;
+        const size_t Tp = align_up((size_t)T, 64), R = (size_t)2 * T, Rp = align_up(R, 64);
+        char* ws = e->ws;
+        auto zp = [&](size_t off, size_t cols, size_t rows, size_t rows_p) {
+            return rows_p > rows ? (int)hipMemsetAsync(ws + off + rows * cols * es, 0, (rows_p - rows) * cols * es, st) : 0;
+        };
+        CK(zp(e->ws_magout, H, T, Tp)); CK(zp(e->ws_pos, H, R, Rp));
+        for (int l = 0; l <= c.n_layer; ++l) CK(zp(e->ws_x[l], H, T, Tp));
+        for (int l = 0; l < c.n_layer; ++l) { CK(zp(e->lw[l].vec, H, T, Tp)); CK(zp(e->lw[l].y1, H, T, Tp)); CK(zp(e->lw[l].g, I, T, Tp)); }
+        for (int k = 0; k < 2; ++k) {
+            CK(zp(e->ws_dsa[k], H, T, Tp)); CK(zp(e->ws_dzda[k], H, T, Tp)); CK(zp(e->ws_dsb[k], H, T, Tp)); CK(zp(e->ws_dzdb[k], H, T, Tp));
+            CK(zp(e->ws_du[k], I, T, Tp)); CK(zp(e->ws_dqkv[k], 3 * H, T, Tp)); CK(zp(e->ws_dkr[k], H, R, Rp));
+        }
     }
     e->padT = T;
     return MB_OK;
@@ -186,6 +201,10 @@ int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out) {
                   cfg->d_model % e->group_wgrad == 0;
     e->c = *cfg;
     xl_build_layout(e);
+    if (const char* v = getenv("MB_ADAMW_KEEP")) e->keep_enable = atoi(v);
+    // lazy zeroing (engine_common.h): the seven GEMM weights of every layer, stored by the grouped launches of a pass that may overwrite
+    e->ow_covers = (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->d_inner % e->group_wgrad == 0 && cfg->d_model % e->group_wgrad == 0;
+    e->stale_begin = e->lo[0].q; e->stale_end = e->wsum;
     *out = e;
     return MB_OK;
 }
@@ -301,7 +320,7 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
     const size_t es = esize(dt);
     if (stage_begin < 0) stage_begin = 0;
     if (stage_end > NL + 2) stage_end = NL + 2;
-    if (stage_begin == 0) e->begin_backward_pass();
+    if (stage_begin == 0) CK(e->begin_backward_pass(e->G, st));
     float* P = e->P; float* G = e->G;
     char* ws = e->ws;
     const float pd = c.dropout;
@@ -439,7 +458,9 @@ static int xl_enqueue_step(mb_xlnet_engine* e, int B, int L, float* logits, floa
         const AdamArgs none = {};
         const size_t nd = e->n_decay, n = e->n_trainable;        // the frozen mask_emb slot behind n_trainable is never updated
         void* sh = e->c.dtype == DT_BF16 ? (void*)e->SH : nullptr;
-        CK(adamw_step(e->P, e->G, m, v, sh, nd, nd, e->sh_begin, e->sh_end, none, 1, st, e->adam_state(ws)));
+        const bool keep = e->keep_in_step();          // the layers' GEMM weight gradients: overwritten by the next backward, not zeroed
+        CK(adamw_step(e->P, e->G, m, v, sh, nd, nd, e->sh_begin, e->sh_end, none, 1, st, e->adam_state(ws), keep ? e->stale_begin : 0,
+                      keep ? e->stale_end : 0));
         CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
     }
     return MB_OK;
@@ -473,9 +494,15 @@ int mb_xlnet_set_head_mask(mb_xlnet_engine* e, const float* head_mask) {
     e->head_mask = head_mask;
     return MB_OK;
 }
+int mb_xlnet_materialize_grads(mb_xlnet_engine* e, void* stream) {
+    if (!e) return MB_ERR_ARG;
+    return e->materialize_grads(e->G, (hipStream_t)stream);
+}
+int mb_xlnet_grads_stale(const mb_xlnet_engine* e) { return e && e->grads_stale ? 1 : 0; }
 int mb_xlnet_mark_grads_zero(mb_xlnet_engine* e, int known_zero) {
     if (!e) return MB_ERR_ARG;
     e->grads_zero = known_zero != 0;
+    if (known_zero) e->grads_stale = false;
     return MB_OK;
 }
 

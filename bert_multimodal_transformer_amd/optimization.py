@@ -111,6 +111,8 @@ class AdamW(torch.optim.Optimizer):
             self._build_plan()
         L = _lib.lib()
         self._t += 1
+        for core, _ in self._covers.values():        # gradients a fused step left "logically zero" become real zeros before they are read
+            core.materialize_grads()
         dp = self._dp
         late = []
         if dp is not None and getattr(dp, "late_ranges", None):

@@ -84,13 +84,18 @@ class PinnedBatchRing(object):
 
     def __iter__(self):
         prev = None
-        for batch in self.loader:
-            blk, views = self._pack(batch)
-            if prev is not None:                # the consumer has enqueued everything that reads the previous block
+        try:
+            for batch in self.loader:
+                blk, views = self._pack(batch)
+                if prev is not None:                # the consumer has enqueued everything that reads the previous block
+                    prev.done.record(torch.cuda.current_stream(self.device))
+                    prev.busy = True
+                prev = blk
+                yield views
+        finally:
+            # also when the consumer breaks out, raises or closes the generator: the step it enqueued last may still be reading
+            # its block across PCIe (graph replay lets the host run several steps ahead) -- the block stays marked until that
+            # work has passed, so a later _pack cannot overwrite it underneath the GPU
+            if prev is not None:
                 prev.done.record(torch.cuda.current_stream(self.device))
                 prev.busy = True
-            prev = blk
-            yield views
-        if prev is not None:
-            prev.done.record(torch.cuda.current_stream(self.device))
-            prev.busy = True

@@ -190,17 +190,26 @@ int mb_bert_stage_grad_ranges(const mb_bert_engine* e, int stage, size_t* offs, 
  * mb_adamw_step with zero_grad) says so with known_zero = 1; anything else that writes gradients must leave / set it 0.  The
  * flag is consumed by the first stage of the next backward.  MB_WGRAD_OVERWRITE=0 disables the optimisation. */
 int mb_bert_mark_grads_zero(mb_bert_engine* e, int known_zero);
+/* Lazy zeroing.  The zeros mb_bert_train_step's AdamW would write over the layers' GEMM weight gradients are only ever
+ * overwritten by the next backward, so a step that ends with the optimizer leaves that range "logically zero, physically stale"
+ * (the rest of the buffer IS zeroed).  The engine writes the zeros itself before any of its own backwards that accumulates;
+ * a host about to READ the bound gradient buffer after such a step (its own optimizer, a gradient exchange, a user looking at
+ * .grad) calls mb_bert_materialize_grads first (a no-op when nothing is stale; mb_bert_grads_stale tells).  known_zero = 1
+ * above also clears the state.  MB_ADAMW_KEEP=0 disables lazy zeroing: every fused step then really clears the buffer. */
+int mb_bert_materialize_grads(mb_bert_engine* e, void* stream);
+int mb_bert_grads_stale(const mb_bert_engine* e);
 
 /* One whole optimizer step of train_epoch (multimodal_driver.py:354-388): `batch = tuple(t.to(DEVICE) ...)` staging, forward,
  * MSE (`:372-373`), loss.backward() (`:378`), optimizer.step() + optimizer.zero_grad() (`:384-386`) -- as TWO launches:
  *   1. a step prologue kernel that gathers the six batch tensors (device pointers, e.g. the landing buffer of an asynchronous
  *      H2D prefetch) into the engine's fixed staging buffers and writes this step's dropout keys (seed, step) and AdamW
  *      scalars (lr, bias-corrected step size from opt_step, grad_scale) into device memory;
- *   2. a replayed hipGraph with every other kernel of the step (captured on first use for each (B, L, output pointers);
- *      the internal side-stream fork / join of the weight-gradient launches is part of the graph).
+ *   2. a replayed hipGraph with every other kernel of the step (captured on first use for each (B, L, output pointers)):
+ *      one in-order kernel sequence -- the grouped weight-gradient launches run in line on the caller's stream.
  * Same kernels, same arithmetic, same dropout masks as mb_bert_forward + mb_bert_backward + 2 x mb_adamw_step with the same
  * (seed, step).  m, v: Adam moments parallel to the bound parameters; both NULL = no optimizer update (a gradient-accumulation
- * micro-step: gradients are accumulated, nothing is cleared).  With an update the gradient buffer is cleared in the same pass.
+ * micro-step: gradients are accumulated, nothing is cleared).  With an update the gradient buffer is cleared in the same pass
+ * (lazily over the layers' GEMM weights: see mb_bert_materialize_grads).
  * The two parameter groups of multimodal_driver.py:329-343 are [0, decay_count) with `weight_decay` and the rest with 0.
  * loss[0] = this step's MSE, loss_run (optional) += it.  mode: 1 = graph replay, 2 = the same sequence launched kernel by
  * kernel (reference for tests / profiling).  Pass the same logits / loss / m / v pointers every step: they are baked into the
@@ -278,6 +287,8 @@ const void* mb_xlnet_attention_probs(const mb_xlnet_engine* e, int layer, int* p
 int mb_xlnet_set_head_mask(mb_xlnet_engine* e, const float* head_mask);
 int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap);
 int mb_xlnet_mark_grads_zero(mb_xlnet_engine* e, int known_zero);      /* as mb_bert_mark_grads_zero */
+int mb_xlnet_materialize_grads(mb_xlnet_engine* e, void* stream);       /* as mb_bert_materialize_grads */
+int mb_xlnet_grads_stale(const mb_xlnet_engine* e);
 /* the MAG-XLNet counterparts of mb_bert_train_step / mb_bert_load_batch / mb_bert_graph_stats (same contracts; one iteration of
  * train_epoch, multimodal_driver.py:359-386, for the xlnet-base-cased model).  The two parameter groups are [0, decay_count) and
  * [decay_count, trainable_count); the frozen transformer.mask_emb slot behind them is never updated (HF AdamW skips grad-less
