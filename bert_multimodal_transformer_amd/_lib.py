@@ -93,6 +93,10 @@ PROTOTYPES = {
     "mb_bert_graph_stats": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "mb_bert_set_profiling": (_i, [_vp, _i]),
     "mb_bert_profile_wgrad_us": (_i, [_vp, C.POINTER(_f)]),
+    "mb_bert_profile_adamw_us": (_i, [_vp, C.POINTER(_f)]),
+    "mb_xlnet_set_profiling": (_i, [_vp, _i]),
+    "mb_xlnet_profile_wgrad_us": (_i, [_vp, C.POINTER(_f)]),
+    "mb_xlnet_profile_adamw_us": (_i, [_vp, C.POINTER(_f)]),
     "mb_xlnet_create": (_i, [C.POINTER(XlnetEngineConfig), C.POINTER(_vp)]),
     "mb_xlnet_destroy": (None, [_vp]),
     "mb_xlnet_num_tensors": (_i, [_vp]),

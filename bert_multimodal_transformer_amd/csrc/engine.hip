@@ -51,8 +51,6 @@ struct mb_bert_engine : StepMixin {
     int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128), 0 = four launches
     bool grouped = false;          // the layer's four weight gradients are ONE launch
     bool deferred = false;         // ... on the side stream, joined one stage later (MB_OVERLAP_WGRAD=0: on the caller's stream, in line)
-    bool prof = false;             // mb_bert_set_profiling: timing events around every grouped wgrad launch (on the side stream)
-    std::vector<hipEvent_t> pev;   // [2 * num_layers]
     float* attn_out = nullptr;     // mb_bert_set_attention_output: [num_layers][B][nh][L][L] fp32, filled by the next forwards
     const float* head_mask = nullptr;   // mb_bert_set_head_mask: [num_layers][num_heads] fp32 (caller-owned device memory)
     const float* emb_in = nullptr;      // mb_bert_set_inputs_embeds: [B*L][H] fp32 word embeddings given instead of input_ids
@@ -370,7 +368,7 @@ void mb_bert_destroy(mb_bert_engine* e) {
     if (!e) return;
     if (e->side) hipStreamDestroy(e->side);
     for (auto& ev : e->evs) if (ev) hipEventDestroy(ev);
-    for (auto& ev : e->pev) if (ev) hipEventDestroy(ev);
+    e->destroy_prof();
     e->drop_graphs();
     delete e;
 }
@@ -655,9 +653,11 @@ static int enqueue_step(mb_bert_engine* e, int B, int L, float* logits, float* l
         const size_t nd = e->n_decay, n = e->n_params;
         void* sh = e->c.dtype == DT_BF16 ? (void*)e->SH : nullptr;
         const bool keep = e->keep_in_step();          // the layers' GEMM weight gradients: overwritten by the next backward, not zeroed
+        CK(e->prof_mark(2 * e->c.num_layers, st));
         CK(adamw_step(e->P, e->G, m, v, sh, nd, nd, e->sh_begin, e->sh_end, none, 1, st, e->adam_state(ws), keep ? e->stale_begin : 0,
                       keep ? e->stale_end : 0));
         CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
+        CK(e->prof_mark(2 * e->c.num_layers + 1, st));
     }
     return MB_OK;
 }
@@ -714,25 +714,15 @@ int mb_bert_graph_stats(const mb_bert_engine* e, size_t* captures, size_t* launc
 
 int mb_bert_set_profiling(mb_bert_engine* e, int on) {
     if (!e) return MB_ERR_ARG;
-    if (on && e->pev.empty()) {
-        e->pev.assign((size_t)2 * e->c.num_layers, nullptr);
-        for (auto& ev : e->pev) CK((int)hipEventCreate(&ev));
-    }
-    e->prof = on != 0;
-    return MB_OK;
+    return e->set_profiling(on, e->c.num_layers);
 }
-
 int mb_bert_profile_wgrad_us(mb_bert_engine* e, float* avg_us) {
-    if (!e || !avg_us || !e->prof || !e->grouped) return MB_ERR_ARG;
-    double sum = 0.0;
-    for (int l = 0; l < e->c.num_layers; ++l) {
-        float ms = 0.f;
-        CK((int)hipEventSynchronize(e->pev[2 * l + 1]));
-        CK((int)hipEventElapsedTime(&ms, e->pev[2 * l], e->pev[2 * l + 1]));
-        sum += ms;
-    }
-    *avg_us = (float)(sum * 1e3 / e->c.num_layers);
-    return MB_OK;
+    if (!e || !e->grouped) return MB_ERR_ARG;
+    return e->prof_span_us(0, e->c.num_layers, avg_us);
+}
+int mb_bert_profile_adamw_us(mb_bert_engine* e, float* us) {
+    if (!e) return MB_ERR_ARG;
+    return e->prof_span_us(2 * e->c.num_layers, 1, us);
 }
 
 // ---- optional outputs and the autograd edge of the base model (bert.py:147-156, 227-237)

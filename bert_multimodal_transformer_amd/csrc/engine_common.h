@@ -173,6 +173,35 @@ struct StepMixin {
         return MB_OK;
     }
 
+    // measurement hooks (bench.py): timing events around every grouped weight-gradient launch and around the optimizer launches
+    // of a single-call step; steps run launch by launch while they are on (events cannot live inside a captured graph)
+    bool prof = false;
+    std::vector<hipEvent_t> pev;   // [2 * layers] grouped weight gradients, then [2] AdamW
+    int prof_layers = 0;
+    int set_profiling(int on, int layers) {
+        if (on && pev.empty()) {
+            prof_layers = layers;
+            pev.assign((size_t)2 * layers + 2, nullptr);
+            for (auto& ev : pev) CK((int)hipEventCreate(&ev));
+        }
+        prof = on != 0;
+        return MB_OK;
+    }
+    int prof_mark(int idx, hipStream_t st) { return (prof && !capturing && idx < (int)pev.size()) ? (int)hipEventRecord(pev[idx], st) : 0; }
+    int prof_span_us(int first, int pairs, float* avg_us) {
+        if (!prof || !avg_us || pev.empty()) return MB_ERR_ARG;
+        double sum = 0.0;
+        for (int i = 0; i < pairs; ++i) {
+            float ms = 0.f;
+            CK((int)hipEventSynchronize(pev[first + 2 * i + 1]));
+            CK((int)hipEventElapsedTime(&ms, pev[first + 2 * i], pev[first + 2 * i + 1]));
+            sum += ms;
+        }
+        *avg_us = (float)(sum * 1e3 / pairs);
+        return MB_OK;
+    }
+    void destroy_prof() { for (auto& ev : pev) if (ev) hipEventDestroy(ev); pev.clear(); }
+
     void carve_step(Carver& w, size_t Tpad, int V, int A, int max_batch, int num_labels, int nsites_) {
         nsites = nsites_;
         ws_state = w.take(2 * sizeof(AdamArgs) + (size_t)nsites * 8);

@@ -212,6 +212,7 @@ void mb_xlnet_destroy(mb_xlnet_engine* e) {
     if (!e) return;
     if (e->side) hipStreamDestroy(e->side);
     for (auto& ev : e->evs) if (ev) hipEventDestroy(ev);
+    e->destroy_prof();
     e->drop_graphs();
     delete e;
 }
@@ -409,7 +410,9 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                 CK(gemm_grouped_tn_launch(dt, wg, 7, e->group_wgrad, e->side));
                 CK((int)hipEventRecord(e->evs[2 * l + 1], e->side));              // "weight gradients of layer l are final"
             } else if (grouped) {
+                CK(e->prof_mark(2 * l, st));
                 CK(gemm_grouped_tn_launch(dt, wg, 7, e->group_wgrad, st));
+                CK(e->prof_mark(2 * l + 1, st));
             } else {
                 CK(wgrad(dt, H, H, Rk, ws + e->ws_pos, H, dkr, H, G + o.r, H, st));
                 CK(wgrad(dt, H, H, Tk, xin, H, dqkv, 3 * H, G + o.q, H, st));
@@ -459,9 +462,11 @@ static int xl_enqueue_step(mb_xlnet_engine* e, int B, int L, float* logits, floa
         const size_t nd = e->n_decay, n = e->n_trainable;        // the frozen mask_emb slot behind n_trainable is never updated
         void* sh = e->c.dtype == DT_BF16 ? (void*)e->SH : nullptr;
         const bool keep = e->keep_in_step();          // the layers' GEMM weight gradients: overwritten by the next backward, not zeroed
+        CK(e->prof_mark(2 * e->c.n_layer, st));
         CK(adamw_step(e->P, e->G, m, v, sh, nd, nd, e->sh_begin, e->sh_end, none, 1, st, e->adam_state(ws), keep ? e->stale_begin : 0,
                       keep ? e->stale_end : 0));
         CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
+        CK(e->prof_mark(2 * e->c.n_layer + 1, st));
     }
     return MB_OK;
 }
@@ -483,7 +488,7 @@ int mb_xlnet_train_step(mb_xlnet_engine* e, const int64_t* input_ids, const floa
     CK(xl_prepare_pass(e, B * L, st));
     return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
                            labels, B, L, seed, step, logits, loss, loss_run, m, v, lr, beta1, beta2, eps, weight_decay, opt_step,
-                           correct_bias, grad_scale, loss_scale, mode, false, st,
+                           correct_bias, grad_scale, loss_scale, mode, e->prof, st,
                            [&](float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
                                return xl_enqueue_step(e, B, L, lg, ls, lr_, m_, v_, sc, s);
                            });
@@ -493,6 +498,18 @@ int mb_xlnet_set_head_mask(mb_xlnet_engine* e, const float* head_mask) {
     if (!e) return MB_ERR_ARG;
     e->head_mask = head_mask;
     return MB_OK;
+}
+int mb_xlnet_set_profiling(mb_xlnet_engine* e, int on) {
+    if (!e) return MB_ERR_ARG;
+    return e->set_profiling(on, e->c.n_layer);
+}
+int mb_xlnet_profile_wgrad_us(mb_xlnet_engine* e, float* avg_us) {
+    if (!e || !e->ow_covers || e->deferred) return MB_ERR_ARG;
+    return e->prof_span_us(0, e->c.n_layer, avg_us);
+}
+int mb_xlnet_profile_adamw_us(mb_xlnet_engine* e, float* us) {
+    if (!e) return MB_ERR_ARG;
+    return e->prof_span_us(2 * e->c.n_layer, 1, us);
 }
 int mb_xlnet_materialize_grads(mb_xlnet_engine* e, void* stream) {
     if (!e) return MB_ERR_ARG;

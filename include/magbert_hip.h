@@ -238,6 +238,8 @@ int mb_bert_graph_stats(const mb_bert_engine* e, size_t* captures, size_t* launc
  * duration over the layers, i.e. the in-step duration (concurrent with the dgrad chain), comparable with rocprofv3. */
 int mb_bert_set_profiling(mb_bert_engine* e, int on);
 int mb_bert_profile_wgrad_us(mb_bert_engine* e, float* avg_us);
+/* the same for the two optimizer launches of the last mb_bert_train_step (first launch issued -> second complete, us) */
+int mb_bert_profile_adamw_us(mb_bert_engine* e, float* us);
 
 /* ------------------------------------------------------------------------------------------------ MAG-XLNet engine
  * MAG_XLNetForSequenceClassification forward / backward (xlnet.py:432-527 -> :15-429; XLNetLayer / SequenceSummary of
@@ -287,6 +289,9 @@ const void* mb_xlnet_attention_probs(const mb_xlnet_engine* e, int layer, int* p
 int mb_xlnet_set_head_mask(mb_xlnet_engine* e, const float* head_mask);
 int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap);
 int mb_xlnet_mark_grads_zero(mb_xlnet_engine* e, int known_zero);      /* as mb_bert_mark_grads_zero */
+int mb_xlnet_set_profiling(mb_xlnet_engine* e, int on);                 /* as mb_bert_set_profiling (the grouped launch has 7 problems) */
+int mb_xlnet_profile_wgrad_us(mb_xlnet_engine* e, float* avg_us);
+int mb_xlnet_profile_adamw_us(mb_xlnet_engine* e, float* us);
 int mb_xlnet_materialize_grads(mb_xlnet_engine* e, void* stream);       /* as mb_bert_materialize_grads */
 int mb_xlnet_grads_stale(const mb_xlnet_engine* e);
 /* the MAG-XLNet counterparts of mb_bert_train_step / mb_bert_load_batch / mb_bert_graph_stats (same contracts; one iteration of

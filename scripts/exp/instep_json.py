@@ -8,7 +8,7 @@ with open(path) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[2]]
+ad = [i for i, r in enumerate(rows) if "adamw" in r[2] and "tail" not in r[2]]
 ends = ad[1::2]
 lo, hi = ends[-steps - 1] + 1, ends[-1] + 1
 seg = rows[lo:hi]

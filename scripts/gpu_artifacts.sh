@@ -1,7 +1,7 @@
 #!/bin/bash
 # round artefacts: bench lines (headline, C5 shape, MAG-XLNet), rocprofv3 kernel stats, in-step kernel table, PMC passes.
-# usage: bash scripts/gpu_artifacts.sh r02     (every command under its own timeout)
-R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r02}
+# usage: bash scripts/gpu_artifacts.sh r03     (every command under its own timeout)
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r03}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 SB=$R/tools/bin/step_bench
@@ -14,6 +14,7 @@ for set in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rm -rf /tmp/p_$set && timeout 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/p_$set -o p -- $SB --graph 2 --h2d 2 --steps 6 --warmup 2 > /dev/null 2>&1 )
   f=$(find /tmp/p_$set -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 scripts/exp/pmc_reduce.py $f $set > $O/pmc_$set.txt
 done
+python3 scripts/exp/pmc_traffic_json.py $O "bert B=48 L=50 bf16" $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1 && cp $O/pmc_traffic.json profiles/pmc_traffic.json
 ( cd /tmp && rm -rf /tmp/p_sq && timeout 120 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d /tmp/p_sq -o p -- $SB --graph 2 --h2d 2 --steps 6 --warmup 2 > /dev/null 2>&1 )
 f=$(find /tmp/p_sq -name "*counter_collection.csv" | head -1)
 [ -n "$f" ] && python3 - "$f" > $O/pmc_SQ.txt <<'PY'
@@ -40,6 +41,7 @@ timeout 60 tools/bin/gemm_bench --T 4096 > $O/gemm_bench_T4096.txt 2>&1
 MB_GEMM_TRACE=1 timeout 60 tools/bin/gemm_bench --trace 1 > $O/gemm_phases.txt 2>&1
 { MB_ATTN_TRACE=1 timeout 60 tools/bin/attn_bench; MB_ATTN_TRACE=1 timeout 60 tools/bin/attn_bench --batch 32 --seq 128; timeout 60 tools/bin/attn_bench; } > $O/attention_phases.txt 2>&1
 timeout 60 tools/bin/launch_floor > $O/launch_floor.txt 2>&1
+{ timeout 60 tools/bin/adamw_bench; MB_ADAMW_VAR=0 timeout 60 tools/bin/adamw_bench; timeout 60 tools/bin/adamw_bench --zero 0; } > $O/adamw_bench.txt 2>&1
 # ---- 2. C5 shape and a second headline timing from the C++ driver
 { timeout 60 $SB --graph 1 --h2d 2 --steps 40 --warmup 8; timeout 60 $SB --graph 1 --h2d 2 --batch 32 --seq 128 --visual 35 --steps 30 --warmup 6; } > $O/step_bench.txt 2>&1
 ( cd /tmp && rm -rf /tmp/p_c5 && timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c5 -o sb -- $SB --graph 1 --h2d 2 --batch 32 --seq 128 --visual 35 --steps 12 --warmup 4 > /dev/null 2>&1 )
