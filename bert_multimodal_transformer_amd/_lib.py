@@ -84,6 +84,7 @@ PROTOTYPES = {
     "mb_xlnet_grads_stale": (_i, [_vp]),
     "mb_bert_set_head_mask": (_i, [_vp, _vp]),
     "mb_bert_set_inputs_embeds": (_i, [_vp, _vp]),
+    "mb_bert_set_position_ids": (_i, [_vp, _vp]),
     "mb_bert_inputs_embeds_grad": (_vp, [_vp]),
     "mb_bert_backward_outputs": (_i, [_vp, _vp, _vp, _vp]),
     "mb_bert_stage_grad_ranges": (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz), _i]),
@@ -94,6 +95,10 @@ PROTOTYPES = {
     "mb_bert_set_profiling": (_i, [_vp, _i]),
     "mb_bert_profile_wgrad_us": (_i, [_vp, C.POINTER(_f)]),
     "mb_bert_profile_adamw_us": (_i, [_vp, C.POINTER(_f)]),
+    "mb_xlnet_set_inputs_embeds": (_i, [_vp, _vp]),
+    "mb_xlnet_inputs_embeds_grad": (_vp, [_vp]),
+    "mb_xlnet_model_output": (_vp, [_vp, _vp]),
+    "mb_xlnet_backward_outputs": (_i, [_vp, _vp, _vp]),
     "mb_xlnet_set_profiling": (_i, [_vp, _i]),
     "mb_xlnet_profile_wgrad_us": (_i, [_vp, C.POINTER(_f)]),
     "mb_xlnet_profile_adamw_us": (_i, [_vp, C.POINTER(_f)]),

@@ -14,7 +14,7 @@ Different by design (MI355X-first):
   * `compute_dtype=torch.bfloat16` (perf mode) keeps bf16 activations + a bf16 operand shadow of the GEMM weights;
     `torch.float32` (parity mode) runs exact-fp32 MFMA and matches the CPU reference logits to < 1e-3;
   * the optional arguments of forward are built on the HIP path too (head_mask, inputs_embeds, output_attentions,
-    output_hidden_states); what is not (non-default position_ids, the decoder's encoder_hidden_states) raises
+    output_hidden_states, position_ids); what is not (the decoder's encoder_hidden_states) raises
     NotImplementedError instead of silently taking a slow path.
 """
 import ctypes as C
@@ -97,7 +97,7 @@ class _BaseFn(torch.autograd.Function):
         (pooled,) = ctx.saved_tensors
         cd = core.compute_dtype
         ds = None if d_seq is None else d_seq.to(cd).contiguous()
-        dz = None if d_pooled is None else (d_pooled.float() * (1.0 - pooled * pooled)).to(cd).contiguous()    # tanh'
+        dz = None if (d_pooled is None or core.kind != "bert") else (d_pooled.float() * (1.0 - pooled * pooled)).to(cd).contiguous()    # tanh'
         core.mark_grads_zero(False)           # as in _EngineFn: a node of somebody else's graph accumulates
         core.backward_outputs(ds, dz)
         return torch.zeros((), device=core.device), None, None, None, core.inputs_embeds_grad() if ctx.want_emb else None
@@ -143,7 +143,7 @@ class _Core(object):
         self.anchor = torch.zeros((), device=self.device, requires_grad=True)
         self.weights_dirty = True
         self.loss_buf = torch.zeros(2, dtype=torch.float32, device=self.device)   # [last step, running sum]
-        self._optional = (None, None)
+        self._optional = (None, None, None)
         self._gz = True             # the flat gradient buffer holds zeros (mirror of the engine's flag: survives a re-created engine)
 
     # -- engine lifecycle ---------------------------------------------------------------------------
@@ -175,7 +175,7 @@ class _Core(object):
             self._fn("destroy")(self.handle)
             self.ws = None
         self.handle = h
-        self._optional = (None, None)          # a new engine starts without head_mask / inputs_embeds
+        self._optional = (None, None, None)    # a new engine starts without head_mask / inputs_embeds / position_ids
         self.max_B, self.max_L = B, L
 
     def _ensure(self, B, L):
@@ -283,22 +283,23 @@ class _Core(object):
         self._ids_dev = ids.reshape(-1)
         return [_lib.ptr(t) for t in keep], keep
 
-    def _set_optional(self, head_mask=None, inputs_embeds=None):
-        """head_mask [n_layers][n_heads] / inputs_embeds [B*L][H] (fp32 device tensors or None) -> engine state; sticky in the
-        engine, so every pass states what it wants (the single-call step refuses to run with either set)."""
+    def _set_optional(self, head_mask=None, inputs_embeds=None, position_ids=None):
+        """head_mask [n_layers][n_heads] / inputs_embeds [B*L][H] (fp32 device tensors) / position_ids [B*L] (int64, MAG-BERT) or
+        None -> engine state; sticky in the engine, so every pass states what it wants (the single-call step refuses to run with
+        any of them set)."""
+        want = (head_mask, inputs_embeds, position_ids)
+        if all(x is None for x in want) and all(x is None for x in self._optional):
+            return
         if self.kind != "bert":
-            if inputs_embeds is not None:
-                raise NotImplementedError("inputs_embeds is built for MAG-BERT only")
-            if head_mask is None and self._optional == (None, None):
-                return
+            if position_ids is not None:
+                raise NotImplementedError("position_ids is an argument of MAG-BERT only (XLNet has relative positions)")
             _lib.check(self.lib.mb_xlnet_set_head_mask(self.handle, _lib.ptr(head_mask)))
-            self._optional = (head_mask, None)
-            return
-        if head_mask is None and inputs_embeds is None and self._optional == (None, None):
-            return
-        _lib.check(self.lib.mb_bert_set_head_mask(self.handle, _lib.ptr(head_mask)))
-        _lib.check(self.lib.mb_bert_set_inputs_embeds(self.handle, _lib.ptr(inputs_embeds)))
-        self._optional = (head_mask, inputs_embeds)          # kept alive: the engine holds raw pointers through the backward
+            _lib.check(self.lib.mb_xlnet_set_inputs_embeds(self.handle, _lib.ptr(inputs_embeds)))
+        else:
+            _lib.check(self.lib.mb_bert_set_head_mask(self.handle, _lib.ptr(head_mask)))
+            _lib.check(self.lib.mb_bert_set_inputs_embeds(self.handle, _lib.ptr(inputs_embeds)))
+            _lib.check(self.lib.mb_bert_set_position_ids(self.handle, _lib.ptr(position_ids)))
+        self._optional = want          # kept alive: the engine holds raw pointers through the backward
 
     def mark_grads_zero(self, known_zero=True):
         """tells the engine the flat gradient buffer holds zeros (it then stores, instead of accumulating, the layer weight
@@ -335,15 +336,15 @@ class _Core(object):
 
     def inputs_embeds_grad(self):
         """gradient of the inputs_embeds of the last forward, after its backward: fp32 [B, L, H] (a copy)"""
-        p = self.lib.mb_bert_inputs_embeds_grad(self.handle)
+        p = self._fn("inputs_embeds_grad")(self.handle)
         B, L, H = self._emb_shape
         off = p - self.ws.data_ptr()
         return self.ws[off: off + B * L * H * 4].view(torch.float32).view(B, L, H).clone()
 
     def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, training, head_mask=None,
-                inputs_embeds=None):
+                inputs_embeds=None, position_ids=None):
         dev = self.device
-        if inputs_embeds is not None:               # bert.py:158-168: shapes come from the embeddings, the ids are not read
+        if inputs_embeds is not None:               # bert.py:158-168 / xlnet.py:306-313: shapes come from the embeddings, the ids are not read
             inputs_embeds = inputs_embeds.detach().to(dev, torch.float32).contiguous()
             B, L, H = inputs_embeds.shape
             if H != self.config.hidden_size:
@@ -354,7 +355,9 @@ class _Core(object):
         self._ensure(B, L)
         if self.weights_dirty:
             self.sync_weights()
-        self._set_optional(self.head_mask_table(head_mask), inputs_embeds)
+        if position_ids is not None:
+            position_ids = position_ids.to(dev, torch.int64).expand(B, L).contiguous()
+        self._set_optional(self.head_mask_table(head_mask), inputs_embeds, position_ids)
         ptr, keep = self._inputs(input_ids, visual, acoustic, attention_mask, token_type_ids, labels)
         logits = torch.empty(B, self.config.num_labels, dtype=torch.float32, device=dev)
         if training:
@@ -404,7 +407,7 @@ class _Core(object):
             self.sync_weights()
         if labels is None:
             raise ValueError("the fused step needs label_ids")
-        self._set_optional(None, None)
+        self._set_optional(None, None, None)
         ptr, keep = self._inputs(input_ids, visual, acoustic, attention_mask, token_type_ids, labels, gather_in_step=True)
         if not hasattr(self, "_logit_bufs"):
             self._logit_bufs = {}
@@ -480,18 +483,30 @@ class _Core(object):
             _lib.check(self.lib.mb_bert_set_attention_output(self.handle, None))
 
     def backward_outputs(self, d_seq, d_pre):
-        """backward of the base model from the gradients of (sequence_output, pooler pre-activation): mb_bert_backward_outputs,
-        then the encoder / MAG / embedding stages"""
+        """backward of the base model from the gradients of its outputs -- MAG-BERT: (sequence_output, pooler pre-activation),
+        mb_bert_backward_outputs; MAG-XLNet: the dropped last hidden state, mb_xlnet_backward_outputs -- then the encoder / MAG /
+        embedding stages"""
         nstage = self.n_layers + 2
         self._gz = False
         with _Core._Hop(self):
-            _lib.check(self.lib.mb_bert_backward_outputs(self.handle, _lib.ptr(d_seq), _lib.ptr(d_pre), self.stream()))
+            if self.kind == "bert":
+                _lib.check(self.lib.mb_bert_backward_outputs(self.handle, _lib.ptr(d_seq), _lib.ptr(d_pre), self.stream()))
+            else:
+                _lib.check(self.lib.mb_xlnet_backward_outputs(self.handle, _lib.ptr(d_seq), self.stream()))
             for hook in self.stage_hooks:
                 hook(0)
             for s in range(1, nstage):
-                _lib.check(self.lib.mb_bert_backward(self.handle, None, None, 1.0, s, s + 1, self.stream()))
+                _lib.check(self._fn("backward")(self.handle, None, None, 1.0, s, s + 1, self.stream()))
                 for hook in self.stage_hooks:
                     hook(s)
+
+    def xl_model_output(self, B, L):
+        """MAG_XLNetModel's return value (xlnet.py:396-405): the last layer's output after the final dropout, fp32 [B, L, H]"""
+        with _Core._Hop(self):
+            p = self.lib.mb_xlnet_model_output(self.handle, self.stream())
+        if not p:
+            raise _lib.MagbertError("no forward has run")
+        return self._act(p, B, L).clone()          # the engine's scratch is reused by the backward: hand out a copy
 
     def sequence_output(self, B, L):
         return self._act(self._fn("sequence_output")(self.handle), B, L)
@@ -621,10 +636,16 @@ class _MagBertBase(nn.Module):
             raise ValueError("You have to specify either input_ids or inputs_embeds")
         B, L = input_ids.shape if input_ids is not None else inputs_embeds.shape[:-1]
         dev = self._core.device
-        if position_ids is not None:      # only the default arange (BertEmbeddings) is built: the position is the row index
-            want = torch.arange(L, device=position_ids.device).expand(position_ids.shape[0], L)
-            if tuple(position_ids.shape[-1:]) != (L,) or not torch.equal(position_ids.reshape(-1, L), want):
-                raise NotImplementedError("position_ids other than arange(seq_len) are not supported by the HIP path")
+        if position_ids is not None:      # bert.py:211-216 -> BertEmbeddings: rows of the position table, [B, L] or broadcastable to it
+            position_ids = torch.as_tensor(position_ids)
+            if position_ids.shape[-1] != L or position_ids.numel() not in (L, B * L):
+                raise ValueError("position_ids must be [batch, seq_len] or [1, seq_len], got %s" % (tuple(position_ids.shape),))
+            position_ids = position_ids.reshape(-1, L)
+            if int(position_ids.min()) < 0 or int(position_ids.max()) >= self.config.max_position_embeddings:
+                raise IndexError("position_ids out of range of the %d-row position table" % self.config.max_position_embeddings)
+            if torch.equal(position_ids.cpu(), torch.arange(L).expand(position_ids.shape[0], L)):
+                position_ids = None       # the default: the kernels index the table with the row's place in its sample
+        self._position_ids = position_ids
         if attention_mask is None:
             attention_mask = torch.ones(B, L, dtype=torch.int64, device=dev)       # bert.py:173-174
         if token_type_ids is None:
@@ -833,7 +854,8 @@ class MAG_BertModel(_MagBertBase):
         """-> (sequence_output, pooled_output, (hidden_states), (attentions)) like bert.py:233-237.  sequence_output and
         pooled_output carry an autograd edge into the engine (a head built on top of this model trains the whole stack, and
         inputs_embeds receives its gradient); hidden_states / attentions are detached fp32 copies.  head_mask: [num_heads] or
-        [num_layers, num_heads].  Non-default position_ids and the decoder arguments are not built on the HIP path and raise."""
+        [num_layers, num_heads]; position_ids: rows of the position table, [B, L] or [1, L].  The decoder arguments
+        (encoder_hidden_states / encoder_attention_mask: cross-attention, which MAG-BERT's encoder does not have) raise."""
         self._unsupported(encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
@@ -846,7 +868,7 @@ class MAG_BertModel(_MagBertBase):
             probs = core.attention_buffer(B, L)
         try:
             core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, head_mask=head_mask,
-                         inputs_embeds=inputs_embeds)
+                         inputs_embeds=inputs_embeds, position_ids=self._position_ids)
         finally:
             if output_attentions:
                 core.attention_done()
@@ -890,7 +912,7 @@ class MAG_BertForSequenceClassification(_FusedStep, _MagBertBase):
             probs = core.attention_buffer(B, L)
         try:
             logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training,
-                                  head_mask=head_mask, inputs_embeds=inputs_embeds)
+                                  head_mask=head_mask, inputs_embeds=inputs_embeds, position_ids=self._position_ids)
         finally:
             if output_attentions:
                 core.attention_done()

@@ -54,6 +54,7 @@ struct mb_bert_engine : StepMixin {
     float* attn_out = nullptr;     // mb_bert_set_attention_output: [num_layers][B][nh][L][L] fp32, filled by the next forwards
     const float* head_mask = nullptr;   // mb_bert_set_head_mask: [num_layers][num_heads] fp32 (caller-owned device memory)
     const float* emb_in = nullptr;      // mb_bert_set_inputs_embeds: [B*L][H] fp32 word embeddings given instead of input_ids
+    const int64_t* pos_ids = nullptr;   // mb_bert_set_position_ids: [B*L] rows of the position table (null: arange(L), the default)
     bool ran_forward = false;
     bool ws_zeroed = false;
     uint64_t seed = 0, step = 0;
@@ -431,7 +432,7 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     // embeddings (bert.py:211-216)
     CK(embed_ln_forward(dt, input_ids, token_type_ids, e->emb_in ? e->emb_in : P + e->word, P + e->pos, P + e->type, P + e->emb_lnw, P + e->emb_lnb,
                         c.layer_norm_eps, ws + e->ws_emb, (float*)(ws + e->ws_emb_st), (float*)(ws + e->ws_emb_st) + T, B, L,
-                        H, e->key(SITE_EMB, c.hidden_dropout), st));
+                        H, e->key(SITE_EMB, c.hidden_dropout), st, e->pos_ids));
     // MAG (bert.py:219): packed weights are refreshed every pass (5.5 MB, one launch) so optimizer steps are seen
     CK(mag_fwd_impl(dt, ws + e->ws_emb, visual, acoustic, P + e->mag_whv, P + e->mag_bhv, P + e->mag_wha, P + e->mag_bha,
                     P + e->mag_wv, P + e->mag_bv, P + e->mag_wa, P + e->mag_ba, P + e->mag_lnw, P + e->mag_lnb,
@@ -623,7 +624,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             CK(embed_ln_backward(dt, de, e->ids, e->seg, e->ids ? P + e->word : e->emb_in, P + e->pos, P + e->type, P + e->emb_lnw,
                                  (const float*)(ws + e->ws_emb_st), (const float*)(ws + e->ws_emb_st) + T,
                                  (float*)(ws + e->ws_dsum), e->ids ? G + e->word : nullptr, G + e->pos, G + e->type, G + e->emb_lnw,
-                                 G + e->emb_lnb, B, L, H, c.pad_token_id, e->key(SITE_EMB, c.hidden_dropout), st));
+                                 G + e->emb_lnb, B, L, H, c.pad_token_id, e->key(SITE_EMB, c.hidden_dropout), st, e->pos_ids));
         }
     }
     return MB_OK;
@@ -643,7 +644,7 @@ static int enqueue_step(mb_bert_engine* e, int B, int L, float* logits, float* l
     float* keep_attn = e->attn_out;
     e->attn_out = nullptr;                      // optional outputs belong to explicit forwards, never to a (captured) training step
     struct Restore { mb_bert_engine* e; float* p; ~Restore() { e->attn_out = p; } } restore{e, keep_attn};
-    if (e->head_mask || e->emb_in) return MB_ERR_MODE;     // head_mask / inputs_embeds are arguments of explicit forwards only
+    if (e->head_mask || e->emb_in || e->pos_ids) return MB_ERR_MODE;     // head_mask / inputs_embeds / position_ids are arguments of explicit forwards only
     CK(mb_bert_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
                        (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
                        loss_run, st));
@@ -754,6 +755,11 @@ int mb_bert_set_head_mask(mb_bert_engine* e, const float* head_mask) {
 int mb_bert_set_inputs_embeds(mb_bert_engine* e, const float* inputs_embeds) {
     if (!e) return MB_ERR_ARG;
     e->emb_in = inputs_embeds;
+    return MB_OK;
+}
+int mb_bert_set_position_ids(mb_bert_engine* e, const int64_t* position_ids) {
+    if (!e) return MB_ERR_ARG;
+    e->pos_ids = position_ids;
     return MB_OK;
 }
 const float* mb_bert_inputs_embeds_grad(const mb_bert_engine* e) {

@@ -93,11 +93,12 @@ int ln_reduce_partials_layers(const float* partials_a, const float* partials_b, 
 // BertEmbeddings: e = dropout(LN(word[ids] + pos[l] + type[seg])).
 int embed_ln_forward(int dtype, const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
                      const float* type, const float* gamma, const float* beta, float eps, void* out,
-                     float* mean, float* rstd, int B, int L, int H, DropKey drop, hipStream_t st);
+                     float* mean, float* rstd, int B, int L, int H, DropKey drop, hipStream_t st,
+                     const int64_t* pos_ids = nullptr);       // [B*L] rows of `pos` (null: arange(L) per sample, bert.py:211-216)
 int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int64_t* seg, const float* word,
                       const float* pos, const float* type, const float* gamma, const float* mean, const float* rstd,
                       float* dsum_ws, float* dword, float* dpos, float* dtype_, float* dgamma, float* dbeta,
-                      int B, int L, int H, int pad_id, DropKey drop, hipStream_t st);
+                      int B, int L, int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids = nullptr);
 
 // column sums: out[n] += sum_m x[m][n]
 int colsum(int dtype, const void* x, int ldx, float* out, int rows, int cols, hipStream_t st);
@@ -155,6 +156,9 @@ int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const f
 // out[t] = dropout(word[ids[t]])  (xlnet.py:304-305) ; backward scatter-adds into dword
 int gather_drop_forward(int dtype, const int64_t* ids, const float* word, void* out, int rows, int H, DropKey drop, hipStream_t st);
 int gather_drop_backward(int dtype, const void* dout, const int64_t* ids, float* dword, int rows, int H, DropKey drop, hipStream_t st);
+// (both: ids == nullptr = inputs_embeds -- `word` / `dword` are then [rows][H] fp32, read / written row by row)
+// y = x * dropout mask over [rows][H] (element index = offset)
+int drop_rows(int dtype, const void* x, void* y, int rows, int H, DropKey drop, hipStream_t st);
 // pos[b][p][:] = dropout([sin(pos_p * inv_freq) | cos(...)]) with pos_p = L - p, p in [0, 2L)   (xlnet.py:93-146,332-333)
 int xlnet_pos_emb(int dtype, void* out, int B, int L, int H, DropKey drop, hipStream_t st);
 // xs[b] = x[b, L-1, :] * dropout   (final dropout xlnet.py:396 + SequenceSummary "last") ; backward scatters into a zeroed dx

@@ -212,14 +212,15 @@ __global__ void __launch_bounds__(256) embed_fwd_kernel(const int64_t* __restric
                                                         const float* __restrict__ type, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, T* __restrict__ out,
                                                         float* __restrict__ mean, float* __restrict__ rstd, int rows, int L,
-                                                        DropKey drop) {
+                                                        DropKey drop, const int64_t* __restrict__ pos_ids) {
     drop.resolve();
     constexpr int H = CH * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
     // ids == nullptr: inputs_embeds (bert.py:185-195) -- `word` is then the [rows][H] fp32 embedding of each token itself
-    const size_t id = ids ? (size_t)ids[row] : (size_t)row, sg = (size_t)seg[row], l = (size_t)(row % L);
+    // pos_ids == nullptr: BertEmbeddings' default position_ids = arange(L) (bert.py:211-216), i.e. the row's index in its sample
+    const size_t id = ids ? (size_t)ids[row] : (size_t)row, sg = (size_t)seg[row], l = pos_ids ? (size_t)pos_ids[row] : (size_t)(row % L);
     f32x4 v[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -249,7 +250,7 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, float* __restrict__ dsum_ws,
                                                         float* dword, float* dgamma, float* dbeta, int rows, int L,
-                                                        int pad_id, DropKey drop) {
+                                                        int pad_id, DropKey drop, const int64_t* __restrict__ pos_ids) {
     drop.resolve();
     constexpr int H = CH * 256;
     constexpr float invH = 1.0f / H;
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
     for (int i = 0; i < RPW; ++i) {
         const int row = (blockIdx.x * 4 + wave) * RPW + i;
         if (row >= rows) break;
-        const size_t id = ids ? (size_t)ids[row] : (size_t)row, sg = (size_t)seg[row], l = (size_t)(row % L);
+        const size_t id = ids ? (size_t)ids[row] : (size_t)row, sg = (size_t)seg[row], l = pos_ids ? (size_t)pos_ids[row] : (size_t)(row % L);
         const float mu = mean[row], rs = rstd[row];
         f32x4 dyv[CH], xh[CH], gg[CH];
         float s1 = 0.f, s2 = 0.f;
@@ -304,7 +305,8 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
 
 // position / token-type table grads: block (l, c) sums 256 columns of dsum over the batch (sole owner of that piece of dpos[l]).
 __global__ void __launch_bounds__(256) embed_pos_type_kernel(const float* __restrict__ dsum_ws, const int64_t* __restrict__ seg,
-                                                             float* dpos, float* dtype_, int B, int L, int H) {
+                                                             float* dpos, float* dtype_, int B, int L, int H,
+                                                             const int64_t* __restrict__ pos_ids) {
     const int l = blockIdx.x;
     {
         const int col = blockIdx.y * 256 + threadIdx.x;
@@ -313,7 +315,7 @@ __global__ void __launch_bounds__(256) embed_pos_type_kernel(const float* __rest
         // eight samples per batch of loads (one sample per iteration made the sweep over B a chain of B memory round trips)
         for (int b0 = 0; b0 < B; b0 += 8) {
             float d[8];
-            int64_t sg[8];
+            int64_t sg[8], pp[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int b = b0 + u;
@@ -321,16 +323,18 @@ __global__ void __launch_bounds__(256) embed_pos_type_kernel(const float* __rest
                 const int t = (ok ? b : 0) * L + l;
                 d[u] = ok ? dsum_ws[(size_t)t * H + col] : 0.f;
                 sg[u] = ok ? seg[t] : 0;
+                pp[u] = (ok && pos_ids) ? pos_ids[t] : -1;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                ap += d[u];
+                if (pp[u] >= 0) atomicAdd(dpos + (size_t)pp[u] * H + col, d[u]);      // explicit position_ids: rows of other blocks too
+                else ap += d[u];
                 if (sg[u] == 0) a0 += d[u];
                 else if (sg[u] == 1) a1 += d[u];
                 else atomicAdd(dtype_ + (size_t)sg[u] * H + col, d[u]);
             }
         }
-        dpos[(size_t)l * H + col] += ap;
+        if (!pos_ids) dpos[(size_t)l * H + col] += ap;
         atomicAdd(dtype_ + col, a0);
         atomicAdd(dtype_ + H + col, a1);
     }
@@ -446,12 +450,12 @@ int ln_reduce_partials_layers(const float* pa, const float* pb, size_t layer_str
 
 int embed_ln_forward(int dtype, const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
                      const float* type, const float* gamma, const float* beta, float eps, void* out, float* mean,
-                     float* rstd, int B, int L, int H, DropKey drop, hipStream_t st) {
+                     float* rstd, int B, int L, int H, DropKey drop, hipStream_t st, const int64_t* pos_ids) {
     const int rows = B * L;
     if (rows <= 0) return MB_OK;
     MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
         hipLaunchKernelGGL((embed_fwd_kernel<T, CH>), dim3((rows + 3) / 4), dim3(256), 0, st, ids, seg, word, pos, type,
-                           gamma, beta, eps, (T*)out, mean, rstd, rows, L, drop);
+                           gamma, beta, eps, (T*)out, mean, rstd, rows, L, drop, pos_ids);
     }))
     return (int)hipGetLastError();
 }
@@ -459,16 +463,16 @@ int embed_ln_forward(int dtype, const int64_t* ids, const int64_t* seg, const fl
 int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int64_t* seg, const float* word,
                       const float* pos, const float* type, const float* gamma, const float* mean, const float* rstd,
                       float* dsum_ws, float* dword, float* dpos, float* dtype_, float* dgamma, float* dbeta, int B, int L,
-                      int H, int pad_id, DropKey drop, hipStream_t st) {
+                      int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids) {
     const int rows = B * L;
     if (rows <= 0) return MB_OK;
     constexpr int RPW = 4;
     MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
         hipLaunchKernelGGL((embed_bwd_kernel<T, CH, RPW>), dim3((rows + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st,
                            (const T*)dout, ids, seg, word, pos, type, gamma, mean, rstd, dsum_ws, dword, dgamma, dbeta,
-                           rows, L, pad_id, drop);
+                           rows, L, pad_id, drop, pos_ids);
     }))
-    hipLaunchKernelGGL(embed_pos_type_kernel, dim3(L, (H + 255) / 256), dim3(256), 0, st, dsum_ws, seg, dpos, dtype_, B, L, H);
+    hipLaunchKernelGGL(embed_pos_type_kernel, dim3(L, (H + 255) / 256), dim3(256), 0, st, dsum_ws, seg, dpos, dtype_, B, L, H, pos_ids);
     return (int)hipGetLastError();
 }
 

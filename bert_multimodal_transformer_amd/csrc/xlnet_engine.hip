@@ -34,6 +34,9 @@ struct mb_xlnet_engine : StepMixin {
     size_t ws_dxa, ws_dxb, ws_dvec, ws_gsave, ws_dz, ws_dxs, ws_lnp_a, ws_lnp_b;
     size_t lnp_stride = 0;         // floats per layer in each of the two LayerNorm partial buffers
     const float* head_mask = nullptr;   // mb_xlnet_set_head_mask: [n_layer][n_head] fp32 (caller-owned device memory)
+    const float* emb_in = nullptr;      // mb_xlnet_set_inputs_embeds: [B*L][H] fp32 word embeddings given instead of input_ids (xlnet.py:306-313)
+    size_t ws_demb = 0;                 // fp32 [T][H]: gradient of the given embeddings
+    bool ran_forward = false;
     size_t ws_bytes;
     float* P = nullptr; float* G = nullptr; char* SH = nullptr; char* ws = nullptr;
     const int64_t* ids = nullptr; const int64_t* seg = nullptr; const int64_t* mask = nullptr;
@@ -151,6 +154,7 @@ static void xl_build_layout(mb_xlnet_engine* e) {
         e->ws_dkr[k] = w.take(R * H * es);
     }
     e->ws_dvec = w.take(T * H * es); e->ws_gsave = w.take(PP * es);
+    e->ws_demb = w.take(T * H * 4);
     e->ws_dz = w.take((size_t)c.max_batch * H * es); e->ws_dxs = w.take((size_t)c.max_batch * H * es);
     e->lnp_stride = ln_partials_floats((int)T, (int)H);        // per-layer slabs: the single-call step reduces all layers at once
     e->ws_lnp_a = w.take(e->lnp_stride * 4 * c.n_layer); e->ws_lnp_b = w.take(e->lnp_stride * 4 * c.n_layer);
@@ -256,16 +260,17 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
     const mb_xlnet_config& c = e->c;
     if (!e->P || !e->ws) return MB_ERR_ARG;
     if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
-    if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !logits) return MB_ERR_ARG;
+    if ((!input_ids && !e->emb_in) || !visual || !acoustic || !attention_mask || !token_type_ids || !logits) return MB_ERR_ARG;
     const int dt = c.dtype, H = c.d_model, I = c.d_inner, T = B * L, nh = c.n_head, R = B * 2 * L;
     const size_t es = esize(dt);
-    e->ids = input_ids; e->seg = token_type_ids; e->mask = attention_mask;
+    if (e->emb_in) input_ids = nullptr;           // inputs_embeds given: no table gather, no scatter into the word table
+    e->ids = input_ids; e->seg = token_type_ids; e->mask = attention_mask; e->ran_forward = true;
     e->B = B; e->L = L; e->training = training; e->seed = seed; e->step = step; e->logits = logits;
     float* P = e->P;
     char* ws = e->ws;
     if (!e->capturing) CK(xl_prepare_pass(e, T, st));
     const float pd = c.dropout;
-    CK(gather_drop_forward(dt, input_ids, P + e->word, ws + e->ws_x[0], T, H, e->key(XS_EMB, pd), st));            // xlnet.py:304-305
+    CK(gather_drop_forward(dt, input_ids, e->emb_in ? e->emb_in : P + e->word, ws + e->ws_x[0], T, H, e->key(XS_EMB, pd), st));   // xlnet.py:304-313
     CK(xlnet_pos_emb(dt, ws + e->ws_pos, B, L, H, e->key(XS_POS, pd), st));                                         // xlnet.py:332-333
     for (int l = 0; l < c.n_layer; ++l) {
         const XlLayerOff& o = e->lo[l];
@@ -315,7 +320,7 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                       int stage_end, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const mb_xlnet_config& c = e->c;
-    if (!e->G || !e->ids) return MB_ERR_ARG;
+    if (!e->G || !e->ran_forward) return MB_ERR_ARG;
     const int dt = c.dtype, H = c.d_model, I = c.d_inner, B = e->B, L = e->L, T = B * L, nh = c.n_head, NL = c.n_layer;
     const int Tk = (int)align_up((size_t)T, 64), Rk = (int)align_up((size_t)B * 2 * L, 64);
     const size_t es = esize(dt);
@@ -442,7 +447,7 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
             if (grouped && e->deferred && l + 1 < NL) CK((int)hipStreamWaitEvent(st, e->evs[2 * (l + 1) + 1], 0));
         } else {
             if (e->deferred && e->side) CK((int)hipStreamWaitEvent(st, e->evs[1], 0));       // weight gradients of layer 0
-            CK(gather_drop_backward(dt, ws + e->ws_dxa, e->ids, G + e->word, T, H, e->key(XS_EMB, pd), st));
+            CK(gather_drop_backward(dt, ws + e->ws_dxa, e->ids, e->ids ? G + e->word : (float*)(ws + e->ws_demb), T, H, e->key(XS_EMB, pd), st));
         }
     }
     return MB_OK;
@@ -483,7 +488,7 @@ int mb_xlnet_train_step(mb_xlnet_engine* e, const int64_t* input_ids, const floa
     if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !labels || !logits || !loss) return MB_ERR_ARG;
     if ((m == nullptr) != (v == nullptr) || (mode != 1 && mode != 2)) return MB_ERR_ARG;
     if (e->deferred) return MB_ERR_MODE;          // MB_OVERLAP_WGRAD=1: the side-stream scheme is driven stage by stage (mb_xlnet_backward)
-    if (e->head_mask) return MB_ERR_MODE;         // head_mask is an argument of explicit forwards only
+    if (e->head_mask || e->emb_in) return MB_ERR_MODE;         // head_mask / inputs_embeds are arguments of explicit forwards only
     e->training = 1;
     CK(xl_prepare_pass(e, B * L, st));
     return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
@@ -553,11 +558,38 @@ const void* mb_xlnet_hidden_state(const mb_xlnet_engine* e, int i) {      // inp
     return e->ws + e->ws_x[i];
 }
 const void* mb_xlnet_attention_probs(const mb_xlnet_engine* e, int layer, int* padded_len) {
-    if (!e || !e->ws || !e->ids || layer < 0 || layer >= e->c.n_layer) return nullptr;
+    if (!e || !e->ws || !e->ran_forward || layer < 0 || layer >= e->c.n_layer) return nullptr;
     if (padded_len) *padded_len = (e->L + 31) / 32 * 32;
     return e->ws + e->lw[layer].psave;
 }
 const void* mb_xlnet_sequence_output(const mb_xlnet_engine* e) { return e->ws ? e->ws + e->ws_x[e->c.n_layer] : nullptr; }
+int mb_xlnet_set_inputs_embeds(mb_xlnet_engine* e, const float* inputs_embeds) {
+    if (!e) return MB_ERR_ARG;
+    e->emb_in = inputs_embeds;
+    return MB_OK;
+}
+const float* mb_xlnet_inputs_embeds_grad(const mb_xlnet_engine* e) {
+    if (!e || !e->ws || !e->ran_forward) return nullptr;
+    return (const float*)(e->ws + e->ws_demb);
+}
+// MAG_XLNetModel's return value (xlnet.py:396-405): the last layer's output AFTER the final dropout, whole sequence.  Written to a
+// scratch activation (valid until the next backward); eval mode: a copy.
+const void* mb_xlnet_model_output(mb_xlnet_engine* e, void* stream) {
+    if (!e || !e->ws || !e->ran_forward) return nullptr;
+    const mb_xlnet_config& c = e->c;
+    if (drop_rows(c.dtype, e->ws + e->ws_x[c.n_layer], e->ws + e->ws_dxb, e->B * e->L, c.d_model, e->key(XS_FINAL, c.dropout), (hipStream_t)stream))
+        return nullptr;
+    return e->ws + e->ws_dxb;
+}
+// the autograd edge of the base model: d_output [B*L][H] (activation dtype) = gradient of mb_xlnet_model_output's tensor -> entry
+// gradient of the layer stages (the final dropout's mask applied); then mb_xlnet_backward(stage 1 .. n_layer + 1)
+int mb_xlnet_backward_outputs(mb_xlnet_engine* e, const void* d_output, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!e || !e->G || !e->ran_forward || !d_output) return MB_ERR_ARG;
+    CK(e->begin_backward_pass(e->G, st));
+    const mb_xlnet_config& c = e->c;
+    return drop_rows(c.dtype, d_output, e->ws + e->ws_dxa, e->B * e->L, c.d_model, e->key(XS_FINAL, c.dropout), st);
+}
 
 int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap) {
     const int NL = e->c.n_layer;

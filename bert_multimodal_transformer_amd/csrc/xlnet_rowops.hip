@@ -1,5 +1,6 @@
 // Small HBM-bound kernels of the MAG-XLNet path (/root/reference/xlnet.py): word-embedding gather + dropout, the relative
 // sinusoid table with its dropout, and the "last token" summary gather.
+#include <algorithm>
 #include "kernels.h"
 
 namespace mb {
@@ -11,7 +12,7 @@ __global__ void __launch_bounds__(256) gather_drop_fwd_kernel(const int64_t* __r
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
-    const size_t id = (size_t)ids[row];
+    const size_t id = ids ? (size_t)ids[row] : (size_t)row;      // ids == nullptr: inputs_embeds -- `word` is the [rows][H] embedding itself
     for (int col = lane * 4; col < H; col += 256) {
         f32x4 v = *(const f32x4*)(word + id * H + col);
         const uint32_t idx = (uint32_t)row * H + col;
@@ -32,6 +33,11 @@ __global__ void __launch_bounds__(256) gather_drop_bwd_kernel(const T* __restric
     const int col = blockIdx.y * 256 + threadIdx.x;
     if (col >= H) return;
     const int r0 = blockIdx.x * RC, r1 = min(rows, r0 + RC);
+    if (ids == nullptr) {        // inputs_embeds: the gradient of row r is row r of the output (no table, nothing to merge)
+        for (int r = r0; r < r1; ++r)
+            dword[(size_t)r * H + col] = to_f(dout[(size_t)r * H + col]) * drop_mult(drop, (uint32_t)r * (uint32_t)H + (uint32_t)col);
+        return;
+    }
     size_t cur = (size_t)ids[r0];
     float acc = 0.f;
     for (int r = r0; r < r1; ++r) {
@@ -86,6 +92,19 @@ __global__ void last_token_bwd_kernel(const T* __restrict__ dxs, T* __restrict__
     dx[dst] = from_f<T>(to_f(dxs[i]) * drop_mult(drop, (uint32_t)dst));
 }
 
+// y = x * dropout mask over a [rows][H] activation (element index = its offset): the final dropout of xlnet.py:396 on the whole
+// sequence output (MAG_XLNetModel's return value) and on the gradient that comes back for it
+template <class T>
+__global__ void __launch_bounds__(256) drop_rows_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n, DropKey drop) {
+    drop.resolve();
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        f32x4 v = load4(x + i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= drop_mult(drop, (uint32_t)(i + r));
+        store4(y + i, v);
+    }
+}
+
 #define MB_DISPATCH_T(dtype, ...)                                  \
     if ((dtype) == DT_BF16) { typedef bf16 T; __VA_ARGS__ }        \
     else if ((dtype) == DT_F32) { typedef float T; __VA_ARGS__ }   \
@@ -101,6 +120,13 @@ int gather_drop_backward(int dtype, const void* dout, const int64_t* ids, float*
     if (rows <= 0) return MB_OK;
     constexpr int RC = 16;
     MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((gather_drop_bwd_kernel<T, RC>), dim3((rows + RC - 1) / RC, (H + 255) / 256), dim3(256), 0, st, (const T*)dout, ids, dword, rows, H, drop); })
+    return (int)hipGetLastError();
+}
+int drop_rows(int dtype, const void* x, void* y, int rows, int H, DropKey drop, hipStream_t st) {
+    if (rows <= 0) return MB_OK;
+    if (H % 4) return MB_ERR_SHAPE;
+    const size_t n = (size_t)rows * H;
+    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((drop_rows_kernel<T>), dim3((unsigned)std::min<size_t>((n / 4 + 255) / 256, 2048)), dim3(256), 0, st, (const T*)x, (T*)y, n, drop); })
     return (int)hipGetLastError();
 }
 int xlnet_pos_emb(int dtype, void* out, int B, int L, int H, DropKey drop, hipStream_t st) {

@@ -5,16 +5,17 @@ Same class names, constructor `(config, multimodal_config)`, forward argument or
 (transformer.word_embedding.weight, transformer.mask_emb, transformer.layer.{i}.rel_attn.{q,k,v,o,r,r_r_bias,r_s_bias,
 r_w_bias,seg_embed,layer_norm.*}, transformer.layer.{i}.ff.{layer_norm,layer_1,layer_2}.*, transformer.MAG.*,
 sequence_summary.summary.*, logits_proj.*).  Built for the configuration the reference driver runs
-(multimodal_driver.py:363-370: attention_mask + token_type_ids, no mems / perm_mask / target_mapping / input_mask /
-inputs_embeds; those raise NotImplementedError; output_hidden_states / output_attentions are served from the activations the
-engine keeps for its backward, head_mask scales each head's attention output inside the kernels), sequence length <= 64, MAG injected in front of layer
+(multimodal_driver.py:363-370: attention_mask + token_type_ids, no mems / perm_mask / target_mapping / input_mask: those raise
+NotImplementedError; inputs_embeds, output_hidden_states / output_attentions (served from the activations the engine keeps for
+its backward) and head_mask (scales each head's attention output inside the kernels) are built, and MAG_XLNetModel's output is
+differentiable), sequence length <= 64, MAG injected in front of layer
 XLNET_INJECTION_INDEX (global_configs.py:19, xlnet.py:371-372).
 """
 import torch
 import torch.nn as nn
 
 from . import _lib
-from .bert import _Core, _EngineFn, _FusedStep, _MagBertBase, _attach_parameters, _init_weights
+from .bert import _BaseFn, _Core, _EngineFn, _FusedStep, _MagBertBase, _attach_parameters, _init_weights
 from .global_configs import ACOUSTIC_DIM, VISUAL_DIM, XLNET_INJECTION_INDEX
 
 
@@ -73,25 +74,48 @@ class MAG_XLNetModel(_XlBase):
     def forward(self, input_ids, visual, acoustic, attention_mask=None, mems=None, perm_mask=None, target_mapping=None,
                 token_type_ids=None, input_mask=None, head_mask=None, inputs_embeds=None, use_cache=True,
                 output_attentions=None, output_hidden_states=None):
-        self._unsupported(mems=mems, perm_mask=perm_mask, target_mapping=target_mapping, input_mask=input_mask,
-                          inputs_embeds=inputs_embeds)
+        """-> (output [B, L, d_model], (hidden_states), (attentions)) like xlnet.py:400-429.  `output` is the last layer's
+        hidden state after the final dropout (xlnet.py:396) and carries an autograd edge into the engine: a head built on this
+        model trains the whole stack, and inputs_embeds receives its gradient."""
+        _xl_unsupported(self, mems, perm_mask, target_mapping, input_mask)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
-        if input_ids is None:
-            raise ValueError("You have to specify either input_ids or inputs_embeds")          # xlnet.py:211-213
-        if attention_mask is None:
-            attention_mask = torch.ones_like(input_ids)
-        if token_type_ids is None:
-            token_type_ids = torch.zeros_like(input_ids)
-        B, L = input_ids.shape
-        self._core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, head_mask=head_mask)
-        outputs = (self._core.sequence_output(B, L),)
+        B, L, attention_mask, token_type_ids = _xl_front(self, input_ids, inputs_embeds, attention_mask, token_type_ids)
+        core = self._core
+        core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, head_mask=head_mask,
+                     inputs_embeds=inputs_embeds)
+        out = core.xl_model_output(B, L)
+        if torch.is_grad_enabled():
+            emb_edge = inputs_embeds if inputs_embeds is not None and inputs_embeds.requires_grad else None
+            out, _ = _BaseFn.apply(core.anchor, out, out.new_zeros(1), core, emb_edge)
+        outputs = (out,)
         if output_hidden_states:               # xlnet.py:363-392: the input of every layer (before the MAG injection) + the last output
-            outputs = outputs + (self._core.hidden_states(B, L),)
+            outputs = outputs + (core.hidden_states(B, L),)
         if output_attentions:                  # xlnet.py:387-427: per layer [B, n_head, L, L], after the attention dropout
-            outputs = outputs + (self._core.xl_attentions(B, L, self.training),)
+            outputs = outputs + (core.xl_attentions(B, L, self.training),)
         return outputs
+
+
+def _xl_unsupported(model, mems, perm_mask, target_mapping, input_mask):
+    """The reference driver never passes these (multimodal_driver.py:363-370); each is a different attention pattern the
+    relative-attention kernels are not built for (DESIGN.md section 7 lists the reference lines)."""
+    model._unsupported(mems=mems, perm_mask=perm_mask, target_mapping=target_mapping, input_mask=input_mask)
+
+
+def _xl_front(model, input_ids, inputs_embeds, attention_mask, token_type_ids):
+    """argument checks and defaults of MAG_XLNetModel.forward (xlnet.py:201-213, 255-262)"""
+    if input_ids is not None and inputs_embeds is not None:
+        raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")          # xlnet.py:201-203
+    if input_ids is None and inputs_embeds is None:
+        raise ValueError("You have to specify either input_ids or inputs_embeds")                          # xlnet.py:211-213
+    B, L = input_ids.shape if input_ids is not None else inputs_embeds.shape[:-1]
+    dev = model._core.device
+    if attention_mask is None:
+        attention_mask = torch.ones(B, L, dtype=torch.int64, device=dev)
+    if token_type_ids is None:
+        token_type_ids = torch.zeros(B, L, dtype=torch.int64, device=dev)
+    return B, L, attention_mask, token_type_ids
 
 
 class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
@@ -113,24 +137,22 @@ class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
     def forward(self, input_ids, visual, acoustic, attention_mask=None, mems=None, perm_mask=None, target_mapping=None,
                 token_type_ids=None, input_mask=None, head_mask=None, inputs_embeds=None, use_cache=True, labels=None,
                 output_attentions=None, output_hidden_states=None):
-        self._unsupported(mems=mems, perm_mask=perm_mask, target_mapping=target_mapping, input_mask=input_mask,
-                          inputs_embeds=inputs_embeds)
+        _xl_unsupported(self, mems, perm_mask, target_mapping, input_mask)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
-        if attention_mask is None:
-            attention_mask = torch.ones_like(input_ids)
-        if token_type_ids is None:
-            token_type_ids = torch.zeros_like(input_ids)
+        B, L, attention_mask, token_type_ids = _xl_front(self, input_ids, inputs_embeds, attention_mask, token_type_ids)
         core = self._core
-        logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, head_mask=head_mask)
+        logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, head_mask=head_mask,
+                              inputs_embeds=inputs_embeds)
         if torch.is_grad_enabled():
-            logits = _EngineFn.apply(core.anchor, logits, core)
+            emb_edge = inputs_embeds if inputs_embeds is not None and inputs_embeds.requires_grad else None
+            logits = _EngineFn.apply(core.anchor, logits, core, emb_edge)
         outputs = (logits,)
         if output_hidden_states:
-            outputs = outputs + (core.hidden_states(input_ids.shape[0], input_ids.shape[1]),)
+            outputs = outputs + (core.hidden_states(B, L),)
         if output_attentions:
-            outputs = outputs + (core.xl_attentions(input_ids.shape[0], input_ids.shape[1], self.training),)
+            outputs = outputs + (core.xl_attentions(B, L, self.training),)
         if labels is not None:                                        # xlnet.py:515-524
             if self.num_labels == 1:
                 loss = torch.nn.functional.mse_loss(logits.view(-1), labels.to(logits.device).float().view(-1))

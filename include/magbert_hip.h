@@ -174,6 +174,9 @@ int mb_bert_set_attention_output(mb_bert_engine* e, float* probs);
  *   given embeddings, fp32 [B*L][H] (workspace memory, valid until the next backward). */
 int mb_bert_set_head_mask(mb_bert_engine* e, const float* head_mask);
 int mb_bert_set_inputs_embeds(mb_bert_engine* e, const float* inputs_embeds);
+/* position_ids (bert.py:211-216): int64 [B*L] device tensor of position-table rows for the next forwards / backwards, NULL =
+ * BertEmbeddings' default arange(seq_len).  Sticky like head_mask; the single-call step refuses to run while it is set. */
+int mb_bert_set_position_ids(mb_bert_engine* e, const int64_t* position_ids);
 const float* mb_bert_inputs_embeds_grad(const mb_bert_engine* e);
 /* Backward entry of the BASE model, for heads that live outside the engine: replaces stage 0 of mb_bert_backward.
  * d_sequence_output [B*L][H] (dtype; NULL = zero) is the gradient of outputs[0]; d_pooler_preact [B][H] (dtype; NULL = the
@@ -289,6 +292,15 @@ const void* mb_xlnet_attention_probs(const mb_xlnet_engine* e, int layer, int* p
 int mb_xlnet_set_head_mask(mb_xlnet_engine* e, const float* head_mask);
 int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap);
 int mb_xlnet_mark_grads_zero(mb_xlnet_engine* e, int known_zero);      /* as mb_bert_mark_grads_zero */
+/* inputs_embeds (xlnet.py:306-313) / the base model's autograd edge (xlnet.py:396-405 returns autograd tensors), as for MAG-BERT:
+ * mb_xlnet_set_inputs_embeds: fp32 [B*L][d_model] word embeddings for the next passes (NULL = input_ids again), their gradient
+ * after a backward in mb_xlnet_inputs_embeds_grad; mb_xlnet_model_output: the last layer's output after the final dropout
+ * (whole sequence, activation dtype, scratch valid until the next backward); mb_xlnet_backward_outputs: its gradient back in,
+ * then stages 1 .. n_layer + 1 of mb_xlnet_backward. */
+int mb_xlnet_set_inputs_embeds(mb_xlnet_engine* e, const float* inputs_embeds);
+const float* mb_xlnet_inputs_embeds_grad(const mb_xlnet_engine* e);
+const void* mb_xlnet_model_output(mb_xlnet_engine* e, void* stream);
+int mb_xlnet_backward_outputs(mb_xlnet_engine* e, const void* d_output, void* stream);
 int mb_xlnet_set_profiling(mb_xlnet_engine* e, int on);                 /* as mb_bert_set_profiling (the grouped launch has 7 problems) */
 int mb_xlnet_profile_wgrad_us(mb_xlnet_engine* e, float* avg_us);
 int mb_xlnet_profile_adamw_us(mb_xlnet_engine* e, float* us);

@@ -96,10 +96,13 @@ class BertEmbeddings(nn.Module):
         self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
         self.dropout = nn.Dropout(c.hidden_dropout_prob)
 
-    def forward(self, input_ids, token_type_ids, inputs_embeds=None):
+    def forward(self, input_ids, token_type_ids, inputs_embeds=None, position_ids=None):
         # inputs_embeds (bert.py:211-216 passes it through): used in place of word_embeddings(input_ids)
+        # position_ids (same call): rows of the position table; 3.0.2 default = arange(seq_len) for every sample
         L = token_type_ids.shape[1]
         pos = torch.arange(L, dtype=torch.long, device=token_type_ids.device).unsqueeze(0).expand_as(token_type_ids)
+        if position_ids is not None:
+            pos = position_ids.to(torch.long).expand_as(token_type_ids)
         words = self.word_embeddings(input_ids) if inputs_embeds is None else inputs_embeds
         e = words + self.position_embeddings(pos) + self.token_type_embeddings(token_type_ids)
         return self.dropout(self.LayerNorm(e))
@@ -221,7 +224,7 @@ class MAG_BertModel(nn.Module):
                        visual_dim, acoustic_dim)                 # bert.py:84-88
 
     def forward(self, input_ids, visual, acoustic, attention_mask=None, token_type_ids=None, head_mask=None,
-                inputs_embeds=None):
+                inputs_embeds=None, position_ids=None):
         shape = input_ids.shape if input_ids is not None else inputs_embeds.shape[:-1]      # bert.py:158-168
         dev = visual.device
         if attention_mask is None:
@@ -236,7 +239,7 @@ class MAG_BertModel(nn.Module):
             head_mask = head_mask[:, None, :, None, None]
         # 3.0.2 get_extended_attention_mask (bert.py:180-182): (1 - mask)[:,None,None,:] * -10000.0
         ext = (1.0 - attention_mask[:, None, None, :].to(torch.float32)) * -10000.0
-        emb = self.embeddings(input_ids, token_type_ids, inputs_embeds)     # bert.py:211-216
+        emb = self.embeddings(input_ids, token_type_ids, inputs_embeds, position_ids)     # bert.py:211-216
         fused = self.MAG(emb, visual, acoustic)                  # bert.py:219
         seq = self.encoder(fused, ext, head_mask)                # bert.py:221-229
         pooled = self.pooler(seq)                                # bert.py:231
@@ -254,8 +257,8 @@ class MAG_BertForSequenceClassification(nn.Module):
         self.classifier = nn.Linear(config.hidden_size, config.num_labels)  # bert.py:247
 
     def forward(self, input_ids, visual, acoustic, attention_mask=None, token_type_ids=None, labels=None, head_mask=None,
-                inputs_embeds=None):
-        seq, pooled = self.bert(input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask, inputs_embeds)
+                inputs_embeds=None, position_ids=None):
+        seq, pooled = self.bert(input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask, inputs_embeds, position_ids)
         logits = self.classifier(self.dropout(pooled))                      # bert.py:304-307
         outputs = (logits,)
         if labels is not None:                                              # bert.py:313-322

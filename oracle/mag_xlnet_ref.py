@@ -121,20 +121,24 @@ class MAG_XLNetModel(nn.Module):
         pos_emb = torch.cat([torch.sin(sinusoid), torch.cos(sinusoid)], dim=-1)
         return pos_emb[:, None, :].expand(-1, bsz, -1)
 
-    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask=None):
+    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask=None, inputs_embeds=None):
         if head_mask is not None:            # xlnet.py:340-353: [n_head] -> every layer, [n_layer][n_head] as is
             head_mask = head_mask.to(torch.float32)
             if head_mask.dim() == 1:
                 head_mask = head_mask[None].expand(self.n_layer, -1)
-        ids = input_ids.transpose(0, 1).contiguous()                                    # xlnet.py:206
-        L, B = ids.shape
+        if inputs_embeds is not None:        # xlnet.py:208-210: [B, L, d] -> [L, B, d]; used instead of the table (xlnet.py:301-305)
+            emb = inputs_embeds.transpose(0, 1).contiguous()
+            L, B = emb.shape[0], emb.shape[1]
+        else:
+            ids = input_ids.transpose(0, 1).contiguous()                                # xlnet.py:206
+            L, B = ids.shape
         visual = visual.transpose(0, 1).contiguous()                                    # xlnet.py:215-216
         acoustic = acoustic.transpose(0, 1).contiguous()
         seg = token_type_ids.transpose(0, 1).contiguous()
         input_mask = 1.0 - attention_mask.transpose(0, 1).contiguous().float()          # xlnet.py:263-264
         attn_mask = (input_mask[None][:, :, :, None] > 0).float()                       # xlnet.py:267-286 : [1, L, B, 1]
         non_tgt = ((attn_mask - torch.eye(L)[:, :, None, None]) > 0).float()            # xlnet.py:288-296 : [L, L, B, 1]
-        h = self.dropout(self.word_embedding(ids))                                      # xlnet.py:304-305
+        h = self.dropout(emb if inputs_embeds is not None else self.word_embedding(ids))        # xlnet.py:301-305
         seg_mat = (seg[:, None] != seg[None, :]).long()                                 # xlnet.py:326
         seg_mat = F.one_hot(seg_mat, num_classes=2).float()                             # xlnet.py:327
         pos_emb = self.dropout(self.relative_positional_encoding(L, L, B))              # xlnet.py:332-333
@@ -167,8 +171,8 @@ class MAG_XLNetForSequenceClassification(nn.Module):
         self.sequence_summary = SequenceSummary(config)
         self.logits_proj = nn.Linear(config.d_model, config.num_labels)
 
-    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels=None, head_mask=None):
-        out = self.transformer(input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask)
+    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels=None, head_mask=None, inputs_embeds=None):
+        out = self.transformer(input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask, inputs_embeds)
         logits = self.logits_proj(self.sequence_summary(out))                           # xlnet.py:506-509
         outputs = (logits,)
         if labels is not None:

@@ -273,12 +273,48 @@ def test_optional_outputs_and_trainable_base_model_fp32():
     assert len(out) == 3 and len(out[1]) == layers + 1 and len(out[2]) == layers
     for h, r in zip(out[1], ref_h):
         assert float((h.cpu() - r).abs().max()) <= 1e-4
-    # options that are not built raise instead of being ignored
-    with pytest.raises(NotImplementedError):
-        m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, position_ids=torch.arange(L, device=DEV).flip(0)[None].expand(B, L))
+    # options that are not built raise instead of being ignored (the decoder's cross-attention inputs)
     with pytest.raises(NotImplementedError):
         base(ids, vis, aco, encoder_hidden_states=torch.zeros(B, L, 768, device=DEV))
-    m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, position_ids=torch.arange(L, device=DEV)[None].expand(B, L))   # the default is fine
+    m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, position_ids=torch.arange(L, device=DEV)[None].expand(B, L))   # the default, spelled out
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_position_ids_vs_oracle(cdt):
+    """f-4: explicit position_ids (bert.py:211-216 -> BertEmbeddings): rows of the position table per token, [B, L] or [1, L].
+    Logits and every gradient (the position table's rows are scattered by id) against the oracle; the default comes back
+    afterwards and the single-call step runs."""
+    layers, B, L, V = 2, 3, 24, 47
+    fp32 = cdt == torch.float32
+    m = build(V, layers, cdt, p_mag=0.0, hidden_p=0.0, attn_p=0.0).train()
+    o = R.set_dropout(oracle(V, layers, p_mag=0.0), 0.0, 0.0, 0.0).train()
+    b = weights.synthetic_bert_batch(B, L, V, 74, seed=47)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    i2, v2, a2, m2, s2, l2 = tb(b)
+    pos = torch.stack([torch.arange(L).flip(0) + 7, torch.arange(L) * 3 % 101, torch.full((L,), 5)]).long()       # reversed+offset, strided, constant
+    logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, position_ids=pos.to(DEV))[0]
+    torch.nn.MSELoss()(logits.view(-1), lab.view(-1)).backward()
+    lo = o(i2, v2, a2, m2, s2, position_ids=pos)[0]
+    torch.nn.functional.mse_loss(lo.view(-1), l2.view(-1)).backward()
+    torch.cuda.synchronize()
+    err = float((logits.detach().cpu() - lo.detach()).abs().max())
+    print("position_ids (%s): logits %.2e" % (cdt, err))
+    assert err <= (1e-3 if fp32 else 2e-2)
+    _grad_report(m, o, 5e-3 if fp32 else 3e-2, frobenius=not fp32, loose=LOOSE_BF16 + ("classifier.bias",), tol_loose=1e-1, show=3)
+    m.eval(); o.eval()
+    with torch.no_grad():
+        one = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, position_ids=pos[:1].to(DEV))[0]      # [1, L]: every sample
+        ref1 = o(i2, v2, a2, m2, s2, position_ids=pos[:1])[0]
+        plain = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0]                                   # nothing sticks
+        ref = o(i2, v2, a2, m2, s2)[0]
+    assert float((one.cpu() - ref1).abs().max()) <= (1e-3 if fp32 else 2e-2)
+    assert float((plain.cpu() - ref).abs().max()) <= (1e-3 if fp32 else 2e-2)
+    with pytest.raises(IndexError):
+        m(ids, vis, aco, position_ids=torch.full((B, L), 512, device=DEV))
+    m.train()
+    m.zero_grad()
+    m.train_step(ids, vis, aco, mask, seg, lab, optimizer=None)
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])

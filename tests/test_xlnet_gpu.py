@@ -7,6 +7,7 @@ Tolerances as in test_model_gpu.py: fp32 parity mode logits <= 1e-3 (north_star)
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -124,6 +125,76 @@ def test_base_model_sequence_output_fp32():
     err = float((y1 - y0).abs().max())
     print("sequence output max|err| %.3e (max %.3f)" % (err, float(y0.abs().max())))
     assert err <= 1e-3
+
+
+def test_inputs_embeds_and_trainable_base_model_fp32():
+    """f-4 for MAG-XLNet: inputs_embeds (xlnet.py:201-213, 301-305) replaces the table gather and receives its own gradient;
+    MAG_XLNetModel's output (xlnet.py:396-405) carries an autograd edge into the engine -- a user head on it trains the whole
+    stack (gradients vs the oracle); in train mode that output is the last hidden state under the final dropout's mask."""
+    layers, B, L, H = 2, 3, 24, 768
+    # (a) classification model, inputs_embeds with its gradient
+    m = build(layers, p_mag=0.0, p=0.0).train()
+    o = X.set_dropout(oracle(layers, p_mag=0.0), 0.0, 0.0).train()
+    b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=83)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    i2, v2, a2, m2, s2, l2 = tb(b)
+    emb_cpu = (o.transformer.word_embedding(i2).detach() + 0.05 * torch.from_numpy(weights.make_param("probe.emb", (B, L, H), "test"))).requires_grad_(True)
+    emb = emb_cpu.detach().to(DEV).requires_grad_(True)
+    logits = m(None, vis, aco, attention_mask=mask, token_type_ids=seg, inputs_embeds=emb)[0]
+    torch.nn.MSELoss()(logits.view(-1), lab.view(-1)).backward()
+    lo = o(None, v2, a2, m2, s2, inputs_embeds=emb_cpu)[0]
+    F.mse_loss(lo.view(-1), l2.view(-1)).backward()
+    torch.cuda.synchronize()
+    err = float((logits.detach().cpu() - lo.detach()).abs().max())
+    gerr = float((emb.grad.cpu() - emb_cpu.grad).norm() / emb_cpu.grad.norm())
+    print("xlnet inputs_embeds: logits %.2e, d(inputs_embeds) rel. Frobenius %.2e" % (err, gerr))
+    assert err <= 1e-3 and gerr <= 2e-3
+    word = dict(m.named_parameters())["transformer.word_embedding.weight"]
+    assert float(word.grad.abs().max()) == 0.0 and o.transformer.word_embedding.weight.grad is None
+    o.transformer.word_embedding.weight.grad = torch.zeros_like(o.transformer.word_embedding.weight)
+    _grad_report(m, o, 5e-3)
+    with pytest.raises(ValueError):
+        m(ids, vis, aco, inputs_embeds=emb)
+    with pytest.raises(ValueError):
+        m(None, vis, aco)
+    # nothing sticks: the ids path afterwards equals the oracle's, and the single-call step runs
+    m.eval(); o.eval()
+    with torch.no_grad():
+        assert float((m(ids, vis, aco, attention_mask=mask, token_type_ids=seg)[0].cpu() - o(i2, v2, a2, m2, s2)[0]).abs().max()) <= 1e-3
+    m.train()
+    m.zero_grad()
+    m.train_step(ids, vis, aco, mask, seg, lab, optimizer=None)
+    torch.cuda.synchronize()
+    assert float(word.grad.abs().max()) > 0.0
+    # (b) base model: a head on its output back-propagates into the engine
+    cfg = XLNetConfig(n_layer=layers, dropout=0.0, summary_last_dropout=0.0)
+    base = MAG_XLNetModel(cfg, MultimodalConfig(1.0, 0.0), 47, 74).train()
+    ob = X.set_dropout(X.MAG_XLNetModel(X.XLNetConfigLite(n_layer=layers), X.MultimodalConfig(1.0, 0.0), 47, 74), 0.0, 0.0).train()
+    sd = {n: torch.from_numpy(weights.make_param("transformer." + n, tuple(q.shape), "test")) for n, q in base.named_parameters()}
+    base.load_state_dict(sd); ob.load_state_dict(sd)
+    out = base(ids, vis, aco, attention_mask=mask, token_type_ids=seg)[0]
+    assert out.requires_grad
+    w = torch.from_numpy(weights.make_param("probe.seq", (H,), "test"))
+    ((out * w.to(DEV)).sum(-1) ** 2).mean().backward()
+    ro = ob(i2, v2, a2, m2, s2)
+    ((ro * w).sum(-1) ** 2).mean().backward()
+    torch.cuda.synchronize()
+    assert float((out.detach().cpu() - ro.detach()).abs().max()) <= 1e-3
+    og = {n: q.grad for n, q in ob.named_parameters() if q.grad is not None}
+    gmax = max(float(g.abs().max()) for g in og.values())
+    rows = sorted(((float((q.grad.cpu() - og[n]).abs().max()) / max(float(og[n].abs().max()), 1e-3 * gmax), n)
+                   for n, q in base.named_parameters() if n in og), reverse=True)
+    print("base-model gradients through the autograd edge: worst relative errors", ["%.2e %s" % r for r in rows[:4]])
+    assert rows[0][0] <= 5e-3
+    # train mode with dropout: the returned tensor is the last hidden state under the final dropout's counter-hash mask
+    cfg = XLNetConfig(n_layer=layers, dropout=0.1, summary_last_dropout=0.1)
+    base = MAG_XLNetModel(cfg, MultimodalConfig(1.0, 0.5), 47, 74).train()
+    base.load_state_dict(sd)
+    with torch.no_grad():
+        out, hs = base(ids, vis, aco, attention_mask=mask, token_type_ids=seg, output_hidden_states=True)
+    mult = torch.from_numpy(rng.keep_mult(B * L * H, rng.make_key(base._core.seed, base._core.step, rng.XS_FINAL, 0.1))).view(B, L, H)
+    assert float((out.cpu() - hs[-1].cpu() * mult).abs().max()) <= 1e-6
+    assert 0.05 < float((mult == 0).float().mean()) < 0.15
 
 
 def test_output_attentions_and_hidden_states_fp32():
