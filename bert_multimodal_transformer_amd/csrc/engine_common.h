@@ -88,8 +88,9 @@ struct MagWs {
 
 inline int gemm(int dtype, int layout, int mode, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
          int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, DropKey drop, int splits, int tile,
-         hipStream_t st) {
+         hipStream_t st, int bseg = 0, size_t bseg_stride = 0) {
     GemmArgs a = {};
+    a.bseg = bseg; a.bseg_stride = bseg_stride;        // segmented B (kernels.h): pieces of B's contiguous dimension in separate tensors
     a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
     a.C = C; a.ldc = ldc; a.C2 = C2; a.Cf = Cf; a.bias = bias; a.R = R; a.ldr = ldr; a.alpha = 1.0f; a.drop = drop;
     a.kchunk = K; a.colsum = nullptr;

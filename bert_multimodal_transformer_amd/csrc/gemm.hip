@@ -435,7 +435,7 @@ struct Dma {
         return KB == 256 ? (lc ^ (r & 15)) : KB == 128 ? (lc ^ (r & 7)) : (lc ^ ((r >> 1) & 3));
     }
 
-    static __device__ __forceinline__ void issue(const T* __restrict__ base, int ld, int row0, int nrows, int k0,
+    static __device__ __forceinline__ void issue(const T* __restrict__ base, int ld, int row0, int nrows, size_t k0,
                                                  char* lds, int lane, int wave, bool r1) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -645,6 +645,19 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
     const int nt = (kend - kbeg) / BKE;
     const T* __restrict__ A = (const T*)p.A;
     const T* __restrict__ B = (const T*)p.B;
+    // segmented B (GemmArgs::bseg): a k-major B moves its base to the segment of this tile's columns; a row-major B jumps by
+    // seg_extra bytes whenever the k loop crosses into the next segment (every seg_stages stages)
+    int n0b = n0;
+    int seg_stages = 0;
+    uint32_t seg_extra = 0;
+    if (p.bseg > 0) {
+        if constexpr (BK) { B += (size_t)(n0 / p.bseg) * p.bseg_stride; n0b = n0 % p.bseg; }
+        else { seg_stages = p.bseg / BKE; seg_extra = (uint32_t)((p.bseg_stride - (size_t)p.bseg) * sizeof(T)); }
+    }
+    int seg_left = seg_stages;
+    auto seg_step = [&](uint32_t& sob_) {            // after every stage's B offset advance
+        if (seg_stages > 0 && --seg_left == 0) { sob_ += seg_extra; seg_left = seg_stages; }
+    };
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -702,7 +715,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
 #pragma unroll
         for (int i = 0; i < DA::NI; ++i) va[i] = DA::dma_voff(i, p.lda, m0, p.M, lane, wave);
 #pragma unroll
-        for (int i = 0; i < DB::NI; ++i) vb[i] = DB::dma_voff(i, p.ldb, n0, p.N, lane, wave);
+        for (int i = 0; i < DB::NI; ++i) vb[i] = DB::dma_voff(i, p.ldb, n0b, p.N, lane, wave);
         const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, -1, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, -1, 0x00020000);
         const uint32_t ksa = DA::k_stride_bytes(p.lda) * BKE, ksb = DB::k_stride_bytes(p.ldb) * BKE;      // operand bytes per stage
@@ -726,6 +739,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
         auto issue_stage = [&](uint32_t slot) {
             static_for<G>([&](auto ic) { dma_piece(ic, slot); });
             soa += ksa; sob += ksb;
+            seg_step(sob);
         };
         FragU fa[2][MT], fb[2][NT];
         // read instruction R of slab S of the stage at `st` into register set BUF
@@ -752,7 +766,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
                     else dma_piece(std::integral_constant<int, F - (RD ? NRD : 0)>{}, slot_dma);
                 });
             });
-            if constexpr (DMA) { soa += ksa; sob += ksb; }
+            if constexpr (DMA) { soa += ksa; sob += ksb; seg_step(sob); }
         };
         typedef std::integral_constant<int, 0> I0;
         typedef std::integral_constant<int, 1> I1;
@@ -829,7 +843,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
 #pragma unroll
         for (int i = 0; i < DA::NI; ++i) va[i] = DA::dma_voff(i, p.lda, m0, p.M, lane, wave);
 #pragma unroll
-        for (int i = 0; i < DB::NI; ++i) vb[i] = DB::dma_voff(i, p.ldb, n0, p.N, lane, wave);
+        for (int i = 0; i < DB::NI; ++i) vb[i] = DB::dma_voff(i, p.ldb, n0b, p.N, lane, wave);
         const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, -1, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, -1, 0x00020000);
         const uint32_t ksa = DA::k_stride_bytes(p.lda) * BKE, ksb = DB::k_stride_bytes(p.ldb) * BKE;      // operand bytes per stage
@@ -841,6 +855,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
             DA::issue_buf(rsa, va, soa, smem + slot * STAGE, wave);
             DB::issue_buf(rsb, vb, sob, smem + slot * STAGE + BM * KB, wave);
             soa += ksa; sob += ksb;
+            seg_step(sob);
         };
 #pragma unroll
         for (int s = 0; s < NSTAGE - 1; ++s)
@@ -894,7 +909,9 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p, const int m0, cons
         auto issue = [&](int t) {
             char* st = smem + (t % NSTAGE) * STAGE;
             DA::issue(A, p.lda, m0, p.M, kbeg + t * BKE, st, lane, wave, false);
-            DB::issue(B, p.ldb, n0, p.N, kbeg + t * BKE, st + BM * KB, lane, wave, false);
+            const int kb = kbeg + t * BKE;               // row-major segmented B: k -> (segment, k inside it)
+            const size_t kB = seg_stages > 0 ? (size_t)(kb / p.bseg) * p.bseg_stride + (size_t)(kb % p.bseg) : (size_t)kb;
+            DB::issue(B, p.ldb, n0b, p.N, kB, st + BM * KB, lane, wave, false);
         };
 #pragma unroll
         for (int s = 0; s < NSTAGE - 1; ++s)
@@ -1052,6 +1069,9 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
     if (AK) v2ok = v2ok && (p.M % BM == 0);
     if (BK) v2ok = v2ok && (p.N % BN == 0);
     if (g_impl == 1) v2ok = false;
+    if (p.bseg > 0) {          // segmented B: LDS-DMA kernels only, whole tiles / k-stages per segment, no split-K
+        if (splits != 1 || (BK ? (p.bseg % BN != 0) : (p.bseg % 128 != 0)) || p.bseg_stride % EPV || !v2ok) return MB_ERR_SHAPE;
+    }
     if constexpr (BM == 256) {
         // 8-wave single-round kernel (bf16, row-major A): anything it cannot take goes to the 128 x 128 configuration
         if constexpr (sizeof(T) == 2 && !AK && BN == 128) {

@@ -46,6 +46,12 @@ struct GemmArgs {
     int reg_m, reg_n, tpr_m, tpr_n;   // XCD regions (filled by the launcher): reg_m*reg_n == 8, tiles per region
     int overwrite;                    // EPI_ACCUM_F32 without split-K: Cf = acc instead of Cf += acc (the caller knows Cf holds zeros)
     unsigned long long* trace;        // MB_GEMM_TRACE=1: [blocks][8] wall-clock stamps (100 MHz) of the phases of every block, else null
+    // Segmented B (0 = off): B's contiguous dimension (the columns n of a k-major B, the k of a row-major B) is cut into pieces of
+    // `bseg` elements that live in separate tensors `bseg_stride` elements apart: element (r, c) sits at
+    // B + (c / bseg) * bseg_stride + r * ldb + c % bseg.  This is how MAG-XLNet's q | k | v projections -- three [768][768] tensors
+    // next to each other in the flat parameter buffer -- run as ONE forward GEMM (N = 2304) and ONE dgrad (K = 2304) instead of
+    // three each.  bseg must be a multiple of the tile (k-major) / of the k-stage (row-major); no split-K.
+    int bseg; size_t bseg_stride;
 };
 // copies the stamps of the last traced launch to the host (measurement tooling: tools/gemm_bench --trace); returns the block count
 int gemm_trace_fetch(unsigned long long* host_out, int max_blocks);

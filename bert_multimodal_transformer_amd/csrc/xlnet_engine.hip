@@ -37,6 +37,7 @@ struct mb_xlnet_engine : StepMixin {
     const float* emb_in = nullptr;      // mb_xlnet_set_inputs_embeds: [B*L][H] fp32 word embeddings given instead of input_ids (xlnet.py:306-313)
     size_t ws_demb = 0;                 // fp32 [T][H]: gradient of the given embeddings
     bool ran_forward = false;
+    bool fuse_qkv = true;               // MB_XL_FUSE_QKV=0: q, k, v as three GEMMs each way (round-2 form, kept for A/B runs)
     size_t ws_bytes;
     float* P = nullptr; float* G = nullptr; char* SH = nullptr; char* ws = nullptr;
     const int64_t* ids = nullptr; const int64_t* seg = nullptr; const int64_t* mask = nullptr;
@@ -205,6 +206,8 @@ int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out) {
                   cfg->d_model % e->group_wgrad == 0;
     e->c = *cfg;
     xl_build_layout(e);
+    if (const char* v = getenv("MB_XL_FUSE_QKV")) e->fuse_qkv = atoi(v) != 0;
+    if (e->lo[0].k - e->lo[0].q != (size_t)cfg->d_model * cfg->d_model || e->lo[0].v - e->lo[0].k != e->lo[0].k - e->lo[0].q) e->fuse_qkv = false;
     if (const char* v = getenv("MB_ADAMW_KEEP")) e->keep_enable = atoi(v);
     // lazy zeroing (engine_common.h): the seven GEMM weights of every layer, stored by the grouped launches of a pass that may overwrite
     e->ow_covers = (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->d_inner % e->group_wgrad == 0 && cfg->d_model % e->group_wgrad == 0;
@@ -285,9 +288,16 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
         }
         char* qkv = ws + w.qkv;
         // q | k | v | kr projections: x . W with W stored [d_model][n_head*d_head] (einsum "ibh,hnd->ibnd")
-        CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, xin, H, e->W(o.q), H, qkv, 3 * H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
-        CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, xin, H, e->W(o.k), H, qkv + (size_t)H * es, 3 * H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
-        CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, xin, H, e->W(o.v), H, qkv + (size_t)2 * H * es, 3 * H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
+        if (e->fuse_qkv) {
+            // ONE GEMM, N = 3 H: the three [d_model][n_head * d_head] tensors sit next to each other in the flat buffer (a k-major B
+            // whose columns are cut into three segments)
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, 3 * H, H, xin, H, e->W(o.q), H, qkv, 3 * H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0,
+                    st, H, o.k - o.q));
+        } else {
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, xin, H, e->W(o.q), H, qkv, 3 * H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, xin, H, e->W(o.k), H, qkv + (size_t)H * es, 3 * H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
+            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, xin, H, e->W(o.v), H, qkv + (size_t)2 * H * es, 3 * H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
+        }
         CK(gemm(dt, GEMM_NN, EPI_ADD_RES, R, H, H, ws + e->ws_pos, H, e->W(o.r), H, ws + w.kr, H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
         CK(xlnet_attention_forward(dt, qkv, ws + w.kr, P + o.rwb, P + o.rrb, P + o.rsb, P + o.seg, token_type_ids, attention_mask,
                                    ws + w.vec, ws + w.psave, B, L, nh, e->key(XS_LAYER0 + 8 * l + 0, pd), st,
@@ -426,11 +436,17 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
             }
             // dx_in = dq Wq^T + dk Wk^T + dv Wv^T + dsB   (W stored [h_in][nd] = the row operand of an NT GEMM)
             char* t2 = ws + e->ws_dvec;
-            CK(gemm(dt, GEMM_NT, EPI_ADD_RES, T, H, H, dqkv, 3 * H, e->W(o.q), H, t1, H, nullptr, nullptr, nullptr, dsB, H, kNoDrop, 1, 0, st));
-            CK(gemm(dt, GEMM_NT, EPI_ADD_RES, T, H, H, dqkv + (size_t)H * es, 3 * H, e->W(o.k), H, t2, H, nullptr, nullptr, nullptr, t1, H,
-                    kNoDrop, 1, 0, st));
-            CK(gemm(dt, GEMM_NT, EPI_ADD_RES, T, H, H, dqkv + (size_t)2 * H * es, 3 * H, e->W(o.v), H, dx, H, nullptr, nullptr, nullptr, t2,
-                    H, kNoDrop, 1, 0, st));
+            if (e->fuse_qkv) {
+                // ONE GEMM, K = 3 H: A = dqkv as it lies, B = [Wq | Wk | Wv] along k (a row-major B whose k is cut into three segments)
+                CK(gemm(dt, GEMM_NT, EPI_ADD_RES, T, H, 3 * H, dqkv, 3 * H, e->W(o.q), H, dx, H, nullptr, nullptr, nullptr, dsB, H, kNoDrop, 1, 0,
+                        st, H, o.k - o.q));
+            } else {
+                CK(gemm(dt, GEMM_NT, EPI_ADD_RES, T, H, H, dqkv, 3 * H, e->W(o.q), H, t1, H, nullptr, nullptr, nullptr, dsB, H, kNoDrop, 1, 0, st));
+                CK(gemm(dt, GEMM_NT, EPI_ADD_RES, T, H, H, dqkv + (size_t)H * es, 3 * H, e->W(o.k), H, t2, H, nullptr, nullptr, nullptr, t1, H,
+                        kNoDrop, 1, 0, st));
+                CK(gemm(dt, GEMM_NT, EPI_ADD_RES, T, H, H, dqkv + (size_t)2 * H * es, 3 * H, e->W(o.v), H, dx, H, nullptr, nullptr, nullptr, t2,
+                        H, kNoDrop, 1, 0, st));
+            }
             if (l == c.injection_index) {      // MAG sits in front of this layer
                 CK(mag_bwd_impl(dt, dx, ws + e->ws_x[l], P + e->mag_bhv, P + e->mag_bha, P + e->mag_bv, P + e->mag_ba,
                                 P + e->mag_lnw, c.beta_shift, e->key(XS_MAG, c.mag_dropout), ws + e->ws_mag, e->mw, t1, nullptr,
