@@ -87,6 +87,19 @@ __device__ __forceinline__ void stage_heads_var(char* const (&img)[N], int pitch
         }
 }
 
+// one image, plain loop (no register staging of the whole image: for the large images of the L = 128 XLNet kernels, where
+// "every load first" would need hundreds of registers): rows [0, ralloc) x 64 elements, rows >= rows are zero
+template <class T, int NTHR>
+__device__ __forceinline__ void stage_rows(char* img, int pitch, const T* __restrict__ src, size_t ld, int ralloc, int rows) {
+    constexpr int CPR = AttnCfg<T>::ROWB / 16;
+    for (int id = threadIdx.x; id < ralloc * CPR; id += NTHR) {
+        const int row = id / CPR, c = id % CPR;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < rows) v = *(const u32x4*)((const char*)(src + (size_t)row * ld) + c * 16);
+        *(u32x4*)(img + row * pitch + c * 16) = v;
+    }
+}
+
 // multiplies rows [0, LP) x 64 elements of a staged image by s (head_mask: every gradient of a head is linear in the head's dvec,
 // so scaling the staged dvec image scales them all).  Call between two barriers.
 template <class T, int LP, int NTHR>

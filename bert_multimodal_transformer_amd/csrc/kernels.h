@@ -150,7 +150,7 @@ int attention_backward(int dtype, const void* qkv, const int64_t* mask, const vo
 int attention_trace_fetch(unsigned long long* host_out, int max_blocks);     // MB_ATTN_TRACE=1: stamps of the last attention_backward
 
 // ------------------------------------------------------------------------------------------ XLNet (xlnet_attention.hip, xlnet_rowops.hip)
-// relative attention core, L <= 64.  qkv [T][3H] token-major, kr [B][2L][H], psave/gsave [B][nh][L][L].
+// relative attention core, L <= 128.  qkv [T][3H] token-major, kr [B][2L][H], psave/gsave [B][nh][LP][LP] (LP = 32 | 64 | 128 >= L).
 int xlnet_attention_forward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
                             const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask, void* vec,
                             void* psave, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale = nullptr);

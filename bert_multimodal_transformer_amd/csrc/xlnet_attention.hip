@@ -1,5 +1,5 @@
 // XLNet relative attention core (transformers 3.0.2 XLNetRelativeAttention.rel_attn_core, reached from
-// /root/reference/xlnet.py:374-385), forward and backward, L <= 64, head dim 64, one workgroup per (batch, head):
+// /root/reference/xlnet.py:374-385), forward and backward, L <= 128, head dim 64, one workgroup per (batch, head[, strip group]):
 //     ac[i,j] = (q_i + r_w_bias) . k_j
 //     bd[i,j] = (q_i + r_r_bias) . kr_{L-i+j}          (rel_shift folded into the index: no [L,2L] reshape tricks)
 //     ef[i,j] = (q_i + r_s_bias) . seg_embed[seg_i != seg_j]
@@ -36,26 +36,32 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
                                                               int L, int nh, DropKey drop) {
     drop.resolve();
     typedef AttnCfg<T> C;
-    constexpr int RP = 2 * LP;
     constexpr int PIT = C::ROWB + 16;
     constexpr int SPIT = LP * (int)sizeof(T) + 16;
-    // A 16-row strip only needs the positional scores of a window of L + 15 <= 79 relative positions (row i reads raw[i][L-i+j]):
-    // 6 tiles of 16 starting at tile pt0(strip).  The probability strip re-uses the same LDS (written after the last raw read of
-    // the wave, which executes in lock-step).  92.7 KB -> 75.3 KB per block: two blocks per CU.
-    constexpr int RWT = 2 * (LP / 16) < 6 ? 2 * (LP / 16) : 6;      // window tiles
-    constexpr int RPIT = RWT * 16 * 4 + 16;            // raw (fp32) strip pitch
     constexpr int NT = LP / 16, DSL = 64 / C::SLAB, LSL = LP / C::SLAB;
+    // One block = one (batch, head) and NW consecutive 16-row query strips, one per wave (gridDim.y = NT / NW strip groups: one for
+    // L <= 64, more for L <= 128 where all strips of a head do not fit next to the images).  Staged: the QR = NW * 16 query rows of
+    // the group, all keys / values, and the window of relative positions those rows can reach -- row i reads raw[i][L - i + j], so
+    // a group needs L + QR - 1 positions (RW tiles, block window starting at tile pt_lo) and a single strip L + 15 (RWT tiles
+    // starting at pt0).  The probability strip re-uses the raw strip's LDS (written after the last raw read of the wave, which
+    // executes in lock-step).
+    static_assert(NT % NW == 0, "strip groups of NW strips");
+    constexpr int QR = NW * 16;
+    constexpr int RW = NT + NW + 1 < 2 * NT ? NT + NW + 1 : 2 * NT;      // position tiles staged per block
+    constexpr int RR = RW * 16;
+    constexpr int RWT = 2 * NT < NT + 2 ? 2 * NT : NT + 2;               // position tiles of one strip's window
+    constexpr int RPIT = RWT * 16 * 4 + 16;            // raw (fp32) strip pitch
     static_assert(16 * SPIT <= 16 * RPIT, "probability strip must fit inside the raw strip it aliases");
-    __shared__ __attribute__((aligned(16))) char smem[(3 * LP + RP + 16) * PIT + NW * 16 * RPIT + (LP + RP + 4 + 2 * LP) * 4];
-    char* Qi = smem;
-    char* Ki = Qi + LP * PIT;
+    __shared__ __attribute__((aligned(16))) char smem[(QR + 2 * LP + RR + 16) * PIT + NW * 16 * RPIT + (LP + RR + 4 + 2 * LP) * 4];
+    char* Qi = smem;                                   // query rows [rb, rb + QR)
+    char* Ki = Qi + QR * PIT;
     char* Vi = Ki + LP * PIT;
-    char* Ri = Vi + LP * PIT;                          // KR image [RP][64]
-    char* Si = Ri + RP * PIT;                          // seg_embed image [16][64] (rows 0,1)
+    char* Ri = Vi + LP * PIT;                          // KR image: positions [pt_lo * 16, pt_lo * 16 + RR)
+    char* Si = Ri + RR * PIT;                          // seg_embed image [16][64] (rows 0,1)
     char* raws = Si + 16 * PIT;
     float* cK = (float*)(raws + NW * 16 * RPIT);
     float* cR = cK + LP;
-    float* cS = cR + RP;
+    float* cS = cR + RR;
     int* segv = (int*)(cS + 4);
     int* padf = segv + LP;
 
@@ -64,12 +70,24 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
     const int H = nh * 64;
     const size_t ld = (size_t)3 * H;
     const T* base = qkv + (size_t)b * L * ld + h * 64;
+    const int rb = blockIdx.y * QR;                    // first query row of the group
+    int pt_lo = (L - rb - QR + 1) >> 4;                // first position tile any row of the group can touch
+    pt_lo = pt_lo < 0 ? 0 : (pt_lo > 2 * NT - RW ? 2 * NT - RW : pt_lo);
     {
-        char* const img[4] = {Qi, Ki, Vi, Ri};
-        const T* const src[4] = {base, base + H, base + 2 * H, kr + (size_t)b * 2 * L * H + h * 64};
-        const size_t lds[4] = {ld, ld, ld, (size_t)H};
-        const int ra[4] = {LP, LP, LP, RP}, rv[4] = {L, L, L, 2 * L};
-        stage_heads_var<T, NW * 64, 4, RP>(img, PIT, src, lds, ra, rv);       // every load in flight before the first LDS store
+        const int qv = L - rb < 0 ? 0 : (L - rb > QR ? QR : L - rb), rvv = 2 * L - pt_lo * 16 < 0 ? 0 : (2 * L - pt_lo * 16 > RR ? RR : 2 * L - pt_lo * 16);
+        const T* rsrc = kr + ((size_t)b * 2 * L + (size_t)pt_lo * 16) * H + h * 64;
+        if constexpr (LP <= 64) {
+            char* const img[4] = {Qi, Ki, Vi, Ri};
+            const T* const src[4] = {base + (size_t)rb * ld, base + H, base + 2 * H, rsrc};
+            const size_t lds[4] = {ld, ld, ld, (size_t)H};
+            const int ra[4] = {QR, LP, LP, RR}, rv[4] = {qv, L, L, rvv};
+            stage_heads_var<T, NW * 64, 4, (RR > LP ? RR : LP)>(img, PIT, src, lds, ra, rv);       // every load in flight before the first LDS store
+        } else {
+            stage_rows<T, NW * 64>(Qi, PIT, base + (size_t)rb * ld, ld, QR, qv);
+            stage_rows<T, NW * 64>(Ki, PIT, base + H, ld, LP, L);
+            stage_rows<T, NW * 64>(Vi, PIT, base + 2 * H, ld, LP, L);
+            stage_rows<T, NW * 64>(Ri, PIT, rsrc, (size_t)H, RR, rvv);
+        }
     }
     for (int t = threadIdx.x; t < 16 * 64; t += NW * 64) {
         const int row = t >> 6, d = t & 63;
@@ -83,24 +101,25 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
     const float* rwb = xp.r_w_bias + h * 64;
     const float* rrb = xp.r_r_bias + h * 64;
     const float* rsb = xp.r_s_bias + h * 64;
-    for (int t = threadIdx.x; t < LP + RP + 2; t += NW * 64) {
+    for (int t = threadIdx.x; t < LP + RR + 2; t += NW * 64) {
         float s = 0.f;
         if (t < LP) { for (int d = 0; d < 64; ++d) s += rwb[d] * ldT<T>(Ki, PIT, t, d); cK[t] = s; }
-        else if (t < LP + RP) { for (int d = 0; d < 64; ++d) s += rrb[d] * ldT<T>(Ri, PIT, t - LP, d); cR[t - LP] = s; }
-        else { for (int d = 0; d < 64; ++d) s += rsb[d] * ldT<T>(Si, PIT, t - LP - RP, d); cS[t - LP - RP] = s; }
+        else if (t < LP + RR) { for (int d = 0; d < 64; ++d) s += rrb[d] * ldT<T>(Ri, PIT, t - LP, d); cR[t - LP] = s; }
+        else { for (int d = 0; d < 64; ++d) s += rsb[d] * ldT<T>(Si, PIT, t - LP - RR, d); cS[t - LP - RR] = s; }
     }
     __syncthreads();
 
     char* raw = raws + wave * 16 * RPIT;
     char* Ps = raw;                                    // aliases the raw strip (see above)
     const float scale = 0.125f;
-    for (int s0 = 0; s0 < NT; s0 += NW) {
-        const int strip = s0 + wave;
-        const bool active = strip < NT;
+    {
+        const int strip = blockIdx.y * NW + wave;       // global strip of this wave; its query rows are rows wave * 16 .. of Qi
+        const bool active = true;
         f32x4 ac[NT];
         float e0 = 0.f, e1 = 0.f;
         int pt0 = (L - strip * 16 - 15) >> 4;          // first position tile any row of this strip can touch
         pt0 = pt0 < 0 ? 0 : (pt0 > 2 * NT - RWT ? 2 * NT - RWT : pt0);
+        pt0 = pt0 > pt_lo + RW - RWT ? pt_lo + RW - RWT : pt0;      // ... inside the block's staged window
         if (active) {
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
@@ -108,7 +127,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
 #pragma unroll
                 for (int sl = 0; sl < DSL; ++sl)
                     mma16(ac[jt], frag_nat<T>(Ki, PIT, jt * 16 + (lane & 15), sl, lane),
-                          frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
+                          frag_nat<T>(Qi, PIT, wave * 16 + (lane & 15), sl, lane));
             }
 #pragma unroll
             for (int q = 0; q < RWT; ++q) {
@@ -116,16 +135,16 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
                 f32x4 rw = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int sl = 0; sl < DSL; ++sl)
-                    mma16(rw, frag_nat<T>(Ri, PIT, pt * 16 + (lane & 15), sl, lane),
-                          frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
+                    mma16(rw, frag_nat<T>(Ri, PIT, (pt - pt_lo) * 16 + (lane & 15), sl, lane),
+                          frag_nat<T>(Qi, PIT, wave * 16 + (lane & 15), sl, lane));
                 const int p0 = pt * 16 + (lane >> 4) * 4;
-                rw += *(const f32x4*)(cR + p0);
+                rw += *(const f32x4*)(cR + p0 - pt_lo * 16);
                 *(f32x4*)(raw + (lane & 15) * RPIT + (p0 - pt0 * 16) * 4) = rw;          // raw[i][p] = (q_i + r_r_bias) . kr_p
             }
             f32x4 ev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int sl = 0; sl < DSL; ++sl)
-                mma16(ev, frag_nat<T>(Si, PIT, lane & 15, sl, lane), frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
+                mma16(ev, frag_nat<T>(Si, PIT, lane & 15, sl, lane), frag_nat<T>(Qi, PIT, wave * 16 + (lane & 15), sl, lane));
             e0 = __shfl(ev[0] + cS[0], lane & 15, 64);     // lanes 0..15 hold E[i][s = 0, 1]
             e1 = __shfl(ev[1] + cS[1], lane & 15, 64);
         }
@@ -220,19 +239,26 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
                                                                 DropKey drop) {
     drop.resolve();
     typedef AttnCfg<T> C;
-    constexpr int RP = 2 * LP;
     constexpr int PIT = C::ROWB + 16;
     constexpr int SPIT = LP * (int)sizeof(T) + 16;
-    constexpr int GPIT = RP * (int)sizeof(T) + 16;     // shifted-G strip pitch
-    constexpr int NT = LP / 16, DSL = 64 / C::SLAB, LSL = LP / C::SLAB, RSL = RP / C::SLAB;
+    constexpr int NT = LP / 16, DSL = 64 / C::SLAB, LSL = LP / C::SLAB;
+    // strip groups and position windows as in xl_attn_fwd_kernel: NW query strips per block (gridDim.y = NT / NW groups), the
+    // block's RW position tiles of KR staged from tile pt_lo on, a strip's shifted score gradients kept for its RWT-tile window only
+    static_assert(NT % NW == 0, "strip groups of NW strips");
+    constexpr int QR = NW * 16;
+    constexpr int RW = NT + NW + 1 < 2 * NT ? NT + NW + 1 : 2 * NT;
+    constexpr int RR = RW * 16;
+    constexpr int RWT = 2 * NT < NT + 2 ? 2 * NT : NT + 2;
+    constexpr int GPIT = RWT * 16 * (int)sizeof(T) + 16;     // shifted-G strip pitch (the strip's position window)
+    constexpr int RSL = RWT * 16 / C::SLAB;
     // Q is not staged: it is only read once per row at the end (q_i + r_s_bias for the segment-embedding gradient), straight from
-    // HBM/L2.  Without its image the block needs 75 KB of LDS instead of 84 KB -> two blocks per CU (576 blocks: 2 rounds, not 3).
-    __shared__ __attribute__((aligned(16))) char smem[(3 * LP + RP) * PIT + NW * 16 * (SPIT + GPIT) + (192 + 2 * LP) * 4];
+    // HBM/L2.
+    __shared__ __attribute__((aligned(16))) char smem[(2 * LP + QR + RR) * PIT + NW * 16 * (SPIT + GPIT) + (192 + 2 * LP) * 4];
     char* Ki = smem;
     char* Vi = Ki + LP * PIT;
-    char* Oi = Vi + LP * PIT;                          // dvec image
-    char* Ri = Oi + LP * PIT;
-    char* gstr = Ri + RP * PIT;
+    char* Oi = Vi + LP * PIT;                          // dvec image: rows [rb, rb + QR)
+    char* Ri = Oi + QR * PIT;                          // KR image: positions [pt_lo * 16, pt_lo * 16 + RR)
+    char* gstr = Ri + RR * PIT;
     char* sstr = gstr + NW * 16 * SPIT;
     float* sef = (float*)(sstr + NW * 16 * GPIT);     // se0[64] | se1[64] | rsb[64]
     int* segv = (int*)(sef + 192);
@@ -243,12 +269,25 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
     const int H = nh * 64;
     const size_t ld = (size_t)3 * H;
     const T* base = qkv + (size_t)b * L * ld + h * 64;
+    const int rb = blockIdx.y * QR;
+    int pt_lo = (L - rb - QR + 1) >> 4;
+    pt_lo = pt_lo < 0 ? 0 : (pt_lo > 2 * NT - RW ? 2 * NT - RW : pt_lo);
     {
-        char* const img[4] = {Ki, Vi, Oi, Ri};
-        const T* const src[4] = {base + H, base + 2 * H, dvec + (size_t)b * L * H + h * 64, kr + (size_t)b * 2 * L * H + h * 64};
-        const size_t lds[4] = {ld, ld, (size_t)H, (size_t)H};
-        const int ra[4] = {LP, LP, LP, RP}, rv[4] = {L, L, L, 2 * L};
-        stage_heads_var<T, NW * 64, 4, RP>(img, PIT, src, lds, ra, rv);
+        const int qv = L - rb < 0 ? 0 : (L - rb > QR ? QR : L - rb), rvv = 2 * L - pt_lo * 16 < 0 ? 0 : (2 * L - pt_lo * 16 > RR ? RR : 2 * L - pt_lo * 16);
+        const T* osrc = dvec + ((size_t)b * L + rb) * H + h * 64;
+        const T* rsrc = kr + ((size_t)b * 2 * L + (size_t)pt_lo * 16) * H + h * 64;
+        if constexpr (LP <= 64) {
+            char* const img[4] = {Ki, Vi, Oi, Ri};
+            const T* const src[4] = {base + H, base + 2 * H, osrc, rsrc};
+            const size_t lds[4] = {ld, ld, (size_t)H, (size_t)H};
+            const int ra[4] = {LP, LP, QR, RR}, rv[4] = {L, L, qv, rvv};
+            stage_heads_var<T, NW * 64, 4, (RR > LP ? RR : LP)>(img, PIT, src, lds, ra, rv);
+        } else {
+            stage_rows<T, NW * 64>(Ki, PIT, base + H, ld, LP, L);
+            stage_rows<T, NW * 64>(Vi, PIT, base + 2 * H, ld, LP, L);
+            stage_rows<T, NW * 64>(Oi, PIT, osrc, (size_t)H, QR, qv);
+            stage_rows<T, NW * 64>(Ri, PIT, rsrc, (size_t)H, RR, rvv);
+        }
     }
     for (int t = threadIdx.x; t < 192; t += NW * 64)
         sef[t] = t < 128 ? xp.seg_embed[((size_t)(t >> 6) * nh + h) * 64 + (t & 63)] : xp.r_s_bias[h * 64 + (t & 63)];
@@ -258,7 +297,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
     }
     __syncthreads();
     if (xp.head_scale) {                 // head_mask: every gradient of this head is linear in its dvec
-        scale_image<T, LP, NW * 64>(Oi, PIT, xp.head_scale[h]);
+        scale_image<T, QR, NW * 64>(Oi, PIT, xp.head_scale[h]);
         __syncthreads();
     }
 
@@ -270,10 +309,13 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
     const float scale = 0.125f;
     T* dq_base = dqkv + (size_t)b * L * ld + h * 64;
 
-    for (int s0 = 0; s0 < NT; s0 += NW) {
-        const int strip = s0 + wave;
-        const bool active = strip < NT;
+    {
+        const int strip = blockIdx.y * NW + wave;
+        const bool active = true;
         const int i = strip * 16 + (lane & 15);
+        int pt0 = (L - strip * 16 - 15) >> 4;          // the strip's position window (as in the forward)
+        pt0 = pt0 < 0 ? 0 : (pt0 > 2 * NT - RWT ? 2 * NT - RWT : pt0);
+        pt0 = pt0 > pt_lo + RW - RWT ? pt_lo + RW - RWT : pt0;
         float g0 = 0.f, g1 = 0.f;
         if (active) {
             // zero this wave's shifted strip, then fill G (natural) and G shifted to position space
@@ -285,7 +327,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
 #pragma unroll
                 for (int sl = 0; sl < DSL; ++sl)
                     mma16(dp[jt], frag_nat<T>(Vi, PIT, jt * 16 + (lane & 15), sl, lane),
-                          frag_nat<T>(Oi, PIT, strip * 16 + (lane & 15), sl, lane));
+                          frag_nat<T>(Oi, PIT, wave * 16 + (lane & 15), sl, lane));
             }
             const uint32_t rowidx = ((uint32_t)blockIdx.x * L + (uint32_t)i) * L;
             f32x4 pv[NT];
@@ -314,7 +356,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
                     const int j = j0 + r;
                     if (i < L && j < L) {
                         if (si == segv[j]) g0 += g[r]; else g1 += g[r];
-                        *(T*)(Ss + (lane & 15) * GPIT + (L - i + j) * (int)sizeof(T)) = from_f<T>(g[r]);
+                        *(T*)(Ss + (lane & 15) * GPIT + (L - i + j - pt0 * 16) * (int)sizeof(T)) = from_f<T>(g[r]);
                     } else g[r] = 0.f;
                 }
                 if (i < L) store4(gsave + prow + j0, g);          // same padded layout as psave
@@ -334,7 +376,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
                           frag_nat<T>(Gs, SPIT, lane & 15, sl, lane));
 #pragma unroll
                 for (int sl = 0; sl < RSL; ++sl)
-                    mma16(ob, frag_kmaj(Ri, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
+                    mma16(ob, frag_kmaj(Ri, PIT, (pt0 - pt_lo) * 16 + sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
                           frag_nat<T>(Ss, GPIT, lane & 15, sl, lane));
                 const int d = dt * 16 + (lane >> 4) * 4;
                 const f32x4 s0v = *(const f32x4*)(sef + d), s1v = *(const f32x4*)(sef + 64 + d), rs = *(const f32x4*)(sef + 128 + d);
@@ -494,12 +536,21 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv_kernel(const T* __rest
 }
 
 // ================================================================================================ host
+// LP = L rounded up to 32 / 64 / 128; NW_* = waves (query strips per block for the two query-side kernels, whose grid has
+// LP / 16 / NW strip groups in y; plain wave count for the key-side kernel, which loops over its strips).  At LP = 128 the images of a
+// whole head leave room for two strips (one in fp32 for the backward, whose strips also keep the shifted gradients).
 #define XL_DISPATCH(KERNEL_CALL)                                                   \
-    if (L < 1 || L > 64) return MB_ERR_SHAPE;                                      \
+    if (L < 1 || L > 128) return MB_ERR_SHAPE;                                     \
     {                                                                              \
-        const int LPv = (L + 31) / 32 * 32;                                        \
-        if (dtype == DT_BF16) { typedef bf16 T; if (LPv == 32) { constexpr int LP = 32, NW = 2; KERNEL_CALL } else { constexpr int LP = 64, NW = 4; KERNEL_CALL } } \
-        else if (dtype == DT_F32) { typedef float T; if (LPv == 32) { constexpr int LP = 32, NW = 2; KERNEL_CALL } else { constexpr int LP = 64, NW = 4; KERNEL_CALL } } \
+        const int LPv = L <= 32 ? 32 : (L <= 64 ? 64 : 128);                       \
+        if (dtype == DT_BF16) { typedef bf16 T;                                    \
+            if (LPv == 32) { constexpr int LP = 32, NWF = 2, NWQ = 2, NWK = 2; KERNEL_CALL }          \
+            else if (LPv == 64) { constexpr int LP = 64, NWF = 4, NWQ = 4, NWK = 4; KERNEL_CALL }     \
+            else { constexpr int LP = 128, NWF = 2, NWQ = 2, NWK = 8; KERNEL_CALL } }                 \
+        else if (dtype == DT_F32) { typedef float T;                               \
+            if (LPv == 32) { constexpr int LP = 32, NWF = 2, NWQ = 2, NWK = 2; KERNEL_CALL }          \
+            else if (LPv == 64) { constexpr int LP = 64, NWF = 4, NWQ = 4, NWK = 4; KERNEL_CALL }     \
+            else { constexpr int LP = 128, NWF = 2, NWQ = 1, NWK = 8; KERNEL_CALL } }                 \
         else return MB_ERR_DTYPE;                                                  \
     }                                                                              \
     return (int)hipGetLastError();
@@ -509,7 +560,8 @@ int xlnet_attention_forward(int dtype, const void* qkv, const void* kr, const fl
                             void* psave, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale) {
     XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale};
     XL_DISPATCH({
-        hipLaunchKernelGGL((xl_attn_fwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, (const T*)kr, xp,
+        (void)NWQ; (void)NWK;
+        hipLaunchKernelGGL((xl_attn_fwd_kernel<T, LP, NWF>), dim3(B * nh, LP / 16 / NWF), dim3(NWF * 64), 0, st, (const T*)qkv, (const T*)kr, xp,
                            (T*)vec, (T*)psave, L, nh, drop);
     })
 }
@@ -521,9 +573,10 @@ int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const f
                              const float* head_scale) {
     XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale};
     XL_DISPATCH({
-        hipLaunchKernelGGL((xl_attn_bwd_q_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, (const T*)kr,
+        (void)NWF;
+        hipLaunchKernelGGL((xl_attn_bwd_q_kernel<T, LP, NWQ>), dim3(B * nh, LP / 16 / NWQ), dim3(NWQ * 64), 0, st, (const T*)qkv, (const T*)kr,
                            xp, (const T*)psave, (const T*)dvec, (T*)gsave, (T*)dqkv, d_rwb, d_rrb, d_rsb, d_seg, L, nh, drop);
-        hipLaunchKernelGGL((xl_attn_bwd_kv_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, xp,
+        hipLaunchKernelGGL((xl_attn_bwd_kv_kernel<T, LP, NWK>), dim3(B * nh), dim3(NWK * 64), 0, st, (const T*)qkv, xp,
                            (const T*)psave, (const T*)gsave, (const T*)dvec, (T*)dqkv, (T*)dkr, L, nh, drop);
     })
 }

@@ -3,7 +3,7 @@
 // caller-owned flat parameter / gradient / bf16-shadow / workspace buffers, reference state-dict names.
 //
 // Only the configuration the reference driver exercises is built (xlnet-base-cased: attn_type "bi", no mems / perm_mask /
-// target_mapping; multimodal_driver.py:363-370), sequence length <= 64 (MOSI: 50).
+// target_mapping; multimodal_driver.py:363-370), sequence length <= 128 (MOSI: 50).
 //
 // Flat layout:  [ decay | no-decay | frozen ]
 //   decay    : per layer rel_attn.{q,k,v,o,r} ([d_model][n_head*d_head], consumed k-major as stored), ff.layer_1.weight,
@@ -130,7 +130,8 @@ static void xl_build_layout(mb_xlnet_engine* e) {
     const size_t es = esize(c.dtype);
     const size_t T = align_up((size_t)c.max_batch * c.max_seq, 64);
     const size_t R = align_up((size_t)c.max_batch * 2 * c.max_seq, 64);
-    const size_t PP = (size_t)c.max_batch * nh * 64 * 64;      // saved probabilities / score gradients: [B * heads][LP][LP], LP <= 64
+    const size_t LPm = c.max_seq <= 32 ? 32 : (c.max_seq <= 64 ? 64 : 128);
+    const size_t PP = (size_t)c.max_batch * nh * LPm * LPm;    // saved probabilities / score gradients: [B * heads][LP][LP], LP = 32 | 64 | 128
     Carver w;
     e->mw.init(c.dtype, (int)T, (int)H, (int)V, (int)A);
     e->ws_mag = w.take(e->mw.bytes);
@@ -195,7 +196,7 @@ extern "C" {
 int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out) {
     if (!cfg || !out) return MB_ERR_ARG;
     if (cfg->d_model != 768 || cfg->n_head * 64 != cfg->d_model) return MB_ERR_SHAPE;
-    if (cfg->d_inner % 128 || cfg->max_seq < 1 || cfg->max_seq > 64 || cfg->max_batch < 1 || cfg->num_labels < 1) return MB_ERR_SHAPE;
+    if (cfg->d_inner % 128 || cfg->max_seq < 1 || cfg->max_seq > 128 || cfg->max_batch < 1 || cfg->num_labels < 1) return MB_ERR_SHAPE;
     if (cfg->injection_index < 0 || cfg->injection_index >= cfg->n_layer) return MB_ERR_ARG;
     if (cfg->dtype != DT_F32 && cfg->dtype != DT_BF16) return MB_ERR_DTYPE;
     mb_xlnet_engine* e = new mb_xlnet_engine();
@@ -575,7 +576,7 @@ const void* mb_xlnet_hidden_state(const mb_xlnet_engine* e, int i) {      // inp
 }
 const void* mb_xlnet_attention_probs(const mb_xlnet_engine* e, int layer, int* padded_len) {
     if (!e || !e->ws || !e->ran_forward || layer < 0 || layer >= e->c.n_layer) return nullptr;
-    if (padded_len) *padded_len = (e->L + 31) / 32 * 32;
+    if (padded_len) *padded_len = e->L <= 32 ? 32 : (e->L <= 64 ? 64 : 128);
     return e->ws + e->lw[layer].psave;
 }
 const void* mb_xlnet_sequence_output(const mb_xlnet_engine* e) { return e->ws ? e->ws + e->ws_x[e->c.n_layer] : nullptr; }

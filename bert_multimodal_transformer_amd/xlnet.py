@@ -8,7 +8,7 @@ sequence_summary.summary.*, logits_proj.*).  Built for the configuration the ref
 (multimodal_driver.py:363-370: attention_mask + token_type_ids, no mems / perm_mask / target_mapping / input_mask: those raise
 NotImplementedError; inputs_embeds, output_hidden_states / output_attentions (served from the activations the engine keeps for
 its backward) and head_mask (scales each head's attention output inside the kernels) are built, and MAG_XLNetModel's output is
-differentiable), sequence length <= 64, MAG injected in front of layer
+differentiable), sequence length <= 128, MAG injected in front of layer
 XLNET_INJECTION_INDEX (global_configs.py:19, xlnet.py:371-372).
 """
 import torch

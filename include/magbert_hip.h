@@ -246,7 +246,7 @@ int mb_bert_profile_adamw_us(mb_bert_engine* e, float* us);
 
 /* ------------------------------------------------------------------------------------------------ MAG-XLNet engine
  * MAG_XLNetForSequenceClassification forward / backward (xlnet.py:432-527 -> :15-429; XLNetLayer / SequenceSummary of
- * transformers 3.0.2) for the driver's configuration (bi-directional, no mems / perm_mask / target_mapping), L <= 64.
+ * transformers 3.0.2) for the driver's configuration (bi-directional, no mems / perm_mask / target_mapping), L <= 128.
  * Same calling conventions as the mb_bert_* family.  Backward stages: 0 = summary + logits_proj, 1..n_layer = layers (last
  * first; the MAG backward runs inside the stage of layer `injection_index`), n_layer+1 = word embedding. */
 typedef struct {

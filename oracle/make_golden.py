@@ -251,7 +251,7 @@ def gen_full(cb, modeling, bert):
 
 
 def gen_xlnet(modeling, xlnet):
-    """G6: MAG-XLNet -- eval logits (B=4, 48; L=50), train-mode p=0 loss + per-tensor grad norms, one XLNetLayer out."""
+    """G6: MAG-XLNet -- eval logits (B=4, 48 at L=50; B=3 at L=128, B=2 at L=100), train-mode p=0 loss + per-tensor grad norms."""
     from transformers.models.xlnet import modeling_xlnet as mx, configuration_xlnet as cx
     from oracle import weights
     from oracle import mag_xlnet_ref as X
@@ -268,7 +268,7 @@ def gen_xlnet(modeling, xlnet):
 
     ref, mine = pair()
     ref.eval(); mine.eval()
-    for (B, L, seed) in ((4, 50, 31), (48, 50, 32)):
+    for (B, L, seed) in ((4, 50, 31), (48, 50, 32), (3, 128, 34), (2, 100, 35)):      # round 3: sequence lengths above 64
         ids, vis, aco, mask, seg, lab = _tb(weights.synthetic_xlnet_batch(B, L, 47, 74, seed=seed))
         with torch.no_grad():
             a = ref(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)[0]
