@@ -90,6 +90,9 @@ PROTOTYPES = {
     "mb_bert_stage_grad_ranges": (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz), _i]),
     "mb_bert_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f,
                                 _i, _i, _f, _f, _i, _vp]),
+    "mb_bert_stage_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u64, _u64, _vp, _vp, _vp, _i, _vp]),
+    "mb_bert_stage_backward": (_i, [_vp, _f, _i, _i, _vp]),
+    "mb_bert_staged_input_ids": (_vp, [_vp]),
     "mb_bert_load_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_vp), _vp]),
     "mb_bert_graph_stats": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "mb_bert_set_profiling": (_i, [_vp, _i]),

@@ -429,6 +429,38 @@ class _Core(object):
         self._gz = opt is not None          # the fused AdamW left the gradients zeroed / a micro-step left them populated
         return logits
 
+    def stage_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, loss_scale=1.0, mode=1):
+        """forward + MSE + backward of one training step cut at the backward stages (include/magbert_hip.h: mb_bert_stage_forward /
+        mb_bert_stage_backward): every pass is ONE replayed graph, the stage hooks (data parallel: the gradient exchange) run
+        between them.  What a data-parallel rank runs instead of ~210 kernel launches from Python."""
+        B, L = input_ids.shape
+        self._ensure(B, L)
+        if self.weights_dirty:
+            self.sync_weights()
+        self._set_optional(None, None, None)
+        ptr, keep = self._inputs(input_ids, visual, acoustic, attention_mask, token_type_ids, labels, gather_in_step=True)
+        if not hasattr(self, "_logit_bufs"):
+            self._logit_bufs = {}
+        logits = self._logit_bufs.get(B)
+        if logits is None:
+            logits = self._logit_bufs[B] = torch.empty(B, self.config.num_labels, dtype=torch.float32, device=self.device)
+        self.step += 1
+        self._keep = (keep, logits)
+        self._lab_ptr = None
+        self.training_last = True
+        off = self.lib.mb_bert_staged_input_ids(self.handle) - self.ws.data_ptr()
+        self._ids_dev = self.ws[off: off + B * L * 8].view(torch.int64)          # the engine's staging copy of input_ids
+        with _Core._Hop(self):
+            _lib.check(self.lib.mb_bert_stage_forward(
+                self.handle, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5], B, L, self.seed & (2 ** 64 - 1), self.step, _lib.ptr(logits),
+                C.c_void_p(self.loss_buf.data_ptr()), C.c_void_p(self.loss_buf.data_ptr() + 4), int(mode), self.stream()))
+            self._gz = False
+            for s in range(self.n_layers + 2):
+                _lib.check(self.lib.mb_bert_stage_backward(self.handle, float(loss_scale), s, int(mode), self.stream()))
+                for hook in self.stage_hooks:
+                    hook(s)
+        return logits
+
     def graph_stats(self):
         cap, rep = C.c_size_t(), C.c_size_t()
         _lib.check(self._fn("graph_stats")(self.handle, C.byref(cap), C.byref(rep)))
@@ -759,6 +791,12 @@ class _FusedStep(object):
         if self.num_labels != 1:
             raise NotImplementedError("fused loss is the regression MSE of the driver (num_labels == 1)")
         core = self._core
+        # data parallel, MB_DP_GRAPH=1: one replayed graph per pass / backward stage instead of kernel launches from Python.  Opt-in:
+        # measured on one GPU (1-rank RCCL group, profiles/r03_dp_force.txt) the graphs are not faster (4.52 vs 4.43 ms per step; the
+        # single-call step: 3.84) -- what the stage-driven step pays is the exchange machinery itself, not the launches
+        if core.kind == "bert" and core.stage_hooks and os.environ.get("MB_DP_GRAPH", "0") == "1" and os.environ.get("MB_OVERLAP_WGRAD", "0") in ("", "0"):
+            core.stage_step(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, loss_scale=loss_scale)
+            return core.loss_buf[0]
         core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, True)
         core._backward(None, loss_scale)
         return core.loss_buf[0]

@@ -528,7 +528,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             float* lnp_a = (float*)(ws + e->ws_lnp_a) + (size_t)l * e->lnp_stride;
             float* lnp_b = (float*)(ws + e->ws_lnp_b) + (size_t)l * e->lnp_stride;
             // single-call step: nobody needs this layer's LayerNorm / bias gradients before AdamW -> all layers reduced at once
-            const bool defer_ln = e->in_step && NL <= MB_LN_MAX_LAYERS;
+            const bool defer_ln = e->in_step && !e->stage_mode && NL <= MB_LN_MAX_LAYERS;
             // LN2 + dropout backward (column sums -> per-block partial slabs, reduced once per layer below)
             CK(ln_backward_partials(dt, dx, ws + w.s2, P + o.ln2w, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, dsA,
                                     hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(SITE_LAYER0 + 4 * l + 2, c.hidden_dropout), st));
@@ -686,6 +686,54 @@ int mb_bert_train_step(mb_bert_engine* e, const int64_t* input_ids, const float*
                                return enqueue_step(e, B, L, lg, ls, lr_, m_, v_, sc, s);
                            });
 }
+
+// ------------------------------------------------------------------------------------------------ stage-driven step (data parallel)
+// The same step cut at its backward stages, for a host that issues the gradient exchange between them (one RCCL all-reduce piece
+// per stage on a side stream): mb_bert_stage_forward = step prologue (batch gather, dropout keys) + the forward + MSE as ONE
+// replayed graph, mb_bert_stage_backward(stage) = that stage as one replayed graph.  16 graph launches per step instead of ~210
+// kernel launches from a host that is the bottleneck of the launch-by-launch form (4.0 ms of host time per 4.4 ms step inside a
+// torch process, profiles/r03_dp_force.txt).  The optimizer stays with the caller (mb_adamw_step on the reduced gradients).
+int mb_bert_stage_forward(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                          const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                          uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, int mode, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!e || !e->P || !e->G || !e->ws) return MB_ERR_ARG;
+    const mb_bert_config& c = e->c;
+    if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
+    if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !labels || !logits || !loss) return MB_ERR_ARG;
+    if (mode != 1 && mode != 2) return MB_ERR_ARG;
+    if (e->head_mask || e->emb_in || e->pos_ids || e->deferred) return MB_ERR_MODE;
+    if (e->prof) mode = 2;              // timing events around kernels: launch by launch (events cannot live inside a captured graph)
+    char* ws = e->ws;
+    e->training = 1;
+    CK(prepare_pass(e, B * L, st));
+    PrologueArgs pa = {};
+    e->fill_copies(pa, ws, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, B, L, c.visual_dim, c.acoustic_dim, c.num_labels);
+    pa.seed = seed; pa.step = step; pa.keys = e->key_state(ws); pa.nsites = e->nsites;
+    CK(step_prologue(pa, st));
+    float* keep_attn = e->attn_out;
+    e->attn_out = nullptr;
+    struct Restore { mb_bert_engine* e; float* p; ~Restore() { e->attn_out = p; } } restore{e, keep_attn};
+    return e->run_stage_graph(B, L, -1, 0, logits, loss, loss_run, 0.f, mode, st, [&](hipStream_t s) {
+        return mb_bert_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
+                               (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), (const float*)(ws + e->ws_in_lab), B, L, 1,
+                               0, 0, logits, loss, loss_run, s);
+    });
+}
+int mb_bert_stage_backward(mb_bert_engine* e, float loss_scale, int stage, int mode, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!e || !e->G || !e->ran_forward || !e->training) return MB_ERR_ARG;
+    if (stage < 0 || stage > e->c.num_layers + 1 || (mode != 1 && mode != 2)) return MB_ERR_ARG;
+    if (e->deferred) return MB_ERR_MODE;
+    if (e->prof) mode = 2;
+    if (stage == 0) CK(e->begin_backward_pass(e->G, st));        // outside the graph: decides store vs accumulate (part of the graph's identity)
+    const float* lab = (const float*)(e->ws + e->ws_in_lab);
+    return e->run_stage_graph(e->B, e->L, stage, e->ow_pass ? 1 : 0, e->logits, nullptr, nullptr, loss_scale, mode, st, [&](hipStream_t s) {
+        return mb_bert_backward(e, nullptr, lab, loss_scale, stage, stage + 1, s);
+    });
+}
+
+const int64_t* mb_bert_staged_input_ids(const mb_bert_engine* e) { return (e && e->ws) ? (const int64_t*)(e->ws + e->ws_in_ids) : nullptr; }
 
 int mb_bert_load_batch(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
                        const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,

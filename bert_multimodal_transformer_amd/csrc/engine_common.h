@@ -136,8 +136,13 @@ struct StepGraph {
     hipGraph_t graph; hipGraphExec_t exec;
 };
 
+// one captured pass of a stage-driven (data-parallel) step: stage -1 = forward, 0 .. = backward stage
+struct StageGraph { int B, L, stage, overwrite; const void *logits, *loss, *loss_run; float loss_scale; hipStream_t st; hipGraph_t graph; hipGraphExec_t exec; };
+
 struct StepMixin {
     bool dyn = false;              // dropout keys / AdamW scalars are read from device memory (set while a train step is built)
+    bool stage_mode = false;       // a stage-driven step is being built: every stage's gradients must be final when the stage returns
+    std::vector<StageGraph> stage_graphs;
     bool capturing = false;        // the stream is in capture mode: nothing outside the captured sequence may be waited for
     int nsites = 0;
     size_t ws_state = 0, ws_in_ids = 0, ws_in_seg = 0, ws_in_mask = 0, ws_in_vis = 0, ws_in_aco = 0, ws_in_lab = 0;
@@ -213,6 +218,41 @@ struct StepMixin {
     void drop_graphs() {
         for (auto& g : graphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
         graphs.clear();
+        for (auto& g : stage_graphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
+        stage_graphs.clear();
+    }
+    // replay (capturing on first use) one pass of a stage-driven step; enqueue(st) issues its kernels with dyn keys
+    template <class Enq>
+    int run_stage_graph(int B, int L, int stage, int overwrite, const void* logits, const void* loss, const void* loss_run, float loss_scale,
+                        int mode, hipStream_t st, Enq enqueue) {
+        struct Scope { StepMixin* m; ~Scope() { m->dyn = false; m->capturing = false; m->in_step = false; m->stage_mode = false; } } scope{this};
+        dyn = true; in_step = true; stage_mode = true;
+        if (mode == 2) return enqueue(st);
+        StageGraph* g = nullptr;
+        for (auto& x : stage_graphs)
+            if (x.B == B && x.L == L && x.stage == stage && x.overwrite == overwrite && x.logits == logits && x.loss == loss && x.loss_run == loss_run &&
+                x.loss_scale == loss_scale && x.st == st) { g = &x; break; }
+        if (!g) {
+            if (stage_graphs.size() >= 256) {
+                hipGraphExecDestroy(stage_graphs.front().exec); hipGraphDestroy(stage_graphs.front().graph);
+                stage_graphs.erase(stage_graphs.begin());
+            }
+            StageGraph ng = {B, L, stage, overwrite, logits, loss, loss_run, loss_scale, st, nullptr, nullptr};
+            CK((int)hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+            capturing = true;
+            const int r = enqueue(st);
+            capturing = false;
+            const int r2 = (int)hipStreamEndCapture(st, &ng.graph);
+            if (r) { if (ng.graph) hipGraphDestroy(ng.graph); return r; }
+            CK(r2);
+            CK((int)hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0));
+            stage_graphs.push_back(ng);
+            g = &stage_graphs.back();
+            ++graph_captures;
+        }
+        CK((int)hipGraphLaunch(g->exec, st));
+        ++graph_launches;
+        return MB_OK;
     }
     AdamArgs* adam_state(char* ws) const { return (AdamArgs*)(ws + ws_state); }
     uint32_t* key_state(char* ws) const { return (uint32_t*)(ws + ws_state + 2 * sizeof(AdamArgs)); }

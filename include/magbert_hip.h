@@ -223,6 +223,18 @@ int mb_bert_train_step(mb_bert_engine* e, const int64_t* input_ids, const float*
                        uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, float* m, float* v, float lr,
                        float beta1, float beta2, float eps, float weight_decay, int opt_step, int correct_bias, float grad_scale,
                        float loss_scale, int mode, void* stream);
+/* The same step cut at its backward stages, for data-parallel hosts that issue one gradient all-reduce piece per stage between
+ * them (mb_bert_stage_grad_ranges says what each stage makes final): mb_bert_stage_forward = step prologue (batch gather from
+ * device or pinned host pointers, this step's dropout keys) + forward + MSE as one replayed graph; mb_bert_stage_backward(stage),
+ * stage = 0 .. num_layers + 1 in order, = that stage as one replayed graph.  mode 1 = graphs, 2 = the same kernels launched one by
+ * one.  The optimizer update stays with the caller (mb_adamw_step).  Same arithmetic and dropout masks as mb_bert_forward +
+ * mb_bert_backward with the same (seed, step). */
+int mb_bert_stage_forward(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                          const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                          uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, int mode, void* stream);
+int mb_bert_stage_backward(mb_bert_engine* e, float loss_scale, int stage, int mode, void* stream);
+/* the engine's staging copy of the last gathered input_ids ([B*L] int64, device): the rows of the word-embedding gradient */
+const int64_t* mb_bert_staged_input_ids(const mb_bert_engine* e);
 /* `batch = tuple(t.to(DEVICE) for t in batch)` (multimodal_driver.py:359, :396, :429) for callers that drive the passes
  * themselves (evaluation, data parallel): ONE gather launch copies the six batch tensors into the engine's staging buffers.
  * The sources may be pinned HOST memory (hipHostMalloc / torch pin_memory: the kernel reads it across PCIe, no copy engine, no

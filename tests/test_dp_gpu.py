@@ -55,7 +55,7 @@ print("OK", world, rank)
 '''
 
 
-@pytest.mark.parametrize("kind,sparse", [("bert", "1"), ("bert", "0"), ("xlnet", "1")])
+@pytest.mark.parametrize("kind,sparse", [("bert", "1"), ("bert", "0"), ("xlnet", "1"), ("bert-stage-graphs", "1")])
 def test_two_ranks_equal_one_process(tmp_path, kind, sparse):
     """Two ranks with half the batch each vs one process with the whole batch (fp32 parity mode, dropout off).  The quantity that
     must agree is the ALL-REDUCED GRADIENT (the mean over the global batch): <= 5e-6 of the largest gradient everywhere, for the
@@ -68,11 +68,14 @@ def test_two_ranks_equal_one_process(tmp_path, kind, sparse):
     out = str(tmp_path / "params")
     port = 29600 + os.getpid() % 1000
 
+    graphs = kind.endswith("-stage-graphs")        # MB_DP_GRAPH=1: every pass / backward stage of the ranks is ONE replayed graph
+    kind = kind.split("-")[0]
+
     def launch(world):
         procs = []
         for r in range(world):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                       REPO_ROOT=ROOT, OUT=out, KIND=kind, MB_DP_SPARSE_EMB=sparse)
+                       REPO_ROOT=ROOT, OUT=out, KIND=kind, MB_DP_SPARSE_EMB=sparse, MB_DP_GRAPH="1" if graphs else "0")
             procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         for p in procs:
             o, _ = p.communicate(timeout=600)
