@@ -786,10 +786,10 @@ class _FusedStep(object):
     (what the bundled driver's train_epoch and bench.py call instead of the reference's five-line step)."""
 
     def training_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, loss_scale=1.0):
-        """forward + MSE (multimodal_driver.py:372-373) + backward in two C calls, no host sync.
+        """forward + loss + backward in two C calls, no host sync.  The loss is the one the reference's forward computes when it is
+        given labels (bert.py:313-322 / xlnet.py:515-524): MSE for num_labels == 1 (what the driver trains, multimodal_driver.py:372-373),
+        cross entropy over the class indices in label_ids otherwise.
         Returns the device scalar holding this step's loss (running sum is in .loss_running())."""
-        if self.num_labels != 1:
-            raise NotImplementedError("fused loss is the regression MSE of the driver (num_labels == 1)")
         core = self._core
         # data parallel, MB_DP_GRAPH=1: one replayed graph per pass / backward stage instead of kernel launches from Python.  Opt-in:
         # measured on one GPU (1-rank RCCL group, profiles/r03_dp_force.txt) the graphs are not faster (4.52 vs 4.43 ms per step; the
@@ -814,8 +814,6 @@ class _FusedStep(object):
         the kernels one by one.  Otherwise (MAG-XLNet, data parallel, foreign optimizers) the passes are driven from here:
         training_step + optimizer.step(); graph=False forces that path, graph=True raises if the single call is unavailable.
         Pass optimizer=None on gradient-accumulation micro-steps.  Returns the device loss scalar."""
-        if self.num_labels != 1:
-            raise NotImplementedError("fused loss is the regression MSE of the driver (num_labels == 1)")
         core = self._core
         why = core.fused_step_blocker()
         opt = None
@@ -843,8 +841,6 @@ class _FusedStep(object):
     def eval_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids):
         """forward in the module's current mode with the fused MSE of eval_epoch (multimodal_driver.py:405-411): the batch
         loss is added to loss_running() on the device.  Returns the logits."""
-        if self.num_labels != 1:
-            raise NotImplementedError("fused loss is the regression MSE of the driver (num_labels == 1)")
         return self._core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, self.training)
 
     def loss_running(self, reset=False):

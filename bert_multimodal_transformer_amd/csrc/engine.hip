@@ -309,7 +309,7 @@ int mb_mag_forward(int dtype, const void* text, const float* visual, const float
                    const float* b_hv, const float* W_ha, const float* b_ha, const float* W_v, const float* b_v,
                    const float* W_a, const float* b_a, const float* ln_w, const float* ln_b, float beta_shift,
                    const mb_dropkey* drop, void* out, void* ws, int T, int H, int V, int A, void* stream) {
-    if (H != 768 || V < 1 || A < 1) return MB_ERR_SHAPE;
+    if (H % 256 || H < 256 || H > 1024 || V < 1 || A < 1) return MB_ERR_SHAPE;      // the operator; the engines are built for 768
     MagWs w;
     w.init(dtype, T, H, V, A);
     return mag_fwd_impl(dtype, text, visual, acoustic, W_hv, b_hv, W_ha, b_ha, W_v, b_v, W_a, b_a, ln_w, ln_b, 1e-5f,
@@ -322,7 +322,7 @@ int mb_mag_backward(int dtype, const void* d_out, const void* text, const float*
                     float* dW_v, float* db_v, float* dW_a, float* db_a, float* dln_w, float* dln_b, int T, int H, int V,
                     int A, void* stream) {
     (void)W_hv; (void)W_ha; (void)W_v; (void)W_a;   // the packed copies made by the forward are reused
-    if (H != 768) return MB_ERR_SHAPE;
+    if (H % 256 || H < 256 || H > 1024) return MB_ERR_SHAPE;
     MagWs w;
     w.init(dtype, T, H, V, A);
     return mag_bwd_impl(dtype, d_out, text, b_hv, b_ha, b_v, b_a, ln_w, beta_shift, dk(drop), (char*)ws, w, d_text,

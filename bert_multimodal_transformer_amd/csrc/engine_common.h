@@ -272,7 +272,8 @@ struct StepMixin {
         };
         cp(ids, ws_in_ids, T * 8); cp(seg, ws_in_seg, T * 8); cp(mask, ws_in_mask, T * 8);
         cp(vis, ws_in_vis, T * V * 4); cp(aco, ws_in_aco, T * A * 4);
-        if (lab) cp(lab, ws_in_lab, (size_t)B * num_labels * 4);
+        (void)num_labels;          // one float per sample either way: the regression target (num_labels == 1) or the class index
+        if (lab) cp(lab, ws_in_lab, (size_t)B * 4);
     }
     void staged(char* ws, bool with_labels, const void** six) const {
         six[0] = ws + ws_in_ids; six[1] = ws + ws_in_vis; six[2] = ws + ws_in_aco; six[3] = ws + ws_in_mask; six[4] = ws + ws_in_seg;

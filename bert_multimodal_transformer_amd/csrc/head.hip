@@ -1,7 +1,9 @@
 // Classification head of MAG_BertForSequenceClassification (/root/reference/bert.py:304-322) fused with the
 // driver's MSE loss (/root/reference/multimodal_driver.py:372-373):
 //   pooled = tanh(z)  [z = h[:,0] Wp^T + bp comes from the GEMM]  ->  dropout(0.1)  ->  logits = . Wc^T + bc
-//   loss = mean((logits - labels)^2)
+//   loss = mean((logits - labels)^2)                                  num_labels == 1 (the driver's regression)
+//   loss = mean_b(logsumexp(logits_b) - logits_b[label_b])            num_labels  > 1 (bert.py:318-320 / xlnet.py:519-522:
+//          CrossEntropyLoss; labels[b] then holds the class index of sample b as a float)
 // One wave per sample; H = 768 (3 chunks of 4 columns per lane).  Tiny, launch-latency bound.
 #include "kernels.h"
 
@@ -34,6 +36,9 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r) pd[c][r] = t[r] * drop_mult(drop, idx + r);
         }
+        // cross entropy (nl > 1): online log-sum-exp over the classes, kept by lane 0
+        float mx = -3.0e38f, se = 0.f, tgt = 0.f;
+        const int y = (labels && nl > 1) ? (int)labels[b] : -1;
         for (int k = 0; k < nl; ++k) {
             float s = 0.f;
 #pragma unroll
@@ -45,12 +50,18 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__
             s = wave_sum(s) + bc[k];
             if (lane == 0) {
                 logits[(size_t)b * nl + k] = s;
-                if (labels) {
-                    const float d = s - labels[(size_t)b * nl + k];
-                    mine += d * d / (float)(B * nl);
+                if (labels && nl == 1) {
+                    const float d = s - labels[b];
+                    mine += d * d / (float)B;
+                } else if (labels) {
+                    const float nm = fmaxf(mx, s);
+                    se = se * __expf(mx - nm) + __expf(s - nm);
+                    mx = nm;
+                    if (k == y) tgt = s;
                 }
             }
         }
+        if (lane == 0 && labels && nl > 1) mine = (mx + __logf(se) - tgt) / (float)B;
     }
     if (labels == nullptr || (loss == nullptr && loss_run == nullptr)) return;      // uniform
     if (lane == 0) lsum[wave] = mine;
@@ -86,11 +97,22 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r) dm[c][r] = drop_mult(drop, idx + r);
     }
+    float lse = 0.f;
+    int y = -1;
+    if (valid && !dlogits && nl > 1) {          // cross entropy: d logit_k = (softmax_k - [k == label]) / B
+        float mx = -3.0e38f;
+        for (int k = 0; k < nl; ++k) mx = fmaxf(mx, logits[(size_t)b * nl + k]);
+        float se = 0.f;
+        for (int k = 0; k < nl; ++k) se += __expf(logits[(size_t)b * nl + k] - mx);
+        lse = mx + __logf(se);
+        y = (int)labels[b];
+    }
     for (int k = 0; k < nl; ++k) {
         float dl = 0.f;
         if (valid) {
             if (dlogits) dl = dlogits[(size_t)b * nl + k];
-            else dl = 2.0f * (logits[(size_t)b * nl + k] - labels[(size_t)b * nl + k]) / (float)(B * nl) * loss_scale;
+            else if (nl == 1) dl = 2.0f * (logits[b] - labels[b]) / (float)B * loss_scale;
+            else dl = (__expf(logits[(size_t)b * nl + k] - lse) - (k == y ? 1.0f : 0.0f)) / (float)B * loss_scale;
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {

@@ -273,13 +273,14 @@ int mag_gate_forward(int dtype, const void* e, const void* Ze, const void* Zv, c
                      const float* b_ha, const float* b_v, const float* b_a, const float* gamma, const float* beta,
                      float ln_eps, float beta_shift, void* out, float* mean, float* rstd, MagDims d, DropKey drop,
                      hipStream_t st) {
-    if (d.H != 768) return MB_ERR_SHAPE;
+    if (d.H % 256 || d.H < 256 || d.H > 1024) return MB_ERR_SHAPE;      // MAG(hidden_size, ...) (modeling.py:7,22): rows of 256 .. 1024
     if (d.T <= 0) return MB_OK;
+#define MB_MAG_FWD(CHV) hipLaunchKernelGGL((mag_gate_fwd_kernel<T, CHV>), dim3((d.T + 3) / 4), dim3(256), 0, st, (const T*)e, (const T*)Ze, \
+                           (const T*)Zv, (const T*)Za, b_hv, b_ha, b_v, b_a, gamma, beta, ln_eps, beta_shift, (T*)out, mean, rstd, d.T, drop)
     MB_DISPATCH_T(dtype, {
-        hipLaunchKernelGGL((mag_gate_fwd_kernel<T, 3>), dim3((d.T + 3) / 4), dim3(256), 0, st, (const T*)e, (const T*)Ze,
-                           (const T*)Zv, (const T*)Za, b_hv, b_ha, b_v, b_a, gamma, beta, ln_eps, beta_shift, (T*)out,
-                           mean, rstd, d.T, drop);
+        switch (d.H / 256) { case 1: MB_MAG_FWD(1); break; case 2: MB_MAG_FWD(2); break; case 3: MB_MAG_FWD(3); break; default: MB_MAG_FWD(4); }
     })
+#undef MB_MAG_FWD
     return (int)hipGetLastError();
 }
 
@@ -288,15 +289,17 @@ int mag_gate_backward(int dtype, const void* dout, const void* e, const void* Ze
                       const float* mean, const float* rstd, float beta_shift, void* de, void* dZe, void* dZv, void* dZa,
                       float* db_hv, float* db_ha, float* db_v, float* db_a, float* dgamma, float* dbeta, MagDims d,
                       DropKey drop, hipStream_t st) {
-    if (d.H != 768) return MB_ERR_SHAPE;
+    if (d.H % 256 || d.H < 256 || d.H > 1024) return MB_ERR_SHAPE;
     if (d.T <= 0) return MB_OK;
     constexpr int RPW = 2;
+#define MB_MAG_BWD(CHV) hipLaunchKernelGGL((mag_gate_bwd_kernel<T, CHV, RPW>), dim3((d.T + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st, \
+                           (const T*)dout, (const T*)e, (const T*)Ze, (const T*)Zv, (const T*)Za, b_hv, b_ha, b_v, b_a, \
+                           gamma, mean, rstd, beta_shift, (T*)de, (T*)dZe, (T*)dZv, (T*)dZa, db_hv, db_ha, db_v, db_a, \
+                           dgamma, dbeta, d.T, drop)
     MB_DISPATCH_T(dtype, {
-        hipLaunchKernelGGL((mag_gate_bwd_kernel<T, 3, RPW>), dim3((d.T + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st,
-                           (const T*)dout, (const T*)e, (const T*)Ze, (const T*)Zv, (const T*)Za, b_hv, b_ha, b_v, b_a,
-                           gamma, mean, rstd, beta_shift, (T*)de, (T*)dZe, (T*)dZv, (T*)dZa, db_hv, db_ha, db_v, db_a,
-                           dgamma, dbeta, d.T, drop);
+        switch (d.H / 256) { case 1: MB_MAG_BWD(1); break; case 2: MB_MAG_BWD(2); break; case 3: MB_MAG_BWD(3); break; default: MB_MAG_BWD(4); }
     })
+#undef MB_MAG_BWD
     return (int)hipGetLastError();
 }
 

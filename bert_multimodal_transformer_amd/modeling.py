@@ -64,8 +64,8 @@ class MAG(nn.Module):
     def __init__(self, hidden_size, beta_shift, dropout_prob, visual_dim=VISUAL_DIM, acoustic_dim=ACOUSTIC_DIM,
                  compute_dtype=torch.float32):
         super(MAG, self).__init__()
-        if hidden_size != 768:
-            raise NotImplementedError("the HIP MAG kernels are built for TEXT_DIM = 768 (global_configs.py:11)")
+        if hidden_size % 256 or not 256 <= hidden_size <= 1024:
+            raise NotImplementedError("the HIP MAG row kernels take hidden_size = 256, 512, 768 (TEXT_DIM, global_configs.py:11) or 1024")
         self.W_hv = nn.Linear(visual_dim + hidden_size, hidden_size)       # modeling.py:15
         self.W_ha = nn.Linear(acoustic_dim + hidden_size, hidden_size)     # modeling.py:16
         self.W_v = nn.Linear(visual_dim, hidden_size)                      # modeling.py:18

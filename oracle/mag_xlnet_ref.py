@@ -175,8 +175,11 @@ class MAG_XLNetForSequenceClassification(nn.Module):
         out = self.transformer(input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask, inputs_embeds)
         logits = self.logits_proj(self.sequence_summary(out))                           # xlnet.py:506-509
         outputs = (logits,)
-        if labels is not None:
-            outputs = (F.mse_loss(logits.view(-1), labels.view(-1)),) + outputs
+        if labels is not None:                                                          # xlnet.py:515-524
+            if self.num_labels == 1:
+                outputs = (F.mse_loss(logits.view(-1), labels.view(-1)),) + outputs
+            else:
+                outputs = (F.cross_entropy(logits.view(-1, self.num_labels), labels.view(-1)),) + outputs
         return outputs
 
 

@@ -41,6 +41,10 @@ timeout 60 tools/bin/gemm_bench --T 4096 > $O/gemm_bench_T4096.txt 2>&1
 MB_GEMM_TRACE=1 timeout 60 tools/bin/gemm_bench --trace 1 > $O/gemm_phases.txt 2>&1
 { MB_ATTN_TRACE=1 timeout 60 tools/bin/attn_bench; MB_ATTN_TRACE=1 timeout 60 tools/bin/attn_bench --batch 32 --seq 128; timeout 60 tools/bin/attn_bench; } > $O/attention_phases.txt 2>&1
 timeout 60 tools/bin/launch_floor > $O/launch_floor.txt 2>&1
+# per-iteration stamps inside the k loop (library built with -DMB_GEMM_LOOPTRACE by scripts/build_variant.py, if present)
+[ -f gpurun_ab/looptrace/libmagbert_hip.so ] && LD_LIBRARY_PATH=$R/gpurun_ab/looptrace:$LD_LIBRARY_PATH MB_GEMM_TRACE=1 timeout 120 tools/bin/gemm_bench --looptrace 1 > $O/gemm_looptrace.txt 2>&1
+# same-box A/B of the software-pipelined k loop against the plain loop (-DMB_GEMM_PLAIN_LOOP build, if present)
+[ -f gpurun_ab/plainloop/libmagbert_hip.so ] && REPS=2 bash scripts/gpu_ab.sh plainloop > $O/ab_pipelined_vs_plain.txt 2>&1
 { timeout 60 tools/bin/adamw_bench; MB_ADAMW_VAR=0 timeout 60 tools/bin/adamw_bench; timeout 60 tools/bin/adamw_bench --zero 0; } > $O/adamw_bench.txt 2>&1
 # ---- 2. C5 shape and a second headline timing from the C++ driver
 { timeout 60 $SB --graph 1 --h2d 2 --steps 40 --warmup 8; timeout 60 $SB --graph 1 --h2d 2 --batch 32 --seq 128 --visual 35 --steps 30 --warmup 6; } > $O/step_bench.txt 2>&1

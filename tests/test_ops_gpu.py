@@ -334,6 +334,30 @@ def test_mag_module_vs_oracle_train_dropout_replay(cdt, dt):
         close_grad(p.grad, po.grad, dt, "mag grad " + n, 6 if dt == _lib.DT_F32 else 1)
 
 
+@pytest.mark.parametrize("H", [256, 512, 1024])
+def test_mag_module_other_hidden_sizes_vs_oracle(H):
+    """MAG(hidden_size, ...) (modeling.py:7,22) away from TEXT_DIM = 768: output and every gradient against the oracle's MAG, fp32"""
+    from oracle import mag_bert_ref as R, weights
+    from bert_multimodal_transformer_amd import MAG
+    V, A, B, L = 47, 74, 3, 20
+    m = MAG(H, 1.0, 0.0, visual_dim=V, acoustic_dim=A).to(DEV).train()
+    o = R.MAG(H, 1.0, 0.0, V, A).train()
+    sd = {n: torch.from_numpy(weights.make_param("mag%d." % H + n, tuple(p.shape), "test")) for n, p in o.named_parameters()}
+    o.load_state_dict(sd); m.load_state_dict({k: v.to(DEV) for k, v in sd.items()})
+    b = weights.synthetic_bert_batch(B, L, V, A, seed=5)
+    e0 = torch.from_numpy(weights.uniform("mag.eH%d" % H, (B, L, H), -1.5, 1.5))
+    e = e0.clone().to(DEV).requires_grad_(True); eo = e0.clone().requires_grad_(True)
+    w = torch.from_numpy(weights.uniform("mag.dyH%d" % H, (B, L, H)))
+    y = m(e, torch.from_numpy(b["visual"]).to(DEV), torch.from_numpy(b["acoustic"]).to(DEV))
+    yo = o(eo, torch.from_numpy(b["visual"]), torch.from_numpy(b["acoustic"]))
+    (y * w.to(DEV)).sum().backward(); (yo * w).sum().backward()
+    torch.cuda.synchronize()
+    close(y, yo.detach(), _lib.DT_F32, "mag H=%d out" % H, 5)
+    close(e.grad, eo.grad, _lib.DT_F32, "mag H=%d d_text" % H, 5)
+    for (n, p), (_, po) in zip(m.named_parameters(), o.named_parameters()):
+        close_grad(p.grad, po.grad, _lib.DT_F32, "mag H=%d grad %s" % (H, n), 6)
+
+
 def test_adamw_kernel_matches_hf_formula():
     from oracle import optim_ref as O
     L = _lib.lib()
