@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
                                                            const T* __restrict__ dctx, T* __restrict__ dqkv,
                                                            float* __restrict__ dbias,
                                                            const float* __restrict__ head_scale, int L, int nh, DropKey drop,
-                                                           unsigned long long* __restrict__ trace) {
+                                                           unsigned long long* __restrict__ trace, GradAcc acc) {
     // MB_ATTN_TRACE=1: phase stamps of every block (100 MHz wall clock): 0 entry, 1 operands staged, 2 query sweep done,
     // 3 dQ bias flushed, 4 key sweep done, 5 exit
     auto stamp = [&](int k) { if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * 8 + k] = wall_clock64(); };
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) t += csw[(which * NW + w) * 64 + col];
-            atomicAdd(dbias + (size_t)which * H + h * 64 + col, t);
+            grad_add(acc, dbias + (size_t)which * H + h * 64 + col, t);
         }
     };
     __syncthreads();
@@ -386,9 +386,9 @@ static int launch_fwd(const void* qkv, const int64_t* mask, void* ctx, float* pr
 }
 template <class T, int LP, int NW>
 static int launch_bwd(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, float* dbias, const float* hsc, int B,
-                      int L, int nh, DropKey drop, hipStream_t st) {
+                      int L, int nh, DropKey drop, hipStream_t st, GradAcc acc) {
     hipLaunchKernelGGL((attn_bwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, mask,
-                       (const T*)dctx, (T*)dqkv, dbias, hsc, L, nh, drop, attn_trace_buffer(B * nh));
+                       (const T*)dctx, (T*)dqkv, dbias, hsc, L, nh, drop, attn_trace_buffer(B * nh), acc);
     return (int)hipGetLastError();
 }
 
@@ -415,23 +415,23 @@ int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx
 }
 
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx, void* dqkv,
-                       float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale) {
+                       float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale, GradAcc acc) {
     (void)ctx;   // D_i is recomputed as sum_j dP_ij P_ij, the forward output is not needed
     if (L < 1 || L > 128) return MB_ERR_SHAPE;
     const int LP = (L + 31) / 32 * 32;
     if (dtype == DT_BF16) {
         switch (LP) {
-            case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
-            case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
-            case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
-            default: return launch_bwd<bf16, 128, 8>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);   // 8 waves: all eight strips of a sweep at once
+            case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
+            case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
+            case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
+            default: return launch_bwd<bf16, 128, 8>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);   // 8 waves: all eight strips of a sweep at once
         }
     } else if (dtype == DT_F32) {
         switch (LP) {
-            case 32: return launch_bwd<float, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
-            case 64: return launch_bwd<float, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
-            case 96: return launch_bwd<float, 96, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);
-            default: return launch_bwd<float, 128, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st);   // 2 waves: LDS budget
+            case 32: return launch_bwd<float, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
+            case 64: return launch_bwd<float, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
+            case 96: return launch_bwd<float, 96, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
+            default: return launch_bwd<float, 128, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);   // 2 waves: LDS budget
         }
     }
     return MB_ERR_DTYPE;

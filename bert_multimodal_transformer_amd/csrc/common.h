@@ -62,6 +62,22 @@ __device__ __forceinline__ float drop_mult(const DropKey& d, uint32_t idx) {
     return hash32(idx, d.k0, d.k1) < d.thresh ? 0.0f : d.scale;
 }
 
+// ---------------------------------------------------------------- gradient accumulation across workgroups
+// Default: fp32 atomics -- the order in which the workgroups arrive is not reproducible, and one differently rounded sum can flip a
+// bf16 rounding of the weight shadow.  Deterministic mode (MB_DETERMINISTIC=1): the same adds go, as 2^44-scaled 64-bit
+// integers, into a shadow accumulator parallel to the gradient buffer; integer addition is associative, so any arrival order gives
+// the same bits, and one conversion pass folds the shadow into the fp32 gradients before they are read (grad_fold).  Range +-5e5,
+// resolution 5.7e-14 per addend.
+struct GradAcc {
+    long long* shadow;       // [n] parallel to base, or null = plain fp32 atomics
+    const float* base;       // first element of the gradient buffer the shadow mirrors
+};
+constexpr float kGradFix = 17592186044416.0f;       // 2^44
+__device__ __forceinline__ void grad_add(const GradAcc& a, float* dst, float v) {
+    if (a.shadow) atomicAdd((unsigned long long*)(a.shadow + (dst - a.base)), (unsigned long long)__float2ll_rn(v * kGradFix));
+    else atomicAdd(dst, v);
+}
+
 // ---------------------------------------------------------------- reductions
 // Sum over the 64 lanes, returned in every lane.  DPP adds (plain VALU): an inclusive scan inside each 16-lane row (row_shr
 // 1, 2, 4, 8), the row totals chained with row_bcast15 / row_bcast31, the grand total read from lane 63 -- seven instructions

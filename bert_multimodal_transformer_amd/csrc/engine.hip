@@ -160,6 +160,10 @@ static void build_layout(mb_bert_engine* e) {
     e->lnp_stride = ln_partials_floats((int)T, (int)H);
     e->ws_lnp_a = w.take(e->lnp_stride * 4 * c.num_layers); e->ws_lnp_b = w.take(e->lnp_stride * 4 * c.num_layers);
     e->carve_step(w, T, (int)V, (int)A, c.max_batch, c.num_labels, SITE_LAYER0 + 4 * c.num_layers);
+    if (e->deterministic) {          // shadow accumulator of everything behind the layers' GEMM weights (those have ONE writer per element)
+        e->det_begin = e->wp; e->det_end = e->n_params;
+        e->ws_det = w.take((e->det_end - e->det_begin) * sizeof(long long));
+    }
     e->ws_bytes = w.off;
 }
 
@@ -354,6 +358,7 @@ int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
     if (const char* v = getenv("MB_GROUP_WGRAD")) e->group_wgrad = atoi(v);
     if (const char* v = getenv("MB_WGRAD_OVERWRITE")) e->ow_enable = atoi(v);
     if (const char* v = getenv("MB_ADAMW_KEEP")) e->keep_enable = atoi(v);
+    if (const char* v = getenv("MB_DETERMINISTIC")) e->deterministic = atoi(v);
     e->grouped = (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->hidden_size % e->group_wgrad == 0 &&
                  cfg->intermediate_size % e->group_wgrad == 0;
     e->deferred = e->overlap_wgrad && e->grouped;
@@ -484,16 +489,17 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
     float* P = e->P; float* G = e->G;
     char* ws = e->ws;
     const bool hd = e->training && c.hidden_dropout > 0.f;
+    const GradAcc acc = e->acc_of(ws, G);          // deterministic mode: where the multi-writer column sums go
     for (int stage = stage_begin; stage < stage_end; ++stage) {
         if (stage == 0) {
             // ---- head + pooler
             CK(head_backward(dt, dlogits, e->logits, labels, loss_scale, (const float*)(ws + e->ws_head_pooled), P + e->wc,
                              ws + e->ws_dz, G + e->wc, G + e->bc, B, H, c.num_labels, e->key(SITE_HEAD, c.hidden_dropout),
-                             st));
+                             st, acc));
             const char* xf = ws + e->ws_x[NL];
             CK(gemm(dt, GEMM_TN, EPI_ACCUM_F32, H, H, B, ws + e->ws_dz, H, xf, L * H, nullptr, H, nullptr, G + e->wp, nullptr,
                     nullptr, 0, kNoDrop, 1, 64, st));
-            CK(colsum(dt, ws + e->ws_dz, H, G + e->bp, B, H, st));
+            CK(colsum(dt, ws + e->ws_dz, H, G + e->bp, B, H, st, acc));
             CK(zero_fill(ws + e->ws_dxa, (size_t)T * H * esize(dt), st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, B, H, H, ws + e->ws_dz, H, e->W(e->wp), H, ws + e->ws_dxa, L * H, nullptr,
                     nullptr, nullptr, nullptr, 0, kNoDrop, 1, 64, st));
@@ -549,7 +555,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             }
             // du = (dzd . W2) * gelu'(u), with the intermediate bias gradient (column sums of du) fused into the epilogue
             CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, du, I, nullptr, G + o.b1, nullptr,
-                    ws + w.u, I, kNoDrop, 1, 0, st));
+                    ws + w.u, I, kNoDrop, 1, 0, st, 0, 0, acc));
             if (!grouped) {
             CK(fork(1));
             CK(wgrad(dt, I, H, Tk, du, I, ws + w.y1, H, G + o.w1, H, ss));
@@ -566,7 +572,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             e->lnp_nblk = nblk;
             if (!defer_ln) {
                 float* const dst6[6] = {G + o.ln2w, G + o.ln2b, G + o.b2, G + o.ln1w, G + o.ln1b, G + o.bo};
-                CK(ln_reduce_partials(lnp_a, lnp_b, nblk, H, dst6, st));
+                CK(ln_reduce_partials(lnp_a, lnp_b, nblk, H, dst6, st, acc));
             } else if (l == 0) {
                 LnReduceDst dst = {};
                 for (int k = 0; k < NL; ++k) {
@@ -575,14 +581,14 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                     for (int q = 0; q < 6; ++q) dst.d[k][q] = d6[q];
                 }
                 CK(ln_reduce_partials_layers((const float*)(ws + e->ws_lnp_a), (const float*)(ws + e->ws_lnp_b), e->lnp_stride, NL, nblk, H,
-                                             dst, st));
+                                             dst, st, acc));
             }
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.wo), H, ws + e->ws_dctx, H, nullptr, nullptr, nullptr,
                     nullptr, 0, kNoDrop, 1, 0, st));
             // attention backward; the fused-QKV bias gradient (column sums of dqkv) is accumulated inside the kernel
             CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, dqkv, G + o.bqkv, B, L, nh,
                                   e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st,
-                                  e->head_mask ? e->head_mask + (size_t)l * nh : nullptr));
+                                  e->head_mask ? e->head_mask + (size_t)l * nh : nullptr, acc));
             auto launch_group = [&]() -> int {
                 if (inl) {
                     if (e->prof) CK((int)hipEventRecord(e->pev[2 * l], st));
@@ -620,11 +626,13 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                             P + e->mag_lnw, c.beta_shift, e->key(SITE_MAG, c.mag_dropout), ws + e->ws_mag, e->mw, de, nullptr,
                             nullptr, G + e->mag_whv, G + e->mag_bhv, G + e->mag_wha, G + e->mag_bha, G + e->mag_wv,
                             G + e->mag_bv, G + e->mag_wa, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb, T, H, c.visual_dim,
-                            c.acoustic_dim, true, st));
+                            c.acoustic_dim, true, st, acc));
             CK(embed_ln_backward(dt, de, e->ids, e->seg, e->ids ? P + e->word : e->emb_in, P + e->pos, P + e->type, P + e->emb_lnw,
                                  (const float*)(ws + e->ws_emb_st), (const float*)(ws + e->ws_emb_st) + T,
                                  (float*)(ws + e->ws_dsum), e->ids ? G + e->word : nullptr, G + e->pos, G + e->type, G + e->emb_lnw,
-                                 G + e->emb_lnb, B, L, H, c.pad_token_id, e->key(SITE_EMB, c.hidden_dropout), st, e->pos_ids));
+                                 G + e->emb_lnb, B, L, H, c.pad_token_id, e->key(SITE_EMB, c.hidden_dropout), st, e->pos_ids, acc));
+            // deterministic mode: the integer sums become part of the fp32 gradients before anybody (AdamW, an exchange) reads them
+            CK(grad_fold(acc, G, e->det_begin, e->det_end, st));
         }
     }
     return MB_OK;
@@ -829,7 +837,7 @@ int mb_bert_backward_outputs(mb_bert_engine* e, const void* d_sequence_output, c
         const char* xf = ws + e->ws_x[NL];
         CK(gemm(dt, GEMM_TN, EPI_ACCUM_F32, H, H, B, d_pooler_preact, H, xf, L * H, nullptr, H, nullptr, e->G + e->wp, nullptr, nullptr, 0,
                 kNoDrop, 1, 64, st));
-        CK(colsum(dt, d_pooler_preact, H, e->G + e->bp, B, H, st));
+        CK(colsum(dt, d_pooler_preact, H, e->G + e->bp, B, H, st, e->acc_of(ws, e->G)));
         CK(gemm(dt, GEMM_NN, EPI_ADD_RES, B, H, H, d_pooler_preact, H, e->W(e->wp), H, ws + e->ws_dxa, L * H, nullptr, nullptr, nullptr,
                 ws + e->ws_dxa, L * H, kNoDrop, 1, 64, st));
     }

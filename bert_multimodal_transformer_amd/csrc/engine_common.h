@@ -88,8 +88,9 @@ struct MagWs {
 
 inline int gemm(int dtype, int layout, int mode, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
          int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, DropKey drop, int splits, int tile,
-         hipStream_t st, int bseg = 0, size_t bseg_stride = 0) {
+         hipStream_t st, int bseg = 0, size_t bseg_stride = 0, GradAcc acc = {}) {
     GemmArgs a = {};
+    a.acc = acc;
     a.bseg = bseg; a.bseg_stride = bseg_stride;        // segmented B (kernels.h): pieces of B's contiguous dimension in separate tensors
     a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
     a.C = C; a.ldc = ldc; a.C2 = C2; a.Cf = Cf; a.bias = bias; a.R = R; a.ldr = ldr; a.alpha = 1.0f; a.drop = drop;
@@ -161,6 +162,15 @@ struct StepMixin {
     // "logically zero, physically stale" (grads_stale, [stale_begin, stale_end)).  Whoever else is about to look at it gets real
     // zeros first: a backward that accumulates (begin_backward_pass / train_step_impl), mb_*_materialize_grads (called by the
     // Python mirror before optimizer.step(), flat_grads, mark_grads_zero(False)).  MB_ADAMW_KEEP=0 turns it off.
+    // deterministic mode (MB_DETERMINISTIC=1, common.h GradAcc): multi-writer gradient sums go to a 64-bit fixed-point shadow of
+    // G[det_begin, n) in the workspace and are folded into the fp32 gradients at the end of the backward
+    int deterministic = 0;
+    size_t ws_det = 0, det_begin = 0, det_end = 0;
+    GradAcc acc_of(char* ws, const float* G) const {
+        GradAcc a = {nullptr, nullptr};
+        if (deterministic && ws && G) { a.shadow = (long long*)(ws + ws_det) - det_begin; a.base = G; }
+        return a;
+    }
     bool grads_stale = false, ow_covers = false;       // ow_covers: the overwriting (grouped) launch covers [stale_begin, stale_end)
     size_t stale_begin = 0, stale_end = 0;
     int keep_enable = 1;
@@ -389,7 +399,7 @@ inline int mag_bwd_impl(int dtype, const void* d_out, const void* text, const fl
                  const float* b_a, const float* ln_w, float beta_shift, DropKey drop, char* ws, const MagWs& w, void* d_text,
                  float* d_visual, float* d_acoustic, float* dW_hv, float* db_hv, float* dW_ha, float* db_ha, float* dW_v,
                  float* db_v, float* dW_a, float* db_a, float* dln_w, float* dln_b, int T, int H, int V, int A,
-                 bool text_padded, hipStream_t st) {
+                 bool text_padded, hipStream_t st, GradAcc acc = {}) {
     MagDims d = {T, H, V, A, w.Vp, w.Ap};
     const int Tp = (int)align_up((size_t)T, 64);      // zero-padded token rows of the workspace operands
     const size_t es = esize(dtype);
@@ -408,7 +418,7 @@ inline int mag_bwd_impl(int dtype, const void* d_out, const void* text, const fl
     }
     CK(mag_gate_backward(dtype, d_out, text, ws + w.Ze, ws + w.Zv, ws + w.Za, b_hv, b_ha, b_v, b_a, ln_w,
                          (const float*)(ws + w.mean), (const float*)(ws + w.rstd), beta_shift, ws + w.dep, ws + w.dZe,
-                         ws + w.dZv, ws + w.dZa, db_hv, db_ha, db_v, db_a, dln_w, dln_b, d, drop, st));
+                         ws + w.dZv, ws + w.dZa, db_hv, db_ha, db_v, db_a, dln_w, dln_b, d, drop, st, acc));
     {
         // the three packed weight gradients as ONE grouped launch (like a layer's four): alone, the two modality problems are
         // 24 / 48 tiles whose duration is the K = T loop latency (three launches of ~34 us each)

@@ -315,7 +315,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
             if (tid < BN && n0 + tid < p.N) {
                 float t = (red[tid] + red[BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]);
                 if constexpr (NW == 8) t += (red[4 * BN + tid] + red[5 * BN + tid]) + (red[6 * BN + tid] + red[7 * BN + tid]);
-                atomicAdd(p.colsum + n0 + tid, t);
+                grad_add(p.acc, p.colsum + n0 + tid, t);
             }
         }
     }

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ labels, float loss_scale,
                                                        const float* __restrict__ pooled, const float* __restrict__ Wc,
                                                        T* __restrict__ dz, float* dWc, float* dbc, int B, int nl,
-                                                       DropKey drop) {
+                                                       DropKey drop, GradAcc acc) {
     drop.resolve();
     constexpr int H = CH * 256;
     __shared__ float wsum[4][H];
@@ -125,8 +125,8 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__
             __syncthreads();
             if (dWc)
                 for (int col = threadIdx.x; col < H; col += 256)
-                    atomicAdd(dWc + (size_t)k * H + col, (wsum[0][col] + wsum[1][col]) + (wsum[2][col] + wsum[3][col]));
-            if (dbc && threadIdx.x == 0) atomicAdd(dbc + k, (bsum[0] + bsum[1]) + (bsum[2] + bsum[3]));
+                    grad_add(acc, dWc + (size_t)k * H + col, (wsum[0][col] + wsum[1][col]) + (wsum[2][col] + wsum[3][col]));
+            if (dbc && threadIdx.x == 0) grad_add(acc, dbc + k, (bsum[0] + bsum[1]) + (bsum[2] + bsum[3]));
             __syncthreads();
         }
     }
@@ -150,16 +150,16 @@ int head_forward(const float* z, const float* Wc, const float* bc, const float* 
 
 int head_backward(int dtype, const float* dlogits, const float* logits, const float* labels, float loss_scale,
                   const float* pooled, const float* Wc, void* dz, float* dWc, float* dbc, int B, int H, int nl,
-                  DropKey drop, hipStream_t st) {
+                  DropKey drop, hipStream_t st, GradAcc acc) {
     if (H != 768) return MB_ERR_SHAPE;
     if (B <= 0) return MB_OK;
     if (!dlogits && !(logits && labels)) return MB_ERR_ARG;
     if (dtype == DT_BF16)
         hipLaunchKernelGGL((head_bwd_kernel<bf16, 3>), dim3((B + 3) / 4), dim3(256), 0, st, dlogits, logits, labels,
-                           loss_scale, pooled, Wc, (bf16*)dz, dWc, dbc, B, nl, drop);
+                           loss_scale, pooled, Wc, (bf16*)dz, dWc, dbc, B, nl, drop, acc);
     else if (dtype == DT_F32)
         hipLaunchKernelGGL((head_bwd_kernel<float, 3>), dim3((B + 3) / 4), dim3(256), 0, st, dlogits, logits, labels,
-                           loss_scale, pooled, Wc, (float*)dz, dWc, dbc, B, nl, drop);
+                           loss_scale, pooled, Wc, (float*)dz, dWc, dbc, B, nl, drop, acc);
     else return MB_ERR_DTYPE;
     return (int)hipGetLastError();
 }

@@ -52,6 +52,7 @@ struct GemmArgs {
     // next to each other in the flat parameter buffer -- run as ONE forward GEMM (N = 2304) and ONE dgrad (K = 2304) instead of
     // three each.  bseg must be a multiple of the tile (k-major) / of the k-stage (row-major); no split-K.
     int bseg; size_t bseg_stride;
+    GradAcc acc;                      // where colsum goes in deterministic mode (common.h); {} = fp32 atomics
 };
 // copies the stamps of the last traced launch to the host (measurement tooling: tools/gemm_bench --trace); returns the block count
 int gemm_trace_fetch(unsigned long long* host_out, int max_blocks);
@@ -82,19 +83,21 @@ int ln_forward(int dtype, const void* x, const float* gamma, const float* beta, 
 int ln_backward(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                 void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias,
                 int rows, int H, DropKey drop_out, DropKey drop_in, hipStream_t st);
+// folds a deterministic-mode shadow accumulator into the fp32 gradients g[begin, end) and clears it (common.h GradAcc)
+int grad_fold(GradAcc acc, float* g, size_t begin, size_t end, hipStream_t st);
 // same, but the three column sums go to per-block partial slabs partials[nblk][3][H] (no atomics); returns nblk through
 // *nblk.  ln_reduce_partials adds them into up to 6 destinations in one launch (two LayerNorms of a layer).
 size_t ln_partials_floats(int rows, int H);
 int ln_backward_partials(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                          void* dx, void* dx_drop, float* partials, int* nblk, int rows, int H, DropKey drop_in, hipStream_t st);
-int ln_reduce_partials(const float* partials_a, const float* partials_b, int nblk, int H, float* const* dst6, hipStream_t st);
+int ln_reduce_partials(const float* partials_a, const float* partials_b, int nblk, int H, float* const* dst6, hipStream_t st, GradAcc acc = {});
 // The same for `layers` layers in ONE launch: layer l's slabs start at partials_x + l * layer_stride floats, its six destinations
 // are dst[l][0..5].  (A single-process step has no use for a layer's LayerNorm / bias gradients before AdamW: twelve 5-us
 // launches become one.)
 #define MB_LN_MAX_LAYERS 32
 struct LnReduceDst { float* d[MB_LN_MAX_LAYERS][6]; };
 int ln_reduce_partials_layers(const float* partials_a, const float* partials_b, size_t layer_stride, int layers, int nblk, int H,
-                              const LnReduceDst& dst, hipStream_t st);
+                              const LnReduceDst& dst, hipStream_t st, GradAcc acc = {});
 
 // BertEmbeddings: e = dropout(LN(word[ids] + pos[l] + type[seg])).
 int embed_ln_forward(int dtype, const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
@@ -104,10 +107,10 @@ int embed_ln_forward(int dtype, const int64_t* ids, const int64_t* seg, const fl
 int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int64_t* seg, const float* word,
                       const float* pos, const float* type, const float* gamma, const float* mean, const float* rstd,
                       float* dsum_ws, float* dword, float* dpos, float* dtype_, float* dgamma, float* dbeta,
-                      int B, int L, int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids = nullptr);
+                      int B, int L, int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids = nullptr, GradAcc acc = {});
 
 // column sums: out[n] += sum_m x[m][n]
-int colsum(int dtype, const void* x, int ldx, float* out, int rows, int cols, hipStream_t st);
+int colsum(int dtype, const void* x, int ldx, float* out, int rows, int cols, hipStream_t st, GradAcc acc = {});
 
 // fp32 [rows][cols] -> T [rows][cols_pad] zero padded (modality tensors -> MFMA operands)
 int pack_pad(int dtype, const float* src, int cols, void* dst, int cols_pad, int rows, hipStream_t st);
@@ -134,7 +137,7 @@ int mag_gate_backward(int dtype, const void* dout, const void* e, const void* Ze
                       const float* gamma, const float* mean, const float* rstd, float beta_shift,
                       void* de, void* dZe, void* dZv, void* dZa,
                       float* db_hv, float* db_ha, float* db_v, float* db_a, float* dgamma, float* dbeta,
-                      MagDims d, DropKey drop, hipStream_t st);
+                      MagDims d, DropKey drop, hipStream_t st, GradAcc acc = {});
 
 // ------------------------------------------------------------------------------------------ attention (attention.hip)
 // qkv: [B*L][3H] token-major (q | k | v, head h at columns h*64..), mask: int64 [B][L] (1 = attend),
@@ -146,7 +149,7 @@ int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx
 // dbias (fp32 [3H], may be null): += column sums of dqkv (bias grads of the fused QKV Linear)
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx,
                        void* dqkv, float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st,
-                       const float* head_scale = nullptr);
+                       const float* head_scale = nullptr, GradAcc acc = {});
 int attention_trace_fetch(unsigned long long* host_out, int max_blocks);     // MB_ATTN_TRACE=1: stamps of the last attention_backward
 
 // ------------------------------------------------------------------------------------------ XLNet (xlnet_attention.hip, xlnet_rowops.hip)
@@ -180,7 +183,7 @@ int head_forward(const float* z, const float* Wc, const float* bc, const float* 
 // dWc, dbc accumulated.  dz is written in the activation dtype (operand of the pooler dgrad / wgrad GEMMs).
 int head_backward(int dtype, const float* dlogits, const float* logits, const float* labels, float loss_scale,
                   const float* pooled, const float* Wc, void* dz, float* dWc, float* dbc,
-                  int B, int H, int nl, DropKey drop, hipStream_t st);
+                  int B, int H, int nl, DropKey drop, hipStream_t st, GradAcc acc = {});
 
 // ------------------------------------------------------------------------------------------ optimizer (adamw.hip)
 // transformers 3.0.2 AdamW over flat fp32 buffers; elements [0, n_decay) use weight_decay, the rest 0.

@@ -8,6 +8,7 @@
 // Layout: one 64-lane wave owns one row of H = CH*256 elements; lane l holds CH chunks of 4 consecutive
 // elements at columns (c*64 + l)*4  -> every global access is a coalesced 8/16-byte vector.
 // Algorithmic HBM bytes per token are listed per kernel in DESIGN.md.
+#include <algorithm>
 #include "kernels.h"
 
 namespace mb {
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
 
 // shared tail of the backward kernels: reduce per-lane column partials over the block's 4 waves, then atomics.
 template <int CH, int NQ>
-__device__ __forceinline__ void block_colsum_atomic(f32x4 (&part)[NQ][CH], float* const (&dst)[NQ], float* lds) {
+__device__ __forceinline__ void block_colsum_atomic(f32x4 (&part)[NQ][CH], float* const (&dst)[NQ], float* lds, GradAcc acc = {nullptr, nullptr}) {
     constexpr int H = CH * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -75,7 +76,7 @@ __device__ __forceinline__ void block_colsum_atomic(f32x4 (&part)[NQ][CH], float
         if (dst[q] == nullptr) continue;
         const float s = lds[(0 * NQ + q) * H + col] + lds[(1 * NQ + q) * H + col] + lds[(2 * NQ + q) * H + col] +
                         lds[(3 * NQ + q) * H + col];
-        atomicAdd(dst[q] + col, s);
+        grad_add(acc, dst[q] + col, s);
     }
 }
 
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, c
 // column per block at the end (8-way contention).
 __global__ void __launch_bounds__(256) ln_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int nblk,
                                                         int H, float* d0, float* d1, float* d2, float* d3, float* d4,
-                                                        float* d5) {
+                                                        float* d5, GradAcc acc) {
     const int q = blockIdx.y;
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = (threadIdx.x >> 6) + 4 * blockIdx.z;    // 0 .. 4*gridDim.z-1
@@ -180,12 +181,12 @@ __global__ void __launch_bounds__(256) ln_reduce_kernel(const float* __restrict_
     red[threadIdx.x >> 6][threadIdx.x & 63] = s;
     __syncthreads();
     if ((threadIdx.x >> 6) == 0 && dst != nullptr && src != nullptr && col < H)
-        atomicAdd(dst + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+        grad_add(acc, dst + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // all layers at once: blockIdx.z = layer * 8 + slab octant
 __global__ void __launch_bounds__(256) ln_reduce_layers_kernel(const float* __restrict__ pa, const float* __restrict__ pb,
-                                                               size_t layer_stride, int nblk, int H, LnReduceDst dst) {
+                                                               size_t layer_stride, int nblk, int H, LnReduceDst dst, GradAcc acc) {
     const int q = blockIdx.y;
     const int layer = blockIdx.z >> 3;
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(256) ln_reduce_layers_kernel(const float* __re
     red[threadIdx.x >> 6][threadIdx.x & 63] = s;
     __syncthreads();
     if ((threadIdx.x >> 6) == 0 && out != nullptr && col < H)
-        atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+        grad_add(acc, out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------ embeddings
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, float* __restrict__ dsum_ws,
                                                         float* dword, float* dgamma, float* dbeta, int rows, int L,
-                                                        int pad_id, DropKey drop, const int64_t* __restrict__ pos_ids) {
+                                                        int pad_id, DropKey drop, const int64_t* __restrict__ pos_ids, GradAcc acc) {
     drop.resolve();
     constexpr int H = CH * 256;
     constexpr float invH = 1.0f / H;
@@ -293,20 +294,20 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
             // dword == nullptr (inputs_embeds): the gradient of the given embeddings is dsum_ws itself
             if (dword != nullptr && (int)id != pad_id) {      // nn.Embedding(padding_idx=pad_token_id): no gradient for the pad row
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(dword + id * H + col + r, d[r]);
+                for (int r = 0; r < 4; ++r) grad_add(acc, dword + id * H + col + r, d[r]);
             }
             part[0][c] += dyv[c] * xh[c];
             part[1][c] += dyv[c];
         }
     }
     float* const dst[2] = {dgamma, dbeta};
-    block_colsum_atomic<CH, 2>(part, dst, lds);
+    block_colsum_atomic<CH, 2>(part, dst, lds, acc);
 }
 
 // position / token-type table grads: block (l, c) sums 256 columns of dsum over the batch (sole owner of that piece of dpos[l]).
 __global__ void __launch_bounds__(256) embed_pos_type_kernel(const float* __restrict__ dsum_ws, const int64_t* __restrict__ seg,
                                                              float* dpos, float* dtype_, int B, int L, int H,
-                                                             const int64_t* __restrict__ pos_ids) {
+                                                             const int64_t* __restrict__ pos_ids, GradAcc acc) {
     const int l = blockIdx.x;
     {
         const int col = blockIdx.y * 256 + threadIdx.x;
@@ -327,23 +328,23 @@ __global__ void __launch_bounds__(256) embed_pos_type_kernel(const float* __rest
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                if (pp[u] >= 0) atomicAdd(dpos + (size_t)pp[u] * H + col, d[u]);      // explicit position_ids: rows of other blocks too
+                if (pp[u] >= 0) grad_add(acc, dpos + (size_t)pp[u] * H + col, d[u]);      // explicit position_ids: rows of other blocks too
                 else ap += d[u];
                 if (sg[u] == 0) a0 += d[u];
                 else if (sg[u] == 1) a1 += d[u];
-                else atomicAdd(dtype_ + (size_t)sg[u] * H + col, d[u]);
+                else grad_add(acc, dtype_ + (size_t)sg[u] * H + col, d[u]);
             }
         }
         if (!pos_ids) dpos[(size_t)l * H + col] += ap;
-        atomicAdd(dtype_ + col, a0);
-        atomicAdd(dtype_ + H + col, a1);
+        grad_add(acc, dtype_ + col, a0);
+        grad_add(acc, dtype_ + H + col, a1);
     }
 }
 
 // ------------------------------------------------------------------------------------------ column sum
 template <class T>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int ldx, float* out, int rows, int cols,
-                                                     int rows_per_block) {
+                                                     int rows_per_block, GradAcc gacc) {
     __shared__ f32x4 lds[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + lane) * 4;
@@ -356,7 +357,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, in
     if (wave == 0 && col < cols) {
         const f32x4 s = lds[0][lane] + lds[1][lane] + lds[2][lane] + lds[3][lane];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(out + col + r, s[r]);
+        for (int r = 0; r < 4; ++r) grad_add(gacc, out + col + r, s[r]);
     }
 }
 
@@ -433,18 +434,18 @@ int ln_backward_partials(int dtype, const void* dy, const void* x, const float* 
     return (int)hipGetLastError();
 }
 
-int ln_reduce_partials(const float* pa, const float* pb, int nblk, int H, float* const* d, hipStream_t st) {
+int ln_reduce_partials(const float* pa, const float* pb, int nblk, int H, float* const* d, hipStream_t st, GradAcc acc) {
     if (nblk <= 0) return MB_OK;
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((H + 63) / 64, 6, 8), dim3(256), 0, st, pa, pb, nblk, H, d[0], d[1], d[2], d[3], d[4],
-                       d[5]);
+                       d[5], acc);
     return (int)hipGetLastError();
 }
 
 int ln_reduce_partials_layers(const float* pa, const float* pb, size_t layer_stride, int layers, int nblk, int H,
-                              const LnReduceDst& dst, hipStream_t st) {
+                              const LnReduceDst& dst, hipStream_t st, GradAcc acc) {
     if (nblk <= 0 || layers <= 0) return MB_OK;
     if (layers > MB_LN_MAX_LAYERS) return MB_ERR_SHAPE;
-    hipLaunchKernelGGL(ln_reduce_layers_kernel, dim3((H + 63) / 64, 6, 8 * layers), dim3(256), 0, st, pa, pb, layer_stride, nblk, H, dst);
+    hipLaunchKernelGGL(ln_reduce_layers_kernel, dim3((H + 63) / 64, 6, 8 * layers), dim3(256), 0, st, pa, pb, layer_stride, nblk, H, dst, acc);
     return (int)hipGetLastError();
 }
 
@@ -463,20 +464,20 @@ int embed_ln_forward(int dtype, const int64_t* ids, const int64_t* seg, const fl
 int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int64_t* seg, const float* word,
                       const float* pos, const float* type, const float* gamma, const float* mean, const float* rstd,
                       float* dsum_ws, float* dword, float* dpos, float* dtype_, float* dgamma, float* dbeta, int B, int L,
-                      int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids) {
+                      int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids, GradAcc acc) {
     const int rows = B * L;
     if (rows <= 0) return MB_OK;
     constexpr int RPW = 4;
     MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
         hipLaunchKernelGGL((embed_bwd_kernel<T, CH, RPW>), dim3((rows + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st,
                            (const T*)dout, ids, seg, word, pos, type, gamma, mean, rstd, dsum_ws, dword, dgamma, dbeta,
-                           rows, L, pad_id, drop, pos_ids);
+                           rows, L, pad_id, drop, pos_ids, acc);
     }))
-    hipLaunchKernelGGL(embed_pos_type_kernel, dim3(L, (H + 255) / 256), dim3(256), 0, st, dsum_ws, seg, dpos, dtype_, B, L, H, pos_ids);
+    hipLaunchKernelGGL(embed_pos_type_kernel, dim3(L, (H + 255) / 256), dim3(256), 0, st, dsum_ws, seg, dpos, dtype_, B, L, H, pos_ids, acc);
     return (int)hipGetLastError();
 }
 
-int colsum(int dtype, const void* x, int ldx, float* out, int rows, int cols, hipStream_t st) {
+int colsum(int dtype, const void* x, int ldx, float* out, int rows, int cols, hipStream_t st, GradAcc acc) {
     if (rows <= 0 || cols <= 0) return MB_OK;
     if (cols % 4) return MB_ERR_SHAPE;
     const int cblocks = (cols + 255) / 256;
@@ -487,7 +488,7 @@ int colsum(int dtype, const void* x, int ldx, float* out, int rows, int cols, hi
     rblocks = (rows + rpb - 1) / rpb;
     MB_DISPATCH_T(dtype, {
         hipLaunchKernelGGL((colsum_kernel<T>), dim3(cblocks, rblocks), dim3(256), 0, st, (const T*)x, ldx, out, rows,
-                           cols, rpb);
+                           cols, rpb, acc);
     })
     return (int)hipGetLastError();
 }
@@ -613,6 +614,25 @@ int step_prologue(const PrologueArgs& a, hipStream_t st) {
     if (grid < 1) grid = 1;
     if (grid > 512) grid = 512;
     hipLaunchKernelGGL(step_prologue_kernel, dim3(grid), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------ deterministic mode: shadow -> gradients
+__global__ void __launch_bounds__(256) grad_fold_kernel(long long* __restrict__ shadow, float* __restrict__ g, size_t begin, size_t end) {
+    for (size_t i = begin + (size_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (size_t)gridDim.x * 256) {
+        const long long v = shadow[i];
+        if (v != 0) {
+            g[i] += (float)((double)v * (1.0 / (double)kGradFix));
+            shadow[i] = 0;
+        }
+    }
+}
+int grad_fold(GradAcc acc, float* g, size_t begin, size_t end, hipStream_t st) {
+    if (!acc.shadow || end <= begin) return MB_OK;
+    if (g != acc.base) return MB_ERR_ARG;
+    const size_t n = end - begin;
+    hipLaunchKernelGGL(grad_fold_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, acc.shadow, g, begin, end);
     return (int)hipGetLastError();
 }
 

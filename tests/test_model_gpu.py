@@ -588,11 +588,22 @@ def _trajectory(cdt, mode, nsteps=4, accum=1, layers=3, shapes=((5, 40), (5, 40)
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
-def test_step_graph_equals_launch_by_launch(cdt):
+def test_step_graph_equals_launch_by_launch(cdt, monkeypatch):
     """mb_bert_train_step: the replayed whole-step hipGraph (dropout keys, lr and bias correction read from device memory,
-    batch gathered by the step prologue, side-stream fork / join captured) ends every step exactly where the kernels launched
-    one by one end it: same dropout masks, same losses, same parameters / Adam moments / bf16 shadow, gradients cleared.
-    Shapes change inside the run (a second graph is captured and the first one is replayed again afterwards)."""
+    batch gathered by the step prologue) ends every step exactly where the kernels launched one by one end it: same dropout
+    masks, same losses, same parameters / Adam moments / bf16 shadow, gradients cleared.  Shapes change inside the run (a second
+    graph is captured and the first one is replayed again afterwards).  bf16 runs in deterministic mode (MB_DETERMINISTIC=1), where
+    "the same" is bit for bit (in the default mode the fp32-atomics noise of the column sums makes bf16 trajectories bimodal)."""
+    if cdt == torch.bfloat16:
+        monkeypatch.setenv("MB_DETERMINISTIC", "1")
+        ref, eager, graph = _trajectory(cdt, False), _trajectory(cdt, 2), _trajectory(cdt, True)
+        assert graph["stats"][0] == 2 and graph["stats"][1] == 4
+        for name, run in (("prologue+eager", eager), ("graph", graph)):
+            for k in ("p", "m", "v", "shadow", "logits"):
+                assert torch.equal(run[k], ref[k]), "%s: %s differs from the launch-by-launch run" % (name, k)
+            assert float(run["g"].abs().max()) == 0.0
+            assert float((run["losses"] - ref["losses"]).abs().max()) <= 2e-3        # (the loss scalar itself is summed by fp32 atomics)
+        return
     ref = _trajectory(cdt, False)
     ref2 = _trajectory(cdt, False)
     noise = float((ref["p"] - ref2["p"]).abs().max())                  # fp32 atomics: run-to-run noise of the plain path
@@ -637,6 +648,32 @@ def test_step_graph_gradient_accumulation_and_replay_stability():
         worst = max(worst, float((run["p"] - ref["p"]).abs().max()))
     print("graph with accumulation: worst |dparam| over 30 trajectories %.3e (plain run-to-run %.3e)" % (worst, noise))
     assert worst <= 1e-5 + 10 * noise
+
+
+def test_deterministic_mode_bf16_runs_are_bit_identical(monkeypatch):
+    """MB_DETERMINISTIC=1 ("two runs bit-identical with the same seed" stands in for the sanitizers the
+    reference does not have): every multi-writer gradient sum of the MAG-BERT step (bias / LayerNorm / embedding / classifier
+    column sums, otherwise fp32 atomics in arrival order) goes through 64-bit fixed-point accumulators, so bf16 trajectories --
+    where one differently rounded sum flips a weight-shadow rounding and Adam amplifies it -- repeat bit for bit: parameters,
+    Adam moments, bf16 shadow, through graph replays, accumulation micro-steps and the Python-driven passes.  And the mode
+    changes nothing beyond rounding: it stays within the default mode's own run-to-run spread of the fp32 trajectory."""
+    monkeypatch.setenv("MB_DETERMINISTIC", "1")
+    shapes = ((48, 50), (48, 50), (33, 50), (48, 50))          # the benchmark shape and the epoch's ragged last batch
+    runs = [_trajectory(torch.bfloat16, True, nsteps=6, accum=1, layers=3, shapes=shapes) for _ in range(3)]
+    for r in runs[1:]:
+        for k in ("p", "m", "v", "shadow"):
+            assert torch.equal(r[k], runs[0][k]), "deterministic mode: %s differs between two runs" % k
+        assert torch.equal(r["logits"], runs[0]["logits"])
+    acc = [_trajectory(torch.bfloat16, True, nsteps=4, accum=2, layers=2, shapes=((5, 40),)) for _ in range(2)]
+    assert torch.equal(acc[0]["p"], acc[1]["p"]) and torch.equal(acc[0]["shadow"], acc[1]["shadow"])
+    py = [_trajectory(torch.bfloat16, False, nsteps=3, accum=1, layers=2, shapes=((5, 40),)) for _ in range(2)]
+    assert torch.equal(py[0]["p"], py[1]["p"])
+    d32 = _trajectory(torch.float32, True, nsteps=3, accum=1, layers=2, shapes=((5, 40),))
+    monkeypatch.setenv("MB_DETERMINISTIC", "0")
+    ref = _trajectory(torch.float32, True, nsteps=3, accum=1, layers=2, shapes=((5, 40),))
+    err = float((d32["p"] - ref["p"]).abs().max())
+    print("deterministic vs default mode, fp32 parameters after 3 steps: max |diff| %.3e" % err)
+    assert err <= 1e-5
 
 
 def test_known_zero_gradients_are_stored_not_accumulated(monkeypatch):
