@@ -142,7 +142,8 @@ int mb_bert_bind(mb_bert_engine* e, float* params, float* grads, void* shadow, v
 /* refresh operand copies from the fp32 masters (bf16 shadow + packed MAG weights); call after loading weights. */
 int mb_bert_sync_weights(mb_bert_engine* e, void* stream);
 
-/* forward.  labels (fp32 [B*num_labels]) optional: fused MSE -> loss[0] (device, overwritten), loss_run += (optional).
+/* forward.  labels optional: num_labels == 1: fp32 [B] regression targets, fused MSE; num_labels > 1: fp32 [B] holding the class
+ * index of each sample, fused cross entropy (bert.py:318-320) -> loss[0] (device, overwritten), loss_run += (optional).
  * training != 0 enables dropout keyed by (seed, step).  logits: fp32 [B][num_labels] (device, written). */
 int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
                     const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,

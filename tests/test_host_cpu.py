@@ -349,3 +349,53 @@ def test_no_cpu_fallback():
     m = MAG(768, 1.0, 0.5)
     with pytest.raises(_lib.MagbertError):
         m(torch.zeros(1, 2, 768), torch.zeros(1, 2, 47), torch.zeros(1, 2, 74))
+
+
+def _innermost_mfma_loops(disassembly):
+    """(function, body lines) of every innermost backward-branch loop of the gfx950 disassembly that holds an MFMA."""
+    fn, fn_addr, insts, loops = None, 0, [], {}
+    for line in disassembly.split("\n"):
+        m = re.match(r"^([0-9a-f]{16}) <(\w+)>:", line)
+        if m:
+            fn, fn_addr = m.group(2), int(m.group(1), 16)
+            loops[fn] = ([], [])
+            continue
+        m = re.search(r"//\s*([0-9A-F]{12}):", line)
+        if not m or fn is None:
+            continue
+        addr = int(m.group(1), 16)
+        body, back = loops[fn]
+        body.append((addr, line))
+        t = re.search(r"s_c?branch\w*\s.*<\w+\+0x([0-9a-f]+)>", line)
+        if t and fn_addr + int(t.group(1), 16) <= addr:
+            back.append((fn_addr + int(t.group(1), 16), addr))
+    out = []
+    for fn, (body, back) in loops.items():
+        inner = [a for a in back if not any(b != a and b[0] >= a[0] and b[1] <= a[1] for b in back)]
+        for lo, hi in inner:
+            text = [l for a, l in body if lo <= a <= hi]
+            if any("v_mfma" in l for l in text):
+                out.append((fn, text))
+    return out
+
+
+def test_gemm_k_loops_hold_no_scalar_memory_reads(tmp_path):
+    """gemm.hip counts LDS reads with partial `s_waitcnt lgkmcnt(N)` inside its k loops (lds_wait<N>): only valid while no scalar
+    load (same counter, returns out of order) is in flight there.  Checked on the ISA of the object build() produced."""
+    import shutil
+    from bert_multimodal_transformer_amd import build as mb_build
+    mb_build.build(verbose=False)
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not in this image")
+    obj = shutil.copy(os.path.join(mb_build.LIBDIR, "obj", "gemm.o"), tmp_path / "gemm.o")
+    subprocess.run([objdump, "--offloading", str(obj)], check=True, capture_output=True, cwd=tmp_path)
+    dev = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(dev) == 1, os.listdir(tmp_path)
+    dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(tmp_path / dev[0])], check=True, capture_output=True,
+                         text=True).stdout
+    loops = _innermost_mfma_loops(dis)
+    assert len(loops) > 100, len(loops)                  # every instantiation of gemm2_kernel / gemm2_grouped_tn_kernel has some
+    bad = [(fn, [l.strip() for l in text if re.search(r"\bs_(buffer_)?load_|s_memtime|s_memrealtime", l)][:2])
+           for fn, text in loops if any(re.search(r"\bs_(buffer_)?load_|s_memtime|s_memrealtime", l) for l in text)]
+    assert not bad, bad[:4]
