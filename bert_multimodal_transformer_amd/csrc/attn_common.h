@@ -12,12 +12,19 @@ template <class T>
 __device__ __forceinline__ typename Frag<T>::type frag_nat(const char* img, int pitch, int row, int slab, int lane) {
     return *(const typename Frag<T>::type*)(img + row * pitch + slab * 64 + (lane >> 4) * 16);
 }
-// fragment of the TRANSPOSED image: element e = img[k0 + e][col]
+// fragment of the TRANSPOSED image: element e = img[k0 + e][col].  Callers pass the MFMA operand pattern -- col = c0 + (lane & 15)
+// with c0 a multiple of 16, k0 the same for the 16 lanes of a group, pitch and k0 * pitch multiples of 8 bytes -- which is what
+// gfx950's transpose read serves: the 16 lanes of a group name a 4-row x 16-column block (lane t: row t >> 2, four columns from
+// (t & 3) * 4) and each receives ITS column of the four rows.  Two ds_read_b64_tr_b16 per fragment instead of eight 2-byte
+// reads and their packing.  (No LDS-DMA in the attention kernels, so the builtin's implicit vmcnt wait -- gemm.hip -- is harmless.)
 __device__ __forceinline__ bf16x8 frag_kmaj(const char* img, int pitch, int k0, int col, bf16) {
-    bf16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = *(const bf16*)(img + (k0 + e) * pitch + col * 2);
-    return v;
+    typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+    const int t = col & 15;
+    const char* a = img + (k0 + (t >> 2)) * pitch + ((col - t) + (t & 3) * 4) * 2;
+    union { s16x4_t h[2]; bf16x8 v; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(__attribute__((address_space(3))) char*)a);
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(__attribute__((address_space(3))) char*)(a + 4 * pitch));
+    return u.v;
 }
 __device__ __forceinline__ f32x4 frag_kmaj(const char* img, int pitch, int k0, int col, float) {
     f32x4 v;

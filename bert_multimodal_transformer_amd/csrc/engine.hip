@@ -48,6 +48,10 @@ struct mb_bert_engine : StepMixin {
     std::vector<hipEvent_t> evs;      // 5 events per encoder stage (4 forks + 1 join), never reused within a backward
     int overlap_wgrad = 0;         // MB_OVERLAP_WGRAD=1: weight-gradient launches on the internal side stream (round-1 default; measured equal
                                    // to the in-line grouped launch, which keeps the step a single-stream sequence -- and its hipGraph a fast one)
+    // MB_ADAMW_OVERLAP=C: the single-call step forks the optimizer of every finished chunk of C layers onto this stream (enqueue_step)
+    int opt_chunk = 0;
+    hipStream_t opt_side = nullptr;
+    std::vector<hipEvent_t> opt_ev;
     int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128), 0 = four launches
     bool grouped = false;          // the layer's four weight gradients are ONE launch
     bool deferred = false;         // ... on the side stream, joined one stage later (MB_OVERLAP_WGRAD=0: on the caller's stream, in line)
@@ -158,7 +162,7 @@ static void build_layout(mb_bert_engine* e) {
     e->ws_dctx = w.take(T * H * es); e->ws_dsum = w.take(T * H * 4); e->ws_dz = w.take((size_t)c.max_batch * H * es);
     // LayerNorm partial slabs of EVERY layer (2 x 2.8 MB per layer at T = 2400): the single-call step reduces them in one launch
     e->lnp_stride = ln_partials_floats((int)T, (int)H);
-    e->ws_lnp_a = w.take(e->lnp_stride * 4 * c.num_layers); e->ws_lnp_b = w.take(e->lnp_stride * 4 * c.num_layers);
+    e->ws_lnp_a = w.take(e->lnp_stride * 4 * (c.num_layers + 1)); e->ws_lnp_b = w.take(e->lnp_stride * 4 * (c.num_layers + 1));     // (+1: MAG's gate)
     e->carve_step(w, T, (int)V, (int)A, c.max_batch, c.num_labels, SITE_LAYER0 + 4 * c.num_layers);
     if (e->deterministic) {          // shadow accumulator of everything behind the layers' GEMM weights (those have ONE writer per element)
         e->det_begin = e->wp; e->det_end = e->n_params;
@@ -201,6 +205,7 @@ static int prepare_pass(mb_bert_engine* e, int T, hipStream_t st) {
             return (int)hipMemsetAsync(ws + off + (size_t)T * cols * es, 0, (size_t)(Tp - T) * cols * es, st);
         };
         CK(zp(e->ws_emb, H));
+        CK(mag_clear_pad_rows(dt, ws + e->ws_mag, e->mw, T, H, st));
         for (int k = 0; k < 2; ++k) {
             CK(zp(e->ws_ds[k], H)); CK(zp(e->ws_dzd[k], H)); CK(zp(e->ws_ds2[k], H)); CK(zp(e->ws_dzd2[k], H));
             CK(zp(e->ws_du[k], I)); CK(zp(e->ws_dqkv[k], 3 * H));
@@ -359,6 +364,7 @@ int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
     if (const char* v = getenv("MB_WGRAD_OVERWRITE")) e->ow_enable = atoi(v);
     if (const char* v = getenv("MB_ADAMW_KEEP")) e->keep_enable = atoi(v);
     if (const char* v = getenv("MB_DETERMINISTIC")) e->deterministic = atoi(v);
+    if (const char* v = getenv("MB_ADAMW_OVERLAP")) e->opt_chunk = atoi(v);
     e->grouped = (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->hidden_size % e->group_wgrad == 0 &&
                  cfg->intermediate_size % e->group_wgrad == 0;
     e->deferred = e->overlap_wgrad && e->grouped;
@@ -374,6 +380,8 @@ void mb_bert_destroy(mb_bert_engine* e) {
     if (!e) return;
     if (e->side) hipStreamDestroy(e->side);
     for (auto& ev : e->evs) if (ev) hipEventDestroy(ev);
+    if (e->opt_side) hipStreamDestroy(e->opt_side);
+    for (auto& ev : e->opt_ev) if (ev) hipEventDestroy(ev);
     e->destroy_prof();
     e->drop_graphs();
     delete e;
@@ -442,7 +450,7 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     CK(mag_fwd_impl(dt, ws + e->ws_emb, visual, acoustic, P + e->mag_whv, P + e->mag_bhv, P + e->mag_wha, P + e->mag_bha,
                     P + e->mag_wv, P + e->mag_bv, P + e->mag_wa, P + e->mag_ba, P + e->mag_lnw, P + e->mag_lnb,
                     c.mag_layer_norm_eps, c.beta_shift, e->key(SITE_MAG, c.mag_dropout), ws + e->ws_x[0], ws + e->ws_mag,
-                    e->mw, T, H, c.visual_dim, c.acoustic_dim, true, st));
+                    e->mw, T, H, c.visual_dim, c.acoustic_dim, true, st, true));
     // encoder (bert.py:221-229)
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerOff& o = e->lo[l];
@@ -469,7 +477,7 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     float* z = (float*)(ws + e->ws_head_z);
     CK(gemm(dt, GEMM_NT, EPI_BIAS_F32, B, H, H, ws + e->ws_x[c.num_layers], L * H, e->W(e->wp), H, nullptr, H, nullptr, z,
             P + e->bp, nullptr, 0, kNoDrop, 1, 64, st));
-    if (loss) CK(zero_fill(loss, 4, st));
+    if (loss && !(e->in_step && e->loss_cleared)) CK(zero_fill(loss, 4, st));
     CK(head_forward(z, P + e->wc, P + e->bc, labels, (float*)(ws + e->ws_head_pooled), logits, loss, loss_run, B, H,
                     c.num_labels, e->key(SITE_HEAD, c.hidden_dropout), st));
     return MB_OK;
@@ -493,14 +501,14 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
     for (int stage = stage_begin; stage < stage_end; ++stage) {
         if (stage == 0) {
             // ---- head + pooler
+            // (one launch: dz, the classifier gradients, the pooler bias gradient = column sums of dz, and the clearing of the token
+            //  gradient buffer whose [CLS] rows the dgrad below fills)
             CK(head_backward(dt, dlogits, e->logits, labels, loss_scale, (const float*)(ws + e->ws_head_pooled), P + e->wc,
                              ws + e->ws_dz, G + e->wc, G + e->bc, B, H, c.num_labels, e->key(SITE_HEAD, c.hidden_dropout),
-                             st, acc));
+                             st, acc, G + e->bp, ws + e->ws_dxa, (size_t)T * H * esize(dt)));
             const char* xf = ws + e->ws_x[NL];
             CK(gemm(dt, GEMM_TN, EPI_ACCUM_F32, H, H, B, ws + e->ws_dz, H, xf, L * H, nullptr, H, nullptr, G + e->wp, nullptr,
                     nullptr, 0, kNoDrop, 1, 64, st));
-            CK(colsum(dt, ws + e->ws_dz, H, G + e->bp, B, H, st, acc));
-            CK(zero_fill(ws + e->ws_dxa, (size_t)T * H * esize(dt), st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, B, H, H, ws + e->ws_dz, H, e->W(e->wp), H, ws + e->ws_dxa, L * H, nullptr,
                     nullptr, nullptr, nullptr, 0, kNoDrop, 1, 64, st));
         } else if (stage <= NL) {
@@ -534,7 +542,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             float* lnp_a = (float*)(ws + e->ws_lnp_a) + (size_t)l * e->lnp_stride;
             float* lnp_b = (float*)(ws + e->ws_lnp_b) + (size_t)l * e->lnp_stride;
             // single-call step: nobody needs this layer's LayerNorm / bias gradients before AdamW -> all layers reduced at once
-            const bool defer_ln = e->in_step && !e->stage_mode && NL <= MB_LN_MAX_LAYERS;
+            const bool defer_ln = e->in_step && !e->stage_mode && NL + 1 <= MB_LN_MAX_LAYERS;      // (reduced in the last stage)
             // LN2 + dropout backward (column sums -> per-block partial slabs, reduced once per layer below)
             CK(ln_backward_partials(dt, dx, ws + w.s2, P + o.ln2w, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, dsA,
                                     hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(SITE_LAYER0 + 4 * l + 2, c.hidden_dropout), st));
@@ -573,15 +581,6 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             if (!defer_ln) {
                 float* const dst6[6] = {G + o.ln2w, G + o.ln2b, G + o.b2, G + o.ln1w, G + o.ln1b, G + o.bo};
                 CK(ln_reduce_partials(lnp_a, lnp_b, nblk, H, dst6, st, acc));
-            } else if (l == 0) {
-                LnReduceDst dst = {};
-                for (int k = 0; k < NL; ++k) {
-                    const LayerOff& ok = e->lo[k];
-                    float* const d6[6] = {G + ok.ln2w, G + ok.ln2b, G + ok.b2, G + ok.ln1w, G + ok.ln1b, G + ok.bo};
-                    for (int q = 0; q < 6; ++q) dst.d[k][q] = d6[q];
-                }
-                CK(ln_reduce_partials_layers((const float*)(ws + e->ws_lnp_a), (const float*)(ws + e->ws_lnp_b), e->lnp_stride, NL, nblk, H,
-                                             dst, st, acc));
             }
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.wo), H, ws + e->ws_dctx, H, nullptr, nullptr, nullptr,
                     nullptr, 0, kNoDrop, 1, 0, st));
@@ -622,11 +621,33 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             if (e->deferred && e->side) CK((int)hipStreamWaitEvent(st, e->evs[4], 0));      // weight gradients of layer 0
             char* dx = ws + e->ws_dxa;
             char* de = ws + e->ws_dxb;
+            // single-call step: the six column sums of MAG's gate go to partial slabs like the LayerNorm ones, and ONE launch reduces
+            // every layer's and MAG's slabs (nobody needs these small gradients before AdamW)
+            const bool defer_ln = e->in_step && !e->stage_mode && NL + 1 <= MB_LN_MAX_LAYERS && NL > 0;
+            float* mpa = (float*)(ws + e->ws_lnp_a) + (size_t)NL * e->lnp_stride;
+            float* mpb = (float*)(ws + e->ws_lnp_b) + (size_t)NL * e->lnp_stride;
+            int mblk = 0;
             CK(mag_bwd_impl(dt, dx, ws + e->ws_emb, P + e->mag_bhv, P + e->mag_bha, P + e->mag_bv, P + e->mag_ba,
                             P + e->mag_lnw, c.beta_shift, e->key(SITE_MAG, c.mag_dropout), ws + e->ws_mag, e->mw, de, nullptr,
                             nullptr, G + e->mag_whv, G + e->mag_bhv, G + e->mag_wha, G + e->mag_bha, G + e->mag_wv,
                             G + e->mag_bv, G + e->mag_wa, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb, T, H, c.visual_dim,
-                            c.acoustic_dim, true, st, acc));
+                            c.acoustic_dim, true, st, acc, true, mpa, mpb, &mblk));
+            if (!defer_ln) {       // the same slabs, the same summation order (deterministic mode: bit-identical to the single-call step)
+                float* const m6[6] = {G + e->mag_bhv, G + e->mag_bha, G + e->mag_bv, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb};
+                CK(ln_reduce_partials(mpa, mpb, mblk, H, m6, st, acc));
+            } else {
+                if (mblk != e->lnp_nblk) return MB_ERR_SHAPE;       // (both kernels take 8 token rows per block)
+                LnReduceDst dst = {};
+                for (int k = 0; k < NL; ++k) {
+                    const LayerOff& ok = e->lo[k];
+                    float* const d6[6] = {G + ok.ln2w, G + ok.ln2b, G + ok.b2, G + ok.ln1w, G + ok.ln1b, G + ok.bo};
+                    for (int q = 0; q < 6; ++q) dst.d[k][q] = d6[q];
+                }
+                float* const m6[6] = {G + e->mag_bhv, G + e->mag_bha, G + e->mag_bv, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb};
+                for (int q = 0; q < 6; ++q) dst.d[NL][q] = m6[q];
+                CK(ln_reduce_partials_layers((const float*)(ws + e->ws_lnp_a), (const float*)(ws + e->ws_lnp_b), e->lnp_stride, NL + 1, mblk, H,
+                                             dst, st, acc));
+            }
             CK(embed_ln_backward(dt, de, e->ids, e->seg, e->ids ? P + e->word : e->emb_in, P + e->pos, P + e->type, P + e->emb_lnw,
                                  (const float*)(ws + e->ws_emb_st), (const float*)(ws + e->ws_emb_st) + T,
                                  (float*)(ws + e->ws_dsum), e->ids ? G + e->word : nullptr, G + e->pos, G + e->type, G + e->emb_lnw,
@@ -645,28 +666,65 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
 // (the grouped weight-gradient launches run in line: a graph with a side-stream fork / join replays on a slow path).
 // mode 1 = graph replay (captured on first use per shape), mode 2 = the same kernel sequence launched one by one (A/B
 // reference for the graph; also what runs while profiling events are on).
-static int enqueue_step(mb_bert_engine* e, int B, int L, float* logits, float* loss, float* loss_run, float* m, float* v,
+// AdamW of flat range [b, en) of the decay slab (GEMM weights), inside a step (scalars from device memory)
+static int adamw_decay_range(mb_bert_engine* e, float* m, float* v, size_t b, size_t en, hipStream_t st) {
+    if (en <= b) return MB_OK;
+    const AdamArgs none = {};
+    const bool keep = e->keep_in_step();          // the layers' GEMM weight gradients: overwritten by the next backward, not zeroed
+    auto clampr = [&](size_t x) { return x < b ? (size_t)0 : (x > en ? en - b : x - b); };
+    const size_t shb = clampr(e->sh_begin), she = clampr(e->sh_end);
+    const size_t kb = keep ? clampr(e->stale_begin) : 0, ke = keep ? clampr(e->stale_end) : 0;
+    void* sh = e->c.dtype == DT_BF16 ? (void*)(e->SH + b * 2) : nullptr;
+    return adamw_step(e->P + b, e->G + b, m + b, v + b, sh, en - b, en - b, shb, she, none, 1, st, e->adam_state(e->ws), kb, ke);
+}
+
+// The step as `nseg` segments (train_step_impl).  nseg == 1: forward, backward, optimizer.  MB_ADAMW_OVERLAP=C (C layers per chunk,
+// nseg = layers / C + 1): segment i ends with the backward of a chunk of C layers; the host then forks the AdamW of THAT chunk's
+// GEMM weights (7.08 M parameters per layer, 77 % of the model: HBM-bound) onto the optimizer side stream, where it runs under the
+// MFMA-bound backward of the layers below; the last segment holds the MAG / embedding backward and the optimizer of everything
+// else, and the step ends with the join.  Nothing later in the step reads a finished layer's weights, gradients or shadow.
+static int enqueue_step(mb_bert_engine* e, int seg, int nseg, int B, int L, float* logits, float* loss, float* loss_run, float* m, float* v,
                         float loss_scale, hipStream_t st) {
     char* ws = e->ws;
+    const int NL = e->c.num_layers;
     const float* lab = (const float*)(ws + e->ws_in_lab);
     float* keep_attn = e->attn_out;
     e->attn_out = nullptr;                      // optional outputs belong to explicit forwards, never to a (captured) training step
     struct Restore { mb_bert_engine* e; float* p; ~Restore() { e->attn_out = p; } } restore{e, keep_attn};
     if (e->head_mask || e->emb_in || e->pos_ids) return MB_ERR_MODE;     // head_mask / inputs_embeds / position_ids are arguments of explicit forwards only
-    CK(mb_bert_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
-                       (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
-                       loss_run, st));
-    CK(mb_bert_backward(e, nullptr, lab, loss_scale, 0, e->c.num_layers + 2, st));
-    if (m && v) {
+    const int C = nseg > 1 ? NL / (nseg - 1) : 0;
+    if (seg == 0)
+        CK(mb_bert_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
+                           (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
+                           loss_run, st));
+    // backward stages: 0 = head, 1 .. NL = layers NL-1 .. 0, NL+1 = MAG + embeddings
+    const int sb = nseg == 1 ? 0 : (seg == 0 ? 0 : 1 + seg * C);
+    const int se = nseg == 1 ? NL + 2 : (seg + 1 < nseg ? 1 + (seg + 1) * C : NL + 2);
+    CK(mb_bert_backward(e, nullptr, lab, loss_scale, sb, se, st));
+    if (m && v && seg == nseg - 1) {
         const AdamArgs none = {};
         const size_t nd = e->n_decay, n = e->n_params;
-        void* sh = e->c.dtype == DT_BF16 ? (void*)e->SH : nullptr;
-        const bool keep = e->keep_in_step();          // the layers' GEMM weight gradients: overwritten by the next backward, not zeroed
-        CK(e->prof_mark(2 * e->c.num_layers, st));
-        CK(adamw_step(e->P, e->G, m, v, sh, nd, nd, e->sh_begin, e->sh_end, none, 1, st, e->adam_state(ws), keep ? e->stale_begin : 0,
-                      keep ? e->stale_end : 0));
+        CK(e->prof_mark(2 * NL, st));
+        // (with chunks on the side stream, what is left of the decay slab: the pooler weight .. the classifier weight)
+        CK(adamw_decay_range(e, m, v, nseg == 1 ? 0 : e->wp, nd, st));
         CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
-        CK(e->prof_mark(2 * e->c.num_layers + 1, st));
+        CK(e->prof_mark(2 * NL + 1, st));
+    }
+    return MB_OK;
+}
+
+// host side of MB_ADAMW_OVERLAP, after segment `seg` was enqueued (never captured): fork the chunk's optimizer / join at the end
+static int between_segments(mb_bert_engine* e, int seg, int nseg, float* m, float* v, hipStream_t st) {
+    if (nseg == 1 || !m || !v) return MB_OK;
+    const int NL = e->c.num_layers, C = NL / (nseg - 1);
+    if (seg + 1 < nseg) {
+        const int l_lo = NL - (seg + 1) * C, l_hi = NL - seg * C;       // layers [l_lo, l_hi) finished in this segment
+        CK((int)hipEventRecord(e->opt_ev[seg], st));
+        CK((int)hipStreamWaitEvent(e->opt_side, e->opt_ev[seg], 0));
+        CK(adamw_decay_range(e, m, v, e->lo[l_lo].wqkv, l_hi < NL ? e->lo[l_hi].wqkv : e->wp, e->opt_side));
+    } else {
+        CK((int)hipEventRecord(e->opt_ev[seg], e->opt_side));
+        CK((int)hipStreamWaitEvent(st, e->opt_ev[seg], 0));
     }
     return MB_OK;
 }
@@ -687,12 +745,22 @@ int mb_bert_train_step(mb_bert_engine* e, const int64_t* input_ids, const float*
     CK(ensure_side(e));
     e->training = 1;
     CK(prepare_pass(e, T, st));
+    int nseg = 1;
+    if (m && e->opt_chunk > 0 && c.num_layers % e->opt_chunk == 0 && !e->overlap_wgrad && !e->prof) {
+        nseg = c.num_layers / e->opt_chunk + 1;
+        if (!e->opt_side) {
+            CK((int)hipStreamCreateWithFlags(&e->opt_side, hipStreamNonBlocking));
+            e->opt_ev.assign((size_t)c.num_layers + 1, nullptr);
+            for (auto& ev : e->opt_ev) CK((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+    }
     return train_step_impl(e, ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
                            labels, B, L, seed, step, logits, loss, loss_run, m, v, lr, beta1, beta2, eps, weight_decay, opt_step,
                            correct_bias, grad_scale, loss_scale, mode, e->prof, st,
-                           [&](float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
-                               return enqueue_step(e, B, L, lg, ls, lr_, m_, v_, sc, s);
-                           });
+                           [&](int sg, float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
+                               return enqueue_step(e, sg, nseg, B, L, lg, ls, lr_, m_, v_, sc, s);
+                           },
+                           nseg, [&](int sg, hipStream_t s) { return between_segments(e, sg, nseg, m, v, s); });
 }
 
 // ------------------------------------------------------------------------------------------------ stage-driven step (data parallel)

@@ -134,7 +134,13 @@ inline int wgrad(int dtype, int Mo, int No, int rows, const void* dY, int ldy, c
 // be replayed as a hipGraph.
 struct StepGraph {
     int B, L, with_opt, overwrite; const void *logits, *loss, *loss_run, *m, *v; float loss_scale; hipStream_t st;
-    hipGraph_t graph; hipGraphExec_t exec;
+    int nseg;                                       // the step as `nseg` linear graphs launched back to back (1 = the whole step)
+    std::vector<hipGraph_t> graph; std::vector<hipGraphExec_t> exec;
+    void destroy() {
+        for (auto x : exec) if (x) hipGraphExecDestroy(x);
+        for (auto g : graph) if (g) hipGraphDestroy(g);
+        exec.clear(); graph.clear();
+    }
 };
 
 // one captured pass of a stage-driven (data-parallel) step: stage -1 = forward, 0 .. = backward stage
@@ -144,6 +150,7 @@ struct StepMixin {
     bool dyn = false;              // dropout keys / AdamW scalars are read from device memory (set while a train step is built)
     bool stage_mode = false;       // a stage-driven step is being built: every stage's gradients must be final when the stage returns
     std::vector<StageGraph> stage_graphs;
+    bool loss_cleared = false;     // single-call step: the step prologue clears the loss accumulator (no zero_fill launch in the forward)
     bool capturing = false;        // the stream is in capture mode: nothing outside the captured sequence may be waited for
     int nsites = 0;
     size_t ws_state = 0, ws_in_ids = 0, ws_in_seg = 0, ws_in_mask = 0, ws_in_vis = 0, ws_in_aco = 0, ws_in_lab = 0;
@@ -226,7 +233,7 @@ struct StepMixin {
         ws_in_lab = w.take((size_t)max_batch * num_labels * 4);
     }
     void drop_graphs() {
-        for (auto& g : graphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
+        for (auto& g : graphs) g.destroy();
         graphs.clear();
         for (auto& g : stage_graphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
         stage_graphs.clear();
@@ -292,12 +299,16 @@ struct StepMixin {
 };
 
 // enqueue(logits, loss, loss_run, m, v, loss_scale, st): forward (reading the staged batch) + backward + AdamW of one engine
-template <class E, class Enqueue>
+struct NoBetween { int operator()(int, hipStream_t) const { return MB_OK; } };
+template <class E, class Enqueue, class Between = NoBetween>
 inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const void* ids, const void* vis, const void* aco, const void* mask,
                            const void* seg, const void* labels, int B, int L, uint64_t seed, uint64_t step, float* logits, float* loss,
                            float* loss_run, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay,
                            int opt_step, int correct_bias, float grad_scale, float loss_scale, int mode, bool force_launches,
-                           hipStream_t st, Enqueue enqueue_inner) {
+                           hipStream_t st, Enqueue enqueue_inner, int nseg = 1, Between between = Between()) {
+    // The step may be cut into `nseg` segments: enqueue_inner(seg, ...) issues the kernels of one (captured and replayed as its own
+    // LINEAR graph), between(seg, st) runs on the host right after segment `seg` was enqueued and is never captured -- the place for
+    // cross-stream events (a graph with a fork inside runs on ROCm 7.2's slow path; a chain of linear graphs does not).
     // what this step's backward may assume about the gradient buffer -- part of the graph's identity -- and what it leaves behind
     const int ow = (e->grads_zero && e->ow_enable) ? 1 : 0;
     if (!(ow && e->ow_covers)) CK(e->materialize_grads(e->G, st));      // an accumulating backward needs the zeros that were skipped
@@ -306,18 +317,19 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
     struct Flags {
         E* e; bool ok, with_opt, stale_before;
         ~Flags() {
-            e->in_step = false;
+            e->in_step = false; e->loss_cleared = false;
             e->grads_zero = ok && with_opt;
             e->grads_stale = ok ? (with_opt && e->keep_in_step()) : stale_before;
         }
     } flags{e, false, m != nullptr, stale_before};
     e->in_step = true; e->ow_pass = ow != 0;
-    auto enqueue = [&](float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
-        return enqueue_inner(lg, ls, lr_, m_, v_, sc, s);
+    auto enqueue = [&](int sg, float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
+        return enqueue_inner(sg, lg, ls, lr_, m_, v_, sc, s);
     };
     PrologueArgs pa = {};
     e->fill_copies(pa, ws, ids, vis, aco, mask, seg, labels, B, L, V, A, num_labels);
     pa.seed = seed; pa.step = step; pa.keys = e->key_state(ws); pa.nsites = e->nsites;
+    pa.zero_dw = (uint32_t*)loss; e->loss_cleared = loss != nullptr;
     if (m) {
         double ss = lr;
         if (correct_bias) ss = (double)lr * sqrt(1.0 - pow((double)beta2, (double)opt_step)) / (1.0 - pow((double)beta1, (double)opt_step));
@@ -332,7 +344,11 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
     CK(step_prologue(pa, st));
     if (mode == 2 || force_launches) {
         e->dyn = true;
-        const int r = enqueue(logits, loss, loss_run, m, v, loss_scale, st);
+        int r = MB_OK;
+        for (int sg = 0; sg < nseg && r == MB_OK; ++sg) {
+            r = enqueue(sg, logits, loss, loss_run, m, v, loss_scale, st);
+            if (r == MB_OK) r = between(sg, st);
+        }
         e->dyn = false;
         flags.ok = r == MB_OK;
         return r;
@@ -340,41 +356,62 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
     StepGraph* g = nullptr;
     for (auto& x : e->graphs)
         if (x.B == B && x.L == L && x.with_opt == (m != nullptr) && x.overwrite == ow && x.logits == logits && x.loss == loss && x.loss_run == loss_run &&
-            x.m == m && x.v == v && x.loss_scale == loss_scale && x.st == st) { g = &x; break; }
+            x.m == m && x.v == v && x.loss_scale == loss_scale && x.st == st && x.nseg == nseg) { g = &x; break; }
     if (!g) {
         if (e->graphs.size() >= 32) {          // callers that keep changing output pointers: do not grow without bound
-            hipGraphExecDestroy(e->graphs.front().exec); hipGraphDestroy(e->graphs.front().graph);
+            e->graphs.front().destroy();
             e->graphs.erase(e->graphs.begin());
         }
-        StepGraph ng = {B, L, m != nullptr, ow, logits, loss, loss_run, m, v, loss_scale, st, nullptr, nullptr};
-        CK((int)hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-        e->dyn = true; e->capturing = true;
-        const int r = enqueue(logits, loss, loss_run, m, v, loss_scale, st);
-        e->dyn = false; e->capturing = false;
-        const int r2 = (int)hipStreamEndCapture(st, &ng.graph);
-        if (r) { if (ng.graph) hipGraphDestroy(ng.graph); return r; }
-        CK(r2);
-        CK((int)hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0));
+        StepGraph ng = {B, L, m != nullptr, ow, logits, loss, loss_run, m, v, loss_scale, st, nseg, {}, {}};
+        for (int sg = 0; sg < nseg; ++sg) {
+            hipGraph_t gr = nullptr;
+            hipGraphExec_t ex = nullptr;
+            CK((int)hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+            e->dyn = true; e->capturing = true;
+            const int r = enqueue(sg, logits, loss, loss_run, m, v, loss_scale, st);
+            e->dyn = false; e->capturing = false;
+            const int r2 = (int)hipStreamEndCapture(st, &gr);
+            if (r || r2) { if (gr) hipGraphDestroy(gr); ng.destroy(); return r ? r : r2; }
+            const int r3 = (int)hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+            if (r3) { hipGraphDestroy(gr); ng.destroy(); return r3; }
+            ng.graph.push_back(gr); ng.exec.push_back(ex);
+        }
         e->graphs.push_back(ng);
         g = &e->graphs.back();
         ++e->graph_captures;
     }
-    CK((int)hipGraphLaunch(g->exec, st));
+    for (int sg = 0; sg < nseg; ++sg) {
+        CK((int)hipGraphLaunch(g->exec[sg], st));
+        CK(between(sg, st));
+    }
     ++e->graph_launches;
     flags.ok = true;
     return MB_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ MAG operator
+// rows [T, Tp) of MAG's k-major GEMM operands (packed modalities, the three dZ): cleared by the engines whenever the token count
+// changes (never inside a captured step), instead of by a launch in every forward and every backward
+inline int mag_clear_pad_rows(int dtype, char* ws, const MagWs& w, int T, int H, hipStream_t st) {
+    const size_t Tp = align_up((size_t)T, 64), es = esize(dtype);
+    if (Tp == (size_t)T) return MB_OK;
+    auto zp = [&](size_t off, size_t cols) { return (int)hipMemsetAsync(ws + off + (size_t)T * cols * es, 0, (Tp - T) * cols * es, st); };
+    CK(zp(w.vp, w.Vp)); CK(zp(w.ap, w.Ap));
+    CK(zp(w.dZe, 2 * (size_t)H)); CK(zp(w.dZv, 2 * (size_t)H)); CK(zp(w.dZa, 2 * (size_t)H));
+    return MB_OK;
+}
 inline int mag_fwd_impl(int dtype, const void* text, const float* visual, const float* acoustic, const float* W_hv,
                  const float* b_hv, const float* W_ha, const float* b_ha, const float* W_v, const float* b_v,
                  const float* W_a, const float* b_a, const float* ln_w, const float* ln_b, float ln_eps, float beta_shift,
-                 DropKey drop, void* out, char* ws, const MagWs& w, int T, int H, int V, int A, bool repack, hipStream_t st) {
+                 DropKey drop, void* out, char* ws, const MagWs& w, int T, int H, int V, int A, bool repack, hipStream_t st,
+                 bool pads_clean = false) {
+    // pads_clean: the caller keeps rows [T, Tp) of the k-major operands zero itself (the engines: mag_clear_pad_rows whenever the
+    // token count changes -- no kernel ever writes those rows); the stand-alone operator clears them on every call
     MagDims d = {T, H, V, A, w.Vp, w.Ap};
     if (repack) CK(mag_pack_weights(dtype, W_hv, W_ha, W_v, W_a, ws + w.We, ws + w.Wv, ws + w.Wa, d, st));
     CK(pack_pad(dtype, visual, V, ws + w.vp, w.Vp, T, st));
     CK(pack_pad(dtype, acoustic, A, ws + w.ap, w.Ap, T, st));
-    {
+    if (!pads_clean) {
         const int Tp = (int)align_up((size_t)T, 64);
         const size_t es = esize(dtype);
         if (Tp > T) {
@@ -399,39 +436,43 @@ inline int mag_bwd_impl(int dtype, const void* d_out, const void* text, const fl
                  const float* b_a, const float* ln_w, float beta_shift, DropKey drop, char* ws, const MagWs& w, void* d_text,
                  float* d_visual, float* d_acoustic, float* dW_hv, float* db_hv, float* dW_ha, float* db_ha, float* dW_v,
                  float* db_v, float* dW_a, float* db_a, float* dln_w, float* dln_b, int T, int H, int V, int A,
-                 bool text_padded, hipStream_t st, GradAcc acc = {}) {
+                 bool text_padded, hipStream_t st, GradAcc acc = {}, bool pads_clean = false, float* part_a = nullptr,
+                 float* part_b = nullptr, int* part_nblk = nullptr) {
     MagDims d = {T, H, V, A, w.Vp, w.Ap};
     const int Tp = (int)align_up((size_t)T, 64);      // zero-padded token rows of the workspace operands
     const size_t es = esize(dtype);
+    // the three packed weight gradients as ONE grouped launch (like a layer's four): alone, the two modality problems are
+    // 24 / 48 tiles whose duration is the K = T loop latency (three launches of ~34 us each).  The grouped launch STORES its
+    // tiles (no split-K), so the packed accumulators need no clearing.
+    GemmArgs wg[3] = {wgrad_args(2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H),
+                      wgrad_args(2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp),
+                      wgrad_args(2 * H, w.Ap, Tp, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap)};
+    const bool grouped = text_padded && gemm_grouped_tn_ok(dtype, wg, 3, 64);
     {
-        // one launch clears the pad rows of this call's k-major operands and the packed weight-gradient accumulators
+        // one launch clears the pad rows of this call's k-major operands and (ungrouped path) the packed weight-gradient accumulators
         ZeroRanges z = {};
-        if (Tp > T) {
+        if (Tp > T && !pads_clean) {
             z.add(ws + w.dZe + (size_t)T * 2 * H * es, (size_t)(Tp - T) * 2 * H * es);
             z.add(ws + w.dZv + (size_t)T * 2 * H * es, (size_t)(Tp - T) * 2 * H * es);
             z.add(ws + w.dZa + (size_t)T * 2 * H * es, (size_t)(Tp - T) * 2 * H * es);
         }
-        z.add(ws + w.dWe, (size_t)2 * H * H * 4);
-        z.add(ws + w.dWv, (size_t)2 * H * w.Vp * 4);
-        z.add(ws + w.dWa, (size_t)2 * H * w.Ap * 4);
-        CK(zero_fill_ranges(z, st));
+        if (!grouped) {
+            z.add(ws + w.dWe, (size_t)2 * H * H * 4);
+            z.add(ws + w.dWv, (size_t)2 * H * w.Vp * 4);
+            z.add(ws + w.dWa, (size_t)2 * H * w.Ap * 4);
+        }
+        if (z.n) CK(zero_fill_ranges(z, st));
     }
     CK(mag_gate_backward(dtype, d_out, text, ws + w.Ze, ws + w.Zv, ws + w.Za, b_hv, b_ha, b_v, b_a, ln_w,
                          (const float*)(ws + w.mean), (const float*)(ws + w.rstd), beta_shift, ws + w.dep, ws + w.dZe,
-                         ws + w.dZv, ws + w.dZa, db_hv, db_ha, db_v, db_a, dln_w, dln_b, d, drop, st, acc));
-    {
-        // the three packed weight gradients as ONE grouped launch (like a layer's four): alone, the two modality problems are
-        // 24 / 48 tiles whose duration is the K = T loop latency (three launches of ~34 us each)
-        GemmArgs wg[3] = {wgrad_args(2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H),
-                          wgrad_args(2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp),
-                          wgrad_args(2 * H, w.Ap, Tp, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap)};
-        if (text_padded && gemm_grouped_tn_ok(dtype, wg, 3, 64)) {
-            CK(gemm_grouped_tn_launch(dtype, wg, 3, 64, st));
-        } else {
-            CK(wgrad(dtype, 2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H, st));
-            CK(wgrad(dtype, 2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp, st));
-            CK(wgrad(dtype, 2 * H, w.Ap, Tp, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap, st));
-        }
+                         ws + w.dZv, ws + w.dZa, db_hv, db_ha, db_v, db_a, dln_w, dln_b, d, drop, st, acc, part_a, part_b, part_nblk));
+    if (grouped) {
+        for (auto& g : wg) g.overwrite = 1;
+        CK(gemm_grouped_tn_launch(dtype, wg, 3, 64, st));
+    } else {
+        CK(wgrad(dtype, 2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H, st));
+        CK(wgrad(dtype, 2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp, st));
+        CK(wgrad(dtype, 2 * H, w.Ap, Tp, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap, st));
     }
     CK(mag_unpack_wgrads((const float*)(ws + w.dWe), (const float*)(ws + w.dWv), (const float*)(ws + w.dWa), dW_hv, dW_ha,
                          dW_v, dW_a, d, st));

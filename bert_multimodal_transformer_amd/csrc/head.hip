@@ -5,6 +5,7 @@
 //   loss = mean_b(logsumexp(logits_b) - logits_b[label_b])            num_labels  > 1 (bert.py:318-320 / xlnet.py:519-522:
 //          CrossEntropyLoss; labels[b] then holds the class index of sample b as a float)
 // One wave per sample; H = 768 (3 chunks of 4 columns per lane).  Tiny, launch-latency bound.
+#include <algorithm>
 #include "kernels.h"
 
 namespace mb {
@@ -78,7 +79,15 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ labels, float loss_scale,
                                                        const float* __restrict__ pooled, const float* __restrict__ Wc,
                                                        T* __restrict__ dz, float* dWc, float* dbc, int B, int nl,
-                                                       DropKey drop, GradAcc acc) {
+                                                       DropKey drop, GradAcc acc, float* dbp, u32x4* __restrict__ zero_p,
+                                                       size_t zero_n16, int nb) {
+    // blocks [nb, gridDim.x): clear zero_p[0, zero_n16) -- the token-gradient buffer whose [CLS] / last-token rows the next launch
+    // fills (one launch less per backward than a separate zero_fill)
+    if ((int)blockIdx.x >= nb) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (size_t i = (size_t)(blockIdx.x - nb) * 256 + threadIdx.x; i < zero_n16; i += (size_t)(gridDim.x - nb) * 256) zero_p[i] = z;
+        return;
+    }
     drop.resolve();
     constexpr int H = CH * 256;
     __shared__ float wsum[4][H];
@@ -130,12 +139,17 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__
             __syncthreads();
         }
     }
-    if (!valid) return;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int col = (c * 64 + lane) * 4;
-        const f32x4 d = dpd[c] * dm[c] * (1.0f - pl[c] * pl[c]);
-        store4(dz + (size_t)b * H + col, d);
+        const f32x4 d = dpd[c] * dm[c] * (1.0f - pl[c] * pl[c]);       // (dpd == 0 for a wave without a sample)
+        if (valid) store4(dz + (size_t)b * H + col, d);
+        if (dbp) *(f32x4*)(&wsum[wave][col]) = d;
+    }
+    if (dbp) {                            // uniform: the pooler / summary bias gradient = column sums of dz (was a colsum launch)
+        __syncthreads();
+        for (int col = threadIdx.x; col < H; col += 256)
+            grad_add(acc, dbp + col, (wsum[0][col] + wsum[1][col]) + (wsum[2][col] + wsum[3][col]));
     }
 }
 
@@ -150,16 +164,20 @@ int head_forward(const float* z, const float* Wc, const float* bc, const float* 
 
 int head_backward(int dtype, const float* dlogits, const float* logits, const float* labels, float loss_scale,
                   const float* pooled, const float* Wc, void* dz, float* dWc, float* dbc, int B, int H, int nl,
-                  DropKey drop, hipStream_t st, GradAcc acc) {
+                  DropKey drop, hipStream_t st, GradAcc acc, float* dbp, void* zero_p, size_t zero_bytes) {
     if (H != 768) return MB_ERR_SHAPE;
     if (B <= 0) return MB_OK;
     if (!dlogits && !(logits && labels)) return MB_ERR_ARG;
+    if (zero_bytes % 16 || ((uintptr_t)zero_p & 15)) return MB_ERR_SHAPE;
+    const int nb = (B + 3) / 4;
+    const size_t n16 = zero_p ? zero_bytes / 16 : 0;
+    const int zb = n16 ? (int)std::min<size_t>((n16 + 1023) / 1024, 512) : 0;
     if (dtype == DT_BF16)
-        hipLaunchKernelGGL((head_bwd_kernel<bf16, 3>), dim3((B + 3) / 4), dim3(256), 0, st, dlogits, logits, labels,
-                           loss_scale, pooled, Wc, (bf16*)dz, dWc, dbc, B, nl, drop, acc);
+        hipLaunchKernelGGL((head_bwd_kernel<bf16, 3>), dim3(nb + zb), dim3(256), 0, st, dlogits, logits, labels,
+                           loss_scale, pooled, Wc, (bf16*)dz, dWc, dbc, B, nl, drop, acc, dbp, (u32x4*)zero_p, n16, nb);
     else if (dtype == DT_F32)
-        hipLaunchKernelGGL((head_bwd_kernel<float, 3>), dim3((B + 3) / 4), dim3(256), 0, st, dlogits, logits, labels,
-                           loss_scale, pooled, Wc, (float*)dz, dWc, dbc, B, nl, drop, acc);
+        hipLaunchKernelGGL((head_bwd_kernel<float, 3>), dim3(nb + zb), dim3(256), 0, st, dlogits, logits, labels,
+                           loss_scale, pooled, Wc, (float*)dz, dWc, dbc, B, nl, drop, acc, dbp, (u32x4*)zero_p, n16, nb);
     else return MB_ERR_DTYPE;
     return (int)hipGetLastError();
 }

@@ -137,7 +137,10 @@ int mag_gate_backward(int dtype, const void* dout, const void* e, const void* Ze
                       const float* gamma, const float* mean, const float* rstd, float beta_shift,
                       void* de, void* dZe, void* dZv, void* dZa,
                       float* db_hv, float* db_ha, float* db_v, float* db_a, float* dgamma, float* dbeta,
-                      MagDims d, DropKey drop, hipStream_t st, GradAcc acc = {});
+                      MagDims d, DropKey drop, hipStream_t st, GradAcc acc = {},
+                      // part_a / part_b: instead of adding the six column sums to db_* / dgamma / dbeta, every block writes its slab
+                      // of two partial sets [nblk][3][H] ({db_hv, db_ha, db_v}, {db_a, dgamma, dbeta}) for ln_reduce_partials(_layers)
+                      float* part_a = nullptr, float* part_b = nullptr, int* nblk = nullptr);
 
 // ------------------------------------------------------------------------------------------ attention (attention.hip)
 // qkv: [B*L][3H] token-major (q | k | v, head h at columns h*64..), mask: int64 [B][L] (1 = attend),
@@ -183,7 +186,8 @@ int head_forward(const float* z, const float* Wc, const float* bc, const float* 
 // dWc, dbc accumulated.  dz is written in the activation dtype (operand of the pooler dgrad / wgrad GEMMs).
 int head_backward(int dtype, const float* dlogits, const float* logits, const float* labels, float loss_scale,
                   const float* pooled, const float* Wc, void* dz, float* dWc, float* dbc,
-                  int B, int H, int nl, DropKey drop, hipStream_t st, GradAcc acc = {});
+                  int B, int H, int nl, DropKey drop, hipStream_t st, GradAcc acc = {}, float* dbp = nullptr,
+                  void* zero_p = nullptr, size_t zero_bytes = 0);   // dbp += column sums of dz; zero_p[0, zero_bytes) cleared by extra blocks
 
 // ------------------------------------------------------------------------------------------ optimizer (adamw.hip)
 // transformers 3.0.2 AdamW over flat fp32 buffers; elements [0, n_decay) use weight_decay, the rest 0.
@@ -207,6 +211,7 @@ struct PrologueArgs {
     uint64_t seed, step;
     uint32_t* keys; int nsites;            // keys[2 * site + {0, 1}]
     AdamArgs adam[2]; AdamArgs* adam_dst;  // may be null
+    uint32_t* zero_dw;                     // one dword cleared by the launch (the step's loss accumulator), may be null
 };
 int step_prologue(const PrologueArgs& a, hipStream_t st);
 // p[0, bytes) = 0 as a kernel launch (bytes and p multiples of 4); up to MB_ZERO_MAX ranges in one launch

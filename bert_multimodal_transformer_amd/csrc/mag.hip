@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(256) mag_gate_bwd_kernel(const T* __restrict__
                                                            float beta_shift, T* __restrict__ de, T* __restrict__ dZe,
                                                            T* __restrict__ dZv, T* __restrict__ dZa, float* db_hv,
                                                            float* db_ha, float* db_v, float* db_a, float* dgamma,
-                                                           float* dbeta, int rows, DropKey drop, GradAcc acc) {
+                                                           float* dbeta, int rows, DropKey drop, GradAcc acc, float* part_a,
+                                                           float* part_b) {
     drop.resolve();
     constexpr int H = CH * 256;
     constexpr float invH = 1.0f / H;
@@ -242,10 +243,15 @@ __global__ void __launch_bounds__(256) mag_gate_bwd_kernel(const T* __restrict__
     __syncthreads();
     for (int i = threadIdx.x; i < 6 * H; i += 256) {
         const int q = i / H, col = i % H;
-        if (dst[q] == nullptr) continue;
         const float s = lds[(0 * 6 + q) * H + col] + lds[(1 * 6 + q) * H + col] + lds[(2 * 6 + q) * H + col] +
                         lds[(3 * 6 + q) * H + col];
-        grad_add(acc, dst[q] + col, s);
+        if (part_a != nullptr) {
+            // this block's slab of the two partial sets ([block][3][H], the layout of ln_bwd's): no atomics here -- 300 blocks x
+            // 4,608 columns onto the same 4,608 addresses were most of this launch; a ln_reduce launch sums the slabs
+            (q < 3 ? part_a : part_b)[((size_t)blockIdx.x * 3 + q % 3) * H + col] = s;
+        } else if (dst[q] != nullptr) {
+            grad_add(acc, dst[q] + col, s);
+        }
     }
 }
 
@@ -288,14 +294,16 @@ int mag_gate_backward(int dtype, const void* dout, const void* e, const void* Ze
                       const float* b_hv, const float* b_ha, const float* b_v, const float* b_a, const float* gamma,
                       const float* mean, const float* rstd, float beta_shift, void* de, void* dZe, void* dZv, void* dZa,
                       float* db_hv, float* db_ha, float* db_v, float* db_a, float* dgamma, float* dbeta, MagDims d,
-                      DropKey drop, hipStream_t st, GradAcc acc) {
+                      DropKey drop, hipStream_t st, GradAcc acc, float* part_a, float* part_b, int* nblk) {
     if (d.H % 256 || d.H < 256 || d.H > 1024) return MB_ERR_SHAPE;
-    if (d.T <= 0) return MB_OK;
+    if ((part_a == nullptr) != (part_b == nullptr)) return MB_ERR_ARG;
     constexpr int RPW = 2;
+    if (nblk) *nblk = (d.T + 4 * RPW - 1) / (4 * RPW);
+    if (d.T <= 0) return MB_OK;
 #define MB_MAG_BWD(CHV) hipLaunchKernelGGL((mag_gate_bwd_kernel<T, CHV, RPW>), dim3((d.T + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st, \
                            (const T*)dout, (const T*)e, (const T*)Ze, (const T*)Zv, (const T*)Za, b_hv, b_ha, b_v, b_a, \
                            gamma, mean, rstd, beta_shift, (T*)de, (T*)dZe, (T*)dZv, (T*)dZa, db_hv, db_ha, db_v, db_a, \
-                           dgamma, dbeta, d.T, drop, acc)
+                           dgamma, dbeta, d.T, drop, acc, part_a, part_b)
     MB_DISPATCH_T(dtype, {
         switch (d.H / 256) { case 1: MB_MAG_BWD(1); break; case 2: MB_MAG_BWD(2); break; case 3: MB_MAG_BWD(3); break; default: MB_MAG_BWD(4); }
     })

@@ -184,26 +184,30 @@ __global__ void __launch_bounds__(256) ln_reduce_kernel(const float* __restrict_
         grad_add(acc, dst + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// all layers at once: blockIdx.z = layer * 8 + slab octant
+// all layers at once: blockIdx.z = layer * 8 + slab octant; a lane sums FOUR adjacent columns (16-byte loads: a wave reads 1 KB
+// of a slab row; with one column per lane the launch was 24 us for 66 MB)
 __global__ void __launch_bounds__(256) ln_reduce_layers_kernel(const float* __restrict__ pa, const float* __restrict__ pb,
                                                                size_t layer_stride, int nblk, int H, LnReduceDst dst, GradAcc acc) {
     const int q = blockIdx.y;
     const int layer = blockIdx.z >> 3;
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int part = (threadIdx.x >> 6) + 4 * (blockIdx.z & 7);
     constexpr int nparts = 32;
-    __shared__ float red[4][64];
+    __shared__ f32x4 red[4][64];
     float* out = dst.d[layer][q];
     const float* src = (q < 3 ? pa : pb) + (size_t)layer * layer_stride;
-    float s = 0.f;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (out != nullptr && col < H) {
         const int qq = q % 3;
-        for (int b = part; b < nblk; b += nparts) s += src[((size_t)b * 3 + qq) * H + col];
+        for (int b = part; b < nblk; b += nparts) s += *(const f32x4*)(src + ((size_t)b * 3 + qq) * H + col);
     }
     red[threadIdx.x >> 6][threadIdx.x & 63] = s;
     __syncthreads();
-    if ((threadIdx.x >> 6) == 0 && out != nullptr && col < H)
-        grad_add(acc, out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if ((threadIdx.x >> 6) == 0 && out != nullptr && col < H) {
+        const f32x4 t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];      // (ln_reduce_kernel's order)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) grad_add(acc, out + col + r, t[r]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ embeddings
@@ -445,7 +449,8 @@ int ln_reduce_partials_layers(const float* pa, const float* pb, size_t layer_str
                               const LnReduceDst& dst, hipStream_t st, GradAcc acc) {
     if (nblk <= 0 || layers <= 0) return MB_OK;
     if (layers > MB_LN_MAX_LAYERS) return MB_ERR_SHAPE;
-    hipLaunchKernelGGL(ln_reduce_layers_kernel, dim3((H + 63) / 64, 6, 8 * layers), dim3(256), 0, st, pa, pb, layer_stride, nblk, H, dst, acc);
+    if (H % 4) return MB_ERR_SHAPE;
+    hipLaunchKernelGGL(ln_reduce_layers_kernel, dim3((H + 255) / 256, 6, 8 * layers), dim3(256), 0, st, pa, pb, layer_stride, nblk, H, dst, acc);
     return (int)hipGetLastError();
 }
 
@@ -588,18 +593,39 @@ __global__ void __launch_bounds__(256) step_prologue_kernel(const PrologueArgs a
         }
         if (a.adam_dst && threadIdx.x < 2) a.adam_dst[threadIdx.x] = a.adam[threadIdx.x];
     }
+    if (tid == 0 && a.zero_dw) *a.zero_dw = 0u;
+    // The sources may be pinned host memory: every 16-byte load of a pass is issued before the first store, so a thread pays ONE
+    // round trip across PCIe for its pieces of all copies (copy after copy: one round trip per copy, 6 per step).
+    size_t most4 = 0;
+    bool fast = true;
+    for (int c = 0; c < MB_PROLOGUE_MAX_COPIES; ++c)
+        if (c < a.ncopies) {
+            fast = fast && ((((uintptr_t)a.src[c] | (uintptr_t)a.dst[c]) & 15) == 0);
+            if (a.dwords[c] / 4 > most4) most4 = a.dwords[c] / 4;
+        }
+    if (fast) {                                     // uniform
+        for (size_t i = tid; i < most4; i += nth) {
+            u32x4 v[MB_PROLOGUE_MAX_COPIES];
+#pragma unroll
+            for (int c = 0; c < MB_PROLOGUE_MAX_COPIES; ++c)
+                if (c < a.ncopies && i < a.dwords[c] / 4) v[c] = __builtin_nontemporal_load((const u32x4*)a.src[c] + i);
+#pragma unroll
+            for (int c = 0; c < MB_PROLOGUE_MAX_COPIES; ++c)
+                if (c < a.ncopies && i < a.dwords[c] / 4) ((u32x4*)a.dst[c])[i] = v[c];
+        }
+#pragma unroll 1
+        for (int c = 0; c < a.ncopies; ++c) {
+            const size_t n = a.dwords[c];
+            for (size_t i = (n / 4) * 4 + tid; i < n; i += nth) a.dst[c][i] = a.src[c][i];
+        }
+        return;
+    }
 #pragma unroll 1
     for (int c = 0; c < a.ncopies; ++c) {
         const uint32_t* __restrict__ src = a.src[c];
         uint32_t* __restrict__ dst = a.dst[c];
         const size_t n = a.dwords[c];
-        if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
-            const size_t n4 = n / 4;
-            for (size_t i = tid; i < n4; i += nth) ((u32x4*)dst)[i] = ((const u32x4*)src)[i];
-            for (size_t i = n4 * 4 + tid; i < n; i += nth) dst[i] = src[i];
-        } else {
-            for (size_t i = tid; i < n; i += nth) dst[i] = src[i];
-        }
+        for (size_t i = tid; i < n; i += nth) dst[i] = src[i];
     }
 }
 

@@ -159,7 +159,7 @@ static void xl_build_layout(mb_xlnet_engine* e) {
     e->ws_demb = w.take(T * H * 4);
     e->ws_dz = w.take((size_t)c.max_batch * H * es); e->ws_dxs = w.take((size_t)c.max_batch * H * es);
     e->lnp_stride = ln_partials_floats((int)T, (int)H);        // per-layer slabs: the single-call step reduces all layers at once
-    e->ws_lnp_a = w.take(e->lnp_stride * 4 * c.n_layer); e->ws_lnp_b = w.take(e->lnp_stride * 4 * c.n_layer);
+    e->ws_lnp_a = w.take(e->lnp_stride * 4 * (c.n_layer + 1)); e->ws_lnp_b = w.take(e->lnp_stride * 4 * (c.n_layer + 1));      // (+1: MAG's gate)
     e->carve_step(w, T, (int)V, (int)A, c.max_batch, c.num_labels, XS_LAYER0 + 8 * c.n_layer);
     e->ws_bytes = w.off;
 }
@@ -180,6 +180,7 @@ static int xl_prepare_pass(mb_xlnet_engine* e, int T, hipStream_t st) {
             return rows_p > rows ? (int)hipMemsetAsync(ws + off + rows * cols * es, 0, (rows_p - rows) * cols * es, st) : 0;
         };
         CK(zp(e->ws_magout, H, T, Tp)); CK(zp(e->ws_pos, H, R, Rp));
+        CK(mag_clear_pad_rows(c.dtype, ws + e->ws_mag, e->mw, T, (int)H, st));
         for (int l = 0; l <= c.n_layer; ++l) CK(zp(e->ws_x[l], H, T, Tp));
         for (int l = 0; l < c.n_layer; ++l) { CK(zp(e->lw[l].vec, H, T, Tp)); CK(zp(e->lw[l].y1, H, T, Tp)); CK(zp(e->lw[l].g, I, T, Tp)); }
         for (int k = 0; k < 2; ++k) {
@@ -284,7 +285,7 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
             CK(mag_fwd_impl(dt, xin, visual, acoustic, P + e->mag_whv, P + e->mag_bhv, P + e->mag_wha, P + e->mag_bha,
                             P + e->mag_wv, P + e->mag_bv, P + e->mag_wa, P + e->mag_ba, P + e->mag_lnw, P + e->mag_lnb,
                             c.mag_layer_norm_eps, c.beta_shift, e->key(XS_MAG, c.mag_dropout), ws + e->ws_magout,
-                            ws + e->ws_mag, e->mw, T, H, c.visual_dim, c.acoustic_dim, true, st));
+                            ws + e->ws_mag, e->mw, T, H, c.visual_dim, c.acoustic_dim, true, st, true));
             xin = ws + e->ws_magout;
         }
         char* qkv = ws + w.qkv;
@@ -321,7 +322,7 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
     float* z = (float*)(ws + e->ws_head_z);
     CK(gemm(dt, GEMM_NT, EPI_BIAS_F32, B, H, H, ws + e->ws_xs, H, e->W(e->wsum), H, nullptr, H, nullptr, z, P + e->bsum, nullptr, 0,
             kNoDrop, 1, 64, st));
-    if (loss) CK(zero_fill(loss, 4, st));
+    if (loss && !(e->in_step && e->loss_cleared)) CK(zero_fill(loss, 4, st));
     CK(head_forward(z, P + e->wc, P + e->bc, labels, (float*)(ws + e->ws_head_pooled), logits, loss, loss_run, B, H, c.num_labels,
                     e->key(XS_HEAD, c.summary_last_dropout), st));
     return MB_OK;
@@ -345,13 +346,12 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
     for (int stage = stage_begin; stage < stage_end; ++stage) {
         if (stage == 0) {
             CK(head_backward(dt, dlogits, e->logits, labels, loss_scale, (const float*)(ws + e->ws_head_pooled), P + e->wc,
-                             ws + e->ws_dz, G + e->wc, G + e->bc, B, H, c.num_labels, e->key(XS_HEAD, c.summary_last_dropout), st));
+                             ws + e->ws_dz, G + e->wc, G + e->bc, B, H, c.num_labels, e->key(XS_HEAD, c.summary_last_dropout), st,
+                             GradAcc{}, G + e->bsum, ws + e->ws_dxa, (size_t)T * H * es));     // + summary bias gradient, + dx cleared
             CK(gemm(dt, GEMM_TN, EPI_ACCUM_F32, H, H, B, ws + e->ws_dz, H, ws + e->ws_xs, H, nullptr, H, nullptr, G + e->wsum, nullptr,
                     nullptr, 0, kNoDrop, 1, 64, st));
-            CK(colsum(dt, ws + e->ws_dz, H, G + e->bsum, B, H, st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, B, H, H, ws + e->ws_dz, H, e->W(e->wsum), H, ws + e->ws_dxs, H, nullptr, nullptr, nullptr,
                     nullptr, 0, kNoDrop, 1, 64, st));
-            CK(zero_fill(ws + e->ws_dxa, (size_t)T * H * es, st));
             CK(last_token_backward(dt, ws + e->ws_dxs, ws + e->ws_dxa, B, L, H, e->key(XS_FINAL, pd), st));
         } else if (stage <= NL) {
             const int l = NL - stage;
@@ -370,7 +370,8 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
             int nblk = 0;
             float* lnp_a = (float*)(ws + e->ws_lnp_a) + (size_t)l * e->lnp_stride;
             float* lnp_b = (float*)(ws + e->ws_lnp_b) + (size_t)l * e->lnp_stride;
-            const bool defer_ln = e->in_step && NL <= MB_LN_MAX_LAYERS;      // as in engine.hip: one reduction launch for all layers
+            const bool defer_ln = e->in_step && NL + 1 <= MB_LN_MAX_LAYERS;      // as in engine.hip: one reduction launch for all layers
+            const bool mag_slabs = defer_ln && c.injection_index >= 1 && c.injection_index < NL;     // MAG's backward runs before that launch
             // ---- feed-forward block
             CK(ln_backward_partials(dt, dx, ws + w.s2, P + o.fflnw, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, dsA,
                                     hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(XS_LAYER0 + 8 * l + 3, pd), st));
@@ -405,8 +406,12 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                     float* const d6[6] = {G + ok.fflnw, G + ok.fflnb, G + ok.b2, G + ok.ralnw, G + ok.ralnb, nullptr};
                     for (int q = 0; q < 6; ++q) dst.d[k][q] = d6[q];
                 }
-                CK(ln_reduce_partials_layers((const float*)(ws + e->ws_lnp_a), (const float*)(ws + e->ws_lnp_b), e->lnp_stride, NL, nblk, H,
-                                             dst, st));
+                if (mag_slabs) {         // the six column sums of MAG's gate (mag_bwd_impl below wrote slot NL in the injection layer's stage)
+                    float* const m6[6] = {G + e->mag_bhv, G + e->mag_bha, G + e->mag_bv, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb};
+                    for (int q = 0; q < 6; ++q) dst.d[NL][q] = m6[q];
+                }
+                CK(ln_reduce_partials_layers((const float*)(ws + e->ws_lnp_a), (const float*)(ws + e->ws_lnp_b), e->lnp_stride,
+                                             mag_slabs ? NL + 1 : NL, nblk, H, dst, st));
             }
             if (!grouped) CK(wgrad(dt, H, H, Tk, dzdB, H, ws + w.vec, H, G + o.o, H, st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.o), H, ws + e->ws_dvec, H, nullptr, nullptr, nullptr, nullptr, 0,
@@ -449,11 +454,19 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                         H, kNoDrop, 1, 0, st));
             }
             if (l == c.injection_index) {      // MAG sits in front of this layer
+                int mblk = 0;
                 CK(mag_bwd_impl(dt, dx, ws + e->ws_x[l], P + e->mag_bhv, P + e->mag_bha, P + e->mag_bv, P + e->mag_ba,
                                 P + e->mag_lnw, c.beta_shift, e->key(XS_MAG, c.mag_dropout), ws + e->ws_mag, e->mw, t1, nullptr,
                                 nullptr, G + e->mag_whv, G + e->mag_bhv, G + e->mag_wha, G + e->mag_bha, G + e->mag_wv, G + e->mag_bv,
                                 G + e->mag_wa, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb, T, H, c.visual_dim, c.acoustic_dim, true,
-                                st));
+                                st, GradAcc{}, true, (float*)(ws + e->ws_lnp_a) + (size_t)NL * e->lnp_stride,
+                                (float*)(ws + e->ws_lnp_b) + (size_t)NL * e->lnp_stride, &mblk));
+                if (mag_slabs && mblk != nblk) return MB_ERR_SHAPE;
+                if (!mag_slabs) {        // not a single-call step (or MAG in front of layer 0): reduce MAG's slabs right away
+                    float* const m6[6] = {G + e->mag_bhv, G + e->mag_bha, G + e->mag_bv, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb};
+                    CK(ln_reduce_partials((const float*)(ws + e->ws_lnp_a) + (size_t)NL * e->lnp_stride,
+                                          (const float*)(ws + e->ws_lnp_b) + (size_t)NL * e->lnp_stride, mblk, H, m6, st));
+                }
                 {   // dx <- t1 as a kernel (a captured step holds kernel nodes only)
                     PrologueArgs cp = {};
                     cp.src[0] = (const uint32_t*)t1; cp.dst[0] = (uint32_t*)dx; cp.dwords[0] = (uint32_t)((size_t)T * H * es / 4); cp.ncopies = 1;
@@ -511,7 +524,7 @@ int mb_xlnet_train_step(mb_xlnet_engine* e, const int64_t* input_ids, const floa
     return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
                            labels, B, L, seed, step, logits, loss, loss_run, m, v, lr, beta1, beta2, eps, weight_decay, opt_step,
                            correct_bias, grad_scale, loss_scale, mode, e->prof, st,
-                           [&](float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
+                           [&](int, float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
                                return xl_enqueue_step(e, B, L, lg, ls, lr_, m_, v_, sc, s);
                            });
 }

@@ -676,6 +676,25 @@ def test_deterministic_mode_bf16_runs_are_bit_identical(monkeypatch):
     assert err <= 1e-5
 
 
+def test_optimizer_chunks_on_a_side_stream_change_nothing(monkeypatch):
+    """MB_ADAMW_OVERLAP=C (an experiment kept behind its switch: DESIGN 4.5): the single-call step is cut into linear graphs at
+    every C-th layer of the backward and the AdamW of the finished chunk's GEMM weights runs on a side stream under the backward
+    of the layers below.  Same kernels on the same numbers in another order of launches: in deterministic mode the trajectory
+    (parameters, moments, bf16 shadow) is bit-identical to the plain step, through graph replays, a ragged batch and accumulation."""
+    monkeypatch.setenv("MB_DETERMINISTIC", "1")
+    shapes = ((8, 50), (8, 50), (5, 50), (8, 50))
+    ref = _trajectory(torch.bfloat16, True, nsteps=6, accum=1, layers=4, shapes=shapes)
+    acc_ref = _trajectory(torch.bfloat16, True, nsteps=4, accum=2, layers=4, shapes=((5, 40),))
+    for chunk in ("2", "4", "1"):
+        monkeypatch.setenv("MB_ADAMW_OVERLAP", chunk)
+        run = _trajectory(torch.bfloat16, True, nsteps=6, accum=1, layers=4, shapes=shapes)
+        for k in ("p", "m", "v", "shadow"):
+            assert torch.equal(run[k], ref[k]), "MB_ADAMW_OVERLAP=%s: %s differs from the plain step" % (chunk, k)
+        assert run["stats"][0] == ref["stats"][0]                  # as many captured step variants (each now a chain of graphs)
+    acc = _trajectory(torch.bfloat16, True, nsteps=4, accum=2, layers=4, shapes=((5, 40),))
+    assert torch.equal(acc["p"], acc_ref["p"]) and torch.equal(acc["shadow"], acc_ref["shadow"])
+
+
 def test_known_zero_gradients_are_stored_not_accumulated(monkeypatch):
     """After a step that ran the fused AdamW (which zeroes the gradients) the next backward STORES the layer weight gradients
     instead of adding to them.  Storing into zeros and adding to zeros are the same fp32 numbers, so a model with
