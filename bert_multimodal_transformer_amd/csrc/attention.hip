@@ -29,16 +29,15 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
     drop.resolve();
     typedef AttnCfg<T> C;
     constexpr int PIT = C::ROWB + 16;                 // image pitch (bytes)
-    constexpr int SPIT = LP * (int)sizeof(T) + 16;    // strip pitch
     constexpr int NT = LP / 16;                       // 16-wide tiles along L
     constexpr int DSL = 64 / C::SLAB;                 // k-slabs along d
     constexpr int LSL = LP / C::SLAB;                 // k-slabs along L
-    __shared__ __attribute__((aligned(16))) char smem[3 * LP * PIT + NW * 16 * SPIT + LP * 4];
+    typedef AccOp<T> AO;
+    __shared__ __attribute__((aligned(16))) char smem[3 * LP * PIT + LP * 4];
     char* Qi = smem;
     char* Ki = smem + LP * PIT;
     char* Vi = smem + 2 * LP * PIT;
-    char* strips = smem + 3 * LP * PIT;
-    float* mbias = (float*)(strips + NW * 16 * SPIT);
+    float* mbias = (float*)(smem + 3 * LP * PIT);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x / nh, h = blockIdx.x % nh;
@@ -55,69 +54,59 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
         mbias[j] = j < L ? (1.0f - (float)mask[(size_t)b * L + j]) * kMaskNeg : kPadNeg;
     __syncthreads();
 
-    char* Ps = strips + wave * 16 * SPIT;
     const float scale = 0.125f;
     // head_mask (bert.py:196-209 -> BertSelfAttention): the dropped probabilities of head h are multiplied by head_scale[h]
     const float hs = head_scale ? head_scale[h] : 1.0f;
-    for (int s0 = 0; s0 < NT; s0 += NW) {
-        const int strip = s0 + wave;
-        const bool active = strip < NT;
-        if (active) {
-            f32x4 acc[NT];
+    // every wave owns whole query strips from here on: no barrier, the probabilities never leave the registers (AccOp)
+    for (int strip = wave; strip < NT; strip += NW) {
+        f32x4 acc[NT];
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                acc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int jt = 0; jt < NT; ++jt) {
+            acc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int sl = 0; sl < DSL; ++sl)
-                    mma16(acc[jt], frag_nat<T>(Ki, PIT, jt * 16 + (lane & 15), sl, lane),
-                          frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
-            }
-            // acc[jt][r] = S[i][j], i = strip*16 + (lane&15), j = jt*16 + (lane>>4)*4 + r
-            float mx = -3.0e38f;
+            for (int sl = 0; sl < DSL; ++sl)
+                mma16(acc[jt], frag_nat<T>(Ki, PIT, jt * 16 + (lane & 15), sl, lane),
+                      frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
+        }
+        // acc[jt][r] = S[i][j], i = strip*16 + (lane&15), j = jt*16 + (lane>>4)*4 + r
+        float mx = -3.0e38f;
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                const f32x4 mb4 = *(const f32x4*)(mbias + jt * 16 + (lane >> 4) * 4);
-                acc[jt] = acc[jt] * scale + mb4;
-                mx = fmaxf(mx, fmaxf(fmaxf(acc[jt][0], acc[jt][1]), fmaxf(acc[jt][2], acc[jt][3])));
-            }
-            mx = quad_max(mx);
-            float sum = 0.f;
+        for (int jt = 0; jt < NT; ++jt) {
+            const f32x4 mb4 = *(const f32x4*)(mbias + jt * 16 + (lane >> 4) * 4);
+            acc[jt] = acc[jt] * scale + mb4;
+            mx = fmaxf(mx, fmaxf(fmaxf(acc[jt][0], acc[jt][1]), fmaxf(acc[jt][2], acc[jt][3])));
+        }
+        mx = quad_max(mx);
+        float sum = 0.f;
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt)
+        for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { acc[jt][r] = __expf(acc[jt][r] - mx); sum += acc[jt][r]; }
-            const float inv = 1.0f / quad_sum(sum);
-            const int i = strip * 16 + (lane & 15);
-            const uint32_t rowidx = ((uint32_t)blockIdx.x * L + (uint32_t)i) * L;
+            for (int r = 0; r < 4; ++r) { acc[jt][r] = __expf(acc[jt][r] - mx); sum += acc[jt][r]; }
+        const float inv = 1.0f / quad_sum(sum);
+        const int i = strip * 16 + (lane & 15);
+        const uint32_t rowidx = ((uint32_t)blockIdx.x * L + (uint32_t)i) * L;
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                const int j = jt * 16 + (lane >> 4) * 4;
-                f32x4 p = acc[jt] * inv;
+        for (int jt = 0; jt < NT; ++jt) {
+            const int j = jt * 16 + (lane >> 4) * 4;
+            f32x4 p = acc[jt] * inv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p[r] *= drop_mult(drop, rowidx + j + r) * hs;
-                store4((T*)(Ps + (lane & 15) * SPIT) + j, p);
-                if (probs && i < L) {           // output_attentions (bert.py:147-151): the probabilities after dropout, fp32
+            for (int r = 0; r < 4; ++r) p[r] *= drop_mult(drop, rowidx + j + r) * hs;
+            acc[jt] = p;                   // the dropped probabilities: operand of P.V below
+            if (probs && i < L) {           // output_attentions (bert.py:147-151): the probabilities after dropout, fp32
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (j + r < L) probs[(size_t)rowidx + j + r] = p[r];
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (j + r < L) probs[(size_t)rowidx + j + r] = p[r];
             }
         }
-        __syncthreads();
-        if (active) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int sl = 0; sl < LSL; ++sl)
-                    mma16(o, frag_kmaj(Vi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
-                          frag_nat<T>(Ps, SPIT, lane & 15, sl, lane));
-                // o[r] = ctx[i = strip*16 + (lane&15)][d = dt*16 + (lane>>4)*4 + r]
-                const int i = strip * 16 + (lane & 15);
-                if (i < L) store4(ctx + ((size_t)b * L + i) * H + h * 64 + dt * 16 + (lane >> 4) * 4, o);
-            }
+            for (int sl = 0; sl < LSL; ++sl)
+                mma16(o, AO::kmaj(Vi, PIT, sl, dt * 16 + (lane & 15), lane), AO::make(&acc[sl * AO::TILES]));
+            // o[r] = ctx[i = strip*16 + (lane&15)][d = dt*16 + (lane>>4)*4 + r]
+            if (i < L) store4(ctx + ((size_t)b * L + i) * H + h * 64 + dt * 16 + (lane >> 4) * 4, o);
         }
-        __syncthreads();
     }
 }
 
@@ -134,18 +123,19 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
     stamp(0);
     drop.resolve();
     typedef AttnCfg<T> C;
+    typedef AccOp<T> AO;
     constexpr int PIT = C::ROWB + 16;
-    constexpr int SPIT = LP * (int)sizeof(T) + 16;
     constexpr int NT = LP / 16;
     constexpr int DSL = 64 / C::SLAB;
     constexpr int LSL = LP / C::SLAB;
-    __shared__ __attribute__((aligned(16))) char smem[4 * LP * PIT + NW * 16 * SPIT + 4 * LP * 4];
+    // four [row][d] images + the row vectors; the three column-sum tiles of the final flush reuse the Q image (dead by then)
+    __shared__ __attribute__((aligned(16))) char smem[4 * LP * PIT + 4 * LP * 4];
+    static_assert(LP * PIT >= 3 * NW * 64 * 4, "the Q image holds the three column-sum tiles of the flush");
     char* Qi = smem;
     char* Ki = smem + LP * PIT;
     char* Vi = smem + 2 * LP * PIT;
     char* Oi = smem + 3 * LP * PIT;          // dO image
-    char* strips = smem + 4 * LP * PIT;
-    float* mbias = (float*)(strips + NW * 16 * SPIT);
+    float* mbias = (float*)(smem + 4 * LP * PIT);
     float* rmax = mbias + LP;
     float* rinv = rmax + LP;
     float* rD = rinv + LP;
@@ -164,17 +154,17 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
     for (int j = threadIdx.x; j < LP; j += NW * 64)
         mbias[j] = j < L ? (1.0f - (float)mask[(size_t)b * L + j]) * kMaskNeg : kPadNeg;
     // per-lane running column sums of the dQ / dK / dV tiles this wave produces (its own row only; rows >= L excluded);
-    // reduced over the 16 rows and the waves once, at the end of each sweep
+    // reduced over the 16 rows and the waves once, at the very end
     f32x4 cq[4], ck[4], cv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) cq[dt] = ck[dt] = cv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // Fused QKV bias gradient: ONE reduction + one atomic per column per block, at the very end (the strips are free then).
-    // Flushed after each sweep, the barrier behind every batch of atomics waited for their round trip to L2 -- 8 of the 25 us
-    // of a launch (profiles/r02_attention_phases.txt).
-    auto flush_all = [&]() {                 // called by every thread of the block (uniform), after the last strip barrier
+    // Fused QKV bias gradient: ONE reduction + one atomic per column per block, at the very end.  Flushed after each sweep, the
+    // barrier behind every batch of atomics waited for their round trip to L2 -- 8 of the 25 us of a launch
+    // (profiles/r02_attention_phases.txt).
+    auto flush_all = [&]() {                 // called by every thread of the block (uniform)
         if (dbias == nullptr) return;
-        float* csw = (float*)strips;         // [3][NW][64]
-        static_assert(NW * 16 * SPIT >= 3 * NW * 64 * 4, "the strip buffers hold the three column-sum tiles");
+        __syncthreads();                     // every wave is done with the Q image
+        float* csw = (float*)Qi;             // [3][NW][64]
 #pragma unroll
         for (int which = 0; which < 3; ++which) {
             f32x4 (&c4)[4] = which == 0 ? cq : which == 1 ? ck : cv;
@@ -199,158 +189,123 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
     __syncthreads();
     stamp(1);
 
-    char* St = strips + wave * 16 * SPIT;
     const float scale = 0.125f;
     // head_mask: ctx_h = head_scale[h] * (dropped P) V, so dQ, dK and dV of the head are the unmasked ones times head_scale[h]
     const float hs = head_scale ? head_scale[h] : 1.0f;
     T* dq_base = dqkv + (size_t)b * L * ld + h * 64;
 
     // ------------------------------------------------------------------ sweep A: query strips -> dQ, row stats
-    for (int s0 = 0; s0 < NT; s0 += NW) {
-        const int strip = s0 + wave;
-        const bool active = strip < NT;
-        if (active) {
-            f32x4 sp[NT], dp[NT];
+    // (a wave owns whole strips; dS stays in the accumulator registers and is the operand of dS.K -- AccOp -- so no barrier here)
+    for (int strip = wave; strip < NT; strip += NW) {
+        f32x4 sp[NT], dp[NT];
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                sp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int jt = 0; jt < NT; ++jt) {
+            sp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int sl = 0; sl < DSL; ++sl) {
-                    mma16(sp[jt], frag_nat<T>(Ki, PIT, jt * 16 + (lane & 15), sl, lane),
-                          frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
-                    mma16(dp[jt], frag_nat<T>(Vi, PIT, jt * 16 + (lane & 15), sl, lane),
-                          frag_nat<T>(Oi, PIT, strip * 16 + (lane & 15), sl, lane));
-                }
-            }
-            float mx = -3.0e38f;
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                const f32x4 mb4 = *(const f32x4*)(mbias + jt * 16 + (lane >> 4) * 4);
-                sp[jt] = sp[jt] * scale + mb4;
-                mx = fmaxf(mx, fmaxf(fmaxf(sp[jt][0], sp[jt][1]), fmaxf(sp[jt][2], sp[jt][3])));
-            }
-            mx = quad_max(mx);
-            float sum = 0.f;
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { sp[jt][r] = __expf(sp[jt][r] - mx); sum += sp[jt][r]; }
-            const float inv = 1.0f / quad_sum(sum);
-            const int i = strip * 16 + (lane & 15);
-            const uint32_t rowidx = ((uint32_t)blockIdx.x * L + (uint32_t)i) * L;
-            float dsum = 0.f;
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                const int j = jt * 16 + (lane >> 4) * 4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    sp[jt][r] *= inv;                                   // P_ij
-                    dp[jt][r] *= drop_mult(drop, rowidx + j + r);       // dP_ij (through the dropout)
-                    dsum += dp[jt][r] * sp[jt][r];
-                }
-            }
-            const float D = quad_sum(dsum);
-            if ((lane >> 4) == 0) { rmax[i] = mx; rinv[i] = inv; rD[i] = D; }
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                const int j = jt * 16 + (lane >> 4) * 4;
-                const f32x4 ds = sp[jt] * (dp[jt] - D) * scale;
-                store4((T*)(St + (lane & 15) * SPIT) + j, ds);
+            for (int sl = 0; sl < DSL; ++sl) {
+                mma16(sp[jt], frag_nat<T>(Ki, PIT, jt * 16 + (lane & 15), sl, lane),
+                      frag_nat<T>(Qi, PIT, strip * 16 + (lane & 15), sl, lane));
+                mma16(dp[jt], frag_nat<T>(Vi, PIT, jt * 16 + (lane & 15), sl, lane),
+                      frag_nat<T>(Oi, PIT, strip * 16 + (lane & 15), sl, lane));
             }
         }
-        __syncthreads();
-        if (active) {
+        float mx = -3.0e38f;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int jt = 0; jt < NT; ++jt) {
+            const f32x4 mb4 = *(const f32x4*)(mbias + jt * 16 + (lane >> 4) * 4);
+            sp[jt] = sp[jt] * scale + mb4;
+            mx = fmaxf(mx, fmaxf(fmaxf(sp[jt][0], sp[jt][1]), fmaxf(sp[jt][2], sp[jt][3])));
+        }
+        mx = quad_max(mx);
+        float sum = 0.f;
 #pragma unroll
-                for (int sl = 0; sl < LSL; ++sl)
-                    mma16(o, frag_kmaj(Ki, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
-                          frag_nat<T>(St, SPIT, lane & 15, sl, lane));
-                o = o * hs;
-                const int i = strip * 16 + (lane & 15);
-                if (i < L) store4(dq_base + (size_t)i * ld + dt * 16 + (lane >> 4) * 4, o);
-                if (i < L) cq[dt] += o;
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sp[jt][r] = __expf(sp[jt][r] - mx); sum += sp[jt][r]; }
+        const float inv = 1.0f / quad_sum(sum);
+        const int i = strip * 16 + (lane & 15);
+        const uint32_t rowidx = ((uint32_t)blockIdx.x * L + (uint32_t)i) * L;
+        float dsum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            const int j = jt * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sp[jt][r] *= inv;                                   // P_ij
+                dp[jt][r] *= drop_mult(drop, rowidx + j + r);       // dP_ij (through the dropout)
+                dsum += dp[jt][r] * sp[jt][r];
             }
         }
-        __syncthreads();
+        const float D = quad_sum(dsum);
+        if ((lane >> 4) == 0) { rmax[i] = mx; rinv[i] = inv; rD[i] = D; }
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) sp[jt] = sp[jt] * (dp[jt] - D) * scale;      // dS_ij
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sl = 0; sl < LSL; ++sl)
+                mma16(o, AO::kmaj(Ki, PIT, sl, dt * 16 + (lane & 15), lane), AO::make(&sp[sl * AO::TILES]));
+            o = o * hs;
+            if (i < L) store4(dq_base + (size_t)i * ld + dt * 16 + (lane >> 4) * 4, o);
+            if (i < L) cq[dt] += o;
+        }
     }
-
+    __syncthreads();          // the row statistics of every strip are in LDS
     stamp(2);
     stamp(3);
 
     // ------------------------------------------------------------------ sweep B: key strips -> dV, dK
-    for (int s0 = 0; s0 < NT; s0 += NW) {
-        const int strip = s0 + wave;
-        const bool active = strip < NT;
+    for (int strip = wave; strip < NT; strip += NW) {
         f32x4 sp[NT], dp[NT];
         const int j = strip * 16 + (lane & 15);          // this lane's key
-        if (active) {
 #pragma unroll
-            for (int it = 0; it < NT; ++it) {
-                sp[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < NT; ++it) {
+            sp[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[it] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int sl = 0; sl < DSL; ++sl) {
-                    mma16(sp[it], frag_nat<T>(Qi, PIT, it * 16 + (lane & 15), sl, lane),
-                          frag_nat<T>(Ki, PIT, strip * 16 + (lane & 15), sl, lane));
-                    mma16(dp[it], frag_nat<T>(Oi, PIT, it * 16 + (lane & 15), sl, lane),
-                          frag_nat<T>(Vi, PIT, strip * 16 + (lane & 15), sl, lane));
-                }
-            }
-            // sp[it][r] = S[i][j] (pre-scale), dp[it][r] = (dO V^T)[i][j],  i = it*16 + (lane>>4)*4 + r
-            const float mbj = mbias[j];
-#pragma unroll
-            for (int it = 0; it < NT; ++it) {
-                const int i0 = it * 16 + (lane >> 4) * 4;
-                f32x4 pd;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = i0 + r;
-                    const float p = __expf(sp[it][r] * scale + mbj - rmax[i]) * rinv[i];
-                    const float dm = drop_mult(drop, ((uint32_t)blockIdx.x * L + (uint32_t)i) * L + (uint32_t)j);
-                    pd[r] = p * dm;                                        // dropped P^T -> dV
-                    sp[it][r] = p * (dp[it][r] * dm - rD[i]) * scale;      // dS^T       -> dK
-                }
-                store4((T*)(St + (lane & 15) * SPIT) + i0, pd);
+            for (int sl = 0; sl < DSL; ++sl) {
+                mma16(sp[it], frag_nat<T>(Qi, PIT, it * 16 + (lane & 15), sl, lane),
+                      frag_nat<T>(Ki, PIT, strip * 16 + (lane & 15), sl, lane));
+                mma16(dp[it], frag_nat<T>(Oi, PIT, it * 16 + (lane & 15), sl, lane),
+                      frag_nat<T>(Vi, PIT, strip * 16 + (lane & 15), sl, lane));
             }
         }
-        __syncthreads();
-        if (active) {
+        // sp[it][r] = S[i][j] (pre-scale), dp[it][r] = (dO V^T)[i][j],  i = it*16 + (lane>>4)*4 + r
+        const float mbj = mbias[j];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < NT; ++it) {
+            const int i0 = it * 16 + (lane >> 4) * 4;
 #pragma unroll
-                for (int sl = 0; sl < LSL; ++sl)
-                    mma16(o, frag_kmaj(Oi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
-                          frag_nat<T>(St, SPIT, lane & 15, sl, lane));
-                o = o * hs;
-                if (j < L) store4(dq_base + (size_t)j * ld + 2 * H + dt * 16 + (lane >> 4) * 4, o);
-                if (j < L) cv[dt] += o;
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + r;
+                const float p = __expf(sp[it][r] * scale + mbj - rmax[i]) * rinv[i];
+                const float dm = drop_mult(drop, ((uint32_t)blockIdx.x * L + (uint32_t)i) * L + (uint32_t)j);
+                sp[it][r] = p * (dp[it][r] * dm - rD[i]) * scale;      // dS^T       -> dK
+                dp[it][r] = p * dm;                                    // dropped P^T -> dV
             }
         }
-        __syncthreads();
-        if (active) {
 #pragma unroll
-            for (int it = 0; it < NT; ++it)
-                store4((T*)(St + (lane & 15) * SPIT) + it * 16 + (lane >> 4) * 4, sp[it]);
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sl = 0; sl < LSL; ++sl)
+                mma16(o, AO::kmaj(Oi, PIT, sl, dt * 16 + (lane & 15), lane), AO::make(&dp[sl * AO::TILES]));
+            o = o * hs;
+            if (j < L) store4(dq_base + (size_t)j * ld + 2 * H + dt * 16 + (lane >> 4) * 4, o);
+            if (j < L) cv[dt] += o;
         }
-        __syncthreads();
-        if (active) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int sl = 0; sl < LSL; ++sl)
-                    mma16(o, frag_kmaj(Qi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
-                          frag_nat<T>(St, SPIT, lane & 15, sl, lane));
-                o = o * hs;
-                if (j < L) store4(dq_base + (size_t)j * ld + H + dt * 16 + (lane >> 4) * 4, o);
-                if (j < L) ck[dt] += o;
-            }
+            for (int sl = 0; sl < LSL; ++sl)
+                mma16(o, AO::kmaj(Qi, PIT, sl, dt * 16 + (lane & 15), lane), AO::make(&sp[sl * AO::TILES]));
+            o = o * hs;
+            if (j < L) store4(dq_base + (size_t)j * ld + H + dt * 16 + (lane >> 4) * 4, o);
+            if (j < L) ck[dt] += o;
         }
-        __syncthreads();
     }
     stamp(4);
     flush_all();

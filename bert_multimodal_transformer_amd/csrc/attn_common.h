@@ -33,6 +33,41 @@ __device__ __forceinline__ f32x4 frag_kmaj(const char* img, int pitch, int k0, i
     return v;
 }
 
+// ---- products whose reduction index is the COLUMN index of an accumulator tile, without a round trip through LDS -----------
+// After S^T-shaped tiles acc[t][r] = X[row = t*16 + (lane>>4)*4 + r][col = lane & 15] (mma16's layout) the next product sums over
+// `row` (P.V over the keys, dS.K, Pd^T.dO, dS^T.Q).  An MFMA's k index is only a label: both operands just have to agree on which
+// k slot holds which row.  So the lane's own accumulator values ARE its operand fragment -- bf16: slots 0..3 <- tile 2*sl, slots
+// 4..7 <- tile 2*sl+1 (rows 2sl*16 + g*4 + r and (2sl+1)*16 + g*4 + r, g = lane >> 4); fp32 (16-wide slabs): tile sl as it is --
+// and the k-major fragment of the other operand is read with the same row order (two transpose reads from two row groups).
+// Before: every tile stored to a per-wave LDS strip, a barrier, and 16-byte reads back (3 strips and 6 barriers per backward strip).
+template <class T> struct AccOp;
+template <> struct AccOp<bf16> {
+    static constexpr int TILES = 2;                                   // accumulator tiles per k-slab of 32
+    static __device__ __forceinline__ bf16x8 make(const f32x4* t) {    // t[0], t[1]: tiles 2*sl, 2*sl+1
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = from_f<bf16>(t[0][e]); v[4 + e] = from_f<bf16>(t[1][e]); }
+        return v;
+    }
+    // element e of the fragment = img[row(e)][col], row(e) as above; col = c0 + (lane & 15), c0 a multiple of 16
+    static __device__ __forceinline__ bf16x8 kmaj(const char* img, int pitch, int sl, int col, int lane) {
+        typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+        const int t = col & 15, g = lane >> 4;
+        const char* a = img + ((2 * sl) * 16 + g * 4 + (t >> 2)) * pitch + ((col - t) + (t & 3) * 4) * 2;
+        union { s16x4_t h[2]; bf16x8 v; } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(__attribute__((address_space(3))) char*)a);
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(__attribute__((address_space(3))) char*)(a + 16 * pitch));
+        return u.v;
+    }
+};
+template <> struct AccOp<float> {
+    static constexpr int TILES = 1;
+    static __device__ __forceinline__ f32x4 make(const f32x4* t) { return t[0]; }
+    static __device__ __forceinline__ f32x4 kmaj(const char* img, int pitch, int sl, int col, int lane) {
+        return frag_kmaj(img, pitch, sl * 16 + (lane >> 4) * 4, col, float());
+    }
+};
+
 // stage rows [0, LP) x 64 elements of one head from the token-major tensor into an LDS image (rows >= L are zero)
 template <class T, int LP, int NTHR>
 __device__ __forceinline__ void stage_head(char* img, int pitch, const T* __restrict__ src, size_t ld, int L) {
