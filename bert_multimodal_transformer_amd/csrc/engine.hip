@@ -140,6 +140,11 @@ static void build_layout(mb_bert_engine* e) {
     Carver w;
     e->mw.init(c.dtype, (int)T, (int)H, (int)V, (int)A);
     e->ws_mag = w.take(e->mw.bytes);
+    {   // MB_PROLOGUE_PACK=0: the step prologue stages the fp32 modality tensors and the forward packs them (two more launches)
+        const char* pv = getenv("MB_PROLOGUE_PACK");
+        e->pk_enable = !(pv && atoi(pv) == 0);
+        e->pk_vis = e->ws_mag + e->mw.vp; e->pk_aco = e->ws_mag + e->mw.ap; e->pk_Vp = e->mw.Vp; e->pk_Ap = e->mw.Ap; e->pk_dtype = c.dtype;
+    }
     e->ws_emb = w.take(T * H * es);
     e->ws_emb_st = w.take(2 * T * 4);
     e->ws_x.resize(c.num_layers + 1);
@@ -162,7 +167,7 @@ static void build_layout(mb_bert_engine* e) {
     e->ws_dctx = w.take(T * H * es); e->ws_dsum = w.take(T * H * 4); e->ws_dz = w.take((size_t)c.max_batch * H * es);
     // LayerNorm partial slabs of EVERY layer (2 x 2.8 MB per layer at T = 2400): the single-call step reduces them in one launch
     e->lnp_stride = ln_partials_floats((int)T, (int)H);
-    e->ws_lnp_a = w.take(e->lnp_stride * 4 * (c.num_layers + 1)); e->ws_lnp_b = w.take(e->lnp_stride * 4 * (c.num_layers + 1));     // (+1: MAG's gate)
+    e->ws_lnp_a = w.take(e->lnp_stride * 4 * (c.num_layers + 2)); e->ws_lnp_b = w.take(e->lnp_stride * 4 * (c.num_layers + 1));     // (+1: MAG's gate, +1 in set a: the embedding LayerNorm)
     e->carve_step(w, T, (int)V, (int)A, c.max_batch, c.num_labels, SITE_LAYER0 + 4 * c.num_layers);
     if (e->deterministic) {          // shadow accumulator of everything behind the layers' GEMM weights (those have ONE writer per element)
         e->det_begin = e->wp; e->det_end = e->n_params;
@@ -450,7 +455,7 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     CK(mag_fwd_impl(dt, ws + e->ws_emb, visual, acoustic, P + e->mag_whv, P + e->mag_bhv, P + e->mag_wha, P + e->mag_bha,
                     P + e->mag_wv, P + e->mag_bv, P + e->mag_wa, P + e->mag_ba, P + e->mag_lnw, P + e->mag_lnb,
                     c.mag_layer_norm_eps, c.beta_shift, e->key(SITE_MAG, c.mag_dropout), ws + e->ws_x[0], ws + e->ws_mag,
-                    e->mw, T, H, c.visual_dim, c.acoustic_dim, true, st, true));
+                    e->mw, T, H, c.visual_dim, c.acoustic_dim, true, st, true, e->in_step && e->packed));
     // encoder (bert.py:221-229)
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerOff& o = e->lo[l];
@@ -542,7 +547,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             float* lnp_a = (float*)(ws + e->ws_lnp_a) + (size_t)l * e->lnp_stride;
             float* lnp_b = (float*)(ws + e->ws_lnp_b) + (size_t)l * e->lnp_stride;
             // single-call step: nobody needs this layer's LayerNorm / bias gradients before AdamW -> all layers reduced at once
-            const bool defer_ln = e->in_step && !e->stage_mode && NL + 1 <= MB_LN_MAX_LAYERS;      // (reduced in the last stage)
+            const bool defer_ln = e->in_step && !e->stage_mode && NL + 2 <= MB_LN_MAX_LAYERS;      // (reduced in the last stage)
             // LN2 + dropout backward (column sums -> per-block partial slabs, reduced once per layer below)
             CK(ln_backward_partials(dt, dx, ws + w.s2, P + o.ln2w, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, dsA,
                                     hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(SITE_LAYER0 + 4 * l + 2, c.hidden_dropout), st));
@@ -623,7 +628,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             char* de = ws + e->ws_dxb;
             // single-call step: the six column sums of MAG's gate go to partial slabs like the LayerNorm ones, and ONE launch reduces
             // every layer's and MAG's slabs (nobody needs these small gradients before AdamW)
-            const bool defer_ln = e->in_step && !e->stage_mode && NL + 1 <= MB_LN_MAX_LAYERS && NL > 0;
+            const bool defer_ln = e->in_step && !e->stage_mode && NL + 2 <= MB_LN_MAX_LAYERS && NL > 0;
             float* mpa = (float*)(ws + e->ws_lnp_a) + (size_t)NL * e->lnp_stride;
             float* mpb = (float*)(ws + e->ws_lnp_b) + (size_t)NL * e->lnp_stride;
             int mblk = 0;
@@ -632,26 +637,31 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                             nullptr, G + e->mag_whv, G + e->mag_bhv, G + e->mag_wha, G + e->mag_bha, G + e->mag_wv,
                             G + e->mag_bv, G + e->mag_wa, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb, T, H, c.visual_dim,
                             c.acoustic_dim, true, st, acc, true, mpa, mpb, &mblk));
-            if (!defer_ln) {       // the same slabs, the same summation order (deterministic mode: bit-identical to the single-call step)
-                float* const m6[6] = {G + e->mag_bhv, G + e->mag_bha, G + e->mag_bv, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb};
-                CK(ln_reduce_partials(mpa, mpb, mblk, H, m6, st, acc));
-            } else {
-                if (mblk != e->lnp_nblk) return MB_ERR_SHAPE;       // (both kernels take 8 token rows per block)
-                LnReduceDst dst = {};
-                for (int k = 0; k < NL; ++k) {
-                    const LayerOff& ok = e->lo[k];
-                    float* const d6[6] = {G + ok.ln2w, G + ok.ln2b, G + ok.b2, G + ok.ln1w, G + ok.ln1b, G + ok.bo};
-                    for (int q = 0; q < 6; ++q) dst.d[k][q] = d6[q];
-                }
-                float* const m6[6] = {G + e->mag_bhv, G + e->mag_bha, G + e->mag_bv, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb};
-                for (int q = 0; q < 6; ++q) dst.d[NL][q] = m6[q];
-                CK(ln_reduce_partials_layers((const float*)(ws + e->ws_lnp_a), (const float*)(ws + e->ws_lnp_b), e->lnp_stride, NL + 1, mblk, H,
-                                             dst, st, acc));
-            }
+            int eblk = 0;
             CK(embed_ln_backward(dt, de, e->ids, e->seg, e->ids ? P + e->word : e->emb_in, P + e->pos, P + e->type, P + e->emb_lnw,
                                  (const float*)(ws + e->ws_emb_st), (const float*)(ws + e->ws_emb_st) + T,
                                  (float*)(ws + e->ws_dsum), e->ids ? G + e->word : nullptr, G + e->pos, G + e->type, G + e->emb_lnw,
-                                 G + e->emb_lnb, B, L, H, c.pad_token_id, e->key(SITE_EMB, c.hidden_dropout), st, e->pos_ids, acc));
+                                 G + e->emb_lnb, B, L, H, c.pad_token_id, e->key(SITE_EMB, c.hidden_dropout), st, e->pos_ids, acc,
+                                 (float*)(ws + e->ws_lnp_a) + (size_t)(NL + 1) * e->lnp_stride, &eblk));
+            {
+                // ONE reduction launch: every layer's LayerNorm / bias slabs (single-call step only: the other modes reduced them per
+                // layer, their stage hooks need them early), MAG's six sums (slot NL) and the embedding LayerNorm's two (slot NL + 1).
+                // Same slabs and summation order in every mode (deterministic mode: bit-identical trajectories across the modes).
+                if (eblk != mblk || (defer_ln && mblk != e->lnp_nblk)) return MB_ERR_SHAPE;       // (all three kernels: 8 token rows per block)
+                const int first = defer_ln ? 0 : NL;
+                LnReduceDst dst = {};
+                for (int k = first; k < NL; ++k) {
+                    const LayerOff& ok = e->lo[k];
+                    float* const d6[6] = {G + ok.ln2w, G + ok.ln2b, G + ok.b2, G + ok.ln1w, G + ok.ln1b, G + ok.bo};
+                    for (int q = 0; q < 6; ++q) dst.d[k - first][q] = d6[q];
+                }
+                float* const m6[6] = {G + e->mag_bhv, G + e->mag_bha, G + e->mag_bv, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb};
+                for (int q = 0; q < 6; ++q) dst.d[NL - first][q] = m6[q];
+                dst.d[NL + 1 - first][0] = G + e->emb_lnw; dst.d[NL + 1 - first][1] = G + e->emb_lnb;   // (rows 0 / 1 of set a; the rest of the slot: no destination)
+                CK(ln_reduce_partials_layers((const float*)(ws + e->ws_lnp_a) + (size_t)first * e->lnp_stride,
+                                             (const float*)(ws + e->ws_lnp_b) + (size_t)first * e->lnp_stride, e->lnp_stride, NL + 2 - first,
+                                             mblk, H, dst, st, acc));
+            }
             // deterministic mode: the integer sums become part of the fp32 gradients before anybody (AdamW, an exchange) reads them
             CK(grad_fold(acc, G, e->det_begin, e->det_end, st));
         }

@@ -61,6 +61,12 @@ struct Carver {
 };
 
 // workspace of the MAG operator: saved activations + scratch (shared by the op-level API and the engine)
+inline int mag_wgrad_tile() {
+    static int t = -1;
+    if (t < 0) { const char* v = getenv("MB_MAG_WGRAD_TILE"); t = (v && atoi(v) == 128) ? 128 : 64; }
+    return t;
+}
+
 struct MagWs {
     int Vp, Ap;
     size_t We, Wv, Wa, vp, ap, Ze, Zv, Za, mean, rstd;                       // forward (saved)
@@ -69,8 +75,12 @@ struct MagWs {
     void init(int dtype, int T_, int H, int V, int A) {
         const size_t es = esize(dtype);
         const size_t T = align_up((size_t)T_, 64);   // token rows padded to the GEMM k-tile (pad rows stay zero)
-        Vp = (V + 63) / 64 * 64;
-        Ap = (A + 63) / 64 * 64;
+        // modality widths padded to the tile of the grouped weight-gradient launch: 64 -- three problems of 288 + 24 + 48 tiles whose
+        // K = T loop of 38 stages is pure latency (35 us for 7 GFLOP).  MB_MAG_WGRAD_TILE=128 (72 + 12 + 12 tiles of 19 stages, one
+        // per CU) was measured SLOWER: ~48 us in the kernel trace, +12 .. 28 us per step (profiles/r03_oneoffs_ab.txt)
+        const int tile = mag_wgrad_tile();
+        Vp = (V + tile - 1) / tile * tile;
+        Ap = (A + tile - 1) / tile * tile;
         Carver c;
         We = c.take((size_t)2 * H * H * es); Wv = c.take((size_t)2 * H * Vp * es); Wa = c.take((size_t)2 * H * Ap * es);
         vp = c.take((size_t)T * Vp * es); ap = c.take((size_t)T * Ap * es);
@@ -150,6 +160,10 @@ struct StepMixin {
     bool dyn = false;              // dropout keys / AdamW scalars are read from device memory (set while a train step is built)
     bool stage_mode = false;       // a stage-driven step is being built: every stage's gradients must be final when the stage returns
     std::vector<StageGraph> stage_graphs;
+    // single-call step: the step prologue converts the two modality tensors straight into MAG's packed GEMM operands (set by the
+    // engines: workspace offsets of the operands); `packed` tells mag_fwd_impl of the step that the pack_pad launches already happened
+    bool pk_enable = false, packed = false;
+    size_t pk_vis = 0, pk_aco = 0; int pk_Vp = 0, pk_Ap = 0, pk_dtype = 0;
     bool loss_cleared = false;     // single-call step: the step prologue clears the loss accumulator (no zero_fill launch in the forward)
     bool capturing = false;        // the stream is in capture mode: nothing outside the captured sequence may be waited for
     int nsites = 0;
@@ -281,14 +295,20 @@ struct StepMixin {
         return k;
     }
     void fill_copies(PrologueArgs& pa, char* ws, const void* ids, const void* vis, const void* aco, const void* mask, const void* seg,
-                     const void* lab, int B, int L, int V, int A, int num_labels) const {
+                     const void* lab, int B, int L, int V, int A, int num_labels, bool pack_modalities = false) const {
         const size_t T = (size_t)B * L;
         auto cp = [&](const void* src, size_t off, size_t bytes) {
             pa.src[pa.ncopies] = (const uint32_t*)src; pa.dst[pa.ncopies] = (uint32_t*)(ws + off); pa.dwords[pa.ncopies] = (uint32_t)(bytes / 4);
             ++pa.ncopies;
         };
         cp(ids, ws_in_ids, T * 8); cp(seg, ws_in_seg, T * 8); cp(mask, ws_in_mask, T * 8);
-        cp(vis, ws_in_vis, T * V * 4); cp(aco, ws_in_aco, T * A * 4);
+        if (pack_modalities) {
+            pa.pack[0] = {(const float*)vis, ws + pk_vis, (int)T, V, pk_Vp, pk_dtype};
+            pa.pack[1] = {(const float*)aco, ws + pk_aco, (int)T, A, pk_Ap, pk_dtype};
+            pa.npack = 2;
+        } else {
+            cp(vis, ws_in_vis, T * V * 4); cp(aco, ws_in_aco, T * A * 4);
+        }
         (void)num_labels;          // one float per sample either way: the regression target (num_labels == 1) or the class index
         if (lab) cp(lab, ws_in_lab, (size_t)B * 4);
     }
@@ -317,7 +337,7 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
     struct Flags {
         E* e; bool ok, with_opt, stale_before;
         ~Flags() {
-            e->in_step = false; e->loss_cleared = false;
+            e->in_step = false; e->loss_cleared = false; e->packed = false;
             e->grads_zero = ok && with_opt;
             e->grads_stale = ok ? (with_opt && e->keep_in_step()) : stale_before;
         }
@@ -327,7 +347,8 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
         return enqueue_inner(sg, lg, ls, lr_, m_, v_, sc, s);
     };
     PrologueArgs pa = {};
-    e->fill_copies(pa, ws, ids, vis, aco, mask, seg, labels, B, L, V, A, num_labels);
+    e->fill_copies(pa, ws, ids, vis, aco, mask, seg, labels, B, L, V, A, num_labels, e->pk_enable);
+    e->packed = e->pk_enable;
     pa.seed = seed; pa.step = step; pa.keys = e->key_state(ws); pa.nsites = e->nsites;
     pa.zero_dw = (uint32_t*)loss; e->loss_cleared = loss != nullptr;
     if (m) {
@@ -404,13 +425,16 @@ inline int mag_fwd_impl(int dtype, const void* text, const float* visual, const 
                  const float* b_hv, const float* W_ha, const float* b_ha, const float* W_v, const float* b_v,
                  const float* W_a, const float* b_a, const float* ln_w, const float* ln_b, float ln_eps, float beta_shift,
                  DropKey drop, void* out, char* ws, const MagWs& w, int T, int H, int V, int A, bool repack, hipStream_t st,
-                 bool pads_clean = false) {
+                 bool pads_clean = false, bool packed = false) {
+    // packed: the step prologue already wrote this batch's packed modality operands (ws + w.vp / w.ap)
     // pads_clean: the caller keeps rows [T, Tp) of the k-major operands zero itself (the engines: mag_clear_pad_rows whenever the
     // token count changes -- no kernel ever writes those rows); the stand-alone operator clears them on every call
     MagDims d = {T, H, V, A, w.Vp, w.Ap};
     if (repack) CK(mag_pack_weights(dtype, W_hv, W_ha, W_v, W_a, ws + w.We, ws + w.Wv, ws + w.Wa, d, st));
-    CK(pack_pad(dtype, visual, V, ws + w.vp, w.Vp, T, st));
-    CK(pack_pad(dtype, acoustic, A, ws + w.ap, w.Ap, T, st));
+    if (!packed) {
+        CK(pack_pad(dtype, visual, V, ws + w.vp, w.Vp, T, st));
+        CK(pack_pad(dtype, acoustic, A, ws + w.ap, w.Ap, T, st));
+    }
     if (!pads_clean) {
         const int Tp = (int)align_up((size_t)T, 64);
         const size_t es = esize(dtype);
@@ -447,7 +471,8 @@ inline int mag_bwd_impl(int dtype, const void* d_out, const void* text, const fl
     GemmArgs wg[3] = {wgrad_args(2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H),
                       wgrad_args(2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp),
                       wgrad_args(2 * H, w.Ap, Tp, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap)};
-    const bool grouped = text_padded && gemm_grouped_tn_ok(dtype, wg, 3, 64);
+    const int wtile = (w.Vp % 128 == 0 && w.Ap % 128 == 0 && H % 128 == 0 && mag_wgrad_tile() == 128 && gemm_grouped_tn_ok(dtype, wg, 3, 128)) ? 128 : 64;
+    const bool grouped = text_padded && gemm_grouped_tn_ok(dtype, wg, 3, wtile);
     {
         // one launch clears the pad rows of this call's k-major operands and (ungrouped path) the packed weight-gradient accumulators
         ZeroRanges z = {};
@@ -468,7 +493,7 @@ inline int mag_bwd_impl(int dtype, const void* d_out, const void* text, const fl
                          ws + w.dZv, ws + w.dZa, db_hv, db_ha, db_v, db_a, dln_w, dln_b, d, drop, st, acc, part_a, part_b, part_nblk));
     if (grouped) {
         for (auto& g : wg) g.overwrite = 1;
-        CK(gemm_grouped_tn_launch(dtype, wg, 3, 64, st));
+        CK(gemm_grouped_tn_launch(dtype, wg, 3, wtile, st));
     } else {
         CK(wgrad(dtype, 2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H, st));
         CK(wgrad(dtype, 2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp, st));

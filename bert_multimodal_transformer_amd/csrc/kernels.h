@@ -107,7 +107,9 @@ int embed_ln_forward(int dtype, const int64_t* ids, const int64_t* seg, const fl
 int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int64_t* seg, const float* word,
                       const float* pos, const float* type, const float* gamma, const float* mean, const float* rstd,
                       float* dsum_ws, float* dword, float* dpos, float* dtype_, float* dgamma, float* dbeta,
-                      int B, int L, int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids = nullptr, GradAcc acc = {});
+                      int B, int L, int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids = nullptr, GradAcc acc = {},
+                      // part: dgamma / dbeta go to rows 0 / 1 of a partial set [nblk][3][H] instead (reduced by ln_reduce_partials*)
+                      float* part = nullptr, int* nblk = nullptr);
 
 // column sums: out[n] += sum_m x[m][n]
 int colsum(int dtype, const void* x, int ldx, float* out, int rows, int cols, hipStream_t st, GradAcc acc = {});
@@ -212,6 +214,10 @@ struct PrologueArgs {
     uint32_t* keys; int nsites;            // keys[2 * site + {0, 1}]
     AdamArgs adam[2]; AdamArgs* adam_dst;  // may be null
     uint32_t* zero_dw;                     // one dword cleared by the launch (the step's loss accumulator), may be null
+    // modality tensors packed on the way in: src fp32 [rows][cols] (device or pinned host) -> dst [rows][pitch] of `dtype` (MAG's
+    // GEMM operands; columns [cols, pitch) are never written and stay zero) -- what pack_pad does, without its two launches
+    struct PackJob { const float* src; void* dst; int rows, cols, pitch, dtype; } pack[2];
+    int npack;
 };
 int step_prologue(const PrologueArgs& a, hipStream_t st);
 // p[0, bytes) = 0 as a kernel launch (bytes and p multiples of 4); up to MB_ZERO_MAX ranges in one launch

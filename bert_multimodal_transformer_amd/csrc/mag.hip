@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) mag_gate_fwd_kernel(const T* __restrict__
 }
 
 template <class T, int CH, int RPW>
-__global__ void __launch_bounds__(256) mag_gate_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ e,
+__global__ void __launch_bounds__(256, 2) mag_gate_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ e,
                                                            const T* __restrict__ Ze, const T* __restrict__ Zv,
                                                            const T* __restrict__ Za, const float* b_hv, const float* b_ha,
                                                            const float* b_v, const float* b_a, const float* __restrict__ gamma,

@@ -61,6 +61,8 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+constexpr int LN_RPW = 2;     // rows per wave in the partial-sum variants (8 rows per block -> 300 blocks at T = 2400)
+
 // shared tail of the backward kernels: reduce per-lane column partials over the block's 4 waves, then atomics.
 template <int CH, int NQ>
 __device__ __forceinline__ void block_colsum_atomic(f32x4 (&part)[NQ][CH], float* const (&dst)[NQ], float* lds, GradAcc acc = {nullptr, nullptr}) {
@@ -248,7 +250,7 @@ __global__ void __launch_bounds__(256) embed_fwd_kernel(const int64_t* __restric
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-template <class T, int CH, int RPW>
+template <class T, int CH, int RPW, bool PARTIAL>
 __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids,
                                                         const int64_t* __restrict__ seg, const float* __restrict__ word,
                                                         const float* __restrict__ pos, const float* __restrict__ type,
@@ -304,8 +306,23 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
             part[1][c] += dyv[c];
         }
     }
-    float* const dst[2] = {dgamma, dbeta};
-    block_colsum_atomic<CH, 2>(part, dst, lds, acc);
+    if constexpr (PARTIAL) {
+        // dgamma points at a partial set [nblk][3][H] (ln_bwd's layout; row 2 unused): this block's slab gets the 4-wave sums of
+        // dgamma / dbeta, no atomics -- the step's ONE reduction launch (ln_reduce_partials_layers) adds them up
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) *(f32x4*)(lds + (wave * 2 + q) * H + (c * 64 + lane) * 4) = part[q][c];
+        __syncthreads();
+        float* slab = dgamma + (size_t)blockIdx.x * 3 * H;
+        for (int i = threadIdx.x; i < 2 * H; i += 256) {
+            const int q = i / H, col = i % H;
+            slab[i] = lds[(0 * 2 + q) * H + col] + lds[(1 * 2 + q) * H + col] + lds[(2 * 2 + q) * H + col] + lds[(3 * 2 + q) * H + col];
+        }
+    } else {
+        float* const dst[2] = {dgamma, dbeta};
+        block_colsum_atomic<CH, 2>(part, dst, lds, acc);
+    }
 }
 
 // position / token-type table grads: block (l, c) sums 256 columns of dsum over the batch (sole owner of that piece of dpos[l]).
@@ -421,7 +438,6 @@ int ln_backward(int dtype, const void* dy, const void* x, const float* gamma, co
     return (int)hipGetLastError();
 }
 
-constexpr int LN_RPW = 2;     // rows per wave in the partial-sum variant (8 rows per block -> 300 blocks at T = 2400)
 size_t ln_partials_floats(int rows, int H) { return (size_t)((rows + 4 * LN_RPW - 1) / (4 * LN_RPW)) * 3 * H; }
 
 int ln_backward_partials(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
@@ -469,15 +485,24 @@ int embed_ln_forward(int dtype, const int64_t* ids, const int64_t* seg, const fl
 int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int64_t* seg, const float* word,
                       const float* pos, const float* type, const float* gamma, const float* mean, const float* rstd,
                       float* dsum_ws, float* dword, float* dpos, float* dtype_, float* dgamma, float* dbeta, int B, int L,
-                      int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids, GradAcc acc) {
+                      int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids, GradAcc acc, float* part, int* nblk) {
     const int rows = B * L;
+    if (nblk) *nblk = (rows + 4 * LN_RPW - 1) / (4 * LN_RPW);
     if (rows <= 0) return MB_OK;
+    if (part != nullptr) {       // dgamma / dbeta as one slab per block of 4 * LN_RPW rows (the block count of ln_backward_partials)
+        MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
+            hipLaunchKernelGGL((embed_bwd_kernel<T, CH, LN_RPW, true>), dim3((rows + 4 * LN_RPW - 1) / (4 * LN_RPW)), dim3(256), 0, st,
+                               (const T*)dout, ids, seg, word, pos, type, gamma, mean, rstd, dsum_ws, dword, part, (float*)nullptr,
+                               rows, L, pad_id, drop, pos_ids, acc);
+        }))
+    } else {
     constexpr int RPW = 4;
     MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
-        hipLaunchKernelGGL((embed_bwd_kernel<T, CH, RPW>), dim3((rows + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st,
+        hipLaunchKernelGGL((embed_bwd_kernel<T, CH, RPW, false>), dim3((rows + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st,
                            (const T*)dout, ids, seg, word, pos, type, gamma, mean, rstd, dsum_ws, dword, dgamma, dbeta,
                            rows, L, pad_id, drop, pos_ids, acc);
     }))
+    }
     hipLaunchKernelGGL(embed_pos_type_kernel, dim3(L, (H + 255) / 256), dim3(256), 0, st, dsum_ws, seg, dpos, dtype_, B, L, H, pos_ids, acc);
     return (int)hipGetLastError();
 }
@@ -594,6 +619,33 @@ __global__ void __launch_bounds__(256) step_prologue_kernel(const PrologueArgs a
         if (a.adam_dst && threadIdx.x < 2) a.adam_dst[threadIdx.x] = a.adam[threadIdx.x];
     }
     if (tid == 0 && a.zero_dw) *a.zero_dw = 0u;
+    for (int k = 0; k < a.npack; ++k) {          // (before the copies: these loads cross PCIe too and should be in flight with them)
+        const PrologueArgs::PackJob& j = a.pack[k];
+        const size_t n = (size_t)j.rows * j.cols;
+        if ((((uintptr_t)j.src) & 15) == 0) {
+            for (size_t i = tid; i < (n + 3) / 4; i += nth) {
+                const size_t e0 = i * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (e0 + 4 <= n) v = __builtin_nontemporal_load((const f32x4*)j.src + i);
+                else for (int r = 0; r < 4; ++r) if (e0 + r < n) v[r] = j.src[e0 + r];
+                size_t row = e0 / j.cols;
+                int c = (int)(e0 - row * j.cols);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (e0 + r < n) {
+                        const size_t d = row * j.pitch + c;
+                        if (j.dtype == DT_BF16) ((bf16*)j.dst)[d] = from_f<bf16>(v[r]); else ((float*)j.dst)[d] = v[r];
+                    }
+                    if (++c == j.cols) { c = 0; ++row; }
+                }
+            }
+        } else {
+            for (size_t e = tid; e < n; e += nth) {
+                const size_t row = e / j.cols, d = row * j.pitch + (e - row * j.cols);
+                if (j.dtype == DT_BF16) ((bf16*)j.dst)[d] = from_f<bf16>(j.src[e]); else ((float*)j.dst)[d] = j.src[e];
+            }
+        }
+    }
     // The sources may be pinned host memory: every 16-byte load of a pass is issued before the first store, so a thread pays ONE
     // round trip across PCIe for its pieces of all copies (copy after copy: one round trip per copy, 6 per step).
     size_t most4 = 0;
@@ -631,7 +683,12 @@ __global__ void __launch_bounds__(256) step_prologue_kernel(const PrologueArgs a
 
 int step_prologue(const PrologueArgs& a, hipStream_t st) {
     if (a.ncopies < 0 || a.ncopies > MB_PROLOGUE_MAX_COPIES || a.nsites < 0 || (a.nsites > 0 && !a.keys)) return MB_ERR_ARG;
+    if (a.npack < 0 || a.npack > 2) return MB_ERR_ARG;
     size_t most = 0;
+    for (int k = 0; k < a.npack; ++k) {
+        if (!a.pack[k].src || !a.pack[k].dst || a.pack[k].cols < 1 || a.pack[k].pitch < a.pack[k].cols) return MB_ERR_ARG;
+        most = std::max(most, (size_t)a.pack[k].rows * a.pack[k].cols);
+    }
     for (int c = 0; c < a.ncopies; ++c) {
         if (a.dwords[c] && (!a.src[c] || !a.dst[c])) return MB_ERR_ARG;
         if (a.dwords[c] > most) most = a.dwords[c];

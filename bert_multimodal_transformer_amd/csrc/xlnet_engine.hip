@@ -135,6 +135,11 @@ static void xl_build_layout(mb_xlnet_engine* e) {
     Carver w;
     e->mw.init(c.dtype, (int)T, (int)H, (int)V, (int)A);
     e->ws_mag = w.take(e->mw.bytes);
+    {   // MB_PROLOGUE_PACK=0: the step prologue stages the fp32 modality tensors and the forward packs them (two more launches)
+        const char* pv = getenv("MB_PROLOGUE_PACK");
+        e->pk_enable = !(pv && atoi(pv) == 0);
+        e->pk_vis = e->ws_mag + e->mw.vp; e->pk_aco = e->ws_mag + e->mw.ap; e->pk_Vp = e->mw.Vp; e->pk_Ap = e->mw.Ap; e->pk_dtype = c.dtype;
+    }
     e->ws_magout = w.take(T * H * es);
     e->ws_pos = w.take(R * H * es);
     e->ws_x.resize(c.n_layer + 1);
@@ -285,7 +290,7 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
             CK(mag_fwd_impl(dt, xin, visual, acoustic, P + e->mag_whv, P + e->mag_bhv, P + e->mag_wha, P + e->mag_bha,
                             P + e->mag_wv, P + e->mag_bv, P + e->mag_wa, P + e->mag_ba, P + e->mag_lnw, P + e->mag_lnb,
                             c.mag_layer_norm_eps, c.beta_shift, e->key(XS_MAG, c.mag_dropout), ws + e->ws_magout,
-                            ws + e->ws_mag, e->mw, T, H, c.visual_dim, c.acoustic_dim, true, st, true));
+                            ws + e->ws_mag, e->mw, T, H, c.visual_dim, c.acoustic_dim, true, st, true, e->in_step && e->packed));
             xin = ws + e->ws_magout;
         }
         char* qkv = ws + w.qkv;
