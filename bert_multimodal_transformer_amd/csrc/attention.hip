@@ -58,6 +58,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
     // head_mask (bert.py:196-209 -> BertSelfAttention): the dropped probabilities of head h are multiplied by head_scale[h]
     const float hs = head_scale ? head_scale[h] : 1.0f;
     // every wave owns whole query strips from here on: no barrier, the probabilities never leave the registers (AccOp)
+#pragma unroll 1
     for (int strip = wave; strip < NT; strip += NW) {
         f32x4 acc[NT];
 #pragma unroll
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
 
 // =============================================================================================== backward
 template <class T, int LP, int NW>
-__global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
+__global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : 1) attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                            const T* __restrict__ dctx, T* __restrict__ dqkv,
                                                            float* __restrict__ dbias,
                                                            const float* __restrict__ head_scale, int L, int nh, DropKey drop,
@@ -196,6 +197,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
 
     // ------------------------------------------------------------------ sweep A: query strips -> dQ, row stats
     // (a wave owns whole strips; dS stays in the accumulator registers and is the operand of dS.K -- AccOp -- so no barrier here)
+#pragma unroll 1
     for (int strip = wave; strip < NT; strip += NW) {
         f32x4 sp[NT], dp[NT];
 #pragma unroll
@@ -257,6 +259,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
     stamp(3);
 
     // ------------------------------------------------------------------ sweep B: key strips -> dV, dK
+#pragma unroll 1
     for (int strip = wave; strip < NT; strip += NW) {
         f32x4 sp[NT], dp[NT];
         const int j = strip * 16 + (lane & 15);          // this lane's key
@@ -379,7 +382,9 @@ int attention_backward(int dtype, const void* qkv, const int64_t* mask, const vo
             case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
             case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
             case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
-            default: return launch_bwd<bf16, 128, 8>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);   // 8 waves: all eight strips of a sweep at once
+            // 8 waves: all eight strips of a sweep at once, one block per CU (222 VGPRs, 76 KB of LDS).  Four waves with two strips each
+            // (two blocks per CU, one round for the 384 blocks of B = 32) need 487 VGPRs, 217 of them spilled when capped at 256: not built.
+            default: return launch_bwd<bf16, 128, 8>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
         }
     } else if (dtype == DT_F32) {
         switch (LP) {

@@ -46,6 +46,9 @@ timeout 60 tools/bin/launch_floor > $O/launch_floor.txt 2>&1
 # same-box A/B of the software-pipelined k loop against the plain loop (-DMB_GEMM_PLAIN_LOOP build, if present)
 [ -f gpurun_ab/plainloop/libmagbert_hip.so ] && REPS=2 bash scripts/gpu_ab.sh plainloop > $O/ab_pipelined_vs_plain.txt 2>&1
 { timeout 60 tools/bin/adamw_bench; MB_ADAMW_VAR=0 timeout 60 tools/bin/adamw_bench; timeout 60 tools/bin/adamw_bench --zero 0; } > $O/adamw_bench.txt 2>&1
+# clocks / power while the step runs (sustained load: what the in-step kernel durations are measured at)
+{ timeout 60 $SB --graph 1 --h2d 2 --steps 3000 --warmup 10 > $O/clocks_step.txt 2>&1 & SBPID=$!
+  sleep 4; for k in 1 2 3; do timeout 10 rocm-smi --showclocks --showpower 2>&1 | grep -E "sclk|mclk|fclk|Power|power" ; echo --; sleep 2; done; wait $SBPID; cat $O/clocks_step.txt; } > $O/clocks_under_load.txt 2>&1
 # ---- 2. C5 shape and a second headline timing from the C++ driver
 { timeout 60 $SB --graph 1 --h2d 2 --steps 40 --warmup 8; timeout 60 $SB --graph 1 --h2d 2 --batch 32 --seq 128 --visual 35 --steps 30 --warmup 6; } > $O/step_bench.txt 2>&1
 ( cd /tmp && rm -rf /tmp/p_c5 && timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c5 -o sb -- $SB --graph 1 --h2d 2 --batch 32 --seq 128 --visual 35 --steps 12 --warmup 4 > /dev/null 2>&1 )
