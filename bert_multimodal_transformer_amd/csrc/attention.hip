@@ -383,7 +383,8 @@ int attention_backward(int dtype, const void* qkv, const int64_t* mask, const vo
             case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
             case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
             // 8 waves: all eight strips of a sweep at once, one block per CU (222 VGPRs, 76 KB of LDS).  Four waves with two strips each
-            // (two blocks per CU, one round for the 384 blocks of B = 32) need 487 VGPRs, 217 of them spilled when capped at 256: not built.
+            // (two blocks per CU, one round for the 384 blocks of B = 32) need 487 VGPRs, 217 of them spilled when capped at 256: not built; this kernel capped at 128 VGPRs
+            // (two 8-wave blocks per CU, 118 registers spilled): 45 us against 36 us (scripts/exp/r3/attn128.sh).
             default: return launch_bwd<bf16, 128, 8>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
         }
     } else if (dtype == DT_F32) {
