@@ -167,7 +167,11 @@ static void build_layout(mb_bert_engine* e) {
     e->ws_dctx = w.take(T * H * es); e->ws_dsum = w.take(T * H * 4); e->ws_dz = w.take((size_t)c.max_batch * H * es);
     // LayerNorm partial slabs of EVERY layer (2 x 2.8 MB per layer at T = 2400): the single-call step reduces them in one launch
     e->lnp_stride = ln_partials_floats((int)T, (int)H);
-    e->ws_lnp_a = w.take(e->lnp_stride * 4 * (c.num_layers + 2)); e->ws_lnp_b = w.take(e->lnp_stride * 4 * (c.num_layers + 1));     // (+1: MAG's gate, +1 in set a: the embedding LayerNorm)
+    {   // the one-launch embedding backward writes max_seq * ceil(max_batch / 8) slabs (more than ceil(T / 8) for batches not a multiple of 8)
+        const size_t emb = (size_t)c.max_seq * ((c.max_batch + 7) / 8) * 3 * H;
+        if (emb > e->lnp_stride) e->lnp_stride = emb;
+    }
+    e->ws_lnp_a = w.take(e->lnp_stride * 4 * (c.num_layers + 2)); e->ws_lnp_b = w.take(e->lnp_stride * 4 * (c.num_layers + 2));     // (+1: MAG's gate, +1: the embeddings)
     e->carve_step(w, T, (int)V, (int)A, c.max_batch, c.num_labels, SITE_LAYER0 + 4 * c.num_layers);
     if (e->deterministic) {          // shadow accumulator of everything behind the layers' GEMM weights (those have ONE writer per element)
         e->det_begin = e->wp; e->det_end = e->n_params;
@@ -642,12 +646,12 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                                  (const float*)(ws + e->ws_emb_st), (const float*)(ws + e->ws_emb_st) + T,
                                  (float*)(ws + e->ws_dsum), e->ids ? G + e->word : nullptr, G + e->pos, G + e->type, G + e->emb_lnw,
                                  G + e->emb_lnb, B, L, H, c.pad_token_id, e->key(SITE_EMB, c.hidden_dropout), st, e->pos_ids, acc,
-                                 (float*)(ws + e->ws_lnp_a) + (size_t)(NL + 1) * e->lnp_stride, &eblk));
+                                 (float*)(ws + e->ws_lnp_a) + (size_t)(NL + 1) * e->lnp_stride, &eblk,
+                                 (float*)(ws + e->ws_lnp_b) + (size_t)(NL + 1) * e->lnp_stride));
             {
                 // ONE reduction launch: every layer's LayerNorm / bias slabs (single-call step only: the other modes reduced them per
                 // layer, their stage hooks need them early), MAG's six sums (slot NL) and the embedding LayerNorm's two (slot NL + 1).
                 // Same slabs and summation order in every mode (deterministic mode: bit-identical trajectories across the modes).
-                if (eblk != mblk || (defer_ln && mblk != e->lnp_nblk)) return MB_ERR_SHAPE;       // (all three kernels: 8 token rows per block)
                 const int first = defer_ln ? 0 : NL;
                 LnReduceDst dst = {};
                 for (int k = first; k < NL; ++k) {
@@ -657,10 +661,14 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                 }
                 float* const m6[6] = {G + e->mag_bhv, G + e->mag_bha, G + e->mag_bv, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb};
                 for (int q = 0; q < 6; ++q) dst.d[NL - first][q] = m6[q];
-                dst.d[NL + 1 - first][0] = G + e->emb_lnw; dst.d[NL + 1 - first][1] = G + e->emb_lnb;   // (rows 0 / 1 of set a; the rest of the slot: no destination)
+                dst.nblk[NL - first] = mblk; dst.nblk[NL + 1 - first] = eblk;         // (their kernels: 8 rows per block; ln_bwd: 16)
+                dst.d[NL + 1 - first][0] = G + e->emb_lnw; dst.d[NL + 1 - first][1] = G + e->emb_lnb;   // (rows 0 / 1 of set a)
+                if (e->pos_ids == nullptr) {       // the one-launch embedding backward: token-type sums in row 2 of set a / row 0 of set b
+                    dst.d[NL + 1 - first][2] = G + e->type; dst.d[NL + 1 - first][3] = G + e->type + H;
+                }
                 CK(ln_reduce_partials_layers((const float*)(ws + e->ws_lnp_a) + (size_t)first * e->lnp_stride,
                                              (const float*)(ws + e->ws_lnp_b) + (size_t)first * e->lnp_stride, e->lnp_stride, NL + 2 - first,
-                                             mblk, H, dst, st, acc));
+                                             e->lnp_nblk, H, dst, st, acc));
             }
             // deterministic mode: the integer sums become part of the fp32 gradients before anybody (AdamW, an exchange) reads them
             CK(grad_fold(acc, G, e->det_begin, e->det_end, st));

@@ -95,7 +95,7 @@ int ln_reduce_partials(const float* partials_a, const float* partials_b, int nbl
 // are dst[l][0..5].  (A single-process step has no use for a layer's LayerNorm / bias gradients before AdamW: twelve 5-us
 // launches become one.)
 #define MB_LN_MAX_LAYERS 32
-struct LnReduceDst { float* d[MB_LN_MAX_LAYERS][6]; };
+struct LnReduceDst { float* d[MB_LN_MAX_LAYERS][6]; int nblk[MB_LN_MAX_LAYERS]; };    // nblk[slot] > 0: that slot's own slab count
 int ln_reduce_partials_layers(const float* partials_a, const float* partials_b, size_t layer_stride, int layers, int nblk, int H,
                               const LnReduceDst& dst, hipStream_t st, GradAcc acc = {});
 
@@ -109,7 +109,10 @@ int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int
                       float* dsum_ws, float* dword, float* dpos, float* dtype_, float* dgamma, float* dbeta,
                       int B, int L, int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids = nullptr, GradAcc acc = {},
                       // part: dgamma / dbeta go to rows 0 / 1 of a partial set [nblk][3][H] instead (reduced by ln_reduce_partials*)
-                      float* part = nullptr, int* nblk = nullptr);
+                      float* part = nullptr, int* nblk = nullptr,
+                      // part_b (with part, default positions only): ONE launch that also produces dpos / dtype; dtype[0] -> row 2 of `part`,
+                      // dtype[1] -> row 0 of `part_b` (the caller's reduction adds them to dtype_), *nblk = L * ceil(B / 8)
+                      float* part_b = nullptr);
 
 // column sums: out[n] += sum_m x[m][n]
 int colsum(int dtype, const void* x, int ldx, float* out, int rows, int cols, hipStream_t st, GradAcc acc = {});

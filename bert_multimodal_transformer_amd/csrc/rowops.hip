@@ -83,8 +83,8 @@ __device__ __forceinline__ void block_colsum_atomic(f32x4 (&part)[NQ][CH], float
 }
 
 // ------------------------------------------------------------------------------------------ LayerNorm backward
-template <class T, int CH, int RPW, bool PARTIAL>
-__global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+template <class T, int CH, int RPW, bool PARTIAL, int NWV = 4>
+__global__ void __launch_bounds__(NWV * 64) ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
                                                      T* __restrict__ dx_drop, float* dgamma, float* dbeta, float* dbias,
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, c
     drop_in.resolve();
     constexpr int H = CH * 256;
     constexpr float invH = 1.0f / H;
-    __shared__ float lds[4 * 3 * H];
+    __shared__ float lds[NWV * 3 * H];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 part[3][CH];
 #pragma unroll
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, c
     // (issuing the loads of all RPW rows ahead of the first reduction was measured: 12.8 vs 8.4 us per launch -- the rolled loop
     //  keeps the block at 124 VGPRs and lets the four waves drift apart, which overlaps their round trips better)
     for (int i = 0; i < RPW; ++i) {
-        const int row = (blockIdx.x * 4 + wave) * RPW + i;
+        const int row = (blockIdx.x * NWV + wave) * RPW + i;
         if (row >= rows) break;
         const float mu = mean[row], rs = rstd[row];
         f32x4 dyv[CH], xh[CH];
@@ -150,13 +150,16 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, c
             for (int c = 0; c < CH; ++c) *(f32x4*)(lds + (wave * 3 + q) * H + (c * 64 + lane) * 4) = part[q][c];
         __syncthreads();
         float* slab = dgamma + (size_t)blockIdx.x * 3 * H;
-        for (int i = threadIdx.x; i < 3 * H; i += 256) {
+        for (int i = threadIdx.x; i < 3 * H; i += NWV * 64) {
             const int q = i / H, col = i % H;
-            slab[i] = lds[(0 * 3 + q) * H + col] + lds[(1 * 3 + q) * H + col] + lds[(2 * 3 + q) * H + col] +
-                      lds[(3 * 3 + q) * H + col];
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) t += lds[(w * 3 + q) * H + col];
+            slab[i] = t;
         }
     } else {
         float* const dst[3] = {dgamma, dbeta, dbias};
+        static_assert(PARTIAL || NWV == 4, "block_colsum_atomic sums four waves");
         block_colsum_atomic<CH, 3>(part, dst, lds);
     }
 }
@@ -189,9 +192,10 @@ __global__ void __launch_bounds__(256) ln_reduce_kernel(const float* __restrict_
 // all layers at once: blockIdx.z = layer * 8 + slab octant; a lane sums FOUR adjacent columns (16-byte loads: a wave reads 1 KB
 // of a slab row; with one column per lane the launch was 24 us for 66 MB)
 __global__ void __launch_bounds__(256) ln_reduce_layers_kernel(const float* __restrict__ pa, const float* __restrict__ pb,
-                                                               size_t layer_stride, int nblk, int H, LnReduceDst dst, GradAcc acc) {
+                                                               size_t layer_stride, int nblk_all, int H, LnReduceDst dst, GradAcc acc) {
     const int q = blockIdx.y;
     const int layer = blockIdx.z >> 3;
+    const int nblk = dst.nblk[layer] > 0 ? dst.nblk[layer] : nblk_all;      // slabs of this slot
     const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int part = (threadIdx.x >> 6) + 4 * (blockIdx.z & 7);
     constexpr int nparts = 32;
@@ -325,6 +329,92 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
     }
 }
 
+// The embedding backward of the engines' default case (position_ids = arange(L)): block (l, g) takes the rows of position l of
+// samples [8g, 8g + 8) -- two per wave -- so that the position-table gradient of l is a sum over the block's own rows: no [T][H]
+// fp32 round trip through dsum_ws and no second launch (embed_pos_type_kernel: 14 us) for dpos / dtype.  Five column sums per
+// block: dgamma, dbeta, dtype[0] (set a of the slab, rows 0..2), dtype[1] (set b, row 0) -> the step's reduction launch; dpos[l]
+// by one add per column per block (B / 8 blocks share a row).  dsum_ws is still written when it IS the result (inputs_embeds).
+template <class T, int CH>
+__global__ void __launch_bounds__(256) embed_bwd_fused_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids,
+                                                              const int64_t* __restrict__ seg, const float* __restrict__ word,
+                                                              const float* __restrict__ pos, const float* __restrict__ type,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, float* __restrict__ dsum_ws,
+                                                              float* dword, float* dpos, float* dtype_, float* part_a, float* part_b,
+                                                              int B, int L, int pad_id, DropKey drop, GradAcc acc) {
+    drop.resolve();
+    constexpr int H = CH * 256;
+    constexpr float invH = 1.0f / H;
+    __shared__ float lds[4 * 5 * H];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nbg = (B + 7) / 8;
+    const int l = blockIdx.x / nbg, g = blockIdx.x % nbg;
+    f32x4 part[5][CH];          // dgamma, dbeta, dtype0, dtype1, dpos
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) part[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 2; ++i) {
+        const int b = g * 8 + wave * 2 + i;
+        if (b >= B) break;
+        const int row = b * L + l;
+        const size_t id = ids ? (size_t)ids[row] : (size_t)row, sg = (size_t)seg[row];
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 dyv[CH], xh[CH], gg[CH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int col = (c * 64 + lane) * 4;
+            const f32x4 xv = *(const f32x4*)(word + id * H + col) + *(const f32x4*)(pos + (size_t)l * H + col) +
+                             *(const f32x4*)(type + sg * H + col);
+            xh[c] = (xv - mu) * rs;
+            dyv[c] = load4(dout + (size_t)row * H + col);
+            const uint32_t idx = (uint32_t)row * H + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dyv[c][r] *= drop_mult(drop, idx + r);
+            gg[c] = *(const f32x4*)(gamma + col);
+            const f32x4 dxh = dyv[c] * gg[c];
+            s1 += (dxh[0] + dxh[1]) + (dxh[2] + dxh[3]);
+            const f32x4 t = dxh * xh[c];
+            s2 += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+        const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int col = (c * 64 + lane) * 4;
+            const f32x4 d = (dyv[c] * gg[c] - m1 - xh[c] * m2) * rs;
+            if (ids == nullptr) *(f32x4*)(dsum_ws + (size_t)row * H + col) = d;      // inputs_embeds: this IS their gradient
+            if (dword != nullptr && (int)id != pad_id) {      // nn.Embedding(padding_idx=pad_token_id): no gradient for the pad row
+#pragma unroll
+                for (int r = 0; r < 4; ++r) grad_add(acc, dword + id * H + col + r, d[r]);
+            }
+            part[0][c] += dyv[c] * xh[c];
+            part[1][c] += dyv[c];
+            part[4][c] += d;
+            if (sg == 0) part[2][c] += d;
+            else if (sg == 1) part[3][c] += d;
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) grad_add(acc, dtype_ + sg * H + col + r, d[r]);     // (type_vocab_size > 2: rare rows)
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) *(f32x4*)(lds + (wave * 5 + q) * H + (c * 64 + lane) * 4) = part[q][c];
+    __syncthreads();
+    float* slab_a = part_a + (size_t)blockIdx.x * 3 * H;
+    float* slab_b = part_b + (size_t)blockIdx.x * 3 * H;
+    for (int i = threadIdx.x; i < 5 * H; i += 256) {
+        const int q = i / H, col = i % H;
+        const float t = lds[(0 * 5 + q) * H + col] + lds[(1 * 5 + q) * H + col] + lds[(2 * 5 + q) * H + col] + lds[(3 * 5 + q) * H + col];
+        if (q < 3) slab_a[q * H + col] = t;
+        else if (q == 3) slab_b[col] = t;
+        else grad_add(acc, dpos + (size_t)l * H + col, t);
+    }
+}
+
 // position / token-type table grads: block (l, c) sums 256 columns of dsum over the batch (sole owner of that piece of dpos[l]).
 __global__ void __launch_bounds__(256) embed_pos_type_kernel(const float* __restrict__ dsum_ws, const int64_t* __restrict__ seg,
                                                              float* dpos, float* dtype_, int B, int L, int H,
@@ -440,15 +530,18 @@ int ln_backward(int dtype, const void* dy, const void* x, const float* gamma, co
 
 size_t ln_partials_floats(int rows, int H) { return (size_t)((rows + 4 * LN_RPW - 1) / (4 * LN_RPW)) * 3 * H; }
 
+// rows per block of the partial-sum LayerNorm backward: 8 waves x LN_RPW rows (half the slabs of a 4-wave block -- the reduction
+// launch reads them all -- at the same number of waves in flight)
+constexpr int LN_NWV = 8;
 int ln_backward_partials(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                          void* dx, void* dx_drop, float* partials, int* nblk, int rows, int H, DropKey drop_in,
                          hipStream_t st) {
     if (rows <= 0) { *nblk = 0; return MB_OK; }
-    const int nb = (rows + 4 * LN_RPW - 1) / (4 * LN_RPW);
+    const int nb = (rows + LN_NWV * LN_RPW - 1) / (LN_NWV * LN_RPW);
     *nblk = nb;
     const DropKey nodrop = {0u, 0u, 0u, 1.0f};
     MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
-        hipLaunchKernelGGL((ln_bwd_kernel<T, CH, LN_RPW, true>), dim3(nb), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma,
+        hipLaunchKernelGGL((ln_bwd_kernel<T, CH, LN_RPW, true, LN_NWV>), dim3(nb), dim3(LN_NWV * 64), 0, st, (const T*)dy, (const T*)x, gamma,
                            mean, rstd, (T*)dx, (T*)dx_drop, partials, (float*)nullptr, (float*)nullptr, rows, nodrop, drop_in);
     }))
     return (int)hipGetLastError();
@@ -485,11 +578,21 @@ int embed_ln_forward(int dtype, const int64_t* ids, const int64_t* seg, const fl
 int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int64_t* seg, const float* word,
                       const float* pos, const float* type, const float* gamma, const float* mean, const float* rstd,
                       float* dsum_ws, float* dword, float* dpos, float* dtype_, float* dgamma, float* dbeta, int B, int L,
-                      int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids, GradAcc acc, float* part, int* nblk) {
+                      int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids, GradAcc acc, float* part, int* nblk,
+                      float* part_b) {
     const int rows = B * L;
     if (nblk) *nblk = (rows + 4 * LN_RPW - 1) / (4 * LN_RPW);
     if (rows <= 0) return MB_OK;
-    if (part != nullptr) {       // dgamma / dbeta as one slab per block of 4 * LN_RPW rows (the block count of ln_backward_partials)
+    if (part != nullptr && part_b != nullptr && pos_ids == nullptr) {
+        // default positions: one launch for everything (embed_bwd_fused_kernel); L * ceil(B / 8) slabs in both sets
+        if (nblk) *nblk = L * ((B + 7) / 8);
+        MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
+            hipLaunchKernelGGL((embed_bwd_fused_kernel<T, CH>), dim3(L * ((B + 7) / 8)), dim3(256), 0, st, (const T*)dout, ids, seg, word,
+                               pos, type, gamma, mean, rstd, dsum_ws, dword, dpos, dtype_, part, part_b, B, L, pad_id, drop, acc);
+        }))
+        return (int)hipGetLastError();
+    }
+    if (part != nullptr) {       // dgamma / dbeta as one slab per block of 4 * LN_RPW rows (explicit position_ids: dpos / dtype by the second launch)
         MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
             hipLaunchKernelGGL((embed_bwd_kernel<T, CH, LN_RPW, true>), dim3((rows + 4 * LN_RPW - 1) / (4 * LN_RPW)), dim3(256), 0, st,
                                (const T*)dout, ids, seg, word, pos, type, gamma, mean, rstd, dsum_ws, dword, part, (float*)nullptr,

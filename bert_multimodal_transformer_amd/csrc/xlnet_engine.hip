@@ -33,6 +33,7 @@ struct mb_xlnet_engine : StepMixin {
     size_t ws_dsa[2], ws_dzda[2], ws_dsb[2], ws_dzdb[2], ws_du[2], ws_dqkv[2], ws_dkr[2];   // dY operands of the weight gradients: ping-pong by layer parity
     size_t ws_dxa, ws_dxb, ws_dvec, ws_gsave, ws_dz, ws_dxs, ws_lnp_a, ws_lnp_b;
     size_t lnp_stride = 0;         // floats per layer in each of the two LayerNorm partial buffers
+    int mag_nblk = 0;              // slabs MAG's gate backward wrote into slot n_layer
     const float* head_mask = nullptr;   // mb_xlnet_set_head_mask: [n_layer][n_head] fp32 (caller-owned device memory)
     const float* emb_in = nullptr;      // mb_xlnet_set_inputs_embeds: [B*L][H] fp32 word embeddings given instead of input_ids (xlnet.py:306-313)
     size_t ws_demb = 0;                 // fp32 [T][H]: gradient of the given embeddings
@@ -414,6 +415,7 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                 if (mag_slabs) {         // the six column sums of MAG's gate (mag_bwd_impl below wrote slot NL in the injection layer's stage)
                     float* const m6[6] = {G + e->mag_bhv, G + e->mag_bha, G + e->mag_bv, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb};
                     for (int q = 0; q < 6; ++q) dst.d[NL][q] = m6[q];
+                    dst.nblk[NL] = e->mag_nblk;
                 }
                 CK(ln_reduce_partials_layers((const float*)(ws + e->ws_lnp_a), (const float*)(ws + e->ws_lnp_b), e->lnp_stride,
                                              mag_slabs ? NL + 1 : NL, nblk, H, dst, st));
@@ -466,7 +468,7 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                                 G + e->mag_wa, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb, T, H, c.visual_dim, c.acoustic_dim, true,
                                 st, GradAcc{}, true, (float*)(ws + e->ws_lnp_a) + (size_t)NL * e->lnp_stride,
                                 (float*)(ws + e->ws_lnp_b) + (size_t)NL * e->lnp_stride, &mblk));
-                if (mag_slabs && mblk != nblk) return MB_ERR_SHAPE;
+                e->mag_nblk = mblk;
                 if (!mag_slabs) {        // not a single-call step (or MAG in front of layer 0): reduce MAG's slabs right away
                     float* const m6[6] = {G + e->mag_bhv, G + e->mag_bha, G + e->mag_bv, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb};
                     CK(ln_reduce_partials((const float*)(ws + e->ws_lnp_a) + (size_t)NL * e->lnp_stride,
