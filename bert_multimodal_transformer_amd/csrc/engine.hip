@@ -60,6 +60,7 @@ struct mb_bert_engine : StepMixin {
     const float* emb_in = nullptr;      // mb_bert_set_inputs_embeds: [B*L][H] fp32 word embeddings given instead of input_ids
     const int64_t* pos_ids = nullptr;   // mb_bert_set_position_ids: [B*L] rows of the position table (null: arange(L), the default)
     bool ran_forward = false;
+
     bool ws_zeroed = false;
     uint64_t seed = 0, step = 0;
     float* logits = nullptr;
@@ -173,6 +174,8 @@ static void build_layout(mb_bert_engine* e) {
     }
     e->ws_lnp_a = w.take(e->lnp_stride * 4 * (c.num_layers + 2)); e->ws_lnp_b = w.take(e->lnp_stride * 4 * (c.num_layers + 2));     // (+1: MAG's gate, +1: the embeddings)
     e->carve_step(w, T, (int)V, (int)A, c.max_batch, c.num_labels, SITE_LAYER0 + 4 * c.num_layers);
+    e->idcnt_off = w.take((size_t)c.vocab_size * 4);          // token-id occurrence table of the single-call step (MB_EMBED_UNIQUE=0: off)
+    { const char* uv = getenv("MB_EMBED_UNIQUE"); e->idcnt_enable = !(uv && atoi(uv) == 0); }
     if (e->deterministic) {          // shadow accumulator of everything behind the layers' GEMM weights (those have ONE writer per element)
         e->det_begin = e->wp; e->det_end = e->n_params;
         e->ws_det = w.take((e->det_end - e->det_begin) * sizeof(long long));
@@ -647,7 +650,8 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                                  (float*)(ws + e->ws_dsum), e->ids ? G + e->word : nullptr, G + e->pos, G + e->type, G + e->emb_lnw,
                                  G + e->emb_lnb, B, L, H, c.pad_token_id, e->key(SITE_EMB, c.hidden_dropout), st, e->pos_ids, acc,
                                  (float*)(ws + e->ws_lnp_a) + (size_t)(NL + 1) * e->lnp_stride, &eblk,
-                                 (float*)(ws + e->ws_lnp_b) + (size_t)(NL + 1) * e->lnp_stride));
+                                 (float*)(ws + e->ws_lnp_b) + (size_t)(NL + 1) * e->lnp_stride,
+                                 (e->in_step && e->counted && e->ids && !e->emb_in) ? (int*)(ws + e->idcnt_off) : nullptr));
             {
                 // ONE reduction launch: every layer's LayerNorm / bias slabs (single-call step only: the other modes reduced them per
                 // layer, their stage hooks need them early), MAG's six sums (slot NL) and the embedding LayerNorm's two (slot NL + 1).

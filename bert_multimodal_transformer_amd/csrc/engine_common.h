@@ -164,6 +164,9 @@ struct StepMixin {
     // engines: workspace offsets of the operands); `packed` tells mag_fwd_impl of the step that the pack_pad launches already happened
     bool pk_enable = false, packed = false;
     size_t pk_vis = 0, pk_aco = 0; int pk_Vp = 0, pk_Ap = 0, pk_dtype = 0;
+    // single-call step: the prologue counts the occurrences of every token id (workspace offset of the table, 0 = none); `counted`
+    // tells the engine's backward that the table describes the batch of this step
+    size_t idcnt_off = 0; bool idcnt_enable = false, counted = false;
     bool loss_cleared = false;     // single-call step: the step prologue clears the loss accumulator (no zero_fill launch in the forward)
     bool capturing = false;        // the stream is in capture mode: nothing outside the captured sequence may be waited for
     int nsites = 0;
@@ -337,7 +340,7 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
     struct Flags {
         E* e; bool ok, with_opt, stale_before;
         ~Flags() {
-            e->in_step = false; e->loss_cleared = false; e->packed = false;
+            e->in_step = false; e->loss_cleared = false; e->packed = false; e->counted = false;
             e->grads_zero = ok && with_opt;
             e->grads_stale = ok ? (with_opt && e->keep_in_step()) : stale_before;
         }
@@ -351,6 +354,8 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
     e->packed = e->pk_enable;
     pa.seed = seed; pa.step = step; pa.keys = e->key_state(ws); pa.nsites = e->nsites;
     pa.zero_dw = (uint32_t*)loss; e->loss_cleared = loss != nullptr;
+    if (e->idcnt_enable && ids) { pa.ids = (const int64_t*)ids; pa.n_ids = B * L; pa.id_count = (int*)(ws + e->idcnt_off); }
+    e->counted = pa.id_count != nullptr;
     if (m) {
         double ss = lr;
         if (correct_bias) ss = (double)lr * sqrt(1.0 - pow((double)beta2, (double)opt_step)) / (1.0 - pow((double)beta1, (double)opt_step));

@@ -112,7 +112,10 @@ int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int
                       float* part = nullptr, int* nblk = nullptr,
                       // part_b (with part, default positions only): ONE launch that also produces dpos / dtype; dtype[0] -> row 2 of `part`,
                       // dtype[1] -> row 0 of `part_b` (the caller's reduction adds them to dtype_), *nblk = L * ceil(B / 8)
-                      float* part_b = nullptr);
+                      float* part_b = nullptr,
+                      // id_count: the table the step prologue of THIS batch counted token ids into (vocab_size ints, zero between steps):
+                      // rows whose id occurs once add their word-embedding gradient without atomics; the entries are cleared again
+                      int* id_count = nullptr);
 
 // column sums: out[n] += sum_m x[m][n]
 int colsum(int dtype, const void* x, int ldx, float* out, int rows, int cols, hipStream_t st, GradAcc acc = {});
@@ -221,6 +224,7 @@ struct PrologueArgs {
     // GEMM operands; columns [cols, pitch) are never written and stay zero) -- what pack_pad does, without its two launches
     struct PackJob { const float* src; void* dst; int rows, cols, pitch, dtype; } pack[2];
     int npack;
+    const int64_t* ids; int n_ids; int* id_count;     // id_count[ids[i]] += 1 (see embed_ln_backward), may be null
 };
 int step_prologue(const PrologueArgs& a, hipStream_t st);
 // p[0, bytes) = 0 as a kernel launch (bytes and p multiples of 4); up to MB_ZERO_MAX ranges in one launch

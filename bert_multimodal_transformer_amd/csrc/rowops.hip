@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, float* __restrict__ dsum_ws,
                                                         float* dword, float* dgamma, float* dbeta, int rows, int L,
-                                                        int pad_id, DropKey drop, const int64_t* __restrict__ pos_ids, GradAcc acc) {
+                                                        int pad_id, DropKey drop, const int64_t* __restrict__ pos_ids, GradAcc acc, int* id_count) {
     drop.resolve();
     constexpr int H = CH * 256;
     constexpr float invH = 1.0f / H;
@@ -277,6 +277,8 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
         if (row >= rows) break;
         const size_t id = ids ? (size_t)ids[row] : (size_t)row, sg = (size_t)seg[row], l = pos_ids ? (size_t)pos_ids[row] : (size_t)(row % L);
         const float mu = mean[row], rs = rstd[row];
+        // (a stale 0 -- another row of the same id was faster and cleared the entry -- only selects the atomic path)
+        const bool uniq = id_count != nullptr && ids != nullptr && acc.shadow == nullptr && id_count[id] == 1;
         f32x4 dyv[CH], xh[CH], gg[CH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -303,12 +305,18 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const T* __restrict__ do
             *(f32x4*)(dsum_ws + (size_t)row * H + col) = d;
             // dword == nullptr (inputs_embeds): the gradient of the given embeddings is dsum_ws itself
             if (dword != nullptr && (int)id != pad_id) {      // nn.Embedding(padding_idx=pad_token_id): no gradient for the pad row
+                if (uniq) {                   // the only row of the batch with this id: nobody else touches its gradient row
+                    f32x4* gp = (f32x4*)(dword + id * H + col);
+                    *gp = *gp + d;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) grad_add(acc, dword + id * H + col + r, d[r]);
+                    for (int r = 0; r < 4; ++r) grad_add(acc, dword + id * H + col + r, d[r]);
+                }
             }
             part[0][c] += dyv[c] * xh[c];
             part[1][c] += dyv[c];
         }
+        if (id_count != nullptr && ids != nullptr && lane == 0) id_count[id] = 0;      // (the table is all zero again after the backward)
     }
     if constexpr (PARTIAL) {
         // dgamma points at a partial set [nblk][3][H] (ln_bwd's layout; row 2 unused): this block's slab gets the 4-wave sums of
@@ -341,7 +349,7 @@ __global__ void __launch_bounds__(256) embed_bwd_fused_kernel(const T* __restric
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, float* __restrict__ dsum_ws,
                                                               float* dword, float* dpos, float* dtype_, float* part_a, float* part_b,
-                                                              int B, int L, int pad_id, DropKey drop, GradAcc acc) {
+                                                              int B, int L, int pad_id, DropKey drop, GradAcc acc, int* id_count) {
     drop.resolve();
     constexpr int H = CH * 256;
     constexpr float invH = 1.0f / H;
@@ -360,6 +368,8 @@ __global__ void __launch_bounds__(256) embed_bwd_fused_kernel(const T* __restric
         const int row = b * L + l;
         const size_t id = ids ? (size_t)ids[row] : (size_t)row, sg = (size_t)seg[row];
         const float mu = mean[row], rs = rstd[row];
+        // (a stale 0 -- another row of the same id was faster and cleared the entry -- only selects the atomic path)
+        const bool uniq = id_count != nullptr && ids != nullptr && acc.shadow == nullptr && id_count[id] == 1;
         f32x4 dyv[CH], xh[CH], gg[CH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -385,8 +395,13 @@ __global__ void __launch_bounds__(256) embed_bwd_fused_kernel(const T* __restric
             const f32x4 d = (dyv[c] * gg[c] - m1 - xh[c] * m2) * rs;
             if (ids == nullptr) *(f32x4*)(dsum_ws + (size_t)row * H + col) = d;      // inputs_embeds: this IS their gradient
             if (dword != nullptr && (int)id != pad_id) {      // nn.Embedding(padding_idx=pad_token_id): no gradient for the pad row
+                if (uniq) {                   // the only row of the batch with this id: nobody else touches its gradient row
+                    f32x4* gp = (f32x4*)(dword + id * H + col);
+                    *gp = *gp + d;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) grad_add(acc, dword + id * H + col + r, d[r]);
+                    for (int r = 0; r < 4; ++r) grad_add(acc, dword + id * H + col + r, d[r]);
+                }
             }
             part[0][c] += dyv[c] * xh[c];
             part[1][c] += dyv[c];
@@ -398,6 +413,7 @@ __global__ void __launch_bounds__(256) embed_bwd_fused_kernel(const T* __restric
                 for (int r = 0; r < 4; ++r) grad_add(acc, dtype_ + sg * H + col + r, d[r]);     // (type_vocab_size > 2: rare rows)
             }
         }
+        if (id_count != nullptr && ids != nullptr && lane == 0) id_count[id] = 0;      // (the table is all zero again after the backward)
     }
 #pragma unroll
     for (int q = 0; q < 5; ++q)
@@ -579,7 +595,7 @@ int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int
                       const float* pos, const float* type, const float* gamma, const float* mean, const float* rstd,
                       float* dsum_ws, float* dword, float* dpos, float* dtype_, float* dgamma, float* dbeta, int B, int L,
                       int H, int pad_id, DropKey drop, hipStream_t st, const int64_t* pos_ids, GradAcc acc, float* part, int* nblk,
-                      float* part_b) {
+                      float* part_b, int* id_count) {
     const int rows = B * L;
     if (nblk) *nblk = (rows + 4 * LN_RPW - 1) / (4 * LN_RPW);
     if (rows <= 0) return MB_OK;
@@ -588,7 +604,7 @@ int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int
         if (nblk) *nblk = L * ((B + 7) / 8);
         MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
             hipLaunchKernelGGL((embed_bwd_fused_kernel<T, CH>), dim3(L * ((B + 7) / 8)), dim3(256), 0, st, (const T*)dout, ids, seg, word,
-                               pos, type, gamma, mean, rstd, dsum_ws, dword, dpos, dtype_, part, part_b, B, L, pad_id, drop, acc);
+                               pos, type, gamma, mean, rstd, dsum_ws, dword, dpos, dtype_, part, part_b, B, L, pad_id, drop, acc, id_count);
         }))
         return (int)hipGetLastError();
     }
@@ -596,14 +612,14 @@ int embed_ln_backward(int dtype, const void* dout, const int64_t* ids, const int
         MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
             hipLaunchKernelGGL((embed_bwd_kernel<T, CH, LN_RPW, true>), dim3((rows + 4 * LN_RPW - 1) / (4 * LN_RPW)), dim3(256), 0, st,
                                (const T*)dout, ids, seg, word, pos, type, gamma, mean, rstd, dsum_ws, dword, part, (float*)nullptr,
-                               rows, L, pad_id, drop, pos_ids, acc);
+                               rows, L, pad_id, drop, pos_ids, acc, id_count);
         }))
     } else {
     constexpr int RPW = 4;
     MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
         hipLaunchKernelGGL((embed_bwd_kernel<T, CH, RPW, false>), dim3((rows + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st,
                            (const T*)dout, ids, seg, word, pos, type, gamma, mean, rstd, dsum_ws, dword, dgamma, dbeta,
-                           rows, L, pad_id, drop, pos_ids, acc);
+                           rows, L, pad_id, drop, pos_ids, acc, id_count);
     }))
     }
     hipLaunchKernelGGL(embed_pos_type_kernel, dim3(L, (H + 255) / 256), dim3(256), 0, st, dsum_ws, seg, dpos, dtype_, B, L, H, pos_ids, acc);
@@ -722,6 +738,11 @@ __global__ void __launch_bounds__(256) step_prologue_kernel(const PrologueArgs a
         if (a.adam_dst && threadIdx.x < 2) a.adam_dst[threadIdx.x] = a.adam[threadIdx.x];
     }
     if (tid == 0 && a.zero_dw) *a.zero_dw = 0u;
+    // occurrences of every token id of this batch (a vocab-sized table that is all zero between steps): the embedding backward adds
+    // the gradient row of an id that occurs ONCE with plain 16-byte read-modify-writes instead of four atomics per lane.  Counted
+    // here because this launch waits for PCIe anyway (inside embed_fwd the 2,400 device-scope atomics cost 10 us)
+    if (a.id_count != nullptr)
+        for (size_t i = tid; i < (size_t)a.n_ids; i += nth) atomicAdd(a.id_count + a.ids[i], 1);
     for (int k = 0; k < a.npack; ++k) {          // (before the copies: these loads cross PCIe too and should be in flight with them)
         const PrologueArgs::PackJob& j = a.pack[k];
         const size_t n = (size_t)j.rows * j.cols;
