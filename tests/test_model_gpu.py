@@ -676,6 +676,47 @@ def test_deterministic_mode_bf16_runs_are_bit_identical(monkeypatch):
     assert err <= 1e-5
 
 
+def test_single_call_step_word_gradient_with_repeated_and_unique_token_ids():
+    """The single-call step adds the word-embedding gradient of a token id that occurs ONCE in the batch with plain read-modify-writes
+    (the step prologue counts the occurrences, the backward clears the table again) and everything else with atomics.  A batch built
+    to hold ids repeated inside a sample, across samples, pad tokens (no gradient) and unique ids -- and the next step with the roles
+    swapped, which a stale occurrence table would get wrong -- against the gradient accumulated by the Python-driven passes (atomics
+    only), fp32, no dropout; word_embeddings is compared row by row."""
+    torch.manual_seed(3)
+    def batches():
+        out = []
+        for s in range(3):
+            ids, vis, aco, mask, seg, lab = tb(weights.synthetic_bert_batch(6, 24, 47, 74, seed=400 + s), DEV)
+            ids = ids.clone()
+            ids[0, 1:6] = 1000 + s                       # repeated inside a sample
+            ids[1:4, 7] = 2000 + (s % 2)                 # repeated across samples
+            ids[4, 2:5] = torch.tensor([3000, 3001 + s, 3002], device=ids.device)     # unique now, repeated in another step
+            ids[5, 3] = 3000 if s == 1 else 2000         # ... 3000 twice in step 1, 2000 x 4 otherwise
+            ids[5, 20:] = 0                              # pad tokens
+            out.append((ids, vis, aco, mask, seg, lab))
+        return out
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(9)
+        m = build(layers=2, cdt=torch.float32, p_mag=0.0, hidden_p=0.0, attn_p=0.0).train()
+        snaps = []
+        with m.stream_scope():
+            for b in batches():
+                if fused:
+                    m.train_step(*b, optimizer=None)               # accumulation micro-step of the single-call path (graph replay)
+                else:
+                    m.training_step(*b)                            # passes driven from Python: atomics everywhere
+                snaps.append(dict(m.named_parameters())["bert.embeddings.word_embeddings.weight"].grad.clone())
+        torch.cuda.synchronize()
+        res.append(snaps)
+    for k, (a, b) in enumerate(zip(*res)):
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        print("word-embedding gradient after %d accumulated steps: max |diff| %.3e (max |g| %.3e)" % (k + 1, err, scale))
+        assert err <= 2e-6 * scale
+        assert float(a[0].abs().max()) == 0.0             # padding_idx row
+
+
 def test_optimizer_chunks_on_a_side_stream_change_nothing(monkeypatch):
     """MB_ADAMW_OVERLAP=C (an experiment kept behind its switch: DESIGN 4.5): the single-call step is cut into linear graphs at
     every C-th layer of the backward and the AdamW of the finished chunk's GEMM weights runs on a side stream under the backward
