@@ -117,6 +117,43 @@ __device__ __forceinline__ float row16_sum_to_lane15(float v) {
 // 64-byte k-slab of an LDS/global image stored [row][k] with k contiguous:
 //   bf16 : 8 elements k = (lane>>4)*8 + j   -> one v_mfma_f32_16x16x32_bf16
 //   fp32 : 4 elements k = (lane>>4)*4 + j   -> four v_mfma_f32_16x16x4_f32 (exact fp32 fma chain)
+// ---- piggy-backed prefetch ------------------------------------------------------------------------------------------------
+// In the step the GEMMs find their weights in HBM, not in the 256 MB Infinity Cache (AdamW's 3 GB sweep and ~600 MB of activations
+// pass between two uses), and run 15 % slower than over cache-resident operands (tools/gemm_bench --nset 48 vs 6:
+// profiles/r03_gemm_cold_vs_warm.txt).  The latency-bound row kernels in front of them have the memory system idle: each of their
+// blocks touches its slice of the NEXT launches' weights (K 16-byte loads per thread, issued behind the kernel's own first loads,
+// retired at its end), which leaves the lines in the memory-side cache for every XCD.  `sink` is never written (null): it only
+// keeps the loads alive.
+struct Prefetch { const void* p; size_t bytes; uint32_t* sink; };
+// `fallback`: any 16 readable bytes (what a launch without a prefetch region loads instead: K cache hits per thread).  The loads are
+// unconditional -- offsets past the region are clamped to its last 16 bytes -- because a load inside divergent control flow makes
+// the compiler wait for it at the join.
+template <int K>
+__device__ __forceinline__ void prefetch_issue(const Prefetch& pf, const void* fallback, u32x4 (&v)[K]) {
+    const char* base = pf.p != nullptr ? (const char*)pf.p : (const char*)fallback;
+    const size_t last = (pf.p != nullptr && pf.bytes >= 16 ? pf.bytes : (size_t)16) - 16;
+    const size_t nthr = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __builtin_amdgcn_sched_barrier(0);           // every load the kernel issued so far stays in front of these ...
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        size_t off = ((size_t)k * nthr + tid) * 16;
+        off = off < last ? off : last;
+        v[k] = *(const u32x4*)(base + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);           // ... and nothing that follows is scheduled in between
+}
+template <int K>
+__device__ __forceinline__ void prefetch_retire(const Prefetch& pf, u32x4 (&v)[K]) {
+    uint32_t a = 0u;
+    // (the empty asm pins the first use of the loaded registers HERE: without it the compiler folds them right behind the loads and
+    //  the kernel's own work waits for the prefetch -- loads return in order)
+#pragma unroll
+    for (int k = 0; k < K; ++k) asm volatile("" : "+v"(v[k]) : : "memory");
+#pragma unroll
+    for (int k = 0; k < K; ++k) a ^= v[k][0] ^ v[k][1] ^ v[k][2] ^ v[k][3];
+    if (pf.sink != nullptr) *pf.sink = a;
+}
+
 // mma16(acc, x, y):  acc[r] += sum_k X[(lane>>4)*4 + r][k] * Y[lane & 15][k]
 // where x / y are the fragments this lane loaded from images X / Y.
 template <class T> struct Frag;

@@ -50,6 +50,7 @@ struct mb_bert_engine : StepMixin {
                                    // to the in-line grouped launch, which keeps the step a single-stream sequence -- and its hipGraph a fast one)
     // MB_ADAMW_OVERLAP=C: the single-call step forks the optimizer of every finished chunk of C layers onto this stream (enqueue_step)
     int opt_chunk = 0;
+    int prefetch = 1;              // MB_PREFETCH=0: the LayerNorm kernels do not touch the next GEMMs' weights (common.h Prefetch)
     hipStream_t opt_side = nullptr;
     std::vector<hipEvent_t> opt_ev;
     int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128), 0 = four launches
@@ -377,6 +378,7 @@ int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
     if (const char* v = getenv("MB_ADAMW_KEEP")) e->keep_enable = atoi(v);
     if (const char* v = getenv("MB_DETERMINISTIC")) e->deterministic = atoi(v);
     if (const char* v = getenv("MB_ADAMW_OVERLAP")) e->opt_chunk = atoi(v);
+    if (const char* v = getenv("MB_PREFETCH")) e->prefetch = atoi(v);
     e->grouped = (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->hidden_size % e->group_wgrad == 0 &&
                  cfg->intermediate_size % e->group_wgrad == 0;
     e->deferred = e->overlap_wgrad && e->grouped;
@@ -476,14 +478,18 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
                              e->head_mask ? e->head_mask + (size_t)l * nh : nullptr));
         CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, T, H, H, ws + w.ctx, H, e->W(o.wo), H, ws + w.s1, H, nullptr, nullptr,
                 P + o.bo, x, H, e->key(SITE_LAYER0 + 4 * l + 1, c.hidden_dropout), 1, 0, st));
+        // (the two LayerNorm launches of a layer touch the weights of the GEMMs behind them: W1 | W2, then the next layer's Wqkv | Wo)
+        const size_t wes = dt == DT_BF16 ? 2 : 4;
+        const Prefetch pf1 = {e->prefetch ? e->W(o.w1) : nullptr, (size_t)2 * I * H * wes, nullptr};
+        const Prefetch pf2 = {(e->prefetch && l + 1 < c.num_layers) ? e->W(e->lo[l + 1].wqkv) : nullptr, (size_t)4 * H * H * wes, nullptr};
         CK(ln_forward(dt, ws + w.s1, P + o.ln1w, P + o.ln1b, c.layer_norm_eps, ws + w.y1, (float*)(ws + w.st1),
-                      (float*)(ws + w.st1) + T, T, H, kNoDrop, st));
+                      (float*)(ws + w.st1) + T, T, H, kNoDrop, st, pf1));
         CK(gemm(dt, GEMM_NT, EPI_BIAS_GELU, T, I, H, ws + w.y1, H, e->W(o.w1), H, ws + w.u, I, ws + w.g, nullptr, P + o.b1,
                 nullptr, 0, kNoDrop, 1, 0, st));
         CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, T, H, I, ws + w.g, I, e->W(o.w2), I, ws + w.s2, H, nullptr, nullptr,
                 P + o.b2, ws + w.y1, H, e->key(SITE_LAYER0 + 4 * l + 2, c.hidden_dropout), 1, 0, st));
         CK(ln_forward(dt, ws + w.s2, P + o.ln2w, P + o.ln2b, c.layer_norm_eps, ws + e->ws_x[l + 1], (float*)(ws + w.st2),
-                      (float*)(ws + w.st2) + T, T, H, kNoDrop, st));
+                      (float*)(ws + w.st2) + T, T, H, kNoDrop, st, pf2));
     }
     // pooler + classifier (+ MSE) (bert.py:231, 304-307; multimodal_driver.py:372-373)
     float* z = (float*)(ws + e->ws_head_z);
@@ -557,7 +563,9 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             const bool defer_ln = e->in_step && !e->stage_mode && NL + 2 <= MB_LN_MAX_LAYERS;      // (reduced in the last stage)
             // LN2 + dropout backward (column sums -> per-block partial slabs, reduced once per layer below)
             CK(ln_backward_partials(dt, dx, ws + w.s2, P + o.ln2w, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, dsA,
-                                    hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(SITE_LAYER0 + 4 * l + 2, c.hidden_dropout), st));
+                                    hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(SITE_LAYER0 + 4 * l + 2, c.hidden_dropout), st,
+                                    // ... and touches W1 | W2 for the two FFN dgrads behind it (common.h Prefetch)
+                                    Prefetch{e->prefetch ? e->W(o.w1) : nullptr, (size_t)2 * I * H * (dt == DT_BF16 ? 2 : 4), nullptr}));
             // The four weight gradients of the layer: one grouped launch once dqkv exists (MB_GROUP_WGRAD=0: four launches,
             // each forked as soon as its dY is final).
             GemmArgs wg[4] = {wgrad_args(H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I),
@@ -584,7 +592,9 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                     H, kNoDrop, 1, 0, st));
             // LN1 + dropout backward
             CK(ln_backward_partials(dt, dy1, ws + w.s1, P + o.ln1w, (const float*)(ws + w.st1), (const float*)(ws + w.st1) + T, dsB,
-                                    hd ? dzdB : nullptr, lnp_b, &nblk, T, H, e->key(SITE_LAYER0 + 4 * l + 1, c.hidden_dropout), st));
+                                    hd ? dzdB : nullptr, lnp_b, &nblk, T, H, e->key(SITE_LAYER0 + 4 * l + 1, c.hidden_dropout), st,
+                                    // ... Wqkv | Wo for the attention-side dgrads
+                                    Prefetch{e->prefetch ? e->W(o.wqkv) : nullptr, (size_t)4 * H * H * (dt == DT_BF16 ? 2 : 4), nullptr}));
             if (!grouped) {
             CK(fork(2));
             CK(wgrad(dt, H, H, Tk, dzdB, H, ws + w.ctx, H, G + o.wo, H, ss));
@@ -599,7 +609,9 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             // attention backward; the fused-QKV bias gradient (column sums of dqkv) is accumulated inside the kernel
             CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, dqkv, G + o.bqkv, B, L, nh,
                                   e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st,
-                                  e->head_mask ? e->head_mask + (size_t)l * nh : nullptr, acc));
+                                  e->head_mask ? e->head_mask + (size_t)l * nh : nullptr, acc,
+                                  // ... and touches the GELU output, the largest operand the grouped weight gradient behind it reads cold
+                                  Prefetch{e->prefetch ? (const void*)(ws + w.g) : nullptr, (size_t)T * I * esize(dt), nullptr}));
             auto launch_group = [&]() -> int {
                 if (inl) {
                     if (e->prof) CK((int)hipEventRecord(e->pev[2 * l], st));

@@ -75,7 +75,8 @@ int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile
 // ------------------------------------------------------------------------------------------ row kernels (rowops.hip)
 // LayerNorm over the last dim H (H % 256 == 0, H <= 1024): y = (x-mean)*rstd*gamma + beta ; optional dropout on y.
 int ln_forward(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,
-               float* mean, float* rstd, int rows, int H, DropKey drop, hipStream_t st);
+               float* mean, float* rstd, int rows, int H, DropKey drop, hipStream_t st,
+               Prefetch pf = {nullptr, 0, nullptr});
 // LayerNorm backward. dy: grad of LN output (after optional dropout `drop_out`), x: saved LN input.
 //   dx      = grad wrt LN input                         (T)  [required]
 //   dx_drop = dx * mask(drop_in)                        (T)  [optional: grad of the pre-dropout Linear output]
@@ -89,7 +90,8 @@ int grad_fold(GradAcc acc, float* g, size_t begin, size_t end, hipStream_t st);
 // *nblk.  ln_reduce_partials adds them into up to 6 destinations in one launch (two LayerNorms of a layer).
 size_t ln_partials_floats(int rows, int H);
 int ln_backward_partials(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                         void* dx, void* dx_drop, float* partials, int* nblk, int rows, int H, DropKey drop_in, hipStream_t st);
+                         void* dx, void* dx_drop, float* partials, int* nblk, int rows, int H, DropKey drop_in, hipStream_t st,
+                         Prefetch pf = {nullptr, 0, nullptr});
 int ln_reduce_partials(const float* partials_a, const float* partials_b, int nblk, int H, float* const* dst6, hipStream_t st, GradAcc acc = {});
 // The same for `layers` layers in ONE launch: layer l's slabs start at partials_x + l * layer_stride floats, its six destinations
 // are dst[l][0..5].  (A single-process step has no use for a layer's LayerNorm / bias gradients before AdamW: twelve 5-us
@@ -160,7 +162,8 @@ int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx
 // dbias (fp32 [3H], may be null): += column sums of dqkv (bias grads of the fused QKV Linear)
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx,
                        void* dqkv, float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st,
-                       const float* head_scale = nullptr, GradAcc acc = {});
+                       const float* head_scale = nullptr, GradAcc acc = {},
+                       Prefetch pf = {nullptr, 0, nullptr});       // region the kernel touches under its sweeps (common.h)
 int attention_trace_fetch(unsigned long long* host_out, int max_blocks);     // MB_ATTN_TRACE=1: stamps of the last attention_backward
 
 // ------------------------------------------------------------------------------------------ XLNet (xlnet_attention.hip, xlnet_rowops.hip)

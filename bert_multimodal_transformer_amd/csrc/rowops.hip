@@ -37,7 +37,7 @@ template <class T, int CH>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                     DropKey drop) {
+                                                     DropKey drop, Prefetch pf) {
     drop.resolve();
     constexpr int H = CH * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -48,17 +48,27 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
     for (int c = 0; c < CH; ++c) v[c] = load4(x + (size_t)row * H + (c * 64 + lane) * 4);
     float mu, rs;
     RowStat<CH>::compute(v, eps, mu, rs);
+    f32x4 g[CH], bt[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        g[c] = *(const f32x4*)(gamma + (c * 64 + lane) * 4);
+        bt[c] = *(const f32x4*)(beta + (c * 64 + lane) * 4);
+    }
+    // behind the LAST of the kernel's own loads (loads return in order: anything issued after the prefetch would wait for it);
+    // the stores below do not wait for loads, the wave does at its end
+    u32x4 pfv[4];
+    prefetch_issue<4>(pf, gamma, pfv);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int col = (c * 64 + lane) * 4;
-        const f32x4 g = *(const f32x4*)(gamma + col), b = *(const f32x4*)(beta + col);
-        f32x4 o = (v[c] - mu) * rs * g + b;
+        f32x4 o = (v[c] - mu) * rs * g[c] + bt[c];
         const uint32_t idx = (uint32_t)row * H + col;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] *= drop_mult(drop, idx + r);
         store4(y + (size_t)row * H + col, o);
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    prefetch_retire<4>(pf, pfv);
 }
 
 constexpr int LN_RPW = 2;     // rows per wave in the partial-sum variants (8 rows per block -> 300 blocks at T = 2400)
@@ -88,7 +98,7 @@ __global__ void __launch_bounds__(NWV * 64) ln_bwd_kernel(const T* __restrict__ 
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
                                                      T* __restrict__ dx_drop, float* dgamma, float* dbeta, float* dbias,
-                                                     int rows, DropKey drop_out, DropKey drop_in) {
+                                                     int rows, DropKey drop_out, DropKey drop_in, Prefetch pf) {
     drop_out.resolve();
     drop_in.resolve();
     constexpr int H = CH * 256;
@@ -103,7 +113,6 @@ __global__ void __launch_bounds__(NWV * 64) ln_bwd_kernel(const T* __restrict__ 
     f32x4 g[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) g[c] = *(const f32x4*)(gamma + (c * 64 + lane) * 4);
-
     // (issuing the loads of all RPW rows ahead of the first reduction was measured: 12.8 vs 8.4 us per launch -- the rolled loop
     //  keeps the block at 124 VGPRs and lets the four waves drift apart, which overlaps their round trips better)
     for (int i = 0; i < RPW; ++i) {
@@ -142,6 +151,8 @@ __global__ void __launch_bounds__(NWV * 64) ln_bwd_kernel(const T* __restrict__ 
             part[2][c] += d;
         }
     }
+    u32x4 pfv[8];
+    prefetch_issue<8>(pf, gamma, pfv);       // behind the last of the kernel's own loads; runs under the column-sum epilogue
     if constexpr (PARTIAL) {
         // dgamma points at partials[nblk][3][H]: this block's slab gets the 4-wave sums, no atomics
 #pragma unroll
@@ -161,7 +172,7 @@ __global__ void __launch_bounds__(NWV * 64) ln_bwd_kernel(const T* __restrict__ 
         float* const dst[3] = {dgamma, dbeta, dbias};
         static_assert(PARTIAL || NWV == 4, "block_colsum_atomic sums four waves");
         block_colsum_atomic<CH, 3>(part, dst, lds);
-    }
+    }    prefetch_retire<8>(pf, pfv);
 }
 
 // out[q][col] += sum_b partials[b][q][col] for two partial sets (q = 0..2 from set a, 3..5 from set b).
@@ -522,11 +533,11 @@ __global__ void widen_kernel(const T* __restrict__ src, float* __restrict__ dst,
     else return MB_ERR_SHAPE;
 
 int ln_forward(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
-               float* rstd, int rows, int H, DropKey drop, hipStream_t st) {
+               float* rstd, int rows, int H, DropKey drop, hipStream_t st, Prefetch pf) {
     if (rows <= 0) return MB_OK;
     MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
         hipLaunchKernelGGL((ln_fwd_kernel<T, CH>), dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)x, gamma, beta, eps,
-                           (T*)y, mean, rstd, rows, drop);
+                           (T*)y, mean, rstd, rows, drop, pf);
     }))
     return (int)hipGetLastError();
 }
@@ -539,7 +550,7 @@ int ln_backward(int dtype, const void* dy, const void* x, const float* gamma, co
     MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
         hipLaunchKernelGGL((ln_bwd_kernel<T, CH, RPW, false>), dim3((rows + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st,
                            (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, (T*)dx_drop, dgamma, dbeta, dbias, rows,
-                           drop_out, drop_in);
+                           drop_out, drop_in, Prefetch{nullptr, 0, nullptr});
     }))
     return (int)hipGetLastError();
 }
@@ -551,14 +562,14 @@ size_t ln_partials_floats(int rows, int H) { return (size_t)((rows + 4 * LN_RPW 
 constexpr int LN_NWV = 8;
 int ln_backward_partials(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                          void* dx, void* dx_drop, float* partials, int* nblk, int rows, int H, DropKey drop_in,
-                         hipStream_t st) {
+                         hipStream_t st, Prefetch pf) {
     if (rows <= 0) { *nblk = 0; return MB_OK; }
     const int nb = (rows + LN_NWV * LN_RPW - 1) / (LN_NWV * LN_RPW);
     *nblk = nb;
     const DropKey nodrop = {0u, 0u, 0u, 1.0f};
     MB_DISPATCH_T(dtype, MB_DISPATCH_CH(H, {
         hipLaunchKernelGGL((ln_bwd_kernel<T, CH, LN_RPW, true, LN_NWV>), dim3(nb), dim3(LN_NWV * 64), 0, st, (const T*)dy, (const T*)x, gamma,
-                           mean, rstd, (T*)dx, (T*)dx_drop, partials, (float*)nullptr, (float*)nullptr, rows, nodrop, drop_in);
+                           mean, rstd, (T*)dx, (T*)dx_drop, partials, (float*)nullptr, (float*)nullptr, rows, nodrop, drop_in, pf);
     }))
     return (int)hipGetLastError();
 }

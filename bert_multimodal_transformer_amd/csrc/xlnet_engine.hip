@@ -34,6 +34,7 @@ struct mb_xlnet_engine : StepMixin {
     size_t ws_dxa, ws_dxb, ws_dvec, ws_gsave, ws_dz, ws_dxs, ws_lnp_a, ws_lnp_b;
     size_t lnp_stride = 0;         // floats per layer in each of the two LayerNorm partial buffers
     int mag_nblk = 0;              // slabs MAG's gate backward wrote into slot n_layer
+    int prefetch = 1;              // MB_PREFETCH=0: the LayerNorm kernels do not touch the next GEMMs' weights (common.h Prefetch)
     const float* head_mask = nullptr;   // mb_xlnet_set_head_mask: [n_layer][n_head] fp32 (caller-owned device memory)
     const float* emb_in = nullptr;      // mb_xlnet_set_inputs_embeds: [B*L][H] fp32 word embeddings given instead of input_ids (xlnet.py:306-313)
     size_t ws_demb = 0;                 // fp32 [T][H]: gradient of the given embeddings
@@ -215,6 +216,7 @@ int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out) {
     e->c = *cfg;
     xl_build_layout(e);
     if (const char* v = getenv("MB_XL_FUSE_QKV")) e->fuse_qkv = atoi(v) != 0;
+    if (const char* pv = getenv("MB_PREFETCH")) e->prefetch = atoi(pv);
     if (e->lo[0].k - e->lo[0].q != (size_t)cfg->d_model * cfg->d_model || e->lo[0].v - e->lo[0].k != e->lo[0].k - e->lo[0].q) e->fuse_qkv = false;
     if (const char* v = getenv("MB_ADAMW_KEEP")) e->keep_enable = atoi(v);
     // lazy zeroing (engine_common.h): the seven GEMM weights of every layer, stored by the grouped launches of a pass that may overwrite
@@ -313,15 +315,20 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
         // post_attention: dropout(vec . o^T) + h -> LayerNorm
         CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, T, H, H, ws + w.vec, H, e->W(o.o), H, ws + w.s1, H, nullptr, nullptr, nullptr, xin, H,
                 e->key(XS_LAYER0 + 8 * l + 1, pd), 1, 0, st));
+        // (the LayerNorm launches touch the weights of the GEMMs behind them -- common.h Prefetch: layer_1 | layer_2 here, the next
+        //  layer's q | k | v | o | r behind the second one)
+        const size_t wes = dt == DT_BF16 ? 2 : 4;
+        const Prefetch pf1 = {e->prefetch ? e->W(o.w1) : nullptr, (size_t)2 * I * H * wes, nullptr};
+        const Prefetch pf2 = {(e->prefetch && l + 1 < c.n_layer) ? e->W(e->lo[l + 1].q) : nullptr, (size_t)5 * H * H * wes, nullptr};
         CK(ln_forward(dt, ws + w.s1, P + o.ralnw, P + o.ralnb, c.layer_norm_eps, ws + w.y1, (float*)(ws + w.st1),
-                      (float*)(ws + w.st1) + T, T, H, kNoDrop, st));
+                      (float*)(ws + w.st1) + T, T, H, kNoDrop, st, pf1));
         // feed forward: layer_1 -> gelu -> dropout -> layer_2 -> dropout -> LayerNorm(. + inp)
         CK(gemm(dt, GEMM_NT, EPI_BIAS_GELU, T, I, H, ws + w.y1, H, e->W(o.w1), H, ws + w.u, I, ws + w.g, nullptr, P + o.b1, nullptr, 0,
                 e->key(XS_LAYER0 + 8 * l + 2, pd), 1, 0, st));
         CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, T, H, I, ws + w.g, I, e->W(o.w2), I, ws + w.s2, H, nullptr, nullptr, P + o.b2,
                 ws + w.y1, H, e->key(XS_LAYER0 + 8 * l + 3, pd), 1, 0, st));
         CK(ln_forward(dt, ws + w.s2, P + o.fflnw, P + o.fflnb, c.layer_norm_eps, ws + e->ws_x[l + 1], (float*)(ws + w.st2),
-                      (float*)(ws + w.st2) + T, T, H, kNoDrop, st));
+                      (float*)(ws + w.st2) + T, T, H, kNoDrop, st, pf2));
     }
     // final dropout (xlnet.py:396) on the only row SequenceSummary("last") reads, then summary -> tanh -> dropout -> logits_proj
     CK(last_token_forward(dt, ws + e->ws_x[c.n_layer], ws + e->ws_xs, B, L, H, e->key(XS_FINAL, pd), st));
@@ -380,7 +387,8 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
             const bool mag_slabs = defer_ln && c.injection_index >= 1 && c.injection_index < NL;     // MAG's backward runs before that launch
             // ---- feed-forward block
             CK(ln_backward_partials(dt, dx, ws + w.s2, P + o.fflnw, (const float*)(ws + w.st2), (const float*)(ws + w.st2) + T, dsA,
-                                    hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(XS_LAYER0 + 8 * l + 3, pd), st));
+                                    hd ? dzdA : nullptr, lnp_a, &nblk, T, H, e->key(XS_LAYER0 + 8 * l + 3, pd), st,
+                                    Prefetch{e->prefetch ? e->W(o.w1) : nullptr, (size_t)2 * I * H * (dt == DT_BF16 ? 2 : 4), nullptr}));
             // the layer's seven weight gradients go out as ONE grouped launch once every dY exists (MB_GROUP_WGRAD=0: one by one)
             char* dqkv = ws + e->ws_dqkv[par];
             GemmArgs wg[7] = {wgrad_args(H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I),
@@ -401,7 +409,8 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                     kNoDrop, 1, 0, st));
             // ---- relative attention block
             CK(ln_backward_partials(dt, t1, ws + w.s1, P + o.ralnw, (const float*)(ws + w.st1), (const float*)(ws + w.st1) + T, dsB,
-                                    hd ? dzdB : nullptr, lnp_b, &nblk, T, H, e->key(XS_LAYER0 + 8 * l + 1, pd), st));
+                                    hd ? dzdB : nullptr, lnp_b, &nblk, T, H, e->key(XS_LAYER0 + 8 * l + 1, pd), st,
+                                    Prefetch{e->prefetch ? e->W(o.q) : nullptr, (size_t)5 * H * H * (dt == DT_BF16 ? 2 : 4), nullptr}));
             if (!defer_ln) {
                 float* const dst6[6] = {G + o.fflnw, G + o.fflnb, G + o.b2, G + o.ralnw, G + o.ralnb, nullptr};
                 CK(ln_reduce_partials(lnp_a, lnp_b, nblk, H, dst6, st));
