@@ -113,11 +113,11 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
 
 // =============================================================================================== backward
 template <class T, int LP, int NW>
-__global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
+__global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : 1) attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                            const T* __restrict__ dctx, T* __restrict__ dqkv,
                                                            float* __restrict__ dbias,
                                                            const float* __restrict__ head_scale, int L, int nh, DropKey drop,
-                                                           unsigned long long* __restrict__ trace, GradAcc acc, Prefetch pf) {
+                                                           unsigned long long* __restrict__ trace, GradAcc acc) {
     // MB_ATTN_TRACE=1: phase stamps of every block (100 MHz wall clock): 0 entry, 1 operands staged, 2 query sweep done,
     // 3 dQ bias flushed, 4 key sweep done, 5 exit
     auto stamp = [&](int k) { if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * 8 + k] = wall_clock64(); };
@@ -154,10 +154,6 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
     }
     for (int j = threadIdx.x; j < LP; j += NW * 64)
         mbias[j] = j < L ? (1.0f - (float)mask[(size_t)b * L + j]) * kMaskNeg : kPadNeg;
-    // the kernel's own global loads are done (staged): touch this block's slice of what the launches behind it will read cold
-    // (common.h Prefetch); the loads drain under the two sweeps, which only use LDS
-    u32x4 pfv[4];
-    prefetch_issue<4>(pf, mask, pfv);
     // per-lane running column sums of the dQ / dK / dV tiles this wave produces (its own row only; rows >= L excluded);
     // reduced over the 16 rows and the waves once, at the very end
     f32x4 cq[4], ck[4], cv[4];
@@ -316,7 +312,6 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(const T* __restrict__
     }
     stamp(4);
     flush_all();
-    prefetch_retire<4>(pf, pfv);
     stamp(5);
 }
 
@@ -349,9 +344,9 @@ static int launch_fwd(const void* qkv, const int64_t* mask, void* ctx, float* pr
 }
 template <class T, int LP, int NW>
 static int launch_bwd(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, float* dbias, const float* hsc, int B,
-                      int L, int nh, DropKey drop, hipStream_t st, GradAcc acc, Prefetch pf) {
+                      int L, int nh, DropKey drop, hipStream_t st, GradAcc acc) {
     hipLaunchKernelGGL((attn_bwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, mask,
-                       (const T*)dctx, (T*)dqkv, dbias, hsc, L, nh, drop, attn_trace_buffer(B * nh), acc, pf);
+                       (const T*)dctx, (T*)dqkv, dbias, hsc, L, nh, drop, attn_trace_buffer(B * nh), acc);
     return (int)hipGetLastError();
 }
 
@@ -378,26 +373,26 @@ int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx
 }
 
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx, void* dqkv,
-                       float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale, GradAcc acc, Prefetch pf) {
+                       float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale, GradAcc acc) {
     (void)ctx;   // D_i is recomputed as sum_j dP_ij P_ij, the forward output is not needed
     if (L < 1 || L > 128) return MB_ERR_SHAPE;
     const int LP = (L + 31) / 32 * 32;
     if (dtype == DT_BF16) {
         switch (LP) {
-            case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, pf);
-            case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, pf);
-            case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, pf);
+            case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
+            case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
+            case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
             // 8 waves: all eight strips of a sweep at once, one block per CU (222 VGPRs, 76 KB of LDS).  Four waves with two strips each
             // (two blocks per CU, one round for the 384 blocks of B = 32) need 487 VGPRs, 217 of them spilled when capped at 256: not built; this kernel capped at 128 VGPRs
             // (two 8-wave blocks per CU, 118 registers spilled): 45 us against 36 us (scripts/exp/r3/attn128.sh).
-            default: return launch_bwd<bf16, 128, 8>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, pf);
+            default: return launch_bwd<bf16, 128, 8>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
         }
     } else if (dtype == DT_F32) {
         switch (LP) {
-            case 32: return launch_bwd<float, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, pf);
-            case 64: return launch_bwd<float, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, pf);
-            case 96: return launch_bwd<float, 96, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, pf);
-            default: return launch_bwd<float, 128, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, pf);   // 2 waves: LDS budget
+            case 32: return launch_bwd<float, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
+            case 64: return launch_bwd<float, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
+            case 96: return launch_bwd<float, 96, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
+            default: return launch_bwd<float, 128, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);   // 2 waves: LDS budget
         }
     }
     return MB_ERR_DTYPE;

@@ -125,19 +125,21 @@ __device__ __forceinline__ float row16_sum_to_lane15(float v) {
 // retired at its end), which leaves the lines in the memory-side cache for every XCD.  `sink` is never written (null): it only
 // keeps the loads alive.
 struct Prefetch { const void* p; size_t bytes; uint32_t* sink; };
-// `fallback`: any 16 readable bytes (what a launch without a prefetch region loads instead: K cache hits per thread).  The loads are
+// `fallback`: 1 KB of readable memory (what a launch without a prefetch region loads instead: K cache hits per thread).  The loads are
 // unconditional -- offsets past the region are clamped to its last 16 bytes -- because a load inside divergent control flow makes
 // the compiler wait for it at the join.
 template <int K>
 __device__ __forceinline__ void prefetch_issue(const Prefetch& pf, const void* fallback, u32x4 (&v)[K]) {
     const char* base = pf.p != nullptr ? (const char*)pf.p : (const char*)fallback;
-    const size_t last = (pf.p != nullptr && pf.bytes >= 16 ? pf.bytes : (size_t)16) - 16;
+    const bool real = pf.p != nullptr && pf.bytes >= 16;
+    const size_t last = (real ? pf.bytes : (size_t)16) - 16;
+    const size_t wrap = real ? ~(size_t)0 : (size_t)1008;     // no region: spread over 1 KB of `fallback` (not 76,800 threads on one line)
     const size_t nthr = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     __builtin_amdgcn_sched_barrier(0);           // every load the kernel issued so far stays in front of these ...
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         size_t off = ((size_t)k * nthr + tid) * 16;
-        off = off < last ? off : last;
+        off = real ? (off < last ? off : last) : (off & wrap);
         v[k] = *(const u32x4*)(base + off);
     }
     __builtin_amdgcn_sched_barrier(0);           // ... and nothing that follows is scheduled in between

@@ -50,8 +50,9 @@ struct mb_bert_engine : StepMixin {
                                    // to the in-line grouped launch, which keeps the step a single-stream sequence -- and its hipGraph a fast one)
     // MB_ADAMW_OVERLAP=C: the single-call step forks the optimizer of every finished chunk of C layers onto this stream (enqueue_step)
     int opt_chunk = 0;
-    int prefetch = 1;              // MB_PREFETCH bit 0: the LayerNorm kernels touch the next GEMMs' weights (common.h Prefetch); bit 1 (off: measured
-                                   // +9 us per step): the attention backward touches the GELU output for the grouped weight gradient; 0 = off
+    int prefetch = 1;              // MB_PREFETCH=0: the LayerNorm kernels do not touch the next GEMMs' weights (common.h Prefetch).  Touching
+                                   // ACTIVATIONS the same way (GELU output for the weight gradient, saved q | k | v for the attention backward)
+                                   // was measured +9 / +15 us per step and is not in the code (profiles/r03_prefetch_ab2.txt)
     hipStream_t opt_side = nullptr;
     std::vector<hipEvent_t> opt_ev;
     int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128), 0 = four launches
@@ -610,9 +611,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             // attention backward; the fused-QKV bias gradient (column sums of dqkv) is accumulated inside the kernel
             CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, dqkv, G + o.bqkv, B, L, nh,
                                   e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st,
-                                  e->head_mask ? e->head_mask + (size_t)l * nh : nullptr, acc,
-                                  // (MB_PREFETCH=3: ... and touches the GELU output, the largest operand the grouped weight gradient reads cold)
-                                  Prefetch{(e->prefetch & 2) ? (const void*)(ws + w.g) : nullptr, (size_t)T * I * esize(dt), nullptr}));
+                                  e->head_mask ? e->head_mask + (size_t)l * nh : nullptr, acc));
             auto launch_group = [&]() -> int {
                 if (inl) {
                     if (e->prof) CK((int)hipEventRecord(e->pev[2 * l], st));

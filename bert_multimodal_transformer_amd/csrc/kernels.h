@@ -162,8 +162,7 @@ int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx
 // dbias (fp32 [3H], may be null): += column sums of dqkv (bias grads of the fused QKV Linear)
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx,
                        void* dqkv, float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st,
-                       const float* head_scale = nullptr, GradAcc acc = {},
-                       Prefetch pf = {nullptr, 0, nullptr});       // region the kernel touches under its sweeps (common.h)
+                       const float* head_scale = nullptr, GradAcc acc = {});
 int attention_trace_fetch(unsigned long long* host_out, int max_blocks);     // MB_ATTN_TRACE=1: stamps of the last attention_backward
 
 // ------------------------------------------------------------------------------------------ XLNet (xlnet_attention.hip, xlnet_rowops.hip)
