@@ -399,3 +399,31 @@ def test_gemm_k_loops_hold_no_scalar_memory_reads(tmp_path):
     bad = [(fn, [l.strip() for l in text if re.search(r"\bs_(buffer_)?load_|s_memtime|s_memrealtime", l)][:2])
            for fn, text in loops if any(re.search(r"\bs_(buffer_)?load_|s_memtime|s_memrealtime", l) for l in text)]
     assert not bad, bad[:4]
+
+
+def test_prefetch_loads_do_not_delay_their_host_kernel(tmp_path):
+    """common.h Prefetch: the LayerNorm forward touches the next GEMMs' weights with four 16-byte loads per thread.  Loads return in
+    order, so the property that makes this free is a placement: the four loads sit BEHIND every load of the kernel's own and nothing
+    waits for memory between them and the output stores (the wave waits at its end).  Checked on the ISA of the object build()
+    produced: the compiler is free to reorder independent loads, the sched_barriers / the empty asm in common.h are what stops it."""
+    import shutil
+    from bert_multimodal_transformer_amd import build as mb_build
+    mb_build.build(verbose=False)
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not in this image")
+    obj = shutil.copy(os.path.join(mb_build.LIBDIR, "obj", "rowops.o"), tmp_path / "rowops.o")
+    subprocess.run([objdump, "--offloading", str(obj)], check=True, capture_output=True, cwd=tmp_path)
+    dev = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(tmp_path / dev[0])], check=True, capture_output=True, text=True).stdout
+    m = re.search(r"<_ZN2mb13ln_fwd_kernelIDF16bLi3E\w*>:\n(.*?)s_endpgm", dis, re.S)
+    assert m, "bf16 ln_fwd_kernel<3> not found"
+    ops = [l.split("//")[0].strip() for l in m.group(1).split("\n") if re.search(r"global_(load|store)|s_waitcnt vmcnt", l)]
+    # the prefetch loads are the only 16-byte loads through a 64-bit VGPR address (gamma / beta come through an SGPR base)
+    pf = [i for i, o in enumerate(ops) if re.match(r"global_load_dwordx4 v\[\d+:\d+\], v\[\d+:\d+\], off", o)]
+    assert len(pf) == 4, ops
+    own = [i for i, o in enumerate(ops) if o.startswith("global_load") and i not in pf]
+    stores = [i for i, o in enumerate(ops) if o.startswith("global_store")]
+    assert max(own) < pf[0], "a load of the kernel's own behind the prefetch would wait for it: %s" % ops
+    first_store = min(s for s in stores if s > pf[-1])
+    assert not any(o.startswith("s_waitcnt vmcnt") for o in ops[pf[0]:first_store]), ops
