@@ -699,7 +699,9 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
 // scalars into device memory) and a replayed hipGraph holding every other kernel of the step -- ONE in-order kernel sequence
 // (the grouped weight-gradient launches run in line: a graph with a side-stream fork / join replays on a slow path).
 // mode 1 = graph replay (captured on first use per shape), mode 2 = the same kernel sequence launched one by one (A/B
-// reference for the graph; also what runs while profiling events are on).
+// reference for the graph; also what runs while profiling events are on).  The prologue also converts the modality tensors into
+// MAG's packed GEMM operands, counts the occurrences of every token id and clears the loss accumulator (rowops.hip).
+
 // AdamW of flat range [b, en) of the decay slab (GEMM weights), inside a step (scalars from device memory)
 static int adamw_decay_range(mb_bert_engine* e, float* m, float* v, size_t b, size_t en, hipStream_t st) {
     if (en <= b) return MB_OK;
