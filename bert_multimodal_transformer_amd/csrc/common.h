@@ -126,8 +126,8 @@ __device__ __forceinline__ float row16_sum_to_lane15(float v) {
 // keeps the loads alive.
 struct Prefetch { const void* p; size_t bytes; uint32_t* sink; };
 // `fallback`: 1 KB of readable memory (what a launch without a prefetch region loads instead: K cache hits per thread).  The loads are
-// unconditional -- offsets past the region are clamped to its last 16 bytes -- because a load inside divergent control flow makes
-// the compiler wait for it at the join.
+// unconditional -- offsets past the region wrap into its first 1 KB (spread cache hits; clamping them all to one line made a
+// hot spot) -- because a load inside divergent control flow makes the compiler wait for it at the join.
 template <int K>
 __device__ __forceinline__ void prefetch_issue(const Prefetch& pf, const void* fallback, u32x4 (&v)[K]) {
     const char* base = pf.p != nullptr ? (const char*)pf.p : (const char*)fallback;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void prefetch_issue(const Prefetch& pf, const void* f
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         size_t off = ((size_t)k * nthr + tid) * 16;
-        off = real ? (off < last ? off : last) : (off & wrap);
+        off = real ? (off <= last ? off : (off & (size_t)1008)) : (off & wrap);     // past the region: spread over its first 1 KB (cache hits)
         v[k] = *(const u32x4*)(base + off);
     }
     __builtin_amdgcn_sched_barrier(0);           // ... and nothing that follows is scheduled in between
