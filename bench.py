@@ -62,6 +62,9 @@ def parse():
                    help="1 (default): each optimizer step = step prologue + ONE replayed hipGraph (mb_bert_train_step mode 1; MAG-BERT, "
                         "single process); 0: the same single engine call launching the kernels on the stream one by one")
     p.add_argument("--roofline-only", type=int, default=0, help="skip the training loop, print the GEMM table only")
+    p.add_argument("--secondary", type=int, default=1,
+                   help="1 (default, N = 1, headline workload only): also measure BASELINE.json configs[3] (MAG-XLNet, B=48, L=50) and the per-GPU "
+                        "shape of configs[4] (MAG-BERT MOSEI V=35, B=32, L=128) in the same process and append them as `secondary`")
     return p.parse_args()
 
 
@@ -280,6 +283,86 @@ def hbm_roofline(dtype_name, B, L, V, A, reps=20):
     return out
 
 
+def secondary_workload(kind, dataset, B, L, steps=20, warmup=5, dtype="bf16"):
+    """One of the other single-GPU configurations of BASELINE.json, measured in this process the way the headline is: the same
+    train_epoch step (pinned host batch gathered by the step's first launch, forward + MSE + backward + HF-AdamW + schedule +
+    zero_grad as ONE engine call / replayed hipGraph), `warmup` untimed + `steps` timed steps, then 5 launch-by-launch steps with
+    the engine's timing events on for the in-step duration of the dominant GEMM (the per-layer grouped weight gradient)."""
+    import ctypes as C
+    from bert_multimodal_transformer_amd import (AdamW, BertConfig, MAG_BertForSequenceClassification, MultimodalConfig, _lib,
+                                                 get_linear_schedule_with_warmup)
+    from bert_multimodal_transformer_amd.global_configs import DATASET_DIMS
+    from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
+    from bert_multimodal_transformer_amd.prefetch import PinnedBatchRing
+    V, A = DATASET_DIMS[dataset]["visual_dim"], DATASET_DIMS[dataset]["acoustic_dim"]
+    cdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    torch.manual_seed(4321)
+    if kind == "xlnet":
+        from bert_multimodal_transformer_amd import MAG_XLNetForSequenceClassification, XLNetConfig
+        model = MAG_XLNetForSequenceClassification(XLNetConfig(num_labels=1), MultimodalConfig(1.0, 0.5), visual_dim=V, acoustic_dim=A,
+                                                   compute_dtype=cdt)
+    else:
+        model = MAG_BertForSequenceClassification(BertConfig(num_labels=1), MultimodalConfig(1.0, 0.5), visual_dim=V, acoustic_dim=A,
+                                                  compute_dtype=cdt)
+    opt = AdamW(optimizer_grouped_parameters(model), lr=1e-5)
+    sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=0.1 * 1040, num_training_steps=1040)
+    model.train()
+    nb = 4
+    batches = make_batches(nb, B, L, V, A, seed=99, layout=kind)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ring = PinnedBatchRing(None, dev)
+
+    def run(n, start):
+        ring.loader = (batches[(start + i) % nb] for i in range(n))
+        for ids, vis, aco, mask, seg, lab in ring:
+            model.train_step(ids, vis, aco, mask, seg, lab, optimizer=opt, graph=True)
+            sch.step()
+
+    with model.stream_scope():
+        run(warmup, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps, warmup)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        core = model._core
+        fn = lambda name: getattr(_lib.lib(), "mb_%s_%s" % (core.kind, name))
+        resident = [tuple(t.to(dev) for t in b) for b in batches]
+        _lib.check(fn("set_profiling")(core.handle, 1))
+        acc = []
+        for i in range(6):
+            ids, vis, aco, mask, seg, lab = resident[i % nb]
+            model.train_step(ids, vis, aco, mask, seg, lab, optimizer=opt, graph=True)
+            sch.step()
+            torch.cuda.synchronize()
+            v = C.c_float()
+            _lib.check(fn("profile_wgrad_us")(core.handle, C.byref(v)))
+            acc.append(v.value)
+        _lib.check(fn("set_profiling")(core.handle, 0))
+    us = float(np.median(acc[1:]))
+    T, H_, I_ = B * L, 768, 3072
+    fl = 2.0 * T * (2 * H_ * I_ + 4 * H_ * H_)                       # the four weight gradients of a BertLayer
+    if kind == "xlnet":
+        fl += 2.0 * (2 * T) * H_ * H_                               # + the r projection's, over 2T position rows
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    mname = "MAG-BERT" if kind == "bert" else "MAG-XLNet"
+    out = {"metric": "train samples/sec %s %s seq_len=%d" % (mname, dataset.upper(), L), "value": round(B * steps / dt, 2), "unit": "samples/s",
+           "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": dtype,
+           "config": {"workload": "%s, %s dims (V=%d, A=%d), batch %d, seq_len %d, full optimizer step incl. per-step H2D, dropout on, "
+                                  "synthetic batches, random-init weights" % (mname, dataset.upper(), V, A, B, L),
+                      "step_call": "mb_%s_train_step, hipGraph replay" % kind},
+           "roofline": {"bound": "mfma", "kernel": "per-layer grouped weight gradient (%d problems, one launch)" % (4 if kind == "bert" else 7),
+                        "avg_us": round(us, 2), "achieved": round(fl / us * 1e-6, 1), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(fl / us * 1e-6 / peak, 4), "traffic": None,
+                        "timing": "HIP events on the launch stream, in-step (median of 5 launch-by-launch steps)"}}
+    gflop = TRAIN_GFLOP_PER_SAMPLE_C5 if (kind == "bert" and L == 128 and V == 35) else (TRAIN_GFLOP_PER_SAMPLE_L50 if (kind == "bert" and L == 50 and V == 47) else None)
+    if gflop:
+        out["step_tflops_algorithmic"] = round(out["value"] * gflop * 1e-3, 1)
+    del model, opt, sch, resident, ring
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_info():
     model = ""
     try:
@@ -353,9 +436,10 @@ def main():
     nb = 8
     batches = make_batches(nb, B, L, V, A, seed=1234 + rank, layout=a.model)      # pinned host tensors, as a DataLoader yields them
     dev = torch.device("cuda", torch.cuda.current_device())
-    single_call = model._core.fused_step_blocker() is None and opt.flat_step_args(model._core) is not None
-    use_graph = None if not single_call else (True if a.graph else "launches")
-    graph_on = use_graph is True
+    dp_call = dp is not None and dp.fused_ready() and opt.flat_step_args(model._core, allow_dp=True) is not None
+    single_call = dp_call or (model._core.fused_step_blocker() is None and opt.flat_step_args(model._core) is not None)
+    use_graph = None if not single_call else ((None if dp_call else True) if a.graph else "launches")
+    graph_on = single_call and bool(a.graph)
 
     def host_batches(n, start=0):
         for i in range(n):
@@ -441,8 +525,22 @@ def main():
         n3 = 7
     except Exception as ex:          # MB_GROUP_WGRAD=0 (separate launches): no grouped kernel to time
         print("note: in-step kernel timing unavailable (%s)" % ex, file=sys.stderr)
+    comm_stats = None
     if dp is not None:
-        comm_exposed_ms = dp.exposed_ms()
+        if dp_call:          # five more steps with the comm object's timing events on: the compute stream's stalls on the exchange
+            dp.comm.set_timing(True)
+            ex = []
+            for i in range(5):
+                ids, vis, aco, mask, seg, lab = resident[i % nb]
+                model.train_step(ids, vis, aco, mask, seg, lab, optimizer=opt, graph=use_graph)
+                sch.step()
+                ex.append(dp.exposed_ms())
+            dp.comm.set_timing(False)
+            comm_exposed_ms = float(np.median(ex))
+            comm_stats = dp.comm.stats()
+            n3 += 5
+        else:
+            comm_exposed_ms = dp.exposed_ms()
     scope.__exit__(None, None, None)
     loss = float(model.loss_running().item()) / max(1, total_steps + n2 + n3)
     value = world * B * a.steps / dt
@@ -462,7 +560,8 @@ def main():
                                       "optimizer step (per-step H2D of the batch + fwd+MSE+bwd%s+HF-AdamW+schedule+zero_grad), dropout on, "
                                       "random-init weights" % (a.dataset.upper(), V, A, B, L, "+RCCL all-reduce" if world > 1 else ""),
                           "global_batch": world * B, "seq_len": L, "parallelism": "dp%d" % world,
-                          "step_call": ("mb_bert_train_step, " + ("hipGraph replay" if graph_on else "stream launches")) if single_call else "passes driven from Python",
+                          "step_call": ("mb_%s_train_step%s, " % (model._core.kind, "_dp (gradient exchange issued from C between the graphs of the step)" if dp_call else "")
+                                        + ("hipGraph replay" if graph_on else "stream launches")) if single_call else "passes driven from Python",
                           "h2d": "batch packed into one pinned host block, gathered across PCIe by the step's first launch",
                           **({"grad_wire_dtype": "bf16" if dp.reducer.wire_dtype == torch.bfloat16 else "fp32"} if dp is not None else {})},
                "mean_loss": round(loss, 4), "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
@@ -470,6 +569,10 @@ def main():
                "value_inputs_resident": round(world * B / dt_res, 2)}
         if comm_exposed_ms is not None:
             out["comm_exposed_ms"] = round(comm_exposed_ms, 4)
+        if comm_stats is not None:
+            out["comm_collectives_per_step"] = comm_stats[0]
+            out["comm_mbytes_per_step"] = round(comm_stats[1] * 1e-6, 1)
+            out["comm_backend"] = "RCCL called from C (mb_comm)" if dp.comm.backend == "nccl" else "torch.distributed callbacks (%s)" % dp.comm.backend
         if graph_on:
             out["graph_captures_replays"] = list(model._core.graph_stats())
         if gflop:
@@ -561,6 +664,15 @@ def main():
                 out["roofline_hbm"]["instep_replayed"] = rows
         except Exception:
             pass
+    if a.secondary and rank == 0 and world == 1 and dp is None and a.model == "bert" and (B, L, a.dataset, a.dtype) == (48, 50, "mosi", "bf16"):
+        del resident
+        torch.cuda.empty_cache()
+        out["secondary"] = []
+        for kind, dataset, b2, l2 in (("xlnet", "mosi", 48, 50), ("bert", "mosei", 32, 128)):
+            try:
+                out["secondary"].append(secondary_workload(kind, dataset, b2, l2, dtype=a.dtype))
+            except Exception as ex:
+                out["secondary"].append({"metric": "%s %s B=%d L=%d" % (kind, dataset, b2, l2), "error": repr(ex)})
     if a.cpu_baseline and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(B, L, V, A, a.cpu_steps, a.model)
         out["cpu_baseline"].update(cpu_info())

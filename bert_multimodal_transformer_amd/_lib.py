@@ -76,6 +76,7 @@ PROTOTYPES = {
     "mb_debug_attention_trace": (_i, [_vp, _i]),
     "mb_xlnet_attention_probs": (_vp, [_vp, _i, C.POINTER(_i)]),
     "mb_xlnet_set_head_mask": (_i, [_vp, _vp]),
+    "mb_xlnet_set_perm_mask": (_i, [_vp, _vp]),
     "mb_bert_mark_grads_zero": (_i, [_vp, _i]),
     "mb_xlnet_mark_grads_zero": (_i, [_vp, _i]),
     "mb_bert_materialize_grads": (_i, [_vp, _vp]),
@@ -126,7 +127,30 @@ PROTOTYPES = {
     "mb_xlnet_graph_stats": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "mb_xlnet_trainable_count": (_sz, [_vp]),
     "mb_xlnet_stage_grad_ranges": (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz), _i]),
+    # data parallel (csrc/comm.hip)
+    "mb_comm_unique_id": (_i, [_vp]),
+    "mb_comm_create_rccl": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "mb_comm_create_callbacks": (_i, [_i, _i, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "mb_comm_destroy": (None, [_vp]),
+    "mb_comm_rank": (_i, [_vp]),
+    "mb_comm_world": (_i, [_vp]),
+    "mb_comm_stream": (_vp, [_vp]),
+    "mb_comm_scratch_bytes": (_sz, [_i, _i, _sz, _i, _i, _i]),
+    "mb_comm_bind_scratch": (_i, [_vp, _vp, _sz, _i, _sz, _i, _i, _i]),
+    "mb_comm_all_reduce": (_i, [_vp, _vp, _sz, _vp]),
+    "mb_comm_exchange_rows": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "mb_comm_set_timing": (_i, [_vp, _i]),
+    "mb_comm_exposed_ms": (_i, [_vp, C.POINTER(_f)]),
+    "mb_comm_stats": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
+    "mb_comm_last_error": (C.c_char_p, []),
+    "mb_bert_train_step_dp": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f,
+                                   _i, _i, _f, _f, _i, _vp, _vp]),
+    "mb_xlnet_train_step_dp": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f,
+                                    _i, _i, _f, _f, _i, _vp, _vp]),
 }
+
+ALL_REDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+ALL_GATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 _lib = None
 
@@ -154,7 +178,10 @@ def lib():
 
 def check(code):
     if code != 0:
-        raise MagbertError("%s (code %d)" % (lib().mb_error_string(code).decode(), code))
+        msg = lib().mb_error_string(code).decode()
+        if code == 1005 or 2000 <= code < 2100:
+            msg += ": " + (lib().mb_comm_last_error() or b"").decode()
+        raise MagbertError("%s (code %d)" % (msg, code))
 
 
 def ptr(t):

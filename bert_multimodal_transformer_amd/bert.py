@@ -73,8 +73,11 @@ class _EngineFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits):
-        # autograd may already have accumulated other loss terms into the p.grad views: this node adds to the buffer, never stores
-        ctx.core.mark_grads_zero(False)
+        # autograd may already have accumulated other loss terms into the p.grad views: then this node adds to the buffer.  The
+        # store path of the reference loop (model(...); loss.backward(); optimizer.step(); zero_grad()) survives when nothing on
+        # the torch side has written into the flat gradient buffer since it was zeroed (_Core.torch_wrote_grads)
+        if ctx.core.torch_wrote_grads():
+            ctx.core.mark_grads_zero(False)
         ctx.core._backward(dlogits.contiguous().float())
         return torch.zeros((), device=dlogits.device), None, None, ctx.core.inputs_embeds_grad() if ctx.want_emb else None
 
@@ -98,7 +101,8 @@ class _BaseFn(torch.autograd.Function):
         cd = core.compute_dtype
         ds = None if d_seq is None else d_seq.to(cd).contiguous()
         dz = None if (d_pooled is None or core.kind != "bert") else (d_pooled.float() * (1.0 - pooled * pooled)).to(cd).contiguous()    # tanh'
-        core.mark_grads_zero(False)           # as in _EngineFn: a node of somebody else's graph accumulates
+        if core.torch_wrote_grads():          # as in _EngineFn: next to somebody else's gradients this node accumulates
+            core.mark_grads_zero(False)
         core.backward_outputs(ds, dz)
         return torch.zeros((), device=core.device), None, None, None, core.inputs_embeds_grad() if ctx.want_emb else None
 
@@ -143,8 +147,9 @@ class _Core(object):
         self.anchor = torch.zeros((), device=self.device, requires_grad=True)
         self.weights_dirty = True
         self.loss_buf = torch.zeros(2, dtype=torch.float32, device=self.device)   # [last step, running sum]
-        self._optional = (None, None, None)
+        self._optional = (None, None, None, None)
         self._gz = True             # the flat gradient buffer holds zeros (mirror of the engine's flag: survives a re-created engine)
+        self._gz_version = self.grads._version
 
     # -- engine lifecycle ---------------------------------------------------------------------------
     def _fn(self, name):
@@ -175,11 +180,13 @@ class _Core(object):
             self._fn("destroy")(self.handle)
             self.ws = None
         self.handle = h
-        self._optional = (None, None, None)    # a new engine starts without head_mask / inputs_embeds / position_ids
+        self._optional = (None, None, None, None)    # a new engine starts without head_mask / inputs_embeds / position_ids / perm_mask
         self.max_B, self.max_L = B, L
 
     def _ensure(self, B, L):
         if B > self.max_B or L > self.max_L or self.ws is None:
+            # "logically zero, physically stale" gradients are a fact only the OLD engine knows: make them real zeros before it goes
+            self.materialize_grads()
             self._make_engine(max(B, self.max_B), max(L, self.max_L))
             nbytes = self._fn("workspace_bytes")(self.handle)
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -283,11 +290,11 @@ class _Core(object):
         self._ids_dev = ids.reshape(-1)
         return [_lib.ptr(t) for t in keep], keep
 
-    def _set_optional(self, head_mask=None, inputs_embeds=None, position_ids=None):
-        """head_mask [n_layers][n_heads] / inputs_embeds [B*L][H] (fp32 device tensors) / position_ids [B*L] (int64, MAG-BERT) or
-        None -> engine state; sticky in the engine, so every pass states what it wants (the single-call step refuses to run with
-        any of them set)."""
-        want = (head_mask, inputs_embeds, position_ids)
+    def _set_optional(self, head_mask=None, inputs_embeds=None, position_ids=None, perm=None):
+        """head_mask [n_layers][n_heads] / inputs_embeds [B*L][H] (fp32 device tensors) / position_ids [B*L] (int64, MAG-BERT) /
+        perm [B][L][L] (uint8, MAG-XLNet: who may not attend to whom) or None -> engine state; sticky in the engine, so every pass
+        states what it wants (the single-call step refuses to run with any of them set)."""
+        want = (head_mask, inputs_embeds, position_ids, perm)
         if all(x is None for x in want) and all(x is None for x in self._optional):
             return
         if self.kind != "bert":
@@ -295,7 +302,10 @@ class _Core(object):
                 raise NotImplementedError("position_ids is an argument of MAG-BERT only (XLNet has relative positions)")
             _lib.check(self.lib.mb_xlnet_set_head_mask(self.handle, _lib.ptr(head_mask)))
             _lib.check(self.lib.mb_xlnet_set_inputs_embeds(self.handle, _lib.ptr(inputs_embeds)))
+            _lib.check(self.lib.mb_xlnet_set_perm_mask(self.handle, _lib.ptr(perm)))
         else:
+            if perm is not None:
+                raise NotImplementedError("perm_mask is an argument of MAG-XLNet only")
             _lib.check(self.lib.mb_bert_set_head_mask(self.handle, _lib.ptr(head_mask)))
             _lib.check(self.lib.mb_bert_set_inputs_embeds(self.handle, _lib.ptr(inputs_embeds)))
             _lib.check(self.lib.mb_bert_set_position_ids(self.handle, _lib.ptr(position_ids)))
@@ -308,8 +318,16 @@ class _Core(object):
         if not known_zero:
             self.materialize_grads()          # whatever the caller is about to add to: real zeros where a fused step skipped them
         self._gz = bool(known_zero)
+        self._gz_version = self.grads._version     # torch-side writes into the buffer (or any `.grad` view of it) move this counter
         if self.handle is not None:
             _lib.check(self._fn("mark_grads_zero")(self.handle, 1 if known_zero else 0))
+
+    def torch_wrote_grads(self):
+        """True when something on the torch side (autograd accumulating another loss term into a `.grad` view, a hand edit) has
+        written into the flat gradient buffer since our own zeroing declared it known-zero: every `.grad` is a view of the one
+        buffer and shares its version counter, which the engine's own raw-pointer writes never touch.  A second backward without a
+        zero_grad() in between finds the flag already consumed (_gz False) and accumulates as well."""
+        return (not self._gz) or self.grads._version != getattr(self, "_gz_version", -1)
 
     def materialize_grads(self):
         """A single-call step that ends with the optimizer does not write the zeros of optimizer.zero_grad() over the layers'
@@ -342,7 +360,7 @@ class _Core(object):
         return self.ws[off: off + B * L * H * 4].view(torch.float32).view(B, L, H).clone()
 
     def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, training, head_mask=None,
-                inputs_embeds=None, position_ids=None):
+                inputs_embeds=None, position_ids=None, perm=None):
         dev = self.device
         if inputs_embeds is not None:               # bert.py:158-168 / xlnet.py:306-313: shapes come from the embeddings, the ids are not read
             inputs_embeds = inputs_embeds.detach().to(dev, torch.float32).contiguous()
@@ -357,7 +375,11 @@ class _Core(object):
             self.sync_weights()
         if position_ids is not None:
             position_ids = position_ids.to(dev, torch.int64).expand(B, L).contiguous()
-        self._set_optional(self.head_mask_table(head_mask), inputs_embeds, position_ids)
+        if perm is not None:
+            perm = perm.to(dev, torch.uint8).contiguous()
+            if tuple(perm.shape) != (B, L, L):
+                raise ValueError("perm_mask must be [B, L, L] = %s, got %s" % ((B, L, L), tuple(perm.shape)))
+        self._set_optional(self.head_mask_table(head_mask), inputs_embeds, position_ids, perm)
         ptr, keep = self._inputs(input_ids, visual, acoustic, attention_mask, token_type_ids, labels)
         logits = torch.empty(B, self.config.num_labels, dtype=torch.float32, device=dev)
         if training:
@@ -397,10 +419,12 @@ class _Core(object):
             return "MB_OVERLAP_WGRAD=1: the side-stream weight gradients of MAG-XLNet are driven stage by stage"
         return None
 
-    def train_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, opt, loss_scale=1.0, mode=2):
+    def train_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, opt, loss_scale=1.0, mode=2, comm=None):
         """One optimizer step as ONE engine call (include/magbert_hip.h: mb_bert_train_step): the step prologue (batch gather,
         dropout keys, AdamW scalars -> device memory) followed by every kernel of the step, launched one by one (mode 2) or as
-        a replayed hipGraph (mode 1).  opt: None (gradient-accumulation micro-step, no update) or AdamW.flat_step_args()."""
+        a replayed hipGraph (mode 1).  opt: None (gradient-accumulation micro-step, no update) or AdamW.flat_step_args().
+        comm (distributed.Comm): the data-parallel form, mb_*_train_step_dp -- the same step as a chain of graphs with the
+        gradient exchange issued from C between them."""
         B, L = input_ids.shape
         self._ensure(B, L)
         if self.weights_dirty:
@@ -419,14 +443,18 @@ class _Core(object):
         self._lab_ptr = None        # the engine's own staging copy: a later stand-alone backward needs a new forward
         self.training_last = True
         o = opt or {}
+        if comm is not None and opt is None:
+            raise ValueError("the data-parallel single-call step ends with the optimizer (micro-steps exchange nothing)")
+        extra = () if comm is None else (comm.handle,)
         with _Core._Hop(self):
-            _lib.check(self._fn("train_step")(
+            _lib.check(self._fn("train_step" if comm is None else "train_step_dp")(
                 self.handle, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5], B, L,
                 self.seed & (2 ** 64 - 1), self.step, _lib.ptr(logits), C.c_void_p(self.loss_buf.data_ptr()),
                 C.c_void_p(self.loss_buf.data_ptr() + 4), _lib.ptr(o.get("m")), _lib.ptr(o.get("v")), o.get("lr", 0.0),
                 o.get("beta1", 0.9), o.get("beta2", 0.999), o.get("eps", 1e-6), o.get("weight_decay", 0.0), int(o.get("t", 1)),
-                1 if o.get("correct_bias", True) else 0, o.get("grad_scale", 1.0), float(loss_scale), int(mode), self.stream()))
+                1 if o.get("correct_bias", True) else 0, o.get("grad_scale", 1.0), float(loss_scale), int(mode), self.stream(), *extra))
         self._gz = opt is not None          # the fused AdamW left the gradients zeroed / a micro-step left them populated
+        self._gz_version = self.grads._version
         return logits
 
     def stage_step(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, loss_scale=1.0, mode=1):
@@ -815,6 +843,24 @@ class _FusedStep(object):
         training_step + optimizer.step(); graph=False forces that path, graph=True raises if the single call is unavailable.
         Pass optimizer=None on gradient-accumulation micro-steps.  Returns the device loss scalar."""
         core = self._core
+        dp = getattr(optimizer, "_dp", None) if optimizer is not None else None
+        if dp is not None and graph is not False and dp.fused_ready() and core.kind in ("bert", "xlnet") and \
+                os.environ.get("MB_OVERLAP_WGRAD", "0") in ("", "0"):
+            # data parallel: the same single call with the gradient exchange inside (mb_*_train_step_dp, distributed.Comm)
+            opt = optimizer.flat_step_args(core, allow_dp=True)
+            if opt is not None:
+                optimizer._t += 1
+                opt["t"] = optimizer._t
+                optimizer._opt_called = True
+                launches = graph == "launches" or (graph is None and os.environ.get("MB_STEP_GRAPH", "1") == "0")
+                B_, L_ = input_ids.shape
+                core._ensure(B_, L_)
+                core.train_step(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, opt, loss_scale=loss_scale,
+                                mode=2 if launches else 1, comm=dp.get_comm(B_ * L_))
+                dp._last_fused = True
+                return core.loss_buf[0]
+        if dp is not None:
+            dp._last_fused = False
         why = core.fused_step_blocker()
         opt = None
         if why is None and optimizer is not None:

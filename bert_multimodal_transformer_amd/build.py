@@ -10,8 +10,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmagbert_hip.so")
 SOURCES = ["gemm.hip", "rowops.hip", "mag.hip", "attention.hip", "xlnet_attention.hip", "xlnet_rowops.hip", "head.hip", "adamw.hip",
-           "engine.hip", "xlnet_engine.hip"]
-HEADERS = ["common.h", "kernels.h", "attn_common.h", "engine_common.h", os.path.join("..", "..", "include", "magbert_hip.h")]
+           "engine.hip", "xlnet_engine.hip", "comm.hip"]
+HEADERS = ["common.h", "kernels.h", "attn_common.h", "engine_common.h", "comm.h", os.path.join("..", "..", "include", "magbert_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fvisibility=default",
          "-Wno-unused-result"]
 
@@ -57,7 +57,7 @@ def build(force=False, verbose=True):
             list(ex.map(cc, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])

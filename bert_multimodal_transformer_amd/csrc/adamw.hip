@@ -145,9 +145,11 @@ int adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, s
         if (var < 0) { const char* e = getenv("MB_ADAMW_VAR"); var = e ? atoi(e) : 3; const char* g2 = getenv("MB_ADAMW_GRID"); vgrid = g2 ? atoi(g2) : 0; }
         if (vgrid > 0 && (unsigned)vgrid < grid) grid = (unsigned)vgrid;
         const size_t kb = keep_begin, ke = keep_end;
-        if (var == 0 && ke > kb) var = 3;       // (the grid-strided kernel has no keep range)
-#define MB_AV(U, C) hipLaunchKernelGGL((adamw_var_kernel<true, U, C>), dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16*)shadow, n4, n_decay, sh_begin, sh_end, kb, ke, a, dyn, zero_grad)
-        if (var == 1) MB_AV(2, false); else if (var == 2) MB_AV(1, true); else if (var == 3) MB_AV(2, true); else if (var == 4) MB_AV(4, false); else if (var == 5) MB_AV(4, true); else
+        const int use = (var == 0 && ke > kb) ? 3 : var;       // (the grid-strided kernel has no keep range; this call only)
+        // MB_ADAMW_NT selects non-temporal accesses in every variant
+#define MB_AV(U, C) do { if (nt) hipLaunchKernelGGL((adamw_var_kernel<true, U, C>), dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16*)shadow, n4, n_decay, sh_begin, sh_end, kb, ke, a, dyn, zero_grad); \
+                         else hipLaunchKernelGGL((adamw_var_kernel<false, U, C>), dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16*)shadow, n4, n_decay, sh_begin, sh_end, kb, ke, a, dyn, zero_grad); } while (0)
+        if (use == 1) MB_AV(2, false); else if (use == 2) MB_AV(1, true); else if (use == 3) MB_AV(2, true); else if (use == 4) MB_AV(4, false); else if (use == 5) MB_AV(4, true); else
 #undef MB_AV
         if (nt) hipLaunchKernelGGL(adamw_kernel<true>, dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16*)shadow, n4, n_decay, sh_begin,
                                    sh_end, a, dyn, zero_grad);

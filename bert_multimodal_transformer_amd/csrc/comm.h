@@ -1,0 +1,54 @@
+// Gradient exchange of the data-parallel step (comm.hip): one object that owns the comm stream, its events and the backend --
+// RCCL (loaded at run time, called from C) or host callbacks (tests: gloo) -- plus the engine-agnostic "what happens between two
+// segments of a data-parallel step" logic both engines share.  NEW relative to the reference, which is single-device
+// (/root/reference/global_configs.py:4,7; the DistributedSampler import at multimodal_driver.py:21 is never used).
+#pragma once
+#include <vector>
+#include <utility>
+#include "kernels.h"
+#include "../../include/magbert_hip.h"
+
+struct mb_comm {
+    int rank = 0, world = 1;
+    // backend: RCCL communicator (opaque ncclComm_t) or host callbacks
+    void* nccl = nullptr;
+    mb_all_reduce_cb ar_cb = nullptr;
+    mb_all_gather_cb ag_cb = nullptr;
+    void* ctx = nullptr;
+    hipStream_t cs = nullptr;                 // the comm stream (created here: non-blocking, highest priority)
+    std::vector<hipEvent_t> fork_ev;          // "the compute stream got this far": one per piece of a step, re-recorded every step
+    int next_fork = 0;
+    hipEvent_t ev_layers = nullptr, ev_tail = nullptr;     // recorded on cs: every layer piece / every piece has been enqueued before
+    hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};   // timing events around the two places the compute stream waits for cs
+    bool timing = false, tev_used[2] = {false, false};
+    // scratch (caller-owned device memory, mb_comm_bind_scratch)
+    int wire = mb::DT_F32;                    // wire format of the all-reduce pieces: fp32 (exact) or bf16 (staged through `stage`)
+    char* scratch = nullptr; size_t scratch_bytes = 0;
+    size_t n_params = 0; int vocab = 0, H = 0, cap = 0;
+    size_t off_stage = 0, off_slot = 0, off_ids = 0, off_rows = 0;
+    bool rows_ready = false;
+    size_t pieces = 0, bytes_reduced = 0;     // statistics of the last step (tests / bench)
+};
+
+namespace mb {
+
+// what a data-parallel step exchanges: the layers' GEMM weight gradients in `chunk.size()` early pieces (each final when its
+// segment of the backward is done) and everything else in the tail, of which the word-embedding table moves row-wise
+struct DpSpec {
+    std::vector<std::pair<size_t, size_t>> chunk;   // [begin, end) floats of the flat gradient buffer, in the order the backward finishes them
+    size_t tail_begin = 0, tail_end = 0;            // the rest: [tail_begin, tail_end)
+    size_t word_off = 0;                            // the [vocab][H] word-embedding gradient inside the tail (rows = 0: dense)
+    int word_rows = 0, H = 0;
+    const int64_t* ids = nullptr; int T = 0;        // token ids of this rank's batch (device): the rows it touched
+};
+
+// segment numbering of a data-parallel step: [0, nchunk) backward chunks | nchunk: the last backward stage | nchunk + 1: the
+// optimizer over what was reduced early | nchunk + 2: the optimizer over the tail.  Called by train_step_impl's `between` hook
+// right after segment `seg` was enqueued on `st`.
+int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st);
+
+// row-wise sum of a [vocab][H] fp32 table over the ranks (comm.hip): every rank touched the rows ids[0..T)
+int comm_exchange_rows(mb_comm* c, float* table, const int64_t* ids, int T, hipStream_t s);
+int comm_all_reduce(mb_comm* c, float* g, size_t count, hipStream_t s);
+
+}  // namespace mb

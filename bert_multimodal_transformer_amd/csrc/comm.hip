@@ -1,0 +1,358 @@
+// Gradient exchange of the data-parallel training step, issued from C on a side HIP stream.
+//
+// NEW relative to the reference (single device: /root/reference/global_configs.py:4,7; multimodal_driver.py:21 imports a
+// DistributedSampler it never uses).  north_star: "data-parallel fine-tuning shards minibatches across the 8 GPUs of one node with a
+// single RCCL all-reduce of gradients over xGMI per step, overlapped with the backward on a side HIP stream".
+//
+// One logical all-reduce(sum) of the flat fp32 gradient buffer per optimizer step, cut where the backward finishes ranges of it:
+//   * the layers' GEMM weight gradients (77 % of the bytes) in chunks of MB_DP_CHUNK layers, each issued the moment its segment of
+//     the backward has been enqueued (event on the compute stream -> the comm stream waits -> ncclAllReduce in place);
+//   * the tail (pooler, embeddings, MAG, classifier, every bias / LayerNorm) after the last backward stage.  The word-embedding
+//     table -- 30,522 x 768 fp32 = 94 MB of which at most B*L rows per rank are non-zero -- moves ROW-WISE: every rank all-gathers
+//     the ids it touched and those rows (world x 7.4 MB instead of a 94 MB dense piece that would be produced last and fully exposed).
+// xGMI is point-to-point (7 links per GPU): a few large contiguous pieces let RCCL's rings use every link; no bucket copies exist
+// because the flat layout already makes each piece one contiguous range.  1/world is folded into the AdamW kernel.
+//
+// RCCL is loaded at run time (dlopen): the library has no link-time dependency on it, a host process that already carries an RCCL
+// (PyTorch does) shares that copy, and single-GPU users never load it.  The callback backend exists for the two-rank equality
+// tests, which run two ranks on ONE GPU (RCCL refuses that) over gloo.
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <rccl/rccl.h>
+#include "comm.h"
+
+using namespace mb;
+
+#define CK(x) do { int _e = (x); if (_e) return _e; } while (0)
+
+namespace {
+
+enum { MB_ERR_NCCL_BASE = 2000 };
+
+// ------------------------------------------------------------------------------------------------ RCCL, resolved at run time
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    char err[256] = {0};
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+char g_last_error[512] = {0};
+
+void load_rccl() {
+    Rccl& r = g_rccl;
+    // a copy that is already in the process first (torch/lib/librccl.so has no SONAME: it is known as "librccl.so"), then the ROCm install
+    const char* env = getenv("MB_RCCL_PATH");
+    const char* names[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (r.h) break;
+    }
+    for (int i = 0; i < 4 && !r.h; ++i) {
+        if (!names[i] || !*names[i]) continue;
+        r.h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!r.h) { snprintf(r.err, sizeof r.err, "librccl.so not found (%s)", dlerror()); return; }
+#define SYM(f) r.f = (decltype(r.f))dlsym(r.h, "nccl" #f); if (!r.f) { snprintf(r.err, sizeof r.err, "nccl" #f " missing in librccl"); return; }
+    SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllReduce) SYM(AllGather) SYM(GroupStart) SYM(GroupEnd) SYM(GetErrorString)
+#undef SYM
+}
+int rccl_ready() {
+    std::call_once(g_rccl_once, load_rccl);
+    if (g_rccl.err[0]) { snprintf(g_last_error, sizeof g_last_error, "%s", g_rccl.err); return MB_ERR_COMM; }
+    return MB_OK;
+}
+int nccl_rc(ncclResult_t r, const char* what) {
+    if (r == ncclSuccess) return MB_OK;
+    snprintf(g_last_error, sizeof g_last_error, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return MB_ERR_NCCL_BASE + (int)r;
+}
+
+// ------------------------------------------------------------------------------------------------ row exchange kernels
+// slot[r][id] (int32, -1 between exchanges): the position inside rank r's send buffer that carries row `id`, if rank r touched it.
+// A rank sends each touched row ONCE (the position that wins the atomicMax owns it); after the all-gather every rank fills the
+// other ranks' slot tables from the gathered ids, and the lowest rank that touched a row sums the contributions in rank order and
+// STORES the result: no atomics, no clearing pass, and every rank performs the same additions in the same order (the replicas'
+// gradients stay bit-identical).
+__global__ void rows_mark_kernel(const int64_t* __restrict__ ids, int T, int* __restrict__ slot_mine) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) atomicMax(&slot_mine[(int)ids[t]], t);
+}
+__global__ void rows_pack_kernel(const int64_t* __restrict__ ids, int T, const int* __restrict__ slot_mine, const float* __restrict__ table,
+                                 int H, int* __restrict__ send_ids, float* __restrict__ send_rows) {
+    const int t = blockIdx.x;
+    int id = -1;
+    if (t < T) {
+        const int cand = (int)ids[t];
+        if (slot_mine[cand] == t) id = cand;
+    }
+    if (threadIdx.x == 0) send_ids[t] = id;
+    if (id < 0) return;
+    const f32x4* src = (const f32x4*)(table + (size_t)id * H);
+    f32x4* dst = (f32x4*)(send_rows + (size_t)t * H);
+    for (int i = threadIdx.x; i < H / 4; i += blockDim.x) dst[i] = src[i];
+}
+__global__ void rows_index_kernel(const int* __restrict__ recv_ids, int total, int cap, int vocab, int* __restrict__ slot, int set) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int id = recv_ids[i];
+    if (id >= 0) slot[(size_t)(i / cap) * vocab + id] = set ? i % cap : -1;
+}
+__global__ void rows_combine_kernel(const int* __restrict__ recv_ids, const float* __restrict__ recv_rows, int world, int cap, int vocab,
+                                    int H, const int* __restrict__ slot, float* __restrict__ table) {
+    const int r = blockIdx.x / cap, t = blockIdx.x % cap;
+    const int id = recv_ids[(size_t)r * cap + t];
+    if (id < 0) return;
+    for (int q = 0; q < r; ++q)
+        if (slot[(size_t)q * vocab + id] >= 0) return;          // a lower rank touched this row too: it does the sum
+    for (int i = threadIdx.x; i < H / 4; i += blockDim.x) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int q = r; q < world; ++q) {
+            const int s = slot[(size_t)q * vocab + id];
+            if (s >= 0) acc += ((const f32x4*)(recv_rows + ((size_t)q * cap + s) * H))[i];
+        }
+        ((f32x4*)(table + (size_t)id * H))[i] = acc;
+    }
+}
+
+int all_gather(mb_comm* c, void* buf, size_t bytes_per_rank, hipStream_t s) {
+    if (c->nccl) {
+        const char* send = (const char*)buf + (size_t)c->rank * bytes_per_rank;       // in place: the rank's piece sits where it will be received
+        return nccl_rc(g_rccl.AllGather(send, buf, bytes_per_rank, ncclInt8, (ncclComm_t)c->nccl, s), "ncclAllGather");
+    }
+    if (c->ag_cb) return c->ag_cb(c->ctx, buf, bytes_per_rank, (void*)s);
+    return MB_ERR_COMM;
+}
+
+}  // namespace
+
+namespace mb {
+
+int comm_all_reduce(mb_comm* c, float* g, size_t count, hipStream_t s) {
+    if (!c || !g) return MB_ERR_ARG;
+    if (count == 0) return MB_OK;
+    ++c->pieces; c->bytes_reduced += count * (c->wire == DT_BF16 ? 2 : 4);
+    if (c->wire == DT_BF16) {
+        // bf16 wire: every rank rounds its gradients once, the sum travels and is accumulated in bf16, moments and parameters stay
+        // fp32.  Halves the bytes on the links (two GPUs share ONE xGMI link: the fp32 exchange lasts as long as the backward).
+        if (!c->scratch || count > c->n_params) return MB_ERR_ARG;
+        char* stage = c->scratch + c->off_stage;
+        CK(convert(DT_BF16, g, stage, count, s));
+        if (c->nccl) CK(nccl_rc(g_rccl.AllReduce(stage, stage, count, ncclBfloat16, ncclSum, (ncclComm_t)c->nccl, s), "ncclAllReduce"));
+        else if (c->ar_cb) CK(c->ar_cb(c->ctx, stage, count, DT_BF16, (void*)s));
+        else return MB_ERR_COMM;
+        return widen(DT_BF16, stage, g, count, s);
+    }
+    if (c->nccl) return nccl_rc(g_rccl.AllReduce(g, g, count, ncclFloat, ncclSum, (ncclComm_t)c->nccl, s), "ncclAllReduce");
+    if (c->ar_cb) return c->ar_cb(c->ctx, g, count, DT_F32, (void*)s);
+    return MB_ERR_COMM;
+}
+
+int comm_exchange_rows(mb_comm* c, float* table, const int64_t* ids, int T, hipStream_t s) {
+    if (!c || !c->rows_ready || !table || !ids || T < 1 || T > c->cap || (c->H & 3)) return MB_ERR_ARG;
+    const int world = c->world, cap = c->cap, vocab = c->vocab, H = c->H;
+    int* slot = (int*)(c->scratch + c->off_slot);
+    int* rids = (int*)(c->scratch + c->off_ids);
+    float* rrows = (float*)(c->scratch + c->off_rows);
+    int* slot_mine = slot + (size_t)c->rank * vocab;
+    rows_mark_kernel<<<(T + 255) / 256, 256, 0, s>>>(ids, T, slot_mine);
+    rows_pack_kernel<<<cap, 192, 0, s>>>(ids, T, slot_mine, table, H, rids + (size_t)c->rank * cap, rrows + (size_t)c->rank * cap * H);
+    CK((int)hipGetLastError());
+    CK(all_gather(c, rids, (size_t)cap * sizeof(int), s));
+    CK(all_gather(c, rrows, (size_t)cap * H * sizeof(float), s));
+    const int total = world * cap;
+    rows_index_kernel<<<(total + 255) / 256, 256, 0, s>>>(rids, total, cap, vocab, slot, 1);
+    rows_combine_kernel<<<total, 192, 0, s>>>(rids, rrows, world, cap, vocab, H, slot, table);
+    rows_index_kernel<<<(total + 255) / 256, 256, 0, s>>>(rids, total, cap, vocab, slot, 0);      // back to all -1 for the next step
+    c->bytes_reduced += (size_t)cap * (sizeof(int) + (size_t)H * sizeof(float));
+    c->pieces += 2;
+    return (int)hipGetLastError();
+}
+
+// the comm stream picks up after everything enqueued on `st` so far
+static int fork_to_comm(mb_comm* c, hipStream_t st) {
+    hipEvent_t ev = c->fork_ev[c->next_fork];
+    c->next_fork = (c->next_fork + 1) % (int)c->fork_ev.size();
+    CK((int)hipEventRecord(ev, st));
+    return (int)hipStreamWaitEvent(c->cs, ev, 0);
+}
+// the compute stream waits for `ev` (recorded on the comm stream); with timing on, the stall is bracketed by two timing events
+static int wait_timed(mb_comm* c, int k, hipEvent_t ev, hipStream_t st) {
+    if (c->timing) CK((int)hipEventRecord(c->tev[2 * k], st));
+    CK((int)hipStreamWaitEvent(st, ev, 0));
+    if (c->timing) { CK((int)hipEventRecord(c->tev[2 * k + 1], st)); c->tev_used[k] = true; }
+    return MB_OK;
+}
+
+int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st) {
+    const int nchunk = (int)sp.chunk.size();
+    if (seg == 0) { c->pieces = 0; c->bytes_reduced = 0; c->tev_used[0] = c->tev_used[1] = false; }
+    if (seg < nchunk) {
+        CK(fork_to_comm(c, st));
+        return comm_all_reduce(c, G + sp.chunk[seg].first, sp.chunk[seg].second - sp.chunk[seg].first, c->cs);
+    }
+    if (seg == nchunk) {
+        CK((int)hipEventRecord(c->ev_layers, c->cs));          // every layer piece is in front of this
+        CK(fork_to_comm(c, st));
+        const size_t w0 = sp.word_off, w1 = sp.word_off + (size_t)sp.word_rows * sp.H;
+        // (a batch beyond the agreed row capacity is an error, never a silent switch to the dense piece: the ranks must issue the
+        //  same collectives in the same order)
+        if (sp.word_rows > 0 && c->rows_ready && sp.T > c->cap) return MB_ERR_SHAPE;
+        if (sp.word_rows > 0 && c->rows_ready && sp.word_rows == c->vocab && sp.H == c->H && w0 >= sp.tail_begin && w1 <= sp.tail_end) {
+            CK(comm_all_reduce(c, G + sp.tail_begin, w0 - sp.tail_begin, c->cs));
+            CK(comm_exchange_rows(c, G + w0, sp.ids, sp.T, c->cs));
+            CK(comm_all_reduce(c, G + w1, sp.tail_end - w1, c->cs));
+        } else {
+            CK(comm_all_reduce(c, G + sp.tail_begin, sp.tail_end - sp.tail_begin, c->cs));
+        }
+        CK((int)hipEventRecord(c->ev_tail, c->cs));
+        // the optimizer of the layers' weights (next segment) needs the layer pieces only: it runs under the tail's exchange
+        return wait_timed(c, 0, c->ev_layers, st);
+    }
+    if (seg == nchunk + 1) return wait_timed(c, 1, c->ev_tail, st);
+    return MB_OK;
+}
+
+}  // namespace mb
+
+// ================================================================================================ C ABI
+extern "C" {
+
+const char* mb_comm_last_error(void) { return g_last_error; }
+
+int mb_comm_unique_id(void* id128) {
+    if (!id128) return MB_ERR_ARG;
+    CK(rccl_ready());
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    return nccl_rc(g_rccl.GetUniqueId((ncclUniqueId*)id128), "ncclGetUniqueId");
+}
+
+static int comm_common_init(mb_comm* c) {
+    int least = 0, greatest = 0;
+    CK((int)hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const char* pv = getenv("MB_DP_COMM_PRIORITY");
+    const int prio = (pv && atoi(pv) == 0) ? 0 : greatest;      // the exchange's few workgroups go in front of the backward's many
+    CK((int)hipStreamCreateWithPriority(&c->cs, hipStreamNonBlocking, prio));
+    c->fork_ev.assign(32, nullptr);
+    for (auto& ev : c->fork_ev) CK((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    CK((int)hipEventCreateWithFlags(&c->ev_layers, hipEventDisableTiming));
+    CK((int)hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    for (auto& ev : c->tev) CK((int)hipEventCreate(&ev));
+    return MB_OK;
+}
+
+int mb_comm_create_rccl(const void* id128, int rank, int world, mb_comm** out) {
+    if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return MB_ERR_ARG;
+    CK(rccl_ready());
+    mb_comm* c = new mb_comm();
+    c->rank = rank; c->world = world;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t comm = nullptr;
+    int r = nccl_rc(g_rccl.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+    if (r == MB_OK) { c->nccl = comm; r = comm_common_init(c); }
+    if (r != MB_OK) { mb_comm_destroy(c); return r; }
+    *out = c;
+    return MB_OK;
+}
+
+int mb_comm_create_callbacks(int rank, int world, mb_all_reduce_cb all_reduce, mb_all_gather_cb all_gather_, void* ctx, mb_comm** out) {
+    if (!out || !all_reduce || world < 1 || rank < 0 || rank >= world) return MB_ERR_ARG;
+    mb_comm* c = new mb_comm();
+    c->rank = rank; c->world = world; c->ar_cb = all_reduce; c->ag_cb = all_gather_; c->ctx = ctx;
+    const int r = comm_common_init(c);
+    if (r != MB_OK) { mb_comm_destroy(c); return r; }
+    *out = c;
+    return MB_OK;
+}
+
+void mb_comm_destroy(mb_comm* c) {
+    if (!c) return;
+    if (c->cs) hipStreamSynchronize(c->cs);
+    if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->nccl);
+    for (auto ev : c->fork_ev) if (ev) hipEventDestroy(ev);
+    if (c->ev_layers) hipEventDestroy(c->ev_layers);
+    if (c->ev_tail) hipEventDestroy(c->ev_tail);
+    for (auto ev : c->tev) if (ev) hipEventDestroy(ev);
+    if (c->cs) hipStreamDestroy(c->cs);
+    delete c;
+}
+
+int mb_comm_rank(const mb_comm* c) { return c ? c->rank : -1; }
+int mb_comm_world(const mb_comm* c) { return c ? c->world : 0; }
+void* mb_comm_stream(const mb_comm* c) { return c ? (void*)c->cs : nullptr; }
+
+static size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+size_t mb_comm_scratch_bytes(int world, int wire_dtype, size_t n_params, int vocab, int hidden, int capacity_rows) {
+    size_t b = 0;
+    if (wire_dtype == DT_BF16) b += al256(n_params * 2);
+    if (vocab > 0 && capacity_rows > 0) {
+        b += al256((size_t)world * vocab * sizeof(int));
+        b += al256((size_t)world * capacity_rows * sizeof(int));
+        b += al256((size_t)world * capacity_rows * hidden * sizeof(float));
+    }
+    return b ? b : 256;
+}
+
+int mb_comm_bind_scratch(mb_comm* c, void* scratch, size_t bytes, int wire_dtype, size_t n_params, int vocab, int hidden, int capacity_rows) {
+    if (!c || !scratch || (wire_dtype != DT_F32 && wire_dtype != DT_BF16)) return MB_ERR_ARG;
+    if (bytes < mb_comm_scratch_bytes(c->world, wire_dtype, n_params, vocab, hidden, capacity_rows)) return MB_ERR_ARG;
+    c->scratch = (char*)scratch; c->scratch_bytes = bytes; c->wire = wire_dtype; c->n_params = n_params;
+    c->vocab = vocab; c->H = hidden; c->cap = capacity_rows;
+    size_t o = 0;
+    c->off_stage = o; if (wire_dtype == DT_BF16) o += al256(n_params * 2);
+    c->rows_ready = vocab > 0 && capacity_rows > 0 && hidden > 0 && hidden % 4 == 0;
+    if (c->rows_ready) {
+        c->off_slot = o; o += al256((size_t)c->world * vocab * sizeof(int));
+        c->off_ids = o; o += al256((size_t)c->world * capacity_rows * sizeof(int));
+        c->off_rows = o; o += al256((size_t)c->world * capacity_rows * hidden * sizeof(float));
+        CK((int)hipMemsetAsync(c->scratch + c->off_slot, 0xFF, (size_t)c->world * vocab * sizeof(int), c->cs));     // all -1
+    }
+    return MB_OK;
+}
+
+int mb_comm_all_reduce(mb_comm* c, float* buf, size_t count, void* stream) {
+    return comm_all_reduce(c, buf, count, (hipStream_t)stream);
+}
+int mb_comm_exchange_rows(mb_comm* c, float* table, const int64_t* ids, int T, void* stream) {
+    return comm_exchange_rows(c, table, ids, T, (hipStream_t)stream);
+}
+
+int mb_comm_set_timing(mb_comm* c, int on) {
+    if (!c) return MB_ERR_ARG;
+    c->timing = on != 0;
+    if (!on) c->tev_used[0] = c->tev_used[1] = false;
+    return MB_OK;
+}
+int mb_comm_exposed_ms(mb_comm* c, float* ms) {
+    if (!c || !ms) return MB_ERR_ARG;
+    float total = 0.f;
+    for (int k = 0; k < 2; ++k) {
+        if (!c->tev_used[k]) continue;
+        float t = 0.f;
+        CK((int)hipEventSynchronize(c->tev[2 * k + 1]));
+        CK((int)hipEventElapsedTime(&t, c->tev[2 * k], c->tev[2 * k + 1]));
+        total += t;
+    }
+    *ms = total;
+    return MB_OK;
+}
+int mb_comm_stats(const mb_comm* c, size_t* pieces, size_t* bytes) {
+    if (!c) return MB_ERR_ARG;
+    if (pieces) *pieces = c->pieces;
+    if (bytes) *bytes = c->bytes_reduced;
+    return MB_OK;
+}
+
+}  // extern "C"

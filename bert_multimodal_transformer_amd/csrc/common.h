@@ -131,7 +131,7 @@ struct Prefetch { const void* p; size_t bytes; uint32_t* sink; };
 template <int K>
 __device__ __forceinline__ void prefetch_issue(const Prefetch& pf, const void* fallback, u32x4 (&v)[K]) {
     const char* base = pf.p != nullptr ? (const char*)pf.p : (const char*)fallback;
-    const bool real = pf.p != nullptr && pf.bytes >= 16;
+    const bool real = pf.p != nullptr && pf.bytes >= 1024;      // (a smaller region could not take the wrapped offsets below)
     const size_t last = (real ? pf.bytes : (size_t)16) - 16;
     const size_t wrap = real ? ~(size_t)0 : (size_t)1008;     // no region: spread over 1 KB of `fallback` (not 76,800 threads on one line)
     const size_t nthr = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -14,6 +14,7 @@
 //   no-decay group: per layer {q,k,v bias (contiguous [3H]), attn.out bias, LN1 w/b, inter bias, out bias, LN2 w/b};
 //                   embeddings.LayerNorm ; pooler bias ; MAG biases + LayerNorm ; classifier.bias
 #include "engine_common.h"
+#include "comm.h"
 
 // ================================================================================================ engine
 struct LayerOff { size_t wqkv, wo, w1, w2, bqkv, bo, ln1w, ln1b, b1, b2, ln2w, ln2b; };
@@ -241,7 +242,9 @@ const char* mb_error_string(int code) {
         case MB_ERR_MODE: return "magbert: unsupported layout/epilogue combination";
         case MB_ERR_DTYPE: return "magbert: unsupported dtype";
         case MB_ERR_ARG: return "magbert: invalid argument";
-        default: return hipGetErrorString((hipError_t)code);
+        case MB_ERR_COMM: return "magbert: gradient exchange unavailable (mb_comm_last_error())";
+        default:
+            if (code >= 2000 && code < 2100) return "magbert: RCCL call failed (mb_comm_last_error())"; return hipGetErrorString((hipError_t)code);
     }
 }
 int mb_version(void) { return 100; }
@@ -797,6 +800,74 @@ int mb_bert_train_step(mb_bert_engine* e, const int64_t* input_ids, const float*
                                return enqueue_step(e, sg, nseg, B, L, lg, ls, lr_, m_, v_, sc, s);
                            },
                            nseg, [&](int sg, hipStream_t s) { return between_segments(e, sg, nseg, m, v, s); });
+}
+
+// ------------------------------------------------------------------------------------------------ data-parallel step, one call
+// mb_bert_train_step with the gradient exchange inside (include/magbert_hip.h, csrc/comm.hip).  Segments (each a LINEAR graph):
+//   [0, nchunk)  : (segment 0: forward + head) + the backward of C layers  -> between: all-reduce of those layers' GEMM weights
+//   nchunk       : MAG + embeddings + the ONE LayerNorm / bias reduction   -> between: the tail's exchange; wait for the layer pieces
+//   nchunk + 1   : AdamW over the layers' GEMM weights [0, pooler)         -> between: wait for the tail
+//   nchunk + 2   : AdamW over the rest of the decay slab + the no-decay slab
+static int enqueue_step_dp(mb_bert_engine* e, int seg, int nchunk, int C, int B, int L, float* logits, float* loss, float* loss_run, float* m,
+                           float* v, float loss_scale, hipStream_t st) {
+    char* ws = e->ws;
+    const int NL = e->c.num_layers;
+    const float* lab = (const float*)(ws + e->ws_in_lab);
+    float* keep_attn = e->attn_out;
+    e->attn_out = nullptr;
+    struct Restore { mb_bert_engine* e; float* p; ~Restore() { e->attn_out = p; } } restore{e, keep_attn};
+    if (e->head_mask || e->emb_in || e->pos_ids) return MB_ERR_MODE;
+    if (seg == 0)
+        CK(mb_bert_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
+                           (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
+                           loss_run, st));
+    if (seg < nchunk) return mb_bert_backward(e, nullptr, lab, loss_scale, seg == 0 ? 0 : 1 + seg * C, 1 + (seg + 1) * C, st);
+    if (seg == nchunk) return mb_bert_backward(e, nullptr, lab, loss_scale, NL + 1, NL + 2, st);
+    const AdamArgs none = {};
+    const size_t nd = e->n_decay, n = e->n_params;
+    if (seg == nchunk + 1) {
+        CK(e->prof_mark(2 * NL, st));
+        return adamw_decay_range(e, m, v, 0, e->wp, st);
+    }
+    CK(adamw_decay_range(e, m, v, e->wp, nd, st));
+    CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
+    return e->prof_mark(2 * NL + 1, st);
+}
+
+int mb_bert_train_step_dp(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                          const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                          uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, float* m, float* v, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int opt_step, int correct_bias, float grad_scale,
+                          float loss_scale, int mode, void* stream, mb_comm* comm) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!e || !e->P || !e->G || !e->ws || !comm) return MB_ERR_ARG;
+    const mb_bert_config& c = e->c;
+    if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
+    if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !labels || !logits || !loss) return MB_ERR_ARG;
+    if (!m || !v || (mode != 1 && mode != 2)) return MB_ERR_ARG;
+    if (e->overlap_wgrad || !e->grouped) return MB_ERR_MODE;      // the exchange's pieces assume a layer's weight gradients are final when its stage returns
+    const int NL = c.num_layers;
+    int C = 2;
+    { const char* cv = getenv("MB_DP_CHUNK"); if (cv && atoi(cv) > 0) C = atoi(cv); }
+    if (C > NL || NL % C != 0) C = 1;
+    const int nchunk = NL / C, nseg = nchunk + 3;
+    DpSpec sp;
+    for (int s = 0; s < nchunk; ++s) {            // segment s finishes layers [NL - (s + 1) C, NL - s C)
+        const int l_lo = NL - (s + 1) * C, l_hi = NL - s * C;
+        sp.chunk.push_back({e->lo[l_lo].wqkv, l_hi < NL ? e->lo[l_hi].wqkv : e->wp});
+    }
+    sp.tail_begin = e->wp; sp.tail_end = e->n_params;
+    sp.word_off = e->word; sp.word_rows = c.vocab_size; sp.H = c.hidden_size;
+    sp.ids = (const int64_t*)(e->ws + e->ws_in_ids); sp.T = B * L;
+    e->training = 1;
+    CK(prepare_pass(e, B * L, st));
+    return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
+                           labels, B, L, seed, step, logits, loss, loss_run, m, v, lr, beta1, beta2, eps, weight_decay, opt_step,
+                           correct_bias, grad_scale, loss_scale, mode, e->prof, st,
+                           [&](int sg, float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
+                               return enqueue_step_dp(e, sg, nchunk, C, B, L, lg, ls, lr_, m_, v_, sc, s);
+                           },
+                           nseg, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, 1);
 }
 
 // ------------------------------------------------------------------------------------------------ stage-driven step (data parallel)

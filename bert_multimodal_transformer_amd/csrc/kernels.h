@@ -10,6 +10,7 @@ enum {
     MB_ERR_MODE = 1002,      // unsupported epilogue / layout combination
     MB_ERR_DTYPE = 1003,
     MB_ERR_ARG = 1004,
+    MB_ERR_COMM = 1005,      // gradient exchange: RCCL missing / no backend (mb_comm_last_error() has the text); 2000 + n = ncclResult_t n
 };
 
 // ------------------------------------------------------------------------------------------ GEMM
@@ -169,15 +170,17 @@ int attention_trace_fetch(unsigned long long* host_out, int max_blocks);     // 
 // relative attention core, L <= 128.  qkv [T][3H] token-major, kr [B][2L][H], psave/gsave [B][nh][LP][LP] (LP = 32 | 64 | 128 >= L).
 int xlnet_attention_forward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
                             const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask, void* vec,
-                            void* psave, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale = nullptr);
+                            void* psave, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale = nullptr,
+                            const uint8_t* perm = nullptr);      // perm [B][L][L] bytes or null: != 0 <=> query i may not attend to key j (xlnet.py:265-296)
 int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
                              const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask,
                              const void* psave, const void* dvec, void* gsave, void* dqkv, void* dkr, float* d_rwb,
                              float* d_rrb, float* d_rsb, float* d_seg, int B, int L, int nh, DropKey drop, hipStream_t st,
-                             const float* head_scale = nullptr);     // head_scale [nh] or null: head_mask of the layer
+                             const float* head_scale = nullptr,      // head_scale [nh] or null: head_mask of the layer
+                             GradAcc acc = {});                      // deterministic mode: the four bias / seg_embed column sums (common.h)
 // out[t] = dropout(word[ids[t]])  (xlnet.py:304-305) ; backward scatter-adds into dword
 int gather_drop_forward(int dtype, const int64_t* ids, const float* word, void* out, int rows, int H, DropKey drop, hipStream_t st);
-int gather_drop_backward(int dtype, const void* dout, const int64_t* ids, float* dword, int rows, int H, DropKey drop, hipStream_t st);
+int gather_drop_backward(int dtype, const void* dout, const int64_t* ids, float* dword, int rows, int H, DropKey drop, hipStream_t st, GradAcc acc = {});
 // (both: ids == nullptr = inputs_embeds -- `word` / `dword` are then [rows][H] fp32, read / written row by row)
 // y = x * dropout mask over [rows][H] (element index = offset)
 int drop_rows(int dtype, const void* x, void* y, int rows, int H, DropKey drop, hipStream_t st);

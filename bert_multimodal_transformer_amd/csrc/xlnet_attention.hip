@@ -23,6 +23,11 @@ struct XlParams {
     const float* seg_embed;                                                // [2][nh][64]
     const int64_t* seg; const int64_t* mask;                               // [B][L]
     const float* head_scale;                                               // [nh] or null: head_mask of this layer (xlnet.py:383)
+    // [B][L][L] bytes or null: perm[b][i][j] != 0 <=> data_mask[i, j, b] > 0 (xlnet.py:265-286: input_mask[j] + perm_mask[i, j]),
+    // query i may not attend to key j (the i == j exemption of non_tgt_mask, xlnet.py:288-296, still applies).  Forward only: the
+    // backward works from the saved probabilities, which are exact zeros wherever a score was masked.
+    const uint8_t* perm;
+    GradAcc acc;                                                           // deterministic mode: where the bias / seg_embed column sums go (common.h)
 };
 
 template <class T> __device__ __forceinline__ float ldT(const char* img, int pitch, int row, int d) {
@@ -163,7 +168,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
                     const float bd = *(const float*)(raw + (lane & 15) * RPIT + p * 4);
                     float s = (ac[jt][r] + cK[j] + bd + (si == segv[j] ? e0 : e1)) * scale;
                     if (j >= L) s = kPadNeg;
-                    else if (padf[j] && i != j) s -= kXlMask;
+                    else if (i != j && (padf[j] || (xp.perm != nullptr && i < L && xp.perm[((size_t)b * L + i) * L + j] != 0))) s -= kXlMask;
                     ac[jt][r] = s;
                     mx = fmaxf(mx, s);
                 }
@@ -210,7 +215,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
 // One pass for all five bias / segment-embedding gradients: flushed one tile at a time, each flush ended in a barrier that
 // waited for its atomics' round trip to L2.
 template <int NW, int N>
-__device__ __forceinline__ void flush_colsums(f32x4 (* const (&c4)[N])[4], float* const (&dst64)[N], float* scratch, int lane, int wave) {
+__device__ __forceinline__ void flush_colsums(f32x4 (* const (&c4)[N])[4], float* const (&dst64)[N], float* scratch, int lane, int wave, const GradAcc& acc) {
 #pragma unroll
     for (int n = 0; n < N; ++n)
 #pragma unroll
@@ -226,7 +231,7 @@ __device__ __forceinline__ void flush_colsums(f32x4 (* const (&c4)[N])[4], float
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) t += scratch[(n * NW + w) * 64 + col];
-        atomicAdd(dst64[n] + col, t);
+        grad_add(acc, dst64[n] + col, t);
     }
 }
 
@@ -396,7 +401,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
         static_assert(NW * 16 * (SPIT + GPIT) >= 5 * NW * 64 * 4, "strip buffers hold the five column-sum tiles");
         f32x4 (* const tiles[5])[4] = {&cw, &cr, &cs, &d0, &d1};
         float* const dst[5] = {d_rwb + h * 64, d_rrb + h * 64, d_rsb + h * 64, d_seg + (size_t)h * 64, d_seg + ((size_t)nh + h) * 64};
-        flush_colsums<NW, 5>(tiles, dst, (float*)gstr, lane, wave);
+        flush_colsums<NW, 5>(tiles, dst, (float*)gstr, lane, wave, xp.acc);
     }
 }
 
@@ -557,8 +562,8 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv_kernel(const T* __rest
 
 int xlnet_attention_forward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
                             const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask, void* vec,
-                            void* psave, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale) {
-    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale};
+                            void* psave, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale, const uint8_t* perm) {
+    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale, perm, GradAcc{nullptr, nullptr}};
     XL_DISPATCH({
         (void)NWQ; (void)NWK;
         hipLaunchKernelGGL((xl_attn_fwd_kernel<T, LP, NWF>), dim3(B * nh, LP / 16 / NWF), dim3(NWF * 64), 0, st, (const T*)qkv, (const T*)kr, xp,
@@ -570,8 +575,8 @@ int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const f
                              const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask,
                              const void* psave, const void* dvec, void* gsave, void* dqkv, void* dkr, float* d_rwb,
                              float* d_rrb, float* d_rsb, float* d_seg, int B, int L, int nh, DropKey drop, hipStream_t st,
-                             const float* head_scale) {
-    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale};
+                             const float* head_scale, GradAcc acc) {
+    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale, nullptr, acc};
     XL_DISPATCH({
         (void)NWF;
         hipLaunchKernelGGL((xl_attn_bwd_q_kernel<T, LP, NWQ>), dim3(B * nh, LP / 16 / NWQ), dim3(NWQ * 64), 0, st, (const T*)qkv, (const T*)kr,

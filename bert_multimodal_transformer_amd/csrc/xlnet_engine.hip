@@ -15,6 +15,7 @@
 //              summary.bias ; logits_proj.bias
 //   frozen   : transformer.mask_emb (never receives a gradient in this configuration; HF AdamW skips grad-less parameters)
 #include "engine_common.h"
+#include "comm.h"
 
 struct XlLayerOff { size_t q, k, v, o, r, w1, w2, seg, ralnw, fflnw, rrb, rsb, rwb, ralnb, fflnb, b1, b2; };
 struct XlLayerWs { size_t qkv, kr, vec, psave, s1, st1, y1, u, g, s2, st2; };
@@ -36,6 +37,7 @@ struct mb_xlnet_engine : StepMixin {
     int mag_nblk = 0;              // slabs MAG's gate backward wrote into slot n_layer
     int prefetch = 1;              // MB_PREFETCH=0: the LayerNorm kernels do not touch the next GEMMs' weights (common.h Prefetch)
     const float* head_mask = nullptr;   // mb_xlnet_set_head_mask: [n_layer][n_head] fp32 (caller-owned device memory)
+    const uint8_t* perm = nullptr;      // mb_xlnet_set_perm_mask: [B][L][L] bytes, != 0 <=> query i may not attend to key j (xlnet.py:265-296)
     const float* emb_in = nullptr;      // mb_xlnet_set_inputs_embeds: [B*L][H] fp32 word embeddings given instead of input_ids (xlnet.py:306-313)
     size_t ws_demb = 0;                 // fp32 [T][H]: gradient of the given embeddings
     bool ran_forward = false;
@@ -168,6 +170,10 @@ static void xl_build_layout(mb_xlnet_engine* e) {
     e->lnp_stride = ln_partials_floats((int)T, (int)H);        // per-layer slabs: the single-call step reduces all layers at once
     e->ws_lnp_a = w.take(e->lnp_stride * 4 * (c.n_layer + 1)); e->ws_lnp_b = w.take(e->lnp_stride * 4 * (c.n_layer + 1));      // (+1: MAG's gate)
     e->carve_step(w, T, (int)V, (int)A, c.max_batch, c.num_labels, XS_LAYER0 + 8 * c.n_layer);
+    if (e->deterministic) {          // 64-bit shadow of everything behind the layers' GEMM weights (those have ONE writer per element)
+        e->det_begin = e->wsum; e->det_end = e->n_trainable;
+        e->ws_det = w.take((e->det_end - e->det_begin) * sizeof(long long));
+    }
     e->ws_bytes = w.off;
 }
 
@@ -214,6 +220,7 @@ int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out) {
     e->deferred = e->overlap_wgrad && (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->d_inner % e->group_wgrad == 0 &&
                   cfg->d_model % e->group_wgrad == 0;
     e->c = *cfg;
+    if (const char* v = getenv("MB_DETERMINISTIC")) e->deterministic = atoi(v);
     xl_build_layout(e);
     if (const char* v = getenv("MB_XL_FUSE_QKV")) e->fuse_qkv = atoi(v) != 0;
     if (const char* pv = getenv("MB_PREFETCH")) e->prefetch = atoi(pv);
@@ -311,7 +318,7 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
         CK(gemm(dt, GEMM_NN, EPI_ADD_RES, R, H, H, ws + e->ws_pos, H, e->W(o.r), H, ws + w.kr, H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
         CK(xlnet_attention_forward(dt, qkv, ws + w.kr, P + o.rwb, P + o.rrb, P + o.rsb, P + o.seg, token_type_ids, attention_mask,
                                    ws + w.vec, ws + w.psave, B, L, nh, e->key(XS_LAYER0 + 8 * l + 0, pd), st,
-                                   e->head_mask ? e->head_mask + (size_t)l * nh : nullptr));
+                                   e->head_mask ? e->head_mask + (size_t)l * nh : nullptr, e->perm));
         // post_attention: dropout(vec . o^T) + h -> LayerNorm
         CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, T, H, H, ws + w.vec, H, e->W(o.o), H, ws + w.s1, H, nullptr, nullptr, nullptr, xin, H,
                 e->key(XS_LAYER0 + 8 * l + 1, pd), 1, 0, st));
@@ -356,11 +363,12 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
     char* ws = e->ws;
     const float pd = c.dropout;
     const bool hd = e->training && pd > 0.f;
+    const GradAcc acc = e->acc_of(ws, G);          // deterministic mode (MB_DETERMINISTIC=1): where the multi-writer sums go (as engine.hip)
     for (int stage = stage_begin; stage < stage_end; ++stage) {
         if (stage == 0) {
             CK(head_backward(dt, dlogits, e->logits, labels, loss_scale, (const float*)(ws + e->ws_head_pooled), P + e->wc,
                              ws + e->ws_dz, G + e->wc, G + e->bc, B, H, c.num_labels, e->key(XS_HEAD, c.summary_last_dropout), st,
-                             GradAcc{}, G + e->bsum, ws + e->ws_dxa, (size_t)T * H * es));     // + summary bias gradient, + dx cleared
+                             acc, G + e->bsum, ws + e->ws_dxa, (size_t)T * H * es));     // + summary bias gradient, + dx cleared
             CK(gemm(dt, GEMM_TN, EPI_ACCUM_F32, H, H, B, ws + e->ws_dz, H, ws + e->ws_xs, H, nullptr, H, nullptr, G + e->wsum, nullptr,
                     nullptr, 0, kNoDrop, 1, 64, st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, B, H, H, ws + e->ws_dz, H, e->W(e->wsum), H, ws + e->ws_dxs, H, nullptr, nullptr, nullptr,
@@ -403,7 +411,7 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                 for (GemmArgs& a : wg) a.overwrite = e->ow_pass ? 1 : 0;
             if (!grouped) CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, st));
             CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, du, I, nullptr, G + o.b1, nullptr, ws + w.u, I,
-                    e->key(XS_LAYER0 + 8 * l + 2, pd), 1, 0, st));
+                    e->key(XS_LAYER0 + 8 * l + 2, pd), 1, 0, st, 0, 0, acc));
             if (!grouped) CK(wgrad(dt, I, H, Tk, du, I, ws + w.y1, H, G + o.w1, H, st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, I, du, I, e->W(o.w1), H, t1, H, nullptr, nullptr, nullptr, dsA, H,
                     kNoDrop, 1, 0, st));
@@ -413,7 +421,7 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                                     Prefetch{e->prefetch ? e->W(o.q) : nullptr, (size_t)5 * H * H * (dt == DT_BF16 ? 2 : 4), nullptr}));
             if (!defer_ln) {
                 float* const dst6[6] = {G + o.fflnw, G + o.fflnb, G + o.b2, G + o.ralnw, G + o.ralnb, nullptr};
-                CK(ln_reduce_partials(lnp_a, lnp_b, nblk, H, dst6, st));
+                CK(ln_reduce_partials(lnp_a, lnp_b, nblk, H, dst6, st, acc));
             } else if (l == 0) {
                 LnReduceDst dst = {};
                 for (int k = 0; k < NL; ++k) {
@@ -427,7 +435,7 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                     dst.nblk[NL] = e->mag_nblk;
                 }
                 CK(ln_reduce_partials_layers((const float*)(ws + e->ws_lnp_a), (const float*)(ws + e->ws_lnp_b), e->lnp_stride,
-                                             mag_slabs ? NL + 1 : NL, nblk, H, dst, st));
+                                             mag_slabs ? NL + 1 : NL, nblk, H, dst, st, acc));
             }
             if (!grouped) CK(wgrad(dt, H, H, Tk, dzdB, H, ws + w.vec, H, G + o.o, H, st));
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.o), H, ws + e->ws_dvec, H, nullptr, nullptr, nullptr, nullptr, 0,
@@ -435,7 +443,7 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
             CK(xlnet_attention_backward(dt, ws + w.qkv, ws + w.kr, P + o.rwb, P + o.rrb, P + o.rsb, P + o.seg, e->seg, e->mask,
                                         ws + w.psave, ws + e->ws_dvec, ws + e->ws_gsave, dqkv, dkr, G + o.rwb, G + o.rrb,
                                         G + o.rsb, G + o.seg, B, L, nh, e->key(XS_LAYER0 + 8 * l + 0, pd), st,
-                                        e->head_mask ? e->head_mask + (size_t)l * nh : nullptr));
+                                        e->head_mask ? e->head_mask + (size_t)l * nh : nullptr, acc));
             if (grouped && e->deferred) {
                 if (!e->side) {
                     CK((int)hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
@@ -475,13 +483,13 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                                 P + e->mag_lnw, c.beta_shift, e->key(XS_MAG, c.mag_dropout), ws + e->ws_mag, e->mw, t1, nullptr,
                                 nullptr, G + e->mag_whv, G + e->mag_bhv, G + e->mag_wha, G + e->mag_bha, G + e->mag_wv, G + e->mag_bv,
                                 G + e->mag_wa, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb, T, H, c.visual_dim, c.acoustic_dim, true,
-                                st, GradAcc{}, true, (float*)(ws + e->ws_lnp_a) + (size_t)NL * e->lnp_stride,
+                                st, acc, true, (float*)(ws + e->ws_lnp_a) + (size_t)NL * e->lnp_stride,
                                 (float*)(ws + e->ws_lnp_b) + (size_t)NL * e->lnp_stride, &mblk));
                 e->mag_nblk = mblk;
                 if (!mag_slabs) {        // not a single-call step (or MAG in front of layer 0): reduce MAG's slabs right away
                     float* const m6[6] = {G + e->mag_bhv, G + e->mag_bha, G + e->mag_bv, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb};
                     CK(ln_reduce_partials((const float*)(ws + e->ws_lnp_a) + (size_t)NL * e->lnp_stride,
-                                          (const float*)(ws + e->ws_lnp_b) + (size_t)NL * e->lnp_stride, mblk, H, m6, st));
+                                          (const float*)(ws + e->ws_lnp_b) + (size_t)NL * e->lnp_stride, mblk, H, m6, st, acc));
                 }
                 {   // dx <- t1 as a kernel (a captured step holds kernel nodes only)
                     PrologueArgs cp = {};
@@ -493,7 +501,9 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
             if (grouped && e->deferred && l + 1 < NL) CK((int)hipStreamWaitEvent(st, e->evs[2 * (l + 1) + 1], 0));
         } else {
             if (e->deferred && e->side) CK((int)hipStreamWaitEvent(st, e->evs[1], 0));       // weight gradients of layer 0
-            CK(gather_drop_backward(dt, ws + e->ws_dxa, e->ids, e->ids ? G + e->word : (float*)(ws + e->ws_demb), T, H, e->key(XS_EMB, pd), st));
+            CK(gather_drop_backward(dt, ws + e->ws_dxa, e->ids, e->ids ? G + e->word : (float*)(ws + e->ws_demb), T, H, e->key(XS_EMB, pd), st, acc));
+            // deterministic mode: the integer sums become part of the fp32 gradients before anybody (AdamW, an exchange) reads them
+            CK(grad_fold(acc, G, e->det_begin, e->det_end, st));
         }
     }
     return MB_OK;
@@ -534,7 +544,7 @@ int mb_xlnet_train_step(mb_xlnet_engine* e, const int64_t* input_ids, const floa
     if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !labels || !logits || !loss) return MB_ERR_ARG;
     if ((m == nullptr) != (v == nullptr) || (mode != 1 && mode != 2)) return MB_ERR_ARG;
     if (e->deferred) return MB_ERR_MODE;          // MB_OVERLAP_WGRAD=1: the side-stream scheme is driven stage by stage (mb_xlnet_backward)
-    if (e->head_mask || e->emb_in) return MB_ERR_MODE;         // head_mask / inputs_embeds are arguments of explicit forwards only
+    if (e->head_mask || e->emb_in || e->perm) return MB_ERR_MODE;      // head_mask / inputs_embeds / perm_mask are arguments of explicit forwards only
     e->training = 1;
     CK(xl_prepare_pass(e, B * L, st));
     return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
@@ -545,6 +555,81 @@ int mb_xlnet_train_step(mb_xlnet_engine* e, const int64_t* input_ids, const floa
                            });
 }
 
+// ---- data-parallel step in one call (as mb_bert_train_step_dp: include/magbert_hip.h, csrc/comm.hip).  Segments: [0, nchunk) =
+// (segment 0: forward + head) + the backward of C layers | nchunk = the embedding stage | nchunk + 1 = AdamW over the layers' GEMM
+// weights [0, summary weight) | nchunk + 2 = AdamW over the rest
+static int xl_adamw_decay_range(mb_xlnet_engine* e, float* m, float* v, size_t b, size_t en, hipStream_t st) {
+    if (en <= b) return MB_OK;
+    const AdamArgs none = {};
+    const bool keep = e->keep_in_step();
+    auto clampr = [&](size_t x) { return x < b ? (size_t)0 : (x > en ? en - b : x - b); };
+    void* sh = e->c.dtype == DT_BF16 ? (void*)(e->SH + b * 2) : nullptr;
+    return adamw_step(e->P + b, e->G + b, m + b, v + b, sh, en - b, en - b, clampr(e->sh_begin), clampr(e->sh_end), none, 1, st,
+                      e->adam_state(e->ws), keep ? clampr(e->stale_begin) : 0, keep ? clampr(e->stale_end) : 0);
+}
+static int xl_enqueue_step_dp(mb_xlnet_engine* e, int seg, int nchunk, int C, int B, int L, float* logits, float* loss, float* loss_run,
+                              float* m, float* v, float loss_scale, hipStream_t st) {
+    char* ws = e->ws;
+    const int NL = e->c.n_layer;
+    const float* lab = (const float*)(ws + e->ws_in_lab);
+    if (seg == 0)
+        CK(mb_xlnet_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
+                            (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
+                            loss_run, st));
+    if (seg < nchunk) return mb_xlnet_backward(e, nullptr, lab, loss_scale, seg == 0 ? 0 : 1 + seg * C, 1 + (seg + 1) * C, st);
+    if (seg == nchunk) return mb_xlnet_backward(e, nullptr, lab, loss_scale, NL + 1, NL + 2, st);
+    const AdamArgs none = {};
+    const size_t nd = e->n_decay, n = e->n_trainable;
+    if (seg == nchunk + 1) {
+        CK(e->prof_mark(2 * NL, st));
+        return xl_adamw_decay_range(e, m, v, 0, e->wsum, st);
+    }
+    CK(xl_adamw_decay_range(e, m, v, e->wsum, nd, st));
+    CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
+    return e->prof_mark(2 * NL + 1, st);
+}
+
+int mb_xlnet_train_step_dp(mb_xlnet_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                           const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                           uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, float* m, float* v, float lr,
+                           float beta1, float beta2, float eps, float weight_decay, int opt_step, int correct_bias, float grad_scale,
+                           float loss_scale, int mode, void* stream, mb_comm* comm) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!e || !e->P || !e->G || !e->ws || !comm) return MB_ERR_ARG;
+    const mb_xlnet_config& c = e->c;
+    if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
+    if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !labels || !logits || !loss) return MB_ERR_ARG;
+    if (!m || !v || (mode != 1 && mode != 2)) return MB_ERR_ARG;
+    if (e->deferred || e->head_mask || e->emb_in || e->perm) return MB_ERR_MODE;
+    const int NL = c.n_layer;
+    int C = 2;
+    { const char* cv = getenv("MB_DP_CHUNK"); if (cv && atoi(cv) > 0) C = atoi(cv); }
+    if (C > NL || NL % C != 0) C = 1;
+    const int nchunk = NL / C, nseg = nchunk + 3;
+    DpSpec sp;
+    for (int s = 0; s < nchunk; ++s) {
+        const int l_lo = NL - (s + 1) * C, l_hi = NL - s * C;
+        sp.chunk.push_back({e->lo[l_lo].q, l_hi < NL ? e->lo[l_hi].q : e->wsum});
+    }
+    sp.tail_begin = e->wsum; sp.tail_end = e->n_trainable;
+    sp.word_off = e->word; sp.word_rows = c.vocab_size; sp.H = c.d_model;
+    sp.ids = (const int64_t*)(e->ws + e->ws_in_ids); sp.T = B * L;
+    e->training = 1;
+    CK(xl_prepare_pass(e, B * L, st));
+    return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
+                           labels, B, L, seed, step, logits, loss, loss_run, m, v, lr, beta1, beta2, eps, weight_decay, opt_step,
+                           correct_bias, grad_scale, loss_scale, mode, e->prof, st,
+                           [&](int sg, float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
+                               return xl_enqueue_step_dp(e, sg, nchunk, C, B, L, lg, ls, lr_, m_, v_, sc, s);
+                           },
+                           nseg, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, 1);
+}
+
+int mb_xlnet_set_perm_mask(mb_xlnet_engine* e, const uint8_t* perm) {
+    if (!e) return MB_ERR_ARG;
+    e->perm = perm;
+    return MB_OK;
+}
 int mb_xlnet_set_head_mask(mb_xlnet_engine* e, const float* head_mask) {
     if (!e) return MB_ERR_ARG;
     e->head_mask = head_mask;

@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256) gather_drop_fwd_kernel(const int64_t* __r
 // ids in a register before touching memory: the pad run of a sequence costs one atomic per column and chunk instead of one per row.
 template <class T, int RC>
 __global__ void __launch_bounds__(256) gather_drop_bwd_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids,
-                                                              float* dword, int rows, int H, DropKey drop) {
+                                                              float* dword, int rows, int H, DropKey drop, GradAcc ga) {
     drop.resolve();
     const int col = blockIdx.y * 256 + threadIdx.x;
     if (col >= H) return;
@@ -44,13 +44,13 @@ __global__ void __launch_bounds__(256) gather_drop_bwd_kernel(const T* __restric
         const size_t id = (size_t)ids[r];
         const float v = to_f(dout[(size_t)r * H + col]) * drop_mult(drop, (uint32_t)r * (uint32_t)H + (uint32_t)col);
         if (id != cur) {
-            atomicAdd(dword + cur * H + col, acc);
+            grad_add(ga, dword + cur * H + col, acc);
             acc = 0.f;
             cur = id;
         }
         acc += v;
     }
-    atomicAdd(dword + cur * H + col, acc);
+    grad_add(ga, dword + cur * H + col, acc);
 }
 
 // pos_seq = arange(L, -L, -1): row p <-> position L - p ; freq d in [0, H/2): inv = 10000^(-2d/H) ; [sin | cos]
@@ -116,10 +116,11 @@ int gather_drop_forward(int dtype, const int64_t* ids, const float* word, void* 
     MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((gather_drop_fwd_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, st, ids, word, (T*)out, rows, H, drop); })
     return (int)hipGetLastError();
 }
-int gather_drop_backward(int dtype, const void* dout, const int64_t* ids, float* dword, int rows, int H, DropKey drop, hipStream_t st) {
+int gather_drop_backward(int dtype, const void* dout, const int64_t* ids, float* dword, int rows, int H, DropKey drop, hipStream_t st, GradAcc acc) {
     if (rows <= 0) return MB_OK;
     constexpr int RC = 16;
-    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((gather_drop_bwd_kernel<T, RC>), dim3((rows + RC - 1) / RC, (H + 255) / 256), dim3(256), 0, st, (const T*)dout, ids, dword, rows, H, drop); })
+    if (ids == nullptr) acc = GradAcc{nullptr, nullptr};          // inputs_embeds: plain stores into the [rows][H] gradient, no table
+    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((gather_drop_bwd_kernel<T, RC>), dim3((rows + RC - 1) / RC, (H + 255) / 256), dim3(256), 0, st, (const T*)dout, ids, dword, rows, H, drop, acc); })
     return (int)hipGetLastError();
 }
 int drop_rows(int dtype, const void* x, void* y, int rows, int H, DropKey drop, hipStream_t st) {

@@ -20,11 +20,19 @@ import torch
 import torch.distributed as dist
 
 
+def tail_sizes(n_tail, world):
+    """how many samples of a ragged tail of n_tail samples each rank takes: as even as possible, the first n_tail % world ranks one
+    more (every rank gets >= 1 whenever n_tail >= world)"""
+    base, rem = divmod(n_tail, world)
+    return [base + (1 if r < rem else 0) for r in range(world)]
+
+
 def shard_indices(n, rank, world, batch_size, seed, epoch, drop_last=False):
     """Per-rank minibatch index lists for one epoch.  A global shuffle (same on all ranks) is cut into global
     batches of world*batch_size; each rank takes its contiguous slice.  The ragged tail (n % (world*bs)) is split
-    evenly so every rank runs the same number of steps (collectives stay matched); ranks may differ by one sample
-    in the last step, which the SUM/world averaging weights by 1/world per rank (stated in DESIGN.md)."""
+    as evenly as possible so every rank runs the same number of steps (collectives stay matched); ranks may differ by one
+    sample in the last step -- shard_step_sizes() says by how much, and the driver weights each rank's loss by its share
+    (loss_scale = B_rank * world / B_global), so the averaged gradient is the mean over the global batch."""
     g = torch.Generator()
     g.manual_seed(int(seed) * 1000003 + int(epoch))
     perm = torch.randperm(n, generator=g).tolist()
@@ -35,11 +43,20 @@ def shard_indices(n, rank, world, batch_size, seed, epoch, drop_last=False):
         base = i * gb + rank * batch_size
         out.append(perm[base: base + batch_size])
     tail = perm[full * gb:]
-    if tail and not drop_last:
-        per = (len(tail) + world - 1) // world
-        mine = tail[rank * per: (rank + 1) * per]
-        if len(tail) >= world:          # every rank gets >= 1 sample
-            out.append(mine)
+    if tail and not drop_last and len(tail) >= world:          # every rank gets >= 1 sample (a shorter tail is dropped)
+        sizes = tail_sizes(len(tail), world)
+        lo = sum(sizes[:rank])
+        out.append(tail[lo: lo + sizes[rank]])
+    return out
+
+
+def shard_step_sizes(n, world, batch_size, drop_last=False):
+    """[step] -> per-rank batch sizes of shard_indices' plan (the same on every rank, no communication)"""
+    gb = world * batch_size
+    out = [[batch_size] * world for _ in range(n // gb)]
+    t = n % gb
+    if t and not drop_last and t >= world:
+        out.append(tail_sizes(t, world))
     return out
 
 
@@ -136,6 +153,118 @@ def exchange_embedding_rows(grad_table, ids, capacity, group=None):
     return grad_table
 
 
+class Comm(object):
+    """The gradient exchange of the single-call data-parallel step (include/magbert_hip.h: mb_comm, csrc/comm.hip): a C object that
+    owns the comm stream and issues the collectives itself.  Backend "nccl" -> RCCL called from C (rank 0's ncclUniqueId travels
+    over torch.distributed once); any other backend (gloo: the two-ranks-on-one-GPU tests) -> host callbacks that run
+    torch.distributed collectives on the comm stream."""
+
+    def __init__(self, core, process_group=None, wire_dtype=torch.float32, sparse_rows=True, row_capacity=0):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib
+        L = _lib.lib()
+        self.core, self.pg = core, process_group
+        self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        self.backend = dist.get_backend(process_group)
+        dev = core.device
+        h = C.c_void_p()
+        if self.backend == "nccl":
+            idbuf = (C.c_uint8 * 128)()
+            if self.rank == 0:
+                _lib.check(L.mb_comm_unique_id(idbuf))
+            t = torch.tensor(list(idbuf), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+            raw = bytes(t.cpu().tolist())
+            _lib.check(L.mb_comm_create_rccl(C.c_char_p(raw), self.rank, self.world, C.byref(h)))
+            self._cbs = None
+        else:
+            self._cbs = (_lib.ALL_REDUCE_CB(self._all_reduce_cb), _lib.ALL_GATHER_CB(self._all_gather_cb))      # kept alive with the object
+            _lib.check(L.mb_comm_create_callbacks(self.rank, self.world, C.cast(self._cbs[0], C.c_void_p), C.cast(self._cbs[1], C.c_void_p),
+                                                  None, C.byref(h)))
+        self.handle = h
+        self.wire_dtype = wire_dtype
+        wire = _lib.DT_BF16 if wire_dtype == torch.bfloat16 else _lib.DT_F32
+        vocab = H = 0
+        if sparse_rows:
+            for name, off, numel, shape, decay in core.tensors:
+                if name.endswith("word_embeddings.weight") or name.endswith("word_embedding.weight"):
+                    vocab, H = int(shape[0]), int(shape[1])
+        self.sparse = vocab > 0
+        # per-rank row capacity of the word-embedding exchange: agreed once over the group (the largest engine of the group)
+        cap = torch.tensor([max(core.max_B * core.max_L, int(row_capacity), int(os.environ.get("MB_DP_ROW_CAPACITY", "0")))], dtype=torch.int64,
+                           device=dev if self.backend == "nccl" else "cpu")
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=process_group)
+        self.capacity = int(cap.item()) if self.sparse else 0
+        n = int(core.n_params)
+        nbytes = L.mb_comm_scratch_bytes(self.world, wire, n, vocab, H, self.capacity)
+        self.scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(L.mb_comm_bind_scratch(h, _lib.ptr(self.scratch), nbytes, wire, n, vocab, H, self.capacity))
+        self.stream = torch.cuda.ExternalStream(L.mb_comm_stream(h), device=dev)
+        self.stream.synchronize()          # (the slot table's one-time memset)
+
+    # -- callback backend -------------------------------------------------------------------------------------------------------
+    def _view(self, ptr, nbytes):
+        for t in (self.core.grads, self.scratch):
+            base = t.data_ptr()
+            if base <= ptr and ptr + nbytes <= base + t.numel() * t.element_size():
+                return t.view(torch.uint8)[ptr - base: ptr - base + nbytes] if t.dtype == torch.uint8 else \
+                    t.view(-1).view(torch.uint8)[ptr - base: ptr - base + nbytes]
+        raise RuntimeError("collective over memory that is neither the flat gradient buffer nor the comm scratch")
+
+    def _all_reduce_cb(self, ctx, buf, count, dtype, stream):
+        try:
+            tdt = torch.bfloat16 if dtype == self._lib.DT_BF16 else torch.float32
+            v = self._view(buf, count * (2 if tdt == torch.bfloat16 else 4)).view(tdt)
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.core.device)):
+                dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.pg)
+            return 0
+        except Exception:          # an exception must not unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            return 1005
+
+    def _all_gather_cb(self, ctx, buf, bytes_per_rank, stream):
+        try:
+            v = self._view(buf, bytes_per_rank * self.world)
+            parts = [v[r * bytes_per_rank: (r + 1) * bytes_per_rank] for r in range(self.world)]
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.core.device)):
+                dist.all_gather(parts, parts[self.rank].clone(), group=self.pg)
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1005
+
+    # -- measurement ------------------------------------------------------------------------------------------------------------
+    def set_timing(self, on):
+        self._lib.check(self._lib.lib().mb_comm_set_timing(self.handle, 1 if on else 0))
+
+    def exposed_ms(self):
+        import ctypes as C
+        v = C.c_float()
+        self._lib.check(self._lib.lib().mb_comm_exposed_ms(self.handle, C.byref(v)))
+        return float(v.value)
+
+    def stats(self):
+        """(collectives issued, bytes handed to them) in the last step"""
+        import ctypes as C
+        a, b = C.c_size_t(), C.c_size_t()
+        self._lib.check(self._lib.lib().mb_comm_stats(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if getattr(self, "handle", None) is not None:
+            self._lib.lib().mb_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def complement(ranges, n):
     """sorted disjoint (off, len) pieces of [0, n) that no range in `ranges` covers"""
     out, cur = [], 0
@@ -168,8 +297,12 @@ def stage_plan(core):
 class DataParallel(object):
     """Wraps a MAG_BertForSequenceClassification: hooks the engine's backward stages to the reducer."""
 
-    def __init__(self, model, optimizer=None, process_group=None):
+    def __init__(self, model, optimizer=None, process_group=None, row_capacity=0):
+        """row_capacity: tokens per rank and step the row-wise word-embedding exchange must hold (train_batch_size * max_seq_length);
+        0 = the size of the first single-call step (a later, larger batch then raises instead of silently diverging)"""
         self.model = model
+        self.row_capacity = int(row_capacity)
+        self.pg = process_group
         self.core = model._core
         # Wire format of the gradient exchange.  auto: bf16 only where the links are the bound -- bf16 perf mode, RCCL, and a
         # 2-GPU group (xGMI is point-to-point: two GPUs share ONE ~150 GB/s link, so the 443 MB fp32 exchange lasts as long as
@@ -197,6 +330,12 @@ class DataParallel(object):
                     self.word = (off, numel, tuple(shape))
         self.word_capacity = None           # rows per rank, agreed over the group at the first exchange
         self._micro_since_sync = 0
+        # The step as ONE engine call with the exchange issued from C (mb_bert_train_step_dp / mb_xlnet_train_step_dp): what
+        # train_step() runs whenever the step ends with the optimizer.  MB_DP_ENGINE=0 keeps every step on the stage-driven path
+        # below (which also serves gradient-accumulation micro-steps and foreign optimizers).
+        self.comm = None              # created at the first single-call step (the engine has its real size by then)
+        self._last_fused = False
+        self._comm_enabled = self.reducer.active and self.core.grads.is_cuda and os.environ.get("MB_DP_ENGINE", "1") != "0"
         # every rank draws its own dropout masks (the reference is single-process: nothing to be faithful to; identical masks on
         # every shard would correlate the regularisation noise).  The mixed seed is what get_rng_state() saves.
         if self.reducer.active and self.reducer.world > 1:
@@ -293,9 +432,23 @@ class DataParallel(object):
         self._tev[2 * k + 1].record(cs)
         self._tev_used[k] = True
 
+    def fused_ready(self):
+        """True when the next optimizer step can be the single engine call: the comm object exists, this is a synchronising
+        step and no micro-step has accumulated gradients since the last exchange (those are reduced densely by the stage hooks)"""
+        return self._comm_enabled and self.sync and self._micro_since_sync == 0
+
+    def get_comm(self, tokens):
+        """the C-side exchange object, created collectively at the first single-call step"""
+        if self.comm is None:
+            self.comm = Comm(self.core, self.pg, self.reducer.wire_dtype, sparse_rows=self.word is not None,
+                             row_capacity=max(self.row_capacity, int(tokens)))
+        return self.comm
+
     def exposed_ms(self):
         """Time the compute stream of the LAST step spent stalled on the gradient exchange (both waits: before the early
         AdamW ranges and before the late ones); synchronises.  0 when every piece had landed by the time it was needed."""
+        if self._last_fused:
+            return self.comm.exposed_ms()
         if self._tev is None:
             return 0.0
         total = 0.0

@@ -295,6 +295,15 @@ class ShardedBatchSampler(object):
         self.epoch += 1
         return iter(b)
 
+    def loss_scale(self, step):
+        """weight of this rank's mean loss in step `step`: B_rank * world / B_global (1.0 except in a ragged last step), so that the
+        1/world average of the ranks' gradients is the mean over the global batch"""
+        from .distributed import shard_step_sizes
+        sizes = shard_step_sizes(self.n, self.world, self.batch_size)
+        if step >= len(sizes):
+            return 1.0
+        return sizes[step][self.rank] * self.world / float(sum(sizes[step]))
+
     def __len__(self):
         return len(self._batches())
 
@@ -381,7 +390,8 @@ def prep_for_training(num_train_optimization_steps: int):
     rank, world = _dist()
     if world > 1:
         from .distributed import DataParallel
-        model._dp = DataParallel(model, optimizer)          # hooks the backward stages: RCCL all-reduce during the backward
+        # the gradient exchange: issued from C inside the single-call step (distributed.Comm), by stage hooks on accumulation steps
+        model._dp = DataParallel(model, optimizer, row_capacity=args.train_batch_size * args.max_seq_length)
         model._dp.broadcast_parameters(0)
     return model, optimizer, scheduler
 
@@ -440,14 +450,18 @@ def train_epoch(model: nn.Module, train_dataloader: DataLoader, optimizer, sched
         model.loss_running(reset=True)
         batches = _batches(train_dataloader)
         use_graph = None if getattr(args, "step_graph", True) else "launches"
+        sampler = getattr(train_dataloader, "batch_sampler", None)
         for step, batch in enumerate(batches):
             input_ids, visual, acoustic, input_mask, segment_ids, label_ids = batch
             update = (step + 1) % accum == 0
+            share = 1.0
             if dp is not None:
                 dp.sync = update                          # all-reduce only on the micro-step that is followed by step()
+                if hasattr(sampler, "loss_scale"):
+                    share = sampler.loss_scale(step)      # ragged last step: ranks weigh in by their sample counts
             # forward + MSE + backward (+ optimizer.step() + zero_grad()): one replayed hipGraph where the engine can
             model.train_step(input_ids, visual, acoustic, input_mask, segment_ids, label_ids,
-                             optimizer=optimizer if update else None, loss_scale=1.0 / accum, graph=use_graph)
+                             optimizer=optimizer if update else None, loss_scale=share / accum, graph=use_graph)
             nb_tr_steps += 1
             if update:
                 scheduler.step()

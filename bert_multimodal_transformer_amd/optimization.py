@@ -79,12 +79,12 @@ class AdamW(torch.optim.Optimizer):
             if covered:
                 core.mark_grads_zero(True)
 
-    def flat_step_args(self, core):
+    def flat_step_args(self, core, allow_dp=False):
         """Hyper-parameters of step() as ONE whole-buffer update, when this optimizer is exactly the driver's two parameter
         groups (multimodal_driver.py:329-343) over `core`'s flat buffer: [0, n_decay) decayed, the rest not, same lr / betas /
         eps / bias correction in both.  None otherwise (loose tensors, more groups, diverged groups, data parallel): the caller
         then runs step() as usual.  Used by the whole-step graph (mb_bert_train_step), which applies the update itself."""
-        if self._dp is not None or not self.fused_zero_grad:
+        if (self._dp is not None and not allow_dp) or not self.fused_zero_grad:
             return None
         if self._plan is None:
             self._build_plan()

@@ -77,14 +77,14 @@ class MAG_XLNetModel(_XlBase):
         """-> (output [B, L, d_model], (hidden_states), (attentions)) like xlnet.py:400-429.  `output` is the last layer's
         hidden state after the final dropout (xlnet.py:396) and carries an autograd edge into the engine: a head built on this
         model trains the whole stack, and inputs_embeds receives its gradient."""
-        _xl_unsupported(self, mems, perm_mask, target_mapping, input_mask)
+        _xl_unsupported(self, mems, target_mapping)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
-        B, L, attention_mask, token_type_ids = _xl_front(self, input_ids, inputs_embeds, attention_mask, token_type_ids)
+        B, L, attention_mask, token_type_ids, perm = _xl_front(self, input_ids, inputs_embeds, attention_mask, token_type_ids, input_mask, perm_mask)
         core = self._core
         core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, head_mask=head_mask,
-                     inputs_embeds=inputs_embeds)
+                     inputs_embeds=inputs_embeds, perm=perm)
         out = core.xl_model_output(B, L)
         if torch.is_grad_enabled():
             emb_edge = inputs_embeds if inputs_embeds is not None and inputs_embeds.requires_grad else None
@@ -97,25 +97,42 @@ class MAG_XLNetModel(_XlBase):
         return outputs
 
 
-def _xl_unsupported(model, mems, perm_mask, target_mapping, input_mask):
-    """The reference driver never passes these (multimodal_driver.py:363-370); each is a different attention pattern the
-    relative-attention kernels are not built for (DESIGN.md section 7 lists the reference lines)."""
-    model._unsupported(mems=mems, perm_mask=perm_mask, target_mapping=target_mapping, input_mask=input_mask)
+def _xl_unsupported(model, mems, target_mapping):
+    """The reference driver never passes these (multimodal_driver.py:363-370): cached memories of earlier segments (xlnet.py:81-91,
+    363-369) and the query stream of permutation-LM pre-training (xlnet.py:306-313, 387-427) -- neither exists in a fine-tuning
+    encoder (DESIGN.md section 7 lists the reference lines)."""
+    model._unsupported(mems=mems, target_mapping=target_mapping)
 
 
-def _xl_front(model, input_ids, inputs_embeds, attention_mask, token_type_ids):
-    """argument checks and defaults of MAG_XLNetModel.forward (xlnet.py:201-213, 255-262)"""
+def _xl_front(model, input_ids, inputs_embeds, attention_mask, token_type_ids, input_mask=None, perm_mask=None):
+    """argument checks and defaults of MAG_XLNetModel.forward (xlnet.py:201-213, 255-286).  Returns (B, L, attention_mask,
+    token_type_ids, perm): `perm` is None, or the uint8 [B, L, L] form of the reference's data_mask > 0 (xlnet.py:258-286:
+    data_mask[i, j, b] = input_mask[j, b] + perm_mask[i, j, b]; query i may not attend to key j, i == j exempt) -- in which case the
+    attention_mask handed to the engine is all ones, the byte mask carries everything."""
     if input_ids is not None and inputs_embeds is not None:
         raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")          # xlnet.py:201-203
     if input_ids is None and inputs_embeds is None:
         raise ValueError("You have to specify either input_ids or inputs_embeds")                          # xlnet.py:211-213
     B, L = input_ids.shape if input_ids is not None else inputs_embeds.shape[:-1]
     dev = model._core.device
+    # xlnet.py:258-262
+    assert input_mask is None or attention_mask is None, \
+        "You can only use one of input_mask (uses 1 for padding) or attention_mask (uses 0 for padding, added for compatbility with BERT). Please choose one."
+    perm = None
+    if perm_mask is not None or (input_mask is not None and bool(((input_mask != 0) & (input_mask != 1)).any())):
+        im = input_mask if input_mask is not None else (None if attention_mask is None else 1.0 - attention_mask.float())     # xlnet.py:263-264
+        data = perm_mask.to(dev, torch.float32) if perm_mask is not None else torch.zeros(B, L, L, device=dev)
+        if im is not None:
+            data = data + im.to(dev, torch.float32)[:, None, :]              # xlnet.py:265-266: input_mask[None] + perm_mask, as [B, i, j]
+        perm = (data > 0).to(torch.uint8)                                    # xlnet.py:283-284
+        attention_mask = torch.ones(B, L, dtype=torch.int64, device=dev)
+    elif input_mask is not None:                                             # a 0/1 input_mask is attention_mask negated (xlnet.py:263-264)
+        attention_mask = (input_mask.to(dev) <= 0).to(torch.int64)
     if attention_mask is None:
         attention_mask = torch.ones(B, L, dtype=torch.int64, device=dev)
     if token_type_ids is None:
         token_type_ids = torch.zeros(B, L, dtype=torch.int64, device=dev)
-    return B, L, attention_mask, token_type_ids
+    return B, L, attention_mask, token_type_ids, perm
 
 
 class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
@@ -137,14 +154,14 @@ class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
     def forward(self, input_ids, visual, acoustic, attention_mask=None, mems=None, perm_mask=None, target_mapping=None,
                 token_type_ids=None, input_mask=None, head_mask=None, inputs_embeds=None, use_cache=True, labels=None,
                 output_attentions=None, output_hidden_states=None):
-        _xl_unsupported(self, mems, perm_mask, target_mapping, input_mask)
+        _xl_unsupported(self, mems, target_mapping)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
-        B, L, attention_mask, token_type_ids = _xl_front(self, input_ids, inputs_embeds, attention_mask, token_type_ids)
+        B, L, attention_mask, token_type_ids, perm = _xl_front(self, input_ids, inputs_embeds, attention_mask, token_type_ids, input_mask, perm_mask)
         core = self._core
         logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, head_mask=head_mask,
-                              inputs_embeds=inputs_embeds)
+                              inputs_embeds=inputs_embeds, perm=perm)
         if torch.is_grad_enabled():
             emb_edge = inputs_embeds if inputs_embeds is not None and inputs_embeds.requires_grad else None
             logits = _EngineFn.apply(core.anchor, logits, core, emb_edge)

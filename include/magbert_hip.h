@@ -303,6 +303,12 @@ const void* mb_xlnet_attention_probs(const mb_xlnet_engine* e, int layer, int* p
  * contributes head_mask[l][h] times its attention output (attn_prob * head_mask after the dropout).  Explicit forwards /
  * backwards only: mb_xlnet_train_step returns MB_ERR_MODE while it is set. */
 int mb_xlnet_set_head_mask(mb_xlnet_engine* e, const float* head_mask);
+/* perm_mask / input_mask (xlnet.py:258-296): bytes [B][L][L] in device memory, sticky until reset with NULL; perm[b][i][j] != 0 <=>
+ * data_mask[i, j, b] = input_mask[j, b] + perm_mask[i, j, b] > 0, i.e. query i may not attend to key j (i == j is always allowed:
+ * non_tgt_mask, xlnet.py:288-296).  Combined with the attention_mask argument of the passes by OR.  Explicit forwards /
+ * backwards only (mb_xlnet_train_step returns MB_ERR_MODE while it is set).  The content stream (h) only: target_mapping and the
+ * query stream it feeds are not built. */
+int mb_xlnet_set_perm_mask(mb_xlnet_engine* e, const uint8_t* perm);
 int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap);
 int mb_xlnet_mark_grads_zero(mb_xlnet_engine* e, int known_zero);      /* as mb_bert_mark_grads_zero */
 /* inputs_embeds (xlnet.py:306-313) / the base model's autograd edge (xlnet.py:396-405 returns autograd tensors), as for MAG-BERT:
@@ -333,6 +339,60 @@ int mb_xlnet_load_batch(mb_xlnet_engine* e, const int64_t* input_ids, const floa
                         const void** staged6, void* stream);
 int mb_xlnet_graph_stats(const mb_xlnet_engine* e, size_t* captures, size_t* launches);
 size_t mb_xlnet_trainable_count(const mb_xlnet_engine* e);
+
+/* ------------------------------------------------------------------------------------------------ data parallel (new)
+ * The reference is single-device (global_configs.py:4,7; multimodal_driver.py:21 imports a DistributedSampler it never uses).
+ * Data-parallel fine-tuning here = one process per GPU, replicated parameters, the minibatch cut per rank, and ONE logical
+ * all-reduce(sum) of the flat fp32 gradient buffer per optimizer step, issued from C on a side HIP stream in pieces as the backward
+ * finishes them (csrc/comm.hip).  An mb_comm owns that stream, its events and the backend:
+ *   mb_comm_create_rccl      -- RCCL (dlopen'ed at run time; a process that already carries an RCCL, e.g. PyTorch's, shares it).
+ *                               id128 = the 128-byte ncclUniqueId rank 0 got from mb_comm_unique_id and handed to every rank
+ *                               (over torch.distributed, a file, MPI: the caller's plumbing);
+ *   mb_comm_create_callbacks -- host callbacks (tests: two gloo ranks on one GPU).  all_reduce(ctx, buf, count, dtype, stream):
+ *                               in-place sum over the ranks of `count` elements of MB_DT_*; all_gather(ctx, buf, bytes_per_rank,
+ *                               stream): in place, rank r's piece at buf + r * bytes_per_rank; both ordered on `stream`.
+ * Scratch (caller-owned device memory, mb_comm_bind_scratch): the bf16 wire staging ([n_params] bf16, only with wire_dtype =
+ * MB_DT_BF16) and the buffers of the row-wise word-embedding exchange (vocab x world slot table, world x capacity_rows ids and
+ * fp32 rows; vocab = 0 -> the table travels in the dense tail piece).  mb_comm_exposed_ms: with timing on, how long the compute
+ * stream of the LAST step was stalled on the exchange (synchronises on the timing events).  Error text: mb_comm_last_error(). */
+typedef struct mb_comm mb_comm;
+typedef int (*mb_all_reduce_cb)(void* ctx, void* buf, size_t count, int dtype, void* stream);
+typedef int (*mb_all_gather_cb)(void* ctx, void* buf, size_t bytes_per_rank, void* stream);
+int mb_comm_unique_id(void* id128);
+int mb_comm_create_rccl(const void* id128, int rank, int world, mb_comm** out);
+int mb_comm_create_callbacks(int rank, int world, mb_all_reduce_cb all_reduce, mb_all_gather_cb all_gather, void* ctx, mb_comm** out);
+void mb_comm_destroy(mb_comm* c);
+int mb_comm_rank(const mb_comm* c);
+int mb_comm_world(const mb_comm* c);
+void* mb_comm_stream(const mb_comm* c);                 /* the comm stream (hipStream_t) */
+size_t mb_comm_scratch_bytes(int world, int wire_dtype, size_t n_params, int vocab, int hidden, int capacity_rows);
+int mb_comm_bind_scratch(mb_comm* c, void* scratch, size_t bytes, int wire_dtype, size_t n_params, int vocab, int hidden, int capacity_rows);
+/* stand-alone pieces of the exchange (tests; both in place, ordered on `stream`): sum of buf[0, count) over the ranks in the wire
+ * format; row-wise sum of a [vocab][hidden] fp32 table of which this rank touched the rows ids[0, T) (T <= capacity_rows) */
+int mb_comm_all_reduce(mb_comm* c, float* buf, size_t count, void* stream);
+int mb_comm_exchange_rows(mb_comm* c, float* table, const int64_t* ids, int T, void* stream);
+int mb_comm_set_timing(mb_comm* c, int on);
+int mb_comm_exposed_ms(mb_comm* c, float* ms);
+int mb_comm_stats(const mb_comm* c, size_t* pieces, size_t* bytes);      /* collectives issued / bytes handed to them in the last step */
+const char* mb_comm_last_error(void);
+/* One optimizer step of a data-parallel rank as ONE engine call: mb_bert_train_step with the exchange inside.  The step runs as a
+ * chain of LINEAR replayed graphs (a graph with a cross-stream fork replays on ROCm 7.2's slow path) -- forward + head + the first
+ * chunk of layers | further chunks of MB_DP_CHUNK (default 2) layers | MAG + embeddings | AdamW of the layers' GEMM weights | AdamW
+ * of the rest -- and between two of them the host records an event and issues that chunk's all-reduce on the comm stream; the tail
+ * (everything that is not a layer's GEMM weight; the word-embedding table row-wise) goes out after the last backward stage and is
+ * hidden under the first AdamW launch.  Everything the single-call step has stays: the deferred LayerNorm reduction, stored (not
+ * accumulated) weight gradients, lazy zeroing.  grad_scale = 1 / world for the mean over the global batch (the pieces are SUMs).
+ * m, v must be given (a gradient-accumulation micro-step has nothing to exchange: use mb_bert_train_step). */
+int mb_bert_train_step_dp(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                          const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                          uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, float* m, float* v, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int opt_step, int correct_bias, float grad_scale,
+                          float loss_scale, int mode, void* stream, mb_comm* comm);
+int mb_xlnet_train_step_dp(mb_xlnet_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                           const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                           uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, float* m, float* v, float lr,
+                           float beta1, float beta2, float eps, float weight_decay, int opt_step, int correct_bias, float grad_scale,
+                           float loss_scale, int mode, void* stream, mb_comm* comm);
 
 #ifdef __cplusplus
 }

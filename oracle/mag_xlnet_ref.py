@@ -2,7 +2,7 @@
 
 Restates MAG_XLNetModel.forward / MAG_XLNetForSequenceClassification.forward (xlnet.py:148-429, 443-527) for the only
 configuration the driver exercises (xlnet-base-cased: attn_type "bi", bi_data False, clamp_len -1, mem_len None, no
-perm_mask / target_mapping / mems; multimodal_driver.py:363-370) and the transformers==3.0.2 XLNetLayer
+target_mapping / mems; multimodal_driver.py:363-370) and the transformers==3.0.2 XLNetLayer
 (XLNetRelativeAttention + XLNetFeedForward) and SequenceSummary it calls (xlnet.py:30,374-385,438,508).  Checked against
 the reference's own Python by oracle/make_golden.py (G6 fixtures).  Works in the reference's [L, B, .] layout internally.
 
@@ -121,7 +121,8 @@ class MAG_XLNetModel(nn.Module):
         pos_emb = torch.cat([torch.sin(sinusoid), torch.cos(sinusoid)], dim=-1)
         return pos_emb[:, None, :].expand(-1, bsz, -1)
 
-    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask=None, inputs_embeds=None):
+    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask=None, inputs_embeds=None,
+                perm_mask=None, input_mask=None):
         if head_mask is not None:            # xlnet.py:340-353: [n_head] -> every layer, [n_layer][n_head] as is
             head_mask = head_mask.to(torch.float32)
             if head_mask.dim() == 1:
@@ -135,9 +136,24 @@ class MAG_XLNetModel(nn.Module):
         visual = visual.transpose(0, 1).contiguous()                                    # xlnet.py:215-216
         acoustic = acoustic.transpose(0, 1).contiguous()
         seg = token_type_ids.transpose(0, 1).contiguous()
-        input_mask = 1.0 - attention_mask.transpose(0, 1).contiguous().float()          # xlnet.py:263-264
-        attn_mask = (input_mask[None][:, :, :, None] > 0).float()                       # xlnet.py:267-286 : [1, L, B, 1]
-        non_tgt = ((attn_mask - torch.eye(L)[:, :, None, None]) > 0).float()            # xlnet.py:288-296 : [L, L, B, 1]
+        assert input_mask is None or attention_mask is None                            # xlnet.py:258-262
+        input_mask = input_mask.transpose(0, 1).contiguous().float() if input_mask is not None else None      # xlnet.py:236
+        perm_mask = perm_mask.permute(1, 2, 0).contiguous().float() if perm_mask is not None else None        # xlnet.py:237: [i, j, b]
+        if input_mask is None and attention_mask is not None:
+            input_mask = 1.0 - attention_mask.transpose(0, 1).contiguous().float()      # xlnet.py:263-264
+        if input_mask is not None and perm_mask is not None:                            # xlnet.py:265-272
+            data_mask = input_mask[None] + perm_mask
+        elif input_mask is not None:
+            data_mask = input_mask[None]
+        elif perm_mask is not None:
+            data_mask = perm_mask
+        else:
+            data_mask = None
+        if data_mask is not None:
+            attn_mask = (data_mask[:, :, :, None] > 0).float()                          # xlnet.py:274-286 : [1 | L, L, B, 1]
+            non_tgt = ((attn_mask - torch.eye(L)[:, :, None, None]) > 0).float()        # xlnet.py:288-296 : [L, L, B, 1]
+        else:
+            non_tgt = torch.zeros(L, L, B, 1)                                           # (attn_mask None: nothing is masked)
         h = self.dropout(emb if inputs_embeds is not None else self.word_embedding(ids))        # xlnet.py:301-305
         seg_mat = (seg[:, None] != seg[None, :]).long()                                 # xlnet.py:326
         seg_mat = F.one_hot(seg_mat, num_classes=2).float()                             # xlnet.py:327
@@ -171,8 +187,9 @@ class MAG_XLNetForSequenceClassification(nn.Module):
         self.sequence_summary = SequenceSummary(config)
         self.logits_proj = nn.Linear(config.d_model, config.num_labels)
 
-    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels=None, head_mask=None, inputs_embeds=None):
-        out = self.transformer(input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask, inputs_embeds)
+    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels=None, head_mask=None, inputs_embeds=None,
+                perm_mask=None, input_mask=None):
+        out = self.transformer(input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask, inputs_embeds, perm_mask, input_mask)
         logits = self.logits_proj(self.sequence_summary(out))                           # xlnet.py:506-509
         outputs = (logits,)
         if labels is not None:                                                          # xlnet.py:515-524

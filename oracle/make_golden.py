@@ -251,7 +251,7 @@ def gen_full(cb, modeling, bert):
 
 
 def gen_xlnet(modeling, xlnet):
-    """G6: MAG-XLNet -- eval logits (B=4, 48 at L=50; B=3 at L=128, B=2 at L=100), train-mode p=0 loss + per-tensor grad norms."""
+    """G6: MAG-XLNet -- eval logits (B=4, 48 at L=50; B=3 at L=128, B=2 at L=100; with input_mask / perm_mask at B=4), train-mode p=0 loss + per-tensor grad norms."""
     from transformers.models.xlnet import modeling_xlnet as mx, configuration_xlnet as cx
     from oracle import weights
     from oracle import mag_xlnet_ref as X
@@ -277,6 +277,23 @@ def gen_xlnet(modeling, xlnet):
         print("G6 xlnet logits B=%d L=%d: max |diff| = %.3g (|logit| max %.3g)" % (B, L, d, float(a.abs().max())))
         assert d < 2e-5
         out["logits/B%d_L%d_seed%d" % (B, L, seed)] = a.numpy()
+    # round 4: input_mask instead of attention_mask (xlnet.py:258-264) and a perm_mask next to it (xlnet.py:265-296: the additive
+    # [qlen, klen, bsz] term of data_mask; content stream only -- no target_mapping)
+    B, L, seed = 4, 50, 31
+    ids, vis, aco, mask, seg, lab = _tb(weights.synthetic_xlnet_batch(B, L, 47, 74, seed=seed))
+    perm = torch.from_numpy((np.random.RandomState(77).rand(B, L, L) < 0.3).astype(np.float32))
+    with torch.no_grad():
+        a_im = ref(ids, vis, aco, token_type_ids=seg, input_mask=1.0 - mask.float(), labels=None)[0]
+        b_im = mine(ids, vis, aco, None, seg, input_mask=1.0 - mask.float())[0]
+        a_pm = ref(ids, vis, aco, token_type_ids=seg, attention_mask=mask, perm_mask=perm, labels=None)[0]
+        b_pm = mine(ids, vis, aco, mask, seg, perm_mask=perm)[0]
+    d_im, d_pm = _maxdiff(a_im, b_im), _maxdiff(a_pm, b_pm)
+    print("G6 xlnet input_mask logits: max |diff| = %.3g (vs attention_mask logits %.3g) ; perm_mask logits: max |diff| = %.3g, moved by %.3g"
+          % (d_im, _maxdiff(a_im, torch.from_numpy(out["logits/B4_L50_seed31"])), d_pm, _maxdiff(a_pm, a_im)))
+    assert d_im < 2e-5 and d_pm < 2e-5
+    out["logits_input_mask/B4_L50_seed31"] = a_im.numpy()
+    out["logits_perm_mask/B4_L50_seed31"] = a_pm.numpy()
+    out["perm_mask/B4_L50_rs77"] = perm.numpy().astype(np.uint8)
     ref, mine = pair(p_mag=0.0)
     for m in (ref, mine):
         m.train()

@@ -212,3 +212,188 @@ def test_rccl_call_path_single_rank(tmp_path, cdt):
     # same criterion as test_two_ranks_equal_one_process: Adam turns a ~0 gradient whose sign flips with the fp32 summation order
     # into a +-lr move; a missing stream dependency would instead corrupt whole contiguous ranges
     assert float(d.max()) <= 3 * 2 * 1e-3 * 1.1 and frac < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ the exchange inside the engine call
+_ENGINE_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO_ROOT"]); sys.path.insert(0, os.path.join(os.environ["REPO_ROOT"], "tests"))
+kind = os.environ.get("KIND", "bert")
+cdt = torch.bfloat16 if os.environ.get("CDT") == "bf16" else torch.float32
+if kind == "xlnet":
+    from test_xlnet_gpu import build, tb, weights, DEV
+    make = lambda: build(layers=2, p_mag=0.0, p=0.0)
+    batch = lambda seed: weights.synthetic_xlnet_batch(8, 50, 47, 74, seed=seed)
+else:
+    from test_model_gpu import build, tb, weights, DEV
+    make = lambda: build(layers=2, p_mag=0.0, hidden_p=0.0, attn_p=0.0, cdt=cdt)
+    batch = lambda seed: weights.synthetic_bert_batch(8, 50, 47, 74, seed=seed)
+from bert_multimodal_transformer_amd import AdamW, get_linear_schedule_with_warmup
+from bert_multimodal_transformer_amd.distributed import DataParallel
+from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+backend = os.environ.get("BACKEND", "gloo")
+use_dp = os.environ.get("USE_DP", "1") == "1" and (world > 1 or os.environ.get("MB_DP_FORCE") == "1")
+torch.cuda.set_device(0)
+if use_dp:
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}))
+m = make().train()
+opt = AdamW(optimizer_grouped_parameters(m), lr=1e-3)
+sch = get_linear_schedule_with_warmup(opt, 0, 100)
+dp = None
+if use_dp:
+    dp = DataParallel(m, opt)
+    dp.broadcast_parameters(0)
+first_m = None
+with m.stream_scope():
+    for s in range(int(os.environ.get("STEPS", "2"))):
+        ids, vis, aco, mask, seg, lab = tb(batch(90 + s), DEV)
+        lo, hi = (0, 8) if world == 1 else (rank * 4, rank * 4 + 4)
+        m.train_step(ids[lo:hi], vis[lo:hi], aco[lo:hi], mask[lo:hi], seg[lo:hi], lab[lo:hi], optimizer=opt,
+                     graph=None if os.environ.get("GRAPH", "1") == "1" else "launches")
+        sch.step()
+        if first_m is None:
+            torch.cuda.synchronize()
+            first_m = m._core._adam_m.cpu().clone()        # (1 - beta1) x the mean gradient over the global batch: what the exchange delivered
+torch.cuda.synchronize()
+fused = bool(dp is not None and dp._last_fused)
+stats = dp.comm.stats() if fused else (0, 0)
+torch.save(dict(p=m.flat_params.cpu(), m=first_m, fused=fused, stats=stats, sparse=bool(fused and dp.comm.sparse)),
+           os.environ["OUT"] + ".%d.%d.%s" % (world, rank, os.environ.get("USE_DP", "1")))
+if use_dp:
+    dist.barrier(); dist.destroy_process_group()
+print("OK", world, rank)
+"""
+
+
+def _run_engine_workers(tmp_path, world, env_extra, tag="w"):
+    script = tmp_path / (tag + ".py")
+    script.write_text(_ENGINE_WORKER)
+    port = 29900 + os.getpid() % 1000
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), REPO_ROOT=ROOT,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, o.decode()[-3000:]
+
+
+@pytest.mark.parametrize("kind,sparse,chunk", [("bert", "1", "2"), ("bert", "0", "1"), ("xlnet", "1", "2")])
+def test_single_call_dp_step_two_ranks_equal_one_process(tmp_path, kind, sparse, chunk):
+    """mb_*_train_step_dp -- ONE engine call per optimizer step with the gradient exchange issued from C between the graphs of the
+    step -- as two ranks with half the batch each (gloo through the callback backend: two ranks share this GPU) vs the plain
+    single-call step over the whole batch.  fp32, dropout off.  What the exchange delivered is read back from Adam's first moment
+    after step 1 (m = 0.1 x the mean gradient over the global batch): <= 5e-6 of its largest element everywhere, row-wise and dense
+    word-embedding exchange, one or two layers per piece; the replicas stay bit-identical."""
+    import torch
+    out = str(tmp_path / "eng")
+    common = dict(OUT=out, KIND=kind, MB_DP_SPARSE_EMB=sparse, MB_DP_CHUNK=chunk)
+    _run_engine_workers(tmp_path, 1, common)
+    _run_engine_workers(tmp_path, 2, common)
+    ref = torch.load(out + ".1.0.1")
+    a, b = torch.load(out + ".2.0.1"), torch.load(out + ".2.1.1")
+    assert a["fused"] and b["fused"] and not ref["fused"]
+    assert a["sparse"] == (sparse == "1")
+    assert torch.equal(a["p"], b["p"]) and torch.equal(a["m"], b["m"])
+    err = float((a["m"] - ref["m"]).abs().max()) / float(ref["m"].abs().max())
+    print("%s single-call DP(2 x 4) vs single(8): first-moment max |d| / max = %.3e; %d collectives, %.1f MB" %
+          (kind, err, a["stats"][0], a["stats"][1] * 1e-6))
+    assert err <= 5e-6
+    d = (a["p"] - ref["p"]).abs()
+    assert float(d.max()) <= 2 * 1e-3 * 1.1
+
+
+@pytest.mark.parametrize("cdt,graph", [("fp32", "1"), ("fp32", "0"), ("bf16", "1")])
+def test_single_call_dp_step_over_rccl_one_rank(tmp_path, cdt, graph):
+    """the same call over RCCL itself (dlopen'ed and driven from C: ncclCommInitRank from an id made by mb_comm_unique_id,
+    ncclAllReduce / ncclAllGather on the comm stream) with a one-rank communicator: every collective is an identity, so in
+    deterministic mode the parameters after three steps are BIT-IDENTICAL to the plain single-call step -- graph chain, events,
+    row-wise exchange (pack -> gather -> combine) and the split optimizer included.  bf16: the wire format rounds the gradients."""
+    import torch
+    out = str(tmp_path / "rc")
+    common = dict(OUT=out, KIND="bert", MB_DP_FORCE="1", BACKEND="nccl", STEPS="3", CDT=cdt, GRAPH=graph, MB_DETERMINISTIC="1")
+    _run_engine_workers(tmp_path, 1, dict(common, USE_DP="0"))
+    _run_engine_workers(tmp_path, 1, dict(common, USE_DP="1"))
+    a, b = torch.load(out + ".1.0.0"), torch.load(out + ".1.0.1")
+    assert b["fused"] and not a["fused"]
+    d = (a["p"] - b["p"]).abs()
+    print("RCCL 1-rank single-call DP vs plain (%s): max |dparam| %.3e; %d collectives, %.1f MB" % (cdt, float(d.max()), b["stats"][0], b["stats"][1] * 1e-6))
+    if cdt == "bf16":          # auto wire format of a <= 2-rank RCCL group in bf16 mode: bf16 (rounded once per rank)
+        assert float(d.max()) <= 3 * 2 * 1e-3 * 1.1 and float(d.mean()) <= 2e-5
+    else:
+        assert torch.equal(a["p"], b["p"])
+
+
+def test_row_exchange_kernels_with_scripted_peers():
+    """csrc/comm.hip's row-wise exchange of the word-embedding gradient (mark -> pack -> all-gather -> index -> combine) for a
+    THREE-rank group played by one process: the all-gather callback of each rank publishes its piece and fills in the pieces the
+    other ranks published (first pass: publish; second pass, on restored tables: the real exchange).  Every rank must end with the
+    dense sum of the three tables -- repeated ids inside a rank, ids shared between ranks, ids only one rank touched, padding
+    positions beyond T -- and all three bit-identical."""
+    import ctypes as C
+    import torch
+    from bert_multimodal_transformer_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    world, vocab, H, cap = 3, 997, 768, 96
+    g = torch.Generator().manual_seed(5)
+    T = [96, 57, 80]
+    ids = [torch.randint(0, 120 if r < 2 else vocab, (T[r],), generator=g) for r in range(world)]      # ranks 0 / 1 collide a lot
+    ids[2][:10] = ids[0][:10]
+    tables = []
+    for r in range(world):
+        t = torch.zeros(vocab, H)
+        u = ids[r].unique()
+        t[u] = torch.randn(len(u), H, generator=g)
+        tables.append(t)
+    dense = tables[0] + tables[1] + tables[2]
+    published = {}
+    state = {}
+
+    def make_cb(r):
+        def ag(ctx, buf, bpr, stream):
+            torch.cuda.synchronize()
+            sc = state[r]["scratch"]
+            off = buf - sc.data_ptr()
+            v = sc[off: off + bpr * world]
+            published[(r, bpr)] = v[r * bpr:(r + 1) * bpr].clone()
+            for q in range(world):
+                if q != r and (q, bpr) in published:
+                    v[q * bpr:(q + 1) * bpr].copy_(published[(q, bpr)])
+                elif q != r:
+                    v[q * bpr:(q + 1) * bpr].view(torch.int32).fill_(-1)      # nothing published yet: "no rows" (ids) / ignored (rows)
+            torch.cuda.synchronize()
+            return 0
+
+        def ar(ctx, buf, count, dtype, stream):
+            return 1004
+        return _lib.ALL_REDUCE_CB(ar), _lib.ALL_GATHER_CB(ag)
+
+    for r in range(world):
+        cbs = make_cb(r)
+        h = C.c_void_p()
+        _lib.check(L.mb_comm_create_callbacks(r, world, C.cast(cbs[0], C.c_void_p), C.cast(cbs[1], C.c_void_p), None, C.byref(h)))
+        nb = L.mb_comm_scratch_bytes(world, _lib.DT_F32, 1024, vocab, H, cap)
+        sc = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _lib.check(L.mb_comm_bind_scratch(h, _lib.ptr(sc), nb, _lib.DT_F32, 1024, vocab, H, cap))
+        state[r] = dict(h=h, cbs=cbs, scratch=sc, ids=ids[r].to(dev), stream=L.mb_comm_stream(h))
+    torch.cuda.synchronize()
+    results = None
+    for rounds in range(2):
+        results = []
+        for r in range(world):
+            tab = tables[r].to(dev).contiguous()
+            _lib.check(L.mb_comm_exchange_rows(state[r]["h"], _lib.ptr(tab), _lib.ptr(state[r]["ids"]), T[r], state[r]["stream"]))
+            torch.cuda.synchronize()
+            results.append(tab.cpu())
+    for r in range(world):
+        err = float((results[r] - dense).abs().max())
+        assert err <= 1e-5, (r, err)
+        assert torch.equal(results[r], results[0])
+    untouched = torch.ones(vocab, dtype=torch.bool)
+    untouched[torch.cat(ids).unique()] = False
+    assert float(results[0][untouched].abs().max()) == 0.0
+    for r in range(world):
+        L.mb_comm_destroy(state[r]["h"])

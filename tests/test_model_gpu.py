@@ -199,11 +199,16 @@ class _Replay(torch.nn.Module):
         return x * self.mult.view(x.shape)
 
 
-@pytest.mark.parametrize("cdt,tol_logit,tol_grad", [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 1e-2, 3e-2)])   # bf16 gradients: relative Frobenius error; MAG's gated tensors (LOOSE_BF16) 1e-1 (measured 7.7e-2 on W_hv)
-def test_train_mode_dropout_mask_replay(cdt, tol_logit, tol_grad):
+@pytest.mark.parametrize("cdt,tol_logit,tol_grad,layers,B,L", [
+    (torch.float32, 1e-3, 5e-3, 2, 3, 24),
+    (torch.bfloat16, 1e-2, 3e-2, 2, 3, 24),       # bf16 gradients: relative Frobenius error; MAG's gated tensors (LOOSE_BF16) 1e-1 (measured 7.7e-2 on W_hv)
+    (torch.bfloat16, 2e-2, 3e-2, 12, 48, 50),     # the BENCHMARKED step itself: 12 layers, BASELINE configs[1], bf16, dropout on at every site
+    (torch.float32, 1e-3, 5e-3, 12, 48, 50)])
+def test_train_mode_dropout_mask_replay(cdt, tol_logit, tol_grad, layers, B, L):
     """Dropout ON at every site (0.1 / 0.1 / MAG 0.5): the device masks are regenerated on the host from the
-    counter hash and replayed inside the oracle -> exact train-mode parity, forward and backward."""
-    layers, B, L, V, nh, H = 2, 3, 24, 47, 12, 768
+    counter hash and replayed inside the oracle -> exact train-mode parity, forward and backward -- at a toy shape and at the
+    shape bench.py times (12 layers, B=48, L=50: 64 dropout sites, 1.44 M attention-probability mask elements per layer)."""
+    V, nh, H = 47, 12, 768
     torch.manual_seed(99)
     m = build(V, layers, cdt).train()
     o = oracle(V, layers).train()

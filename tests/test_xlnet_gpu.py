@@ -4,12 +4,15 @@
       optimizer trajectory.
 Tolerances as in test_model_gpu.py: fp32 parity mode logits <= 1e-3 (north_star); bf16 stated per test.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from bert_multimodal_transformer_amd import (AdamW, MAG_XLNetForSequenceClassification, MAG_XLNetModel, MultimodalConfig,
                                              XLNetConfig, get_linear_schedule_with_warmup, rng)
@@ -479,3 +482,96 @@ def test_xlnet_single_call_step_equals_python_driven_passes():
         assert float(run["g"].abs().max()) == 0.0
         assert torch.equal(run["frozen"], ref["frozen"])
         assert run["stats"] == ((2, 4) if mode is True else (0, 0))
+
+
+def test_input_mask_and_perm_mask_match_reference_golden_fp32(golden):
+    """xlnet.py:258-296: `input_mask` (1 = padding) in place of attention_mask gives the same logits, and a `perm_mask` [B, L, L]
+    (1 = query i may not attend to key j; the i == j exemption of non_tgt_mask stays) moves them to what the REFERENCE's own
+    xlnet.py computed (fixture entries written by oracle/make_golden.py from the reference stack); passing both masks asserts
+    like the reference does."""
+    g = golden["g6_xlnet"]
+    m = build().eval()
+    ids, vis, aco, mask, seg, lab = tb(weights.synthetic_xlnet_batch(4, 50, 47, 74, seed=31), DEV)
+    perm = torch.from_numpy(g["perm_mask/B4_L50_rs77"].astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        a = m(ids, vis, aco, token_type_ids=seg, input_mask=1.0 - mask.float())[0].cpu().numpy()
+        b = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, perm_mask=perm)[0].cpu().numpy()
+        c = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0].cpu().numpy()          # and a plain forward afterwards is unaffected
+    e_im = float(np.abs(a - g["logits_input_mask/B4_L50_seed31"]).max())
+    e_pm = float(np.abs(b - g["logits_perm_mask/B4_L50_seed31"]).max())
+    e_pl = float(np.abs(c - g["logits/B4_L50_seed31"]).max())
+    moved = float(np.abs(g["logits_perm_mask/B4_L50_seed31"] - g["logits/B4_L50_seed31"]).max())
+    print("xlnet input_mask logits err %.2e, perm_mask logits err %.2e (the mask moves them by %.2e), plain %.2e" % (e_im, e_pm, moved, e_pl))
+    assert e_im <= 1e-3 and e_pm <= 1e-3 and e_pl <= 1e-3 and moved > 1e-2
+    with pytest.raises(AssertionError):
+        m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, input_mask=1.0 - mask.float())
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_perm_mask_gradients_vs_oracle(cdt):
+    """train mode (every dropout p = 0), a random perm_mask plus ragged padding, L = 72 (two strip groups): logits and every
+    parameter gradient against the oracle -- the backward works from the saved probabilities, which are exact zeros wherever the
+    forward masked a score -- then the single-call step still runs (the mask is an argument of explicit forwards only)."""
+    layers, B, L = 2, 3, 72
+    fp32 = cdt == torch.float32
+    m = build(layers, cdt, p_mag=0.0, p=0.0).train()
+    o = X.set_dropout(oracle(layers, p_mag=0.0), 0.0, 0.0).train()
+    b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=58)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    perm = torch.from_numpy((np.random.RandomState(3).rand(B, L, L) < 0.4).astype(np.float32))
+    logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, perm_mask=perm.to(DEV))[0]
+    torch.nn.MSELoss()(logits.view(-1), lab.view(-1)).backward()
+    i2, v2, a2, m2, s2, l2 = tb(b)
+    lo = o(i2, v2, a2, m2, s2, perm_mask=perm)[0]
+    torch.nn.functional.mse_loss(lo.view(-1), l2.view(-1)).backward()
+    torch.cuda.synchronize()
+    err = float((logits.detach().cpu() - lo.detach()).abs().max())
+    print("xlnet perm_mask (%s): logits %.2e" % (cdt, err))
+    assert err <= (1e-3 if fp32 else 5e-2)
+    _grad_report(m, o, 5e-3 if fp32 else 1e-1, frobenius=not fp32)
+    m.zero_grad()
+    m.train_step(ids, vis, aco, mask, seg, lab, optimizer=None)
+    torch.cuda.synchronize()
+
+
+_XL_DET_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["REPO_ROOT"]); sys.path.insert(0, os.path.join(os.environ["REPO_ROOT"], "tests"))
+from test_xlnet_gpu import build, tb, weights, DEV
+from bert_multimodal_transformer_amd import AdamW, get_linear_schedule_with_warmup
+from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
+torch.manual_seed(11)
+m = build(layers=3, cdt=torch.bfloat16).train()
+opt = AdamW(optimizer_grouped_parameters(m), lr=1e-3)
+sch = get_linear_schedule_with_warmup(opt, 0, 100)
+mode = os.environ["MODE"]
+with m.stream_scope():
+    for s in range(4):
+        ids, vis, aco, mask, seg, lab = tb(weights.synthetic_xlnet_batch(6, 50, 47, 74, seed=70 + s), DEV)
+        m.train_step(ids, vis, aco, mask, seg, lab, optimizer=opt, graph={"graph": True, "launches": "launches", "python": False}[mode])
+        sch.step()
+torch.cuda.synchronize()
+torch.save(m.flat_params.cpu(), os.environ["OUT"])
+print("OK")
+"""
+
+
+def test_deterministic_mode_bf16_runs_are_bit_identical(tmp_path):
+    """MB_DETERMINISTIC=1 for MAG-XLNet ("two runs bit-identical" in place of the absent sanitizers): every
+    multi-writer gradient sum of the engine -- r_w / r_r / r_s bias and seg_embed column sums of the attention backward, the
+    word-embedding scatter, LayerNorm / bias slabs, MAG's gate sums, the head -- goes through the 64-bit fixed-point shadow, so
+    two bf16 training runs (dropout on, 4 steps) end with the SAME bits, and so do the replayed graph, the launch-by-launch call
+    and the passes driven from Python."""
+    import subprocess, sys
+    script = tmp_path / "xd.py"
+    script.write_text(_XL_DET_WORKER)
+    outs = {}
+    for tag, mode in (("a", "graph"), ("b", "graph"), ("c", "launches"), ("d", "python")):
+        out = str(tmp_path / ("p_" + tag))
+        env = dict(os.environ, REPO_ROOT=ROOT, OUT=out, MODE=mode, MB_DETERMINISTIC="1")
+        p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode()[-3000:]
+        outs[tag] = torch.load(out)
+    assert torch.equal(outs["a"], outs["b"]), float((outs["a"] - outs["b"]).abs().max())
+    assert torch.equal(outs["a"], outs["c"]), float((outs["a"] - outs["c"]).abs().max())
+    assert torch.equal(outs["a"], outs["d"]), float((outs["a"] - outs["d"]).abs().max())

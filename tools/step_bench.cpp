@@ -5,7 +5,10 @@
 // plain C++ process, so a GPU-box visit costs seconds instead of a Python/torch start-up, and rocprofv3 can wrap it.
 //
 //   step_bench [--steps K] [--warmup W] [--batch B] [--seq L] [--dtype bf16|fp32] [--visual V] [--layers N]
-//              [--graph 0|1|2] [--h2d 0|1|2] [--nbatch n]
+//              [--graph 0|1|2] [--h2d 0|1|2] [--nbatch n] [--dp 0|1] [--wire fp32|bf16] [--sparse 0|1]
+//   --dp 1:  the data-parallel step, mb_bert_train_step_dp, with a ONE-rank RCCL communicator created here through the C ABI
+//            (mb_comm_unique_id / mb_comm_create_rccl): the N > 1 code path -- graph chain, comm stream, events, ncclAllReduce /
+//            ncclAllGather calls, the row-wise word-embedding exchange -- without a second GPU.  Needs --graph 1|2.
 //   --graph: 0 forward/backward/AdamW calls, 1 mb_bert_train_step hipGraph replay, 2 mb_bert_train_step stream launches
 //   --h2d:   0 batch resident in HBM, 1 hipMemcpyAsync per step, 2 batch read in place from pinned host memory by the prologue
 //
@@ -33,12 +36,15 @@ struct Batch { int64_t *ids, *seg, *mask; float *vis, *aco, *lab; };
 
 int main(int argc, char** argv) {
     int steps = 30, warmup = 5, B = 48, L = 50, V = 47, A = 74, layers = 12, graph = 0, h2d = 0, nbatch = 4, dtype = MB_DT_BF16;
+    int dp = 0, wire = MB_DT_F32, sparse = 1;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i]; const char* v = argv[i + 1];
         if (k == "--steps") steps = atoi(v); else if (k == "--warmup") warmup = atoi(v); else if (k == "--batch") B = atoi(v);
         else if (k == "--seq") L = atoi(v); else if (k == "--visual") V = atoi(v); else if (k == "--layers") layers = atoi(v);
         else if (k == "--graph") graph = atoi(v); else if (k == "--h2d") h2d = atoi(v); else if (k == "--nbatch") nbatch = atoi(v);
         else if (k == "--dtype") dtype = strcmp(v, "fp32") == 0 ? MB_DT_F32 : MB_DT_BF16;
+        else if (k == "--dp") dp = atoi(v); else if (k == "--sparse") sparse = atoi(v);
+        else if (k == "--wire") wire = strcmp(v, "bf16") == 0 ? MB_DT_BF16 : MB_DT_F32;
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 1; }
     }
     mb_bert_config c = {};
@@ -96,6 +102,20 @@ int main(int argc, char** argv) {
     float *logits, *loss;
     HCK(hipMalloc(&logits, (size_t)B * 4)); HCK(hipMalloc(&loss, 8)); HCK(hipMemset(loss, 0, 8));
 
+    mb_comm* comm = nullptr;
+    if (dp) {
+        if (!graph) { fprintf(stderr, "--dp 1 needs --graph 1|2\n"); return 1; }
+        char id[128];
+        MCK(mb_comm_unique_id(id));
+        int rc = mb_comm_create_rccl(id, 0, 1, &comm);
+        if (rc) { fprintf(stderr, "mb_comm_create_rccl: %d %s\n", rc, mb_comm_last_error()); return 3; }
+        const int vocab = sparse ? c.vocab_size : 0;
+        const size_t sb = mb_comm_scratch_bytes(1, wire, n, vocab, c.hidden_size, B * L);
+        void* scratch; HCK(hipMalloc(&scratch, sb));
+        MCK(mb_comm_bind_scratch(comm, scratch, sb, wire, n, vocab, c.hidden_size, B * L));
+        MCK(mb_comm_set_timing(comm, 1));
+        HCK(hipDeviceSynchronize());
+    }
     const float lr = 1e-5f, b1 = 0.9f, b2 = 0.999f, eps = 1e-6f, wd = 0.01f;
     int t_opt = 0;
     auto step = [&](int i) {
@@ -104,6 +124,11 @@ int main(int argc, char** argv) {
         if (h2d == 2) src = hb[i % nbatch];       // zero-copy: the step prologue gathers the batch out of pinned host memory (--graph 1|2)
         Batch b = view(src);
         ++t_opt;
+        if (graph && dp) {
+            MCK(mb_bert_train_step_dp(e, b.ids, b.vis, b.aco, b.mask, b.seg, b.lab, B, L, 1234, (uint64_t)t_opt, logits, loss, loss + 1,
+                                      M, Vv, lr, b1, b2, eps, wd, t_opt, 1, 1.0f, 1.0f, graph, st, comm));
+            return;
+        }
         if (graph) {
             MCK(mb_bert_train_step(e, b.ids, b.vis, b.aco, b.mask, b.seg, b.lab, B, L, 1234, (uint64_t)t_opt, logits, loss, loss + 1,
                                    M, Vv, lr, b1, b2, eps, wd, t_opt, 1, 1.0f, 1.0f, graph, st));
@@ -132,6 +157,13 @@ int main(int argc, char** argv) {
            "%.1f samples/s last-loss %.4f mean-loss %.4f\n",
            dtype == MB_DT_BF16 ? "bf16" : "fp32", B, L, V, layers, graph, h2d, ms / steps, wall_ms, host_ms, B * 1e3 / (ms / steps), hl[0],
            hl[1] / (steps + warmup));
+    if (comm) {
+        float ex = 0.f; size_t pieces = 0, cbytes = 0;
+        MCK(mb_comm_exposed_ms(comm, &ex)); MCK(mb_comm_stats(comm, &pieces, &cbytes));
+        printf("step_bench dp: 1-rank RCCL, wire=%s sparse=%d : %zu collectives / %.1f MB per step, comm_exposed %.4f ms (last step)\n",
+               wire == MB_DT_BF16 ? "bf16" : "fp32", sparse, pieces, cbytes * 1e-6, ex);
+        mb_comm_destroy(comm);
+    }
     mb_bert_destroy(e);
     return 0;
 }
