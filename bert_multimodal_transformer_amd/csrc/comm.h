@@ -32,19 +32,27 @@ struct mb_comm {
 
 namespace mb {
 
-// what a data-parallel step exchanges: the layers' GEMM weight gradients in `chunk.size()` early pieces (each final when its
-// segment of the backward is done) and everything else in the tail, of which the word-embedding table moves row-wise
+// What a data-parallel step exchanges, in the order the backward finishes it.  The backward runs as `chunk.size()` segments; the
+// gradient range chunk[s] is final when segment s has been enqueued.  All but the last go out "early" (the optimizer of those
+// ranges starts as soon as THEY have landed); the last segment also ends the backward, so its range travels together with the
+// tail -- everything that is not a layer's GEMM weight, of which the word-embedding table moves row-wise -- under the early
+// ranges' optimizer launch.
 struct DpSpec {
-    std::vector<std::pair<size_t, size_t>> chunk;   // [begin, end) floats of the flat gradient buffer, in the order the backward finishes them
+    std::vector<std::pair<size_t, size_t>> chunk;   // [begin, end) floats of the flat gradient buffer
     size_t tail_begin = 0, tail_end = 0;            // the rest: [tail_begin, tail_end)
     size_t word_off = 0;                            // the [vocab][H] word-embedding gradient inside the tail (rows = 0: dense)
     int word_rows = 0, H = 0;
     const int64_t* ids = nullptr; int T = 0;        // token ids of this rank's batch (device): the rows it touched
 };
 
-// segment numbering of a data-parallel step: [0, nchunk) backward chunks | nchunk: the last backward stage | nchunk + 1: the
-// optimizer over what was reduced early | nchunk + 2: the optimizer over the tail.  Called by train_step_impl's `between` hook
-// right after segment `seg` was enqueued on `st`.
+// layers per backward segment of a data-parallel step: MB_DP_CHUNKS="4,4,2,2" (must add up to n_layer) | MB_DP_CHUNK=n (uniform) |
+// default: pieces of 4 layers (113 MB: few seams between the step's graphs) while the backward has plenty left to hide them, pieces of 2
+// at the end, where what is still on the wire when the backward ends has to fit under the first optimizer launch
+std::vector<int> dp_chunk_plan(int n_layer);
+
+// segment numbering of a data-parallel step: [0, nb) the backward segments (nb = chunk.size(); the last one ends with the MAG /
+// embedding stage) | nb: the optimizer over chunk[0 .. nb-2] | nb + 1: the optimizer over chunk[nb-1] and the tail.  Called by
+// train_step_impl's `between` hook right after segment `seg` was enqueued on `st`.
 int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st);
 
 // row-wise sum of a [vocab][H] fp32 table over the ranks (comm.hip): every rank touched the rows ids[0..T)

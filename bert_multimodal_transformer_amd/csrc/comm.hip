@@ -195,32 +195,65 @@ static int wait_timed(mb_comm* c, int k, hipEvent_t ev, hipStream_t st) {
     return MB_OK;
 }
 
-int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st) {
-    const int nchunk = (int)sp.chunk.size();
-    if (seg == 0) { c->pieces = 0; c->bytes_reduced = 0; c->tev_used[0] = c->tev_used[1] = false; }
-    if (seg < nchunk) {
-        CK(fork_to_comm(c, st));
-        return comm_all_reduce(c, G + sp.chunk[seg].first, sp.chunk[seg].second - sp.chunk[seg].first, c->cs);
+std::vector<int> dp_chunk_plan(int n_layer) {
+    std::vector<int> plan;
+    if (const char* v = getenv("MB_DP_CHUNKS")) {
+        int sum = 0;
+        for (const char* p = v; *p;) {
+            const int c = atoi(p);
+            if (c < 1) { plan.clear(); break; }
+            plan.push_back(c); sum += c;
+            while (*p && *p != ',') ++p;
+            if (*p == ',') ++p;
+        }
+        if (sum == n_layer && !plan.empty()) return plan;
+        plan.clear();
     }
-    if (seg == nchunk) {
-        CK((int)hipEventRecord(c->ev_layers, c->cs));          // every layer piece is in front of this
+    if (const char* v = getenv("MB_DP_CHUNK")) {
+        const int c = atoi(v);
+        if (c > 0 && c <= n_layer && n_layer % c == 0) { plan.assign((size_t)(n_layer / c), c); return plan; }
+    }
+    int left = n_layer;
+    while (left > 4 && left - 4 >= 4) { plan.push_back(4); left -= 4; }
+    while (left > 2) { plan.push_back(2); left -= 2; }
+    if (left > 0) plan.push_back(left);
+    return plan;
+}
+
+int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st) {
+    // MB_DP_DEBUG (measurement only -- the gradients are NOT exchanged): 1 = the segmented step alone (no events, no collectives),
+    // 2 = events and waits but no collectives, 3 = everything except the row-wise exchange (the table is left as it is)
+    static int dbg = -1;
+    if (dbg < 0) { const char* v = getenv("MB_DP_DEBUG"); dbg = v ? atoi(v) : 0; }
+    if (dbg == 1) return MB_OK;
+    const int nb = (int)sp.chunk.size();
+    auto piece = [&](size_t b, size_t e) -> int { return (dbg == 2 || e <= b) ? MB_OK : comm_all_reduce(c, G + b, e - b, c->cs); };
+    if (seg == 0) { c->pieces = 0; c->bytes_reduced = 0; c->tev_used[0] = c->tev_used[1] = false; }
+    if (seg < nb - 1) {
         CK(fork_to_comm(c, st));
+        return piece(sp.chunk[seg].first, sp.chunk[seg].second);
+    }
+    if (seg == nb - 1) {
+        CK((int)hipEventRecord(c->ev_layers, c->cs));          // every early piece is in front of this
+        CK(fork_to_comm(c, st));
+        CK(piece(sp.chunk[seg].first, sp.chunk[seg].second));
         const size_t w0 = sp.word_off, w1 = sp.word_off + (size_t)sp.word_rows * sp.H;
         // (a batch beyond the agreed row capacity is an error, never a silent switch to the dense piece: the ranks must issue the
         //  same collectives in the same order)
         if (sp.word_rows > 0 && c->rows_ready && sp.T > c->cap) return MB_ERR_SHAPE;
         if (sp.word_rows > 0 && c->rows_ready && sp.word_rows == c->vocab && sp.H == c->H && w0 >= sp.tail_begin && w1 <= sp.tail_end) {
-            CK(comm_all_reduce(c, G + sp.tail_begin, w0 - sp.tail_begin, c->cs));
-            CK(comm_exchange_rows(c, G + w0, sp.ids, sp.T, c->cs));
-            CK(comm_all_reduce(c, G + w1, sp.tail_end - w1, c->cs));
+            CK(piece(sp.tail_begin, w0));
+            if (dbg < 2) CK(comm_exchange_rows(c, G + w0, sp.ids, sp.T, c->cs));
+            CK(piece(w1, sp.tail_end));
         } else {
-            CK(comm_all_reduce(c, G + sp.tail_begin, sp.tail_end - sp.tail_begin, c->cs));
+            CK(piece(sp.tail_begin, sp.tail_end));
         }
         CK((int)hipEventRecord(c->ev_tail, c->cs));
-        // the optimizer of the layers' weights (next segment) needs the layer pieces only: it runs under the tail's exchange
-        return wait_timed(c, 0, c->ev_layers, st);
+        // the optimizer of the early ranges (next segment) needs those pieces only: it runs under the late pieces' exchange
+        // (a one-segment backward has no early range: its next segment updates part of the late ones, so it waits for everything)
+        return wait_timed(c, 0, nb > 1 ? c->ev_layers : c->ev_tail, st);
     }
-    if (seg == nchunk + 1) return wait_timed(c, 1, c->ev_tail, st);
+    if (seg == nb) return wait_timed(c, 1, c->ev_tail, st);
     return MB_OK;
 }
 

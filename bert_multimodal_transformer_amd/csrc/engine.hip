@@ -803,15 +803,16 @@ int mb_bert_train_step(mb_bert_engine* e, const int64_t* input_ids, const float*
 }
 
 // ------------------------------------------------------------------------------------------------ data-parallel step, one call
-// mb_bert_train_step with the gradient exchange inside (include/magbert_hip.h, csrc/comm.hip).  Segments (each a LINEAR graph):
-//   [0, nchunk)  : (segment 0: forward + head) + the backward of C layers  -> between: all-reduce of those layers' GEMM weights
-//   nchunk       : MAG + embeddings + the ONE LayerNorm / bias reduction   -> between: the tail's exchange; wait for the layer pieces
-//   nchunk + 1   : AdamW over the layers' GEMM weights [0, pooler)         -> between: wait for the tail
-//   nchunk + 2   : AdamW over the rest of the decay slab + the no-decay slab
-static int enqueue_step_dp(mb_bert_engine* e, int seg, int nchunk, int C, int B, int L, float* logits, float* loss, float* loss_run, float* m,
-                           float* v, float loss_scale, hipStream_t st) {
+// mb_bert_train_step with the gradient exchange inside (include/magbert_hip.h, csrc/comm.hip).  `plan` = layers per backward segment
+// (dp_chunk_plan: 4, 4, 2, 2).  Segments, each a LINEAR graph:
+//   s < nb      : (s = 0: forward + head) + the backward of plan[s] layers (+ s = nb-1: MAG + embeddings + the ONE LayerNorm / bias
+//                 reduction)                 -> between: all-reduce of those layers' GEMM weights (the last one: + the tail's exchange)
+//   nb          : AdamW over the GEMM weights of every layer but the last segment's   (waits for the early pieces only)
+//   nb + 1      : AdamW over the last segment's layers, the rest of the decay slab and the no-decay slab   (waits for everything)
+static int enqueue_step_dp(mb_bert_engine* e, int seg, const std::vector<int>& plan, int B, int L, float* logits, float* loss, float* loss_run,
+                           float* m, float* v, float loss_scale, hipStream_t st) {
     char* ws = e->ws;
-    const int NL = e->c.num_layers;
+    const int NL = e->c.num_layers, nb = (int)plan.size();
     const float* lab = (const float*)(ws + e->ws_in_lab);
     float* keep_attn = e->attn_out;
     e->attn_out = nullptr;
@@ -821,16 +822,24 @@ static int enqueue_step_dp(mb_bert_engine* e, int seg, int nchunk, int C, int B,
         CK(mb_bert_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
                            (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
                            loss_run, st));
-    if (seg < nchunk) return mb_bert_backward(e, nullptr, lab, loss_scale, seg == 0 ? 0 : 1 + seg * C, 1 + (seg + 1) * C, st);
-    if (seg == nchunk) return mb_bert_backward(e, nullptr, lab, loss_scale, NL + 1, NL + 2, st);
+    if (seg < nb) {
+        int done = 0;
+        for (int s = 0; s < seg; ++s) done += plan[s];
+        // backward stages: 0 = head, 1 .. NL = layers NL-1 .. 0, NL+1 = MAG + embeddings
+        return mb_bert_backward(e, nullptr, lab, loss_scale, seg == 0 ? 0 : 1 + done, seg == nb - 1 ? NL + 2 : 1 + done + plan[seg], st);
+    }
     const AdamArgs none = {};
     const size_t nd = e->n_decay, n = e->n_params;
-    if (seg == nchunk + 1) {
+    const size_t split = e->lo[plan[nb - 1] < NL ? plan[nb - 1] : 0].wqkv;      // first GEMM weight of the layers reduced early
+    if (seg == nb) {
         CK(e->prof_mark(2 * NL, st));
-        return adamw_decay_range(e, m, v, 0, e->wp, st);
+        if (nb > 1) return adamw_decay_range(e, m, v, split, e->wp, st);
+        // (one backward segment: no early range -- dp_between waited for everything -- so this segment takes the no-decay slab)
+        return adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1);
     }
+    CK(adamw_decay_range(e, m, v, 0, nb > 1 ? split : e->wp, st));
     CK(adamw_decay_range(e, m, v, e->wp, nd, st));
-    CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
+    if (nb > 1) CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
     return e->prof_mark(2 * NL + 1, st);
 }
 
@@ -847,27 +856,29 @@ int mb_bert_train_step_dp(mb_bert_engine* e, const int64_t* input_ids, const flo
     if (!m || !v || (mode != 1 && mode != 2)) return MB_ERR_ARG;
     if (e->overlap_wgrad || !e->grouped) return MB_ERR_MODE;      // the exchange's pieces assume a layer's weight gradients are final when its stage returns
     const int NL = c.num_layers;
-    int C = 2;
-    { const char* cv = getenv("MB_DP_CHUNK"); if (cv && atoi(cv) > 0) C = atoi(cv); }
-    if (C > NL || NL % C != 0) C = 1;
-    const int nchunk = NL / C, nseg = nchunk + 3;
+    const std::vector<int> plan = dp_chunk_plan(NL);
+    const int nb = (int)plan.size();
     DpSpec sp;
-    for (int s = 0; s < nchunk; ++s) {            // segment s finishes layers [NL - (s + 1) C, NL - s C)
-        const int l_lo = NL - (s + 1) * C, l_hi = NL - s * C;
-        sp.chunk.push_back({e->lo[l_lo].wqkv, l_hi < NL ? e->lo[l_hi].wqkv : e->wp});
+    for (int s = 0, hi = NL; s < nb; ++s) {            // segment s finishes layers [hi - plan[s], hi)
+        const int lo_l = hi - plan[s];
+        sp.chunk.push_back({e->lo[lo_l].wqkv, hi < NL ? e->lo[hi].wqkv : e->wp});
+        hi = lo_l;
     }
     sp.tail_begin = e->wp; sp.tail_end = e->n_params;
     sp.word_off = e->word; sp.word_rows = c.vocab_size; sp.H = c.hidden_size;
     sp.ids = (const int64_t*)(e->ws + e->ws_in_ids); sp.T = B * L;
     e->training = 1;
     CK(prepare_pass(e, B * L, st));
+    // (the plan is part of the graphs' identity: nseg alone would not tell 4,4,2,2 from 2,2,4,4)
+    int variant = 1;
+    for (int x : plan) variant = variant * 13 + x;
     return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
                            labels, B, L, seed, step, logits, loss, loss_run, m, v, lr, beta1, beta2, eps, weight_decay, opt_step,
                            correct_bias, grad_scale, loss_scale, mode, e->prof, st,
                            [&](int sg, float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
-                               return enqueue_step_dp(e, sg, nchunk, C, B, L, lg, ls, lr_, m_, v_, sc, s);
+                               return enqueue_step_dp(e, sg, plan, B, L, lg, ls, lr_, m_, v_, sc, s);
                            },
-                           nseg, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, 1);
+                           nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant);
 }
 
 // ------------------------------------------------------------------------------------------------ stage-driven step (data parallel)

@@ -174,6 +174,17 @@ struct StepMixin {
     size_t ws_state = 0, ws_in_ids = 0, ws_in_seg = 0, ws_in_mask = 0, ws_in_vis = 0, ws_in_aco = 0, ws_in_lab = 0;
     std::vector<StepGraph> graphs;
     size_t graph_launches = 0, graph_captures = 0;
+    // Captures run on a stream of the engine's own, never on the caller's: hipEventQuery on an event whose last record was on a
+    // stream that is capturing NOW fails and invalidates that capture (ROCm 7.2: hipErrorCapturedEvent), and a host framework may
+    // poll such events from another thread at any time -- PyTorch's NCCL watchdog does, for collectives it ran on the caller's
+    // stream (found by the one-rank RCCL test: a race between its 100 ms poll and the first capture).  A graph is launch-stream
+    // agnostic, so the captured sequence is replayed on the caller's stream as before.
+    hipStream_t cap = nullptr;
+    int capture_stream(hipStream_t* out) {
+        if (!cap) CK((int)hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+        *out = cap;
+        return MB_OK;
+    }
     // Known-zero gradients.  The fused AdamW leaves the flat gradient buffer zeroed (optimizer.zero_grad()); when nothing has
     // written to it since, the layer weight gradients of the next backward are STORED instead of accumulated: the read half of
     // a 340 MB read-modify-write per step (28 MB per layer, straight from HBM: AdamW streamed the zeros out non-temporally).
@@ -251,6 +262,7 @@ struct StepMixin {
         ws_in_lab = w.take((size_t)max_batch * num_labels * 4);
     }
     void drop_graphs() {
+        if (cap) { hipStreamDestroy(cap); cap = nullptr; }
         for (auto& g : graphs) g.destroy();
         graphs.clear();
         for (auto& g : stage_graphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
@@ -273,11 +285,13 @@ struct StepMixin {
                 stage_graphs.erase(stage_graphs.begin());
             }
             StageGraph ng = {B, L, stage, overwrite, logits, loss, loss_run, loss_scale, st, nullptr, nullptr};
-            CK((int)hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+            hipStream_t cs = nullptr;
+            CK(capture_stream(&cs));
+            CK((int)hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
             capturing = true;
-            const int r = enqueue(st);
+            const int r = enqueue(cs);
             capturing = false;
-            const int r2 = (int)hipStreamEndCapture(st, &ng.graph);
+            const int r2 = (int)hipStreamEndCapture(cs, &ng.graph);
             if (r) { if (ng.graph) hipGraphDestroy(ng.graph); return r; }
             CK(r2);
             CK((int)hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0));
@@ -390,14 +404,16 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
             e->graphs.erase(e->graphs.begin());
         }
         StepGraph ng = {B, L, m != nullptr, ow, logits, loss, loss_run, m, v, loss_scale, st, nseg, variant, {}, {}};
+        hipStream_t cs = nullptr;
+        CK(e->capture_stream(&cs));
         for (int sg = 0; sg < nseg; ++sg) {
             hipGraph_t gr = nullptr;
             hipGraphExec_t ex = nullptr;
-            CK((int)hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+            CK((int)hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
             e->dyn = true; e->capturing = true;
-            const int r = enqueue(sg, logits, loss, loss_run, m, v, loss_scale, st);
+            const int r = enqueue(sg, logits, loss, loss_run, m, v, loss_scale, cs);
             e->dyn = false; e->capturing = false;
-            const int r2 = (int)hipStreamEndCapture(st, &gr);
+            const int r2 = (int)hipStreamEndCapture(cs, &gr);
             if (r || r2) { if (gr) hipGraphDestroy(gr); ng.destroy(); return r ? r : r2; }
             const int r3 = (int)hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
             if (r3) { hipGraphDestroy(gr); ng.destroy(); return r3; }

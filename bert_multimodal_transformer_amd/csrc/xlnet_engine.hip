@@ -555,9 +555,9 @@ int mb_xlnet_train_step(mb_xlnet_engine* e, const int64_t* input_ids, const floa
                            });
 }
 
-// ---- data-parallel step in one call (as mb_bert_train_step_dp: include/magbert_hip.h, csrc/comm.hip).  Segments: [0, nchunk) =
-// (segment 0: forward + head) + the backward of C layers | nchunk = the embedding stage | nchunk + 1 = AdamW over the layers' GEMM
-// weights [0, summary weight) | nchunk + 2 = AdamW over the rest
+// ---- data-parallel step in one call (as mb_bert_train_step_dp: include/magbert_hip.h, csrc/comm.hip).  Segments: [0, nb) = (segment
+// 0: forward + head) + the backward of plan[s] layers (+ the last: the embedding stage) | nb = AdamW over the GEMM weights of the layers
+// reduced early | nb + 1 = AdamW over the last segment's layers and everything else
 static int xl_adamw_decay_range(mb_xlnet_engine* e, float* m, float* v, size_t b, size_t en, hipStream_t st) {
     if (en <= b) return MB_OK;
     const AdamArgs none = {};
@@ -567,25 +567,32 @@ static int xl_adamw_decay_range(mb_xlnet_engine* e, float* m, float* v, size_t b
     return adamw_step(e->P + b, e->G + b, m + b, v + b, sh, en - b, en - b, clampr(e->sh_begin), clampr(e->sh_end), none, 1, st,
                       e->adam_state(e->ws), keep ? clampr(e->stale_begin) : 0, keep ? clampr(e->stale_end) : 0);
 }
-static int xl_enqueue_step_dp(mb_xlnet_engine* e, int seg, int nchunk, int C, int B, int L, float* logits, float* loss, float* loss_run,
-                              float* m, float* v, float loss_scale, hipStream_t st) {
+static int xl_enqueue_step_dp(mb_xlnet_engine* e, int seg, const std::vector<int>& plan, int B, int L, float* logits, float* loss,
+                              float* loss_run, float* m, float* v, float loss_scale, hipStream_t st) {
     char* ws = e->ws;
-    const int NL = e->c.n_layer;
+    const int NL = e->c.n_layer, nb = (int)plan.size();
     const float* lab = (const float*)(ws + e->ws_in_lab);
     if (seg == 0)
         CK(mb_xlnet_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
                             (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
                             loss_run, st));
-    if (seg < nchunk) return mb_xlnet_backward(e, nullptr, lab, loss_scale, seg == 0 ? 0 : 1 + seg * C, 1 + (seg + 1) * C, st);
-    if (seg == nchunk) return mb_xlnet_backward(e, nullptr, lab, loss_scale, NL + 1, NL + 2, st);
+    if (seg < nb) {
+        int done = 0;
+        for (int s = 0; s < seg; ++s) done += plan[s];
+        return mb_xlnet_backward(e, nullptr, lab, loss_scale, seg == 0 ? 0 : 1 + done, seg == nb - 1 ? NL + 2 : 1 + done + plan[seg], st);
+    }
     const AdamArgs none = {};
     const size_t nd = e->n_decay, n = e->n_trainable;
-    if (seg == nchunk + 1) {
+    const size_t split = e->lo[plan[nb - 1] < NL ? plan[nb - 1] : 0].q;
+    if (seg == nb) {
         CK(e->prof_mark(2 * NL, st));
-        return xl_adamw_decay_range(e, m, v, 0, e->wsum, st);
+        if (nb > 1) return xl_adamw_decay_range(e, m, v, split, e->wsum, st);
+        // (one backward segment: no early range -- dp_between waited for everything -- so this segment takes the no-decay slab)
+        return adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1);
     }
+    CK(xl_adamw_decay_range(e, m, v, 0, nb > 1 ? split : e->wsum, st));
     CK(xl_adamw_decay_range(e, m, v, e->wsum, nd, st));
-    CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
+    if (nb > 1) CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
     return e->prof_mark(2 * NL + 1, st);
 }
 
@@ -602,27 +609,28 @@ int mb_xlnet_train_step_dp(mb_xlnet_engine* e, const int64_t* input_ids, const f
     if (!m || !v || (mode != 1 && mode != 2)) return MB_ERR_ARG;
     if (e->deferred || e->head_mask || e->emb_in || e->perm) return MB_ERR_MODE;
     const int NL = c.n_layer;
-    int C = 2;
-    { const char* cv = getenv("MB_DP_CHUNK"); if (cv && atoi(cv) > 0) C = atoi(cv); }
-    if (C > NL || NL % C != 0) C = 1;
-    const int nchunk = NL / C, nseg = nchunk + 3;
+    const std::vector<int> plan = dp_chunk_plan(NL);
+    const int nb = (int)plan.size();
     DpSpec sp;
-    for (int s = 0; s < nchunk; ++s) {
-        const int l_lo = NL - (s + 1) * C, l_hi = NL - s * C;
-        sp.chunk.push_back({e->lo[l_lo].q, l_hi < NL ? e->lo[l_hi].q : e->wsum});
+    for (int s = 0, hi = NL; s < nb; ++s) {
+        const int lo_l = hi - plan[s];
+        sp.chunk.push_back({e->lo[lo_l].q, hi < NL ? e->lo[hi].q : e->wsum});
+        hi = lo_l;
     }
     sp.tail_begin = e->wsum; sp.tail_end = e->n_trainable;
     sp.word_off = e->word; sp.word_rows = c.vocab_size; sp.H = c.d_model;
     sp.ids = (const int64_t*)(e->ws + e->ws_in_ids); sp.T = B * L;
     e->training = 1;
     CK(xl_prepare_pass(e, B * L, st));
+    int variant = 1;
+    for (int x : plan) variant = variant * 13 + x;
     return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
                            labels, B, L, seed, step, logits, loss, loss_run, m, v, lr, beta1, beta2, eps, weight_decay, opt_step,
                            correct_bias, grad_scale, loss_scale, mode, e->prof, st,
                            [&](int sg, float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
-                               return xl_enqueue_step_dp(e, sg, nchunk, C, B, L, lg, ls, lr_, m_, v_, sc, s);
+                               return xl_enqueue_step_dp(e, sg, plan, B, L, lg, ls, lr_, m_, v_, sc, s);
                            },
-                           nseg, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, 1);
+                           nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant);
 }
 
 int mb_xlnet_set_perm_mask(mb_xlnet_engine* e, const uint8_t* perm) {

@@ -202,6 +202,7 @@ class Comm(object):
         _lib.check(L.mb_comm_bind_scratch(h, _lib.ptr(self.scratch), nbytes, wire, n, vocab, H, self.capacity))
         self.stream = torch.cuda.ExternalStream(L.mb_comm_stream(h), device=dev)
         self.stream.synchronize()          # (the slot table's one-time memset)
+        torch.cuda.synchronize(dev)        # the set-up collectives above are complete before the step that follows starts capturing
 
     # -- callback backend -------------------------------------------------------------------------------------------------------
     def _view(self, ptr, nbytes):

@@ -376,13 +376,14 @@ int mb_comm_exposed_ms(mb_comm* c, float* ms);
 int mb_comm_stats(const mb_comm* c, size_t* pieces, size_t* bytes);      /* collectives issued / bytes handed to them in the last step */
 const char* mb_comm_last_error(void);
 /* One optimizer step of a data-parallel rank as ONE engine call: mb_bert_train_step with the exchange inside.  The step runs as a
- * chain of LINEAR replayed graphs (a graph with a cross-stream fork replays on ROCm 7.2's slow path) -- forward + head + the first
- * chunk of layers | further chunks of MB_DP_CHUNK (default 2) layers | MAG + embeddings | AdamW of the layers' GEMM weights | AdamW
- * of the rest -- and between two of them the host records an event and issues that chunk's all-reduce on the comm stream; the tail
- * (everything that is not a layer's GEMM weight; the word-embedding table row-wise) goes out after the last backward stage and is
- * hidden under the first AdamW launch.  Everything the single-call step has stays: the deferred LayerNorm reduction, stored (not
- * accumulated) weight gradients, lazy zeroing.  grad_scale = 1 / world for the mean over the global batch (the pieces are SUMs).
- * m, v must be given (a gradient-accumulation micro-step has nothing to exchange: use mb_bert_train_step). */
+ * chain of LINEAR replayed graphs (a graph with a cross-stream fork replays on ROCm 7.2's slow path): forward + head + the
+ * backward of the top 4 layers | 4 more | 2 more | the last 2 layers + MAG + embeddings | AdamW of the GEMM weights of the ten
+ * layers reduced early | AdamW of the rest (MB_DP_CHUNKS="4,4,2,2" / MB_DP_CHUNK=n change the cut).  Between two of them the host
+ * records an event and issues that segment's all-reduce on the comm stream; what the last backward segment produces -- its two
+ * layers and the tail (everything that is not a layer's GEMM weight; the word-embedding table row-wise) -- travels under the first
+ * AdamW launch.  Everything the single-call step has stays: the deferred LayerNorm reduction, stored (not accumulated) weight
+ * gradients, lazy zeroing.  grad_scale = 1 / world for the mean over the global batch (the pieces are SUMs).  m, v must be given
+ * (a gradient-accumulation micro-step has nothing to exchange: use mb_bert_train_step). */
 int mb_bert_train_step_dp(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
                           const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
                           uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, float* m, float* v, float lr,
