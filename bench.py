@@ -525,6 +525,19 @@ def main():
         n3 = 7
     except Exception as ex:          # MB_GROUP_WGRAD=0 (separate launches): no grouped kernel to time
         print("note: in-step kernel timing unavailable (%s)" % ex, file=sys.stderr)
+    # host cost of ONE step call with an empty queue (host_enqueue_ms_per_step above is wall time of the enqueue loop: once the host
+    # is a few steps ahead it blocks on the launch queue's depth and the figure approaches the GPU time -- it says nothing about the host)
+    host_call = []
+    for i in range(6):
+        ids, vis, aco, mask, seg, lab = resident[i % nb]
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        model.train_step(ids, vis, aco, mask, seg, lab, optimizer=opt, graph=use_graph)
+        sch.step()
+        host_call.append(time.perf_counter() - th)
+    torch.cuda.synchronize()
+    host_call_ms = float(np.median(host_call[1:])) * 1e3
+    n3 += 6
     comm_stats = None
     if dp is not None:
         if dp_call:          # five more steps with the comm object's timing events on: the compute stream's stalls on the exchange
@@ -565,6 +578,7 @@ def main():
                           "h2d": "batch packed into one pinned host block, gathered across PCIe by the step's first launch",
                           **({"grad_wire_dtype": "bf16" if dp.reducer.wire_dtype == torch.bfloat16 else "fp32"} if dp is not None else {})},
                "mean_loss": round(loss, 4), "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
+               "host_call_ms_per_step": round(host_call_ms, 3),
                "step_ms_median": q(0.5), "step_ms_p10": q(0.1), "step_ms_p90": q(0.9),
                "value_inputs_resident": round(world * B / dt_res, 2)}
         if comm_exposed_ms is not None:

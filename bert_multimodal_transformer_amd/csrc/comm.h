@@ -17,7 +17,6 @@ struct mb_comm {
     void* ctx = nullptr;
     hipStream_t cs = nullptr;                 // the comm stream (created here: non-blocking, highest priority)
     std::vector<hipEvent_t> fork_ev;          // "the compute stream got this far": one per piece of a step, re-recorded every step
-    int next_fork = 0;
     hipEvent_t ev_layers = nullptr, ev_tail = nullptr;     // recorded on cs: every layer piece / every piece has been enqueued before
     hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};   // timing events around the two places the compute stream waits for cs
     bool timing = false, tev_used[2] = {false, false};
@@ -28,6 +27,14 @@ struct mb_comm {
     size_t off_stage = 0, off_slot = 0, off_ids = 0, off_rows = 0;
     bool rows_ready = false;
     size_t pieces = 0, bytes_reduced = 0;     // statistics of the last step (tests / bench)
+    // How the compute stream hands a finished segment to the comm stream (MB_DP_EVENT_MODE; same-box A/B, one-rank RCCL group,
+    // profiles/r04_dp_event_modes.txt: single call 3.66 ms | mode 0: 3.81-3.83 | 1: 3.81-3.84 | 2: 3.64-3.70 | 3: 3.64-3.70):
+    //   0 = hipEventRecord on the compute stream between two graph launches: each such marker costs the stream ~25 us;
+    //   1 = the same with device-scope release events (no difference);
+    //   2 = (default) the event is recorded by the LAST NODE of the segment's graph (dp_segment_end runs inside the capture): the
+    //       graphs stay linear, nothing sits between two launches but the next launch;
+    //   3 = ... and the optimizer segments start with wait nodes instead of stream waits (dp_segment_begin): no further gain.
+    int event_mode = 2;
 };
 
 namespace mb {
@@ -54,6 +61,9 @@ std::vector<int> dp_chunk_plan(int n_layer);
 // embedding stage) | nb: the optimizer over chunk[0 .. nb-2] | nb + 1: the optimizer over chunk[nb-1] and the tail.  Called by
 // train_step_impl's `between` hook right after segment `seg` was enqueued on `st`.
 int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st);
+// called by the engines at the head / at the end of every segment's kernel sequence (inside the capture when the step is captured)
+int dp_segment_begin(mb_comm* c, int nb, int seg, hipStream_t st);
+int dp_segment_end(mb_comm* c, int nb, int seg, hipStream_t st);
 
 // row-wise sum of a [vocab][H] fp32 table over the ranks (comm.hip): every rank touched the rows ids[0..T)
 int comm_exchange_rows(mb_comm* c, float* table, const int64_t* ids, int T, hipStream_t s);

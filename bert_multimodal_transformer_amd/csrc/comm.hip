@@ -180,15 +180,23 @@ int comm_exchange_rows(mb_comm* c, float* table, const int64_t* ids, int T, hipS
     return (int)hipGetLastError();
 }
 
-// the comm stream picks up after everything enqueued on `st` so far
-static int fork_to_comm(mb_comm* c, hipStream_t st) {
-    hipEvent_t ev = c->fork_ev[c->next_fork];
-    c->next_fork = (c->next_fork + 1) % (int)c->fork_ev.size();
-    CK((int)hipEventRecord(ev, st));
+// the comm stream picks up after everything enqueued on `st` so far (segment `seg` of the step)
+static int fork_to_comm(mb_comm* c, int seg, hipStream_t st) {
+    hipEvent_t ev = c->fork_ev[(size_t)seg % c->fork_ev.size()];
+    if (c->event_mode < 2) CK((int)hipEventRecord(ev, st));      // (modes 2, 3: recorded by the segment itself, dp_segment_end)
     return (int)hipStreamWaitEvent(c->cs, ev, 0);
+}
+int dp_segment_end(mb_comm* c, int nb, int seg, hipStream_t st) {
+    if (c->event_mode < 2 || seg >= nb) return MB_OK;
+    return (int)hipEventRecord(c->fork_ev[(size_t)seg % c->fork_ev.size()], st);
+}
+int dp_segment_begin(mb_comm* c, int nb, int seg, hipStream_t st) {
+    if (c->event_mode < 3 || seg < nb) return MB_OK;
+    return (int)hipStreamWaitEvent(st, seg == nb ? (nb > 1 ? c->ev_layers : c->ev_tail) : c->ev_tail, 0);
 }
 // the compute stream waits for `ev` (recorded on the comm stream); with timing on, the stall is bracketed by two timing events
 static int wait_timed(mb_comm* c, int k, hipEvent_t ev, hipStream_t st) {
+    if (c->event_mode >= 3) return MB_OK;          // (the waiting segment's graph starts with the wait: dp_segment_begin)
     if (c->timing) CK((int)hipEventRecord(c->tev[2 * k], st));
     CK((int)hipStreamWaitEvent(st, ev, 0));
     if (c->timing) { CK((int)hipEventRecord(c->tev[2 * k + 1], st)); c->tev_used[k] = true; }
@@ -230,12 +238,12 @@ int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st) 
     auto piece = [&](size_t b, size_t e) -> int { return (dbg == 2 || e <= b) ? MB_OK : comm_all_reduce(c, G + b, e - b, c->cs); };
     if (seg == 0) { c->pieces = 0; c->bytes_reduced = 0; c->tev_used[0] = c->tev_used[1] = false; }
     if (seg < nb - 1) {
-        CK(fork_to_comm(c, st));
+        CK(fork_to_comm(c, seg, st));
         return piece(sp.chunk[seg].first, sp.chunk[seg].second);
     }
     if (seg == nb - 1) {
         CK((int)hipEventRecord(c->ev_layers, c->cs));          // every early piece is in front of this
-        CK(fork_to_comm(c, st));
+        CK(fork_to_comm(c, seg, st));
         CK(piece(sp.chunk[seg].first, sp.chunk[seg].second));
         const size_t w0 = sp.word_off, w1 = sp.word_off + (size_t)sp.word_rows * sp.H;
         // (a batch beyond the agreed row capacity is an error, never a silent switch to the dense piece: the ranks must issue the
@@ -277,10 +285,12 @@ static int comm_common_init(mb_comm* c) {
     const char* pv = getenv("MB_DP_COMM_PRIORITY");
     const int prio = (pv && atoi(pv) == 0) ? 0 : greatest;      // the exchange's few workgroups go in front of the backward's many
     CK((int)hipStreamCreateWithPriority(&c->cs, hipStreamNonBlocking, prio));
+    if (const char* v = getenv("MB_DP_EVENT_MODE")) c->event_mode = atoi(v);
+    const unsigned flags = hipEventDisableTiming | (c->event_mode == 1 ? hipEventReleaseToDevice : 0);
     c->fork_ev.assign(32, nullptr);
-    for (auto& ev : c->fork_ev) CK((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    CK((int)hipEventCreateWithFlags(&c->ev_layers, hipEventDisableTiming));
-    CK((int)hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    for (auto& ev : c->fork_ev) CK((int)hipEventCreateWithFlags(&ev, flags));
+    CK((int)hipEventCreateWithFlags(&c->ev_layers, flags));
+    CK((int)hipEventCreateWithFlags(&c->ev_tail, flags));
     for (auto& ev : c->tev) CK((int)hipEventCreate(&ev));
     return MB_OK;
 }

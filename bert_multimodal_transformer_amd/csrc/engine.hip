@@ -872,11 +872,14 @@ int mb_bert_train_step_dp(mb_bert_engine* e, const int64_t* input_ids, const flo
     // (the plan is part of the graphs' identity: nseg alone would not tell 4,4,2,2 from 2,2,4,4)
     int variant = 1;
     for (int x : plan) variant = variant * 13 + x;
+    variant = variant * 4 + comm->event_mode;
     return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
                            labels, B, L, seed, step, logits, loss, loss_run, m, v, lr, beta1, beta2, eps, weight_decay, opt_step,
                            correct_bias, grad_scale, loss_scale, mode, e->prof, st,
                            [&](int sg, float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
-                               return enqueue_step_dp(e, sg, plan, B, L, lg, ls, lr_, m_, v_, sc, s);
+                               CK(dp_segment_begin(comm, nb, sg, s));
+                               CK(enqueue_step_dp(e, sg, plan, B, L, lg, ls, lr_, m_, v_, sc, s));
+                               return dp_segment_end(comm, nb, sg, s);
                            },
                            nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant);
 }
