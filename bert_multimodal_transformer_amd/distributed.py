@@ -306,13 +306,14 @@ class DataParallel(object):
         self.pg = process_group
         self.core = model._core
         # Wire format of the gradient exchange.  auto: bf16 only where the links are the bound -- bf16 perf mode, RCCL, and a
-        # 2-GPU group (xGMI is point-to-point: two GPUs share ONE ~150 GB/s link, so the 443 MB fp32 exchange lasts as long as
-        # the whole backward; with 4 / 8 GPUs a ring spreads over 3 / 7 links and the fp32 exchange hides under the backward,
-        # while the two conversion passes would cost ~4 % of the step -- measured with a 1-rank RCCL group).
+        # TWO-GPU group (xGMI is point-to-point: two GPUs share ONE link, so the 443 MB fp32 exchange lasts longer than the whole
+        # backward; with 4 / 8 GPUs a ring spreads over 3 / 7 links and the fp32 exchange hides under the backward and the first
+        # optimizer launch, while the two staging passes (fp32 -> bf16 -> fp32 over 91 M elements, 1.1 GB of HBM traffic on the comm
+        # stream) cost 0.25 - 0.85 ms per step -- measured with a one-rank RCCL group, profiles/r04_dp_force.txt).
         wire = os.environ.get("MB_DP_GRAD_DTYPE", "auto")
         if wire == "auto":
             on_rccl = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
-            few_links = dist.is_initialized() and dist.get_world_size(process_group) <= 2
+            few_links = dist.is_initialized() and dist.get_world_size(process_group) == 2
             wire = "bf16" if (self.core.compute_dtype == torch.bfloat16 and self.core.grads.is_cuda and on_rccl and few_links) else "fp32"
         self.reducer = GradReducer(self.core.grads, process_group, torch.bfloat16 if wire == "bf16" else torch.float32)
         self.world = self.reducer.world

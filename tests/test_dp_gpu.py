@@ -196,7 +196,8 @@ def test_rccl_call_path_single_rank(tmp_path, cdt):
     out = str(tmp_path / "rccl")
     for use_dp in ("0", "1"):
         env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 1000),
-                   REPO_ROOT=ROOT, OUT=out, USE_DP=use_dp, MB_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CDT=cdt)
+                   REPO_ROOT=ROOT, OUT=out, USE_DP=use_dp, MB_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CDT=cdt,
+                   MB_DP_GRAD_DTYPE=cdt)       # (the bf16 wire is the automatic choice of two-GPU groups only: asked for here)
         p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         assert p.returncode == 0, p.stdout.decode()[-3000:]
     a, b = torch.load(out + ".0"), torch.load(out + ".1")
@@ -313,14 +314,15 @@ def test_single_call_dp_step_over_rccl_one_rank(tmp_path, cdt, graph):
     row-wise exchange (pack -> gather -> combine) and the split optimizer included.  bf16: the wire format rounds the gradients."""
     import torch
     out = str(tmp_path / "rc")
-    common = dict(OUT=out, KIND="bert", MB_DP_FORCE="1", BACKEND="nccl", STEPS="3", CDT=cdt, GRAPH=graph, MB_DETERMINISTIC="1")
+    common = dict(OUT=out, KIND="bert", MB_DP_FORCE="1", BACKEND="nccl", STEPS="3", CDT=cdt, GRAPH=graph, MB_DETERMINISTIC="1",
+                  MB_DP_GRAD_DTYPE=cdt)        # (bf16 wire: the automatic choice of two-GPU groups only, asked for here)
     _run_engine_workers(tmp_path, 1, dict(common, USE_DP="0"))
     _run_engine_workers(tmp_path, 1, dict(common, USE_DP="1"))
     a, b = torch.load(out + ".1.0.0"), torch.load(out + ".1.0.1")
     assert b["fused"] and not a["fused"]
     d = (a["p"] - b["p"]).abs()
     print("RCCL 1-rank single-call DP vs plain (%s): max |dparam| %.3e; %d collectives, %.1f MB" % (cdt, float(d.max()), b["stats"][0], b["stats"][1] * 1e-6))
-    if cdt == "bf16":          # auto wire format of a <= 2-rank RCCL group in bf16 mode: bf16 (rounded once per rank)
+    if cdt == "bf16":          # bf16 wire: the gradients are rounded once per rank
         assert float(d.max()) <= 3 * 2 * 1e-3 * 1.1 and float(d.mean()) <= 2e-5
     else:
         assert torch.equal(a["p"], b["p"])
