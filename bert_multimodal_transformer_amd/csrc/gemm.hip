@@ -1127,7 +1127,7 @@ static int launch_tile(const GemmArgs& a, int splits, int tile, hipStream_t st) 
         tile = (t128 >= 224) ? 128 : g_tile_n768;
         // one 256 x 128 tile per CU: taken when the whole output is a single, reasonably full round of the 256 CUs
         const long t256 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
-        if (g_tile_big && sizeof(T) == 2 && !AK && splits <= 1 && t256 <= 256 && t256 >= 168) tile = 256;
+        if (g_tile_big && sizeof(T) == 2 && !AK && splits <= 1 && (t256 <= 256 || g_tile_big == 2) && t256 >= 168) tile = 256;      // (2: also when it takes more than one round)
     }
     if constexpr (sizeof(T) == 2 && !AK) {
         if (tile == 256) return launch_cfg<T, 256, 128, AK, BK, MODE>(a, splits, st);

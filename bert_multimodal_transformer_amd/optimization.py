@@ -122,7 +122,20 @@ class AdamW(torch.optim.Optimizer):
             # the full wait.
             late = sorted(dp.late_ranges)
 
+        shards = getattr(dp, "shards", None) if dp is not None else None
+
         def launch(core, group, x, y):
+            if shards is not None and core is shards.core and x < shards.hi and y > shards.lo:
+                # sharded update (distributed.OptimizerShards): of the layers' GEMM weights only this rank's shard; the rest of
+                # [x, y) -- in front of / behind the sharded range -- is replicated as usual
+                pieces = [(x, min(y, shards.lo)), (max(x, shards.a), min(y, shards.b)), (max(x, shards.hi), y)]
+                for px, py in pieces:
+                    if py > px:
+                        launch_range(core, group, px, py)
+                return
+            launch_range(core, group, x, y)
+
+        def launch_range(core, group, x, y):
             if y <= x:
                 return
             b1, b2 = group["betas"]
@@ -172,6 +185,9 @@ class AdamW(torch.optim.Optimizer):
             dp.finish()                    # this stream now waits for the last all-reduce
             for core, group, x, y in deferred:
                 launch(core, group, x, y)
+        if shards is not None:
+            shards.clear_dead_gradients()  # (before the flag below: the buffer really is all zeros again)
+            shards.gather_updated()
         if self.fused_zero_grad:
             self._mark_zero()              # every gradient the update consumed is zero again
         return loss

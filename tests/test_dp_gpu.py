@@ -259,7 +259,15 @@ with m.stream_scope():
 torch.cuda.synchronize()
 fused = bool(dp is not None and dp._last_fused)
 stats = dp.comm.stats() if fused else (0, 0)
-torch.save(dict(p=m.flat_params.cpu(), m=first_m, fused=fused, stats=stats, sparse=bool(fused and dp.comm.sparse)),
+shards = dp.shards.bounds if (dp is not None and dp.shards is not None) else None
+p_before = m.flat_params.cpu().clone()
+sh = m._core.shadow
+shadow = sh[m._core.sh_begin: m._core.sh_end].float().cpu() if sh.numel() > 1 else None
+if shards is not None and os.environ.get("GATHER_MASTERS") == "1":
+    dp.shards.gather_masters()
+    torch.cuda.synchronize()
+torch.save(dict(p=m.flat_params.cpu(), m=first_m, fused=fused, stats=stats, sparse=bool(fused and dp.comm.sparse), shards=shards,
+                p_before_gather=p_before, shadow=shadow),
            os.environ["OUT"] + ".%d.%d.%s" % (world, rank, os.environ.get("USE_DP", "1")))
 if use_dp:
     dist.barrier(); dist.destroy_process_group()
@@ -399,3 +407,34 @@ def test_row_exchange_kernels_with_scripted_peers():
     assert float(results[0][untouched].abs().max()) == 0.0
     for r in range(world):
         L.mb_comm_destroy(state[r]["h"])
+
+
+@pytest.mark.parametrize("cdt", ["fp32", "bf16"])
+def test_sharded_optimizer_update_equals_replicated(tmp_path, cdt):
+    """MB_DP_SHARD_OPT=1 (distributed.OptimizerShards): the gradient pieces of the layers' GEMM weights are reduced to their owner
+    rank only, every rank updates ONE shard of that range (plus the replicated rest), and the operands of the next forward come
+    back by all-gather -- fp32 masters in parity mode, the bf16 shadow in perf mode.  Two ranks over gloo on one GPU, three steps:
+    fp32 -> every parameter on every rank bit-identical to the replicated data-parallel path; bf16 -> each rank's OWN shard of
+    masters bit-identical to the replicated run, the stale foreign shards refreshed by gather_masters()."""
+    import torch
+    out_a, out_b = str(tmp_path / "rep"), str(tmp_path / "shd")
+    common = dict(KIND="bert", MB_DP_ENGINE="0", STEPS="3", CDT=cdt, MB_DETERMINISTIC="1")
+    _run_engine_workers(tmp_path, 2, dict(common, OUT=out_a, MB_DP_SHARD_OPT="0"), tag="rep")
+    _run_engine_workers(tmp_path, 2, dict(common, OUT=out_b, MB_DP_SHARD_OPT="1", GATHER_MASTERS="1"), tag="shd")
+    rep = [torch.load(out_a + ".2.%d.1" % r) for r in range(2)]
+    shd = [torch.load(out_b + ".2.%d.1" % r) for r in range(2)]
+    assert torch.equal(rep[0]["p"], rep[1]["p"])
+    assert not shd[0]["fused"] and shd[0]["shards"] is not None
+    for r in range(2):
+        a, b = shd[r]["shards"][r]
+        assert torch.equal(shd[r]["p_before_gather"][a:b], rep[0]["p"][a:b])          # the owner's shard: the replicated update, bit for bit
+        lo, hi = shd[r]["shards"][0][0], shd[r]["shards"][-1][1]
+        assert torch.equal(shd[r]["p_before_gather"][:lo], rep[0]["p"][:lo]) and torch.equal(shd[r]["p_before_gather"][hi:], rep[0]["p"][hi:])
+        assert torch.equal(shd[r]["p"], rep[0]["p"])                                   # after gather_masters(): everything
+        if cdt == "fp32":
+            assert torch.equal(shd[r]["p_before_gather"], rep[0]["p"])                 # parity mode gathers the masters every step
+        else:
+            other = shd[r]["shards"][1 - r]
+            assert not torch.equal(shd[r]["p_before_gather"][other[0]:other[1]], rep[0]["p"][other[0]:other[1]])      # stale by design
+            assert torch.equal(shd[r]["shadow"], rep[0]["shadow"])                     # ... while the bf16 operands are everybody's
+    print("sharded optimizer (%s): 2 ranks == replicated path bit for bit; shards %s" % (cdt, shd[0]["shards"]))

@@ -433,3 +433,52 @@ def test_prefetch_loads_do_not_delay_their_host_kernel(tmp_path):
         if m2:
             since = sum(1 for o in ops[pf[0]:i] if o.startswith("global_"))
             assert int(m2.group(1)) >= since, "this wait includes the prefetch loads: %s" % ops[pf[0]:i + 1]
+
+
+def test_ragged_tail_is_split_evenly_and_weighted_by_sample_count():
+    """data parallel, ragged last step (distributed.shard_indices / shard_step_sizes, ShardedBatchSampler.loss_scale): every rank
+    gets a batch whenever the tail has >= world samples (5 samples on 4 ranks used to leave the last rank empty), sizes differ by
+    at most one, and each rank's loss weight B_rank * world / B_global makes the 1/world average the mean over the global batch"""
+    from bert_multimodal_transformer_amd.distributed import shard_indices, shard_step_sizes, tail_sizes
+    from bert_multimodal_transformer_amd.multimodal_driver import ShardedBatchSampler
+    assert tail_sizes(5, 4) == [2, 1, 1, 1] and tail_sizes(8, 4) == [2, 2, 2, 2] and sum(tail_sizes(1281 % 384, 8)) == 1281 % 384
+    for n, world, bs in ((101, 4, 24), (1281, 8, 48), (53, 4, 12), (50, 4, 12)):
+        per_rank = [shard_indices(n, r, world, bs, seed=1, epoch=0) for r in range(world)]
+        sizes = shard_step_sizes(n, world, bs)
+        assert len({len(p) for p in per_rank}) == 1 == len({len(p) for p in per_rank + [sizes]})
+        for step, row in enumerate(sizes):
+            assert [len(per_rank[r][step]) for r in range(world)] == row and min(row) >= 1 and max(row) - min(row) <= 1
+        flat = sorted(i for p in per_rank for b in p for i in b)
+        dropped = n % (world * bs) if 0 < n % (world * bs) < world else 0
+        assert len(flat) == n - dropped and len(set(flat)) == len(flat)
+        samplers = [ShardedBatchSampler(n, r, world, bs, 1) for r in range(world)]
+        last = len(sizes) - 1
+        w = [s.loss_scale(last) for s in samplers]
+        assert abs(sum(w) / world - 1.0) < 1e-12 and all(abs(s.loss_scale(0) - 1.0) < 1e-12 for s in samplers)
+        assert all(abs(w[r] - sizes[last][r] * world / float(sum(sizes[last]))) < 1e-12 for r in range(world))
+
+
+def test_optimizer_shards_split_covers_every_element_once():
+    """distributed.OptimizerShards.split: flat gradient ranges -> pieces reduced to ONE owner (inside the sharded range
+    [sh_begin, sh_end), cut at the shard boundaries) + pieces every rank needs (outside it): together they cover every element of
+    the input exactly once, owned pieces lie inside their owner's shard, shard boundaries sit on 256-element marks"""
+    from bert_multimodal_transformer_amd.distributed import OptimizerShards
+
+    class FakeCore(object):
+        sh_begin, sh_end = 0, 85_524_480
+    for world in (2, 3, 8):
+        shards = [OptimizerShards(FakeCore(), r, world) for r in range(world)]
+        b = shards[0].bounds
+        assert b[0][0] == 0 and b[-1][1] == FakeCore.sh_end and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        assert all(x % 256 == 0 for x, _ in b) and all(s.bounds == b for s in shards)
+        ranges = [(0, 7_077_888), (7_077_888 * 3, 7_077_888), (84_934_656, 589_824 + 1000), (90_000_000, 12345)]
+        owned, shared = shards[1].split(ranges)
+        cover = sorted([(o, n) for o, n, _ in owned] + shared)
+        want = sum(n for _, n in ranges)
+        assert sum(n for _, n in cover) == want
+        for (o1, n1), (o2, _) in zip(cover, cover[1:]):
+            assert o1 + n1 <= o2
+        for o, n, r in owned:
+            assert b[r][0] <= o and o + n <= b[r][1]
+        for o, n in shared:
+            assert o >= FakeCore.sh_end or o + n <= FakeCore.sh_begin
