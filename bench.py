@@ -664,9 +664,12 @@ def main():
                 ik = json.load(fh)
             if ik.get("workload") == "%s B=%d L=%d %s" % (a.model, B, L, a.dtype):
                 ik["replayed"] = True
+                ik["busy_ms_per_step_is"] = "the sum of kernel durations UNDER THE PROFILER (a few percent above the untraced step: ms_per_step is the step)"
                 out["instep_kernels"] = ik
                 # achieved HBM rate of the row kernels INSIDE the step (same trace): algorithmic bytes / in-step duration
                 es_, TH = (2 if a.dtype == "bf16" else 4), B * L * 768
+                # bytes: what the kernel itself has to move (its inputs + outputs once); for the MAG gate that is NOT MAG's algorithmic
+                # figure -- the gate re-reads the three GEMM pre-activation panels -- so MAG's forward is reported separately below
                 alg = {"ln_fwd_kernel": 2 * TH * es_, "ln_bwd_kernel": 4 * TH * es_, "mag_gate_fwd_kernel": 8 * TH * es_,
                        "mag_gate_bwd_kernel": 15 * TH * es_, "embed_fwd_kernel": TH * (4 + es_), "embed_bwd_kernel": TH * (es_ + 4 + 4)}
                 rows = []
@@ -674,7 +677,16 @@ def main():
                     for name, nbytes in alg.items():
                         if name in k["kernel"]:
                             rows.append({"kernel": name, "launches_per_step": k["launches_per_step"], "avg_us": k["avg_us"], "bytes": int(nbytes),
+                                         "bytes_are": "the kernel's own inputs + outputs" if name.startswith("mag_gate") else "algorithmic",
                                          "tb_per_s": round(nbytes / k["avg_us"] * 1e-6, 3), "frac_of_8tbs": round(nbytes / k["avg_us"] * 1e-6 / 8.0, 4)})
+                # MAG forward as a whole on SURVEY 8(d)'s algorithmic bytes: read e (bf16), visual, acoustic (fp32), write the output (bf16)
+                # = 3,556 B/token at V = 47, A = 74 -- against the in-step time of everything MAG's forward launches (pack, 3 GEMMs, gate)
+                mag_us = sum(k["avg_us"] * k["launches_per_step"] for k in ik.get("kernels", []) if "mag_gate_fwd" in k["kernel"] or "mag_pack" in k["kernel"])
+                if mag_us > 0:
+                    mag_bytes = B * L * (2 * 768 * es_ + 4 * V + 4 * A)
+                    rows.append({"kernel": "MAG forward, gate + weight pack launches only (its three GEMMs are in the GEMM rows)", "avg_us": round(mag_us, 2),
+                                 "bytes": int(mag_bytes), "bytes_are": "algorithmic, SURVEY 8(d): %d B/token" % (mag_bytes // (B * L)),
+                                 "tb_per_s": round(mag_bytes / mag_us * 1e-6, 3), "frac_of_8tbs": round(mag_bytes / mag_us * 1e-6 / 8.0, 4)})
                 out["roofline_hbm"]["instep_replayed"] = rows
         except Exception:
             pass

@@ -848,15 +848,18 @@ class _FusedStep(object):
                 os.environ.get("MB_OVERLAP_WGRAD", "0") in ("", "0"):
             # data parallel: the same single call with the gradient exchange inside (mb_*_train_step_dp, distributed.Comm)
             opt = optimizer.flat_step_args(core, allow_dp=True)
+            comm = None
             if opt is not None:
+                B_, L_ = input_ids.shape
+                core._ensure(B_, L_)
+                comm = dp.get_comm(B_ * L_)
+            if comm is not None:
                 optimizer._t += 1
                 opt["t"] = optimizer._t
                 optimizer._opt_called = True
                 launches = graph == "launches" or (graph is None and os.environ.get("MB_STEP_GRAPH", "1") == "0")
-                B_, L_ = input_ids.shape
-                core._ensure(B_, L_)
                 core.train_step(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, opt, loss_scale=loss_scale,
-                                mode=2 if launches else 1, comm=dp.get_comm(B_ * L_))
+                                mode=2 if launches else 1, comm=comm)
                 dp._last_fused = True
                 return core.loss_buf[0]
         if dp is not None:

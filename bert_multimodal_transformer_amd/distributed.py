@@ -545,9 +545,15 @@ class DataParallel(object):
 
     def get_comm(self, tokens):
         """the C-side exchange object, created collectively at the first single-call step"""
-        if self.comm is None:
-            self.comm = Comm(self.core, self.pg, self.reducer.wire_dtype, sparse_rows=self.word is not None,
-                             row_capacity=max(self.row_capacity, int(tokens)))
+        if self.comm is None and self._comm_enabled:
+            try:
+                self.comm = Comm(self.core, self.pg, self.reducer.wire_dtype, sparse_rows=self.word is not None,
+                                 row_capacity=max(self.row_capacity, int(tokens)))
+            except Exception as ex:         # no RCCL to load, communicator refused, ...: say so and keep training on the stage-driven path
+                import sys
+                print("warning: the single-call data-parallel step is unavailable (%s); the gradient exchange stays with the "
+                      "stage-driven path (torch.distributed)" % (ex,), file=sys.stderr)
+                self._comm_enabled = False
         return self.comm
 
     def exposed_ms(self):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round artefacts: bench lines (headline, C5 shape, MAG-XLNet), rocprofv3 kernel stats, in-step kernel table, PMC passes.
-# usage: bash scripts/gpu_artifacts.sh r03     (every command under its own timeout)
-R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r03}
+# usage: bash scripts/gpu_artifacts.sh r04     (every command under its own timeout)
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r04}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 SB=$R/tools/bin/step_bench
@@ -56,13 +56,31 @@ f=$(find /tmp/p_c5 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O
 f=$(find /tmp/p_c5 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 scripts/exp/instep_json.py $f 6 "bert B=32 L=128 bf16 (MOSEI V=35)" $O/instep_kernels_c5.json > $O/instep_kernels_c5.txt
 # ---- 3. bench.py lines
 cp $O/instep_kernels.json profiles/instep_kernels.json 2>/dev/null
-(timeout 400 python bench.py 2>&1 | tail -2) > $O/bench_line.log 2>&1
-(timeout 300 python bench.py --dataset mosei --seq 128 --batch 32 --cpu-baseline 0 --steps 30 --warmup 6 2>&1 | tail -2) > $O/bench_line_c5.log 2>&1
-(timeout 300 python bench.py --model xlnet --cpu-steps 2 --steps 30 --warmup 6 2>&1 | tail -2) > $O/bench_line_xlnet.log 2>&1
-( cd /tmp && rm -rf /tmp/p_b && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_b -o b -- python $R/bench.py --steps 10 --warmup 3 --cpu-baseline 0 --roofline 0 > /dev/null 2>&1 )
+J='^{"metric'
+(timeout 500 python bench.py 2>&1 | grep "$J") > $O/bench_line.log 2>&1
+(timeout 300 python bench.py --dataset mosei --seq 128 --batch 32 --cpu-baseline 0 --steps 30 --warmup 6 2>&1 | grep "$J") > $O/bench_line_c5.log 2>&1
+(timeout 300 python bench.py --model xlnet --cpu-steps 2 --steps 30 --warmup 6 2>&1 | grep "$J") > $O/bench_line_xlnet.log 2>&1
+# ---- 3b. the data-parallel step on ONE GPU (one-rank RCCL group, MB_DP_FORCE=1) against the single-call step, same box, twice each
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+{
+for rep in 1 2; do
+  echo "== single call (mb_bert_train_step), bench.py"; timeout 300 python bench.py --cpu-baseline 0 --roofline 0 --secondary 0 --steps 100 --warmup 20 2>&1 | grep "$J" | cut -c1-1400
+  echo "== MB_DP_FORCE=1: mb_bert_train_step_dp, one-rank RCCL communicator driven from C, bench.py"; MB_DP_FORCE=1 timeout 300 python bench.py --cpu-baseline 0 --roofline 0 --steps 100 --warmup 20 2>&1 | grep "$J" | cut -c1-1700
+done
+echo "== MB_DP_FORCE=1 MB_DP_ENGINE=0: round-3 structure (passes and exchange driven from Python)"; MB_DP_FORCE=1 MB_DP_ENGINE=0 timeout 300 python bench.py --cpu-baseline 0 --roofline 0 --steps 100 --warmup 20 2>&1 | grep "$J" | cut -c1-1500
+echo "== MB_DP_FORCE=1 MB_DP_GRAD_DTYPE=bf16: the two-GPU wire format forced on one GPU (staging passes)"; MB_DP_FORCE=1 MB_DP_GRAD_DTYPE=bf16 timeout 300 python bench.py --cpu-baseline 0 --roofline 0 --steps 100 --warmup 20 2>&1 | grep "$J" | cut -c1-1500
+echo "== MAG-XLNet single call / MB_DP_FORCE=1"; timeout 300 python bench.py --model xlnet --cpu-baseline 0 --roofline 0 --steps 60 --warmup 10 2>&1 | grep "$J" | cut -c1-1200
+MB_DP_FORCE=1 timeout 300 python bench.py --model xlnet --cpu-baseline 0 --roofline 0 --steps 60 --warmup 10 2>&1 | grep "$J" | cut -c1-1500
+for rep in 1 2; do
+  echo "== C++ driver: single call"; timeout 120 $SB --graph 1 --h2d 2 --steps 100 --warmup 20
+  echo "== C++ driver: --dp 1 (one-rank RCCL communicator)"; timeout 180 $SB --graph 1 --h2d 2 --steps 100 --warmup 20 --dp 1 2>&1 | grep step_bench
+  echo "== C++ driver: --dp 1, host cost with an empty queue (5 steps)"; timeout 180 $SB --graph 1 --h2d 2 --steps 5 --warmup 20 --dp 1 2>&1 | grep "ms/step"
+done
+} > $O/dp_force.txt 2>&1
+( cd /tmp && rm -rf /tmp/p_b && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_b -o b -- python $R/bench.py --steps 10 --warmup 3 --cpu-baseline 0 --roofline 0 --secondary 0 > /dev/null 2>&1 )
 f=$(find /tmp/p_b -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_kernel_stats.csv
 ( cd /tmp && rm -rf /tmp/p_x && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_x -o b -- python $R/bench.py --model xlnet --steps 10 --warmup 3 --cpu-baseline 0 --roofline 0 > /dev/null 2>&1 )
 f=$(find /tmp/p_x -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/xlnet_kernel_stats.csv
-for f in bench_line bench_line_c5 bench_line_xlnet; do tail -1 $O/$f.log | cut -c1-420; done
+for f in bench_line bench_line_c5 bench_line_xlnet; do tail -n 1 $O/$f.log | cut -c1-420; done
 cat $O/instep_kernels.txt | head -24
 cat $O/step_bench.txt
