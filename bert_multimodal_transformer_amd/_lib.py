@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmagbert_hip.so")
+# MB_LIB_DIR: another build of the same library (scripts/build_variant.py -> gpurun_ab/<name>/) for same-box A/B measurements
+LIB_PATH = os.path.join(os.environ.get("MB_LIB_DIR") or os.path.join(_HERE, "lib"), "libmagbert_hip.so")
 
 DT_F32, DT_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2

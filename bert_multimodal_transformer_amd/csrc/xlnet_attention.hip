@@ -55,15 +55,20 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
     constexpr int RW = NT + NW + 1 < 2 * NT ? NT + NW + 1 : 2 * NT;      // position tiles staged per block
     constexpr int RR = RW * 16;
     constexpr int RWT = 2 * NT < NT + 2 ? 2 * NT : NT + 2;               // position tiles of one strip's window
-    constexpr int RPIT = RWT * 16 * 4 + 16;            // raw (fp32) strip pitch
-    static_assert(16 * SPIT <= 16 * RPIT, "probability strip must fit inside the raw strip it aliases");
-    __shared__ __attribute__((aligned(16))) char smem[(QR + 2 * LP + RR + 16) * PIT + NW * 16 * RPIT + (LP + RR + 4 + 2 * LP) * 4];
-    char* Qi = smem;                                   // query rows [rb, rb + QR)
-    char* Ki = Qi + QR * PIT;
+    // LDS budget (round 4): at L <= 64 the block held 75 KB -- two blocks per CU, 512 slots for the 576 (batch, head) blocks of the
+    // benchmarked shape: TWO rounds.  Three changes bring it to 51.8 KB = three blocks per CU, one round: the query rows are not
+    // staged (a wave's 16 rows are only ever its own MFMA operand: loaded from global memory straight into fragment registers);
+    // the raw shifted-score strip is kept in the activation dtype (bf16 mode: (q + r_r_bias) . kr rounded once more, the same
+    // 2^-9 the operands already carry; fp32 mode: unchanged); the seg_embed image keeps its two rows (the 14 rows of padding a
+    // 16-row MFMA operand reads fall into the strips behind it: their products land in accumulator rows nobody looks at).  The
+    // probabilities stay in the accumulator registers (AccOp, as in attention.hip): no probability strip, no barrier in front of P.V.
+    constexpr int RPIT = RWT * 16 * (int)sizeof(T) + 16;            // raw strip pitch
+    __shared__ __attribute__((aligned(16))) char smem[(2 * LP + RR + 2) * PIT + NW * 16 * RPIT + (LP + RR + 4 + 2 * LP) * 4];
+    char* Ki = smem;
     char* Vi = Ki + LP * PIT;
     char* Ri = Vi + LP * PIT;                          // KR image: positions [pt_lo * 16, pt_lo * 16 + RR)
-    char* Si = Ri + RR * PIT;                          // seg_embed image [16][64] (rows 0,1)
-    char* raws = Si + 16 * PIT;
+    char* Si = Ri + RR * PIT;                          // seg_embed image, rows 0 and 1 (see above)
+    char* raws = Si + 2 * PIT;
     float* cK = (float*)(raws + NW * 16 * RPIT);
     float* cR = cK + LP;
     float* cS = cR + RR;
@@ -81,22 +86,32 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
     {
         const int qv = L - rb < 0 ? 0 : (L - rb > QR ? QR : L - rb), rvv = 2 * L - pt_lo * 16 < 0 ? 0 : (2 * L - pt_lo * 16 > RR ? RR : 2 * L - pt_lo * 16);
         const T* rsrc = kr + ((size_t)b * 2 * L + (size_t)pt_lo * 16) * H + h * 64;
+        (void)qv;
         if constexpr (LP <= 64) {
-            char* const img[4] = {Qi, Ki, Vi, Ri};
-            const T* const src[4] = {base + (size_t)rb * ld, base + H, base + 2 * H, rsrc};
-            const size_t lds[4] = {ld, ld, ld, (size_t)H};
-            const int ra[4] = {QR, LP, LP, RR}, rv[4] = {qv, L, L, rvv};
-            stage_heads_var<T, NW * 64, 4, (RR > LP ? RR : LP)>(img, PIT, src, lds, ra, rv);       // every load in flight before the first LDS store
+            char* const img[3] = {Ki, Vi, Ri};
+            const T* const src[3] = {base + H, base + 2 * H, rsrc};
+            const size_t lds[3] = {ld, ld, (size_t)H};
+            const int ra[3] = {LP, LP, RR}, rv[3] = {L, L, rvv};
+            stage_heads_var<T, NW * 64, 3, (RR > LP ? RR : LP)>(img, PIT, src, lds, ra, rv);       // every load in flight before the first LDS store
         } else {
-            stage_rows<T, NW * 64>(Qi, PIT, base + (size_t)rb * ld, ld, QR, qv);
             stage_rows<T, NW * 64>(Ki, PIT, base + H, ld, LP, L);
             stage_rows<T, NW * 64>(Vi, PIT, base + 2 * H, ld, LP, L);
             stage_rows<T, NW * 64>(Ri, PIT, rsrc, (size_t)H, RR, rvv);
         }
     }
-    for (int t = threadIdx.x; t < 16 * 64; t += NW * 64) {
+    // this wave's query rows as MFMA operand fragments (rows >= L: zeros)
+    typename Frag<T>::type qf[DSL];
+    {
+        const int qi = rb + wave * 16 + (lane & 15);
+#pragma unroll
+        for (int sl = 0; sl < DSL; ++sl) {
+            qf[sl] = typename Frag<T>::type{};
+            if (qi < L) qf[sl] = *(const typename Frag<T>::type*)(base + (size_t)qi * ld + sl * C::SLAB + (lane >> 4) * C::EPV);
+        }
+    }
+    for (int t = threadIdx.x; t < 2 * 64; t += NW * 64) {
         const int row = t >> 6, d = t & 63;
-        *(T*)(Si + row * PIT + d * (int)sizeof(T)) = from_f<T>(row < 2 ? xp.seg_embed[((size_t)row * nh + h) * 64 + d] : 0.f);
+        *(T*)(Si + row * PIT + d * (int)sizeof(T)) = from_f<T>(xp.seg_embed[((size_t)row * nh + h) * 64 + d]);
     }
     for (int j = threadIdx.x; j < LP; j += NW * 64) {
         segv[j] = j < L ? (int)xp.seg[(size_t)b * L + j] : -1;
@@ -115,7 +130,6 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
     __syncthreads();
 
     char* raw = raws + wave * 16 * RPIT;
-    char* Ps = raw;                                    // aliases the raw strip (see above)
     const float scale = 0.125f;
     {
         const int strip = blockIdx.y * NW + wave;       // global strip of this wave; its query rows are rows wave * 16 .. of Qi
@@ -131,8 +145,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
                 ac[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int sl = 0; sl < DSL; ++sl)
-                    mma16(ac[jt], frag_nat<T>(Ki, PIT, jt * 16 + (lane & 15), sl, lane),
-                          frag_nat<T>(Qi, PIT, wave * 16 + (lane & 15), sl, lane));
+                    mma16(ac[jt], frag_nat<T>(Ki, PIT, jt * 16 + (lane & 15), sl, lane), qf[sl]);
             }
 #pragma unroll
             for (int q = 0; q < RWT; ++q) {
@@ -140,16 +153,15 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
                 f32x4 rw = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int sl = 0; sl < DSL; ++sl)
-                    mma16(rw, frag_nat<T>(Ri, PIT, (pt - pt_lo) * 16 + (lane & 15), sl, lane),
-                          frag_nat<T>(Qi, PIT, wave * 16 + (lane & 15), sl, lane));
+                    mma16(rw, frag_nat<T>(Ri, PIT, (pt - pt_lo) * 16 + (lane & 15), sl, lane), qf[sl]);
                 const int p0 = pt * 16 + (lane >> 4) * 4;
                 rw += *(const f32x4*)(cR + p0 - pt_lo * 16);
-                *(f32x4*)(raw + (lane & 15) * RPIT + (p0 - pt0 * 16) * 4) = rw;          // raw[i][p] = (q_i + r_r_bias) . kr_p
+                store4((T*)(raw + (lane & 15) * RPIT) + (p0 - pt0 * 16), rw);          // raw[i][p] = (q_i + r_r_bias) . kr_p
             }
             f32x4 ev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int sl = 0; sl < DSL; ++sl)
-                mma16(ev, frag_nat<T>(Si, PIT, lane & 15, sl, lane), frag_nat<T>(Qi, PIT, wave * 16 + (lane & 15), sl, lane));
+                mma16(ev, frag_nat<T>(Si, PIT, lane & 15, sl, lane), qf[sl]);
             e0 = __shfl(ev[0] + cS[0], lane & 15, 64);     // lanes 0..15 hold E[i][s = 0, 1]
             e1 = __shfl(ev[1] + cS[1], lane & 15, 64);
         }
@@ -165,7 +177,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
                     const int j = jt * 16 + (lane >> 4) * 4 + r;
                     int p = L - i + j - pt0 * 16;          // inside the window for every real (i < L, j < L) pair
                     p = p < 0 ? 0 : (p > RWT * 16 - 1 ? RWT * 16 - 1 : p);
-                    const float bd = *(const float*)(raw + (lane & 15) * RPIT + p * 4);
+                    const float bd = to_f(*(const T*)(raw + (lane & 15) * RPIT + p * (int)sizeof(T)));
                     float s = (ac[jt][r] + cK[j] + bd + (si == segv[j] ? e0 : e1)) * scale;
                     if (j >= L) s = kPadNeg;
                     else if (i != j && (padf[j] || (xp.perm != nullptr && i < L && xp.perm[((size_t)b * L + i) * L + j] != 0))) s -= kXlMask;
@@ -189,18 +201,14 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
                 if (psave != nullptr && i < L) store4(psave + ((size_t)blockIdx.x * LP + i) * LP + j, p);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p[r] *= drop_mult(drop, rowidx + j + r);
-                store4((T*)(Ps + (lane & 15) * SPIT) + j, p);
+                ac[jt] = p;                      // the dropped probabilities: operand of P.V below (AccOp)
             }
-        }
-        __syncthreads();
-        if (active) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int sl = 0; sl < LSL; ++sl)
-                    mma16(o, frag_kmaj(Vi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
-                          frag_nat<T>(Ps, SPIT, lane & 15, sl, lane));
+                    mma16(o, AccOp<T>::kmaj(Vi, PIT, sl, dt * 16 + (lane & 15), lane), AccOp<T>::make(&ac[sl * AccOp<T>::TILES]));
                 const int i = strip * 16 + (lane & 15);
                 if (xp.head_scale) o = o * xp.head_scale[h];      // attn_prob * head_mask, applied to the head's output (same product)
                 if (i < L) store4(vec + ((size_t)b * L + i) * H + h * 64 + dt * 16 + (lane >> 4) * 4, o);
@@ -257,14 +265,16 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
     constexpr int GPIT = RWT * 16 * (int)sizeof(T) + 16;     // shifted-G strip pitch (the strip's position window)
     constexpr int RSL = RWT * 16 / C::SLAB;
     // Q is not staged: it is only read once per row at the end (q_i + r_s_bias for the segment-embedding gradient), straight from
-    // HBM/L2.
-    __shared__ __attribute__((aligned(16))) char smem[(2 * LP + QR + RR) * PIT + NW * 16 * (SPIT + GPIT) + (192 + 2 * LP) * 4];
+    // HBM/L2.  Round 4 (LDS 69.9 -> 51.5 KB at L <= 64: three blocks per CU, the 576 blocks of the benchmarked shape in ONE round
+    // instead of two): the dvec rows of a wave are only its own MFMA operand -> fragment registers loaded from global memory, no
+    // image; the score gradients G stay in the accumulator registers as the operand of G . K (AccOp) -> no natural-order strip,
+    // only the position-shifted one.
+    (void)SPIT;
+    __shared__ __attribute__((aligned(16))) char smem[(2 * LP + RR) * PIT + NW * 16 * GPIT + (192 + 2 * LP) * 4];
     char* Ki = smem;
     char* Vi = Ki + LP * PIT;
-    char* Oi = Vi + LP * PIT;                          // dvec image: rows [rb, rb + QR)
-    char* Ri = Oi + QR * PIT;                          // KR image: positions [pt_lo * 16, pt_lo * 16 + RR)
-    char* gstr = Ri + RR * PIT;
-    char* sstr = gstr + NW * 16 * SPIT;
+    char* Ri = Vi + LP * PIT;                          // KR image: positions [pt_lo * 16, pt_lo * 16 + RR)
+    char* sstr = Ri + RR * PIT;
     float* sef = (float*)(sstr + NW * 16 * GPIT);     // se0[64] | se1[64] | rsb[64]
     int* segv = (int*)(sef + 192);
     int* padf = segv + LP;
@@ -281,17 +291,27 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
         const int qv = L - rb < 0 ? 0 : (L - rb > QR ? QR : L - rb), rvv = 2 * L - pt_lo * 16 < 0 ? 0 : (2 * L - pt_lo * 16 > RR ? RR : 2 * L - pt_lo * 16);
         const T* osrc = dvec + ((size_t)b * L + rb) * H + h * 64;
         const T* rsrc = kr + ((size_t)b * 2 * L + (size_t)pt_lo * 16) * H + h * 64;
+        (void)qv; (void)osrc;
         if constexpr (LP <= 64) {
-            char* const img[4] = {Ki, Vi, Oi, Ri};
-            const T* const src[4] = {base + H, base + 2 * H, osrc, rsrc};
-            const size_t lds[4] = {ld, ld, (size_t)H, (size_t)H};
-            const int ra[4] = {LP, LP, QR, RR}, rv[4] = {L, L, qv, rvv};
-            stage_heads_var<T, NW * 64, 4, (RR > LP ? RR : LP)>(img, PIT, src, lds, ra, rv);
+            char* const img[3] = {Ki, Vi, Ri};
+            const T* const src[3] = {base + H, base + 2 * H, rsrc};
+            const size_t lds[3] = {ld, ld, (size_t)H};
+            const int ra[3] = {LP, LP, RR}, rv[3] = {L, L, rvv};
+            stage_heads_var<T, NW * 64, 3, (RR > LP ? RR : LP)>(img, PIT, src, lds, ra, rv);
         } else {
             stage_rows<T, NW * 64>(Ki, PIT, base + H, ld, LP, L);
             stage_rows<T, NW * 64>(Vi, PIT, base + 2 * H, ld, LP, L);
-            stage_rows<T, NW * 64>(Oi, PIT, osrc, (size_t)H, QR, qv);
             stage_rows<T, NW * 64>(Ri, PIT, rsrc, (size_t)H, RR, rvv);
+        }
+    }
+    // this wave's dvec rows as MFMA operand fragments (rows >= L: zeros)
+    typename Frag<T>::type of[DSL];
+    {
+        const int oi = rb + wave * 16 + (lane & 15);
+#pragma unroll
+        for (int sl = 0; sl < DSL; ++sl) {
+            of[sl] = typename Frag<T>::type{};
+            if (oi < L) of[sl] = *(const typename Frag<T>::type*)(dvec + ((size_t)b * L + oi) * H + h * 64 + sl * C::SLAB + (lane >> 4) * C::EPV);
         }
     }
     for (int t = threadIdx.x; t < 192; t += NW * 64)
@@ -301,15 +321,11 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
         padf[j] = 0;
     }
     __syncthreads();
-    if (xp.head_scale) {                 // head_mask: every gradient of this head is linear in its dvec
-        scale_image<T, QR, NW * 64>(Oi, PIT, xp.head_scale[h]);
-        __syncthreads();
-    }
+    const float hs = xp.head_scale ? xp.head_scale[h] : 1.0f;      // head_mask: every gradient of this head is linear in its dvec
 
     f32x4 cw[4], cr[4], cs[4], d0[4], d1[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) cw[dt] = cr[dt] = cs[dt] = d0[dt] = d1[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    char* Gs = gstr + wave * 16 * SPIT;
     char* Ss = sstr + wave * 16 * GPIT;
     const float scale = 0.125f;
     T* dq_base = dqkv + (size_t)b * L * ld + h * 64;
@@ -322,8 +338,9 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
         pt0 = pt0 < 0 ? 0 : (pt0 > 2 * NT - RWT ? 2 * NT - RWT : pt0);
         pt0 = pt0 > pt_lo + RW - RWT ? pt_lo + RW - RWT : pt0;
         float g0 = 0.f, g1 = 0.f;
+        f32x4 pv[NT];                          // P, then G: stays in registers as the operand of G . K
         if (active) {
-            // zero this wave's shifted strip, then fill G (natural) and G shifted to position space
+            // zero this wave's shifted strip, then G in registers and G shifted to position space
             for (int t = lane; t < 16 * GPIT / 16; t += 64) *(u32x4*)(Ss + t * 16) = u32x4{0u, 0u, 0u, 0u};
             f32x4 dp[NT];
 #pragma unroll
@@ -331,11 +348,10 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
                 dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int sl = 0; sl < DSL; ++sl)
-                    mma16(dp[jt], frag_nat<T>(Vi, PIT, jt * 16 + (lane & 15), sl, lane),
-                          frag_nat<T>(Oi, PIT, wave * 16 + (lane & 15), sl, lane));
+                    mma16(dp[jt], frag_nat<T>(Vi, PIT, jt * 16 + (lane & 15), sl, lane), of[sl]);
+                dp[jt] = dp[jt] * hs;
             }
             const uint32_t rowidx = ((uint32_t)blockIdx.x * L + (uint32_t)i) * L;
-            f32x4 pv[NT];
             float dsum = 0.f;
             const size_t prow = ((size_t)blockIdx.x * LP + (i < LP ? i : 0)) * LP;      // storage row (padded to LP columns)
 #pragma unroll
@@ -365,7 +381,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
                     } else g[r] = 0.f;
                 }
                 if (i < L) store4(gsave + prow + j0, g);          // same padded layout as psave
-                store4((T*)(Gs + (lane & 15) * SPIT) + j0, g);
+                pv[jt] = g;                                          // G stays in registers: the operand of G . K below (AccOp)
             }
             g0 = quad_sum(g0);
             g1 = quad_sum(g1);
@@ -377,8 +393,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
                 f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int sl = 0; sl < LSL; ++sl)
-                    mma16(oa, frag_kmaj(Ki, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
-                          frag_nat<T>(Gs, SPIT, lane & 15, sl, lane));
+                    mma16(oa, AccOp<T>::kmaj(Ki, PIT, sl, dt * 16 + (lane & 15), lane), AccOp<T>::make(&pv[sl * AccOp<T>::TILES]));
 #pragma unroll
                 for (int sl = 0; sl < RSL; ++sl)
                     mma16(ob, frag_kmaj(Ri, PIT, (pt0 - pt_lo) * 16 + sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
@@ -398,10 +413,10 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
     }
     {
         // the strip buffers are free after the last strip barrier: 5 * NW * 64 floats fit (NW * 16 * (SPIT + GPIT) bytes)
-        static_assert(NW * 16 * (SPIT + GPIT) >= 5 * NW * 64 * 4, "strip buffers hold the five column-sum tiles");
+        static_assert(NW * 16 * GPIT >= 5 * NW * 64 * 4, "the shifted strips hold the five column-sum tiles");
         f32x4 (* const tiles[5])[4] = {&cw, &cr, &cs, &d0, &d1};
         float* const dst[5] = {d_rwb + h * 64, d_rrb + h * 64, d_rsb + h * 64, d_seg + (size_t)h * 64, d_seg + ((size_t)nh + h) * 64};
-        flush_colsums<NW, 5>(tiles, dst, (float*)gstr, lane, wave, xp.acc);
+        flush_colsums<NW, 5>(tiles, dst, (float*)sstr, lane, wave, xp.acc);
     }
 }
 
