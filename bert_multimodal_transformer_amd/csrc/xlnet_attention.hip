@@ -12,6 +12,7 @@
 //   xl_attn_fwd    : scores -> softmax -> P (saved, undropped) -> vec
 //   xl_attn_bwd_q  : dP, G (saved), dq = G.K + Gshift.KR + sum_j G.seg ; r_w/r_r/r_s bias and seg_embed gradients
 //   xl_attn_bwd_kv : dv = Pd^T dO ; dk = G^T (q + r_w_bias) ; dkr[p] = sum_i G[i, p-L+i] (q_i + r_r_bias)
+#include <cstdlib>
 #include "attn_common.h"
 
 namespace mb {
@@ -555,6 +556,140 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv_kernel(const T* __rest
     }
 }
 
+// ---- the same for L <= 64 in bf16 (round 4): P (with this step's dropout applied) and G of the head are staged ONCE into LDS with
+// coalesced 16-byte loads, and every product reads them through transposed fragment reads -- dv = Pd^T dO and dk = G^T (q + r_w_bias)
+// take BOTH operands k-major (k = the query index), so there are no per-element global loads (the kernel above fetches its tiles with
+// 2-byte loads in transposed order: 48 dependent round trips per wave), no strips and no barriers for the key side; the position
+// side gathers its diagonals out of the LDS image instead of out of HBM.  46.6 KB of LDS: three blocks per CU.
+template <class T, int LP, int NW>
+__global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv2_kernel(const T* __restrict__ qkv, XlParams xp, const T* __restrict__ psave,
+                                                                  const T* __restrict__ gsave, const T* __restrict__ dvec,
+                                                                  T* __restrict__ dqkv, T* __restrict__ dkr, int L, int nh,
+                                                                  DropKey drop) {
+    drop.resolve();
+    typedef AttnCfg<T> C;
+    constexpr int PIT = C::ROWB + 16;
+    constexpr int SPIT = LP * (int)sizeof(T) + 16;
+    constexpr int NT = LP / 16, LSL = LP / C::SLAB;
+    constexpr int CPR = LP * (int)sizeof(T) / 16;           // 16-byte chunks per P / G row
+    __shared__ __attribute__((aligned(16))) char smem[2 * LP * PIT + 2 * LP * SPIT + NW * 16 * SPIT + 128 * 4];
+    char* Qi = smem;
+    char* Oi = Qi + LP * PIT;
+    char* Pi = Oi + LP * PIT;                           // Pd[i][j]: saved probabilities x this step's dropout multipliers
+    char* Gi = Pi + LP * SPIT;                          // G[i][j]
+    char* strips = Gi + LP * SPIT;
+    float* bia = (float*)(strips + NW * 16 * SPIT);     // r_w_bias[64] | r_r_bias[64]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    const int H = nh * 64;
+    const size_t ld = (size_t)3 * H;
+    const size_t pbase = (size_t)blockIdx.x * LP * LP;       // psave / gsave rows are padded to LP columns
+    const size_t dbase = (size_t)blockIdx.x * L * L;         // dropout element index space (unpadded)
+    {
+        // P and G rows first (their loads are in flight under the staging of Q and dvec below); rows >= L were never written
+        constexpr int IT = (LP * CPR + NW * 64 - 1) / (NW * 64);
+        u32x4 pv[IT], gv[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int id = threadIdx.x + it * NW * 64, row = id / CPR, c = id % CPR;
+            pv[it] = gv[it] = u32x4{0u, 0u, 0u, 0u};
+            if (id < LP * CPR && row < L) {
+                pv[it] = *(const u32x4*)((const char*)(psave + pbase + (size_t)row * LP) + c * 16);
+                gv[it] = *(const u32x4*)((const char*)(gsave + pbase + (size_t)row * LP) + c * 16);
+            }
+        }
+        char* const img[2] = {Qi, Oi};
+        const T* const src[2] = {qkv + (size_t)b * L * ld + h * 64, dvec + (size_t)b * L * H + h * 64};
+        const size_t lds[2] = {ld, (size_t)H};
+        stage_heads<T, LP, NW * 64, 2>(img, PIT, src, lds, L);
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int id = threadIdx.x + it * NW * 64, row = id / CPR, c = id % CPR;
+            if (id >= LP * CPR) continue;
+            union { u32x4 u; T e[C::EPV]; } x;
+            x.u = pv[it];
+            if (row < L) {
+#pragma unroll
+                for (int q = 0; q < C::EPV; ++q) {
+                    const int j = c * C::EPV + q;
+                    x.e[q] = j < L ? from_f<T>(to_f(x.e[q]) * drop_mult(drop, (uint32_t)(dbase + (size_t)row * L + j))) : from_f<T>(0.f);
+                }
+            }
+            *(u32x4*)(Pi + row * SPIT + c * 16) = x.u;
+            *(u32x4*)(Gi + row * SPIT + c * 16) = gv[it];
+        }
+    }
+    for (int t = threadIdx.x; t < 128; t += NW * 64) bia[t] = t < 64 ? xp.r_w_bias[h * 64 + t] : xp.r_r_bias[h * 64 + t - 64];
+    __syncthreads();
+    if (xp.head_scale) {
+        scale_image<T, LP, NW * 64>(Oi, PIT, xp.head_scale[h]);
+        __syncthreads();
+    }
+    T* dq_base = dqkv + (size_t)b * L * ld + h * 64;
+
+    // ---- key strips: dv, dk (a wave owns whole strips; nothing is written to LDS)
+    for (int strip = wave; strip < NT; strip += NW) {
+        const int j = strip * 16 + (lane & 15);
+        float csum = 0.f;
+#pragma unroll
+        for (int m = 0; m < LP / 4; ++m) csum += to_f(*(const T*)(Gi + ((lane >> 4) + 4 * m) * SPIT + j * (int)sizeof(T)));
+        csum = quad_sum(csum);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4 ov = {0.f, 0.f, 0.f, 0.f}, ok = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sl = 0; sl < LSL; ++sl) {
+                const int k0 = sl * C::SLAB + (lane >> 4) * C::EPV;
+                mma16(ov, frag_kmaj(Oi, PIT, k0, dt * 16 + (lane & 15), T()), frag_kmaj(Pi, SPIT, k0, j, T()));
+                mma16(ok, frag_kmaj(Qi, PIT, k0, dt * 16 + (lane & 15), T()), frag_kmaj(Gi, SPIT, k0, j, T()));
+            }
+            const int d = dt * 16 + (lane >> 4) * 4;
+            ok += csum * *(const f32x4*)(bia + d);                // + (sum_i G[i,j]) * r_w_bias
+            if (j < L) {
+                store4(dq_base + (size_t)j * ld + 2 * H + d, ov);
+                store4(dq_base + (size_t)j * ld + H + d, ok);
+            }
+        }
+    }
+    // ---- position strips: dkr[p] = sum_i G[i, p - L + i] (q_i + r_r_bias); the diagonals are gathered out of the G image into the
+    // wave's own strip (written and read by this wave only: LDS operations of a wave execute in order, no block barrier)
+    char* St = strips + wave * 16 * SPIT;
+    for (int strip = wave; strip < 2 * NT; strip += NW) {
+        const int p = strip * 16 + (lane & 15);
+        float csum = 0.f;
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            const int i0 = it * 16 + (lane >> 4) * 4;
+            f32x4 g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + r, j = p - L + i;
+                g[r] = (i < L && j >= 0 && j < L) ? to_f(*(const T*)(Gi + i * SPIT + j * (int)sizeof(T))) : 0.f;
+                csum += g[r];
+            }
+            store4((T*)(St + (lane & 15) * SPIT) + i0, g);
+        }
+        csum = quad_sum(csum);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sl = 0; sl < LSL; ++sl)
+                mma16(o, frag_kmaj(Qi, PIT, sl * C::SLAB + (lane >> 4) * C::EPV, dt * 16 + (lane & 15), T()),
+                      frag_nat<T>(St, SPIT, lane & 15, sl, lane));
+            const int d = dt * 16 + (lane >> 4) * 4;
+            o += csum * *(const f32x4*)(bia + 64 + d);
+            if (p < 2 * L) store4(dkr + ((size_t)b * 2 * L + p) * H + h * 64 + d, o);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ================================================================================================ host
 // LP = L rounded up to 32 / 64 / 128; NW_* = waves (query strips per block for the two query-side kernels, whose grid has
 // LP / 16 / NW strip groups in y; plain wave count for the key-side kernel, which loops over its strips).  At LP = 128 the images of a
@@ -591,11 +726,21 @@ int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const f
                              const void* psave, const void* dvec, void* gsave, void* dqkv, void* dkr, float* d_rwb,
                              float* d_rrb, float* d_rsb, float* d_seg, int B, int L, int nh, DropKey drop, hipStream_t st,
                              const float* head_scale, GradAcc acc) {
+    static int g_kv2 = -1;            // MB_XL_KV2=0: the key / position side of the backward with the round-3 kernel at L <= 64 too (A/B)
+    if (g_kv2 < 0) { const char* v = getenv("MB_XL_KV2"); g_kv2 = v ? atoi(v) : 1; }
     XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale, nullptr, acc};
     XL_DISPATCH({
         (void)NWF;
         hipLaunchKernelGGL((xl_attn_bwd_q_kernel<T, LP, NWQ>), dim3(B * nh, LP / 16 / NWQ), dim3(NWQ * 64), 0, st, (const T*)qkv, (const T*)kr,
                            xp, (const T*)psave, (const T*)dvec, (T*)gsave, (T*)dqkv, d_rwb, d_rrb, d_rsb, d_seg, L, nh, drop);
+        if constexpr (sizeof(T) == 2 && LP <= 64) {
+            if (g_kv2)
+                hipLaunchKernelGGL((xl_attn_bwd_kv2_kernel<T, LP, NWK>), dim3(B * nh), dim3(NWK * 64), 0, st, (const T*)qkv, xp,
+                                   (const T*)psave, (const T*)gsave, (const T*)dvec, (T*)dqkv, (T*)dkr, L, nh, drop);
+            else
+                hipLaunchKernelGGL((xl_attn_bwd_kv_kernel<T, LP, NWK>), dim3(B * nh), dim3(NWK * 64), 0, st, (const T*)qkv, xp,
+                                   (const T*)psave, (const T*)gsave, (const T*)dvec, (T*)dqkv, (T*)dkr, L, nh, drop);
+        } else
         hipLaunchKernelGGL((xl_attn_bwd_kv_kernel<T, LP, NWK>), dim3(B * nh), dim3(NWK * 64), 0, st, (const T*)qkv, xp,
                            (const T*)psave, (const T*)gsave, (const T*)dvec, (T*)dqkv, (T*)dkr, L, nh, drop);
     })
