@@ -834,13 +834,15 @@ class _FusedStep(object):
         """One iteration of train_epoch's loop body (multimodal_driver.py:359-386): batch staging, forward, MSE, backward
         and -- when `optimizer` is given -- optimizer.step() + optimizer.zero_grad().  scheduler.step() stays with the caller.
 
-        Where it can (MAG-BERT, single process, the driver's two parameter groups on this model's flat buffer) the whole
-        iteration is ONE engine call, mb_bert_train_step: a step prologue that gathers the batch (straight from pinned host
-        memory if that is where it is) and puts this step's dropout keys / lr / bias correction into device memory, then every
-        kernel of the step as ONE replayed hipGraph (the step is a single-stream kernel sequence: replay costs ~12 us of host
-        time and runs as fast as the stream launches).  graph="launches" (or MB_STEP_GRAPH=0) keeps the single call but launches
-        the kernels one by one.  Otherwise (MAG-XLNet, data parallel, foreign optimizers) the passes are driven from here:
-        training_step + optimizer.step(); graph=False forces that path, graph=True raises if the single call is unavailable.
+        Where it can (either model, the driver's two parameter groups on this model's flat buffer) the whole iteration is ONE
+        engine call, mb_*_train_step: a step prologue that gathers the batch (straight from pinned host memory if that is where
+        it is) and puts this step's dropout keys / lr / bias correction into device memory, then every kernel of the step as ONE
+        replayed hipGraph (the step is a single-stream kernel sequence: replay costs ~12 us of host time and runs as fast as the
+        stream launches).  Under data parallel (optimizer._dp set by distributed.DataParallel) the same call becomes
+        mb_*_train_step_dp: a chain of linear graphs with the gradient exchange issued from C between them (distributed.Comm).
+        graph="launches" (or MB_STEP_GRAPH=0) keeps the single call but launches the kernels one by one.  Otherwise (foreign
+        optimizers, gradient accumulation under data parallel, MB_DP_ENGINE=0) the passes are driven from here: training_step +
+        optimizer.step(); graph=False forces that path, graph=True raises if the single call is unavailable.
         Pass optimizer=None on gradient-accumulation micro-steps.  Returns the device loss scalar."""
         core = self._core
         dp = getattr(optimizer, "_dp", None) if optimizer is not None else None
