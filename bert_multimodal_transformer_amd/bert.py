@@ -264,6 +264,15 @@ class _Core(object):
         B, L = input_ids.shape
         dev = self.device
         lab_in = None if labels is None else labels.reshape(-1)
+        nl = int(self.config.num_labels)
+        if lab_in is not None and lab_in.numel() != B * (1 if nl > 1 else nl):
+            raise ValueError("labels: expected %d values for a batch of %d, got %d" % (B, B, lab_in.numel()))
+        if lab_in is not None and nl > 1:
+            # fused cross entropy (head.hip): class indices travel as fp32; what torch's CrossEntropyLoss would reject or treat
+            # specially must not silently become class 0 (ignore_index = -100 is not built)
+            lf = lab_in.detach().float()
+            if bool(((lf != lf.round()) | (lf < 0) | (lf >= nl)).any()):
+                raise ValueError("labels of the fused cross entropy must be class indices in [0, %d) (ignore_index is not supported)" % nl)
         six = (input_ids, visual, acoustic, attention_mask, token_type_ids, lab_in)
         if self._pinned_batch(six, B, L):
             ptrs = [None if t is None else C.c_void_p(t.data_ptr()) for t in six]

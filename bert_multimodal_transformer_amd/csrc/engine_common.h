@@ -145,7 +145,8 @@ inline int wgrad(int dtype, int Mo, int No, int rows, const void* dY, int ldy, c
 struct StepGraph {
     int B, L, with_opt, overwrite; const void *logits, *loss, *loss_run, *m, *v; float loss_scale; hipStream_t st;
     int nseg;                                       // the step as `nseg` linear graphs launched back to back (1 = the whole step)
-    int variant;                                    // which segmentation (0 = the single-process step, 1 = the data-parallel step)
+    int variant;                                    // which segmentation (0 = the single-process step, else a hash of the data-parallel plan)
+    const void* tag;                                // whose events the graphs' nodes record (the mb_comm of a data-parallel step), else null
     std::vector<hipGraph_t> graph; std::vector<hipGraphExec_t> exec;
     void destroy() {
         for (auto x : exec) if (x) hipGraphExecDestroy(x);
@@ -343,7 +344,8 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
                            const void* seg, const void* labels, int B, int L, uint64_t seed, uint64_t step, float* logits, float* loss,
                            float* loss_run, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay,
                            int opt_step, int correct_bias, float grad_scale, float loss_scale, int mode, bool force_launches,
-                           hipStream_t st, Enqueue enqueue_inner, int nseg = 1, Between between = Between(), int variant = 0) {
+                           hipStream_t st, Enqueue enqueue_inner, int nseg = 1, Between between = Between(), int variant = 0,
+                           const void* tag = nullptr) {
     // The step may be cut into `nseg` segments: enqueue_inner(seg, ...) issues the kernels of one (captured and replayed as its own
     // LINEAR graph), between(seg, st) runs on the host right after segment `seg` was enqueued and is never captured -- the place for
     // cross-stream events (a graph with a fork inside runs on ROCm 7.2's slow path; a chain of linear graphs does not).
@@ -397,13 +399,13 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
     StepGraph* g = nullptr;
     for (auto& x : e->graphs)
         if (x.B == B && x.L == L && x.with_opt == (m != nullptr) && x.overwrite == ow && x.logits == logits && x.loss == loss && x.loss_run == loss_run &&
-            x.m == m && x.v == v && x.loss_scale == loss_scale && x.st == st && x.nseg == nseg && x.variant == variant) { g = &x; break; }
+            x.m == m && x.v == v && x.loss_scale == loss_scale && x.st == st && x.nseg == nseg && x.variant == variant && x.tag == tag) { g = &x; break; }
     if (!g) {
         if (e->graphs.size() >= 32) {          // callers that keep changing output pointers: do not grow without bound
             e->graphs.front().destroy();
             e->graphs.erase(e->graphs.begin());
         }
-        StepGraph ng = {B, L, m != nullptr, ow, logits, loss, loss_run, m, v, loss_scale, st, nseg, variant, {}, {}};
+        StepGraph ng = {B, L, m != nullptr, ow, logits, loss, loss_run, m, v, loss_scale, st, nseg, variant, tag, {}, {}};
         hipStream_t cs = nullptr;
         CK(e->capture_stream(&cs));
         for (int sg = 0; sg < nseg; ++sg) {

@@ -186,6 +186,10 @@ def test_fused_cross_entropy_step_num_labels_3(kind):
     torch.cuda.synchronize()
     assert abs(float(l_graph) - float(lo)) <= 2e-5 * max(1.0, abs(float(lo)))
     assert float((m.flat_grads - g_fused).abs().max()) <= 1e-5 * float(g_fused.abs().max()) + 1e-9
+    # labels torch's CrossEntropyLoss would reject (or ignore: -100) must not silently become class 0 in the fused head
+    for bad in (torch.tensor([0, 3, 1, 1, 0, 2]), torch.tensor([0, -100, 1, 1, 0, 2]), torch.tensor([0.5, 1, 1, 1, 0, 2]), torch.tensor([0, 1, 2])):
+        with pytest.raises(ValueError):
+            m.training_step(ids, vis, aco, mask, seg, bad.to(DEV))
 
 
 class _Replay(torch.nn.Module):
