@@ -182,6 +182,8 @@ int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const f
 int gather_drop_forward(int dtype, const int64_t* ids, const float* word, void* out, int rows, int H, DropKey drop, hipStream_t st);
 int gather_drop_backward(int dtype, const void* dout, const int64_t* ids, float* dword, int rows, int H, DropKey drop, hipStream_t st, GradAcc acc = {});
 // (both: ids == nullptr = inputs_embeds -- `word` / `dword` are then [rows][H] fp32, read / written row by row)
+// dst[i] += src[i], fp32, n % 4 == 0
+int add_f32(float* dst, const float* src, size_t n, hipStream_t st);
 // y = x * dropout mask over [rows][H] (element index = offset)
 int drop_rows(int dtype, const void* x, void* y, int rows, int H, DropKey drop, hipStream_t st);
 // pos[b][p][:] = dropout([sin(pos_p * inv_freq) | cos(...)]) with pos_p = L - p, p in [0, 2L)   (xlnet.py:93-146,332-333)

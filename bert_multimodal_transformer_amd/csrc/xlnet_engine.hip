@@ -33,6 +33,8 @@ struct mb_xlnet_engine : StepMixin {
     std::vector<XlLayerWs> lw;
     size_t ws_dsa[2], ws_dzda[2], ws_dsb[2], ws_dzdb[2], ws_du[2], ws_dqkv[2], ws_dkr[2];   // dY operands of the weight gradients: ping-pong by layer parity
     size_t ws_dxa, ws_dxb, ws_dvec, ws_gsave, ws_dz, ws_dxs, ws_lnp_a, ws_lnp_b;
+    size_t ws_rhalf = 0;           // fp32 [H][H]: the second k-half of a layer's relative-position weight gradient (see mb_xlnet_backward)
+    int split_r = 1;               // MB_XL_SPLIT_R=0: the r problem of the grouped launch keeps its whole K = 2 x tokens (round-3 form)
     size_t lnp_stride = 0;         // floats per layer in each of the two LayerNorm partial buffers
     int mag_nblk = 0;              // slabs MAG's gate backward wrote into slot n_layer
     int prefetch = 1;              // MB_PREFETCH=0: the LayerNorm kernels do not touch the next GEMMs' weights (common.h Prefetch)
@@ -167,6 +169,7 @@ static void xl_build_layout(mb_xlnet_engine* e) {
     e->ws_dvec = w.take(T * H * es); e->ws_gsave = w.take(PP * es);
     e->ws_demb = w.take(T * H * 4);
     e->ws_dz = w.take((size_t)c.max_batch * H * es); e->ws_dxs = w.take((size_t)c.max_batch * H * es);
+    e->ws_rhalf = w.take((size_t)H * H * 4);
     e->lnp_stride = ln_partials_floats((int)T, (int)H);        // per-layer slabs: the single-call step reduces all layers at once
     e->ws_lnp_a = w.take(e->lnp_stride * 4 * (c.n_layer + 1)); e->ws_lnp_b = w.take(e->lnp_stride * 4 * (c.n_layer + 1));      // (+1: MAG's gate)
     e->carve_step(w, T, (int)V, (int)A, c.max_batch, c.num_labels, XS_LAYER0 + 8 * c.n_layer);
@@ -223,6 +226,7 @@ int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out) {
     if (const char* v = getenv("MB_DETERMINISTIC")) e->deterministic = atoi(v);
     xl_build_layout(e);
     if (const char* v = getenv("MB_XL_FUSE_QKV")) e->fuse_qkv = atoi(v) != 0;
+    if (const char* v = getenv("MB_XL_SPLIT_R")) e->split_r = atoi(v) != 0;
     if (const char* pv = getenv("MB_PREFETCH")) e->prefetch = atoi(pv);
     if (e->lo[0].k - e->lo[0].q != (size_t)cfg->d_model * cfg->d_model || e->lo[0].v - e->lo[0].k != e->lo[0].k - e->lo[0].q) e->fuse_qkv = false;
     if (const char* v = getenv("MB_ADAMW_KEEP")) e->keep_enable = atoi(v);
@@ -399,16 +403,26 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                                     Prefetch{e->prefetch ? e->W(o.w1) : nullptr, (size_t)2 * I * H * (dt == DT_BF16 ? 2 : 4), nullptr}));
             // the layer's seven weight gradients go out as ONE grouped launch once every dY exists (MB_GROUP_WGRAD=0: one by one)
             char* dqkv = ws + e->ws_dqkv[par];
-            GemmArgs wg[7] = {wgrad_args(H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I),
+            // The relative-position problem d r = pos^T dkr reduces over B * 2L rows -- twice the K of the other six -- so in a launch
+            // that is ONE round of tiles its 36 tiles ran 1.6 x as long as everybody else's and set the kernel's duration (71 us against
+            // 48 us for MAG-BERT's group with 16 % less work).  Its K range is cut in two: the second half is an eighth problem that
+            // STORES into a scratch [H][H], added to the gradient by a 3 us launch behind the group (MB_XL_SPLIT_R=0: one problem).
+            const int Rk1 = (e->split_r && Rk >= 256) ? (int)align_up((size_t)Rk / 2, 64) : Rk;
+            GemmArgs wg[8] = {wgrad_args(H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I),
                               wgrad_args(I, H, Tk, du, I, ws + w.y1, H, G + o.w1, H),
                               wgrad_args(H, H, Tk, dzdB, H, ws + w.vec, H, G + o.o, H),                 // d o[h][nd] = dzd^T vec
-                              wgrad_args(H, H, Rk, ws + e->ws_pos, H, dkr, H, G + o.r, H),   // d r = pos^T dkr
+                              wgrad_args(H, H, Rk1, ws + e->ws_pos, H, dkr, H, G + o.r, H),   // d r = pos^T dkr, rows [0, Rk1)
                               wgrad_args(H, H, Tk, xin, H, dqkv, 3 * H, G + o.q, H),
                               wgrad_args(H, H, Tk, xin, H, dqkv + (size_t)H * es, 3 * H, G + o.k, H),
-                              wgrad_args(H, H, Tk, xin, H, dqkv + (size_t)2 * H * es, 3 * H, G + o.v, H)};
-            const bool grouped = e->group_wgrad > 0 && gemm_grouped_tn_ok(dt, wg, 7, e->group_wgrad);
-            if (grouped)
+                              wgrad_args(H, H, Tk, xin, H, dqkv + (size_t)2 * H * es, 3 * H, G + o.v, H),
+                              wgrad_args(H, H, Rk - Rk1, ws + e->ws_pos + (size_t)Rk1 * H * es, H, dkr + (size_t)Rk1 * H * es, H,
+                                         (float*)(ws + e->ws_rhalf), H)};                       // ... rows [Rk1, Rk) -> scratch
+            const int nwg = Rk1 < Rk ? 8 : 7;
+            const bool grouped = e->group_wgrad > 0 && gemm_grouped_tn_ok(dt, wg, nwg, e->group_wgrad);
+            if (grouped) {
                 for (GemmArgs& a : wg) a.overwrite = e->ow_pass ? 1 : 0;
+                wg[7].overwrite = 1;
+            }
             if (!grouped) CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, st));
             CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, du, I, nullptr, G + o.b1, nullptr, ws + w.u, I,
                     e->key(XS_LAYER0 + 8 * l + 2, pd), 1, 0, st, 0, 0, acc));
@@ -452,14 +466,16 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                 }
                 CK((int)hipEventRecord(e->evs[2 * l], st));                       // every dY of the layer is final on `st`
                 CK((int)hipStreamWaitEvent(e->side, e->evs[2 * l], 0));
-                CK(gemm_grouped_tn_launch(dt, wg, 7, e->group_wgrad, e->side));
+                CK(gemm_grouped_tn_launch(dt, wg, nwg, e->group_wgrad, e->side));
+                if (nwg == 8) CK(add_f32(G + o.r, (const float*)(ws + e->ws_rhalf), (size_t)H * H, e->side));
                 CK((int)hipEventRecord(e->evs[2 * l + 1], e->side));              // "weight gradients of layer l are final"
             } else if (grouped) {
                 CK(e->prof_mark(2 * l, st));
-                CK(gemm_grouped_tn_launch(dt, wg, 7, e->group_wgrad, st));
+                CK(gemm_grouped_tn_launch(dt, wg, nwg, e->group_wgrad, st));
                 CK(e->prof_mark(2 * l + 1, st));
+                if (nwg == 8) CK(add_f32(G + o.r, (const float*)(ws + e->ws_rhalf), (size_t)H * H, st));
             } else {
-                CK(wgrad(dt, H, H, Rk, ws + e->ws_pos, H, dkr, H, G + o.r, H, st));
+                CK(wgrad(dt, H, H, Rk, ws + e->ws_pos, H, dkr, H, G + o.r, H, st));        // (one by one: the whole K range, no scratch)
                 CK(wgrad(dt, H, H, Tk, xin, H, dqkv, 3 * H, G + o.q, H, st));
                 CK(wgrad(dt, H, H, Tk, xin, H, dqkv + (size_t)H * es, 3 * H, G + o.k, H, st));
                 CK(wgrad(dt, H, H, Tk, xin, H, dqkv + (size_t)2 * H * es, 3 * H, G + o.v, H, st));

@@ -123,6 +123,20 @@ int gather_drop_backward(int dtype, const void* dout, const int64_t* ids, float*
     MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((gather_drop_bwd_kernel<T, RC>), dim3((rows + RC - 1) / RC, (H + 255) / 256), dim3(256), 0, st, (const T*)dout, ids, dword, rows, H, drop, acc); })
     return (int)hipGetLastError();
 }
+// dst[i] += src[i] (fp32, n % 4 == 0): the second k-half of the relative-position weight gradient joins the first (xlnet_engine.hip)
+__global__ void __launch_bounds__(256) add_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 a = ((const f32x4*)dst)[i];
+        a += ((const f32x4*)src)[i];
+        ((f32x4*)dst)[i] = a;
+    }
+}
+int add_f32(float* dst, const float* src, size_t n, hipStream_t st) {
+    if (n == 0) return MB_OK;
+    if ((n & 3) || (((uintptr_t)dst | (uintptr_t)src) & 15)) return MB_ERR_SHAPE;
+    hipLaunchKernelGGL(add_f32_kernel, dim3((unsigned)std::min<size_t>((n / 4 + 255) / 256, 1024)), dim3(256), 0, st, dst, src, n / 4);
+    return (int)hipGetLastError();
+}
 int drop_rows(int dtype, const void* x, void* y, int rows, int H, DropKey drop, hipStream_t st) {
     if (rows <= 0) return MB_OK;
     if (H % 4) return MB_ERR_SHAPE;
