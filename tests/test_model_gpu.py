@@ -745,6 +745,40 @@ def test_optimizer_chunks_on_a_side_stream_change_nothing(monkeypatch):
     assert torch.equal(acc["p"], acc_ref["p"]) and torch.equal(acc["shadow"], acc_ref["shadow"])
 
 
+def test_stale_gradients_survive_a_recreated_engine():
+    """A fused step leaves the layers' GEMM weight gradients "logically zero, physically stale" -- a fact the C engine holds.  A
+    larger batch afterwards re-creates the engine (dev_batch_size 128 after train batches of 48 in the driver): the stale range
+    must have become real zeros first, or a backward that ACCUMULATES (here: the autograd path after a hand-written gradient, which
+    withdraws the known-zero promise) adds onto garbage.  Compared with the same sequence after an explicit zeroing of the buffer."""
+    from bert_multimodal_transformer_amd.multimodal_driver import optimizer_grouped_parameters
+
+    def run(explicit_zero):
+        torch.manual_seed(5)
+        m = build(layers=2, cdt=torch.float32, p_mag=0.0, hidden_p=0.0, attn_p=0.0).train()
+        opt = AdamW(optimizer_grouped_parameters(m), lr=1e-3)
+        small = tb(weights.synthetic_bert_batch(4, 32, 47, 74, seed=810), DEV)
+        big = tb(weights.synthetic_bert_batch(9, 40, 47, 74, seed=811), DEV)
+        w = dict(m.named_parameters())["bert.encoder.layer.0.output.dense.weight"]
+        with m.stream_scope():
+            m.train_step(*small, optimizer=opt)                          # fused: the encoder's weight gradients are stale now
+            assert m._core._fn("grads_stale")(m._core.handle) == 1 and float(w.grad.abs().max()) > 0.0
+            if explicit_zero:
+                m._core.grads.zero_()
+                m._core.mark_grads_zero(True)
+            b = dict(m.named_parameters())["classifier.bias"]
+            b.grad.add_(0.25)                                            # a torch-side write: this backward must accumulate
+            ids, vis, aco, mask, seg, lab = big
+            logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0]          # larger batch AND longer sequence: new engine
+            torch.nn.functional.mse_loss(logits.view(-1), lab.view(-1)).backward()
+            torch.cuda.synchronize()
+        return m.flat_grads.clone()
+
+    g_lazy, g_zeroed = run(False), run(True)
+    err = float((g_lazy - g_zeroed).abs().max()) / float(g_zeroed.abs().max())
+    print("gradients after an engine re-creation on top of a stale buffer vs on top of real zeros: max |d| / max = %.2e" % err)
+    assert err <= 1e-5
+
+
 def test_known_zero_gradients_are_stored_not_accumulated(monkeypatch):
     """After a step that ran the fused AdamW (which zeroes the gradients) the next backward STORES the layer weight gradients
     instead of adding to them.  Storing into zeros and adding to zeros are the same fp32 numbers, so a model with
