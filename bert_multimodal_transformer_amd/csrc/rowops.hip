@@ -71,7 +71,13 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
     prefetch_retire<4>(pf, pfv);
 }
 
-constexpr int LN_RPW = 2;     // rows per wave in the partial-sum variants (8 rows per block -> 300 blocks at T = 2400)
+#ifndef MB_LN_RPW
+#define MB_LN_RPW 2
+#endif
+#ifndef MB_LN_NWV
+#define MB_LN_NWV 8
+#endif
+constexpr int LN_RPW = MB_LN_RPW;     // rows per wave in the partial-sum variants (-DMB_LN_RPW / -DMB_LN_NWV: A/B builds)
 
 // shared tail of the backward kernels: reduce per-lane column partials over the block's 4 waves, then atomics.
 template <int CH, int NQ>
@@ -103,7 +109,8 @@ __global__ void __launch_bounds__(NWV * 64) ln_bwd_kernel(const T* __restrict__ 
     drop_in.resolve();
     constexpr int H = CH * 256;
     constexpr float invH = 1.0f / H;
-    __shared__ float lds[NWV * 3 * H];
+    constexpr int SL = NWV > 8 ? 8 : NWV;              // LDS slots of the block-level column sums (more waves fold in pairs first)
+    __shared__ float lds[SL * 3 * H];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 part[3][CH];
 #pragma unroll
@@ -154,18 +161,36 @@ __global__ void __launch_bounds__(NWV * 64) ln_bwd_kernel(const T* __restrict__ 
     u32x4 pfv[8];
     prefetch_issue<8>(pf, gamma, pfv);       // behind the last of the kernel's own loads; runs under the column-sum epilogue
     if constexpr (PARTIAL) {
-        // dgamma points at partials[nblk][3][H]: this block's slab gets the 4-wave sums, no atomics
+        // dgamma points at partials[nblk][3][H]: this block's slab gets the sums over its waves, no atomics
+        if constexpr (NWV > SL) {           // waves SL .. NWV-1 hand their sums to waves 0 .. SL-1 first
+            if (wave >= SL) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+                for (int q = 0; q < 3; ++q)
 #pragma unroll
-            for (int c = 0; c < CH; ++c) *(f32x4*)(lds + (wave * 3 + q) * H + (c * 64 + lane) * 4) = part[q][c];
+                    for (int c = 0; c < CH; ++c) *(f32x4*)(lds + ((wave - SL) * 3 + q) * H + (c * 64 + lane) * 4) = part[q][c];
+            }
+            __syncthreads();
+            if (wave < SL) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) part[q][c] += *(const f32x4*)(lds + (wave * 3 + q) * H + (c * 64 + lane) * 4);
+            }
+            __syncthreads();
+        }
+        if (wave < SL) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) *(f32x4*)(lds + (wave * 3 + q) * H + (c * 64 + lane) * 4) = part[q][c];
+        }
         __syncthreads();
         float* slab = dgamma + (size_t)blockIdx.x * 3 * H;
         for (int i = threadIdx.x; i < 3 * H; i += NWV * 64) {
             const int q = i / H, col = i % H;
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < NWV; ++w) t += lds[(w * 3 + q) * H + col];
+            for (int w = 0; w < SL; ++w) t += lds[(w * 3 + q) * H + col];
             slab[i] = t;
         }
     } else {
@@ -559,7 +584,7 @@ size_t ln_partials_floats(int rows, int H) { return (size_t)((rows + 4 * LN_RPW 
 
 // rows per block of the partial-sum LayerNorm backward: 8 waves x LN_RPW rows (half the slabs of a 4-wave block -- the reduction
 // launch reads them all -- at the same number of waves in flight)
-constexpr int LN_NWV = 8;
+constexpr int LN_NWV = MB_LN_NWV;
 int ln_backward_partials(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                          void* dx, void* dx_drop, float* partials, int* nblk, int rows, int H, DropKey drop_in,
                          hipStream_t st, Prefetch pf) {
