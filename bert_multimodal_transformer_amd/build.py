@@ -11,7 +11,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmagbert_hip.so")
 SOURCES = ["gemm.hip", "rowops.hip", "mag.hip", "attention.hip", "xlnet_attention.hip", "xlnet_rowops.hip", "head.hip", "adamw.hip",
            "engine.hip", "xlnet_engine.hip", "comm.hip"]
-HEADERS = ["common.h", "kernels.h", "attn_common.h", "engine_common.h", "comm.h", os.path.join("..", "..", "include", "magbert_hip.h")]
+HEADERS = ["common.h", "kernels.h", "attn_common.h", "engine_common.h", "comm.h", "mag_pack.h", os.path.join("..", "..", "include", "magbert_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fvisibility=default",
          "-Wno-unused-result"]
 

@@ -124,23 +124,29 @@ __device__ __forceinline__ float row16_sum_to_lane15(float v) {
 // blocks touches its slice of the NEXT launches' weights (K 16-byte loads per thread, issued behind the kernel's own first loads,
 // retired at its end), which leaves the lines in the memory-side cache for every XCD.  `sink` is never written (null): it only
 // keeps the loads alive.
-struct Prefetch { const void* p; size_t bytes; uint32_t* sink; };
+// A second region (p2 / bytes2) takes the loads the first one leaves over, ONE load per `stride2` bytes: a touch is enough to bring the
+// whole line into the memory-side cache, and the consumer of that region (the attention backward: q | k | v and the context rows a
+// layer saved ~2 ms earlier) only needs them out of HBM, not in any particular L2.
+struct Prefetch { const void* p; size_t bytes; uint32_t* sink; const void* p2 = nullptr; size_t bytes2 = 0; uint32_t stride2 = 64; };
 // `fallback`: 1 KB of readable memory (what a launch without a prefetch region loads instead: K cache hits per thread).  The loads are
-// unconditional -- offsets past the region wrap into its first 1 KB (spread cache hits; clamping them all to one line made a
+// unconditional -- offsets past the region(s) wrap into the first 1 KB (spread cache hits; clamping them all to one line made a
 // hot spot) -- because a load inside divergent control flow makes the compiler wait for it at the join.
 template <int K>
 __device__ __forceinline__ void prefetch_issue(const Prefetch& pf, const void* fallback, u32x4 (&v)[K]) {
     const char* base = pf.p != nullptr ? (const char*)pf.p : (const char*)fallback;
     const bool real = pf.p != nullptr && pf.bytes >= 1024;      // (a smaller region could not take the wrapped offsets below)
-    const size_t last = (real ? pf.bytes : (size_t)16) - 16;
-    const size_t wrap = real ? ~(size_t)0 : (size_t)1008;     // no region: spread over 1 KB of `fallback` (not 76,800 threads on one line)
+    const size_t n1 = real ? pf.bytes / 16 : (size_t)0;         // loads the first region takes
+    const bool two = pf.p2 != nullptr && pf.bytes2 >= 16;
+    const size_t n2 = two ? (pf.bytes2 - 16) / pf.stride2 + 1 : (size_t)0;
     const size_t nthr = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     __builtin_amdgcn_sched_barrier(0);           // every load the kernel issued so far stays in front of these ...
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        size_t off = ((size_t)k * nthr + tid) * 16;
-        off = real ? (off <= last ? off : (off & (size_t)1008)) : (off & wrap);     // past the region: spread over its first 1 KB (cache hits)
-        v[k] = *(const u32x4*)(base + off);
+        const size_t j = (size_t)k * nthr + tid;
+        const char* src = base + ((j * 16) & (size_t)1008);     // past the region(s): spread over the first 1 KB (cache hits)
+        if (j < n1) src = base + j * 16;
+        else if (j - n1 < n2) src = (const char*)pf.p2 + (j - n1) * pf.stride2;
+        v[k] = *(const u32x4*)src;
     }
     __builtin_amdgcn_sched_barrier(0);           // ... and nothing that follows is scheduled in between
 }

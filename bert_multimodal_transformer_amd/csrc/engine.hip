@@ -54,6 +54,7 @@ struct mb_bert_engine : StepMixin {
     int prefetch = 1;              // MB_PREFETCH=0: the LayerNorm kernels do not touch the next GEMMs' weights (common.h Prefetch).  Touching
                                    // ACTIVATIONS the same way (GELU output for the weight gradient, saved q | k | v for the attention backward)
                                    // was measured +9 / +15 us per step and is not in the code (profiles/r03_prefetch_ab2.txt)
+    int pf_qkv = 0;                // MB_PF_QKV=64|128: ln_bwd(LN1)'s left-over prefetch loads touch the saved q | k | v | context rows, one per 64 / 128 bytes
     hipStream_t opt_side = nullptr;
     std::vector<hipEvent_t> opt_ev;
     int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128), 0 = four launches
@@ -149,6 +150,8 @@ static void build_layout(mb_bert_engine* e) {
         const char* pv = getenv("MB_PROLOGUE_PACK");
         e->pk_enable = !(pv && atoi(pv) == 0);
         e->pk_vis = e->ws_mag + e->mw.vp; e->pk_aco = e->ws_mag + e->mw.ap; e->pk_Vp = e->mw.Vp; e->pk_Ap = e->mw.Ap; e->pk_dtype = c.dtype;
+        const char* pw = getenv("MB_PROLOGUE_PACKW");
+        e->pkw_enable = !(pw && atoi(pw) == 0);
     }
     e->ws_emb = w.take(T * H * es);
     e->ws_emb_st = w.take(2 * T * 4);
@@ -384,6 +387,7 @@ int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
     if (const char* v = getenv("MB_DETERMINISTIC")) e->deterministic = atoi(v);
     if (const char* v = getenv("MB_ADAMW_OVERLAP")) e->opt_chunk = atoi(v);
     if (const char* v = getenv("MB_PREFETCH")) e->prefetch = atoi(v);
+    if (const char* v = getenv("MB_PF_QKV")) e->pf_qkv = atoi(v);
     e->grouped = (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->hidden_size % e->group_wgrad == 0 &&
                  cfg->intermediate_size % e->group_wgrad == 0;
     e->deferred = e->overlap_wgrad && e->grouped;
@@ -430,6 +434,9 @@ int mb_bert_bind(mb_bert_engine* e, float* params, float* grads, void* shadow, v
     e->grads_zero = false;                 // a newly bound gradient buffer: nothing is known about its contents
     e->ws_zeroed = false; e->padT = -1;
     e->drop_graphs();                         // captured against the old buffers
+    char* mws = e->ws + e->ws_mag;
+    e->pkw = {e->P + e->mag_whv, e->P + e->mag_wha, e->P + e->mag_wv, e->P + e->mag_wa, mws + e->mw.We, mws + e->mw.Wv, mws + e->mw.Wa,
+              MagDims{0, e->c.hidden_size, e->c.visual_dim, e->c.acoustic_dim, e->mw.Vp, e->mw.Ap}, e->c.dtype};
     return MB_OK;
 }
 
@@ -465,11 +472,12 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     CK(embed_ln_forward(dt, input_ids, token_type_ids, e->emb_in ? e->emb_in : P + e->word, P + e->pos, P + e->type, P + e->emb_lnw, P + e->emb_lnb,
                         c.layer_norm_eps, ws + e->ws_emb, (float*)(ws + e->ws_emb_st), (float*)(ws + e->ws_emb_st) + T, B, L,
                         H, e->key(SITE_EMB, c.hidden_dropout), st, e->pos_ids));
-    // MAG (bert.py:219): packed weights are refreshed every pass (5.5 MB, one launch) so optimizer steps are seen
+    // MAG (bert.py:219): packed weights are refreshed every pass (5.5 MB) so optimizer steps are seen -- by a launch here, or, in the
+    // single-call step, by extra blocks of the step prologue
     CK(mag_fwd_impl(dt, ws + e->ws_emb, visual, acoustic, P + e->mag_whv, P + e->mag_bhv, P + e->mag_wha, P + e->mag_bha,
                     P + e->mag_wv, P + e->mag_bv, P + e->mag_wa, P + e->mag_ba, P + e->mag_lnw, P + e->mag_lnb,
                     c.mag_layer_norm_eps, c.beta_shift, e->key(SITE_MAG, c.mag_dropout), ws + e->ws_x[0], ws + e->ws_mag,
-                    e->mw, T, H, c.visual_dim, c.acoustic_dim, true, st, true, e->in_step && e->packed));
+                    e->mw, T, H, c.visual_dim, c.acoustic_dim, !(e->in_step && e->packed_w), st, true, e->in_step && e->packed));
     // encoder (bert.py:221-229)
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerOff& o = e->lo[l];
@@ -596,10 +604,18 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, I, du, I, e->W(o.w1), H, dy1, H, nullptr, nullptr, nullptr, dsA,
                     H, kNoDrop, 1, 0, st));
             // LN1 + dropout backward
+            Prefetch pf_attn = {e->prefetch ? e->W(o.wqkv) : nullptr, (size_t)4 * H * H * (dt == DT_BF16 ? 2 : 4), nullptr};
+            if (e->prefetch && e->pf_qkv > 0) {
+                const size_t es = dt == DT_BF16 ? 2 : 4, qb = (size_t)T * 3 * H * es;
+                pf_attn.p2 = ws + w.qkv;
+                pf_attn.bytes2 = (w.ctx - w.qkv) - qb <= 4096 ? (w.ctx - w.qkv) + (size_t)T * H * es : qb;      // context rows follow unless T < max
+                pf_attn.stride2 = (uint32_t)e->pf_qkv;
+            }
             CK(ln_backward_partials(dt, dy1, ws + w.s1, P + o.ln1w, (const float*)(ws + w.st1), (const float*)(ws + w.st1) + T, dsB,
                                     hd ? dzdB : nullptr, lnp_b, &nblk, T, H, e->key(SITE_LAYER0 + 4 * l + 1, c.hidden_dropout), st,
-                                    // ... Wqkv | Wo for the attention-side dgrads
-                                    Prefetch{e->prefetch ? e->W(o.wqkv) : nullptr, (size_t)4 * H * H * (dt == DT_BF16 ? 2 : 4), nullptr}));
+                                    // ... Wqkv | Wo for the attention-side dgrads, and with the loads that leaves over the q | k | v (+ context)
+                                    // rows this layer saved in the forward, which the attention backward two launches on finds in HBM
+                                    pf_attn));
             if (!grouped) {
             CK(fork(2));
             CK(wgrad(dt, H, H, Tk, dzdB, H, ws + w.ctx, H, G + o.wo, H, ss));
@@ -658,7 +674,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                             P + e->mag_lnw, c.beta_shift, e->key(SITE_MAG, c.mag_dropout), ws + e->ws_mag, e->mw, de, nullptr,
                             nullptr, G + e->mag_whv, G + e->mag_bhv, G + e->mag_wha, G + e->mag_bha, G + e->mag_wv,
                             G + e->mag_bv, G + e->mag_wa, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb, T, H, c.visual_dim,
-                            c.acoustic_dim, true, st, acc, true, mpa, mpb, &mblk));
+                            c.acoustic_dim, true, st, acc, true, mpa, mpb, &mblk, e->ow_pass));
             int eblk = 0;
             CK(embed_ln_backward(dt, de, e->ids, e->seg, e->ids ? P + e->word : e->emb_in, P + e->pos, P + e->type, P + e->emb_lnw,
                                  (const float*)(ws + e->ws_emb_st), (const float*)(ws + e->ws_emb_st) + T,

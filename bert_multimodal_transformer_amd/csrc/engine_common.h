@@ -67,6 +67,13 @@ inline int mag_wgrad_tile() {
     return t;
 }
 
+// ring depth of MAG's grouped weight-gradient launch (64 x 64 tiles only): MB_MAG_WGRAD_STAGES = 2 | 3 | 4 | 5
+inline int mag_wgrad_stages() {
+    static int t = -1;
+    if (t < 0) { const char* v = getenv("MB_MAG_WGRAD_STAGES"); t = v ? atoi(v) : 4; }
+    return t;
+}
+
 struct MagWs {
     int Vp, Ap;
     size_t We, Wv, Wa, vp, ap, Ze, Zv, Za, mean, rstd;                       // forward (saved)
@@ -165,6 +172,10 @@ struct StepMixin {
     // single-call step: the step prologue converts the two modality tensors straight into MAG's packed GEMM operands (set by the
     // engines: workspace offsets of the operands); `packed` tells mag_fwd_impl of the step that the pack_pad launches already happened
     bool pk_enable = false, packed = false;
+    // ... and MAG's weight operands too (PrologueArgs::MagPackW, extra blocks of the same launch; the engines fill `pkw` when buffers are
+    // bound): the first kernel of every replayed step used to be that pack.  MB_PROLOGUE_PACKW=0: back in the graph
+    bool pkw_enable = false, packed_w = false;
+    PrologueArgs::MagPackW pkw = {};
     size_t pk_vis = 0, pk_aco = 0; int pk_Vp = 0, pk_Ap = 0, pk_dtype = 0;
     // single-call step: the prologue counts the occurrences of every token id (workspace offset of the table, 0 = none); `counted`
     // tells the engine's backward that the table describes the batch of this step
@@ -357,7 +368,7 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
     struct Flags {
         E* e; bool ok, with_opt, stale_before;
         ~Flags() {
-            e->in_step = false; e->loss_cleared = false; e->packed = false; e->counted = false;
+            e->in_step = false; e->loss_cleared = false; e->packed = false; e->packed_w = false; e->counted = false;
             e->grads_zero = ok && with_opt;
             e->grads_stale = ok ? (with_opt && e->keep_in_step()) : stale_before;
         }
@@ -369,6 +380,8 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
     PrologueArgs pa = {};
     e->fill_copies(pa, ws, ids, vis, aco, mask, seg, labels, B, L, V, A, num_labels, e->pk_enable);
     e->packed = e->pk_enable;
+    if (e->pkw_enable && e->pkw.W_hv) pa.magw = e->pkw;
+    e->packed_w = pa.magw.W_hv != nullptr;
     pa.seed = seed; pa.step = step; pa.keys = e->key_state(ws); pa.nsites = e->nsites;
     pa.zero_dw = (uint32_t*)loss; e->loss_cleared = loss != nullptr;
     if (e->idcnt_enable && ids) { pa.ids = (const int64_t*)ids; pa.n_ids = B * L; pa.id_count = (int*)(ws + e->idcnt_off); }
@@ -485,18 +498,41 @@ inline int mag_bwd_impl(int dtype, const void* d_out, const void* text, const fl
                  float* d_visual, float* d_acoustic, float* dW_hv, float* db_hv, float* dW_ha, float* db_ha, float* dW_v,
                  float* db_v, float* dW_a, float* db_a, float* dln_w, float* dln_b, int T, int H, int V, int A,
                  bool text_padded, hipStream_t st, GradAcc acc = {}, bool pads_clean = false, float* part_a = nullptr,
-                 float* part_b = nullptr, int* part_nblk = nullptr) {
+                 float* part_b = nullptr, int* part_nblk = nullptr, bool dw_zero = false) {
+    // dw_zero: the caller knows the four weight-gradient tensors hold zeros (the engines' store path): plain stores, no read-modify-write
     MagDims d = {T, H, V, A, w.Vp, w.Ap};
     const int Tp = (int)align_up((size_t)T, 64);      // zero-padded token rows of the workspace operands
     const size_t es = esize(dtype);
-    // the three packed weight gradients as ONE grouped launch (like a layer's four): alone, the two modality problems are
-    // 24 / 48 tiles whose duration is the K = T loop latency (three launches of ~34 us each).  The grouped launch STORES its
-    // tiles (no split-K), so the packed accumulators need no clearing.
-    GemmArgs wg[3] = {wgrad_args(2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H),
-                      wgrad_args(2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp),
-                      wgrad_args(2 * H, w.Ap, Tp, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap)};
+    const int Kt = text_padded ? Tp : T;
+    // The weight gradients as ONE grouped launch (like a layer's four): alone, the modality problems are 24 / 48 tiles whose duration
+    // is the K = T loop latency (three launches of ~34 us each).
+    //  * direct (default): six problems of H output rows each -- (text | visual | acoustic operand) x (gate half | projection half of
+    //    the dZ columns) -- that store straight into dW_hv / dW_ha / dW_v / dW_a: column offsets V / A inside rows 815 / 842 floats
+    //    wide, only the V / A real columns of the padded modality operands (GemmArgs::cvalid: dword stores, no alignment needed).
+    //    No packed accumulators, no unpack launch (round 4: 7.4 us + 12 MB of traffic per step).
+    //  * MB_MAG_WGRAD_DIRECT=0: three problems into packed fp32 scratch + mag_unpack_wgrads (rounds 2-3).
+    static int direct_env = -1;
+    if (direct_env < 0) { const char* v = getenv("MB_MAG_WGRAD_DIRECT"); direct_env = v ? atoi(v) : 1; }
+    const char* dZe = ws + w.dZe; const char* dZv = ws + w.dZv; const char* dZa = ws + w.dZa;
+    GemmArgs wg[6];
+    int nwg = 3;
+    wg[0] = wgrad_args(2 * H, H, Kt, dZe, 2 * H, text, H, (float*)(ws + w.dWe), H);
+    wg[1] = wgrad_args(2 * H, w.Vp, Tp, dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp);
+    wg[2] = wgrad_args(2 * H, w.Ap, Tp, dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap);
     const int wtile = (w.Vp % 128 == 0 && w.Ap % 128 == 0 && H % 128 == 0 && mag_wgrad_tile() == 128 && gemm_grouped_tn_ok(dtype, wg, 3, 128)) ? 128 : 64;
     const bool grouped = text_padded && gemm_grouped_tn_ok(dtype, wg, 3, wtile);
+    const bool direct = grouped && direct_env != 0;
+    if (direct) {
+        const size_t half = (size_t)H * es;          // the projection half of a dZ row starts H columns in
+        wg[0] = wgrad_args(H, H, Kt, dZe, 2 * H, text, H, dW_hv + V, V + H);                 wg[0].cvalid = H;
+        wg[1] = wgrad_args(H, H, Kt, dZe + half, 2 * H, text, H, dW_ha + A, A + H);          wg[1].cvalid = H;
+        wg[2] = wgrad_args(H, w.Vp, Tp, dZv, 2 * H, ws + w.vp, w.Vp, dW_hv, V + H);          wg[2].cvalid = V;
+        wg[3] = wgrad_args(H, w.Vp, Tp, dZv + half, 2 * H, ws + w.vp, w.Vp, dW_v, V);        wg[3].cvalid = V;
+        wg[4] = wgrad_args(H, w.Ap, Tp, dZa, 2 * H, ws + w.ap, w.Ap, dW_ha, A + H);          wg[4].cvalid = A;
+        wg[5] = wgrad_args(H, w.Ap, Tp, dZa + half, 2 * H, ws + w.ap, w.Ap, dW_a, A);        wg[5].cvalid = A;
+        nwg = 6;
+        if (!gemm_grouped_tn_ok(dtype, wg, nwg, wtile)) return MB_ERR_SHAPE;
+    }
     {
         // one launch clears the pad rows of this call's k-major operands and (ungrouped path) the packed weight-gradient accumulators
         ZeroRanges z = {};
@@ -516,15 +552,16 @@ inline int mag_bwd_impl(int dtype, const void* d_out, const void* text, const fl
                          (const float*)(ws + w.mean), (const float*)(ws + w.rstd), beta_shift, ws + w.dep, ws + w.dZe,
                          ws + w.dZv, ws + w.dZa, db_hv, db_ha, db_v, db_a, dln_w, dln_b, d, drop, st, acc, part_a, part_b, part_nblk));
     if (grouped) {
-        for (auto& g : wg) g.overwrite = 1;
-        CK(gemm_grouped_tn_launch(dtype, wg, 3, wtile, st));
+        for (int i = 0; i < nwg; ++i) wg[i].overwrite = direct ? (dw_zero ? 1 : 0) : 1;      // (the packed accumulators are always stored)
+        CK(gemm_grouped_tn_launch(dtype, wg, nwg, wtile, st, wtile == 64 ? mag_wgrad_stages() : 0));
     } else {
         CK(wgrad(dtype, 2 * H, H, text_padded ? Tp : T, ws + w.dZe, 2 * H, text, H, (float*)(ws + w.dWe), H, st));
         CK(wgrad(dtype, 2 * H, w.Vp, Tp, ws + w.dZv, 2 * H, ws + w.vp, w.Vp, (float*)(ws + w.dWv), w.Vp, st));
         CK(wgrad(dtype, 2 * H, w.Ap, Tp, ws + w.dZa, 2 * H, ws + w.ap, w.Ap, (float*)(ws + w.dWa), w.Ap, st));
     }
-    CK(mag_unpack_wgrads((const float*)(ws + w.dWe), (const float*)(ws + w.dWv), (const float*)(ws + w.dWa), dW_hv, dW_ha,
-                         dW_v, dW_a, d, st));
+    if (!direct)
+        CK(mag_unpack_wgrads((const float*)(ws + w.dWe), (const float*)(ws + w.dWv), (const float*)(ws + w.dWa), dW_hv, dW_ha,
+                             dW_v, dW_a, d, st));
     // d_text = dZe . We + (ds + d||e|| term)
     CK(gemm(dtype, GEMM_NN, EPI_ADD_RES, T, H, 2 * H, ws + w.dZe, 2 * H, ws + w.We, H, d_text, H, nullptr, nullptr, nullptr,
             ws + w.dep, H, kNoDrop, 1, 0, st));

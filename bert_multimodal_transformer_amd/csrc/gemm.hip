@@ -160,7 +160,11 @@ struct EpiPre {
     bf16x8 r[HAS_R ? NR : 1];
     float bias8[8];
     DropKey key;
+    int ldc, cvalid, overwrite;         // scalars of the row pass, read from the kernel arguments HERE (pinned): left to the compiler, one of
+                                        // them ended up as an s_load inside the k loop, whose waits count scalar loads (tests/test_host_cpu.py)
     __device__ __forceinline__ void fetch(const GemmArgs& p, int m0, int n0, int tid) {
+        ldc = p.ldc; cvalid = p.cvalid; overwrite = p.overwrite;
+        asm volatile("" : "+s"(ldc), "+s"(cvalid), "+s"(overwrite));
         key = p.drop;
         key.resolve();
         const int n = n0 + (tid % TPR) * 8;
@@ -206,6 +210,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
         }
     __syncthreads();
     const int tid = threadIdx.x;
+    if constexpr (MODE == EPI_ACCUM_F32) {
+        if (pre.cvalid > 0) {                       // (uniform) a lane per column: a wave stores whole row segments, dword by dword
+            constexpr int RPP2 = NW * 64 / BN;      // rows per pass
+            const int cc = tid % BN, nn = n0 + cc;
+#pragma unroll 4
+            for (int r = tid / BN; r < BM; r += RPP2) {
+                const int m = m0 + r;
+                if (m >= p.M || nn >= pre.cvalid) continue;
+                const int o = r * RBY + (((cc >> 2) ^ (r & 7)) << 4) + (cc & 3) * 4;
+                float v = *(const float*)(smem + o);
+#pragma unroll
+                for (int w = 1; w < NSUM; ++w) v += *(const float*)(smem + w * REG + o);
+                float* dst = p.Cf + (size_t)m * pre.ldc + nn;
+                if (gridDim.y > 1) atomicAdd(dst, v);
+                else if (pre.overwrite) *dst = v;
+                else *dst += v;
+            }
+            return;
+        }
+    }
     const int c = (tid % TPR) * 8;
     const int n = n0 + c;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -240,7 +264,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
                 if (p.R) Vec8<T>::load((const T*)p.R + (size_t)m * p.ldr + n, res);
             }
         }
-        const size_t off = (size_t)m * p.ldc + n;
+        const size_t off = (size_t)m * pre.ldc + n;
         if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_F32) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = v[q] * p.alpha + bias8[q];
@@ -286,7 +310,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
             if (gridDim.y > 1) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) atomicAdd(dst + q, v[q]);
-            } else if (p.overwrite) {                  // the gradient buffer is known to hold zeros: no read-modify-write
+            } else if (pre.overwrite) {                // the gradient buffer is known to hold zeros: no read-modify-write
                 Vec8<float>::store(dst, v);
             } else {
                 float o[8];
@@ -1172,7 +1196,7 @@ static int launch_T(const GemmArgs& a, int layout, int mode, int splits, int til
 }
 
 template <class T, int BM, int BN>
-static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
+static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st, int stages) {
     constexpr int BKE = 128 / sizeof(T);
     constexpr int EPV = 16 / sizeof(T);
     GroupedGemmArgs ga;
@@ -1184,7 +1208,7 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
         GemmArgs& p = ga.g[i];
         p = probs[i];
         // LDS-DMA path preconditions (as in launch_cfg): whole tiles, whole 128-byte K rows, 16-byte aligned operands
-        if (p.K % BKE || p.M % BM || p.N % BN || p.lda % EPV || p.ldb % EPV || p.N % 8 || p.ldc % 8 ||
+        if (p.K % BKE || p.M % BM || p.N % BN || p.lda % EPV || p.ldb % EPV || p.N % 8 || (p.cvalid <= 0 && p.ldc % 8) || p.cvalid > p.N ||
             (((uintptr_t)p.A | (uintptr_t)p.B) % 16))
             return MB_ERR_SHAPE;
         ga.first[i] = total;
@@ -1213,8 +1237,15 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st) {
         unsigned long long* tr = trace_buffer(grid, st);
         for (int i = 0; i < count; ++i) ga.g[i].trace = tr;
     }
-    int gst = g_gstages;
+    int gst = stages > 0 ? stages : g_gstages;       // the caller's choice for THIS group (MAG's small one: below) or the global switch
     if (sizeof(T) == 2 && gst == 2 && ga.g[0].K / BKE < 2) gst = 3;      // (all problems of a group share K) single-stage k range: plain loop
+    // A group of few 64 x 64 tiles (MAG: 360 tiles for 512 slots, 8 MFMAs per wave and stage) is pure load latency: one k stage
+    // costs one memory round trip divided by the stages in flight.  4 | 5 ring slots of 128-byte rows = 64 | 80 KB, still 2 blocks
+    // per CU.  (The 128 x 128 groups measured slower with any deeper ring: 128 KB would leave one block per CU.)
+    if constexpr (BM == 64 && BN == 64) {
+        if (gst == 4) { hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 4, 128>), dim3(grid), dim3(256), 0, st, ga); return (int)hipGetLastError(); }
+        if (gst == 5) { hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 5, 128>), dim3(grid), dim3(256), 0, st, ga); return (int)hipGetLastError(); }
+    }
     if (gst == 24) {
         hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 4, 64>), dim3(grid), dim3(256), 0, st, ga);
     } else if (gst == 25) {
@@ -1232,17 +1263,17 @@ int gemm_grouped_tn_ok(int dtype, const GemmArgs* probs, int count, int tile) {
     if (count < 1 || count > MB_MAX_GROUP || (tile != 64 && tile != 128)) return 0;
     for (int i = 0; i < count; ++i) {
         const GemmArgs& p = probs[i];
-        if (p.K % BKE || p.M % tile || p.N % tile || p.lda % EPV || p.ldb % EPV || p.ldc % 8 ||
+        if (p.K % BKE || p.M % tile || p.N % tile || p.lda % EPV || p.ldb % EPV || (p.cvalid <= 0 && p.ldc % 8) || p.cvalid > p.N ||
             (((uintptr_t)p.A | (uintptr_t)p.B) % 16))
             return 0;
     }
     return 1;
 }
 
-int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st) {
+int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st, int stages) {
     if (count < 1 || count > MB_MAX_GROUP) return MB_ERR_ARG;
-    if (dtype == DT_BF16) return tile == 128 ? launch_grouped<bf16, 128, 128>(probs, count, st) : launch_grouped<bf16, 64, 64>(probs, count, st);
-    if (dtype == DT_F32) return tile == 128 ? launch_grouped<float, 128, 128>(probs, count, st) : launch_grouped<float, 64, 64>(probs, count, st);
+    if (dtype == DT_BF16) return tile == 128 ? launch_grouped<bf16, 128, 128>(probs, count, st, stages) : launch_grouped<bf16, 64, 64>(probs, count, st, stages);
+    if (dtype == DT_F32) return tile == 128 ? launch_grouped<float, 128, 128>(probs, count, st, stages) : launch_grouped<float, 64, 64>(probs, count, st, stages);
     return MB_ERR_DTYPE;
 }
 

@@ -46,6 +46,8 @@ struct GemmArgs {
     int dbg;                   // ablation switches (MB_GEMM_DBG): 1 = no DMA issue, 2 = no MFMA, 4 = no LDS fragment reads
     int reg_m, reg_n, tpr_m, tpr_n;   // XCD regions (filled by the launcher): reg_m*reg_n == 8, tiles per region
     int overwrite;                    // EPI_ACCUM_F32 without split-K: Cf = acc instead of Cf += acc (the caller knows Cf holds zeros)
+    int cvalid;                       // EPI_ACCUM_F32, > 0: only columns [0, cvalid) of the N (padded) ones are stored, one dword per lane -- Cf / ldc
+                                      // need no alignment then (MAG's weight gradients go straight into tensors 815 / 842 / 47 / 74 floats wide)
     unsigned long long* trace;        // MB_GEMM_TRACE=1: [blocks][8] wall-clock stamps (100 MHz) of the phases of every block, else null
     // Segmented B (0 = off): B's contiguous dimension (the columns n of a k-major B, the k of a row-major B) is cut into pieces of
     // `bseg` elements that live in separate tensors `bseg_stride` elements apart: element (r, c) sits at
@@ -71,7 +73,7 @@ struct GroupedGemmArgs {
     int chunk;                      // > 0: tiles per XCD of the group-wide XCD-compact placement (gemm.hip); 0: per-problem regions
 };
 int gemm_grouped_tn_ok(int dtype, const GemmArgs* probs, int count, int tile);
-int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st);
+int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st, int stages = 0);   // stages: 0 = MB_GROUP_STAGES, 4 | 5 = deeper ring (64 x 64 tiles only)
 
 // ------------------------------------------------------------------------------------------ row kernels (rowops.hip)
 // LayerNorm over the last dim H (H % 256 == 0, H <= 1024): y = (x-mean)*rstd*gamma + beta ; optional dropout on y.
@@ -232,6 +234,10 @@ struct PrologueArgs {
     struct PackJob { const float* src; void* dst; int rows, cols, pitch, dtype; } pack[2];
     int npack;
     const int64_t* ids; int n_ids; int* id_count;     // id_count[ids[i]] += 1 (see embed_ln_backward), may be null
+    // MAG's weights packed into the operands of its regrouped GEMMs (mag_pack.h) by EXTRA blocks of this launch, which is waiting for
+    // PCIe anyway: the first `copy_blocks` blocks (filled by step_prologue) do everything above, the rest this.  W_hv == null: none
+    struct MagPackW { const float* W_hv; const float* W_ha; const float* W_v; const float* W_a; void* We; void* Wv; void* Wa; MagDims d; int dtype; } magw;
+    int copy_blocks;
 };
 int step_prologue(const PrologueArgs& a, hipStream_t st);
 // p[0, bytes) = 0 as a kernel launch (bytes and p multiples of 4); up to MB_ZERO_MAX ranges in one launch

@@ -12,6 +12,7 @@
 //   backward: the exact adjoint, recomputing the gate from the saved pre-activation panels, including the
 //             where / min / norm sub-gradients at the hm==0 rows (zero, never NaN).
 #include "kernels.h"
+#include "mag_pack.h"
 
 namespace mb {
 
@@ -19,26 +20,7 @@ template <class T>
 __global__ void mag_pack_w_kernel(const float* __restrict__ W_hv, const float* __restrict__ W_ha,
                                   const float* __restrict__ W_v, const float* __restrict__ W_a, T* __restrict__ We,
                                   T* __restrict__ Wv, T* __restrict__ Wa, MagDims d) {
-    const int H = d.H, V = d.V, A = d.A, Vp = d.Vp, Ap = d.Ap;
-    const size_t nWe = (size_t)2 * H * H, nWv = (size_t)2 * H * Vp, nWa = (size_t)2 * H * Ap;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nWe + nWv + nWa; i += (size_t)gridDim.x * 256) {
-        if (i < nWe) {
-            const int j = (int)(i / H), c = (int)(i % H);
-            We[i] = from_f<T>(j < H ? W_hv[(size_t)j * (V + H) + V + c] : W_ha[(size_t)(j - H) * (A + H) + A + c]);
-        } else if (i < nWe + nWv) {
-            const size_t k = i - nWe;
-            const int j = (int)(k / Vp), c = (int)(k % Vp);
-            float v = 0.f;
-            if (c < V) v = j < H ? W_hv[(size_t)j * (V + H) + c] : W_v[(size_t)(j - H) * V + c];
-            Wv[k] = from_f<T>(v);
-        } else {
-            const size_t k = i - nWe - nWv;
-            const int j = (int)(k / Ap), c = (int)(k % Ap);
-            float v = 0.f;
-            if (c < A) v = j < H ? W_ha[(size_t)j * (A + H) + c] : W_a[(size_t)(j - H) * A + c];
-            Wa[k] = from_f<T>(v);
-        }
-    }
+    mag_pack_w_range<T>(W_hv, W_ha, W_v, W_a, We, Wv, Wa, d, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
 }
 
 __global__ void mag_unpack_g_kernel(const float* __restrict__ dWe, const float* __restrict__ dWv,

@@ -10,6 +10,7 @@
 // Algorithmic HBM bytes per token are listed per kernel in DESIGN.md.
 #include <algorithm>
 #include "kernels.h"
+#include "mag_pack.h"
 
 namespace mb {
 
@@ -764,7 +765,14 @@ __device__ __forceinline__ uint64_t splitmix64_dev(uint64_t x) {
 }
 
 __global__ void __launch_bounds__(256) step_prologue_kernel(const PrologueArgs a) {
-    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+    if ((int)blockIdx.x >= a.copy_blocks) {         // the extra blocks: MAG's weight operands (device memory only)
+        const size_t first = (size_t)(blockIdx.x - a.copy_blocks) * 256 + threadIdx.x, stride = (size_t)(gridDim.x - a.copy_blocks) * 256;
+        const PrologueArgs::MagPackW& w = a.magw;
+        if (w.dtype == DT_BF16) mag_pack_w_range<bf16>(w.W_hv, w.W_ha, w.W_v, w.W_a, (bf16*)w.We, (bf16*)w.Wv, (bf16*)w.Wa, w.d, first, stride);
+        else mag_pack_w_range<float>(w.W_hv, w.W_ha, w.W_v, w.W_a, (float*)w.We, (float*)w.Wv, (float*)w.Wa, w.d, first, stride);
+        return;
+    }
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)a.copy_blocks * 256;
     if (blockIdx.x == 0) {
         for (int s = threadIdx.x; s < a.nsites; s += 256) {
             const uint64_t h = splitmix64_dev(splitmix64_dev(a.seed) ^ splitmix64_dev(a.step * 0x100000001B3ull + (uint64_t)s));
@@ -856,7 +864,14 @@ int step_prologue(const PrologueArgs& a, hipStream_t st) {
     unsigned grid = (unsigned)((most / 4 + 255) / 256);
     if (grid < 1) grid = 1;
     if (grid > 512) grid = 512;
-    hipLaunchKernelGGL(step_prologue_kernel, dim3(grid), dim3(256), 0, st, a);
+    PrologueArgs b = a;
+    b.copy_blocks = (int)grid;
+    if (a.magw.W_hv != nullptr) {
+        if (!a.magw.W_ha || !a.magw.W_v || !a.magw.W_a || !a.magw.We || !a.magw.Wv || !a.magw.Wa) return MB_ERR_ARG;
+        if (a.magw.dtype != DT_BF16 && a.magw.dtype != DT_F32) return MB_ERR_DTYPE;
+        grid += 256;                                // one more block per CU, next to the ones that sit on their PCIe round trips
+    }
+    hipLaunchKernelGGL(step_prologue_kernel, dim3(grid), dim3(256), 0, st, b);
     return (int)hipGetLastError();
 }
 

@@ -145,6 +145,8 @@ static void xl_build_layout(mb_xlnet_engine* e) {
         const char* pv = getenv("MB_PROLOGUE_PACK");
         e->pk_enable = !(pv && atoi(pv) == 0);
         e->pk_vis = e->ws_mag + e->mw.vp; e->pk_aco = e->ws_mag + e->mw.ap; e->pk_Vp = e->mw.Vp; e->pk_Ap = e->mw.Ap; e->pk_dtype = c.dtype;
+        const char* pw = getenv("MB_PROLOGUE_PACKW");
+        e->pkw_enable = !(pw && atoi(pw) == 0);
     }
     e->ws_magout = w.take(T * H * es);
     e->ws_pos = w.take(R * H * es);
@@ -268,6 +270,9 @@ int mb_xlnet_bind(mb_xlnet_engine* e, float* params, float* grads, void* shadow,
     e->grads_zero = false;                 // a newly bound gradient buffer: nothing is known about its contents
     e->ws_zeroed = false; e->padT = -1;
     e->drop_graphs();
+    char* mws = e->ws + e->ws_mag;
+    e->pkw = {e->P + e->mag_whv, e->P + e->mag_wha, e->P + e->mag_wv, e->P + e->mag_wa, mws + e->mw.We, mws + e->mw.Wv, mws + e->mw.Wa,
+              MagDims{0, e->c.d_model, e->c.visual_dim, e->c.acoustic_dim, e->mw.Vp, e->mw.Ap}, e->c.dtype};
     return MB_OK;
 }
 int mb_xlnet_sync_weights(mb_xlnet_engine* e, void* stream) {
@@ -304,7 +309,7 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
             CK(mag_fwd_impl(dt, xin, visual, acoustic, P + e->mag_whv, P + e->mag_bhv, P + e->mag_wha, P + e->mag_bha,
                             P + e->mag_wv, P + e->mag_bv, P + e->mag_wa, P + e->mag_ba, P + e->mag_lnw, P + e->mag_lnb,
                             c.mag_layer_norm_eps, c.beta_shift, e->key(XS_MAG, c.mag_dropout), ws + e->ws_magout,
-                            ws + e->ws_mag, e->mw, T, H, c.visual_dim, c.acoustic_dim, true, st, true, e->in_step && e->packed));
+                            ws + e->ws_mag, e->mw, T, H, c.visual_dim, c.acoustic_dim, !(e->in_step && e->packed_w), st, true, e->in_step && e->packed));
             xin = ws + e->ws_magout;
         }
         char* qkv = ws + w.qkv;
@@ -500,7 +505,7 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                                 nullptr, G + e->mag_whv, G + e->mag_bhv, G + e->mag_wha, G + e->mag_bha, G + e->mag_wv, G + e->mag_bv,
                                 G + e->mag_wa, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb, T, H, c.visual_dim, c.acoustic_dim, true,
                                 st, acc, true, (float*)(ws + e->ws_lnp_a) + (size_t)NL * e->lnp_stride,
-                                (float*)(ws + e->ws_lnp_b) + (size_t)NL * e->lnp_stride, &mblk));
+                                (float*)(ws + e->ws_lnp_b) + (size_t)NL * e->lnp_stride, &mblk, e->ow_pass));
                 e->mag_nblk = mblk;
                 if (!mag_slabs) {        // not a single-call step (or MAG in front of layer 0): reduce MAG's slabs right away
                     float* const m6[6] = {G + e->mag_bhv, G + e->mag_bha, G + e->mag_bv, G + e->mag_ba, G + e->mag_lnw, G + e->mag_lnb};

@@ -57,19 +57,20 @@ __global__ void __launch_bounds__(256) gather_drop_bwd_kernel(const T* __restric
 template <class T>
 __global__ void __launch_bounds__(256) pos_emb_kernel(T* __restrict__ out, int B, int L, int H, DropKey drop) {
     drop.resolve();
-    const size_t total = (size_t)B * 2 * L * H;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % H);
-        const int p = (int)((i / H) % (2 * L));
-        const int b = (int)(i / ((size_t)H * 2 * L));
-        const int half = H / 2;
-        const int d = c < half ? c : c - half;
-        const float inv_freq = 1.0f / powf(10000.0f, (float)(2 * d) / (float)H);
-        const float a = (float)(L - p) * inv_freq;
-        float v = c < half ? sinf(a) : cosf(a);
+    // one thread per (position, column): powf + sinf / cosf once, then the B copies, which differ only by their dropout masks (one
+    // thread per ELEMENT evaluated the transcendentals B times: 30 us per step at B = 48)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * L * H) return;
+    const int c = i % H, p = i / H;
+    const int half = H / 2;
+    const int d = c < half ? c : c - half;
+    const float inv_freq = 1.0f / powf(10000.0f, (float)(2 * d) / (float)H);
+    const float a = (float)(L - p) * inv_freq;
+    const float v = c < half ? sinf(a) : cosf(a);
+    for (int b = 0; b < B; ++b) {
         // reference index space: pos_emb is [2L, B, H] (xlnet.py:99-100,333) -> element ((p*B + b)*H + c)
-        v *= drop_mult(drop, (uint32_t)(((size_t)p * B + b) * H + c));
-        out[i] = from_f<T>(v);
+        const float m = drop_mult(drop, (uint32_t)(((size_t)p * B + b) * H + c));
+        out[((size_t)b * 2 * L + p) * H + c] = from_f<T>(v * m);
     }
 }
 
@@ -145,7 +146,7 @@ int drop_rows(int dtype, const void* x, void* y, int rows, int H, DropKey drop, 
     return (int)hipGetLastError();
 }
 int xlnet_pos_emb(int dtype, void* out, int B, int L, int H, DropKey drop, hipStream_t st) {
-    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((pos_emb_kernel<T>), dim3(1024), dim3(256), 0, st, (T*)out, B, L, H, drop); })
+    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((pos_emb_kernel<T>), dim3((2 * L * H + 255) / 256), dim3(256), 0, st, (T*)out, B, L, H, drop); })
     return (int)hipGetLastError();
 }
 int last_token_forward(int dtype, const void* x, void* xs, int B, int L, int H, DropKey drop, hipStream_t st) {
