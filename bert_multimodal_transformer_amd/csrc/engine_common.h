@@ -68,10 +68,9 @@ inline int mag_wgrad_tile() {
 }
 
 // ring depth of MAG's grouped weight-gradient launch (64 x 64 tiles only): MB_MAG_WGRAD_STAGES = 2 | 3 | 4 | 5
-inline int mag_wgrad_stages() {
-    static int t = -1;
-    if (t < 0) { const char* v = getenv("MB_MAG_WGRAD_STAGES"); t = v ? atoi(v) : 4; }
-    return t;
+inline int mag_wgrad_stages() {        // (read per call -- capture time only -- so that a test can compare the variants in one process)
+    const char* v = getenv("MB_MAG_WGRAD_STAGES");
+    return v ? atoi(v) : 4;
 }
 
 struct MagWs {
@@ -511,8 +510,8 @@ inline int mag_bwd_impl(int dtype, const void* d_out, const void* text, const fl
     //    wide, only the V / A real columns of the padded modality operands (GemmArgs::cvalid: dword stores, no alignment needed).
     //    No packed accumulators, no unpack launch (round 4: 7.4 us + 12 MB of traffic per step).
     //  * MB_MAG_WGRAD_DIRECT=0: three problems into packed fp32 scratch + mag_unpack_wgrads (rounds 2-3).
-    static int direct_env = -1;
-    if (direct_env < 0) { const char* v = getenv("MB_MAG_WGRAD_DIRECT"); direct_env = v ? atoi(v) : 1; }
+    const char* dv = getenv("MB_MAG_WGRAD_DIRECT");
+    const int direct_env = dv ? atoi(dv) : 1;
     const char* dZe = ws + w.dZe; const char* dZv = ws + w.dZv; const char* dZa = ws + w.dZa;
     GemmArgs wg[6];
     int nwg = 3;

@@ -685,6 +685,31 @@ def test_deterministic_mode_bf16_runs_are_bit_identical(monkeypatch):
     assert err <= 1e-5
 
 
+def test_mag_weight_gradient_paths_agree_bit_for_bit(monkeypatch):
+    """MAG's four weight gradients (/root/reference/modeling.py:13-17) leave one grouped launch of six problems that store straight
+    into the reference-layout tensors -- rows 815 / 842 / 47 / 74 floats wide, column offsets 47 / 74, padded modality columns masked
+    (GemmArgs::cvalid) -- from a 4-slot operand ring, and the forward's packed weight operands are written by the step prologue.
+    The round-2/3 path (three problems into packed scratch + an unpack launch, 2-slot ring, pack launch inside the step) is still
+    there behind switches; the k order inside a tile is the same in all of them, so in deterministic mode whole trajectories must
+    agree BIT FOR BIT: store path (first micro-step after an update), read-modify-write path (accumulation), ragged batch."""
+    monkeypatch.setenv("MB_DETERMINISTIC", "1")
+    shapes = ((48, 50), (33, 50), (7, 24))
+    def run(direct, stages, packw, accum, dtype=torch.bfloat16):
+        monkeypatch.setenv("MB_MAG_WGRAD_DIRECT", direct)
+        monkeypatch.setenv("MB_MAG_WGRAD_STAGES", stages)
+        monkeypatch.setenv("MB_PROLOGUE_PACKW", packw)
+        return _trajectory(dtype, True, nsteps=4, accum=accum, layers=2, shapes=shapes)
+    for accum in (1, 2):
+        ref = run("0", "2", "0", accum)
+        for variant in (("1", "4", "1"), ("1", "2", "0"), ("0", "5", "1"), ("1", "3", "1")):
+            got = run(*variant, accum)
+            for k in ("p", "m", "v", "shadow", "logits"):
+                assert torch.equal(got[k], ref[k]), "accum %d, variant %s: %s differs" % (accum, variant, k)
+    ref32 = run("0", "2", "0", 2, torch.float32)
+    got32 = run("1", "4", "1", 2, torch.float32)
+    assert torch.equal(got32["p"], ref32["p"]) and torch.equal(got32["logits"], ref32["logits"])
+
+
 def test_single_call_step_word_gradient_with_repeated_and_unique_token_ids():
     """The single-call step adds the word-embedding gradient of a token id that occurs ONCE in the batch with plain read-modify-writes
     (the step prologue counts the occurrences, the backward clears the table again) and everything else with atomics.  A batch built
