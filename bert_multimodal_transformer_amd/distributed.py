@@ -171,12 +171,20 @@ class Comm(object):
         h = C.c_void_p()
         if self.backend == "nccl":
             idbuf = (C.c_uint8 * 128)()
-            if self.rank == 0:
-                _lib.check(L.mb_comm_unique_id(idbuf))
+            # on EVERY rank (only rank 0's id is used): RCCL loads -- or fails to -- everywhere before the first collective below, so a
+            # missing library raises on all ranks together instead of leaving the others inside a broadcast
+            _lib.check(L.mb_comm_unique_id(idbuf))
             t = torch.tensor(list(idbuf), dtype=torch.uint8, device=dev)
             dist.broadcast(t, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
             raw = bytes(t.cpu().tolist())
-            _lib.check(L.mb_comm_create_rccl(C.c_char_p(raw), self.rank, self.world, C.byref(h)))
+            rc = L.mb_comm_create_rccl(C.c_char_p(raw), self.rank, self.world, C.byref(h))
+            ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=process_group)      # all ranks use the C-side exchange, or none does
+            if int(ok.item()) == 0:
+                if rc == 0:
+                    L.mb_comm_destroy(h)
+                    raise RuntimeError("another rank could not create its RCCL communicator")
+                _lib.check(rc)
             self._cbs = None
         else:
             self._cbs = (_lib.ALL_REDUCE_CB(self._all_reduce_cb), _lib.ALL_GATHER_CB(self._all_gather_cb))      # kept alive with the object
