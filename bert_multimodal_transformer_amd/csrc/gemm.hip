@@ -1115,8 +1115,8 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
         // three-slot kernel (plain loop)
         if (sizeof(T) == 2 && ns <= 2 && p.kchunk / (kb / (int)sizeof(T)) < 2) ns = 3;
 #define MB_LAUNCH2(NS, KBV) hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, NS, KBV>), grid, dim3(256), 0, st, p)
-        static int g_ks = -1;             // MB_GEMM_KSPLIT: 1 (default) = k-split waves for the 64 x 64 bf16 tiles, 0 = round-1 quarter tiles
-        if (g_ks < 0) g_ks = env_int("MB_GEMM_KSPLIT", 1);
+        static int g_ks = -1;             // MB_GEMM_KSPLIT: 1 = k-split waves for the 64 x 64 bf16 tiles (rounds 2-3), 0 (default) = quarter tiles
+        if (g_ks < 0) g_ks = env_int("MB_GEMM_KSPLIT", 0);
         if constexpr (BM == 64 && BN == 64 && sizeof(T) == 2) {
             // each k-split block holds 64 KB of LDS (2 per CU): worth it while the whole grid is co-resident and the k loop is long
             // enough to amortise the four-tile epilogue (K = 768: 3 stages, measured 10.8 vs 9.8 us); beyond that
@@ -1125,6 +1125,15 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
                 hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, 2, 256, true>), grid, dim3(256), 0, st, p);
                 return (int)hipGetLastError();
             }
+            // Round 4 (late): every 64 x 64 launch of at most 512 tiles takes the quarter-tile kernel with a THREE-slot ring of 128-byte
+            // rows (48 KB: three blocks per CU, plain loop with two stages in flight) -- K = 768 (12 k stages, 8 MFMAs per wave and
+            // stage: load latency, like MAG's weight gradients) AND the K >= 1024 problems the k-split kernel above used to take.
+            // Same box, ms per step (profiles/r04_gemm64_ring_ab.txt): k-split + 2 slots 3.648 | k-split + 3 slots 3.62 | 3 slots
+            // everywhere 3.60 | 4 slots everywhere 3.64; MAG-XLNet 4.25 -> 4.19.  Not beyond 512 tiles: at T = 4096 (768 tiles) the
+            // two-slot kernel's five blocks per CU win (5.14 vs 5.19 ms).  MB_GEMM_64_STAGES=0 MB_GEMM_KSPLIT=1: the round-3 selection.
+            static int g_64st = -1;
+            if (g_64st < 0) g_64st = env_int("MB_GEMM_64_STAGES", 3);
+            if (g_64st >= 3 && g_stages <= 0 && splits == 1 && p.kchunk / BKE >= 2 && tiles <= 512) ns = g_64st > 4 ? 4 : g_64st;
         }
         if (kb == 128) {
             if (BM == 128) { if (ns <= 2) MB_LAUNCH2(2, 128); else if (ns == 3) MB_LAUNCH2(3, 128); else MB_LAUNCH2(4, 128); }
