@@ -5,8 +5,8 @@ Same class names, constructor `(config, multimodal_config)`, forward argument or
 (transformer.word_embedding.weight, transformer.mask_emb, transformer.layer.{i}.rel_attn.{q,k,v,o,r,r_r_bias,r_s_bias,
 r_w_bias,seg_embed,layer_norm.*}, transformer.layer.{i}.ff.{layer_norm,layer_1,layer_2}.*, transformer.MAG.*,
 sequence_summary.summary.*, logits_proj.*).  Built for the configuration the reference driver runs
-(multimodal_driver.py:363-370: attention_mask + token_type_ids, no mems / perm_mask / target_mapping / input_mask: those raise
-NotImplementedError; inputs_embeds, output_hidden_states / output_attentions (served from the activations the engine keeps for
+(multimodal_driver.py:363-370: attention_mask + token_type_ids; perm_mask / input_mask are built too (forward kernel + its
+adjoint); target_mapping (the query stream) raises NotImplementedError; inputs_embeds, output_hidden_states / output_attentions (served from the activations the engine keeps for
 its backward) and head_mask (scales each head's attention output inside the kernels) are built, and MAG_XLNetModel's output is
 differentiable), sequence length <= 128, MAG injected in front of layer
 XLNET_INJECTION_INDEX (global_configs.py:19, xlnet.py:371-372).

@@ -18,3 +18,11 @@ def golden():
     import numpy as np
     d = os.path.join(ROOT, "tests", "golden")
     return {f[:-4]: np.load(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(".npz")}
+
+
+def free_port():
+    """A TCP port the kernel just handed out (bind to 0), for torch.distributed rendezvous in multi-process tests."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

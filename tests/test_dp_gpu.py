@@ -8,6 +8,8 @@ import sys
 
 import pytest
 
+from conftest import free_port
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -66,7 +68,7 @@ def test_two_ranks_equal_one_process(tmp_path, kind, sparse):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
     out = str(tmp_path / "params")
-    port = 29600 + os.getpid() % 1000
+    port = free_port()
 
     graphs = kind.endswith("-stage-graphs")        # MB_DP_GRAPH=1: every pass / backward stage of the ranks is ONE replayed graph
     kind = kind.split("-")[0]
@@ -132,7 +134,7 @@ def test_driver_under_two_ranks(tmp_path, model, accum):
     script = tmp_path / "d.py"
     script.write_text(_DRIVER_WORKER)
     out = str(tmp_path / "drv")
-    port = 29700 + os.getpid() % 1000
+    port = free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
@@ -195,7 +197,7 @@ def test_rccl_call_path_single_rank(tmp_path, cdt):
     script.write_text(_RCCL_WORKER)
     out = str(tmp_path / "rccl")
     for use_dp in ("0", "1"):
-        env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 1000),
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
                    REPO_ROOT=ROOT, OUT=out, USE_DP=use_dp, MB_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CDT=cdt,
                    MB_DP_GRAD_DTYPE=cdt)       # (the bf16 wire is the automatic choice of two-GPU groups only: asked for here)
         p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
@@ -278,7 +280,7 @@ print("OK", world, rank)
 def _run_engine_workers(tmp_path, world, env_extra, tag="w"):
     script = tmp_path / (tag + ".py")
     script.write_text(_ENGINE_WORKER)
-    port = 29900 + os.getpid() % 1000
+    port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), REPO_ROOT=ROOT,

@@ -8,6 +8,8 @@ import sys
 
 import numpy as np
 import pytest
+
+from conftest import free_port
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -244,7 +246,7 @@ print("OK", rank)
 def test_grad_reducer_gloo_world2(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(_DDP_WORKER)
-    port = 29500 + os.getpid() % 2000
+    port = free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), REPO_ROOT=ROOT)
@@ -332,7 +334,7 @@ print("OK", rank)
 def test_embedding_row_exchange_equals_dense_allreduce_gloo_world2(tmp_path):
     script = tmp_path / "rows.py"
     script.write_text(_ROWS_WORKER)
-    port = 29400 + os.getpid() % 500
+    port = free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), REPO_ROOT=ROOT)
