@@ -33,7 +33,12 @@ struct mb_comm {
     //   1 = the same with device-scope release events (no difference);
     //   2 = (default) the event is recorded by the LAST NODE of the segment's graph (dp_segment_end runs inside the capture): the
     //       graphs stay linear, nothing sits between two launches but the next launch;
-    //   3 = ... and the optimizer segments start with wait nodes instead of stream waits (dp_segment_begin): no further gain.
+    //   3 = ... and the optimizer segments start with wait nodes instead of stream waits (dp_segment_begin).
+    // Inside a capture the record MUST be hipEventRecordWithFlags(.., hipEventRecordExternal) and the wait hipStreamWaitEvent(..,
+    // hipEventWaitExternal): a plain hipEventRecord in a capturing stream only marks a dependency INSIDE the capture, adds no node and
+    // records nothing on replay (tools/event_capture_probe.cpp on ROCm 7.2: dependency held in 0 of 20 replays plain, 20 of 20
+    // external; profiles/r05_event_capture_probe.txt).  Round 4 shipped the plain form: its numbers above for modes 2 / 3 were
+    // measured WITHOUT the dependency.  dp_verify_segment_graph checks every captured segment for its event node.
     int event_mode = 2;
 };
 
@@ -64,6 +69,9 @@ int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st);
 // called by the engines at the head / at the end of every segment's kernel sequence (inside the capture when the step is captured)
 int dp_segment_begin(mb_comm* c, int nb, int seg, hipStream_t st);
 int dp_segment_end(mb_comm* c, int nb, int seg, hipStream_t st);
+// train_step_impl's post-capture check (tag = the mb_comm, nseg = nb + 2): in event modes 2 / 3 a backward segment's graph must END
+// with an event-record node, in mode 3 an optimizer segment's graph must START with a wait-event node; MB_ERR_MODE otherwise
+int dp_verify_segment_graph(const void* tag, int nseg, int seg, hipGraph_t graph);
 
 // row-wise sum of a [vocab][H] fp32 table over the ranks (comm.hip): every rank touched the rows ids[0..T)
 int comm_exchange_rows(mb_comm* c, float* table, const int64_t* ids, int T, hipStream_t s);

@@ -26,7 +26,7 @@
 
 using namespace mb;
 
-#define CK(x) do { int _e = (x); if (_e) return _e; } while (0)
+#define CK(x) do { int _e = (x); if (_e) { mb::ck_trace(#x, __FILE__, __LINE__, _e); return _e; } } while (0)
 
 namespace {
 
@@ -184,15 +184,72 @@ int comm_exchange_rows(mb_comm* c, float* table, const int64_t* ids, int T, hipS
 static int fork_to_comm(mb_comm* c, int seg, hipStream_t st) {
     hipEvent_t ev = c->fork_ev[(size_t)seg % c->fork_ev.size()];
     if (c->event_mode < 2) CK((int)hipEventRecord(ev, st));      // (modes 2, 3: recorded by the segment itself, dp_segment_end)
+    static int dbg = -1;
+    if (dbg < 0) { const char* v = getenv("MB_DP_DEBUG"); dbg = v ? atoi(v) : 0; }
+    if (dbg == 4) return MB_OK;          // NEGATIVE CONTROL of the equality tests: the hand-off is dropped, the exchange races the backward
     return (int)hipStreamWaitEvent(c->cs, ev, 0);
+}
+// MB_DP_TEST_DELAY_US (tests only): every backward segment starts with a kernel that spins this long, so that the host has issued
+// the segment's collectives long before the segment's gradients exist -- a missing compute -> comm dependency then fails the
+// equality tests deterministically instead of hiding behind a slow host (tests/test_dp_gpu.py)
+__global__ void dp_test_delay_kernel(long long ticks) {
+    const long long t0 = wall_clock64();           // 100 MHz
+    while (wall_clock64() - t0 < ticks) {}
+}
+static int test_delay_us() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MB_DP_TEST_DELAY_US"); v = e ? atoi(e) : 0; if (v < 0) v = 0; }
+    return v;
+}
+static bool is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cst) == hipSuccess && cst == hipStreamCaptureStatusActive;
 }
 int dp_segment_end(mb_comm* c, int nb, int seg, hipStream_t st) {
     if (c->event_mode < 2 || seg >= nb) return MB_OK;
-    return (int)hipEventRecord(c->fork_ev[(size_t)seg % c->fork_ev.size()], st);
+    hipEvent_t ev = c->fork_ev[(size_t)seg % c->fork_ev.size()];
+    // captured: an EXTERNAL record = an event-record node that fires on every replay (a plain record would add no node at all)
+    return is_capturing(st) ? (int)hipEventRecordWithFlags(ev, st, hipEventRecordExternal) : (int)hipEventRecord(ev, st);
 }
 int dp_segment_begin(mb_comm* c, int nb, int seg, hipStream_t st) {
+    if (seg < nb && test_delay_us() > 0) {
+        dp_test_delay_kernel<<<1, 1, 0, st>>>((long long)test_delay_us() * 100);
+        CK((int)hipGetLastError());
+    }
     if (c->event_mode < 3 || seg < nb) return MB_OK;
-    return (int)hipStreamWaitEvent(st, seg == nb ? (nb > 1 ? c->ev_layers : c->ev_tail) : c->ev_tail, 0);
+    hipEvent_t ev = seg == nb ? (nb > 1 ? c->ev_layers : c->ev_tail) : c->ev_tail;
+    return (int)hipStreamWaitEvent(st, ev, is_capturing(st) ? hipEventWaitExternal : 0);
+}
+int dp_verify_segment_graph(const void* tag, int nseg, int seg, hipGraph_t graph) {
+    const mb_comm* c = (const mb_comm*)tag;
+    if (!c || c->event_mode < 2) return MB_OK;
+    const int nb = nseg - 2;
+    size_t n = 0;
+    CK((int)hipGraphGetNodes(graph, nullptr, &n));
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n) CK((int)hipGraphGetNodes(graph, nodes.data(), &n));
+    int records = 0, waits = 0, record_is_leaf = 0, wait_is_root = 0;
+    for (auto nd : nodes) {
+        hipGraphNodeType t;
+        CK((int)hipGraphNodeGetType(nd, &t));
+        size_t nout = 0, nin = 0;
+        if (t == hipGraphNodeTypeEventRecord) {
+            ++records;
+            CK((int)hipGraphNodeGetDependentNodes(nd, nullptr, &nout));
+            record_is_leaf += nout == 0;
+        } else if (t == hipGraphNodeTypeWaitEvent) {
+            ++waits;
+            CK((int)hipGraphNodeGetDependencies(nd, nullptr, &nin));
+            wait_is_root += nin == 0;
+        }
+    }
+    const bool ok = seg < nb ? (records == 1 && record_is_leaf == 1) : (c->event_mode < 3 || (waits == 1 && wait_is_root == 1));
+    if (!ok) {
+        snprintf(g_last_error, sizeof g_last_error, "data-parallel segment %d of %d: captured graph has %d event-record / %d wait-event "
+                 "nodes (event mode %d): the hand-off to the comm stream would not be ordered", seg, nseg, records, waits, c->event_mode);
+        return MB_ERR_MODE;
+    }
+    return MB_OK;
 }
 // the compute stream waits for `ev` (recorded on the comm stream); with timing on, the stall is bracketed by two timing events
 static int wait_timed(mb_comm* c, int k, hipEvent_t ev, hipStream_t st) {
@@ -230,7 +287,8 @@ std::vector<int> dp_chunk_plan(int n_layer) {
 
 int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st) {
     // MB_DP_DEBUG (measurement only -- the gradients are NOT exchanged): 1 = the segmented step alone (no events, no collectives),
-    // 2 = events and waits but no collectives, 3 = everything except the row-wise exchange (the table is left as it is)
+    // 2 = events and waits but no collectives, 3 = everything except the row-wise exchange (the table is left as it is);
+    // 4 = (tests' negative control) everything, but the comm stream does not wait for the backward segment (fork_to_comm)
     static int dbg = -1;
     if (dbg < 0) { const char* v = getenv("MB_DP_DEBUG"); dbg = v ? atoi(v) : 0; }
     if (dbg == 1) return MB_OK;

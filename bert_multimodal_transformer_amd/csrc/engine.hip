@@ -897,7 +897,7 @@ int mb_bert_train_step_dp(mb_bert_engine* e, const int64_t* input_ids, const flo
                                CK(enqueue_step_dp(e, sg, plan, B, L, lg, ls, lr_, m_, v_, sc, s));
                                return dp_segment_end(comm, nb, sg, s);
                            },
-                           nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant, comm);
+                           nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant, comm, dp_verify_segment_graph);
 }
 
 // ------------------------------------------------------------------------------------------------ stage-driven step (data parallel)

@@ -100,7 +100,7 @@ struct MagWs {
     }
 };
 
-#define CK(x) do { int _e = (x); if (_e) return _e; } while (0)
+#define CK(x) do { int _e = (x); if (_e) { mb::ck_trace(#x, __FILE__, __LINE__, _e); return _e; } } while (0)
 
 inline int gemm(int dtype, int layout, int mode, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
          int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, DropKey drop, int splits, int tile,
@@ -355,7 +355,7 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
                            float* loss_run, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay,
                            int opt_step, int correct_bias, float grad_scale, float loss_scale, int mode, bool force_launches,
                            hipStream_t st, Enqueue enqueue_inner, int nseg = 1, Between between = Between(), int variant = 0,
-                           const void* tag = nullptr) {
+                           const void* tag = nullptr, int (*verify)(const void* tag, int nseg, int sg, hipGraph_t gr) = nullptr) {
     // The step may be cut into `nseg` segments: enqueue_inner(seg, ...) issues the kernels of one (captured and replayed as its own
     // LINEAR graph), between(seg, st) runs on the host right after segment `seg` was enqueued and is never captured -- the place for
     // cross-stream events (a graph with a fork inside runs on ROCm 7.2's slow path; a chain of linear graphs does not).
@@ -429,6 +429,7 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
             e->dyn = false; e->capturing = false;
             const int r2 = (int)hipStreamEndCapture(cs, &gr);
             if (r || r2) { if (gr) hipGraphDestroy(gr); ng.destroy(); return r ? r : r2; }
+            if (verify) { const int rv = verify(tag, nseg, sg, gr); if (rv) { hipGraphDestroy(gr); ng.destroy(); return rv; } }
             const int r3 = (int)hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
             if (r3) { hipGraphDestroy(gr); ng.destroy(); return r3; }
             ng.graph.push_back(gr); ng.exec.push_back(ex);

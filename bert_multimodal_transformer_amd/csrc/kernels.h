@@ -1,5 +1,7 @@
 // Internal C++ launch API of the HIP kernels (host side).  The public C ABI is include/magbert_hip.h.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
 
 namespace mb {
@@ -12,6 +14,14 @@ enum {
     MB_ERR_ARG = 1004,
     MB_ERR_COMM = 1005,      // gradient exchange: RCCL missing / no backend (mb_comm_last_error() has the text); 2000 + n = ncclResult_t n
 };
+
+// MB_CK_TRACE=1: every failing call of a CK(...) chain is printed with its source line (a bare HIP error code from the middle of a
+// 200-kernel step says nothing about which call produced it)
+inline void ck_trace(const char* expr, const char* file, int line, int code) {
+    static int on = -1;
+    if (on < 0) { const char* v = getenv("MB_CK_TRACE"); on = (v && atoi(v)) ? 1 : 0; }
+    if (on) fprintf(stderr, "[magbert] %s:%d: %s -> %d\n", file, line, expr, code);
+}
 
 // ------------------------------------------------------------------------------------------ GEMM
 enum { GEMM_NT = 0,   // A [M][K] row, B [N][K] row      : Y = X W^T            (forward Linear)

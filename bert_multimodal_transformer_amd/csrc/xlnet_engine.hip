@@ -654,7 +654,7 @@ int mb_xlnet_train_step_dp(mb_xlnet_engine* e, const int64_t* input_ids, const f
                                CK(xl_enqueue_step_dp(e, sg, plan, B, L, lg, ls, lr_, m_, v_, sc, s));
                                return dp_segment_end(comm, nb, sg, s);
                            },
-                           nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant, comm);
+                           nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant, comm, dp_verify_segment_graph);
 }
 
 int mb_xlnet_set_perm_mask(mb_xlnet_engine* e, const uint8_t* perm) {

@@ -241,13 +241,14 @@ torch.cuda.set_device(0)
 if use_dp:
     dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}))
 m = make().train()
-opt = AdamW(optimizer_grouped_parameters(m), lr=1e-3)
+opt = AdamW(optimizer_grouped_parameters(m), lr=float(os.environ.get("LR", "1e-3")))
 sch = get_linear_schedule_with_warmup(opt, 0, 100)
 dp = None
 if use_dp:
     dp = DataParallel(m, opt)
     dp.broadcast_parameters(0)
 first_m = None
+every_m = []
 with m.stream_scope():
     for s in range(int(os.environ.get("STEPS", "2"))):
         ids, vis, aco, mask, seg, lab = tb(batch(90 + s), DEV)
@@ -258,6 +259,9 @@ with m.stream_scope():
         if first_m is None:
             torch.cuda.synchronize()
             first_m = m._core._adam_m.cpu().clone()        # (1 - beta1) x the mean gradient over the global batch: what the exchange delivered
+        if os.environ.get("EVERY_M") == "1":
+            torch.cuda.synchronize()
+            every_m.append(m._core._adam_m.cpu().clone())
 torch.cuda.synchronize()
 fused = bool(dp is not None and dp._last_fused)
 stats = dp.comm.stats() if fused else (0, 0)
@@ -269,7 +273,7 @@ if shards is not None and os.environ.get("GATHER_MASTERS") == "1":
     dp.shards.gather_masters()
     torch.cuda.synchronize()
 torch.save(dict(p=m.flat_params.cpu(), m=first_m, fused=fused, stats=stats, sparse=bool(fused and dp.comm.sparse), shards=shards,
-                p_before_gather=p_before, shadow=shadow),
+                p_before_gather=p_before, shadow=shadow, every_m=every_m),
            os.environ["OUT"] + ".%d.%d.%s" % (world, rank, os.environ.get("USE_DP", "1")))
 if use_dp:
     dist.barrier(); dist.destroy_process_group()
@@ -314,6 +318,39 @@ def test_single_call_dp_step_two_ranks_equal_one_process(tmp_path, kind, sparse,
     assert err <= 5e-6
     d = (a["p"] - ref["p"]).abs()
     assert float(d.max()) <= 2 * 1e-3 * 1.1
+
+
+@pytest.mark.parametrize("kind,event_mode,control", [("bert", "2", "0"), ("bert", "3", "0"), ("bert", "0", "0"), ("xlnet", "2", "0"),
+                                                     ("bert", "2", "1")])
+def test_single_call_dp_step_replayed_steps_with_a_delayed_backward(tmp_path, kind, event_mode, control):
+    """The compute -> comm hand-off of REPLAYED steps: lr = 0 so that the parameters stay put and Adam's first
+    moment after step s is a fixed function of the all-reduced gradients of steps 1..s (a different batch every step); every backward
+    segment starts with a 3 ms spin kernel (MB_DP_TEST_DELAY_US), so the host has issued the segment's collectives long before its
+    gradients exist.  Two ranks (4 + 4 samples) must match one process (8 samples) <= 5e-6 after EVERY one of 4 steps (steps 2-4
+    replay the captured graphs), for the event-record node (mode 2), the wait nodes (mode 3) and host-side records (mode 0).
+    control = 1 is the negative control: MB_DP_DEBUG=4 drops the comm stream's wait -- the same comparison must then FAIL, i.e.
+    this test does detect an exchange that runs ahead of the backward (round 4's plain hipEventRecord inside the capture did)."""
+    import torch
+    out = str(tmp_path / "dl")
+    common = dict(OUT=out, KIND=kind, MB_DP_SPARSE_EMB="1", MB_DP_CHUNK="1", LR="0", STEPS="4", EVERY_M="1")
+    _run_engine_workers(tmp_path, 1, common)
+    extra = dict(MB_DP_EVENT_MODE=event_mode, MB_DP_TEST_DELAY_US="3000")
+    if control == "1":
+        extra["MB_DP_DEBUG"] = "4"
+    _run_engine_workers(tmp_path, 2, dict(common, **extra))
+    ref = torch.load(out + ".1.0.1")
+    a, b = torch.load(out + ".2.0.1"), torch.load(out + ".2.1.1")
+    assert a["fused"] and b["fused"] and not ref["fused"] and len(a["every_m"]) == 4
+    errs = []
+    for s in range(4):
+        assert torch.equal(a["every_m"][s], b["every_m"][s]) or control == "1"
+        errs.append(float((a["every_m"][s] - ref["every_m"][s]).abs().max()) / float(ref["every_m"][s].abs().max()))
+    print("%s event mode %s%s: first-moment max |d| / max after steps 1..4 = %s" %
+          (kind, event_mode, " NEGATIVE CONTROL (no wait)" if control == "1" else "", ", ".join("%.2e" % e for e in errs)))
+    if control == "1":
+        assert max(errs) > 1e-3, "the negative control passed: this test cannot see a missing dependency"
+    else:
+        assert max(errs) <= 5e-6
 
 
 @pytest.mark.parametrize("cdt,graph", [("fp32", "1"), ("fp32", "0"), ("bf16", "1")])

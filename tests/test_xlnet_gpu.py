@@ -41,11 +41,14 @@ def tb(b, dev="cpu"):
     return t("input_ids"), t("visual"), t("acoustic"), t("input_mask"), t("segment_ids"), t("label_ids")
 
 
-def _grad_report(m, o, tol, frobenius=False):
+LOOSE_BF16 = ("MAG.W_hv", "MAG.W_ha", "MAG.W_v", "MAG.W_a")      # relu / clamp gated: single elements flip on a bf16 pre-activation
+
+
+def _grad_report(m, o, tol, frobenius=False, loose=(), tol_loose=None, show=0):
     og = {n: p.grad for n, p in o.named_parameters() if p.grad is not None}
     gmax = max(float(g.abs().max()) for g in og.values())
     gnorm = max(float(g.norm()) for g in og.values())
-    worst = (0.0, None)
+    rows = []
     for n, p in m.named_parameters():
         if n not in og:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
@@ -55,10 +58,14 @@ def _grad_report(m, o, tol, frobenius=False):
             rel = float((g - r).norm()) / max(float(r.norm()), 1e-3 * gnorm)
         else:
             rel = float((g - r).abs().max()) / max(float(r.abs().max()), 1e-3 * gmax)
-        if not rel <= worst[0]:
-            worst = (rel, n)
-    print("worst relative gradient error %.3e at %s" % worst)
-    assert worst[0] <= tol, worst
+        rows.append((rel if rel == rel else float("inf"), n))
+    rows.sort(reverse=True)
+    print("worst relative gradient error %.3e at %s" % rows[0])
+    for rel, n in rows[:show]:
+        print("    %.3e  %s" % (rel, n))
+    for rel, n in rows:
+        t = tol_loose if (tol_loose is not None and any(k in n for k in loose)) else tol
+        assert rel <= t, (rel, n, t)
 
 
 def test_state_dict_and_frozen_mask_emb():
@@ -310,20 +317,31 @@ class _SeqReplay(torch.nn.Module):
         return x * mlt
 
 
-@pytest.mark.parametrize("cdt,tol_logit,tol_grad,L", [(torch.float32, 1e-3, 5e-3, 24), (torch.bfloat16, 5e-2, 1e-1, 24),   # bf16 gradients: relative Frobenius error, dominated by relu / clamp flips in MAG (measured 7.7e-2 on W_hv)
-                                                       (torch.float32, 1e-3, 5e-3, 100)])                                      # ... and above the L = 64 kernel boundary
-def test_train_mode_dropout_mask_replay(cdt, tol_logit, tol_grad, L):
+@pytest.mark.parametrize("cdt,tol_logit,tol_grad,L,layers,B", [
+    (torch.float32, 1e-3, 5e-3, 24, 2, 3),
+    (torch.bfloat16, 5e-2, 1e-1, 24, 2, 3),      # bf16 gradients: relative Frobenius error, dominated by relu / clamp flips in MAG (measured 7.7e-2 on W_hv)
+    (torch.float32, 1e-3, 5e-3, 100, 2, 3),      # ... and above the L = 64 kernel boundary
+    (torch.bfloat16, 5e-2, 3e-2, 50, 12, 48),    # the shape bench.py's `secondary` line times: 12 layers, B=48, L=50 (one strip group, 50 -> 64 padding),
+    (torch.float32, 1e-3, 5e-3, 50, 12, 48)])    # bf16 (xl_attn_bwd_kv2_kernel) and fp32, through the FUSED training step
+def test_train_mode_dropout_mask_replay(cdt, tol_logit, tol_grad, L, layers, B):
     """Dropout ON at every site (0.1 hidden / attention / pos_emb / summary, MAG 0.5): device masks regenerated on the
-    host and replayed inside the oracle (which works in the reference's [L, B, .] layout) -> exact train-mode parity."""
-    layers, B, nh, H, DI = 2, 3, 12, 768, 3072
+    host and replayed inside the oracle (which works in the reference's [L, B, .] layout) -> exact train-mode parity.  The
+    per-(position, sample) mask of pos_emb (xlnet.py:332-333 drops the [2L, B, H] expansion) is part of the replay.  The 12-layer
+    legs run the fused training step (what train_epoch / bench.py call); the 2-layer legs the autograd route with attentions."""
+    nh, H, DI = 12, 768, 3072
+    full = layers == 12
     m = build(layers, cdt).train()
     o = oracle(layers).train()
     core = m._core
     b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=41)
     ids, vis, aco, mask, seg, lab = tb(b, DEV)
-    out = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None, output_attentions=True)
-    logits, att = out[0], out[1]
-    torch.nn.MSELoss()(logits.view(-1), lab.view(-1)).backward()
+    if full:
+        loss = m.training_step(ids, vis, aco, mask, seg, lab)
+        logits = att = None
+    else:
+        out = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None, output_attentions=True)
+        logits, att = out[0], out[1]
+        torch.nn.MSELoss()(logits.view(-1), lab.view(-1)).backward()
     seed, step = core.seed, core.step
     mult = lambda site, p, n: torch.from_numpy(rng.keep_mult(n, rng.make_key(seed, step, site, p)))
     blx = lambda site, p, Xd: mult(site, p, B * L * Xd).view(B, L, Xd).permute(1, 0, 2)        # engine [B,L,X] -> oracle [L,B,X]
@@ -337,16 +355,55 @@ def test_train_mode_dropout_mask_replay(cdt, tol_logit, tol_grad, L):
         lyr.ff.dropout = _SeqReplay([blx(s0 + 2, 0.1, DI), blx(s0 + 3, 0.1, H)])
     i2, v2, a2, m2, s2, l2 = tb(b)
     lo = o(i2, v2, a2, m2, s2)[0]
-    torch.nn.functional.mse_loss(lo.view(-1), l2.view(-1)).backward()
+    loss_o = torch.nn.functional.mse_loss(lo.view(-1), l2.view(-1))
+    loss_o.backward()
     torch.cuda.synchronize()
-    err = float((logits.detach().cpu() - lo.detach()).abs().max())
-    print("xlnet train-mode logits max|err|:", err)
-    assert err <= tol_logit
-    # output_attentions in train mode: the probabilities AFTER the (replayed) attention dropout
-    perr = max(float((att[l].cpu() - lyr.rel_attn.last_probs.detach()).abs().max()) for l, lyr in enumerate(o.transformer.layer))
-    print("xlnet train-mode attention probabilities max|err|:", perr)
-    assert perr <= (1e-5 if cdt == torch.float32 else 2e-2)
-    _grad_report(m, o, tol_grad, frobenius=(cdt == torch.bfloat16))
+    if full:
+        print("xlnet train-mode fused step %s: loss %.6f vs oracle %.6f" % (cdt, float(loss), float(loss_o)))
+        assert abs(float(loss) - float(loss_o)) <= (2e-5 if cdt == torch.float32 else 5e-3) * max(1.0, abs(float(loss_o)))
+    else:
+        err = float((logits.detach().cpu() - lo.detach()).abs().max())
+        print("xlnet train-mode logits max|err|:", err)
+        assert err <= tol_logit
+        # output_attentions in train mode: the probabilities AFTER the (replayed) attention dropout
+        perr = max(float((att[l].cpu() - lyr.rel_attn.last_probs.detach()).abs().max()) for l, lyr in enumerate(o.transformer.layer))
+        print("xlnet train-mode attention probabilities max|err|:", perr)
+        assert perr <= (1e-5 if cdt == torch.float32 else 2e-2)
+    _grad_report(m, o, tol_grad, frobenius=(cdt == torch.bfloat16), loose=LOOSE_BF16 if full else (), tol_loose=1e-1, show=6 if full else 0)
+
+
+@pytest.mark.parametrize("B,L", [(48, 50)])
+def test_training_step_bf16_full_model_vs_oracle(B, L):
+    """The MAG-XLNet configuration bench.py times (BASELINE configs[3]: 12 layers, bf16 perf mode, B=48, L=50, MOSI), one fused
+    training step with every dropout p = 0: loss within 2e-3, every gradient tensor within 3e-2 relative Frobenius error of the
+    fp32 CPU oracle (MAG's gated tensors 1e-1), the 13 per-layer hidden states within 2e-2.  (xl_attn_bwd_kv2_kernel is the bf16
+    L <= 64 key / position-side backward: this is its 12-layer check at the padded 50 -> 64 strip.)"""
+    m = build(12, torch.bfloat16, p_mag=0.0, p=0.0).train()
+    o = X.set_dropout(oracle(12, p_mag=0.0), 0.0, 0.0).train()
+    b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=71)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    loss = m.training_step(ids, vis, aco, mask, seg, lab)
+    hs = m._core.hidden_states(B, L)
+    hooks, ref_h = [], []
+    hooks.append(o.transformer.layer[0].register_forward_pre_hook(lambda mod, args: ref_h.append(args[0].detach())))
+    for lyr in o.transformer.layer:
+        hooks.append(lyr.register_forward_hook(lambda mod, args, out: ref_h.append(out.detach())))
+    i2, v2, a2, m2, s2, l2 = tb(b)
+    lo = F.mse_loss(o(i2, v2, a2, m2, s2)[0].view(-1), l2.view(-1))
+    lo.backward()
+    for h in hooks:
+        h.remove()
+    torch.cuda.synchronize()
+    print("xlnet bf16 B=%d L=%d: loss %.5f vs oracle %.5f" % (B, L, float(loss), float(lo)))
+    assert abs(float(loss) - float(lo)) <= 2e-3 * max(1.0, abs(float(lo)))
+    assert len(hs) == len(ref_h) == 13
+    worst = 0.0
+    for h, r in zip(hs, ref_h):                                # engine [B, L, H] vs oracle [L, B, H]
+        r = r.permute(1, 0, 2)
+        worst = max(worst, float((h.float().cpu() - r).norm() / r.norm()))
+    print("hidden states: worst relative Frobenius error over the 13 entries %.3e" % worst)
+    assert worst <= 2e-2
+    _grad_report(m, o, 3e-2, frobenius=True, loose=LOOSE_BF16, tol_loose=1e-1, show=6)
 
 
 def test_three_optimizer_steps_track_the_oracle_fp32():
