@@ -363,6 +363,143 @@ def secondary_workload(kind, dataset, B, L, steps=20, warmup=5, dtype="bf16"):
     return out
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start N ranks of this script, one per visible device,
+    on a free rendezvous port, and wait for them.  Rank 0 prints the JSON line (stdout is inherited).  Fewer devices than N is an
+    error, never a silent 1-GPU number -- except under MB_DIST_BACKEND=gloo, the callback backend of the one-GPU tests, where ranks
+    may share a device (the line then says so in `devices_visible`)."""
+    import socket
+    import subprocess
+    n = a.gpus
+    have = torch.cuda.device_count()
+    backend = os.environ.get("MB_DIST_BACKEND", "nccl")
+    if have < 1:
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the product path)")
+    if have < n and backend == "nccl":
+        raise SystemExit("bench.py --gpus %d: only %d device(s) visible; RCCL needs one device per rank (no silent fallback to fewer GPUs)" % (n, have))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % have), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MB_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:            # a rank that dies leaves the others inside a collective: stop them (exact PIDs) instead of hanging
+        time.sleep(0.2)
+        for p_ in list(alive):
+            code = p_.poll()
+            if code is None:
+                continue
+            alive.remove(p_)
+            if code != 0 and rc == 0:
+                rc = code
+                for q_ in alive:
+                    q_.terminate()
+    raise SystemExit(rc)
+
+
+def instep_trace(B, L, V, dtype, n_update, steps=10, warmup=3):
+    """A rocprofv3 kernel trace of the step, taken by bench.py itself: tools/bin/step_bench (the torch-free driver of the same
+    mb_bert_train_step call: prologue + one replayed hipGraph, batch gathered from pinned host memory) runs `steps` traced steps as a
+    subprocess; MB_GEMM_LOG=1 makes the library print, per GEMM launch, the kernel symbol and the FLOPs it was launched with, so every
+    symbol of the trace is priced against what it computed.  -> (per-kernel table like profiles/instep_kernels.json, roofline rows)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    sb = os.path.join(ROOT, "tools", "bin", "step_bench")
+    if not prof or not os.path.exists(sb):
+        return None, "rocprofv3 or tools/bin/step_bench missing"
+    d = tempfile.mkdtemp(prefix="mb_trace_", dir="/tmp")
+    cmd = [prof, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "sb", "--", sb, "--graph", "1", "--h2d", "2", "--steps", str(steps),
+           "--warmup", str(warmup), "--batch", str(B), "--seq", str(L), "--visual", str(V), "--dtype", dtype]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", MB_GEMM_LOG="1"), capture_output=True, text=True, timeout=150)
+    except Exception as ex:
+        shutil.rmtree(d, ignore_errors=True)
+        return None, "trace failed: %r" % (ex,)
+    took = time.perf_counter() - t0
+    path = None
+    for dp_, _, fs in os.walk(d):
+        for f in fs:
+            if f.endswith("kernel_trace.csv"):
+                path = os.path.join(dp_, f)
+    if r.returncode != 0 or path is None:
+        shutil.rmtree(d, ignore_errors=True)
+        return None, "trace failed (rc %d): %s" % (r.returncode, (r.stderr or "")[-300:])
+    rows = []
+    with open(path) as fh:
+        for x in csv.DictReader(fh):
+            rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), x["Kernel_Name"]))
+    shutil.rmtree(d, ignore_errors=True)
+    rows.sort()
+    ad = [i for i, x in enumerate(rows) if "adamw" in x[2] and "tail" not in x[2]]
+    ends = ad[1::2]                       # two AdamW launches end a step
+    if len(ends) < steps + 1:
+        return None, "trace too short (%d optimizer launches)" % len(ad)
+    seg = rows[ends[-steps - 1] + 1: ends[-1] + 1]
+    busy, cs, ce = 0, seg[0][0], seg[0][1]
+    for s_, e_, _ in seg[1:]:
+        if s_ > ce:
+            busy += ce - cs
+            cs, ce = s_, e_
+        else:
+            ce = max(ce, e_)
+    busy += ce - cs
+    agg = {}
+    for s_, e_, k in seg:
+        q = agg.setdefault(k, [0, 0])
+        q[0] += 1; q[1] += e_ - s_
+    # what each GEMM symbol computed (one log line per launch of every enqueue pass)
+    flops = {}
+    Tt, Tp = B * L, (B * L + 63) // 64 * 64
+    for line in (r.stderr or "").splitlines():
+        if not line.startswith("[magbert gemm] "):
+            continue
+        w = line.split()
+        kv = dict(t.split("=") for t in w[3:])
+        fl, K = float(kv["flop"]), int(kv["K"])
+        if K == Tp and Tp != Tt and "_tn_" in w[2]:
+            fl *= Tt / Tp                  # weight gradients run over the zero-padded token rows: algorithmic FLOPs count T
+        q = flops.setdefault(w[2], [0, 0.0])
+        q[0] += 1; q[1] += fl
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    ks = sorted(agg.items(), key=lambda kv_: -kv_[1][1])
+    table, roof = [], []
+    for k, (n, t) in ks[:24]:
+        short = k.split("(")[0][:110]
+        row = {"kernel": short, "launches_per_step": round(n / steps, 2), "avg_us": round(t / n / 1e3, 2), "ms_per_step": round(t / steps / 1e6, 4)}
+        table.append(row)
+        us = t / n / 1e3
+        f = flops.get(k) or flops.get(k.split("(")[0])
+        if f:
+            per = f[1] / f[0]
+            roof.append(dict(row, bound="mfma", flop_per_launch=per, achieved=round(per / us * 1e-6, 1), peak=peak, unit="TFLOP/s",
+                             frac=round(per / us * 1e-6 / peak, 4), gflop_per_step=round(per * n / steps * 1e-9, 2)))
+        elif "adamw" in k and "tail" not in k:
+            per = 28.0 * n_update / 2.0     # SURVEY 8(d): read p, g, m, v; write p, m, v -- the step's two launches share the sweep
+            roof.append(dict(row, bound="hbm", algorithmic_bytes_per_launch=int(per), achieved=round(per / us * 1e-3, 1), peak=8000.0, unit="GB/s",
+                             frac=round(per / us * 1e-3 / 8000.0, 4)))
+    doc = {"workload": "bert B=%d L=%d %s" % (B, L, dtype), "replayed": False,
+           "source": "rocprofv3 --kernel-trace run BY THIS bench.py invocation over tools/bin/step_bench --graph 1 --h2d 2 (the same "
+                     "mb_bert_train_step call, torch-free), last %d steps; %.1f s" % (steps, took),
+           "busy_ms_per_step": round(busy / steps / 1e6, 4), "kernels_per_step": round(len(seg) / steps, 1),
+           "busy_ms_per_step_is": "the sum of kernel durations UNDER THE PROFILER (a few percent above the untraced step: ms_per_step is the step)",
+           "kernels": table}
+    gemm_ms = sum(x["ms_per_step"] for x in roof if x["bound"] == "mfma")
+    gemm_gf = sum(x["gflop_per_step"] for x in roof if x["bound"] == "mfma")
+    if gemm_ms > 0:
+        doc["gemm_aggregate"] = {"ms_per_step": round(gemm_ms, 4), "gflop_per_step": round(gemm_gf, 1), "tflops": round(gemm_gf / gemm_ms, 1),
+                                 "frac": round(gemm_gf / gemm_ms / peak, 4), "note": "every GEMM symbol of the trace, in-step durations"}
+    return doc, roof
+
+
 def cpu_info():
     model = ""
     try:
@@ -384,6 +521,8 @@ def cpu_info():
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a)                     # (does not return)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -398,8 +537,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("MB_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
                                 **({"device_id": torch.device("cuda", local)} if os.environ.get("MB_DIST_BACKEND", "nccl") == "nccl" else {}))
-    if a.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d (using WORLD_SIZE)" % (a.gpus, world), file=sys.stderr)
+    if a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
 
     if a.roofline_only:
         rl = gemm_roofline(a.dtype, a.batch * a.seq)
@@ -440,6 +579,26 @@ def main():
     single_call = dp_call or (model._core.fused_step_blocker() is None and opt.flat_step_args(model._core) is not None)
     use_graph = None if not single_call else ((None if dp_call else True) if a.graph else "launches")
     graph_on = single_call and bool(a.graph)
+    rccl_ranks = None
+    if dp_call:                                      # the C-side exchange object is created collectively, at the latest here
+        model._core._ensure(B, L)
+        if dp.get_comm(B * L) is None:               # (RCCL could not be loaded / initialised: the Python-driven exchange runs)
+            dp_call = single_call = graph_on = False
+            use_graph = None
+    if dp_call:
+        # proof that the C-side communicator spans the ranks: an all-reduce(sum) of ones through mb_comm_all_reduce (the call the
+        # step's exchange is made of) on the comm stream, in place on the head of the (still all-zero) flat gradient buffer
+        from bert_multimodal_transformer_amd import _lib as _l
+        g = model._core.grads
+        g[:16].fill_(1.0)
+        torch.cuda.synchronize()
+        _l.check(_l.lib().mb_comm_all_reduce(dp.comm.handle, g.data_ptr(), 16, dp.comm.stream.cuda_stream))
+        dp.comm.stream.synchronize()
+        rccl_ranks = int(round(float(g[:16].sum().item()) / 16.0))
+        g[:16].zero_()
+        torch.cuda.synchronize()
+        if rccl_ranks != world:
+            raise SystemExit("bench.py: the gradient exchange spans %d rank(s), WORLD_SIZE is %d" % (rccl_ranks, world))
 
     def host_batches(n, start=0):
         for i in range(n):
@@ -581,6 +740,10 @@ def main():
                "host_call_ms_per_step": round(host_call_ms, 3),
                "step_ms_median": q(0.5), "step_ms_p10": q(0.1), "step_ms_p90": q(0.9),
                "value_inputs_resident": round(world * B / dt_res, 2)}
+        if dp is not None:
+            out["rccl_ranks"] = rccl_ranks
+            out["devices_visible"] = torch.cuda.device_count()
+            out["launched_by"] = "bench.py itself (one process per rank)" if os.environ.get("MB_BENCH_SPAWNED") == "1" else "external launcher"
         if comm_exposed_ms is not None:
             out["comm_exposed_ms"] = round(comm_exposed_ms, 4)
         if comm_stats is not None:
@@ -643,11 +806,35 @@ def main():
                         blk.setdefault("algorithmic_bytes", e.get("algorithmic_bytes"))
         except Exception:
             pass
-        # `roofline` = the kernel with the largest share of the step (launches x in-step duration); the other one rides along
+        # `roofline` = the kernel with the largest share of the step, chosen over EVERY symbol of a kernel trace this run takes itself
+        # (tools/bin/step_bench under rocprofv3, ~10 s): durations from the trace, FLOPs from the library's launch log, AdamW's bytes
+        # from SURVEY 8(d).  Without rocprofv3 / the driver binary: the two candidates timed by engine events above.
+        trace_doc = trace_roof = None
+        trace_note = "in-run trace only for the headline model (MAG-BERT)"
+        if a.model == "bert" and world == 1 and os.environ.get("MB_BENCH_TRACE", "1") != "0":
+            try:
+                trace_doc, trace_roof = instep_trace(B, L, V, a.dtype, int(model._core.n_update_end))
+            except Exception as ex:          # noqa: BLE001
+                trace_doc, trace_roof = None, "trace failed: %r" % (ex,)
+            if trace_doc is None:
+                trace_note, trace_roof = trace_roof, None
         cands = [c for c in (mfma, hbm) if c is not None]
-        top = max(cands, key=lambda c: c["ms_per_step"])
-        out["roofline"] = dict(top, dominant_by="ms_per_step (launches x in-step duration): " +
-                               ", ".join("%s %.3f ms" % (c["kernel"].split(" (")[0], c["ms_per_step"]) for c in cands))
+        if trace_roof:
+            top = dict(trace_roof[0])
+            top["dominant_by"] = "ms_per_step over all %d symbols of the in-run kernel trace: " % len(trace_doc["kernels"]) + \
+                                 ", ".join("%s %.3f ms (%.3f of %s peak)" % (c["kernel"][:48], c["ms_per_step"], c["frac"], c["bound"]) for c in trace_roof[:4])
+            top["timing"] = "rocprofv3 kernel trace taken by this run (in-step, graph replay), average over %d launches" % round(top["launches_per_step"] * 10)
+            top["traffic"] = None
+            for blk, key in ((mfma, "gemm2_grouped_tn_kernel"), (hbm, "adamw")):      # PMC bytes: replayed, for the two kernels a PMC pass exists for
+                if blk is not None and key in top["kernel"] and blk.get("traffic") is not None and ("Li128ELi128E" in top["kernel"] or key == "adamw"):
+                    for f_ in ("traffic", "traffic_unit", "traffic_replayed", "traffic_source"):
+                        top[f_] = blk.get(f_)
+            out["roofline"] = top
+            out["roofline_trace"] = trace_roof[:8]
+        else:
+            top = max(cands, key=lambda c: c["ms_per_step"])
+            out["roofline"] = dict(top, dominant_by="ms_per_step (launches x in-step duration) of the two engine-timed candidates (%s): " % trace_note +
+                                   ", ".join("%s %.3f ms" % (c["kernel"].split(" (")[0], c["ms_per_step"]) for c in cands))
         out["roofline_mfma"] = mfma
         if hbm is not None:
             out["roofline_adamw"] = hbm
@@ -659,12 +846,15 @@ def main():
                                  "kernels": [{k: r[k] for k in ("kernel", "avg_us", "tflops")} for r in rl]}
         out["roofline_hbm"] = {"peak_tb_per_s": 8.0, "timing": "HIP events over rotating operand sets, median of 9 spans per kernel",
                                "kernels": hbm_roofline(a.dtype, B, L, V, A)}
-        try:       # in-step per-kernel table (rocprofv3 --kernel-trace over this step), REPLAYED from the round's committed profiles
-            with open(os.path.join(ROOT, "profiles", "instep_kernels.json")) as fh:
-                ik = json.load(fh)
-            if ik.get("workload") == "%s B=%d L=%d %s" % (a.model, B, L, a.dtype):
+        try:       # in-step per-kernel table: this run's own trace, else REPLAYED from the round's committed profiles
+            if trace_doc is not None:
+                ik = trace_doc
+            else:
+                with open(os.path.join(ROOT, "profiles", "instep_kernels.json")) as fh:
+                    ik = json.load(fh)
                 ik["replayed"] = True
                 ik["busy_ms_per_step_is"] = "the sum of kernel durations UNDER THE PROFILER (a few percent above the untraced step: ms_per_step is the step)"
+            if ik.get("workload") == "%s B=%d L=%d %s" % (a.model, B, L, a.dtype):
                 out["instep_kernels"] = ik
                 # achieved HBM rate of the row kernels INSIDE the step (same trace): algorithmic bytes / in-step duration
                 es_, TH = (2 if a.dtype == "bf16" else 4), B * L * 768
@@ -687,7 +877,7 @@ def main():
                     rows.append({"kernel": "MAG forward, gate + weight pack launches only (its three GEMMs are in the GEMM rows)", "avg_us": round(mag_us, 2),
                                  "bytes": int(mag_bytes), "bytes_are": "algorithmic, SURVEY 8(d): %d B/token" % (mag_bytes // (B * L)),
                                  "tb_per_s": round(mag_bytes / mag_us * 1e-6, 3), "frac_of_8tbs": round(mag_bytes / mag_us * 1e-6 / 8.0, 4)})
-                out["roofline_hbm"]["instep_replayed"] = rows
+                out["roofline_hbm"]["instep_replayed" if ik.get("replayed") else "instep"] = rows
         except Exception:
             pass
     if a.secondary and rank == 0 and world == 1 and dp is None and a.model == "bert" and (B, L, a.dataset, a.dtype) == (48, 50, "mosi", "bf16"):

@@ -140,6 +140,12 @@ PROTOTYPES = {
     "mb_comm_bind_scratch": (_i, [_vp, _vp, _sz, _i, _sz, _i, _i, _i]),
     "mb_comm_all_reduce": (_i, [_vp, _vp, _sz, _vp]),
     "mb_comm_exchange_rows": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "mb_comm_set_row_exchange": (_i, [_vp, _i]),
+    "mb_comm_set_sharding": (_i, [_vp, _i]),
+    "mb_comm_sharding": (_i, [_vp]),
+    "mb_comm_join": (_i, [_vp, _vp]),
+    "mb_comm_gather_shards": (_i, [_vp, _vp, _i, _vp]),
+    "mb_comm_shard_slices": (_i, [_vp, C.POINTER(_sz), _i]),
     "mb_comm_set_timing": (_i, [_vp, _i]),
     "mb_comm_exposed_ms": (_i, [_vp, C.POINTER(_f)]),
     "mb_comm_stats": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),

@@ -183,7 +183,28 @@ class _Core(object):
         self._optional = (None, None, None, None)    # a new engine starts without head_mask / inputs_embeds / position_ids / perm_mask
         self.max_B, self.max_L = B, L
 
+    def _comm_join(self):
+        """sharded optimizer update under data parallel (distributed.Comm.set_sharding): the operands of this pass come back from the
+        other ranks by all-gathers on the comm stream -- the current stream waits for the last of them (a no-op otherwise)"""
+        comm = getattr(self, "_dp_comm", None)
+        if comm is not None and comm.sharding and comm.handle is not None:
+            _lib.check(self.lib.mb_comm_join(comm.handle, self.stream()))
+
+    def refresh_sharded_state(self, adam=True):
+        """sharded optimizer update: every rank holds current fp32 masters (and Adam moments) of ITS slices only; gather the rest
+        before anything reads the whole flat buffers (state_dict, checkpoints, sync_weights).  Collective: every rank must call it."""
+        comm = getattr(self, "_dp_comm", None)
+        if comm is None or not comm.sharding or comm.handle is None:
+            return
+        self._comm_join()
+        st = self.stream()
+        _lib.check(self.lib.mb_comm_gather_shards(comm.handle, _lib.ptr(self.params), 4, st))
+        if adam and hasattr(self, "_adam_m"):
+            _lib.check(self.lib.mb_comm_gather_shards(comm.handle, _lib.ptr(self._adam_m), 4, st))
+            _lib.check(self.lib.mb_comm_gather_shards(comm.handle, _lib.ptr(self._adam_v), 4, st))
+
     def _ensure(self, B, L):
+        self._comm_join()
         if B > self.max_B or L > self.max_L or self.ws is None:
             # "logically zero, physically stale" gradients are a fact only the OLD engine knows: make them real zeros before it goes
             self.materialize_grads()
@@ -239,6 +260,8 @@ class _Core(object):
 
     def sync_weights(self):
         """refresh bf16 shadow + packed MAG operands from the fp32 masters (after load / manual edits)"""
+        if self.dt == _lib.DT_BF16:
+            self.refresh_sharded_state(adam=False)       # (sharded update: the shadow must not be rebuilt from stale masters)
         with _Core._Hop(self):
             _lib.check(self._fn("sync_weights")(self.handle, self.stream()))
         self.weights_dirty = False
@@ -751,6 +774,11 @@ class _MagBertBase(nn.Module):
         self._core.weights_dirty = True
         return r
 
+    def state_dict(self, *args, **kwargs):
+        # sharded optimizer update under data parallel: a rank's fp32 masters outside its slices are stale until gathered
+        self._core.refresh_sharded_state()
+        return super().state_dict(*args, **kwargs)
+
     def init_weights(self):
         _init_weights(self._core)
 
@@ -855,6 +883,18 @@ class _FusedStep(object):
         Pass optimizer=None on gradient-accumulation micro-steps.  Returns the device loss scalar."""
         core = self._core
         dp = getattr(optimizer, "_dp", None) if optimizer is not None else None
+        mdp = getattr(self, "_dp", None)
+        if optimizer is None and mdp is not None and not mdp.sync and mdp.micro_ready() and graph is not False and \
+                os.environ.get("MB_OVERLAP_WGRAD", "0") in ("", "0"):
+            # gradient-accumulation micro-step of a data-parallel rank (multimodal_driver.py:375-376, 383): nothing is exchanged, so it is the
+            # plain single call without the optimizer (the backward accumulates); the exchange of the step that ends the window
+            # moves the word-embedding table densely (distributed.DataParallel._micro_since_sync)
+            launches = graph == "launches" or (graph is None and os.environ.get("MB_STEP_GRAPH", "1") == "0")
+            core.train_step(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, None, loss_scale=loss_scale,
+                            mode=2 if launches else 1)
+            mdp._micro_since_sync += 1
+            mdp._last_fused = True
+            return core.loss_buf[0]
         if dp is not None and graph is not False and dp.fused_ready() and core.kind in ("bert", "xlnet") and \
                 os.environ.get("MB_OVERLAP_WGRAD", "0") in ("", "0"):
             # data parallel: the same single call with the gradient exchange inside (mb_*_train_step_dp, distributed.Comm)
@@ -869,8 +909,10 @@ class _FusedStep(object):
                 opt["t"] = optimizer._t
                 optimizer._opt_called = True
                 launches = graph == "launches" or (graph is None and os.environ.get("MB_STEP_GRAPH", "1") == "0")
+                comm.set_row_exchange(dp._micro_since_sync == 0)     # after micro-steps: the union of their rows -> dense table
                 core.train_step(input_ids, visual, acoustic, attention_mask, token_type_ids, label_ids, opt, loss_scale=loss_scale,
                                 mode=2 if launches else 1, comm=comm)
+                dp._micro_since_sync = 0
                 dp._last_fused = True
                 return core.loss_buf[0]
         if dp is not None:

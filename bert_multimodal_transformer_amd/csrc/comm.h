@@ -34,12 +34,28 @@ struct mb_comm {
     //   2 = (default) the event is recorded by the LAST NODE of the segment's graph (dp_segment_end runs inside the capture): the
     //       graphs stay linear, nothing sits between two launches but the next launch;
     //   3 = ... and the optimizer segments start with wait nodes instead of stream waits (dp_segment_begin).
-    // Inside a capture the record MUST be hipEventRecordWithFlags(.., hipEventRecordExternal) and the wait hipStreamWaitEvent(..,
-    // hipEventWaitExternal): a plain hipEventRecord in a capturing stream only marks a dependency INSIDE the capture, adds no node and
-    // records nothing on replay (tools/event_capture_probe.cpp on ROCm 7.2: dependency held in 0 of 20 replays plain, 20 of 20
-    // external; profiles/r05_event_capture_probe.txt).  Round 4 shipped the plain form: its numbers above for modes 2 / 3 were
-    // measured WITHOUT the dependency.  dp_verify_segment_graph checks every captured segment for its event node.
+    // These nodes are ADDED TO THE CAPTURED GRAPH (hipGraphAddEventRecordNode / hipGraphAddEventWaitNode, dp_finish_segment_graph): a
+    // plain hipEventRecord in a capturing stream only marks a dependency INSIDE the capture, adds no node and records nothing on
+    // replay (tools/event_capture_probe.cpp: dependency held in 0 of 20 replays plain, 20 of 20 with a node;
+    // profiles/r05_event_capture_probe.txt), and the in-capture external form (hipEventRecordWithFlags) is refused by the HIP 7.0
+    // runtime a PyTorch process maps.  Round 4 shipped the plain form: its numbers above for modes 2 / 3 were measured WITHOUT the
+    // dependency (re-measured in profiles/r05_dp_event_modes.txt).
     int event_mode = 2;
+    // Gradient accumulation (multimodal_driver.py:375-376, 383-386): the step that follows micro-steps exchanges the word-embedding
+    // table densely -- the rows its gradient holds are the union over the micro-steps, not this step's ids (mb_comm_set_row_exchange)
+    bool rowwise = true;
+    // Sharded optimizer update (mb_comm_set_sharding; NEW relative to the reference, which runs one AdamW over everything:
+    // multimodal_driver.py:345, 384-386).  Every piece of layer GEMM weights the backward hands over (DpSpec::chunk) is cut into
+    // `world` equal slices: the piece is REDUCE-SCATTERED instead of all-reduced (half the wire bytes; every rank receives its slice
+    // of every piece, so all links carry every piece), each rank's AdamW covers its slices only (p, m, v of the other slices are not
+    // touched: 28 B/parameter of HBM traffic less for (world-1)/world of 77 % of the model), and the operands of the next forward --
+    // the bf16 shadow in bf16 mode, the fp32 parameters in parity mode -- come back by in-place all-gathers on the comm stream,
+    // issued behind the optimizer launch that produced them; the next step's first launch waits for the last of them (ev_gather).
+    // A remainder that does not divide by world x 256 elements stays replicated (all-reduced, updated by everyone).
+    bool shard = false, gather_pending = false;
+    hipEvent_t ev_gather = nullptr;
+    std::vector<std::pair<size_t, size_t>> shard_chunks;     // the chunks of the last sharded step (mb_comm_gather_shards)
+    size_t bytes_gathered = 0;
 };
 
 namespace mb {
@@ -55,7 +71,18 @@ struct DpSpec {
     size_t word_off = 0;                            // the [vocab][H] word-embedding gradient inside the tail (rows = 0: dense)
     int word_rows = 0, H = 0;
     const int64_t* ids = nullptr; int T = 0;        // token ids of this rank's batch (device): the rows it touched
+    char* gather_base = nullptr; int gather_es = 0; // sharded update: what the next forward reads of a chunk (bf16 shadow: 2 | fp32 parameters: 4)
 };
+
+// a chunk [b, e) of the flat buffers under the sharded update: this rank's slice, and the replicated remainder at the chunk's end
+struct ShardSlice { size_t per, mine_b, mine_e, rem_b, rem_e; };
+inline ShardSlice dp_shard_slice(const mb_comm* c, size_t b, size_t e) {
+    ShardSlice s;
+    s.per = (e - b) / (size_t)c->world / 256 * 256;          // slice boundaries on 1-KB marks (AdamW works on 16-byte quads)
+    s.mine_b = b + (size_t)c->rank * s.per; s.mine_e = s.mine_b + s.per;
+    s.rem_b = b + (size_t)c->world * s.per; s.rem_e = e;
+    return s;
+}
 
 // layers per backward segment of a data-parallel step: MB_DP_CHUNKS="4,4,2,2" (must add up to n_layer) | MB_DP_CHUNK=n (uniform) |
 // default: pieces of 4 layers (113 MB: few seams between the step's graphs) while the backward has plenty left to hide them, pieces of 2
@@ -69,9 +96,13 @@ int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st);
 // called by the engines at the head / at the end of every segment's kernel sequence (inside the capture when the step is captured)
 int dp_segment_begin(mb_comm* c, int nb, int seg, hipStream_t st);
 int dp_segment_end(mb_comm* c, int nb, int seg, hipStream_t st);
-// train_step_impl's post-capture check (tag = the mb_comm, nseg = nb + 2): in event modes 2 / 3 a backward segment's graph must END
-// with an event-record node, in mode 3 an optimizer segment's graph must START with a wait-event node; MB_ERR_MODE otherwise
-int dp_verify_segment_graph(const void* tag, int nseg, int seg, hipGraph_t graph);
+// train_step_impl's post-capture hook (tag = the mb_comm, nseg = nb + 2): in event modes 2 / 3 appends the event-record node to a
+// backward segment's graph, in mode 3 puts the wait-event node in front of an optimizer segment's graph, then checks the result
+// (MB_ERR_MODE if the hand-off nodes are not where they must be)
+int dp_finish_segment_graph(const void* tag, int nseg, int seg, hipGraph_t graph);
+
+// at the head of a data-parallel step: the stream waits for the previous step's all-gathers (sharded update)
+int dp_step_begin(mb_comm* c, hipStream_t st);
 
 // row-wise sum of a [vocab][H] fp32 table over the ranks (comm.hip): every rank touched the rows ids[0..T)
 int comm_exchange_rows(mb_comm* c, float* table, const int64_t* ids, int T, hipStream_t s);

@@ -40,6 +40,7 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -65,7 +66,7 @@ void load_rccl() {
     }
     if (!r.h) { snprintf(r.err, sizeof r.err, "librccl.so not found (%s)", dlerror()); return; }
 #define SYM(f) r.f = (decltype(r.f))dlsym(r.h, "nccl" #f); if (!r.f) { snprintf(r.err, sizeof r.err, "nccl" #f " missing in librccl"); return; }
-    SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllReduce) SYM(AllGather) SYM(GroupStart) SYM(GroupEnd) SYM(GetErrorString)
+    SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllReduce) SYM(AllGather) SYM(ReduceScatter) SYM(GroupStart) SYM(GroupEnd) SYM(GetErrorString)
 #undef SYM
 }
 int rccl_ready() {
@@ -159,6 +160,33 @@ int comm_all_reduce(mb_comm* c, float* g, size_t count, hipStream_t s) {
     return MB_ERR_COMM;
 }
 
+// sum over the ranks of g[0, world * per), delivered slice-wise: afterwards g[rank * per, (rank + 1) * per) holds the sum on this rank
+// (the other slices are dead).  In place.  The callback backend has no reduce-scatter: its all-reduce delivers a superset.
+static int comm_reduce_scatter(mb_comm* c, float* g, size_t per, hipStream_t s) {
+    if (per == 0) return MB_OK;
+    const size_t count = per * (size_t)c->world;
+    ++c->pieces; c->bytes_reduced += count * (c->wire == DT_BF16 ? 2 : 4) / 2;      // (half an all-reduce's traffic)
+    if (c->wire == DT_BF16) {
+        if (!c->scratch || count > c->n_params) return MB_ERR_ARG;
+        char* stage = c->scratch + c->off_stage;
+        char* mine = stage + (size_t)c->rank * per * 2;
+        CK(convert(DT_BF16, g, stage, count, s));
+        if (c->nccl) CK(nccl_rc(g_rccl.ReduceScatter(stage, mine, per, ncclBfloat16, ncclSum, (ncclComm_t)c->nccl, s), "ncclReduceScatter"));
+        else if (c->ar_cb) CK(c->ar_cb(c->ctx, stage, count, DT_BF16, (void*)s));
+        else return MB_ERR_COMM;
+        return widen(DT_BF16, mine, g + (size_t)c->rank * per, per, s);
+    }
+    if (c->nccl) return nccl_rc(g_rccl.ReduceScatter(g, g + (size_t)c->rank * per, per, ncclFloat, ncclSum, (ncclComm_t)c->nccl, s), "ncclReduceScatter");
+    if (c->ar_cb) return c->ar_cb(c->ctx, g, count, DT_F32, (void*)s);
+    return MB_ERR_COMM;
+}
+// in-place all-gather of the `world` slices of `per` elements (of `es` bytes) that start at element `b` of `base`
+static int comm_gather_slices(mb_comm* c, char* base, int es, size_t b, size_t per, hipStream_t s) {
+    if (per == 0) return MB_OK;
+    c->bytes_gathered += per * (size_t)es * (size_t)c->world;
+    return all_gather(c, base + b * (size_t)es, per * (size_t)es, s);
+}
+
 int comm_exchange_rows(mb_comm* c, float* table, const int64_t* ids, int T, hipStream_t s) {
     if (!c || !c->rows_ready || !table || !ids || T < 1 || T > c->cap || (c->H & 3)) return MB_ERR_ARG;
     const int world = c->world, cap = c->cap, vocab = c->vocab, H = c->H;
@@ -187,7 +215,8 @@ static int fork_to_comm(mb_comm* c, int seg, hipStream_t st) {
     static int dbg = -1;
     if (dbg < 0) { const char* v = getenv("MB_DP_DEBUG"); dbg = v ? atoi(v) : 0; }
     if (dbg == 4) return MB_OK;          // NEGATIVE CONTROL of the equality tests: the hand-off is dropped, the exchange races the backward
-    return (int)hipStreamWaitEvent(c->cs, ev, 0);
+    CK((int)hipStreamWaitEvent(c->cs, ev, 0));
+    return MB_OK;
 }
 // MB_DP_TEST_DELAY_US (tests only): every backward segment starts with a kernel that spins this long, so that the host has issued
 // the segment's collectives long before the segment's gradients exist -- a missing compute -> comm dependency then fails the
@@ -205,11 +234,17 @@ static bool is_capturing(hipStream_t st) {
     hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
     return hipStreamIsCapturing(st, &cst) == hipSuccess && cst == hipStreamCaptureStatusActive;
 }
+// which segments end with a hand-off to the comm stream: the backward segments; under the sharded update the two optimizer segments too
+// (their slices go out by all-gather)
+static bool hands_off(const mb_comm* c, int nb, int seg) { return seg < nb || (c->shard && seg < nb + 2); }
 int dp_segment_end(mb_comm* c, int nb, int seg, hipStream_t st) {
-    if (c->event_mode < 2 || seg >= nb) return MB_OK;
-    hipEvent_t ev = c->fork_ev[(size_t)seg % c->fork_ev.size()];
-    // captured: an EXTERNAL record = an event-record node that fires on every replay (a plain record would add no node at all)
-    return is_capturing(st) ? (int)hipEventRecordWithFlags(ev, st, hipEventRecordExternal) : (int)hipEventRecord(ev, st);
+    if (c->event_mode < 2 || !hands_off(c, nb, seg)) return MB_OK;
+    // captured: nothing here -- a plain hipEventRecord inside a capture adds NO node (it only orders captured work), and the external
+    // form (hipEventRecordWithFlags) is refused by the 7.0 runtime a PyTorch process maps; dp_finish_segment_graph appends the
+    // event-record node to the captured graph instead
+    if (is_capturing(st)) return MB_OK;
+    CK((int)hipEventRecord(c->fork_ev[(size_t)seg % c->fork_ev.size()], st));
+    return MB_OK;
 }
 int dp_segment_begin(mb_comm* c, int nb, int seg, hipStream_t st) {
     if (seg < nb && test_delay_us() > 0) {
@@ -217,36 +252,62 @@ int dp_segment_begin(mb_comm* c, int nb, int seg, hipStream_t st) {
         CK((int)hipGetLastError());
     }
     if (c->event_mode < 3 || seg < nb) return MB_OK;
-    hipEvent_t ev = seg == nb ? (nb > 1 ? c->ev_layers : c->ev_tail) : c->ev_tail;
-    return (int)hipStreamWaitEvent(st, ev, is_capturing(st) ? hipEventWaitExternal : 0);
+    if (is_capturing(st)) return MB_OK;          // (dp_finish_segment_graph puts the wait node in front of the captured sequence)
+    CK((int)hipStreamWaitEvent(st, seg == nb ? (nb > 1 ? c->ev_layers : c->ev_tail) : c->ev_tail, 0));
+    return MB_OK;
 }
-int dp_verify_segment_graph(const void* tag, int nseg, int seg, hipGraph_t graph) {
-    const mb_comm* c = (const mb_comm*)tag;
+// After the capture of segment `seg` (train_step_impl's hook; tag = the mb_comm, nseg = nb + 2): the hand-off events become NODES of
+// the segment's graph -- event modes 2 / 3: a backward segment ENDS with an event-record node of its fork event (the comm stream's
+// hipStreamWaitEvent, issued right behind the graph launch, then waits for this replay's record); mode 3: an optimizer segment
+// STARTS with a wait-event node on the comm stream's "pieces enqueued" event.  The graph stays a linear chain.  Then the result is
+// checked: exactly one such node, at the right end (tools/event_capture_probe.cpp is the stand-alone demonstration that these
+// nodes order a replay against another stream, and that a record issued inside the capture does not).
+int dp_finish_segment_graph(const void* tag, int nseg, int seg, hipGraph_t graph) {
+    mb_comm* c = (mb_comm*)tag;
     if (!c || c->event_mode < 2) return MB_OK;
     const int nb = nseg - 2;
-    size_t n = 0;
-    CK((int)hipGraphGetNodes(graph, nullptr, &n));
-    std::vector<hipGraphNode_t> nodes(n);
-    if (n) CK((int)hipGraphGetNodes(graph, nodes.data(), &n));
-    int records = 0, waits = 0, record_is_leaf = 0, wait_is_root = 0;
+    auto nodes_of = [&](std::vector<hipGraphNode_t>& v) -> int {
+        size_t n = 0;
+        CK((int)hipGraphGetNodes(graph, nullptr, &n));
+        v.resize(n);
+        if (n) CK((int)hipGraphGetNodes(graph, v.data(), &n));
+        return MB_OK;
+    };
+    std::vector<hipGraphNode_t> nodes;
+    CK(nodes_of(nodes));
+    if (hands_off(c, nb, seg)) {
+        std::vector<hipGraphNode_t> leaves;
+        for (auto nd : nodes) { size_t nout = 0; CK((int)hipGraphNodeGetDependentNodes(nd, nullptr, &nout)); if (nout == 0) leaves.push_back(nd); }
+        hipGraphNode_t rec = nullptr;
+        CK((int)hipGraphAddEventRecordNode(&rec, graph, leaves.data(), leaves.size(), c->fork_ev[(size_t)seg % c->fork_ev.size()]));
+    }
+    if (seg >= nb && c->event_mode >= 3) {
+        size_t nr = 0;
+        CK((int)hipGraphGetRootNodes(graph, nullptr, &nr));
+        std::vector<hipGraphNode_t> roots(nr);
+        if (nr) CK((int)hipGraphGetRootNodes(graph, roots.data(), &nr));
+        hipGraphNode_t wn = nullptr;
+        CK((int)hipGraphAddEventWaitNode(&wn, graph, nullptr, 0, seg == nb ? (nb > 1 ? c->ev_layers : c->ev_tail) : c->ev_tail));
+        for (auto r : roots) CK((int)hipGraphAddDependencies(graph, &wn, &r, 1));
+    }
+    // verification
+    CK(nodes_of(nodes));
+    int records = 0, waits = 0, record_is_leaf = 0, wait_is_root = 0, leaves = 0, roots = 0;
     for (auto nd : nodes) {
         hipGraphNodeType t;
         CK((int)hipGraphNodeGetType(nd, &t));
         size_t nout = 0, nin = 0;
-        if (t == hipGraphNodeTypeEventRecord) {
-            ++records;
-            CK((int)hipGraphNodeGetDependentNodes(nd, nullptr, &nout));
-            record_is_leaf += nout == 0;
-        } else if (t == hipGraphNodeTypeWaitEvent) {
-            ++waits;
-            CK((int)hipGraphNodeGetDependencies(nd, nullptr, &nin));
-            wait_is_root += nin == 0;
-        }
+        CK((int)hipGraphNodeGetDependentNodes(nd, nullptr, &nout));
+        CK((int)hipGraphNodeGetDependencies(nd, nullptr, &nin));
+        leaves += nout == 0; roots += nin == 0;
+        if (t == hipGraphNodeTypeEventRecord) { ++records; record_is_leaf += nout == 0; }
+        if (t == hipGraphNodeTypeWaitEvent) { ++waits; wait_is_root += nin == 0; }
     }
-    const bool ok = seg < nb ? (records == 1 && record_is_leaf == 1) : (c->event_mode < 3 || (waits == 1 && wait_is_root == 1));
+    const bool ok = (!hands_off(c, nb, seg) || (records == 1 && record_is_leaf == 1 && leaves == 1)) &&
+                    (seg < nb || c->event_mode < 3 || (waits == 1 && wait_is_root == 1 && roots == 1));
     if (!ok) {
-        snprintf(g_last_error, sizeof g_last_error, "data-parallel segment %d of %d: captured graph has %d event-record / %d wait-event "
-                 "nodes (event mode %d): the hand-off to the comm stream would not be ordered", seg, nseg, records, waits, c->event_mode);
+        snprintf(g_last_error, sizeof g_last_error, "data-parallel segment %d of %d: graph has %d event-record / %d wait-event nodes, %d leaves, "
+                 "%d roots (event mode %d): the hand-off to the comm stream would not be ordered", seg, nseg, records, waits, leaves, roots, c->event_mode);
         return MB_ERR_MODE;
     }
     return MB_OK;
@@ -294,20 +355,33 @@ int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st) 
     if (dbg == 1) return MB_OK;
     const int nb = (int)sp.chunk.size();
     auto piece = [&](size_t b, size_t e) -> int { return (dbg == 2 || e <= b) ? MB_OK : comm_all_reduce(c, G + b, e - b, c->cs); };
-    if (seg == 0) { c->pieces = 0; c->bytes_reduced = 0; c->tev_used[0] = c->tev_used[1] = false; }
+    // a chunk of layer GEMM weights: all-reduced, or -- sharded update -- reduce-scattered slice-wise (+ its replicated remainder)
+    auto chunk_piece = [&](int k) -> int {
+        const size_t b = sp.chunk[k].first, e = sp.chunk[k].second;
+        if (!c->shard) return piece(b, e);
+        const ShardSlice sl = dp_shard_slice(c, b, e);
+        if (dbg != 2) CK(comm_reduce_scatter(c, G + b, sl.per, c->cs));
+        return piece(sl.rem_b, sl.rem_e);
+    };
+    auto gather_chunk = [&](int k) -> int {
+        if (dbg == 2 || !sp.gather_base) return MB_OK;
+        const ShardSlice sl = dp_shard_slice(c, sp.chunk[k].first, sp.chunk[k].second);
+        return comm_gather_slices(c, sp.gather_base, sp.gather_es, sp.chunk[k].first, sl.per, c->cs);
+    };
+    if (seg == 0) { c->pieces = 0; c->bytes_reduced = 0; c->bytes_gathered = 0; c->tev_used[0] = c->tev_used[1] = false; if (c->shard) c->shard_chunks = sp.chunk; }
     if (seg < nb - 1) {
         CK(fork_to_comm(c, seg, st));
-        return piece(sp.chunk[seg].first, sp.chunk[seg].second);
+        return chunk_piece(seg);
     }
     if (seg == nb - 1) {
         CK((int)hipEventRecord(c->ev_layers, c->cs));          // every early piece is in front of this
         CK(fork_to_comm(c, seg, st));
-        CK(piece(sp.chunk[seg].first, sp.chunk[seg].second));
+        CK(chunk_piece(seg));
         const size_t w0 = sp.word_off, w1 = sp.word_off + (size_t)sp.word_rows * sp.H;
         // (a batch beyond the agreed row capacity is an error, never a silent switch to the dense piece: the ranks must issue the
         //  same collectives in the same order)
-        if (sp.word_rows > 0 && c->rows_ready && sp.T > c->cap) return MB_ERR_SHAPE;
-        if (sp.word_rows > 0 && c->rows_ready && sp.word_rows == c->vocab && sp.H == c->H && w0 >= sp.tail_begin && w1 <= sp.tail_end) {
+        if (sp.word_rows > 0 && c->rows_ready && c->rowwise && sp.T > c->cap) return MB_ERR_SHAPE;
+        if (sp.word_rows > 0 && c->rows_ready && c->rowwise && sp.word_rows == c->vocab && sp.H == c->H && w0 >= sp.tail_begin && w1 <= sp.tail_end) {
             CK(piece(sp.tail_begin, w0));
             if (dbg < 2) CK(comm_exchange_rows(c, G + w0, sp.ids, sp.T, c->cs));
             CK(piece(w1, sp.tail_end));
@@ -319,7 +393,28 @@ int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st) 
         // (a one-segment backward has no early range: its next segment updates part of the late ones, so it waits for everything)
         return wait_timed(c, 0, nb > 1 ? c->ev_layers : c->ev_tail, st);
     }
-    if (seg == nb) return wait_timed(c, 1, c->ev_tail, st);
+    if (seg == nb) {
+        // sharded update: the slices the first optimizer launch produced (the early chunks) go out while the second one runs, the
+        // lowest layers first (the next forward needs them in that order)
+        if (c->shard && nb > 1) {
+            CK(fork_to_comm(c, seg, st));
+            for (int k = nb - 2; k >= 0; --k) CK(gather_chunk(k));
+        }
+        return wait_timed(c, 1, c->ev_tail, st);
+    }
+    if (seg == nb + 1 && c->shard) {
+        CK(fork_to_comm(c, seg, st));
+        CK(gather_chunk(nb - 1));
+        CK((int)hipEventRecord(c->ev_gather, c->cs));
+        c->gather_pending = true;
+    }
+    return MB_OK;
+}
+
+int dp_step_begin(mb_comm* c, hipStream_t st) {
+    if (!c->gather_pending) return MB_OK;
+    c->gather_pending = false;
+    CK((int)hipStreamWaitEvent(st, c->ev_gather, 0));
     return MB_OK;
 }
 
@@ -349,6 +444,7 @@ static int comm_common_init(mb_comm* c) {
     for (auto& ev : c->fork_ev) CK((int)hipEventCreateWithFlags(&ev, flags));
     CK((int)hipEventCreateWithFlags(&c->ev_layers, flags));
     CK((int)hipEventCreateWithFlags(&c->ev_tail, flags));
+    CK((int)hipEventCreateWithFlags(&c->ev_gather, flags));
     for (auto& ev : c->tev) CK((int)hipEventCreate(&ev));
     return MB_OK;
 }
@@ -385,6 +481,7 @@ void mb_comm_destroy(mb_comm* c) {
     for (auto ev : c->fork_ev) if (ev) hipEventDestroy(ev);
     if (c->ev_layers) hipEventDestroy(c->ev_layers);
     if (c->ev_tail) hipEventDestroy(c->ev_tail);
+    if (c->ev_gather) hipEventDestroy(c->ev_gather);
     for (auto ev : c->tev) if (ev) hipEventDestroy(ev);
     if (c->cs) hipStreamDestroy(c->cs);
     delete c;
@@ -428,6 +525,43 @@ int mb_comm_all_reduce(mb_comm* c, float* buf, size_t count, void* stream) {
 }
 int mb_comm_exchange_rows(mb_comm* c, float* table, const int64_t* ids, int T, void* stream) {
     return comm_exchange_rows(c, table, ids, T, (hipStream_t)stream);
+}
+
+int mb_comm_set_row_exchange(mb_comm* c, int rowwise) {
+    if (!c) return MB_ERR_ARG;
+    c->rowwise = rowwise != 0;
+    return MB_OK;
+}
+int mb_comm_set_sharding(mb_comm* c, int on) {
+    if (!c) return MB_ERR_ARG;
+    if (on && c->gather_pending) return MB_ERR_MODE;
+    c->shard = on != 0 && c->world > 1;
+    return MB_OK;
+}
+int mb_comm_sharding(const mb_comm* c) { return (c && c->shard) ? 1 : 0; }
+int mb_comm_join(mb_comm* c, void* stream) {
+    if (!c) return MB_ERR_ARG;
+    return dp_step_begin(c, (hipStream_t)stream);
+}
+int mb_comm_gather_shards(mb_comm* c, void* base, int elem_bytes, void* stream) {
+    if (!c || !base || (elem_bytes != 2 && elem_bytes != 4)) return MB_ERR_ARG;
+    if (!c->shard) return MB_OK;
+    hipStream_t st = (hipStream_t)stream;
+    for (const auto& ch : c->shard_chunks) {
+        const ShardSlice sl = dp_shard_slice(c, ch.first, ch.second);
+        CK(comm_gather_slices(c, (char*)base, elem_bytes, ch.first, sl.per, st));
+    }
+    return MB_OK;
+}
+int mb_comm_shard_slices(const mb_comm* c, size_t* begin_end_pairs, int max_pairs) {
+    if (!c || !begin_end_pairs) return 0;
+    int n = 0;
+    for (const auto& ch : c->shard_chunks) {
+        if (n >= max_pairs) break;
+        const ShardSlice sl = dp_shard_slice(c, ch.first, ch.second);
+        begin_end_pairs[2 * n] = sl.mine_b; begin_end_pairs[2 * n + 1] = sl.mine_e; ++n;
+    }
+    return n;
 }
 
 int mb_comm_set_timing(mb_comm* c, int on) {

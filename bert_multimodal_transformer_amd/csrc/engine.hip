@@ -825,8 +825,34 @@ int mb_bert_train_step(mb_bert_engine* e, const int64_t* input_ids, const float*
 //                 reduction)                 -> between: all-reduce of those layers' GEMM weights (the last one: + the tail's exchange)
 //   nb          : AdamW over the GEMM weights of every layer but the last segment's   (waits for the early pieces only)
 //   nb + 1      : AdamW over the last segment's layers, the rest of the decay slab and the no-decay slab   (waits for everything)
-static int enqueue_step_dp(mb_bert_engine* e, int seg, const std::vector<int>& plan, int B, int L, float* logits, float* loss, float* loss_run,
-                           float* m, float* v, float loss_scale, hipStream_t st) {
+// AdamW over [b, en) of the decay slab inside a data-parallel step.  Sharded update (comm->shard): of every chunk of layer GEMM weights
+// inside the range only this rank's slice and the replicated remainder are updated (csrc/comm.h: dp_shard_slice); the other slices'
+// gradient copies were not reduced here -- they are dead, and cleared unless the next backward overwrites them anyway.
+static int adamw_decay_range_dp(mb_bert_engine* e, const mb_comm* comm, const DpSpec& sp, float* m, float* v, size_t b, size_t en, hipStream_t st) {
+    if (!comm->shard) return adamw_decay_range(e, m, v, b, en, st);
+    std::vector<std::pair<size_t, size_t>> ch(sp.chunk);
+    std::sort(ch.begin(), ch.end());
+    size_t cur = b;
+    ZeroRanges dead = {};
+    for (const auto& c : ch) {
+        if (c.second <= cur || c.first >= en) continue;
+        if (c.first < cur || c.second > en) return MB_ERR_MODE;          // (ranges are unions of whole chunks)
+        CK(adamw_decay_range(e, m, v, cur, c.first, st));
+        const ShardSlice sl = dp_shard_slice(comm, c.first, c.second);
+        CK(adamw_decay_range(e, m, v, sl.mine_b, sl.mine_e, st));
+        CK(adamw_decay_range(e, m, v, sl.rem_b, sl.rem_e, st));
+        if (!e->keep_in_step()) {
+            dead.add(e->G + c.first, (sl.mine_b - c.first) * 4);
+            dead.add(e->G + sl.mine_e, (sl.rem_b - sl.mine_e) * 4);
+        }
+        cur = c.second;
+    }
+    if (dead.n) CK(zero_fill_ranges(dead, st));
+    return adamw_decay_range(e, m, v, cur, en, st);
+}
+
+static int enqueue_step_dp(mb_bert_engine* e, int seg, const std::vector<int>& plan, const mb_comm* comm, const DpSpec& sp, int B, int L,
+                           float* logits, float* loss, float* loss_run, float* m, float* v, float loss_scale, hipStream_t st) {
     char* ws = e->ws;
     const int NL = e->c.num_layers, nb = (int)plan.size();
     const float* lab = (const float*)(ws + e->ws_in_lab);
@@ -849,11 +875,11 @@ static int enqueue_step_dp(mb_bert_engine* e, int seg, const std::vector<int>& p
     const size_t split = e->lo[plan[nb - 1] < NL ? plan[nb - 1] : 0].wqkv;      // first GEMM weight of the layers reduced early
     if (seg == nb) {
         CK(e->prof_mark(2 * NL, st));
-        if (nb > 1) return adamw_decay_range(e, m, v, split, e->wp, st);
+        if (nb > 1) return adamw_decay_range_dp(e, comm, sp, m, v, split, e->wp, st);
         // (one backward segment: no early range -- dp_between waited for everything -- so this segment takes the no-decay slab)
         return adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1);
     }
-    CK(adamw_decay_range(e, m, v, 0, nb > 1 ? split : e->wp, st));
+    CK(adamw_decay_range_dp(e, comm, sp, m, v, 0, nb > 1 ? split : e->wp, st));
     CK(adamw_decay_range(e, m, v, e->wp, nd, st));
     if (nb > 1) CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
     return e->prof_mark(2 * NL + 1, st);
@@ -883,21 +909,30 @@ int mb_bert_train_step_dp(mb_bert_engine* e, const int64_t* input_ids, const flo
     sp.tail_begin = e->wp; sp.tail_end = e->n_params;
     sp.word_off = e->word; sp.word_rows = c.vocab_size; sp.H = c.hidden_size;
     sp.ids = (const int64_t*)(e->ws + e->ws_in_ids); sp.T = B * L;
+    if (comm->shard) {
+        // what the next forward reads of a layer's GEMM weights: their bf16 shadow (bf16 mode) or the fp32 parameters themselves
+        const bool bf = c.dtype == DT_BF16;
+        for (const auto& ch : sp.chunk)
+            if (bf && (!e->SH || ch.first < e->sh_begin || ch.second > e->sh_end)) return MB_ERR_MODE;
+        sp.gather_base = bf ? (char*)e->SH : (char*)e->P; sp.gather_es = bf ? 2 : 4;
+    }
+    CK(dp_step_begin(comm, st));          // (sharded update: the previous step's all-gathers)
     e->training = 1;
     CK(prepare_pass(e, B * L, st));
     // (the plan is part of the graphs' identity: nseg alone would not tell 4,4,2,2 from 2,2,4,4)
     int variant = 1;
     for (int x : plan) variant = variant * 13 + x;
-    variant = variant * 4 + comm->event_mode;
+    variant = (variant * 4 + comm->event_mode) * 2 + (comm->shard ? 1 : 0);
     return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
                            labels, B, L, seed, step, logits, loss, loss_run, m, v, lr, beta1, beta2, eps, weight_decay, opt_step,
                            correct_bias, grad_scale, loss_scale, mode, e->prof, st,
                            [&](int sg, float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
                                CK(dp_segment_begin(comm, nb, sg, s));
-                               CK(enqueue_step_dp(e, sg, plan, B, L, lg, ls, lr_, m_, v_, sc, s));
-                               return dp_segment_end(comm, nb, sg, s);
+                               CK(enqueue_step_dp(e, sg, plan, comm, sp, B, L, lg, ls, lr_, m_, v_, sc, s));
+                               CK(dp_segment_end(comm, nb, sg, s));
+                               return (int)MB_OK;
                            },
-                           nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant, comm, dp_verify_segment_graph);
+                           nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant, comm, dp_finish_segment_graph);
 }
 
 // ------------------------------------------------------------------------------------------------ stage-driven step (data parallel)

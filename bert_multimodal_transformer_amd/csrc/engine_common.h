@@ -428,10 +428,11 @@ inline int train_step_impl(E* e, char* ws, int V, int A, int num_labels, const v
             const int r = enqueue(sg, logits, loss, loss_run, m, v, loss_scale, cs);
             e->dyn = false; e->capturing = false;
             const int r2 = (int)hipStreamEndCapture(cs, &gr);
-            if (r || r2) { if (gr) hipGraphDestroy(gr); ng.destroy(); return r ? r : r2; }
-            if (verify) { const int rv = verify(tag, nseg, sg, gr); if (rv) { hipGraphDestroy(gr); ng.destroy(); return rv; } }
+            if (r || r2) { mb::ck_trace(r ? "enqueue(segment) inside the capture" : "hipStreamEndCapture", __FILE__, __LINE__, r ? r : r2);
+                           if (gr) hipGraphDestroy(gr); ng.destroy(); return r ? r : r2; }
+            if (verify) { const int rv = verify(tag, nseg, sg, gr); if (rv) { mb::ck_trace("finish(segment graph)", __FILE__, __LINE__, rv); hipGraphDestroy(gr); ng.destroy(); return rv; } }
             const int r3 = (int)hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
-            if (r3) { hipGraphDestroy(gr); ng.destroy(); return r3; }
+            if (r3) { mb::ck_trace("hipGraphInstantiate", __FILE__, __LINE__, r3); hipGraphDestroy(gr); ng.destroy(); return r3; }
             ng.graph.push_back(gr); ng.exec.push_back(ex);
         }
         e->graphs.push_back(ng);

@@ -1036,6 +1036,21 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
+// MB_GEMM_LOG=1: one stderr line per GEMM launch -- kernel symbol (as a kernel trace prints it), number of problems, launch FLOPs and
+// the first problem's M N K -- so that a profile's per-symbol durations can be priced against what the symbol actually computed
+// (bench.py's in-run trace: a captured step logs each of its launches once)
+static int g_gemm_log = -1;
+static void gemm_log(const void* fn, hipStream_t st, const GemmArgs* p, int count) {
+    if (g_gemm_log < 0) g_gemm_log = env_int("MB_GEMM_LOG", 0);
+    if (!g_gemm_log) return;
+    double fl = 0.0;
+    for (int i = 0; i < count; ++i) fl += 2.0 * (double)p[i].M * (double)p[i].N * (double)p[i].K;
+    const char* name = hipKernelNameRefByPtr(fn, st);
+    fprintf(stderr, "[magbert gemm] %s problems=%d flop=%.0f M=%d N=%d K=%d\n", name ? name : "?", count, fl, p[0].M, p[0].N, p[0].K);
+}
+#define MB_GEMM_LAUNCH(KERN, grid, block, st, arg, plog, cnt) \
+    do { gemm_log((const void*)(KERN), st, plog, cnt); hipLaunchKernelGGL((KERN), grid, block, 0, st, arg); } while (0)
+
 static unsigned long long* g_trace = nullptr;       // MB_GEMM_TRACE=1: device buffer of phase stamps, [kTraceBlocks][8]
 static int g_trace_on = -1, g_trace_blocks = 0;
 constexpr int kTraceBlocks = 8192 * 8 / kTraceStride;
@@ -1100,7 +1115,7 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
         // 8-wave single-round kernel (bf16, row-major A): anything it cannot take goes to the 128 x 128 configuration
         if constexpr (sizeof(T) == 2 && !AK && BN == 128) {
             if (v2ok && splits == 1) {
-                hipLaunchKernelGGL((gemm2_kernel<T, 256, 128, AK, BK, MODE, 3, 128, false, 8>), grid, dim3(512), 0, st, p);
+                MB_GEMM_LAUNCH((gemm2_kernel<T, 256, 128, AK, BK, MODE, 3, 128, false, 8>), grid, dim3(512), st, p, &p, 1);
                 return (int)hipGetLastError();
             }
         }
@@ -1114,7 +1129,7 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
         // the two-slot bf16 loop is a software pipeline with its last two stages peeled: a k range of a single stage takes the
         // three-slot kernel (plain loop)
         if (sizeof(T) == 2 && ns <= 2 && p.kchunk / (kb / (int)sizeof(T)) < 2) ns = 3;
-#define MB_LAUNCH2(NS, KBV) hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, NS, KBV>), grid, dim3(256), 0, st, p)
+#define MB_LAUNCH2(NS, KBV) MB_GEMM_LAUNCH((gemm2_kernel<T, BM, BN, AK, BK, MODE, NS, KBV>), grid, dim3(256), st, p, &p, 1)
         static int g_ks = -1;             // MB_GEMM_KSPLIT: 1 = k-split waves for the 64 x 64 bf16 tiles (rounds 2-3), 0 (default) = quarter tiles
         if (g_ks < 0) g_ks = env_int("MB_GEMM_KSPLIT", 0);
         if constexpr (BM == 64 && BN == 64 && sizeof(T) == 2) {
@@ -1122,7 +1137,7 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
             // enough to amortise the four-tile epilogue (K = 768: 3 stages, measured 10.8 vs 9.8 us); beyond that
             // (T = 4096: 768 tiles) the 32 KB quarter-tile kernel's higher residency wins (measured: 7.30 vs 7.97 ms per step)
             if (g_ks && g_stages <= 0 && p.kchunk % 128 == 0 && p.kchunk >= 1024 && splits == 1 && tiles <= 512) {
-                hipLaunchKernelGGL((gemm2_kernel<T, BM, BN, AK, BK, MODE, 2, 256, true>), grid, dim3(256), 0, st, p);
+                MB_GEMM_LAUNCH((gemm2_kernel<T, BM, BN, AK, BK, MODE, 2, 256, true>), grid, dim3(256), st, p, &p, 1);
                 return (int)hipGetLastError();
             }
             // Round 4 (late): every 64 x 64 launch of at most 512 tiles takes the quarter-tile kernel with a THREE-slot ring of 128-byte
@@ -1143,7 +1158,7 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
         }
 #undef MB_LAUNCH2
     } else {
-        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, AK, BK, MODE>), grid, dim3(256), 0, st, p);
+        MB_GEMM_LAUNCH((gemm_kernel<T, BM, BN, AK, BK, MODE>), grid, dim3(256), st, p, &p, 1);
     }
     return (int)hipGetLastError();
 }
@@ -1252,17 +1267,17 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st, int 
     // costs one memory round trip divided by the stages in flight.  4 | 5 ring slots of 128-byte rows = 64 | 80 KB, still 2 blocks
     // per CU.  (The 128 x 128 groups measured slower with any deeper ring: 128 KB would leave one block per CU.)
     if constexpr (BM == 64 && BN == 64) {
-        if (gst == 4) { hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 4, 128>), dim3(grid), dim3(256), 0, st, ga); return (int)hipGetLastError(); }
-        if (gst == 5) { hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 5, 128>), dim3(grid), dim3(256), 0, st, ga); return (int)hipGetLastError(); }
+        if (gst == 4) { MB_GEMM_LAUNCH((gemm2_grouped_tn_kernel<T, BM, BN, 4, 128>), dim3(grid), dim3(256), st, ga, ga.g, count); return (int)hipGetLastError(); }
+        if (gst == 5) { MB_GEMM_LAUNCH((gemm2_grouped_tn_kernel<T, BM, BN, 5, 128>), dim3(grid), dim3(256), st, ga, ga.g, count); return (int)hipGetLastError(); }
     }
     if (gst == 24) {
-        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 4, 64>), dim3(grid), dim3(256), 0, st, ga);
+        MB_GEMM_LAUNCH((gemm2_grouped_tn_kernel<T, BM, BN, 4, 64>), dim3(grid), dim3(256), st, ga, ga.g, count);
     } else if (gst == 25) {
-        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 5, 64>), dim3(grid), dim3(256), 0, st, ga);
+        MB_GEMM_LAUNCH((gemm2_grouped_tn_kernel<T, BM, BN, 5, 64>), dim3(grid), dim3(256), st, ga, ga.g, count);
     } else if (gst >= 3) {
-        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 3, 128>), dim3(grid), dim3(256), 0, st, ga);
+        MB_GEMM_LAUNCH((gemm2_grouped_tn_kernel<T, BM, BN, 3, 128>), dim3(grid), dim3(256), st, ga, ga.g, count);
     } else {
-        hipLaunchKernelGGL((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128>), dim3(grid), dim3(256), 0, st, ga);
+        MB_GEMM_LAUNCH((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128>), dim3(grid), dim3(256), st, ga, ga.g, count);
     }
     return (int)hipGetLastError();
 }

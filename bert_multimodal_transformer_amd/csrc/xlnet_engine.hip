@@ -588,8 +588,31 @@ static int xl_adamw_decay_range(mb_xlnet_engine* e, float* m, float* v, size_t b
     return adamw_step(e->P + b, e->G + b, m + b, v + b, sh, en - b, en - b, clampr(e->sh_begin), clampr(e->sh_end), none, 1, st,
                       e->adam_state(e->ws), keep ? clampr(e->stale_begin) : 0, keep ? clampr(e->stale_end) : 0);
 }
-static int xl_enqueue_step_dp(mb_xlnet_engine* e, int seg, const std::vector<int>& plan, int B, int L, float* logits, float* loss,
-                              float* loss_run, float* m, float* v, float loss_scale, hipStream_t st) {
+// sharded update: of every chunk of layer GEMM weights inside [b, en) only this rank's slice + the replicated remainder (engine.hip)
+static int xl_adamw_decay_range_dp(mb_xlnet_engine* e, const mb_comm* comm, const DpSpec& sp, float* m, float* v, size_t b, size_t en, hipStream_t st) {
+    if (!comm->shard) return xl_adamw_decay_range(e, m, v, b, en, st);
+    std::vector<std::pair<size_t, size_t>> ch(sp.chunk);
+    std::sort(ch.begin(), ch.end());
+    size_t cur = b;
+    ZeroRanges dead = {};
+    for (const auto& c : ch) {
+        if (c.second <= cur || c.first >= en) continue;
+        if (c.first < cur || c.second > en) return MB_ERR_MODE;
+        CK(xl_adamw_decay_range(e, m, v, cur, c.first, st));
+        const ShardSlice sl = dp_shard_slice(comm, c.first, c.second);
+        CK(xl_adamw_decay_range(e, m, v, sl.mine_b, sl.mine_e, st));
+        CK(xl_adamw_decay_range(e, m, v, sl.rem_b, sl.rem_e, st));
+        if (!e->keep_in_step()) {
+            dead.add(e->G + c.first, (sl.mine_b - c.first) * 4);
+            dead.add(e->G + sl.mine_e, (sl.rem_b - sl.mine_e) * 4);
+        }
+        cur = c.second;
+    }
+    if (dead.n) CK(zero_fill_ranges(dead, st));
+    return xl_adamw_decay_range(e, m, v, cur, en, st);
+}
+static int xl_enqueue_step_dp(mb_xlnet_engine* e, int seg, const std::vector<int>& plan, const mb_comm* comm, const DpSpec& sp, int B, int L,
+                              float* logits, float* loss, float* loss_run, float* m, float* v, float loss_scale, hipStream_t st) {
     char* ws = e->ws;
     const int NL = e->c.n_layer, nb = (int)plan.size();
     const float* lab = (const float*)(ws + e->ws_in_lab);
@@ -607,11 +630,11 @@ static int xl_enqueue_step_dp(mb_xlnet_engine* e, int seg, const std::vector<int
     const size_t split = e->lo[plan[nb - 1] < NL ? plan[nb - 1] : 0].q;
     if (seg == nb) {
         CK(e->prof_mark(2 * NL, st));
-        if (nb > 1) return xl_adamw_decay_range(e, m, v, split, e->wsum, st);
+        if (nb > 1) return xl_adamw_decay_range_dp(e, comm, sp, m, v, split, e->wsum, st);
         // (one backward segment: no early range -- dp_between waited for everything -- so this segment takes the no-decay slab)
         return adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1);
     }
-    CK(xl_adamw_decay_range(e, m, v, 0, nb > 1 ? split : e->wsum, st));
+    CK(xl_adamw_decay_range_dp(e, comm, sp, m, v, 0, nb > 1 ? split : e->wsum, st));
     CK(xl_adamw_decay_range(e, m, v, e->wsum, nd, st));
     if (nb > 1) CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
     return e->prof_mark(2 * NL + 1, st);
@@ -641,20 +664,28 @@ int mb_xlnet_train_step_dp(mb_xlnet_engine* e, const int64_t* input_ids, const f
     sp.tail_begin = e->wsum; sp.tail_end = e->n_trainable;
     sp.word_off = e->word; sp.word_rows = c.vocab_size; sp.H = c.d_model;
     sp.ids = (const int64_t*)(e->ws + e->ws_in_ids); sp.T = B * L;
+    if (comm->shard) {
+        const bool bf = c.dtype == DT_BF16;
+        for (const auto& ch : sp.chunk)
+            if (bf && (!e->SH || ch.first < e->sh_begin || ch.second > e->sh_end)) return MB_ERR_MODE;
+        sp.gather_base = bf ? (char*)e->SH : (char*)e->P; sp.gather_es = bf ? 2 : 4;
+    }
+    CK(dp_step_begin(comm, st));          // (sharded update: the previous step's all-gathers)
     e->training = 1;
     CK(xl_prepare_pass(e, B * L, st));
     int variant = 1;
     for (int x : plan) variant = variant * 13 + x;
-    variant = variant * 4 + comm->event_mode;
+    variant = (variant * 4 + comm->event_mode) * 2 + (comm->shard ? 1 : 0);
     return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
                            labels, B, L, seed, step, logits, loss, loss_run, m, v, lr, beta1, beta2, eps, weight_decay, opt_step,
                            correct_bias, grad_scale, loss_scale, mode, e->prof, st,
                            [&](int sg, float* lg, float* ls, float* lr_, float* m_, float* v_, float sc, hipStream_t s) {
                                CK(dp_segment_begin(comm, nb, sg, s));
-                               CK(xl_enqueue_step_dp(e, sg, plan, B, L, lg, ls, lr_, m_, v_, sc, s));
-                               return dp_segment_end(comm, nb, sg, s);
+                               CK(xl_enqueue_step_dp(e, sg, plan, comm, sp, B, L, lg, ls, lr_, m_, v_, sc, s));
+                               CK(dp_segment_end(comm, nb, sg, s));
+                               return (int)MB_OK;
                            },
-                           nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant, comm, dp_verify_segment_graph);
+                           nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant, comm, dp_finish_segment_graph);
 }
 
 int mb_xlnet_set_perm_mask(mb_xlnet_engine* e, const uint8_t* perm) {

@@ -208,6 +208,7 @@ class Comm(object):
         nbytes = L.mb_comm_scratch_bytes(self.world, wire, n, vocab, H, self.capacity)
         self.scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.check(L.mb_comm_bind_scratch(h, _lib.ptr(self.scratch), nbytes, wire, n, vocab, H, self.capacity))
+        self.sharding = False
         self.stream = torch.cuda.ExternalStream(L.mb_comm_stream(h), device=dev)
         self.stream.synchronize()          # (the slot table's one-time memset)
         torch.cuda.synchronize(dev)        # the set-up collectives above are complete before the step that follows starts capturing
@@ -244,6 +245,23 @@ class Comm(object):
             import traceback
             traceback.print_exc()
             return 1005
+
+    # -- modes ------------------------------------------------------------------------------------------------------------------
+    def set_row_exchange(self, rowwise):
+        """False for the step that ends a gradient-accumulation window (the table's rows are the union over the micro-steps)"""
+        self._lib.check(self._lib.lib().mb_comm_set_row_exchange(self.handle, 1 if rowwise else 0))
+
+    def set_sharding(self, on):
+        """sharded optimizer update inside the single-call step (include/magbert_hip.h: mb_comm_set_sharding)"""
+        self._lib.check(self._lib.lib().mb_comm_set_sharding(self.handle, 1 if on else 0))
+        self.sharding = bool(self._lib.lib().mb_comm_sharding(self.handle))
+
+    def shard_slices(self):
+        """this rank's [begin, end) slices of the flat buffers in the last sharded step"""
+        import ctypes as C
+        buf = (C.c_size_t * 64)()
+        n = self._lib.lib().mb_comm_shard_slices(self.handle, buf, 32)
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]
 
     # -- measurement ------------------------------------------------------------------------------------------------------------
     def set_timing(self, on):
@@ -437,11 +455,17 @@ class DataParallel(object):
         # MB_DP_SHARD_OPT=1: the optimizer update of the layers' GEMM weights is sharded over the ranks (OptimizerShards: reduce to
         # the owner, update one shard, all-gather the operands).  Runs on the stage-driven path (the single engine call keeps the
         # replicated update).  Design + equality tests only: nothing about it has been measured on more than one GPU.
+        # Round 5: with the single engine call available the sharding lives INSIDE it (csrc/comm.hip: reduce-scatter of every layer piece,
+        # AdamW over this rank's slices, in-place all-gathers of the next forward's operands on the comm stream); the Python-driven
+        # OptimizerShards below remains the MB_DP_ENGINE=0 form.
         self.shards = None
+        self.shard_in_engine = False
         if self.reducer.active and self.reducer.world > 1 and os.environ.get("MB_DP_SHARD_OPT", "0") == "1":
-            self.shards = OptimizerShards(self.core, dist.get_rank(process_group), self.reducer.world, process_group)
-            self._comm_enabled = False
-            self.word = None                    # (dense last piece: keeps this path's plan simple)
+            if self._comm_enabled:
+                self.shard_in_engine = True
+            else:
+                self.shards = OptimizerShards(self.core, dist.get_rank(process_group), self.reducer.world, process_group)
+                self.word = None                    # (dense last piece: keeps this path's plan simple)
         # every rank draws its own dropout masks (the reference is single-process: nothing to be faithful to; identical masks on
         # every shard would correlate the regularisation noise).  The mixed seed is what get_rng_state() saves.
         if self.reducer.active and self.reducer.world > 1:
@@ -453,6 +477,10 @@ class DataParallel(object):
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
             optimizer._dp = self
+        try:
+            model._dp = self              # (train_step finds it on micro-steps, which carry no optimizer)
+        except Exception:
+            pass
 
     def broadcast_parameters(self, src=0):
         if self.reducer.active:
@@ -547,9 +575,14 @@ class DataParallel(object):
         self._tev_used[k] = True
 
     def fused_ready(self):
-        """True when the next optimizer step can be the single engine call: the comm object exists, this is a synchronising
-        step and no micro-step has accumulated gradients since the last exchange (those are reduced densely by the stage hooks)"""
-        return self._comm_enabled and self.sync and self._micro_since_sync == 0
+        """True when the next optimizer step can be the single engine call (mb_*_train_step_dp): a synchronising step with the C-side
+        exchange available.  Micro-steps of a gradient-accumulation window ran as plain single calls before it (micro_ready); the
+        step then exchanges the word-embedding table densely (Comm.set_row_exchange)."""
+        return self._comm_enabled and self.sync
+
+    def micro_ready(self):
+        """True when a gradient-accumulation micro-step can be the plain single call (no exchange, no stage hooks)"""
+        return self._comm_enabled and self.shards is None
 
     def get_comm(self, tokens):
         """the C-side exchange object, created collectively at the first single-call step"""
@@ -557,6 +590,9 @@ class DataParallel(object):
             try:
                 self.comm = Comm(self.core, self.pg, self.reducer.wire_dtype, sparse_rows=self.word is not None,
                                  row_capacity=max(self.row_capacity, int(tokens)))
+                if self.shard_in_engine:
+                    self.comm.set_sharding(True)
+                self.core._dp_comm = self.comm
             except Exception as ex:         # no RCCL to load, communicator refused, ...: say so and keep training on the stage-driven path
                 import sys
                 print("warning: the single-call data-parallel step is unavailable (%s); the gradient exchange stays with the "

@@ -371,6 +371,22 @@ int mb_comm_bind_scratch(mb_comm* c, void* scratch, size_t bytes, int wire_dtype
  * format; row-wise sum of a [vocab][hidden] fp32 table of which this rank touched the rows ids[0, T) (T <= capacity_rows) */
 int mb_comm_all_reduce(mb_comm* c, float* buf, size_t count, void* stream);
 int mb_comm_exchange_rows(mb_comm* c, float* table, const int64_t* ids, int T, void* stream);
+/* Gradient accumulation (/root/reference/multimodal_driver.py:375-376, 383-386): micro-steps are plain mb_*_train_step calls without
+ * m / v (they accumulate and exchange nothing); the mb_*_train_step_dp that follows them must move the word-embedding table DENSELY
+ * (its gradient holds the rows of every micro-step, not only this step's ids): mb_comm_set_row_exchange(c, 0) before it, 1 after. */
+int mb_comm_set_row_exchange(mb_comm* c, int rowwise);
+/* Sharded optimizer update (ZeRO-1 over the layers' GEMM weights; NEW: the reference runs one AdamW over everything,
+ * multimodal_driver.py:345, 384-386).  With sharding on, mb_*_train_step_dp reduce-scatters every piece of layer GEMM-weight
+ * gradients instead of all-reducing it, updates this rank's slice of every piece only, and all-gathers what the next forward reads
+ * (the bf16 shadow in bf16 mode, the fp32 parameters in fp32 mode) on the comm stream; the NEXT mb_*_train_step_dp waits for those
+ * gathers, any other consumer of the weights calls mb_comm_join(c, its stream) first.  In bf16 mode the fp32 masters -- and in either
+ * mode Adam's m / v -- of the other ranks' slices are stale until mb_comm_gather_shards(c, flat buffer, 4, stream) refreshes them
+ * (state_dict / checkpoints).  mb_comm_shard_slices: this rank's [begin, end) slices of the last sharded step. */
+int mb_comm_set_sharding(mb_comm* c, int on);
+int mb_comm_sharding(const mb_comm* c);
+int mb_comm_join(mb_comm* c, void* stream);
+int mb_comm_gather_shards(mb_comm* c, void* base, int elem_bytes, void* stream);
+int mb_comm_shard_slices(const mb_comm* c, size_t* begin_end_pairs, int max_pairs);
 int mb_comm_set_timing(mb_comm* c, int on);
 int mb_comm_exposed_ms(mb_comm* c, float* ms);
 int mb_comm_stats(const mb_comm* c, size_t* pieces, size_t* bytes);      /* collectives issued / bytes handed to them in the last step */

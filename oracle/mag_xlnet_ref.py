@@ -157,7 +157,9 @@ class MAG_XLNetModel(nn.Module):
         h = self.dropout(emb if inputs_embeds is not None else self.word_embedding(ids))        # xlnet.py:301-305
         seg_mat = (seg[:, None] != seg[None, :]).long()                                 # xlnet.py:326
         seg_mat = F.one_hot(seg_mat, num_classes=2).float()                             # xlnet.py:327
-        pos_emb = self.dropout(self.relative_positional_encoding(L, L, B))              # xlnet.py:332-333
+        dt = self.word_embedding.weight.dtype          # float32; float64 when a conditioning analysis runs the oracle in double
+        non_tgt, seg_mat = non_tgt.to(dt), seg_mat.to(dt)
+        pos_emb = self.dropout(self.relative_positional_encoding(L, L, B).to(dt))       # xlnet.py:332-333
         for i, layer in enumerate(self.layer):
             if i == self.injection_index:
                 h = self.MAG(h, visual, acoustic)                                       # xlnet.py:371-372

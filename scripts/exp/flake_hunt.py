@@ -11,6 +11,14 @@ they go back to torch's cache (an uninitialised read of recycled memory then sho
 On the first miss: per-tensor table against the reference gradient + the location of the differing elements, then continue.
 
     python scripts/exp/flake_hunt.py [--n 300] [--L 24] [--dtype fp32|bf16]        (MB_DETERMINISTIC is read from the environment)
+
+--vary N: the second hypothesis.  The test never seeds torch, so the engine's dropout seed (torch.initial_seed() at model creation)
+-- and with it every mask and every activation behind the first dropout -- differs from one pytest run to the next; MAG's two
+relu gates and its min(threshold, 1) clamp have discontinuous derivatives, so a pre-activation that lands within fp32 rounding of
+zero can take different sides on the CPU and on the GPU: identical logits, one token's contribution to dW_hv / dW_ha flipped.  N
+repetitions with a DIFFERENT dropout draw each (one model, the counter advances), each against the CPU oracle with the masks
+replayed; per repetition the smallest |relu pre-activation| of the oracle's MAG is recorded; on a miss the oracle is re-run in
+float64 and the GPU and the fp32 oracle are both compared with it.
 """
 import argparse
 import os
@@ -29,10 +37,16 @@ from oracle import weights                                           # noqa: E40
 DEV = "cuda:0"
 
 
-def oracle_grads(layers, B, L, seed, step, b):
+def oracle_grads(layers, B, L, seed, step, b, double=False, probe=None):
     o = TX.oracle(layers).train()
+    if double:
+        o = o.double()
+    if probe is not None:          # the pre-activations of MAG's relu gates (modeling.py:27-28)
+        for lin in (o.transformer.MAG.W_hv, o.transformer.MAG.W_ha):
+            lin.register_forward_hook(lambda mod, args, out: probe.append(out.detach()))
     nh, H, DI = 12, 768, 3072
-    mult = lambda site, p, n: torch.from_numpy(rng.keep_mult(n, rng.make_key(seed, step, site, p)))
+    cast = (lambda t: t.double()) if double else (lambda t: t)
+    mult = lambda site, p, n: cast(torch.from_numpy(rng.keep_mult(n, rng.make_key(seed, step, site, p))))
     blx = lambda site, p, Xd: mult(site, p, B * L * Xd).view(B, L, Xd).permute(1, 0, 2)
     S = TX._SeqReplay
     o.transformer.dropout = S([blx(rng.XS_EMB, 0.1, H), mult(rng.XS_POS, 0.1, 2 * L * B * H).view(2 * L, B, H), blx(rng.XS_FINAL, 0.1, H)])
@@ -43,9 +57,61 @@ def oracle_grads(layers, B, L, seed, step, b):
         lyr.rel_attn.dropout = S([mult(s0 + 0, 0.1, B * nh * L * L).view(B, nh, L, L), blx(s0 + 1, 0.1, H)])
         lyr.ff.dropout = S([blx(s0 + 2, 0.1, DI), blx(s0 + 3, 0.1, H)])
     i2, v2, a2, m2, s2, l2 = TX.tb(b)
+    if double:
+        v2, a2, l2 = v2.double(), a2.double(), l2.double()
     lo = o(i2, v2, a2, m2, s2)[0]
     torch.nn.functional.mse_loss(lo.view(-1), l2.view(-1)).backward()
     return {n: p.grad for n, p in o.named_parameters() if p.grad is not None}, lo.detach()
+
+
+def vary(a, cdt):
+    """a different dropout draw per repetition, GPU vs CPU oracle each time (see the module docstring)"""
+    layers, B, L = 2, 3, a.L
+    b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=41)
+    batch = TX.tb(b, DEV)
+    ids, vis, aco, mask, seg, lab = batch
+    torch.manual_seed(a.seed)
+    m = TX.build(layers, cdt).train()
+    tol = 5e-3 if cdt == torch.float32 else 1e-1
+    misses, margins, t0 = 0, [], time.time()
+    for rep in range(a.vary):
+        m.zero_grad()
+        out = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)
+        torch.nn.MSELoss()(out[0].view(-1), lab.view(-1)).backward()
+        torch.cuda.synchronize()
+        seed, step = m._core.seed, m._core.step
+        probe = []
+        og, lo = oracle_grads(layers, B, L, seed, step, b, probe=probe)
+        margin = min(float(x.abs().min()) for x in probe)
+        margins.append(margin)
+        gmax = max(float(g.abs().max()) for g in og.values())
+        rows = sorted(((float((p.grad.detach().cpu() - og[n]).abs().max()) / max(float(og[n].abs().max()), 1e-3 * gmax), n)
+                       for n, p in m.named_parameters() if n in og), reverse=True)
+        if rows[0][0] > tol:
+            misses += 1
+            lerr = float((out[0].detach().cpu() - lo).abs().max())
+            print("  MISS rep=%d (seed %d, step %d): worst gradient %.3e at %s, logits %.2e, smallest |relu pre-activation| %.3e" %
+                  (rep, seed, step, rows[0][0], rows[0][1], lerr, margin))
+            for e_, n_ in rows[:5]:
+                print("      %.3e  %s" % (e_, n_))
+            probe64 = []
+            o64, _ = oracle_grads(layers, B, L, seed, step, b, double=True, probe=probe64)
+            for nm, x32, x64 in zip(("W_hv", "W_ha"), probe, probe64):
+                flip = ((x32 > 0) != (x64 > 0)).nonzero()
+                print("      relu gate %s: %d of %d pre-activations have different signs in the fp32 and the float64 oracle%s" %
+                      (nm, flip.shape[0], x32.numel(), "".join("; [%s] fp32 %.3e float64 %.3e" % (",".join(str(int(i)) for i in ix), float(x32[tuple(ix)]), float(x64[tuple(ix)]))
+                                                                for ix in flip[:3])))
+            g64max = max(float(g.abs().max()) for g in o64.values())
+            for n_ in [r[1] for r in rows[:3]]:
+                ref = o64[n_]
+                den = max(float(ref.abs().max()), 1e-3 * g64max)
+                p_ = dict(m.named_parameters())[n_]
+                print("      %s vs the float64 oracle: GPU %.3e, fp32 CPU oracle %.3e" %
+                      (n_, float((p_.grad.detach().cpu().double() - ref).abs().max()) / den, float((og[n_].double() - ref).abs().max()) / den))
+    ms = sorted(margins)
+    print("vary: %d repetitions with different dropout draws (%s, L=%d), %d misses at tolerance %.0e; smallest |relu pre-activation| per "
+          "repetition: min %.2e, median %.2e   (%.0f s)" % (a.vary, a.dtype, L, misses, tol, ms[0], ms[len(ms) // 2], time.time() - t0))
+    return misses
 
 
 def churn(rep):
@@ -93,8 +159,14 @@ def main():
     ap.add_argument("--n", type=int, default=300)
     ap.add_argument("--L", type=int, default=24)
     ap.add_argument("--dtype", default="fp32")
+    ap.add_argument("--vary", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=12345)
     a = ap.parse_args()
     cdt = torch.float32 if a.dtype == "fp32" else torch.bfloat16
+    if a.vary > 0:
+        torch.cuda.set_device(0)
+        vary(a, cdt)
+        return 0
     det = os.environ.get("MB_DETERMINISTIC", "0") == "1"
     layers, B, L = 2, 3, a.L
     torch.cuda.set_device(0)

@@ -249,12 +249,21 @@ if use_dp:
     dp.broadcast_parameters(0)
 first_m = None
 every_m = []
+accum = int(os.environ.get("ACCUM", "1")) if use_dp else 1
+micro_fused = []
 with m.stream_scope():
     for s in range(int(os.environ.get("STEPS", "2"))):
         ids, vis, aco, mask, seg, lab = tb(batch(90 + s), DEV)
         lo, hi = (0, 8) if world == 1 else (rank * 4, rank * 4 + 4)
-        m.train_step(ids[lo:hi], vis[lo:hi], aco[lo:hi], mask[lo:hi], seg[lo:hi], lab[lo:hi], optimizer=opt,
-                     graph=None if os.environ.get("GRAPH", "1") == "1" else "launches")
+        n = (hi - lo) // accum
+        for k in range(accum):               # a gradient-accumulation window: micro-steps without the optimizer, then the update
+            a0, a1, last = lo + k * n, lo + (k + 1) * n, k == accum - 1
+            if dp is not None:
+                dp.sync = last
+            m.train_step(ids[a0:a1], vis[a0:a1], aco[a0:a1], mask[a0:a1], seg[a0:a1], lab[a0:a1], optimizer=opt if last else None,
+                         loss_scale=1.0 / accum, graph=None if os.environ.get("GRAPH", "1") == "1" else "launches")
+            if dp is not None and not last:
+                micro_fused.append(bool(dp._last_fused))
         sch.step()
         if first_m is None:
             torch.cuda.synchronize()
@@ -266,14 +275,23 @@ torch.cuda.synchronize()
 fused = bool(dp is not None and dp._last_fused)
 stats = dp.comm.stats() if fused else (0, 0)
 shards = dp.shards.bounds if (dp is not None and dp.shards is not None) else None
+slices = dp.comm.shard_slices() if (fused and dp.comm.sharding) else None          # the sharded update INSIDE the engine call
+if fused and dp.comm.sharding:
+    m._core._comm_join()
+    torch.cuda.synchronize()
 p_before = m.flat_params.cpu().clone()
+m_before = m._core._adam_m.cpu().clone()
 sh = m._core.shadow
 shadow = sh[m._core.sh_begin: m._core.sh_end].float().cpu() if sh.numel() > 1 else None
-if shards is not None and os.environ.get("GATHER_MASTERS") == "1":
-    dp.shards.gather_masters()
+if os.environ.get("GATHER_MASTERS") == "1":
+    if shards is not None:
+        dp.shards.gather_masters()
+    elif slices is not None:
+        m._core.refresh_sharded_state()
     torch.cuda.synchronize()
 torch.save(dict(p=m.flat_params.cpu(), m=first_m, fused=fused, stats=stats, sparse=bool(fused and dp.comm.sparse), shards=shards,
-                p_before_gather=p_before, shadow=shadow, every_m=every_m),
+                p_before_gather=p_before, shadow=shadow, every_m=every_m, slices=slices, micro_fused=micro_fused,
+                adam_m=m._core._adam_m.cpu(), adam_m_before_gather=m_before),
            os.environ["OUT"] + ".%d.%d.%s" % (world, rank, os.environ.get("USE_DP", "1")))
 if use_dp:
     dist.barrier(); dist.destroy_process_group()
@@ -351,6 +369,68 @@ def test_single_call_dp_step_replayed_steps_with_a_delayed_backward(tmp_path, ki
         assert max(errs) > 1e-3, "the negative control passed: this test cannot see a missing dependency"
     else:
         assert max(errs) <= 5e-6
+
+
+@pytest.mark.parametrize("kind", ["bert", "xlnet"])
+def test_gradient_accumulation_in_the_single_call_lane(tmp_path, kind):
+    """multimodal_driver.py:375-376, 383-386 under data parallel, fast lane: two ranks x two micro-steps of 2 samples -- the micro-steps
+    are plain mb_*_train_step calls without the optimizer (nothing exchanged), the step that ends the window is mb_*_train_step_dp
+    with the word-embedding table moved DENSELY (its rows are the union over the micro-steps) -- against one process with the
+    whole batch of 8: Adam's first moment after step 1 <= 5e-6, replicas bit-identical, after 2 steps."""
+    import torch
+    out = str(tmp_path / "acc")
+    common = dict(OUT=out, KIND=kind, MB_DP_SPARSE_EMB="1", MB_DP_CHUNK="1")
+    _run_engine_workers(tmp_path, 1, common)
+    _run_engine_workers(tmp_path, 2, dict(common, ACCUM="2"))
+    ref = torch.load(out + ".1.0.1")
+    a, b = torch.load(out + ".2.0.1"), torch.load(out + ".2.1.1")
+    assert a["fused"] and b["fused"] and a["micro_fused"] == [True, True], a["micro_fused"]
+    assert torch.equal(a["p"], b["p"]) and torch.equal(a["m"], b["m"])
+    err = float((a["m"] - ref["m"]).abs().max()) / float(ref["m"].abs().max())
+    print("%s accumulation 2 ranks x 2 micro-steps x 2 samples vs single(8): first-moment max |d| / max = %.3e; %d collectives, %.1f MB" %
+          (kind, err, a["stats"][0], a["stats"][1] * 1e-6))
+    assert err <= 5e-6
+    assert float((a["p"] - ref["p"]).abs().max()) <= 2 * 1e-3 * 1.1
+
+
+@pytest.mark.parametrize("kind,cdt", [("bert", "fp32"), ("bert", "bf16"), ("xlnet", "fp32")])
+def test_sharded_update_inside_the_engine_call_equals_replicated(tmp_path, kind, cdt):
+    """MB_DP_SHARD_OPT=1 in the single-call lane (csrc/comm.hip: every layer piece reduce-scattered, AdamW over this rank's slices,
+    in-place all-gathers of the next forward's operands on the comm stream) against the replicated single-call step, two ranks over
+    the callback backend, three steps, deterministic mode.  fp32: parameters on every rank bit-identical to the replicated run
+    after every gather (the forward reads the gathered fp32 parameters).  bf16: each rank's own slices of the masters bit-identical,
+    the foreign ones stale by design, the bf16 shadow everybody's; after refresh_sharded_state() masters and Adam moments match
+    the replicated run everywhere."""
+    import torch
+    out_a, out_b = str(tmp_path / "rep"), str(tmp_path / "shd")
+    common = dict(KIND=kind, STEPS="3", CDT=cdt, MB_DETERMINISTIC="1", MB_DP_CHUNK="1")
+    _run_engine_workers(tmp_path, 2, dict(common, OUT=out_a, MB_DP_SHARD_OPT="0"), tag="rep")
+    _run_engine_workers(tmp_path, 2, dict(common, OUT=out_b, MB_DP_SHARD_OPT="1", GATHER_MASTERS="1"), tag="shd")
+    rep = [torch.load(out_a + ".2.%d.1" % r) for r in range(2)]
+    shd = [torch.load(out_b + ".2.%d.1" % r) for r in range(2)]
+    assert rep[0]["fused"] and shd[0]["fused"] and shd[0]["slices"] and not rep[0]["slices"]
+    assert torch.equal(rep[0]["p"], rep[1]["p"])
+    n_sharded = sum(e - b for b, e in shd[0]["slices"])
+    for r in range(2):
+        assert torch.equal(shd[r]["p"], rep[0]["p"]), "masters after the gather"
+        assert torch.equal(shd[r]["adam_m"], rep[0]["adam_m"]), "Adam moments after the gather"
+        mine = torch.zeros(rep[0]["p"].numel(), dtype=torch.bool)
+        for b, e in shd[r]["slices"]:
+            mine[b:e] = True
+            assert torch.equal(shd[r]["p_before_gather"][b:e], rep[0]["p"][b:e])
+        other = torch.zeros_like(mine)
+        for b, e in shd[1 - r]["slices"]:
+            other[b:e] = True
+        assert not bool((mine & other).any())
+        assert torch.equal(shd[r]["p_before_gather"][~other], rep[0]["p"][~other])          # everything this rank updates itself
+        assert not torch.equal(shd[r]["adam_m_before_gather"][other], rep[0]["adam_m"][other])     # foreign moments: never touched here
+        if cdt == "fp32":
+            assert torch.equal(shd[r]["p_before_gather"], rep[0]["p"])                       # the gathers deliver the fp32 parameters
+        else:
+            assert not torch.equal(shd[r]["p_before_gather"][other], rep[0]["p"][other])    # stale masters by design
+            assert torch.equal(shd[r]["shadow"], rep[0]["shadow"])                           # ... while the bf16 operands are everybody's
+    print("%s sharded update in the engine call (%s): 2 ranks == replicated bit for bit; %d of %d parameters sharded, %d slices per rank; "
+          "%d collectives, %.1f MB reduced" % (kind, cdt, 2 * n_sharded, rep[0]["p"].numel(), len(shd[0]["slices"]), shd[0]["stats"][0], shd[0]["stats"][1] * 1e-6))
 
 
 @pytest.mark.parametrize("cdt,graph", [("fp32", "1"), ("fp32", "0"), ("bf16", "1")])

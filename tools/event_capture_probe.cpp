@@ -7,7 +7,9 @@
 // kernel that stores `it` at its end, [event], and on a second stream: hipStreamWaitEvent(ev) + a reader kernel.  "held" counts the
 // replays in which the reader saw the value of its own iteration.
 // The wait side: variant 3 = hipStreamWaitEvent(s, ev, 0) inside a capture on an event recorded outside; variant 4 = the same with
-// hipEventWaitExternal.
+// hipEventWaitExternal; variant 5 = hipGraphAddEventWaitNode put in front of the captured root after the capture.
+// Run it under BOTH runtimes a process may carry: as built (ROCm 7.2, /opt/rocm) and with
+// LD_PRELOAD=<torch>/lib/libamdhip64.so (the 7.0 runtime every Python process of this image maps).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -58,7 +60,10 @@ static int record_variant(int variant) {
     spin_store<<<1, 1, 0, cap>>>(flag, -7, ticks);            // (value replaced below: the flag takes the iteration from itv)
     store_param<<<1, 1, 0, cap>>>(flag, itv);
     if (variant == 0) CK(hipEventRecord(ev, cap));
-    if (variant == 1) CK(hipEventRecordWithFlags(ev, cap, hipEventRecordExternal));
+    if (variant == 1) {
+        hipError_t er = hipEventRecordWithFlags(ev, cap, hipEventRecordExternal);
+        if (er != hipSuccess) { printf("  hipEventRecordWithFlags(External) inside the capture -> %s\n", hipGetErrorString(er)); (void)hipGetLastError(); }
+    }
     CK(hipStreamEndCapture(cap, &g));
     if (variant == 2) {
         size_t n = 0; CK(hipGraphGetNodes(g, nullptr, &n));
@@ -102,11 +107,18 @@ static int wait_variant(int variant) {
     hipGraph_t g = nullptr; hipGraphExec_t ex = nullptr;
     CK(hipEventRecord(ev, side));          // a first record outside any capture
     CK(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
-    hipError_t w = variant == 3 ? hipStreamWaitEvent(cap, ev, 0) : hipStreamWaitEvent(cap, ev, hipEventWaitExternal);
-    if (w != hipSuccess) printf("  wait inside the capture -> %s\n", hipGetErrorString(w));
+    hipError_t w = variant == 3 ? hipStreamWaitEvent(cap, ev, 0) : variant == 4 ? hipStreamWaitEvent(cap, ev, hipEventWaitExternal) : hipSuccess;
+    if (w != hipSuccess) { printf("  wait inside the capture -> %s\n", hipGetErrorString(w)); (void)hipGetLastError(); }
     read_flag<<<1, 1, 0, cap>>>(flag, out, 0);
     hipError_t e2 = hipStreamEndCapture(cap, &g);
     if (e2 != hipSuccess) { printf("  hipStreamEndCapture -> %s\n", hipGetErrorString(e2)); return 0; }
+    if (variant == 5) {
+        size_t nr = 0; CK(hipGraphGetRootNodes(g, nullptr, &nr));
+        std::vector<hipGraphNode_t> roots(nr); CK(hipGraphGetRootNodes(g, roots.data(), &nr));
+        hipGraphNode_t wn;
+        CK(hipGraphAddEventWaitNode(&wn, g, nullptr, 0, ev));
+        for (auto r : roots) CK(hipGraphAddDependencies(g, &wn, &r, 1));
+    }
     if (show_nodes(g)) return 1;
     CK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
     // the reader of the graph stores out[0]; copy it to out[it] afterwards on the same stream
@@ -126,8 +138,10 @@ static int wait_variant(int variant) {
 }
 
 int main() {
-    int rc = 0;
+    int rc = 0, rtv = 0;
+    (void)hipRuntimeGetVersion(&rtv);
+    printf("HIP runtime version %d\n", rtv);
     for (int v = 0; v < 3; ++v) rc |= record_variant(v);
-    for (int v = 3; v < 5; ++v) rc |= wait_variant(v);
+    for (int v = 3; v < 6; ++v) rc |= wait_variant(v);
     return rc;
 }
