@@ -825,10 +825,27 @@ def main():
                                  ", ".join("%s %.3f ms (%.3f of %s peak)" % (c["kernel"][:48], c["ms_per_step"], c["frac"], c["bound"]) for c in trace_roof[:4])
             top["timing"] = "rocprofv3 kernel trace taken by this run (in-step, graph replay), average over %d launches" % round(top["launches_per_step"] * 10)
             top["traffic"] = None
-            for blk, key in ((mfma, "gemm2_grouped_tn_kernel"), (hbm, "adamw")):      # PMC bytes: replayed, for the two kernels a PMC pass exists for
-                if blk is not None and key in top["kernel"] and blk.get("traffic") is not None and ("Li128ELi128E" in top["kernel"] or key == "adamw"):
-                    for f_ in ("traffic", "traffic_unit", "traffic_replayed", "traffic_source"):
-                        top[f_] = blk.get(f_)
+            # HBM-side bytes per launch: PMC counters need their own rocprofv3 passes (FETCH_SIZE / WRITE_SIZE, separately) -- REPLAYED
+            # from the committed passes over this same step (profiles/pmc_traffic.json, scripts/gpu_artifacts.sh)
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                    pm_ = json.load(fh)
+                if pm_.get("workload") == "%s B=%d L=%d %s" % (a.model, B, L, a.dtype):
+                    e_ = None
+                    if "adamw" in top["kernel"]:
+                        e_ = pm_["kernels"].get("adamw")
+                        if e_:
+                            top["traffic"] = (e_["fetch_bytes"] + e_["write_bytes"]) // 2
+                    else:
+                        e_ = next((v_ for k_, v_ in pm_.get("by_symbol", {}).items() if top["kernel"].startswith(k_) or k_.startswith(top["kernel"][:90])), None)
+                        if e_:
+                            top["traffic"] = e_["fetch_bytes"] + e_["write_bytes"]
+                    if top["traffic"] is not None:
+                        top["traffic_unit"] = "bytes/launch (mean over the symbol's launches)"
+                        top["traffic_replayed"] = True
+                        top["traffic_source"] = pm_["source"]
+            except Exception:
+                pass
             out["roofline"] = top
             out["roofline_trace"] = trace_roof[:8]
         else:

@@ -78,6 +78,7 @@ PROTOTYPES = {
     "mb_xlnet_attention_probs": (_vp, [_vp, _i, C.POINTER(_i)]),
     "mb_xlnet_set_head_mask": (_i, [_vp, _vp]),
     "mb_xlnet_set_perm_mask": (_i, [_vp, _vp]),
+    "mb_xlnet_set_mems": (_i, [_vp, _vp, _i]),
     "mb_bert_mark_grads_zero": (_i, [_vp, _i]),
     "mb_xlnet_mark_grads_zero": (_i, [_vp, _i]),
     "mb_bert_materialize_grads": (_i, [_vp, _vp]),

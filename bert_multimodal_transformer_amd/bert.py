@@ -147,7 +147,7 @@ class _Core(object):
         self.anchor = torch.zeros((), device=self.device, requires_grad=True)
         self.weights_dirty = True
         self.loss_buf = torch.zeros(2, dtype=torch.float32, device=self.device)   # [last step, running sum]
-        self._optional = (None, None, None, None)
+        self._optional = (None, None, None, None, None)
         self._gz = True             # the flat gradient buffer holds zeros (mirror of the engine's flag: survives a re-created engine)
         self._gz_version = self.grads._version
 
@@ -180,7 +180,7 @@ class _Core(object):
             self._fn("destroy")(self.handle)
             self.ws = None
         self.handle = h
-        self._optional = (None, None, None, None)    # a new engine starts without head_mask / inputs_embeds / position_ids / perm_mask
+        self._optional = (None, None, None, None, None)    # a new engine starts without head_mask / inputs_embeds / position_ids / perm_mask
         self.max_B, self.max_L = B, L
 
     def _comm_join(self):
@@ -322,11 +322,11 @@ class _Core(object):
         self._ids_dev = ids.reshape(-1)
         return [_lib.ptr(t) for t in keep], keep
 
-    def _set_optional(self, head_mask=None, inputs_embeds=None, position_ids=None, perm=None):
+    def _set_optional(self, head_mask=None, inputs_embeds=None, position_ids=None, perm=None, mems=None):
         """head_mask [n_layers][n_heads] / inputs_embeds [B*L][H] (fp32 device tensors) / position_ids [B*L] (int64, MAG-BERT) /
         perm [B][L][L] (uint8, MAG-XLNet: who may not attend to whom) or None -> engine state; sticky in the engine, so every pass
         states what it wants (the single-call step refuses to run with any of them set)."""
-        want = (head_mask, inputs_embeds, position_ids, perm)
+        want = (head_mask, inputs_embeds, position_ids, perm, mems)
         if all(x is None for x in want) and all(x is None for x in self._optional):
             return
         if self.kind != "bert":
@@ -335,9 +335,11 @@ class _Core(object):
             _lib.check(self.lib.mb_xlnet_set_head_mask(self.handle, _lib.ptr(head_mask)))
             _lib.check(self.lib.mb_xlnet_set_inputs_embeds(self.handle, _lib.ptr(inputs_embeds)))
             _lib.check(self.lib.mb_xlnet_set_perm_mask(self.handle, _lib.ptr(perm)))
+            # mems: [n_layer][B][mlen][H] in the activation dtype (xlnet.py:374-385; include/magbert_hip.h: mb_xlnet_set_mems)
+            _lib.check(self.lib.mb_xlnet_set_mems(self.handle, _lib.ptr(mems), 0 if mems is None else int(mems.shape[2])))
         else:
-            if perm is not None:
-                raise NotImplementedError("perm_mask is an argument of MAG-XLNet only")
+            if perm is not None or mems is not None:
+                raise NotImplementedError("perm_mask / mems are arguments of MAG-XLNet only")
             _lib.check(self.lib.mb_bert_set_head_mask(self.handle, _lib.ptr(head_mask)))
             _lib.check(self.lib.mb_bert_set_inputs_embeds(self.handle, _lib.ptr(inputs_embeds)))
             _lib.check(self.lib.mb_bert_set_position_ids(self.handle, _lib.ptr(position_ids)))
@@ -391,7 +393,7 @@ class _Core(object):
         off = p - self.ws.data_ptr()
         return self.ws[off: off + B * L * H * 4].view(torch.float32).view(B, L, H).clone()
 
-    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, training, head_mask=None,
+    def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, training, mems=None, head_mask=None,
                 inputs_embeds=None, position_ids=None, perm=None):
         dev = self.device
         if inputs_embeds is not None:               # bert.py:158-168 / xlnet.py:306-313: shapes come from the embeddings, the ids are not read
@@ -411,7 +413,7 @@ class _Core(object):
             perm = perm.to(dev, torch.uint8).contiguous()
             if tuple(perm.shape) != (B, L, L):
                 raise ValueError("perm_mask must be [B, L, L] = %s, got %s" % ((B, L, L), tuple(perm.shape)))
-        self._set_optional(self.head_mask_table(head_mask), inputs_embeds, position_ids, perm)
+        self._set_optional(self.head_mask_table(head_mask), inputs_embeds, position_ids, perm, mems)
         ptr, keep = self._inputs(input_ids, visual, acoustic, attention_mask, token_type_ids, labels)
         logits = torch.empty(B, self.config.num_labels, dtype=torch.float32, device=dev)
         if training:

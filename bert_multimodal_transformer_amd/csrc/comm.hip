@@ -535,7 +535,10 @@ int mb_comm_set_row_exchange(mb_comm* c, int rowwise) {
 int mb_comm_set_sharding(mb_comm* c, int on) {
     if (!c) return MB_ERR_ARG;
     if (on && c->gather_pending) return MB_ERR_MODE;
-    c->shard = on != 0 && c->world > 1;
+    // (a one-rank group has nothing to shard; MB_DP_SHARD_FORCE=1 runs the sharded code path anyway -- every collective an identity --
+    //  so that its launches, event nodes and gathers can be timed on one GPU: tools/step_bench --dp 1 --shard 1)
+    const char* f = getenv("MB_DP_SHARD_FORCE");
+    c->shard = on != 0 && (c->world > 1 || (f && atoi(f) != 0));
     return MB_OK;
 }
 int mb_comm_sharding(const mb_comm* c) { return (c && c->shard) ? 1 : 0; }

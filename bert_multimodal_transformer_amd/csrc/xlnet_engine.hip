@@ -39,6 +39,7 @@ struct mb_xlnet_engine : StepMixin {
     int mag_nblk = 0;              // slabs MAG's gate backward wrote into slot n_layer
     int prefetch = 1;              // MB_PREFETCH=0: the LayerNorm kernels do not touch the next GEMMs' weights (common.h Prefetch)
     const float* head_mask = nullptr;   // mb_xlnet_set_head_mask: [n_layer][n_head] fp32 (caller-owned device memory)
+    const char* mems = nullptr; int mlen = 0;      // mb_xlnet_set_mems: [n_layer][B][mlen][d_model], activation dtype (caller-owned)
     const uint8_t* perm = nullptr;      // mb_xlnet_set_perm_mask: [B][L][L] bytes, != 0 <=> query i may not attend to key j (xlnet.py:265-296)
     const float* emb_in = nullptr;      // mb_xlnet_set_inputs_embeds: [B*L][H] fp32 word embeddings given instead of input_ids (xlnet.py:306-313)
     size_t ws_demb = 0;                 // fp32 [T][H]: gradient of the given embeddings
@@ -290,6 +291,7 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
     if (!e->P || !e->ws) return MB_ERR_ARG;
     if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
     if ((!input_ids && !e->emb_in) || !visual || !acoustic || !attention_mask || !token_type_ids || !logits) return MB_ERR_ARG;
+    if (e->mems && (training || e->mlen >= L || e->in_step)) return MB_ERR_MODE;      // memories: inference passes only
     const int dt = c.dtype, H = c.d_model, I = c.d_inner, T = B * L, nh = c.n_head, R = B * 2 * L;
     const size_t es = esize(dt);
     if (e->emb_in) input_ids = nullptr;           // inputs_embeds given: no table gather, no scatter into the word table
@@ -311,6 +313,17 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
                             c.mag_layer_norm_eps, c.beta_shift, e->key(XS_MAG, c.mag_dropout), ws + e->ws_magout,
                             ws + e->ws_mag, e->mw, T, H, c.visual_dim, c.acoustic_dim, !(e->in_step && e->packed_w), st, true, e->in_step && e->packed));
             xin = ws + e->ws_magout;
+        }
+        if (e->mems) {
+            // cached memories (xlnet.py:81-91, 374-385 -> XLNetRelativeAttention: keys / values over cat([mems[l], h])): the caller laid the
+            // segment out as klen = mlen + qlen rows per sample whose first mlen rows are the memory -- their ids / modalities are
+            // dummies, their mask is "visible", their segment id 0 (the reference's mem_pad) -- so rows [0, mlen) of every sample of
+            // this layer's input are REPLACED by mems[l] here, behind the MAG injection (which the reference applies to h only).  The
+            // relative position of query row mlen + i and key row j is (klen - (mlen + i) + j) = qlen - i + j: exactly the index the
+            // reference's rel_shift produces for klen keys, so the attention kernels run unchanged on klen rows.  What the layer
+            // computes for the memory rows themselves is never read: the next layer replaces them again, the head reads the last row.
+            CK((int)hipMemcpy2DAsync((void*)xin, (size_t)L * H * es, e->mems + (size_t)l * B * e->mlen * H * es, (size_t)e->mlen * H * es,
+                                     (size_t)e->mlen * H * es, (size_t)B, hipMemcpyDeviceToDevice, st));
         }
         char* qkv = ws + w.qkv;
         // q | k | v | kr projections: x . W with W stored [d_model][n_head*d_head] (einsum "ibh,hnd->ibnd")
@@ -565,7 +578,7 @@ int mb_xlnet_train_step(mb_xlnet_engine* e, const int64_t* input_ids, const floa
     if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !labels || !logits || !loss) return MB_ERR_ARG;
     if ((m == nullptr) != (v == nullptr) || (mode != 1 && mode != 2)) return MB_ERR_ARG;
     if (e->deferred) return MB_ERR_MODE;          // MB_OVERLAP_WGRAD=1: the side-stream scheme is driven stage by stage (mb_xlnet_backward)
-    if (e->head_mask || e->emb_in || e->perm) return MB_ERR_MODE;      // head_mask / inputs_embeds / perm_mask are arguments of explicit forwards only
+    if (e->head_mask || e->emb_in || e->perm || e->mems) return MB_ERR_MODE;      // head_mask / inputs_embeds / perm_mask / mems are arguments of explicit forwards only
     e->training = 1;
     CK(xl_prepare_pass(e, B * L, st));
     return train_step_impl(e, e->ws, c.visual_dim, c.acoustic_dim, c.num_labels, input_ids, visual, acoustic, attention_mask, token_type_ids,
@@ -651,7 +664,7 @@ int mb_xlnet_train_step_dp(mb_xlnet_engine* e, const int64_t* input_ids, const f
     if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
     if (!input_ids || !visual || !acoustic || !attention_mask || !token_type_ids || !labels || !logits || !loss) return MB_ERR_ARG;
     if (!m || !v || (mode != 1 && mode != 2)) return MB_ERR_ARG;
-    if (e->deferred || e->head_mask || e->emb_in || e->perm) return MB_ERR_MODE;
+    if (e->deferred || e->head_mask || e->emb_in || e->perm || e->mems) return MB_ERR_MODE;
     const int NL = c.n_layer;
     const std::vector<int> plan = dp_chunk_plan(NL);
     const int nb = (int)plan.size();
@@ -691,6 +704,11 @@ int mb_xlnet_train_step_dp(mb_xlnet_engine* e, const int64_t* input_ids, const f
 int mb_xlnet_set_perm_mask(mb_xlnet_engine* e, const uint8_t* perm) {
     if (!e) return MB_ERR_ARG;
     e->perm = perm;
+    return MB_OK;
+}
+int mb_xlnet_set_mems(mb_xlnet_engine* e, const void* mems, int mlen) {
+    if (!e || (mems && (mlen < 1 || mlen >= e->c.max_seq))) return MB_ERR_ARG;
+    e->mems = (const char*)mems; e->mlen = mems ? mlen : 0;
     return MB_OK;
 }
 int mb_xlnet_set_head_mask(mb_xlnet_engine* e, const float* head_mask) {

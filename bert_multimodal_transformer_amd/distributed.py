@@ -215,18 +215,26 @@ class Comm(object):
 
     # -- callback backend -------------------------------------------------------------------------------------------------------
     def _view(self, ptr, nbytes):
-        for t in (self.core.grads, self.scratch):
+        flat = [self.core.grads, self.scratch, self.core.params, getattr(self.core, "shadow", None), getattr(self.core, "_adam_m", None),
+                getattr(self.core, "_adam_v", None)]          # (the sharded update gathers parameters / the bf16 shadow / Adam moments)
+        for t in flat:
+            if t is None or t.numel() < 2:
+                continue
             base = t.data_ptr()
             if base <= ptr and ptr + nbytes <= base + t.numel() * t.element_size():
                 return t.view(torch.uint8)[ptr - base: ptr - base + nbytes] if t.dtype == torch.uint8 else \
                     t.view(-1).view(torch.uint8)[ptr - base: ptr - base + nbytes]
-        raise RuntimeError("collective over memory that is neither the flat gradient buffer nor the comm scratch")
+        raise RuntimeError("collective over memory that is none of the engine's flat buffers nor the comm scratch")
+
+    def _stream_of(self, stream):
+        """torch stream object of a raw hipStream_t handed to a callback (NULL = the device's default stream)"""
+        return torch.cuda.ExternalStream(stream, device=self.core.device) if stream else torch.cuda.default_stream(self.core.device)
 
     def _all_reduce_cb(self, ctx, buf, count, dtype, stream):
         try:
             tdt = torch.bfloat16 if dtype == self._lib.DT_BF16 else torch.float32
             v = self._view(buf, count * (2 if tdt == torch.bfloat16 else 4)).view(tdt)
-            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.core.device)):
+            with torch.cuda.stream(self._stream_of(stream)):
                 dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.pg)
             return 0
         except Exception:          # an exception must not unwind through the C frames
@@ -238,7 +246,7 @@ class Comm(object):
         try:
             v = self._view(buf, bytes_per_rank * self.world)
             parts = [v[r * bytes_per_rank: (r + 1) * bytes_per_rank] for r in range(self.world)]
-            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.core.device)):
+            with torch.cuda.stream(self._stream_of(stream)):
                 dist.all_gather(parts, parts[self.rank].clone(), group=self.pg)
             return 0
         except Exception:

@@ -6,7 +6,8 @@ Same class names, constructor `(config, multimodal_config)`, forward argument or
 r_w_bias,seg_embed,layer_norm.*}, transformer.layer.{i}.ff.{layer_norm,layer_1,layer_2}.*, transformer.MAG.*,
 sequence_summary.summary.*, logits_proj.*).  Built for the configuration the reference driver runs
 (multimodal_driver.py:363-370: attention_mask + token_type_ids; perm_mask / input_mask are built too (forward kernel + its
-adjoint); target_mapping (the query stream) raises NotImplementedError; inputs_embeds, output_hidden_states / output_attentions (served from the activations the engine keeps for
+adjoint); mems (inference passes) and the new_mems return (config.mem_len, use_cache); target_mapping (the query stream)
+raises NotImplementedError; inputs_embeds, output_hidden_states / output_attentions (served from the activations the engine keeps for
 its backward) and head_mask (scales each head's attention output inside the kernels) are built, and MAG_XLNetModel's output is
 differentiable), sequence length <= 128, MAG injected in front of layer
 XLNET_INJECTION_INDEX (global_configs.py:19, xlnet.py:371-372).
@@ -26,9 +27,10 @@ class XLNetConfig(object):
                  attn_type="bi", initializer_range=0.02, layer_norm_eps=1e-12, dropout=0.1, mem_len=None, reuse_len=None,
                  bi_data=False, clamp_len=-1, same_length=False, summary_type="last", summary_use_proj=True,
                  summary_activation="tanh", summary_last_dropout=0.1, num_labels=1, **kwargs):
-        if ff_activation != "gelu" or attn_type != "bi" or bi_data or clamp_len != -1 or mem_len not in (None, 0) \
+        if ff_activation != "gelu" or attn_type != "bi" or bi_data or clamp_len != -1 or reuse_len not in (None, 0) \
                 or summary_type != "last" or not summary_use_proj or summary_activation != "tanh":
             raise NotImplementedError("only the xlnet-base-cased configuration used by multimodal_driver.py is built")
+        self.mem_len = mem_len          # > 0 with use_cache: forward() also returns new_mems (xlnet.py:81-91, 363-365, 406-407)
         self.vocab_size = vocab_size
         self.d_model = d_model
         self.hidden_size = d_model
@@ -77,31 +79,84 @@ class MAG_XLNetModel(_XlBase):
         """-> (output [B, L, d_model], (hidden_states), (attentions)) like xlnet.py:400-429.  `output` is the last layer's
         hidden state after the final dropout (xlnet.py:396) and carries an autograd edge into the engine: a head built on this
         model trains the whole stack, and inputs_embeds receives its gradient."""
-        _xl_unsupported(self, mems, target_mapping)
+        _xl_unsupported(self, target_mapping)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
         B, L, attention_mask, token_type_ids, perm = _xl_front(self, input_ids, inputs_embeds, attention_mask, token_type_ids, input_mask, perm_mask)
         core = self._core
-        core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, head_mask=head_mask,
+        mlen, stack = 0, None
+        if mems is not None:
+            mlen, input_ids, inputs_embeds, visual, acoustic, attention_mask, token_type_ids, perm, stack = _xl_mems_front(
+                self, mems, input_ids, inputs_embeds, visual, acoustic, attention_mask, token_type_ids, perm)
+        K = mlen + L
+        core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, mems=stack, head_mask=head_mask,
                      inputs_embeds=inputs_embeds, perm=perm)
-        out = core.xl_model_output(B, L)
+        out = core.xl_model_output(B, K)[:, mlen:]
         if torch.is_grad_enabled():
             emb_edge = inputs_embeds if inputs_embeds is not None and inputs_embeds.requires_grad else None
             out, _ = _BaseFn.apply(core.anchor, out, out.new_zeros(1), core, emb_edge)
         outputs = (out,)
+        mem_len = getattr(self.config, "mem_len", None)
+        if mem_len is not None and mem_len > 0 and use_cache is True:          # xlnet.py:363-365, 406-407
+            outputs = outputs + (_xl_new_mems(core, mems, mlen, B, K, mem_len),)
         if output_hidden_states:               # xlnet.py:363-392: the input of every layer (before the MAG injection) + the last output
-            outputs = outputs + (core.hidden_states(B, L),)
-        if output_attentions:                  # xlnet.py:387-427: per layer [B, n_head, L, L], after the attention dropout
-            outputs = outputs + (core.xl_attentions(B, L, self.training),)
+            outputs = outputs + (tuple(h[:, mlen:] for h in core.hidden_states(B, K)),)
+        if output_attentions:                  # xlnet.py:387-427: per layer [B, n_head, qlen, klen], after the attention dropout
+            outputs = outputs + (tuple(a[:, :, mlen:] for a in core.xl_attentions(B, K, self.training)),)
         return outputs
 
+def _xl_mems_front(model, mems, input_ids, inputs_embeds, visual, acoustic, attention_mask, token_type_ids, perm):
+    """mems (xlnet.py:244-245, 276-293, 317-323, 374-385): n_layer tensors [mlen, B, d_model], the hidden states cached from the previous
+    segment.  Keys / values of layer l run over cat([mems[l], h]); queries over h.  The engine takes the segment as klen = mlen + L
+    rows per sample whose first mlen rows are placeholders -- dummy ids, zero modalities, visible (the reference's mems_mask is all
+    zeros), segment id 0 (the reference's mem_pad) -- and replaces those rows of every layer's input by mems[l]
+    (include/magbert_hip.h: mb_xlnet_set_mems).  Inference only.  -> (mlen, the extended arguments..., stacked memories)"""
+    core = model._core
+    if model.training or torch.is_grad_enabled():
+        raise NotImplementedError("mems are built for inference passes (model.eval() under torch.no_grad()); training with cached "
+                                  "memories (xlnet.py:374-385) is not")
+    mems = list(mems)
+    if len(mems) != core.n_layers or any(m is None for m in mems):
+        raise ValueError("mems must hold one tensor per layer (%d), got %d" % (core.n_layers, len(mems)))
+    B, L = input_ids.shape if input_ids is not None else inputs_embeds.shape[:2]
+    mlen, H, dev = int(mems[0].shape[0]), core.config.d_model, core.device
+    if any(tuple(m.shape) != (mlen, B, H) for m in mems):
+        raise ValueError("every element of mems must be [mlen, batch, d_model] = %s" % ((mlen, B, H),))
+    if mlen + L > 128:
+        raise NotImplementedError("klen = mlen + seq_len = %d exceeds the 128 rows the relative-attention kernels hold" % (mlen + L))
+    stack = torch.stack([m.detach().to(dev, torch.float32).permute(1, 0, 2) for m in mems]).to(core.compute_dtype).contiguous()
+    pad = lambda t, fill, dt: torch.cat([torch.full((B, mlen) + tuple(t.shape[2:]), fill, dtype=dt, device=dev), t.to(dev, dt)], dim=1)
+    if input_ids is not None:
+        input_ids = pad(input_ids, 0, torch.int64)
+    else:
+        inputs_embeds = pad(inputs_embeds, 0.0, torch.float32)
+    visual, acoustic = pad(visual, 0.0, torch.float32), pad(acoustic, 0.0, torch.float32)
+    attention_mask = pad(attention_mask, 1, torch.int64)
+    token_type_ids = pad(token_type_ids, 0, torch.int64)
+    if perm is not None:                 # [B, L, L] -> [B, klen, klen]: every memory key is visible to every query
+        ext = torch.zeros(B, mlen + L, mlen + L, dtype=torch.uint8, device=dev)
+        ext[:, mlen:, mlen:] = perm.to(dev)
+        perm = ext
+    return mlen, input_ids, inputs_embeds, visual, acoustic, attention_mask, token_type_ids, perm, stack
 
-def _xl_unsupported(model, mems, target_mapping):
-    """The reference driver never passes these (multimodal_driver.py:363-370): cached memories of earlier segments (xlnet.py:81-91,
-    363-369) and the query stream of permutation-LM pre-training (xlnet.py:306-313, 387-427) -- neither exists in a fine-tuning
-    encoder (DESIGN.md section 7 lists the reference lines)."""
-    model._unsupported(mems=mems, target_mapping=target_mapping)
+
+def _xl_new_mems(core, mems, mlen, B, klen, mem_len):
+    """xlnet.py:81-91 (reuse_len None), 363-365: per layer, the last mem_len rows of cat([prev_mem, curr_out]) where curr_out is the
+    hidden state in front of the layer (before the MAG injection), [len, B, d_model], detached"""
+    hs = core.hidden_states(B, klen)
+    out = []
+    for i in range(core.n_layers):
+        cur = hs[i][:, mlen:].permute(1, 0, 2)
+        new = cur if mems is None else torch.cat([mems[i].to(cur.device, cur.dtype), cur], dim=0)
+        out.append(new[-mem_len:].detach().contiguous())
+    return tuple(out)
+
+
+def _xl_unsupported(model, target_mapping):
+    """The reference driver never passes it (multimodal_driver.py:363-370): the query stream of permutation-LM pre-training
+    (xlnet.py:306-313, 387-427) does not exist in a fine-tuning encoder (DESIGN.md section 7 lists the reference lines)."""
+    model._unsupported(target_mapping=target_mapping)
 
 
 def _xl_front(model, input_ids, inputs_embeds, attention_mask, token_type_ids, input_mask=None, perm_mask=None):
@@ -154,22 +209,30 @@ class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
     def forward(self, input_ids, visual, acoustic, attention_mask=None, mems=None, perm_mask=None, target_mapping=None,
                 token_type_ids=None, input_mask=None, head_mask=None, inputs_embeds=None, use_cache=True, labels=None,
                 output_attentions=None, output_hidden_states=None):
-        _xl_unsupported(self, mems, target_mapping)
+        _xl_unsupported(self, target_mapping)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
         B, L, attention_mask, token_type_ids, perm = _xl_front(self, input_ids, inputs_embeds, attention_mask, token_type_ids, input_mask, perm_mask)
         core = self._core
-        logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, head_mask=head_mask,
+        mlen, stack = 0, None
+        if mems is not None:
+            mlen, input_ids, inputs_embeds, visual, acoustic, attention_mask, token_type_ids, perm, stack = _xl_mems_front(
+                self, mems, input_ids, inputs_embeds, visual, acoustic, attention_mask, token_type_ids, perm)
+        K = mlen + L
+        logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, mems=stack, head_mask=head_mask,
                               inputs_embeds=inputs_embeds, perm=perm)
         if torch.is_grad_enabled():
             emb_edge = inputs_embeds if inputs_embeds is not None and inputs_embeds.requires_grad else None
             logits = _EngineFn.apply(core.anchor, logits, core, emb_edge)
         outputs = (logits,)
+        mem_len = getattr(self.config, "mem_len", None)
+        if mem_len is not None and mem_len > 0 and use_cache is True:          # xlnet.py:363-365, 406-407, 511-513: (logits, mems, ...)
+            outputs = outputs + (_xl_new_mems(core, mems, mlen, B, K, mem_len),)
         if output_hidden_states:
-            outputs = outputs + (core.hidden_states(B, L),)
+            outputs = outputs + (tuple(h[:, mlen:] for h in core.hidden_states(B, K)),)
         if output_attentions:
-            outputs = outputs + (core.xl_attentions(B, L, self.training),)
+            outputs = outputs + (tuple(a[:, :, mlen:] for a in core.xl_attentions(B, K, self.training)),)
         if labels is not None:                                        # xlnet.py:515-524
             if self.num_labels == 1:
                 loss = torch.nn.functional.mse_loss(logits.view(-1), labels.to(logits.device).float().view(-1))

@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE -- pure-torch fp32 CPU restatement of the MAG-XLNet hot path (BASELINE.json config 4).
 
 Restates MAG_XLNetModel.forward / MAG_XLNetForSequenceClassification.forward (xlnet.py:148-429, 443-527) for the only
-configuration the driver exercises (xlnet-base-cased: attn_type "bi", bi_data False, clamp_len -1, mem_len None, no
-target_mapping / mems; multimodal_driver.py:363-370) and the transformers==3.0.2 XLNetLayer
+configuration the driver exercises (xlnet-base-cased: attn_type "bi", bi_data False, clamp_len -1, no target_mapping;
+multimodal_driver.py:363-370; round 5: mems / mem_len, xlnet.py:81-91, 244-245, 276-293, 317-323, 363-365) and the transformers==3.0.2 XLNetLayer
 (XLNetRelativeAttention + XLNetFeedForward) and SequenceSummary it calls (xlnet.py:30,374-385,438,508).  Checked against
 the reference's own Python by oracle/make_golden.py (G6 fixtures).  Works in the reference's [L, B, .] layout internally.
 
@@ -56,10 +56,13 @@ class XLNetRelativeAttention(nn.Module):
         x = x.reshape(s[0], s[1], s[2], s[3] - 1)
         return x[:, :, :, :klen]          # => bd[i, j] = raw[i, L - i + j]
 
-    def forward(self, h, attn_mask, r, seg_mat, head_mask=None):
+    def forward(self, h, attn_mask, r, seg_mat, head_mask=None, mems=None):
+        # 3.0.2 XLNetRelativeAttention.forward: keys and values over cat([mems, h]) (the cached hidden states of the previous
+        # segment, xlnet.py:374-385 passes mems[i]); queries over h only
+        cat = h if mems is None else torch.cat([mems, h], dim=0)
         q = torch.einsum("ibh,hnd->ibnd", h, self.q)
-        k = torch.einsum("ibh,hnd->ibnd", h, self.k)
-        v = torch.einsum("ibh,hnd->ibnd", h, self.v)
+        k = torch.einsum("ibh,hnd->ibnd", cat, self.k)
+        v = torch.einsum("ibh,hnd->ibnd", cat, self.v)
         kr = torch.einsum("ibh,hnd->ibnd", r, self.r)
         ac = torch.einsum("ibnd,jbnd->bnij", q + self.r_w_bias, k)
         bd = self.rel_shift_bnij(torch.einsum("ibnd,jbnd->bnij", q + self.r_r_bias, kr), ac.shape[3])
@@ -96,8 +99,8 @@ class XLNetLayer(nn.Module):
         self.rel_attn = XLNetRelativeAttention(c)
         self.ff = XLNetFeedForward(c)
 
-    def forward(self, h, attn_mask, r, seg_mat, head_mask=None):
-        return self.ff(self.rel_attn(h, attn_mask, r, seg_mat, head_mask))
+    def forward(self, h, attn_mask, r, seg_mat, head_mask=None, mems=None):
+        return self.ff(self.rel_attn(h, attn_mask, r, seg_mat, head_mask, mems))
 
 
 class MAG_XLNetModel(nn.Module):
@@ -121,8 +124,17 @@ class MAG_XLNetModel(nn.Module):
         pos_emb = torch.cat([torch.sin(sinusoid), torch.cos(sinusoid)], dim=-1)
         return pos_emb[:, None, :].expand(-1, bsz, -1)
 
+    @staticmethod
+    def cache_mem(curr_out, prev_mem, mem_len):
+        """xlnet.py:81-91 (reuse_len None): the last mem_len rows of cat([prev_mem, curr_out]), detached"""
+        new_mem = curr_out[-mem_len:] if prev_mem is None else torch.cat([prev_mem, curr_out], dim=0)[-mem_len:]
+        return new_mem.detach()
+
     def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask=None, inputs_embeds=None,
-                perm_mask=None, input_mask=None):
+                perm_mask=None, input_mask=None, mems=None, mem_len=None):
+        """mems: list of n_layer tensors [mlen, B, d] (the hidden states cached from the previous segment, xlnet.py:244-245,
+        374-385) or None; mem_len: > 0 -> self.new_mems is set to the n_layer tensors cache_mem produces (xlnet.py:363-365,
+        use_cache True)"""
         if head_mask is not None:            # xlnet.py:340-353: [n_head] -> every layer, [n_layer][n_head] as is
             head_mask = head_mask.to(torch.float32)
             if head_mask.dim() == 1:
@@ -139,6 +151,7 @@ class MAG_XLNetModel(nn.Module):
         assert input_mask is None or attention_mask is None                            # xlnet.py:258-262
         input_mask = input_mask.transpose(0, 1).contiguous().float() if input_mask is not None else None      # xlnet.py:236
         perm_mask = perm_mask.permute(1, 2, 0).contiguous().float() if perm_mask is not None else None        # xlnet.py:237: [i, j, b]
+        mlen = mems[0].shape[0] if mems is not None and mems[0] is not None else 0      # xlnet.py:244-245; klen = mlen + L
         if input_mask is None and attention_mask is not None:
             input_mask = 1.0 - attention_mask.transpose(0, 1).contiguous().float()      # xlnet.py:263-264
         if input_mask is not None and perm_mask is not None:                            # xlnet.py:265-272
@@ -150,20 +163,28 @@ class MAG_XLNetModel(nn.Module):
         else:
             data_mask = None
         if data_mask is not None:
-            attn_mask = (data_mask[:, :, :, None] > 0).float()                          # xlnet.py:274-286 : [1 | L, L, B, 1]
-            non_tgt = ((attn_mask - torch.eye(L)[:, :, None, None]) > 0).float()        # xlnet.py:288-296 : [L, L, B, 1]
+            if mlen > 0:                                                                # xlnet.py:276-280: all mems can be attended to
+                data_mask = torch.cat([torch.zeros(data_mask.shape[0], mlen, B), data_mask], dim=1)
+            attn_mask = (data_mask[:, :, :, None] > 0).float()                          # xlnet.py:274-286 : [1 | L, klen, B, 1]
+            eye = torch.eye(L) if mlen == 0 else torch.cat([torch.zeros(L, mlen), torch.eye(L)], dim=-1)      # xlnet.py:289-293
+            non_tgt = ((attn_mask - eye[:, :, None, None]) > 0).float()                 # xlnet.py:288-296 : [L, klen, B, 1]
         else:
-            non_tgt = torch.zeros(L, L, B, 1)                                           # (attn_mask None: nothing is masked)
+            non_tgt = torch.zeros(L, L + mlen, B, 1)                                    # (attn_mask None: nothing is masked)
         h = self.dropout(emb if inputs_embeds is not None else self.word_embedding(ids))        # xlnet.py:301-305
-        seg_mat = (seg[:, None] != seg[None, :]).long()                                 # xlnet.py:326
+        cat_ids = seg if mlen == 0 else torch.cat([torch.zeros(mlen, B, dtype=seg.dtype), seg], dim=0)      # xlnet.py:317-323: mem_pad
+        seg_mat = (seg[:, None] != cat_ids[None, :]).long()                             # xlnet.py:326
         seg_mat = F.one_hot(seg_mat, num_classes=2).float()                             # xlnet.py:327
         dt = self.word_embedding.weight.dtype          # float32; float64 when a conditioning analysis runs the oracle in double
         non_tgt, seg_mat = non_tgt.to(dt), seg_mat.to(dt)
-        pos_emb = self.dropout(self.relative_positional_encoding(L, L, B).to(dt))       # xlnet.py:332-333
+        pos_emb = self.dropout(self.relative_positional_encoding(L, L + mlen, B).to(dt))       # xlnet.py:332-333
+        self.new_mems = None if not mem_len else []
         for i, layer in enumerate(self.layer):
+            if mem_len:                                                                 # xlnet.py:363-365
+                self.new_mems.append(self.cache_mem(h, None if mems is None else mems[i], mem_len))
             if i == self.injection_index:
                 h = self.MAG(h, visual, acoustic)                                       # xlnet.py:371-372
-            h = layer(h, non_tgt, pos_emb, seg_mat, None if head_mask is None else head_mask[i])     # xlnet.py:374-385
+            h = layer(h, non_tgt, pos_emb, seg_mat, None if head_mask is None else head_mask[i],
+                      None if mems is None else mems[i])                                # xlnet.py:374-385
         return self.dropout(h).permute(1, 0, 2).contiguous()                            # xlnet.py:396-399
 
 
@@ -190,8 +211,9 @@ class MAG_XLNetForSequenceClassification(nn.Module):
         self.logits_proj = nn.Linear(config.d_model, config.num_labels)
 
     def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels=None, head_mask=None, inputs_embeds=None,
-                perm_mask=None, input_mask=None):
-        out = self.transformer(input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask, inputs_embeds, perm_mask, input_mask)
+                perm_mask=None, input_mask=None, mems=None, mem_len=None):
+        out = self.transformer(input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask, inputs_embeds, perm_mask, input_mask,
+                               mems, mem_len)
         logits = self.logits_proj(self.sequence_summary(out))                           # xlnet.py:506-509
         outputs = (logits,)
         if labels is not None:                                                          # xlnet.py:515-524

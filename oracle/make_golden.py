@@ -294,6 +294,32 @@ def gen_xlnet(modeling, xlnet):
     out["logits_input_mask/B4_L50_seed31"] = a_im.numpy()
     out["logits_perm_mask/B4_L50_seed31"] = a_pm.numpy()
     out["perm_mask/B4_L50_rs77"] = perm.numpy().astype(np.uint8)
+    # round 5: mems (xlnet.py:81-91, 244-245, 276-293, 317-323, 363-385).  Segment 1 runs with use_cache and mem_len set -> new_mems (the
+    # hidden state in front of every layer); segment 2 consumes them (keys / values over cat([mem, h]), klen = mlen + L) and caches again
+    for (B, L, ml, seed) in ((4, 24, 24, 36), (3, 50, 40, 37)):          # klen 48 (one strip group) and 90 (above the L = 64 kernel boundary)
+        ref.transformer.mem_len = ml
+        b1, b2 = _tb(weights.synthetic_xlnet_batch(B, L, 47, 74, seed=seed)), _tb(weights.synthetic_xlnet_batch(B, L, 47, 74, seed=seed + 100))
+        with torch.no_grad():
+            r1 = ref(b1[0], b1[1], b1[2], token_type_ids=b1[4], attention_mask=b1[3], labels=None, use_cache=True)
+            r2 = ref(b2[0], b2[1], b2[2], token_type_ids=b2[4], attention_mask=b2[3], labels=None, use_cache=True, mems=list(r1[1]))
+            m1 = mine(b1[0], b1[1], b1[2], b1[3], b1[4], mem_len=ml)
+            mems1 = mine.transformer.new_mems
+            m2 = mine(b2[0], b2[1], b2[2], b2[3], b2[4], mems=mems1, mem_len=ml)
+            mems2 = mine.transformer.new_mems
+        d1, d2 = _maxdiff(r1[0], m1[0]), _maxdiff(r2[0], m2[0])
+        dm1 = max(_maxdiff(a_, b_) for a_, b_ in zip(r1[1], mems1))
+        dm2 = max(_maxdiff(a_, b_) for a_, b_ in zip(r2[1], mems2))
+        no_mem = mine(b2[0], b2[1], b2[2], b2[3], b2[4])[0]
+        print("G6 xlnet mems B=%d L=%d mem_len=%d: logits seg 1 / seg 2 max |diff| = %.3g / %.3g, new_mems %.3g / %.3g; the memory moves the "
+              "segment-2 logits by %.3g" % (B, L, ml, d1, d2, dm1, dm2, _maxdiff(r2[0], no_mem)))
+        assert max(d1, d2) < 2e-5 and max(dm1, dm2) < 2e-5 and tuple(r2[1][0].shape) == (min(ml, 2 * L), B, 768)
+        tag = "B%d_L%d_M%d_seed%d" % (B, L, ml, seed)
+        out["mems/logits_seg1/" + tag] = r1[0].numpy()
+        out["mems/logits_seg2/" + tag] = r2[0].numpy()
+        for i in (0, 1, 2, 11):          # layer 0 = the embeddings, 1 = in front of the MAG injection, 2 = behind it
+            out["mems/new_mems_seg1/%s/layer%d" % (tag, i)] = _slice(r1[1][i], 64)
+            out["mems/new_mems_seg2/%s/layer%d" % (tag, i)] = _slice(r2[1][i], 64)
+    ref.transformer.mem_len = None
     ref, mine = pair(p_mag=0.0)
     for m in (ref, mine):
         m.train()

@@ -28,5 +28,9 @@ nf, f = pick(fe, "adamw"); nw, w = pick(wr, "adamw")
 # two launches per step (decay / no-decay group): the table holds the mean over both, so x2 = bytes per step
 doc["kernels"]["adamw"] = {"fetch_bytes": int(2 * f * 1024 * 2), "write_bytes": int(w * 1024 * 2), "algorithmic_bytes": 28 * 110853121,
                            "note": "per step (both launches); reads p, g, m, v = 16 B/param = 1.774 GB: the calibration point of the x2 correction"}
+# every symbol both passes saw, keyed by the first 90 characters of its name (what pmc_reduce.py keeps): bench.py looks its
+# in-run trace's dominant symbol up here, whichever kernel that is
+doc["by_symbol"] = {k: {"launches": n, "fetch_bytes": int(2 * v * 1024), "write_bytes": int(wr[k][1] * 1024)}
+                    for k, (n, v) in fe.items() if k in wr and "adamw" not in k}
 json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps(doc["kernels"]))

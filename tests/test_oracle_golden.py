@@ -112,3 +112,27 @@ def test_xlnet_oracle_logits_and_grads(golden):
         if p.grad is not None:
             np.testing.assert_allclose(float(p.grad.norm()), float(g["train/gnorm/" + n]), rtol=2e-3, atol=1e-6)
             np.testing.assert_allclose(weights.strided_sample(p.grad.numpy(), 16), g["train/gslice/" + n], rtol=5e-3, atol=1e-6)
+
+
+def test_xlnet_oracle_mems(golden):
+    """G6, round 5: the oracle's mems / mem_len path (xlnet.py:81-91, 244-245, 276-293, 317-323, 363-385) vs the reference's own outputs:
+    segment 1 caches, segment 2 consumes (klen = mlen + L) and caches again -- logits of both segments, samples of the memories."""
+    from oracle import mag_xlnet_ref as X
+    g = golden["g6_xlnet"]
+    torch.set_num_threads(8)
+    B, L, ml, seed = 4, 24, 24, 36
+    tag = "B%d_L%d_M%d_seed%d" % (B, L, ml, seed)
+    t = lambda b: (torch.from_numpy(b["input_ids"]), torch.from_numpy(b["visual"]), torch.from_numpy(b["acoustic"]),
+                   torch.from_numpy(b["input_mask"]), torch.from_numpy(b["segment_ids"]))
+    m = X.load_deterministic(X.MAG_XLNetForSequenceClassification(X.XLNetConfigLite(), X.MultimodalConfig(1.0, 0.5), 47, 74)).eval()
+    with torch.no_grad():
+        l1 = m(*t(weights.synthetic_xlnet_batch(B, L, 47, 74, seed=seed)), mem_len=ml)[0]
+        mems1 = m.transformer.new_mems
+        l2 = m(*t(weights.synthetic_xlnet_batch(B, L, 47, 74, seed=seed + 100)), mems=mems1, mem_len=ml)[0]
+        mems2 = m.transformer.new_mems
+    np.testing.assert_allclose(l1.numpy(), g["mems/logits_seg1/" + tag], atol=2e-5)
+    np.testing.assert_allclose(l2.numpy(), g["mems/logits_seg2/" + tag], atol=2e-5)
+    assert len(mems2) == 12 and tuple(mems2[0].shape) == (ml, B, 768)
+    for i in (0, 1, 2, 11):
+        np.testing.assert_allclose(weights.strided_sample(mems1[i].numpy(), 64), g["mems/new_mems_seg1/%s/layer%d" % (tag, i)], atol=2e-5)
+        np.testing.assert_allclose(weights.strided_sample(mems2[i].numpy(), 64), g["mems/new_mems_seg2/%s/layer%d" % (tag, i)], atol=2e-5)

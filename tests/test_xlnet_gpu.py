@@ -23,8 +23,8 @@ from oracle import weights
 DEV = "cuda:0"
 
 
-def build(layers=12, cdt=torch.float32, p_mag=0.5, p=0.1, mode="test", V=47):
-    cfg = XLNetConfig(n_layer=layers, num_labels=1, dropout=p, summary_last_dropout=p)
+def build(layers=12, cdt=torch.float32, p_mag=0.5, p=0.1, mode="test", V=47, mem_len=None):
+    cfg = XLNetConfig(n_layer=layers, num_labels=1, dropout=p, summary_last_dropout=p, mem_len=mem_len)
     m = MAG_XLNetForSequenceClassification(cfg, MultimodalConfig(1.0, p_mag), visual_dim=V, acoustic_dim=74, compute_dtype=cdt)
     sd = {n: torch.from_numpy(weights.make_param(n, tuple(q.shape), mode)) for n, q in m.named_parameters()}
     m.load_state_dict(sd)
@@ -330,6 +330,13 @@ def test_train_mode_dropout_mask_replay(cdt, tol_logit, tol_grad, L, layers, B):
     legs run the fused training step (what train_epoch / bench.py call); the 2-layer legs the autograd route with attentions."""
     nh, H, DI = 12, 768, 3072
     full = layers == 12
+    # The engine's dropout seed is torch.initial_seed() at model creation: without this line every pytest run draws other masks, and
+    # about one draw in a hundred puts a pre-activation of MAG's relu gates (modeling.py:27-28) within fp32 rounding of zero -- the
+    # CPU and the GPU then take different sides of a discontinuous derivative: identical logits, one token's contribution to
+    # dW_hv / dW_ha flipped (3e-2 .. 8e-2 of the tensor's largest gradient).  That was round 4's "7.9e-2 at MAG.W_ha once in eight
+    # runs" (scripts/exp/flake_hunt.py --vary reproduces it at will and compares both sides with a float64 oracle:
+    # profiles/r05_flake_hunt.txt).  A pinned seed makes the case the same every run.
+    torch.manual_seed(99)
     m = build(layers, cdt).train()
     o = oracle(layers).train()
     core = m._core
@@ -471,6 +478,72 @@ def test_long_sequences_train_vs_oracle(cdt, L, tol_logit, tol_grad):
     # the fused single-call step runs at this length too (graph capture included)
     m.zero_grad()
     m.train_step(ids, vis, aco, mask, seg, lab, optimizer=None)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,L,ml,seed,cdt", [(4, 24, 24, 36, torch.float32), (3, 50, 40, 37, torch.float32), (3, 50, 40, 37, torch.bfloat16)])
+def test_mems_match_reference_golden(golden, B, L, ml, seed, cdt):
+    """f-4, mems (xlnet.py:81-91, 244-245, 276-293, 317-323, 363-385): segment 1 with use_cache and config.mem_len -> new_mems; segment 2
+    consumes them (keys / values over cat([mem, h]): klen = 48, and 90 -- above the L = 64 kernel boundary) and caches again.
+    Logits of both segments and samples of the cached memories against the values the REFERENCE's own xlnet.py produced
+    (tests/golden/g6_xlnet.npz, oracle/make_golden.py), and -- attentions [B, n_head, qlen, klen], hidden states -- against the
+    oracle run live.  fp32 <= 1e-3 (north_star); bf16 logits <= 5e-2."""
+    fp32 = cdt == torch.float32
+    g = golden["g6_xlnet"]
+    tag = "B%d_L%d_M%d_seed%d" % (B, L, ml, seed)
+    m = build(cdt=cdt, mem_len=ml).eval()
+    o = oracle().eval()
+    b1, b2 = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=seed), weights.synthetic_xlnet_batch(B, L, 47, 74, seed=seed + 100)
+    i1, v1, a1, m1, s1, _ = tb(b1, DEV)
+    i2, v2, a2, m2, s2, _ = tb(b2, DEV)
+    with torch.no_grad():
+        r1 = m(i1, v1, a1, token_type_ids=s1, attention_mask=m1, use_cache=True)
+        assert len(r1) == 2 and len(r1[1]) == 12 and tuple(r1[1][0].shape) == (min(ml, L), B, 768)
+        r2 = m(i2, v2, a2, token_type_ids=s2, attention_mask=m2, use_cache=True, mems=list(r1[1]), output_attentions=True,
+               output_hidden_states=True)
+        c2 = tb(b2)
+        mems_cpu = [t.cpu() for t in r1[1]]
+        lo = o(c2[0], c2[1], c2[2], c2[3], c2[4], mems=mems_cpu, mem_len=ml)[0]
+    tol = 1e-3 if fp32 else 5e-2
+    e1 = float(np.abs(r1[0].cpu().numpy() - g["mems/logits_seg1/" + tag]).max())
+    e2 = float(np.abs(r2[0].cpu().numpy() - g["mems/logits_seg2/" + tag]).max())
+    eo = float((r2[0].cpu() - lo).abs().max())
+    print("mems %s %s: logits vs reference golden seg 1 %.2e, seg 2 %.2e (vs the oracle fed OUR memories %.2e)" % (tag, cdt, e1, e2, eo))
+    assert e1 <= tol and e2 <= tol and eo <= tol
+    assert len(r2) == 4 and tuple(r2[1][0].shape) == (min(ml, 2 * L), B, 768)
+    worst = 0.0
+    for seg_name, mems in (("seg1", r1[1]), ("seg2", r2[1])):
+        for i in (0, 1, 2, 11):
+            ref = g["mems/new_mems_%s/%s/layer%d" % (seg_name, tag, i)]
+            got = weights.strided_sample(mems[i].float().cpu().numpy(), 64)
+            worst = max(worst, float(np.abs(got - ref).max()) / max(float(np.abs(ref).max()), 1e-6))
+    print("new_mems samples vs reference golden: worst relative error %.2e" % worst)
+    assert worst <= (1e-3 if fp32 else 3e-2)
+    # hidden states [B, qlen, d] x 13 and attentions [B, n_head, qlen, klen] x 12 of the segment that consumed memories
+    assert len(r2[2]) == 13 and tuple(r2[2][0].shape) == (B, L, 768)
+    assert len(r2[3]) == 12 and tuple(r2[3][0].shape) == (B, 12, L, min(ml, L) + L)
+    perr = max(float((r2[3][l].cpu() - lyr.rel_attn.last_probs).abs().max()) for l, lyr in enumerate(o.transformer.layer))
+    print("attention probabilities over klen = %d keys vs the oracle: %.2e" % (min(ml, L) + L, perr))
+    assert perr <= (1e-5 if fp32 else 2e-2)
+
+
+def test_mems_argument_checks():
+    m = build(layers=2, mem_len=16)
+    ids, vis, aco, mask, seg, _ = tb(weights.synthetic_xlnet_batch(2, 24, 47, 74, seed=3), DEV)
+    mems = [torch.zeros(16, 2, 768) for _ in range(2)]
+    with pytest.raises(NotImplementedError):                 # training with cached memories is not built
+        m.train()(ids, vis, aco, token_type_ids=seg, attention_mask=mask, mems=mems)
+    m.eval()
+    with torch.no_grad():
+        with pytest.raises(ValueError):
+            m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, mems=mems[:1])
+        with pytest.raises(NotImplementedError):             # klen = 120 + 24 > 128
+            m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, mems=[torch.zeros(120, 2, 768) for _ in range(2)])
+        out = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, mems=mems, use_cache=False)
+        assert len(out) == 1
+    # the training step is unaffected by a memory pass before it (the engine's mems pointer is per pass)
+    m.train()
+    m.train_step(ids, vis, aco, mask, seg, torch.zeros(2, device=DEV), optimizer=None)
     torch.cuda.synchronize()
 
 

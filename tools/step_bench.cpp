@@ -5,7 +5,7 @@
 // plain C++ process, so a GPU-box visit costs seconds instead of a Python/torch start-up, and rocprofv3 can wrap it.
 //
 //   step_bench [--steps K] [--warmup W] [--batch B] [--seq L] [--dtype bf16|fp32] [--visual V] [--layers N]
-//              [--graph 0|1|2] [--h2d 0|1|2] [--nbatch n] [--dp 0|1] [--wire fp32|bf16] [--sparse 0|1] [--timing 0|1]
+//              [--graph 0|1|2] [--h2d 0|1|2] [--nbatch n] [--dp 0|1] [--wire fp32|bf16] [--sparse 0|1] [--timing 0|1] [--shard 0|1]
 //   --dp 1:  the data-parallel step, mb_bert_train_step_dp, with a ONE-rank RCCL communicator created here through the C ABI
 //            (mb_comm_unique_id / mb_comm_create_rccl): the N > 1 code path -- graph chain, comm stream, events, ncclAllReduce /
 //            ncclAllGather calls, the row-wise word-embedding exchange -- without a second GPU.  Needs --graph 1|2.
@@ -36,7 +36,7 @@ struct Batch { int64_t *ids, *seg, *mask; float *vis, *aco, *lab; };
 
 int main(int argc, char** argv) {
     int steps = 30, warmup = 5, B = 48, L = 50, V = 47, A = 74, layers = 12, graph = 0, h2d = 0, nbatch = 4, dtype = MB_DT_BF16;
-    int dp = 0, wire = MB_DT_F32, sparse = 1, timing = 0;
+    int dp = 0, wire = MB_DT_F32, sparse = 1, timing = 0, shard = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i]; const char* v = argv[i + 1];
         if (k == "--steps") steps = atoi(v); else if (k == "--warmup") warmup = atoi(v); else if (k == "--batch") B = atoi(v);
@@ -44,6 +44,7 @@ int main(int argc, char** argv) {
         else if (k == "--graph") graph = atoi(v); else if (k == "--h2d") h2d = atoi(v); else if (k == "--nbatch") nbatch = atoi(v);
         else if (k == "--dtype") dtype = strcmp(v, "fp32") == 0 ? MB_DT_F32 : MB_DT_BF16;
         else if (k == "--dp") dp = atoi(v); else if (k == "--sparse") sparse = atoi(v); else if (k == "--timing") timing = atoi(v);
+        else if (k == "--shard") shard = atoi(v);
         else if (k == "--wire") wire = strcmp(v, "bf16") == 0 ? MB_DT_BF16 : MB_DT_F32;
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 1; }
     }
@@ -114,6 +115,7 @@ int main(int argc, char** argv) {
         void* scratch; HCK(hipMalloc(&scratch, sb));
         MCK(mb_comm_bind_scratch(comm, scratch, sb, wire, n, vocab, c.hidden_size, B * L));
         MCK(mb_comm_set_timing(comm, timing));
+        if (shard) { MCK(mb_comm_set_sharding(comm, 1)); if (!mb_comm_sharding(comm)) fprintf(stderr, "--shard 1: a one-rank group shards nothing without MB_DP_SHARD_FORCE=1\n"); }
         HCK(hipDeviceSynchronize());
     }
     const float lr = 1e-5f, b1 = 0.9f, b2 = 0.999f, eps = 1e-6f, wd = 0.01f;
@@ -160,8 +162,8 @@ int main(int argc, char** argv) {
     if (comm) {
         float ex = 0.f; size_t pieces = 0, cbytes = 0;
         MCK(mb_comm_exposed_ms(comm, &ex)); MCK(mb_comm_stats(comm, &pieces, &cbytes));
-        printf("step_bench dp: 1-rank RCCL, wire=%s sparse=%d : %zu collectives / %.1f MB per step, comm_exposed %.4f ms (last step)\n",
-               wire == MB_DT_BF16 ? "bf16" : "fp32", sparse, pieces, cbytes * 1e-6, ex);
+        printf("step_bench dp: 1-rank RCCL, wire=%s sparse=%d shard=%d : %zu collectives / %.1f MB per step, comm_exposed %.4f ms (last step)\n",
+               wire == MB_DT_BF16 ? "bf16" : "fp32", sparse, mb_comm_sharding(comm), pieces, cbytes * 1e-6, ex);
         mb_comm_destroy(comm);
     }
     mb_bert_destroy(e);
