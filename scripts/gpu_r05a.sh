@@ -14,5 +14,8 @@ for rep in 1 2; do
   echo "== --dp 1 --shard 1 (MB_DP_SHARD_FORCE=1), mode 2"; MB_DP_SHARD_FORCE=1 timeout 180 $SB --graph 1 --h2d 2 --steps 200 --warmup 20 --dp 1 --shard 1 2>&1 | grep "ms/step\|step_bench dp"
   echo "== --dp 1 --shard 1 (MB_DP_SHARD_FORCE=1), mode 3"; MB_DP_EVENT_MODE=3 MB_DP_SHARD_FORCE=1 timeout 180 $SB --graph 1 --h2d 2 --steps 200 --warmup 20 --dp 1 --shard 1 2>&1 | grep "ms/step"
 done
+for chunks in "6,6" "12" "4,4,4" "2,2,2,2,2,2"; do
+  echo "== --dp 1, mode 2, MB_DP_CHUNKS=$chunks (layers per backward segment)"; MB_DP_CHUNKS=$chunks timeout 180 $SB --graph 1 --h2d 2 --steps 200 --warmup 20 --dp 1 2>&1 | grep "ms/step"
+done
 } > $O/dp_event_modes.txt 2>&1
 cat $O/dp_event_modes.txt

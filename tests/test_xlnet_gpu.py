@@ -317,6 +317,93 @@ class _SeqReplay(torch.nn.Module):
         return x * mlt
 
 
+def oracle_replay_grads(layers, B, L, seed, step, b, double=False, probe=None, flip=None):
+    """flip = (gate, index): the sign of that ONE pre-activation of MAG's relu gate `gate` ("W_hv" | "W_ha") is inverted (|x| ~ 1e-7: the
+    forward does not change, the gate's derivative does)"""
+    o = oracle(layers).train()
+    if double:
+        o = o.double()
+    if flip is not None:
+        def _flip(mod, args, out, idx=tuple(flip[1])):
+            out = out.clone()
+            out[idx] = -out[idx]
+            return out
+        getattr(o.transformer.MAG, flip[0]).register_forward_hook(_flip)
+    if probe is not None:          # the pre-activations of MAG's relu gates (modeling.py:27-28) ...
+        for lin in (o.transformer.MAG.W_hv, o.transformer.MAG.W_ha):
+            lin.register_forward_hook(lambda mod, args, out: probe.append(out.detach()))
+
+        def _clamp_margin(mod, args):          # ... and the argument of the other kink, alpha = min(|e| / (|h_m| + eps) * beta, 1) (modeling.py:32-43)
+            e, v, a = (x.detach() for x in args)
+            lin = lambda layer, x: F.linear(x, layer.weight, layer.bias)          # (not layer(x): that would fire the probes' hooks)
+            wv = torch.relu(lin(mod.W_hv, torch.cat((v, e), dim=-1)))
+            wa = torch.relu(lin(mod.W_ha, torch.cat((a, e), dim=-1)))
+            hm = (wv * lin(mod.W_v, v) + wa * lin(mod.W_a, a)).norm(2, dim=-1)
+            hm = torch.where(hm == 0, torch.ones_like(hm), hm)
+            probe.append((e.norm(2, dim=-1) / (hm + 1e-6) * mod.beta_shift - 1.0).detach())
+        o.transformer.MAG.register_forward_pre_hook(_clamp_margin)
+    nh, H, DI = 12, 768, 3072
+    cast = (lambda t: t.double()) if double else (lambda t: t)
+    mult = lambda site, p, n: cast(torch.from_numpy(rng.keep_mult(n, rng.make_key(seed, step, site, p))))
+    blx = lambda site, p, Xd: mult(site, p, B * L * Xd).view(B, L, Xd).permute(1, 0, 2)
+    S = _SeqReplay
+    o.transformer.dropout = S([blx(rng.XS_EMB, 0.1, H), mult(rng.XS_POS, 0.1, 2 * L * B * H).view(2 * L, B, H), blx(rng.XS_FINAL, 0.1, H)])
+    o.transformer.MAG.dropout = S([blx(rng.XS_MAG, 0.5, H)])
+    o.sequence_summary.last_dropout = S([mult(rng.XS_HEAD, 0.1, B * H).view(B, H)])
+    for l, lyr in enumerate(o.transformer.layer):
+        s0 = rng.XS_LAYER0 + 8 * l
+        lyr.rel_attn.dropout = S([mult(s0 + 0, 0.1, B * nh * L * L).view(B, nh, L, L), blx(s0 + 1, 0.1, H)])
+        lyr.ff.dropout = S([blx(s0 + 2, 0.1, DI), blx(s0 + 3, 0.1, H)])
+    i2, v2, a2, m2, s2, l2 = tb(b)
+    if double:
+        v2, a2, l2 = v2.double(), a2.double(), l2.double()
+    lo = o(i2, v2, a2, m2, s2)[0]
+    torch.nn.functional.mse_loss(lo.view(-1), l2.view(-1)).backward()
+    return {n: p.grad for n, p in o.named_parameters() if p.grad is not None}, lo.detach()
+
+
+def test_mag_gate_kink_explains_gradient_outliers_fp32():
+    """Round 4's once-seen 7.9e-2 at MAG.W_ha (identical logits) was not a race: MAG's relu gates (modeling.py:27-28) have a kink at
+    zero, and about one dropout draw in forty puts a pre-activation within fp32 rounding of it -- the GPU and the CPU then take
+    different sides of a discontinuous derivative and ONE token's contribution to dW_hv / dW_ha flips.  This is draw (seed 12345, step
+    81) of scripts/exp/flake_hunt.py --vary (profiles/r05_flake_hunt.txt): against a float64 oracle the GPU gradient is off by 6e-2 of
+    the tensor's maximum as it stands and by 2e-6 once the sign of ONE gate pre-activation (|x| = 4.6e-7) is inverted in the oracle.
+    The assertion holds whichever side a future kernel lands on: the GPU gradient must equal the exact gradient for one of the two
+    states of a gate whose pre-activation is within 1e-5 of zero."""
+    layers, B, L = 2, 3, 24
+    torch.manual_seed(12345)
+    m = build(layers, torch.float32).train()
+    m._core.step = 80
+    b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=41)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    out = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, labels=None)
+    torch.nn.MSELoss()(out[0].view(-1), lab.view(-1)).backward()
+    torch.cuda.synchronize()
+    seed, step = m._core.seed, m._core.step
+    assert (seed, step) == (12345, 81)
+    probe = []
+    o64, lo = oracle_replay_grads(layers, B, L, seed, step, b, double=True, probe=probe)
+    probe = probe[1:]                                        # [clamp margin, W_hv, W_ha] -> the two gates
+    assert float((out[0].detach().cpu().double() - lo).abs().max()) <= 1e-5          # the forward does not see the kink
+    gmax = max(float(g.abs().max()) for g in o64.values())
+    worst = lambda ref: max(float((p.grad.detach().cpu().double() - ref[n]).abs().max()) / max(float(ref[n].abs().max()), 1e-3 * gmax)
+                            for n, p in m.named_parameters() if n in ref)
+    as_is = worst(o64)
+    best = (as_is, None)
+    for k in range(2):
+        flat = probe[k].abs().flatten()
+        for j in torch.topk(flat, 3, largest=False).indices.tolist():
+            if float(flat[j]) > 1e-5:
+                continue
+            idx = [int(i) for i in torch.unravel_index(torch.tensor(j), probe[k].shape)]
+            of, _ = oracle_replay_grads(layers, B, L, seed, step, b, double=True, flip=(("W_hv", "W_ha")[k], idx))
+            w = worst(of)
+            if w < best[0]:
+                best = (w, (("W_hv", "W_ha")[k], idx, float(probe[k][tuple(idx)])))
+    print("GPU vs float64 oracle, every tensor: %.3e as is; %.3e with the gate state %s" % (as_is, best[0], best[1]))
+    assert best[0] <= 5e-5
+
+
 @pytest.mark.parametrize("cdt,tol_logit,tol_grad,L,layers,B", [
     (torch.float32, 1e-3, 5e-3, 24, 2, 3),
     (torch.bfloat16, 5e-2, 1e-1, 24, 2, 3),      # bf16 gradients: relative Frobenius error, dominated by relu / clamp flips in MAG (measured 7.7e-2 on W_hv)
