@@ -291,7 +291,7 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
     if (!e->P || !e->ws) return MB_ERR_ARG;
     if (B < 1 || B > c.max_batch || L < 1 || L > c.max_seq) return MB_ERR_SHAPE;
     if ((!input_ids && !e->emb_in) || !visual || !acoustic || !attention_mask || !token_type_ids || !logits) return MB_ERR_ARG;
-    if (e->mems && (training || e->mlen >= L || e->in_step)) return MB_ERR_MODE;      // memories: inference passes only
+    if (e->mems && (e->mlen >= L || e->in_step)) return MB_ERR_MODE;      // memories: explicit forwards / backwards only (not the single-call step)
     const int dt = c.dtype, H = c.d_model, I = c.d_inner, T = B * L, nh = c.n_head, R = B * 2 * L;
     const size_t es = esize(dt);
     if (e->emb_in) input_ids = nullptr;           // inputs_embeds given: no table gather, no scatter into the word table
@@ -510,6 +510,13 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                         kNoDrop, 1, 0, st));
                 CK(gemm(dt, GEMM_NT, EPI_ADD_RES, T, H, H, dqkv + (size_t)2 * H * es, 3 * H, e->W(o.v), H, dx, H, nullptr, nullptr, nullptr, t2,
                         H, kNoDrop, 1, 0, st));
+            }
+            if (e->mems) {
+                // training with cached memories (xlnet.py:81-91: cache_mem detaches): rows [0, mlen) of this layer's input were REPLACED by
+                // mems[l] in the forward, so neither the memory (detached) nor what the layer below computed for those rows (overwritten)
+                // receives a gradient -- the rows are cleared at every seam.  What the rows contributed as keys / values to THIS layer's
+                // k / v weight gradients stays (the reference's k_head_h = einsum(cat([mems, h]), k) does the same).
+                CK((int)hipMemset2DAsync(dx, (size_t)L * H * es, 0, (size_t)e->mlen * H * es, (size_t)B, st));
             }
             if (l == c.injection_index) {      // MAG sits in front of this layer
                 int mblk = 0;

@@ -171,9 +171,16 @@ class Comm(object):
         h = C.c_void_p()
         if self.backend == "nccl":
             idbuf = (C.c_uint8 * 128)()
-            # on EVERY rank (only rank 0's id is used): RCCL loads -- or fails to -- everywhere before the first collective below, so a
-            # missing library raises on all ranks together instead of leaving the others inside a broadcast
-            _lib.check(L.mb_comm_unique_id(idbuf))
+            # on EVERY rank (only rank 0's id is used): RCCL loads -- or fails to -- everywhere before the first collective below.  A rank
+            # whose library is missing must not raise yet (the others would sit in the broadcast forever): the return codes
+            # are agreed over the group first, then every rank falls back together
+            rc0 = L.mb_comm_unique_id(idbuf)
+            ok = torch.tensor([1 if rc0 == 0 else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=process_group)
+            if int(ok.item()) == 0:
+                if rc0 != 0:
+                    _lib.check(rc0)
+                raise RuntimeError("another rank could not load RCCL")
             t = torch.tensor(list(idbuf), dtype=torch.uint8, device=dev)
             dist.broadcast(t, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
             raw = bytes(t.cpu().tolist())

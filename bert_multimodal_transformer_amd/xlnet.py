@@ -6,7 +6,8 @@ Same class names, constructor `(config, multimodal_config)`, forward argument or
 r_w_bias,seg_embed,layer_norm.*}, transformer.layer.{i}.ff.{layer_norm,layer_1,layer_2}.*, transformer.MAG.*,
 sequence_summary.summary.*, logits_proj.*).  Built for the configuration the reference driver runs
 (multimodal_driver.py:363-370: attention_mask + token_type_ids; perm_mask / input_mask are built too (forward kernel + its
-adjoint); mems (inference passes) and the new_mems return (config.mem_len, use_cache); target_mapping (the query stream)
+adjoint); mems (forward and backward of MAG_XLNetForSequenceClassification; the base model under no_grad) and the new_mems return
+(config.mem_len, use_cache); target_mapping (the query stream)
 raises NotImplementedError; inputs_embeds, output_hidden_states / output_attentions (served from the activations the engine keeps for
 its backward) and head_mask (scales each head's attention output inside the kernels) are built, and MAG_XLNetModel's output is
 differentiable), sequence length <= 128, MAG injected in front of layer
@@ -106,16 +107,17 @@ class MAG_XLNetModel(_XlBase):
             outputs = outputs + (tuple(a[:, :, mlen:] for a in core.xl_attentions(B, K, self.training)),)
         return outputs
 
-def _xl_mems_front(model, mems, input_ids, inputs_embeds, visual, acoustic, attention_mask, token_type_ids, perm):
+def _xl_mems_front(model, mems, input_ids, inputs_embeds, visual, acoustic, attention_mask, token_type_ids, perm, allow_grad=False):
     """mems (xlnet.py:244-245, 276-293, 317-323, 374-385): n_layer tensors [mlen, B, d_model], the hidden states cached from the previous
     segment.  Keys / values of layer l run over cat([mems[l], h]); queries over h.  The engine takes the segment as klen = mlen + L
     rows per sample whose first mlen rows are placeholders -- dummy ids, zero modalities, visible (the reference's mems_mask is all
     zeros), segment id 0 (the reference's mem_pad) -- and replaces those rows of every layer's input by mems[l]
-    (include/magbert_hip.h: mb_xlnet_set_mems).  Inference only.  -> (mlen, the extended arguments..., stacked memories)"""
+    (include/magbert_hip.h: mb_xlnet_set_mems); its backward clears those rows' gradients at every layer seam (the memories are
+    detached, xlnet.py:91).  -> (mlen, the extended arguments..., stacked memories)"""
     core = model._core
-    if model.training or torch.is_grad_enabled():
-        raise NotImplementedError("mems are built for inference passes (model.eval() under torch.no_grad()); training with cached "
-                                  "memories (xlnet.py:374-385) is not")
+    if torch.is_grad_enabled() and not allow_grad:
+        raise NotImplementedError("the differentiable base model does not take mems (its output gradient would have to be mapped back "
+                                  "onto klen rows): call it under torch.no_grad(), or train through MAG_XLNetForSequenceClassification")
     mems = list(mems)
     if len(mems) != core.n_layers or any(m is None for m in mems):
         raise ValueError("mems must hold one tensor per layer (%d), got %d" % (core.n_layers, len(mems)))
@@ -217,8 +219,10 @@ class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
         core = self._core
         mlen, stack = 0, None
         if mems is not None:
+            if inputs_embeds is not None and inputs_embeds.requires_grad and torch.is_grad_enabled():
+                raise NotImplementedError("inputs_embeds with a gradient together with mems")
             mlen, input_ids, inputs_embeds, visual, acoustic, attention_mask, token_type_ids, perm, stack = _xl_mems_front(
-                self, mems, input_ids, inputs_embeds, visual, acoustic, attention_mask, token_type_ids, perm)
+                self, mems, input_ids, inputs_embeds, visual, acoustic, attention_mask, token_type_ids, perm, allow_grad=True)
         K = mlen + L
         logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, mems=stack, head_mask=head_mask,
                               inputs_embeds=inputs_embeds, perm=perm)

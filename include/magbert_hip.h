@@ -310,10 +310,12 @@ int mb_xlnet_set_head_mask(mb_xlnet_engine* e, const float* head_mask);
  * query stream it feeds are not built. */
 int mb_xlnet_set_perm_mask(mb_xlnet_engine* e, const uint8_t* perm);
 /* mems (xlnet.py:81-91, 244-245, 374-385: the hidden states cached from the previous segment; keys / values of layer l run over
- * cat([mems[l], h]), klen = mlen + qlen <= max_seq).  Inference passes only (mb_xlnet_forward with training = 0; the training entry
- * points return MB_ERR_MODE while it is set).  The caller passes the segment as klen rows per sample whose first mlen rows are
+ * cat([mems[l], h]), klen = mlen + qlen <= max_seq).  Explicit mb_xlnet_forward / mb_xlnet_backward passes only (the single-call
+ * steps return MB_ERR_MODE while it is set).  The caller passes the segment as klen rows per sample whose first mlen rows are
  * placeholders (any ids, zero modalities, attention_mask 1, token_type 0): before layer l the engine replaces those rows of the
- * layer's input by mems[l] -- [n_layer][B][mlen][d_model] in the activation dtype, caller-owned device memory, NULL = none. */
+ * layer's input by mems[l] -- [n_layer][B][mlen][d_model] in the activation dtype, caller-owned device memory, NULL = none; the
+ * backward clears the gradient of those rows at every layer seam (the memory is detached, xlnet.py:91) and keeps their share of the
+ * k / v weight gradients. */
 int mb_xlnet_set_mems(mb_xlnet_engine* e, const void* mems, int mlen);
 int mb_xlnet_stage_grad_ranges(const mb_xlnet_engine* e, int stage, size_t* offs, size_t* lens, int cap);
 int mb_xlnet_mark_grads_zero(mb_xlnet_engine* e, int known_zero);      /* as mb_bert_mark_grads_zero */

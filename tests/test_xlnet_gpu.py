@@ -614,12 +614,43 @@ def test_mems_match_reference_golden(golden, B, L, ml, seed, cdt):
     assert perr <= (1e-5 if fp32 else 2e-2)
 
 
+@pytest.mark.parametrize("cdt,L,ml,tol", [(torch.float32, 24, 16, 5e-3), (torch.float32, 50, 40, 5e-3),
+                                          (torch.bfloat16, 24, 16, 5e-2)])     # bf16: relative Frobenius; MAG's gated tensors 2e-1 (measured 1.0e-1: relu flips at T = 72)
+def test_mems_training_gradients_vs_oracle(cdt, L, ml, tol):
+    """Training WITH cached memories (xlnet.py:81-91, 374-385): keys / values of every layer over cat([mems[l], h]) with the memories
+    detached.  The engine replaces the first mlen rows of every layer's input in the forward and clears their gradient at every seam
+    in the backward; the k / v weights still receive the memory rows' share (the reference's einsum over cat does).  Train mode, p = 0:
+    loss and every parameter gradient vs the oracle (klen 40: one strip group; klen 90: above the L = 64 kernel boundary)."""
+    layers, B = 2, 3
+    fp32 = cdt == torch.float32
+    m = build(layers, cdt, p_mag=0.0, p=0.0).train()
+    o = X.set_dropout(oracle(layers, p_mag=0.0), 0.0, 0.0).train()
+    b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=91)
+    g = torch.Generator().manual_seed(5)
+    mems = [torch.randn(ml, B, 768, generator=g) * 0.5 for _ in range(layers)]
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, mems=[t.to(DEV) for t in mems], labels=None)[0]
+    torch.nn.MSELoss()(logits.view(-1), lab.view(-1)).backward()
+    i2, v2, a2, m2, s2, l2 = tb(b)
+    lo = o(i2, v2, a2, m2, s2, mems=mems)[0]
+    F.mse_loss(lo.view(-1), l2.view(-1)).backward()
+    torch.cuda.synchronize()
+    err = float((logits.detach().cpu() - lo.detach()).abs().max())
+    print("mems training (%s, klen %d): logits %.2e" % (cdt, ml + L, err))
+    assert err <= (1e-3 if fp32 else 5e-2)
+    _grad_report(m, o, tol, frobenius=not fp32, loose=() if fp32 else LOOSE_BF16, tol_loose=2e-1, show=3)
+    # and the plain pass afterwards is unaffected (the engine's mems pointer is per pass)
+    m.zero_grad()
+    m.train_step(ids, vis, aco, mask, seg, lab, optimizer=None)
+    torch.cuda.synchronize()
+
+
 def test_mems_argument_checks():
     m = build(layers=2, mem_len=16)
     ids, vis, aco, mask, seg, _ = tb(weights.synthetic_xlnet_batch(2, 24, 47, 74, seed=3), DEV)
     mems = [torch.zeros(16, 2, 768) for _ in range(2)]
-    with pytest.raises(NotImplementedError):                 # training with cached memories is not built
-        m.train()(ids, vis, aco, token_type_ids=seg, attention_mask=mask, mems=mems)
+    with pytest.raises(NotImplementedError):                 # the differentiable BASE model does not take mems with autograd on
+        m.transformer(ids, vis, aco, token_type_ids=seg, attention_mask=mask, mems=mems)
     m.eval()
     with torch.no_grad():
         with pytest.raises(ValueError):
