@@ -14,7 +14,8 @@ Different by design (MI355X-first):
   * `compute_dtype=torch.bfloat16` (perf mode) keeps bf16 activations + a bf16 operand shadow of the GEMM weights;
     `torch.float32` (parity mode) runs exact-fp32 MFMA and matches the CPU reference logits to < 1e-3;
   * the optional arguments of forward are built on the HIP path too (head_mask, inputs_embeds, output_attentions,
-    output_hidden_states, position_ids); what is not (the decoder's encoder_hidden_states) raises
+    output_hidden_states, position_ids; encoder_hidden_states / encoder_attention_mask are ignored unless config.is_decoder, like the
+    reference); a decoder configuration raises
     NotImplementedError instead of silently taking a slow path.
 """
 import ctypes as C
@@ -193,6 +194,13 @@ class _Core(object):
     def refresh_sharded_state(self, adam=True):
         """sharded optimizer update: every rank holds current fp32 masters (and Adam moments) of ITS slices only; gather the rest
         before anything reads the whole flat buffers (state_dict, checkpoints, sync_weights).  Collective: every rank must call it."""
+        old = getattr(self, "_dp_shards", None)          # the Python-driven form (distributed.OptimizerShards, MB_DP_ENGINE=0)
+        if old is not None:
+            old.gather_masters()
+            if adam and hasattr(self, "_adam_m"):
+                old._gather([self._adam_m[a:b] for a, b in old.bounds])
+                old._gather([self._adam_v[a:b] for a, b in old.bounds])
+            return
         comm = getattr(self, "_dp_comm", None)
         if comm is None or not comm.sharding or comm.handle is None:
             return
@@ -993,8 +1001,12 @@ class MAG_BertModel(_MagBertBase):
         pooled_output carry an autograd edge into the engine (a head built on top of this model trains the whole stack, and
         inputs_embeds receives its gradient); hidden_states / attentions are detached fp32 copies.  head_mask: [num_heads] or
         [num_layers, num_heads]; position_ids: rows of the position table, [B, L] or [1, L].  The decoder arguments
-        (encoder_hidden_states / encoder_attention_mask: cross-attention, which MAG-BERT's encoder does not have) raise."""
-        self._unsupported(encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask)
+        (encoder_hidden_states / encoder_attention_mask) behave as in the reference: with config.is_decoder False -- every
+        MAG-BERT configuration -- bert.py:185-201 sets the cross-attention mask to None and transformers 3.0.2's BertLayer only
+        looks at encoder_hidden_states `if self.is_decoder`: the arguments are accepted and IGNORED; a decoder stack
+        (config.is_decoder True: cross-attention layers the MAG encoder never builds) raises."""
+        if getattr(self.config, "is_decoder", False):
+            self._unsupported(is_decoder=True)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))

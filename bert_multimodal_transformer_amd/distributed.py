@@ -480,6 +480,7 @@ class DataParallel(object):
                 self.shard_in_engine = True
             else:
                 self.shards = OptimizerShards(self.core, dist.get_rank(process_group), self.reducer.world, process_group)
+                self.core._dp_shards = self.shards  # (state_dict / sync_weights gather the stale masters first: ADVICE r4)
                 self.word = None                    # (dense last piece: keeps this path's plan simple)
         # every rank draws its own dropout masks (the reference is single-process: nothing to be faithful to; identical masks on
         # every shard would correlate the regularisation noise).  The mixed seed is what get_rng_state() saves.

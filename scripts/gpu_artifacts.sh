@@ -81,6 +81,9 @@ done
 f=$(find /tmp/p_b -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_kernel_stats.csv
 ( cd /tmp && rm -rf /tmp/p_x && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_x -o b -- python $R/bench.py --model xlnet --steps 10 --warmup 3 --cpu-baseline 0 --roofline 0 > /dev/null 2>&1 )
 f=$(find /tmp/p_x -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/xlnet_kernel_stats.csv
+# bench.py starting its own ranks (round 5): two ranks sharing this GPU over the callback backend -- the launcher, the rccl_ranks proof and the JSON contract, not a speed
+(MB_DIST_BACKEND=gloo timeout 300 python bench.py --gpus 2 --cpu-baseline 0 --roofline 0 --steps 10 --warmup 3 2>&1 | grep "$J" | cut -c1-1800) > $O/bench_line_gpus2_gloo.log 2>&1
+{ timeout 60 python bench.py --gpus 2 --cpu-baseline 0 --roofline 0 > $O/.g2.tmp 2>&1; rc=$?; tail -n 2 $O/.g2.tmp; rm -f $O/.g2.tmp; echo "exit code $rc"; } > $O/bench_gpus2_without_devices.log 2>&1
 for f in bench_line bench_line_c5 bench_line_xlnet; do tail -n 1 $O/$f.log | cut -c1-420; done
 cat $O/instep_kernels.txt | head -24
 cat $O/step_bench.txt

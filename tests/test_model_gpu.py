@@ -330,9 +330,17 @@ def test_optional_outputs_and_trainable_base_model_fp32():
     assert len(out) == 3 and len(out[1]) == layers + 1 and len(out[2]) == layers
     for h, r in zip(out[1], ref_h):
         assert float((h.cpu() - r).abs().max()) <= 1e-4
-    # options that are not built raise instead of being ignored (the decoder's cross-attention inputs)
+    # the decoder's cross-attention inputs behave as in the reference (bert.py:185-201; 3.0.2 BertLayer looks at them only `if
+    # self.is_decoder`): ignored by an encoder configuration, refused by a decoder one (cross-attention layers are not built)
+    with torch.no_grad():
+        plain = base.eval()(ids, vis, aco, token_type_ids=seg, attention_mask=mask)[0]
+        ign = base(ids, vis, aco, token_type_ids=seg, attention_mask=mask, encoder_hidden_states=torch.randn(B, L, 768, device=DEV),
+                   encoder_attention_mask=torch.ones(B, L, device=DEV))[0]
+    assert torch.equal(plain, ign)
+    base.config.is_decoder = True
     with pytest.raises(NotImplementedError):
         base(ids, vis, aco, encoder_hidden_states=torch.zeros(B, L, 768, device=DEV))
+    base.config.is_decoder = False
     m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, position_ids=torch.arange(L, device=DEV)[None].expand(B, L))   # the default, spelled out
 
 
