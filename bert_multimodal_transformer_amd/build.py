@@ -69,7 +69,7 @@ def build_tools(force=False):
     root = os.path.dirname(HERE)
     outdir = os.path.join(root, "tools", "bin")
     outs = []
-    for name in ("step_bench", "gemm_bench", "launch_floor", "attn_bench", "adamw_bench", "event_capture_probe"):
+    for name in ("step_bench", "gemm_bench", "launch_floor", "attn_bench", "adamw_bench", "event_capture_probe", "stream_handoff_probe"):
         src = os.path.join(root, "tools", name + ".cpp")
         if not os.path.exists(src):
             continue

@@ -15,7 +15,7 @@ struct mb_comm {
     mb_all_reduce_cb ar_cb = nullptr;
     mb_all_gather_cb ag_cb = nullptr;
     void* ctx = nullptr;
-    hipStream_t cs = nullptr;                 // the comm stream (created here: non-blocking, highest priority)
+    hipStream_t cs = nullptr;                 // the comm stream (created here: non-blocking; normal priority, MB_DP_COMM_PRIORITY=1: highest)
     std::vector<hipEvent_t> fork_ev;          // "the compute stream got this far": one per piece of a step, re-recorded every step
     hipEvent_t ev_layers = nullptr, ev_tail = nullptr;     // recorded on cs: every layer piece / every piece has been enqueued before
     hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};   // timing events around the two places the compute stream waits for cs

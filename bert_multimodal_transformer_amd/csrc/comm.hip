@@ -435,8 +435,13 @@ int mb_comm_unique_id(void* id128) {
 static int comm_common_init(mb_comm* c) {
     int least = 0, greatest = 0;
     CK((int)hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // Normal priority by default.  Round 4 gave the comm stream the highest priority ("the exchange's few workgroups go in front of
+    // the backward's many": 3.71 vs 3.77 ms) -- measured while the hand-off events ordered nothing.  With real dependencies a
+    // highest-priority comm stream inside a PyTorch process makes every hand-off cost ~1 ms (10.5 vs 3.67 ms per step; the torch-free
+    // driver does not show it, and the runtime is not the reason: tools/stream_handoff_probe measures 12 us per hand-off under both;
+    // profiles/r05_dp_comm_priority.txt).  MB_DP_COMM_PRIORITY=1 brings the high-priority stream back.
     const char* pv = getenv("MB_DP_COMM_PRIORITY");
-    const int prio = (pv && atoi(pv) == 0) ? 0 : greatest;      // the exchange's few workgroups go in front of the backward's many
+    const int prio = (pv && atoi(pv) == 1) ? greatest : 0;
     CK((int)hipStreamCreateWithPriority(&c->cs, hipStreamNonBlocking, prio));
     if (const char* v = getenv("MB_DP_EVENT_MODE")) c->event_mode = atoi(v);
     const unsigned flags = hipEventDisableTiming | (c->event_mode == 1 ? hipEventReleaseToDevice : 0);

@@ -475,7 +475,8 @@ class DataParallel(object):
         # OptimizerShards below remains the MB_DP_ENGINE=0 form.
         self.shards = None
         self.shard_in_engine = False
-        if self.reducer.active and self.reducer.world > 1 and os.environ.get("MB_DP_SHARD_OPT", "0") == "1":
+        force1 = os.environ.get("MB_DP_SHARD_FORCE", "0") == "1"          # (one-rank group, identity collectives: one-GPU timing only)
+        if self.reducer.active and (self.reducer.world > 1 or force1) and os.environ.get("MB_DP_SHARD_OPT", "0") == "1":
             if self._comm_enabled:
                 self.shard_in_engine = True
             else:
