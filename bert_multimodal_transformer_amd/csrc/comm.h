@@ -54,6 +54,14 @@ struct mb_comm {
     // A remainder that does not divide by world x 256 elements stays replicated (all-reduced, updated by everyone).
     bool shard = false, gather_pending = false;
     hipEvent_t ev_gather = nullptr;
+    // Sharded update with MORE THAN ONE piece ("cut" mode): the piece the backward finishes LAST -- the lowest layers -- is the one the next
+    // forward needs FIRST, so it stays replicated (all-reduced, updated by every rank: no gather to wait for), and the forward of a
+    // data-parallel step is cut at the same seams as its backward: `nf` forward-only segments in front of the backward segments, the
+    // forward of piece k waits (host-side stream wait in front of its graph launch) for the all-gather of ITS piece only
+    // (ev_chunk[k], recorded on the comm stream behind that gather).  The gathers run under the second optimizer segment and the
+    // next step's first forward piece.  nf is set by the engines per step (0: forward in one piece inside the first segment).
+    int nf = 0;
+    std::vector<hipEvent_t> ev_chunk;
     std::vector<std::pair<size_t, size_t>> shard_chunks;     // the chunks of the last sharded step (mb_comm_gather_shards)
     size_t bytes_gathered = 0;
 };
@@ -72,7 +80,12 @@ struct DpSpec {
     int word_rows = 0, H = 0;
     const int64_t* ids = nullptr; int T = 0;        // token ids of this rank's batch (device): the rows it touched
     char* gather_base = nullptr; int gather_es = 0; // sharded update: what the next forward reads of a chunk (bf16 shadow: 2 | fp32 parameters: 4)
+    int n_sharded = 0;                              // sharded update: chunks [0, n_sharded) are sliced over the ranks, the rest stays replicated
 };
+// sharded update: how many of `nb` chunks are sliced -- all of a single piece; all but the last (lowest layers) of several
+inline int dp_sharded_chunks(const mb_comm* c, int nb) { return !c->shard ? 0 : (nb > 1 ? nb - 1 : nb); }
+// ... and how many forward-only segments a step of `nb` backward pieces then has in front
+inline int dp_forward_segments(const mb_comm* c, int nb) { return (c->shard && nb > 1) ? nb - 1 : 0; }
 
 // a chunk [b, e) of the flat buffers under the sharded update: this rank's slice, and the replicated remainder at the chunk's end
 struct ShardSlice { size_t per, mine_b, mine_e, rem_b, rem_e; };
@@ -102,7 +115,7 @@ int dp_segment_end(mb_comm* c, int nb, int seg, hipStream_t st);
 int dp_finish_segment_graph(const void* tag, int nseg, int seg, hipGraph_t graph);
 
 // at the head of a data-parallel step: the stream waits for the previous step's all-gathers (sharded update)
-int dp_step_begin(mb_comm* c, hipStream_t st);
+int dp_step_begin(mb_comm* c, hipStream_t st, bool cut);
 
 // row-wise sum of a [vocab][H] fp32 table over the ranks (comm.hip): every rank touched the rows ids[0..T)
 int comm_exchange_rows(mb_comm* c, float* table, const int64_t* ids, int T, hipStream_t s);

@@ -238,7 +238,8 @@ static bool is_capturing(hipStream_t st) {
 // (their slices go out by all-gather)
 static bool hands_off(const mb_comm* c, int nb, int seg) { return seg < nb || (c->shard && seg < nb + 2); }
 int dp_segment_end(mb_comm* c, int nb, int seg, hipStream_t st) {
-    if (c->event_mode < 2 || !hands_off(c, nb, seg)) return MB_OK;
+    if (seg < c->nf) return MB_OK;          // a forward-only piece hands nothing over
+    if (c->event_mode < 2 || !hands_off(c, nb, seg - c->nf)) return MB_OK;
     // captured: nothing here -- a plain hipEventRecord inside a capture adds NO node (it only orders captured work), and the external
     // form (hipEventRecordWithFlags) is refused by the 7.0 runtime a PyTorch process maps; dp_finish_segment_graph appends the
     // event-record node to the captured graph instead
@@ -246,7 +247,9 @@ int dp_segment_end(mb_comm* c, int nb, int seg, hipStream_t st) {
     CK((int)hipEventRecord(c->fork_ev[(size_t)seg % c->fork_ev.size()], st));
     return MB_OK;
 }
-int dp_segment_begin(mb_comm* c, int nb, int seg, hipStream_t st) {
+int dp_segment_begin(mb_comm* c, int nb, int seg_abs, hipStream_t st) {
+    if (seg_abs < c->nf) return MB_OK;
+    const int seg = seg_abs - c->nf;
     if (seg < nb && test_delay_us() > 0) {
         dp_test_delay_kernel<<<1, 1, 0, st>>>((long long)test_delay_us() * 100);
         CK((int)hipGetLastError());
@@ -262,10 +265,10 @@ int dp_segment_begin(mb_comm* c, int nb, int seg, hipStream_t st) {
 // STARTS with a wait-event node on the comm stream's "pieces enqueued" event.  The graph stays a linear chain.  Then the result is
 // checked: exactly one such node, at the right end (tools/event_capture_probe.cpp is the stand-alone demonstration that these
 // nodes order a replay against another stream, and that a record issued inside the capture does not).
-int dp_finish_segment_graph(const void* tag, int nseg, int seg, hipGraph_t graph) {
+int dp_finish_segment_graph(const void* tag, int nseg, int seg_abs, hipGraph_t graph) {
     mb_comm* c = (mb_comm*)tag;
-    if (!c || c->event_mode < 2) return MB_OK;
-    const int nb = nseg - 2;
+    if (!c || c->event_mode < 2 || seg_abs < c->nf) return MB_OK;
+    const int nb = nseg - 2 - c->nf, seg = seg_abs - c->nf;
     auto nodes_of = [&](std::vector<hipGraphNode_t>& v) -> int {
         size_t n = 0;
         CK((int)hipGraphGetNodes(graph, nullptr, &n));
@@ -279,7 +282,7 @@ int dp_finish_segment_graph(const void* tag, int nseg, int seg, hipGraph_t graph
         std::vector<hipGraphNode_t> leaves;
         for (auto nd : nodes) { size_t nout = 0; CK((int)hipGraphNodeGetDependentNodes(nd, nullptr, &nout)); if (nout == 0) leaves.push_back(nd); }
         hipGraphNode_t rec = nullptr;
-        CK((int)hipGraphAddEventRecordNode(&rec, graph, leaves.data(), leaves.size(), c->fork_ev[(size_t)seg % c->fork_ev.size()]));
+        CK((int)hipGraphAddEventRecordNode(&rec, graph, leaves.data(), leaves.size(), c->fork_ev[(size_t)seg_abs % c->fork_ev.size()]));
     }
     if (seg >= nb && c->event_mode >= 3) {
         size_t nr = 0;
@@ -307,7 +310,7 @@ int dp_finish_segment_graph(const void* tag, int nseg, int seg, hipGraph_t graph
                     (seg < nb || c->event_mode < 3 || (waits == 1 && wait_is_root == 1 && roots == 1));
     if (!ok) {
         snprintf(g_last_error, sizeof g_last_error, "data-parallel segment %d of %d: graph has %d event-record / %d wait-event nodes, %d leaves, "
-                 "%d roots (event mode %d): the hand-off to the comm stream would not be ordered", seg, nseg, records, waits, leaves, roots, c->event_mode);
+                 "%d roots (event mode %d): the hand-off to the comm stream would not be ordered", seg_abs, nseg, records, waits, leaves, roots, c->event_mode);
         return MB_ERR_MODE;
     }
     return MB_OK;
@@ -354,28 +357,41 @@ int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st) 
     if (dbg < 0) { const char* v = getenv("MB_DP_DEBUG"); dbg = v ? atoi(v) : 0; }
     if (dbg == 1) return MB_OK;
     const int nb = (int)sp.chunk.size();
+    const int seg_abs = seg;
+    if (seg_abs == 0) {
+        c->pieces = 0; c->bytes_reduced = 0; c->bytes_gathered = 0; c->tev_used[0] = c->tev_used[1] = false;
+        if (c->shard) c->shard_chunks.assign(sp.chunk.begin(), sp.chunk.begin() + sp.n_sharded);
+    }
+    if (seg_abs < c->nf) {
+        // behind forward piece k (chunk nb-1-k): the NEXT piece's weights (chunk nb-2-k) come from the previous step's all-gather
+        return dbg == 2 ? MB_OK : (int)hipStreamWaitEvent(st, c->ev_chunk[(size_t)(nb - 2 - seg_abs) % c->ev_chunk.size()], 0);
+    }
+    seg -= c->nf;
     auto piece = [&](size_t b, size_t e) -> int { return (dbg == 2 || e <= b) ? MB_OK : comm_all_reduce(c, G + b, e - b, c->cs); };
     // a chunk of layer GEMM weights: all-reduced, or -- sharded update -- reduce-scattered slice-wise (+ its replicated remainder)
     auto chunk_piece = [&](int k) -> int {
         const size_t b = sp.chunk[k].first, e = sp.chunk[k].second;
-        if (!c->shard) return piece(b, e);
+        if (k >= sp.n_sharded) return piece(b, e);
         const ShardSlice sl = dp_shard_slice(c, b, e);
         if (dbg != 2) CK(comm_reduce_scatter(c, G + b, sl.per, c->cs));
         return piece(sl.rem_b, sl.rem_e);
     };
     auto gather_chunk = [&](int k) -> int {
-        if (dbg == 2 || !sp.gather_base) return MB_OK;
-        const ShardSlice sl = dp_shard_slice(c, sp.chunk[k].first, sp.chunk[k].second);
-        return comm_gather_slices(c, sp.gather_base, sp.gather_es, sp.chunk[k].first, sl.per, c->cs);
+        if (k >= sp.n_sharded) return MB_OK;
+        if (dbg != 2 && sp.gather_base) {
+            const ShardSlice sl = dp_shard_slice(c, sp.chunk[k].first, sp.chunk[k].second);
+            CK(comm_gather_slices(c, sp.gather_base, sp.gather_es, sp.chunk[k].first, sl.per, c->cs));
+        }
+        CK((int)hipEventRecord(c->ev_chunk[(size_t)k % c->ev_chunk.size()], c->cs));      // "chunk k's operands are everybody's"
+        return MB_OK;
     };
-    if (seg == 0) { c->pieces = 0; c->bytes_reduced = 0; c->bytes_gathered = 0; c->tev_used[0] = c->tev_used[1] = false; if (c->shard) c->shard_chunks = sp.chunk; }
     if (seg < nb - 1) {
-        CK(fork_to_comm(c, seg, st));
+        CK(fork_to_comm(c, seg_abs, st));
         return chunk_piece(seg);
     }
     if (seg == nb - 1) {
         CK((int)hipEventRecord(c->ev_layers, c->cs));          // every early piece is in front of this
-        CK(fork_to_comm(c, seg, st));
+        CK(fork_to_comm(c, seg_abs, st));
         CK(chunk_piece(seg));
         const size_t w0 = sp.word_off, w1 = sp.word_off + (size_t)sp.word_rows * sp.H;
         // (a batch beyond the agreed row capacity is an error, never a silent switch to the dense piece: the ranks must issue the
@@ -397,23 +413,26 @@ int dp_between(mb_comm* c, const DpSpec& sp, float* G, int seg, hipStream_t st) 
         // sharded update: the slices the first optimizer launch produced (the early chunks) go out while the second one runs, the
         // lowest layers first (the next forward needs them in that order)
         if (c->shard && nb > 1) {
-            CK(fork_to_comm(c, seg, st));
+            CK(fork_to_comm(c, seg_abs, st));
             for (int k = nb - 2; k >= 0; --k) CK(gather_chunk(k));
         }
         return wait_timed(c, 1, c->ev_tail, st);
     }
     if (seg == nb + 1 && c->shard) {
-        CK(fork_to_comm(c, seg, st));
-        CK(gather_chunk(nb - 1));
+        CK(fork_to_comm(c, seg_abs, st));
+        CK(gather_chunk(nb - 1));          // (several pieces: the last one is replicated -- nothing to gather)
         CK((int)hipEventRecord(c->ev_gather, c->cs));
         c->gather_pending = true;
     }
     return MB_OK;
 }
 
-int dp_step_begin(mb_comm* c, hipStream_t st) {
+// head of a data-parallel step.  cut = the step's forward is cut into pieces that wait for their own gathers (dp_between): nothing to
+// wait for here; else (one piece, or a consumer outside the step: mb_comm_join) the stream waits for the last gather
+int dp_step_begin(mb_comm* c, hipStream_t st, bool cut) {
     if (!c->gather_pending) return MB_OK;
     c->gather_pending = false;
+    if (cut) return MB_OK;
     CK((int)hipStreamWaitEvent(st, c->ev_gather, 0));
     return MB_OK;
 }
@@ -450,6 +469,8 @@ static int comm_common_init(mb_comm* c) {
     CK((int)hipEventCreateWithFlags(&c->ev_layers, flags));
     CK((int)hipEventCreateWithFlags(&c->ev_tail, flags));
     CK((int)hipEventCreateWithFlags(&c->ev_gather, flags));
+    c->ev_chunk.assign(16, nullptr);
+    for (auto& ev : c->ev_chunk) CK((int)hipEventCreateWithFlags(&ev, flags));
     for (auto& ev : c->tev) CK((int)hipEventCreate(&ev));
     return MB_OK;
 }
@@ -487,6 +508,7 @@ void mb_comm_destroy(mb_comm* c) {
     if (c->ev_layers) hipEventDestroy(c->ev_layers);
     if (c->ev_tail) hipEventDestroy(c->ev_tail);
     if (c->ev_gather) hipEventDestroy(c->ev_gather);
+    for (auto ev : c->ev_chunk) if (ev) hipEventDestroy(ev);
     for (auto ev : c->tev) if (ev) hipEventDestroy(ev);
     if (c->cs) hipStreamDestroy(c->cs);
     delete c;
@@ -549,7 +571,7 @@ int mb_comm_set_sharding(mb_comm* c, int on) {
 int mb_comm_sharding(const mb_comm* c) { return (c && c->shard) ? 1 : 0; }
 int mb_comm_join(mb_comm* c, void* stream) {
     if (!c) return MB_ERR_ARG;
-    return dp_step_begin(c, (hipStream_t)stream);
+    return dp_step_begin(c, (hipStream_t)stream, false);
 }
 int mb_comm_gather_shards(mb_comm* c, void* base, int elem_bytes, void* stream) {
     if (!c || !base || (elem_bytes != 2 && elem_bytes != 4)) return MB_ERR_ARG;

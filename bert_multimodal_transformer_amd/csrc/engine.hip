@@ -453,9 +453,13 @@ int mb_bert_sync_weights(mb_bert_engine* e, void* stream) {
     return MB_OK;
 }
 
-int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
-                    const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
-                    int training, uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, void* stream) {
+// The forward of layers [l0, l1): `first` = with the pass set-up, the embeddings and MAG in front; `last` = with the pooler, the classifier
+// and the loss behind.  mb_bert_forward is the whole range; the sharded data-parallel step runs it in pieces whose weights arrive by
+// all-gather (csrc/comm.h: cut mode).
+static int bert_forward_range(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                              const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                              int training, uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, void* stream,
+                              int l0, int l1, bool first, bool last) {
     hipStream_t st = (hipStream_t)stream;
     const mb_bert_config& c = e->c;
     if (!e->P || !e->ws) return MB_ERR_ARG;
@@ -467,19 +471,19 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     e->B = B; e->L = L; e->training = training; e->seed = seed; e->step = step; e->logits = logits;
     float* P = e->P;
     char* ws = e->ws;
-    if (!e->capturing) CK(prepare_pass(e, T, st));
+    if (first && !e->capturing) CK(prepare_pass(e, T, st));
     // embeddings (bert.py:211-216)
-    CK(embed_ln_forward(dt, input_ids, token_type_ids, e->emb_in ? e->emb_in : P + e->word, P + e->pos, P + e->type, P + e->emb_lnw, P + e->emb_lnb,
+    if (first) CK(embed_ln_forward(dt, input_ids, token_type_ids, e->emb_in ? e->emb_in : P + e->word, P + e->pos, P + e->type, P + e->emb_lnw, P + e->emb_lnb,
                         c.layer_norm_eps, ws + e->ws_emb, (float*)(ws + e->ws_emb_st), (float*)(ws + e->ws_emb_st) + T, B, L,
                         H, e->key(SITE_EMB, c.hidden_dropout), st, e->pos_ids));
     // MAG (bert.py:219): packed weights are refreshed every pass (5.5 MB) so optimizer steps are seen -- by a launch here, or, in the
     // single-call step, by extra blocks of the step prologue
-    CK(mag_fwd_impl(dt, ws + e->ws_emb, visual, acoustic, P + e->mag_whv, P + e->mag_bhv, P + e->mag_wha, P + e->mag_bha,
+    if (first) CK(mag_fwd_impl(dt, ws + e->ws_emb, visual, acoustic, P + e->mag_whv, P + e->mag_bhv, P + e->mag_wha, P + e->mag_bha,
                     P + e->mag_wv, P + e->mag_bv, P + e->mag_wa, P + e->mag_ba, P + e->mag_lnw, P + e->mag_lnb,
                     c.mag_layer_norm_eps, c.beta_shift, e->key(SITE_MAG, c.mag_dropout), ws + e->ws_x[0], ws + e->ws_mag,
                     e->mw, T, H, c.visual_dim, c.acoustic_dim, !(e->in_step && e->packed_w), st, true, e->in_step && e->packed));
     // encoder (bert.py:221-229)
-    for (int l = 0; l < c.num_layers; ++l) {
+    for (int l = l0; l < l1; ++l) {
         const LayerOff& o = e->lo[l];
         const LayerWs& w = e->lw[l];
         const char* x = ws + e->ws_x[l];
@@ -494,7 +498,8 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
         // (the two LayerNorm launches of a layer touch the weights of the GEMMs behind them: W1 | W2, then the next layer's Wqkv | Wo)
         const size_t wes = dt == DT_BF16 ? 2 : 4;
         const Prefetch pf1 = {e->prefetch ? e->W(o.w1) : nullptr, (size_t)2 * I * H * wes, nullptr};
-        const Prefetch pf2 = {(e->prefetch && l + 1 < c.num_layers) ? e->W(e->lo[l + 1].wqkv) : nullptr, (size_t)4 * H * H * wes, nullptr};
+        // (not across the seam of a forward cut into pieces: the next piece's weights may still be on their way -- sharded update)
+        const Prefetch pf2 = {(e->prefetch && l + 1 < c.num_layers && (l + 1 < l1 || last)) ? e->W(e->lo[l + 1].wqkv) : nullptr, (size_t)4 * H * H * wes, nullptr};
         CK(ln_forward(dt, ws + w.s1, P + o.ln1w, P + o.ln1b, c.layer_norm_eps, ws + w.y1, (float*)(ws + w.st1),
                       (float*)(ws + w.st1) + T, T, H, kNoDrop, st, pf1));
         CK(gemm(dt, GEMM_NT, EPI_BIAS_GELU, T, I, H, ws + w.y1, H, e->W(o.w1), H, ws + w.u, I, ws + w.g, nullptr, P + o.b1,
@@ -504,6 +509,7 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
         CK(ln_forward(dt, ws + w.s2, P + o.ln2w, P + o.ln2b, c.layer_norm_eps, ws + e->ws_x[l + 1], (float*)(ws + w.st2),
                       (float*)(ws + w.st2) + T, T, H, kNoDrop, st, pf2));
     }
+    if (!last) return MB_OK;
     // pooler + classifier (+ MSE) (bert.py:231, 304-307; multimodal_driver.py:372-373)
     float* z = (float*)(ws + e->ws_head_z);
     CK(gemm(dt, GEMM_NT, EPI_BIAS_F32, B, H, H, ws + e->ws_x[c.num_layers], L * H, e->W(e->wp), H, nullptr, H, nullptr, z,
@@ -512,6 +518,13 @@ int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* vi
     CK(head_forward(z, P + e->wc, P + e->bc, labels, (float*)(ws + e->ws_head_pooled), logits, loss, loss_run, B, H,
                     c.num_labels, e->key(SITE_HEAD, c.hidden_dropout), st));
     return MB_OK;
+}
+
+int mb_bert_forward(mb_bert_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                    const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                    int training, uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, void* stream) {
+    return bert_forward_range(e, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, B, L, training, seed, step, logits,
+                              loss, loss_run, stream, 0, e->c.num_layers, true, true);
 }
 
 int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* labels, float loss_scale, int stage_begin,
@@ -830,7 +843,7 @@ int mb_bert_train_step(mb_bert_engine* e, const int64_t* input_ids, const float*
 // gradient copies were not reduced here -- they are dead, and cleared unless the next backward overwrites them anyway.
 static int adamw_decay_range_dp(mb_bert_engine* e, const mb_comm* comm, const DpSpec& sp, float* m, float* v, size_t b, size_t en, hipStream_t st) {
     if (!comm->shard) return adamw_decay_range(e, m, v, b, en, st);
-    std::vector<std::pair<size_t, size_t>> ch(sp.chunk);
+    std::vector<std::pair<size_t, size_t>> ch(sp.chunk.begin(), sp.chunk.begin() + sp.n_sharded);      // (the rest is replicated)
     std::sort(ch.begin(), ch.end());
     size_t cur = b;
     ZeroRanges dead = {};
@@ -860,10 +873,19 @@ static int enqueue_step_dp(mb_bert_engine* e, int seg, const std::vector<int>& p
     e->attn_out = nullptr;
     struct Restore { mb_bert_engine* e; float* p; ~Restore() { e->attn_out = p; } } restore{e, keep_attn};
     if (e->head_mask || e->emb_in || e->pos_ids) return MB_ERR_MODE;
-    if (seg == 0)
-        CK(mb_bert_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
-                           (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
-                           loss_run, st));
+    // sharded update with several pieces: nf forward-only segments in front (piece k = the layers of chunk nb-1-k, lowest first); the
+    // last piece -- the top layers + head -- stays in front of the first backward segment
+    const int nf = comm->nf;
+    auto layers_of = [&](int chunk, int& l0, int& l1) { l1 = NL; for (int s = 0; s < chunk; ++s) l1 -= plan[s]; l0 = l1 - plan[chunk]; };
+    if (seg <= nf) {
+        int l0 = 0, l1 = NL;
+        if (nf > 0) layers_of(nb - 1 - seg, l0, l1);
+        CK(bert_forward_range(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
+                              (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
+                              loss_run, st, l0, l1, seg == 0, seg == nf));
+        if (seg < nf) return MB_OK;
+    }
+    seg -= nf;
     if (seg < nb) {
         int done = 0;
         for (int s = 0; s < seg; ++s) done += plan[s];
@@ -909,6 +931,9 @@ int mb_bert_train_step_dp(mb_bert_engine* e, const int64_t* input_ids, const flo
     sp.tail_begin = e->wp; sp.tail_end = e->n_params;
     sp.word_off = e->word; sp.word_rows = c.vocab_size; sp.H = c.hidden_size;
     sp.ids = (const int64_t*)(e->ws + e->ws_in_ids); sp.T = B * L;
+    sp.n_sharded = dp_sharded_chunks(comm, nb);
+    const int nf = dp_forward_segments(comm, nb);
+    comm->nf = nf;
     if (comm->shard) {
         // what the next forward reads of a layer's GEMM weights: their bf16 shadow (bf16 mode) or the fp32 parameters themselves
         const bool bf = c.dtype == DT_BF16;
@@ -916,7 +941,7 @@ int mb_bert_train_step_dp(mb_bert_engine* e, const int64_t* input_ids, const flo
             if (bf && (!e->SH || ch.first < e->sh_begin || ch.second > e->sh_end)) return MB_ERR_MODE;
         sp.gather_base = bf ? (char*)e->SH : (char*)e->P; sp.gather_es = bf ? 2 : 4;
     }
-    CK(dp_step_begin(comm, st));          // (sharded update: the previous step's all-gathers)
+    CK(dp_step_begin(comm, st, nf > 0));          // (sharded update: the previous step's all-gathers -- cut mode: awaited piece by piece)
     e->training = 1;
     CK(prepare_pass(e, B * L, st));
     // (the plan is part of the graphs' identity: nseg alone would not tell 4,4,2,2 from 2,2,4,4)
@@ -932,7 +957,7 @@ int mb_bert_train_step_dp(mb_bert_engine* e, const int64_t* input_ids, const flo
                                CK(dp_segment_end(comm, nb, sg, s));
                                return (int)MB_OK;
                            },
-                           nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant, comm, dp_finish_segment_graph);
+                           nf + nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant, comm, dp_finish_segment_graph);
 }
 
 // ------------------------------------------------------------------------------------------------ stage-driven step (data parallel)

@@ -283,9 +283,12 @@ int mb_xlnet_sync_weights(mb_xlnet_engine* e, void* stream) {
     return MB_OK;
 }
 
-int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
-                     const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
-                     int training, uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, void* stream) {
+// the forward of layers [l0, l1) (`first`: with the pass set-up, the embeddings and the positional table in front; `last`: with the
+// summary and the head behind): mb_xlnet_forward is the whole range, the sharded data-parallel step runs it in pieces (engine.hip)
+static int xl_forward_range(mb_xlnet_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                            const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                            int training, uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, void* stream,
+                            int l0, int l1, bool first, bool last) {
     hipStream_t st = (hipStream_t)stream;
     const mb_xlnet_config& c = e->c;
     if (!e->P || !e->ws) return MB_ERR_ARG;
@@ -299,11 +302,13 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
     e->B = B; e->L = L; e->training = training; e->seed = seed; e->step = step; e->logits = logits;
     float* P = e->P;
     char* ws = e->ws;
-    if (!e->capturing) CK(xl_prepare_pass(e, T, st));
+    if (first && !e->capturing) CK(xl_prepare_pass(e, T, st));
     const float pd = c.dropout;
-    CK(gather_drop_forward(dt, input_ids, e->emb_in ? e->emb_in : P + e->word, ws + e->ws_x[0], T, H, e->key(XS_EMB, pd), st));   // xlnet.py:304-313
-    CK(xlnet_pos_emb(dt, ws + e->ws_pos, B, L, H, e->key(XS_POS, pd), st));                                         // xlnet.py:332-333
-    for (int l = 0; l < c.n_layer; ++l) {
+    if (first) {
+        CK(gather_drop_forward(dt, input_ids, e->emb_in ? e->emb_in : P + e->word, ws + e->ws_x[0], T, H, e->key(XS_EMB, pd), st));   // xlnet.py:304-313
+        CK(xlnet_pos_emb(dt, ws + e->ws_pos, B, L, H, e->key(XS_POS, pd), st));                                         // xlnet.py:332-333
+    }
+    for (int l = l0; l < l1; ++l) {
         const XlLayerOff& o = e->lo[l];
         const XlLayerWs& w = e->lw[l];
         const char* xin = ws + e->ws_x[l];
@@ -348,7 +353,7 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
         //  layer's q | k | v | o | r behind the second one)
         const size_t wes = dt == DT_BF16 ? 2 : 4;
         const Prefetch pf1 = {e->prefetch ? e->W(o.w1) : nullptr, (size_t)2 * I * H * wes, nullptr};
-        const Prefetch pf2 = {(e->prefetch && l + 1 < c.n_layer) ? e->W(e->lo[l + 1].q) : nullptr, (size_t)5 * H * H * wes, nullptr};
+        const Prefetch pf2 = {(e->prefetch && l + 1 < c.n_layer && (l + 1 < l1 || last)) ? e->W(e->lo[l + 1].q) : nullptr, (size_t)5 * H * H * wes, nullptr};      // (not across a forward seam)
         CK(ln_forward(dt, ws + w.s1, P + o.ralnw, P + o.ralnb, c.layer_norm_eps, ws + w.y1, (float*)(ws + w.st1),
                       (float*)(ws + w.st1) + T, T, H, kNoDrop, st, pf1));
         // feed forward: layer_1 -> gelu -> dropout -> layer_2 -> dropout -> LayerNorm(. + inp)
@@ -359,6 +364,7 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
         CK(ln_forward(dt, ws + w.s2, P + o.fflnw, P + o.fflnb, c.layer_norm_eps, ws + e->ws_x[l + 1], (float*)(ws + w.st2),
                       (float*)(ws + w.st2) + T, T, H, kNoDrop, st, pf2));
     }
+    if (!last) return MB_OK;
     // final dropout (xlnet.py:396) on the only row SequenceSummary("last") reads, then summary -> tanh -> dropout -> logits_proj
     CK(last_token_forward(dt, ws + e->ws_x[c.n_layer], ws + e->ws_xs, B, L, H, e->key(XS_FINAL, pd), st));
     float* z = (float*)(ws + e->ws_head_z);
@@ -368,6 +374,13 @@ int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* 
     CK(head_forward(z, P + e->wc, P + e->bc, labels, (float*)(ws + e->ws_head_pooled), logits, loss, loss_run, B, H, c.num_labels,
                     e->key(XS_HEAD, c.summary_last_dropout), st));
     return MB_OK;
+}
+
+int mb_xlnet_forward(mb_xlnet_engine* e, const int64_t* input_ids, const float* visual, const float* acoustic,
+                     const int64_t* attention_mask, const int64_t* token_type_ids, const float* labels, int B, int L,
+                     int training, uint64_t seed, uint64_t step, float* logits, float* loss, float* loss_run, void* stream) {
+    return xl_forward_range(e, input_ids, visual, acoustic, attention_mask, token_type_ids, labels, B, L, training, seed, step, logits, loss,
+                            loss_run, stream, 0, e->c.n_layer, true, true);
 }
 
 int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* labels, float loss_scale, int stage_begin,
@@ -611,7 +624,7 @@ static int xl_adamw_decay_range(mb_xlnet_engine* e, float* m, float* v, size_t b
 // sharded update: of every chunk of layer GEMM weights inside [b, en) only this rank's slice + the replicated remainder (engine.hip)
 static int xl_adamw_decay_range_dp(mb_xlnet_engine* e, const mb_comm* comm, const DpSpec& sp, float* m, float* v, size_t b, size_t en, hipStream_t st) {
     if (!comm->shard) return xl_adamw_decay_range(e, m, v, b, en, st);
-    std::vector<std::pair<size_t, size_t>> ch(sp.chunk);
+    std::vector<std::pair<size_t, size_t>> ch(sp.chunk.begin(), sp.chunk.begin() + sp.n_sharded);      // (the rest is replicated)
     std::sort(ch.begin(), ch.end());
     size_t cur = b;
     ZeroRanges dead = {};
@@ -636,10 +649,17 @@ static int xl_enqueue_step_dp(mb_xlnet_engine* e, int seg, const std::vector<int
     char* ws = e->ws;
     const int NL = e->c.n_layer, nb = (int)plan.size();
     const float* lab = (const float*)(ws + e->ws_in_lab);
-    if (seg == 0)
-        CK(mb_xlnet_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
+    const int nf = comm->nf;          // sharded update with several pieces: forward-only segments in front (engine.hip)
+    auto layers_of = [&](int chunk, int& l0, int& l1) { l1 = NL; for (int s = 0; s < chunk; ++s) l1 -= plan[s]; l0 = l1 - plan[chunk]; };
+    if (seg <= nf) {
+        int l0 = 0, l1 = NL;
+        if (nf > 0) layers_of(nb - 1 - seg, l0, l1);
+        CK(xl_forward_range(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
                             (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
-                            loss_run, st));
+                            loss_run, st, l0, l1, seg == 0, seg == nf));
+        if (seg < nf) return MB_OK;
+    }
+    seg -= nf;
     if (seg < nb) {
         int done = 0;
         for (int s = 0; s < seg; ++s) done += plan[s];
@@ -684,13 +704,16 @@ int mb_xlnet_train_step_dp(mb_xlnet_engine* e, const int64_t* input_ids, const f
     sp.tail_begin = e->wsum; sp.tail_end = e->n_trainable;
     sp.word_off = e->word; sp.word_rows = c.vocab_size; sp.H = c.d_model;
     sp.ids = (const int64_t*)(e->ws + e->ws_in_ids); sp.T = B * L;
+    sp.n_sharded = dp_sharded_chunks(comm, nb);
+    const int nf = dp_forward_segments(comm, nb);
+    comm->nf = nf;
     if (comm->shard) {
         const bool bf = c.dtype == DT_BF16;
         for (const auto& ch : sp.chunk)
             if (bf && (!e->SH || ch.first < e->sh_begin || ch.second > e->sh_end)) return MB_ERR_MODE;
         sp.gather_base = bf ? (char*)e->SH : (char*)e->P; sp.gather_es = bf ? 2 : 4;
     }
-    CK(dp_step_begin(comm, st));          // (sharded update: the previous step's all-gathers)
+    CK(dp_step_begin(comm, st, nf > 0));          // (sharded update: the previous step's all-gathers -- cut mode: awaited piece by piece)
     e->training = 1;
     CK(xl_prepare_pass(e, B * L, st));
     int variant = 1;
@@ -705,7 +728,7 @@ int mb_xlnet_train_step_dp(mb_xlnet_engine* e, const int64_t* input_ids, const f
                                CK(dp_segment_end(comm, nb, sg, s));
                                return (int)MB_OK;
                            },
-                           nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant, comm, dp_finish_segment_graph);
+                           nf + nb + 2, [&](int sg, hipStream_t s) { return dp_between(comm, sp, e->G, sg, s); }, variant, comm, dp_finish_segment_graph);
 }
 
 int mb_xlnet_set_perm_mask(mb_xlnet_engine* e, const uint8_t* perm) {

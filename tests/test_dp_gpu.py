@@ -229,7 +229,7 @@ if kind == "xlnet":
     batch = lambda seed: weights.synthetic_xlnet_batch(8, 50, 47, 74, seed=seed)
 else:
     from test_model_gpu import build, tb, weights, DEV
-    make = lambda: build(layers=2, p_mag=0.0, hidden_p=0.0, attn_p=0.0, cdt=cdt)
+    make = lambda: build(layers=int(os.environ.get("LAYERS", "2")), p_mag=0.0, hidden_p=0.0, attn_p=0.0, cdt=cdt)
     batch = lambda seed: weights.synthetic_bert_batch(8, 50, 47, 74, seed=seed)
 from bert_multimodal_transformer_amd import AdamW, get_linear_schedule_with_warmup
 from bert_multimodal_transformer_amd.distributed import DataParallel
@@ -431,6 +431,25 @@ def test_sharded_update_inside_the_engine_call_equals_replicated(tmp_path, kind,
             assert torch.equal(shd[r]["shadow"], rep[0]["shadow"])                           # ... while the bf16 operands are everybody's
     print("%s sharded update in the engine call (%s): 2 ranks == replicated bit for bit; %d of %d parameters sharded, %d slices per rank; "
           "%d collectives, %.1f MB reduced" % (kind, cdt, 2 * n_sharded, rep[0]["p"].numel(), len(shd[0]["slices"]), shd[0]["stats"][0], shd[0]["stats"][1] * 1e-6))
+
+
+@pytest.mark.parametrize("cdt", ["fp32", "bf16"])
+def test_sharded_step_with_a_cut_forward_over_rccl_one_rank(tmp_path, cdt):
+    """The sharded update with FOUR pieces (4 layers, one per piece): the forward of the step is cut into three forward-only graphs +
+    the one in front of the first backward segment, each waiting for the all-gather of its own piece; the lowest piece stays
+    replicated (csrc/comm.h: cut mode).  Over RCCL itself with a one-rank communicator (MB_DP_SHARD_FORCE=1: reduce-scatter and
+    all-gather are identities) in deterministic mode: parameters after three steps BIT-IDENTICAL to the plain single-call step."""
+    import torch
+    out = str(tmp_path / "cut")
+    common = dict(OUT=out, KIND="bert", MB_DP_FORCE="1", BACKEND="nccl", STEPS="3", CDT=cdt, MB_DETERMINISTIC="1", LAYERS="4", MB_DP_CHUNK="1",
+                  MB_DP_GRAD_DTYPE="fp32")
+    _run_engine_workers(tmp_path, 1, dict(common, USE_DP="0"))
+    _run_engine_workers(tmp_path, 1, dict(common, USE_DP="1", MB_DP_SHARD_OPT="1", MB_DP_SHARD_FORCE="1"))
+    a, b = torch.load(out + ".1.0.0"), torch.load(out + ".1.0.1")
+    assert b["fused"] and not a["fused"] and b["slices"] and len(b["slices"]) == 3          # three sharded pieces, the fourth replicated
+    print("cut forward, one-rank RCCL (%s): %d collectives, %.1f MB; max |dparam| %.3e" % (cdt, b["stats"][0], b["stats"][1] * 1e-6,
+                                                                                          float((a["p"] - b["p"]).abs().max())))
+    assert torch.equal(a["p"], b["p"])
 
 
 @pytest.mark.parametrize("cdt,graph", [("fp32", "1"), ("fp32", "0"), ("bf16", "1")])
