@@ -211,8 +211,11 @@ class _Core(object):
             _lib.check(self.lib.mb_comm_gather_shards(comm.handle, _lib.ptr(self._adam_m), 4, st))
             _lib.check(self.lib.mb_comm_gather_shards(comm.handle, _lib.ptr(self._adam_v), 4, st))
 
-    def _ensure(self, B, L):
-        self._comm_join()
+    def _ensure(self, B, L, join=True):
+        # join=False: the pass about to run is the data-parallel single call itself, which waits for the previous step's all-gathers
+        # on its own -- piece by piece when the sharded update cut its forward (a full join here would undo that overlap)
+        if join:
+            self._comm_join()
         if B > self.max_B or L > self.max_L or self.ws is None:
             # "logically zero, physically stale" gradients are a fact only the OLD engine knows: make them real zeros before it goes
             self.materialize_grads()
@@ -468,7 +471,7 @@ class _Core(object):
         comm (distributed.Comm): the data-parallel form, mb_*_train_step_dp -- the same step as a chain of graphs with the
         gradient exchange issued from C between them."""
         B, L = input_ids.shape
-        self._ensure(B, L)
+        self._ensure(B, L, join=comm is None)
         if self.weights_dirty:
             self.sync_weights()
         if labels is None:
@@ -912,7 +915,7 @@ class _FusedStep(object):
             comm = None
             if opt is not None:
                 B_, L_ = input_ids.shape
-                core._ensure(B_, L_)
+                core._ensure(B_, L_, join=False)
                 comm = dp.get_comm(B_ * L_)
             if comm is not None:
                 optimizer._t += 1

@@ -386,8 +386,9 @@ int mb_comm_set_row_exchange(mb_comm* c, int rowwise);
 /* Sharded optimizer update (ZeRO-1 over the layers' GEMM weights; NEW: the reference runs one AdamW over everything,
  * multimodal_driver.py:345, 384-386).  With sharding on, mb_*_train_step_dp reduce-scatters every piece of layer GEMM-weight
  * gradients instead of all-reducing it, updates this rank's slice of every piece only, and all-gathers what the next forward reads
- * (the bf16 shadow in bf16 mode, the fp32 parameters in fp32 mode) on the comm stream; the NEXT mb_*_train_step_dp waits for those
- * gathers, any other consumer of the weights calls mb_comm_join(c, its stream) first.  In bf16 mode the fp32 masters -- and in either
+ * (the bf16 shadow in bf16 mode, the fp32 parameters in fp32 mode) on the comm stream.  With more than one piece the piece finished
+ * last (the lowest layers, needed first) stays replicated and the NEXT mb_*_train_step_dp runs its forward as one graph per piece,
+ * each waiting for the gather of its own piece only; any other consumer of the weights calls mb_comm_join(c, its stream) first.  In bf16 mode the fp32 masters -- and in either
  * mode Adam's m / v -- of the other ranks' slices are stale until mb_comm_gather_shards(c, flat buffer, 4, stream) refreshes them
  * (state_dict / checkpoints).  mb_comm_shard_slices: this rank's [begin, end) slices of the last sharded step. */
 int mb_comm_set_sharding(mb_comm* c, int on);
