@@ -576,3 +576,30 @@ def test_sharded_optimizer_update_equals_replicated(tmp_path, cdt):
             assert not torch.equal(shd[r]["p_before_gather"][other[0]:other[1]], rep[0]["p"][other[0]:other[1]])      # stale by design
             assert torch.equal(shd[r]["shadow"], rep[0]["shadow"])                     # ... while the bf16 operands are everybody's
     print("sharded optimizer (%s): 2 ranks == replicated path bit for bit; shards %s" % (cdt, shd[0]["shards"]))
+
+
+def test_bench_py_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` with no launcher around it: N ranks started by bench.py itself, rank 0 prints the ONE
+    JSON line with n_gpus = N, rccl_ranks = N (an all-reduce of ones through mb_comm_all_reduce), the data-parallel step call and the
+    comm statistics.  Two ranks share this GPU over the callback backend (MB_DIST_BACKEND=gloo); asked for two ranks over RCCL with one
+    device visible it exits non-zero with a message -- never a silent 1-GPU number."""
+    import json
+    env = dict(os.environ, MB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--cpu-baseline", "0",
+                        "--roofline", "0", "--secondary", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["global_batch"] == 96 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["step_call"].startswith("mb_bert_train_step_dp") and d["launched_by"].startswith("bench.py itself")
+    assert d["comm_collectives_per_step"] >= 5 and d["comm_mbytes_per_step"] > 300 and "comm_exposed_ms" in d
+    import torch
+    if torch.cuda.device_count() < 2:
+        env.pop("MB_DIST_BACKEND")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-baseline", "0", "--roofline", "0"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "device(s) visible" in (r.stdout + r.stderr)
+        assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric')]
