@@ -402,6 +402,71 @@ def spawn_ranks(a):
     raise SystemExit(rc)
 
 
+def price_trace(rows, gemm_log, B, L, dtype, n_update, steps):
+    """rows: (start ns, end ns, kernel name) of a kernel trace of consecutive training steps (two AdamW launches end a step); gemm_log: the
+    library's MB_GEMM_LOG=1 lines of the same run.  -> (per-kernel table over the last `steps` steps, roofline rows: every GEMM symbol
+    priced with the FLOPs it was launched with -- weight gradients count T, not the zero-padded Tp -- and AdamW with SURVEY 8(d)'s 28
+    B/parameter), or (None, reason).  Pure function (tests/test_host_cpu.py runs it on a synthetic trace)."""
+    rows = sorted(rows)
+    ad = [i for i, x in enumerate(rows) if "adamw" in x[2] and "tail" not in x[2]]
+    ends = ad[1::2]                       # two AdamW launches end a step
+    if len(ends) < steps + 1:
+        return None, "trace too short (%d optimizer launches)" % len(ad)
+    seg = rows[ends[-steps - 1] + 1: ends[-1] + 1]
+    busy, cs, ce = 0, seg[0][0], seg[0][1]
+    for s_, e_, _ in seg[1:]:
+        if s_ > ce:
+            busy += ce - cs
+            cs, ce = s_, e_
+        else:
+            ce = max(ce, e_)
+    busy += ce - cs
+    agg = {}
+    for s_, e_, k in seg:
+        q = agg.setdefault(k, [0, 0])
+        q[0] += 1; q[1] += e_ - s_
+    # what each GEMM symbol computed (one log line per launch of every enqueue pass)
+    flops = {}
+    Tt, Tp = B * L, (B * L + 63) // 64 * 64
+    for line in gemm_log.splitlines():
+        if not line.startswith("[magbert gemm] "):
+            continue
+        w = line.split()
+        kv = dict(t.split("=") for t in w[3:])
+        fl, K = float(kv["flop"]), int(kv["K"])
+        if K == Tp and Tp != Tt and "_tn_" in w[2]:
+            fl *= Tt / Tp                  # weight gradients run over the zero-padded token rows: algorithmic FLOPs count T
+        q = flops.setdefault(w[2], [0, 0.0])
+        q[0] += 1; q[1] += fl
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    ks = sorted(agg.items(), key=lambda kv_: -kv_[1][1])
+    table, roof = [], []
+    for k, (n, t) in ks[:24]:
+        short = k.split("(")[0][:110]
+        row = {"kernel": short, "launches_per_step": round(n / steps, 2), "avg_us": round(t / n / 1e3, 2), "ms_per_step": round(t / steps / 1e6, 4)}
+        table.append(row)
+        us = t / n / 1e3
+        f = flops.get(k) or flops.get(k.split("(")[0])
+        if f:
+            per = f[1] / f[0]
+            roof.append(dict(row, bound="mfma", flop_per_launch=per, achieved=round(per / us * 1e-6, 1), peak=peak, unit="TFLOP/s",
+                             frac=round(per / us * 1e-6 / peak, 4), gflop_per_step=round(per * n / steps * 1e-9, 2)))
+        elif "adamw" in k and "tail" not in k:
+            per = 28.0 * n_update / 2.0     # SURVEY 8(d): read p, g, m, v; write p, m, v -- the step's two launches share the sweep
+            roof.append(dict(row, bound="hbm", algorithmic_bytes_per_launch=int(per), achieved=round(per / us * 1e-3, 1), peak=8000.0, unit="GB/s",
+                             frac=round(per / us * 1e-3 / 8000.0, 4)))
+    doc = {"workload": "bert B=%d L=%d %s" % (B, L, dtype), "replayed": False,
+           "busy_ms_per_step": round(busy / steps / 1e6, 4), "kernels_per_step": round(len(seg) / steps, 1),
+           "busy_ms_per_step_is": "the sum of kernel durations UNDER THE PROFILER (a few percent above the untraced step: ms_per_step is the step)",
+           "kernels": table}
+    gemm_ms = sum(x["ms_per_step"] for x in roof if x["bound"] == "mfma")
+    gemm_gf = sum(x["gflop_per_step"] for x in roof if x["bound"] == "mfma")
+    if gemm_ms > 0:
+        doc["gemm_aggregate"] = {"ms_per_step": round(gemm_ms, 4), "gflop_per_step": round(gemm_gf, 1), "tflops": round(gemm_gf / gemm_ms, 1),
+                                 "frac": round(gemm_gf / gemm_ms / peak, 4), "note": "every GEMM symbol of the trace, in-step durations"}
+    return doc, roof
+
+
 def instep_trace(B, L, V, dtype, n_update, steps=10, warmup=3):
     """A rocprofv3 kernel trace of the step, taken by bench.py itself: tools/bin/step_bench (the torch-free driver of the same
     mb_bert_train_step call: prologue + one replayed hipGraph, batch gathered from pinned host memory) runs `steps` traced steps as a
@@ -440,65 +505,11 @@ def instep_trace(B, L, V, dtype, n_update, steps=10, warmup=3):
         for x in csv.DictReader(fh):
             rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), x["Kernel_Name"]))
     shutil.rmtree(d, ignore_errors=True)
-    rows.sort()
-    ad = [i for i, x in enumerate(rows) if "adamw" in x[2] and "tail" not in x[2]]
-    ends = ad[1::2]                       # two AdamW launches end a step
-    if len(ends) < steps + 1:
-        return None, "trace too short (%d optimizer launches)" % len(ad)
-    seg = rows[ends[-steps - 1] + 1: ends[-1] + 1]
-    busy, cs, ce = 0, seg[0][0], seg[0][1]
-    for s_, e_, _ in seg[1:]:
-        if s_ > ce:
-            busy += ce - cs
-            cs, ce = s_, e_
-        else:
-            ce = max(ce, e_)
-    busy += ce - cs
-    agg = {}
-    for s_, e_, k in seg:
-        q = agg.setdefault(k, [0, 0])
-        q[0] += 1; q[1] += e_ - s_
-    # what each GEMM symbol computed (one log line per launch of every enqueue pass)
-    flops = {}
-    Tt, Tp = B * L, (B * L + 63) // 64 * 64
-    for line in (r.stderr or "").splitlines():
-        if not line.startswith("[magbert gemm] "):
-            continue
-        w = line.split()
-        kv = dict(t.split("=") for t in w[3:])
-        fl, K = float(kv["flop"]), int(kv["K"])
-        if K == Tp and Tp != Tt and "_tn_" in w[2]:
-            fl *= Tt / Tp                  # weight gradients run over the zero-padded token rows: algorithmic FLOPs count T
-        q = flops.setdefault(w[2], [0, 0.0])
-        q[0] += 1; q[1] += fl
-    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
-    ks = sorted(agg.items(), key=lambda kv_: -kv_[1][1])
-    table, roof = [], []
-    for k, (n, t) in ks[:24]:
-        short = k.split("(")[0][:110]
-        row = {"kernel": short, "launches_per_step": round(n / steps, 2), "avg_us": round(t / n / 1e3, 2), "ms_per_step": round(t / steps / 1e6, 4)}
-        table.append(row)
-        us = t / n / 1e3
-        f = flops.get(k) or flops.get(k.split("(")[0])
-        if f:
-            per = f[1] / f[0]
-            roof.append(dict(row, bound="mfma", flop_per_launch=per, achieved=round(per / us * 1e-6, 1), peak=peak, unit="TFLOP/s",
-                             frac=round(per / us * 1e-6 / peak, 4), gflop_per_step=round(per * n / steps * 1e-9, 2)))
-        elif "adamw" in k and "tail" not in k:
-            per = 28.0 * n_update / 2.0     # read p, g, m, v; write p, m, v -- the step's two launches share the sweep
-            roof.append(dict(row, bound="hbm", algorithmic_bytes_per_launch=int(per), achieved=round(per / us * 1e-3, 1), peak=8000.0, unit="GB/s",
-                             frac=round(per / us * 1e-3 / 8000.0, 4)))
-    doc = {"workload": "bert B=%d L=%d %s" % (B, L, dtype), "replayed": False,
-           "source": "rocprofv3 --kernel-trace run BY THIS bench.py invocation over tools/bin/step_bench --graph 1 --h2d 2 (the same "
-                     "mb_bert_train_step call, torch-free), last %d steps; %.1f s" % (steps, took),
-           "busy_ms_per_step": round(busy / steps / 1e6, 4), "kernels_per_step": round(len(seg) / steps, 1),
-           "busy_ms_per_step_is": "the sum of kernel durations UNDER THE PROFILER (a few percent above the untraced step: ms_per_step is the step)",
-           "kernels": table}
-    gemm_ms = sum(x["ms_per_step"] for x in roof if x["bound"] == "mfma")
-    gemm_gf = sum(x["gflop_per_step"] for x in roof if x["bound"] == "mfma")
-    if gemm_ms > 0:
-        doc["gemm_aggregate"] = {"ms_per_step": round(gemm_ms, 4), "gflop_per_step": round(gemm_gf, 1), "tflops": round(gemm_gf / gemm_ms, 1),
-                                 "frac": round(gemm_gf / gemm_ms / peak, 4), "note": "every GEMM symbol of the trace, in-step durations"}
+    doc, roof = price_trace(rows, r.stderr or "", B, L, dtype, n_update, steps)
+    if doc is None:
+        return None, roof
+    doc["source"] = ("rocprofv3 --kernel-trace run BY THIS bench.py invocation over tools/bin/step_bench --graph 1 --h2d 2 (the same "
+                     "mb_bert_train_step call, torch-free), last %d steps; %.1f s" % (steps, took))
     return doc, roof
 
 

@@ -484,3 +484,27 @@ def test_optimizer_shards_split_covers_every_element_once():
             assert b[r][0] <= o and o + n <= b[r][1]
         for o, n in shared:
             assert o >= FakeCore.sh_end or o + n <= FakeCore.sh_begin
+
+
+def test_bench_prices_a_kernel_trace():
+    """bench.py's `roofline` comes from a kernel trace it takes itself (price_trace): steps are delimited by the two AdamW launches, every
+    GEMM symbol is priced with the FLOPs the library logged for it (weight gradients: T, not the padded Tp), AdamW with 28 B/parameter."""
+    import bench
+    B, L, T, Tp = 48, 50, 2400, 2432
+    gemm_a, gemm_w, adam, ln = "_ZN2mb12gemm2_kernelIA", "_ZN2mb23gemm2_grouped_tn_kernelIW", "void mb::adamw_var_kernel<true, 2, true>(float*)", "ln_fwd"
+    rows, t = [], 0
+    for step in range(4):                          # one untraced-looking warm-up step + 3 timed ones
+        for name, dur, n in ((gemm_a, 10_000, 3), (ln, 2_000, 2), (gemm_w, 40_000, 1), (adam, 250_000, 2)):
+            for _ in range(n):
+                rows.append((t, t + dur, name)); t += dur + 500
+    log = "\n".join(["[magbert gemm] %s problems=1 flop=%d M=%d N=768 K=768" % (gemm_a, 2 * T * 768 * 768, T)] * 3 +
+                    ["[magbert gemm] %s problems=4 flop=%d M=768 N=3072 K=%d" % (gemm_w, 2 * Tp * 768 * 3072 * 4, Tp), "noise line"])
+    doc, roof = bench.price_trace(rows[::-1], log, B, L, "bf16", 110_853_121, steps=3)
+    assert doc["kernels_per_step"] == 8.0 and abs(doc["busy_ms_per_step"] - (3 * 10 + 2 * 2 + 40 + 2 * 250) * 1e-3) < 1e-6
+    by = {r["kernel"][:20]: r for r in roof}
+    a, w, ad = by[gemm_a[:20]], by[gemm_w[:20]], by[adam[:20]]
+    assert a["launches_per_step"] == 3 and abs(a["achieved"] - 2 * T * 768 * 768 / 10.0 * 1e-6) < 0.1 and a["bound"] == "mfma"
+    assert abs(w["flop_per_launch"] - 2 * T * 768 * 3072 * 4) < 1.0            # the padded K = Tp scaled back to T
+    assert ad["bound"] == "hbm" and abs(ad["achieved"] - 14 * 110_853_121 / 250.0 * 1e-3) < 0.5
+    assert doc["gemm_aggregate"]["gflop_per_step"] > 0 and not doc["replayed"]
+    assert bench.price_trace(rows[:5], log, B, L, "bf16", 1, steps=3)[0] is None          # too short: a reason, not a crash
