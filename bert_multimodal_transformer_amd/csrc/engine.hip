@@ -57,6 +57,10 @@ struct mb_bert_engine : StepMixin {
     int pf_qkv = 0;                // MB_PF_QKV=64|128: ln_bwd(LN1)'s left-over prefetch loads touch the saved q | k | v | context rows, one per 64 / 128 bytes
     hipStream_t opt_side = nullptr;
     std::vector<hipEvent_t> opt_ev;
+    // EXPERIMENT MB_ADAMW_IN_WGRAD=1 (kernels.h: EPI_WGRAD_ADAM): in a single-process single-call step whose gradient buffer is known-zero,
+    // the layers' grouped weight-gradient launches update the parameters themselves and the optimizer sweep skips that range.
+    int adam_in_wgrad = 0;
+    float* fuse_m = nullptr; float* fuse_v = nullptr;      // Adam moments of the step being enqueued, when the fusion applies to it
     int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128), 0 = four launches
     bool grouped = false;          // the layer's four weight gradients are ONE launch
     bool deferred = false;         // ... on the side stream, joined one stage later (MB_OVERLAP_WGRAD=0: on the caller's stream, in line)
@@ -384,6 +388,7 @@ int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
     if (const char* v = getenv("MB_GROUP_WGRAD")) e->group_wgrad = atoi(v);
     if (const char* v = getenv("MB_WGRAD_OVERWRITE")) e->ow_enable = atoi(v);
     if (const char* v = getenv("MB_ADAMW_KEEP")) e->keep_enable = atoi(v);
+    if (const char* v = getenv("MB_ADAMW_IN_WGRAD")) e->adam_in_wgrad = atoi(v);
     if (const char* v = getenv("MB_DETERMINISTIC")) e->deterministic = atoi(v);
     if (const char* v = getenv("MB_ADAMW_OVERLAP")) e->opt_chunk = atoi(v);
     if (const char* v = getenv("MB_PREFETCH")) e->prefetch = atoi(v);
@@ -644,10 +649,23 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, dqkv, G + o.bqkv, B, L, nh,
                                   e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st,
                                   e->head_mask ? e->head_mask + (size_t)l * nh : nullptr, acc));
+            // (experiment) the update inside the launch: the tile of the gradient becomes the new parameters -- so every reader of the
+            // OLD weights of this layer (the qkv dgrad below) goes first
+            const bool fuse = inl && e->fuse_m && e->fuse_v && e->ow_pass && e->group_wgrad == 128;
+            if (fuse) {
+                const size_t offs[4] = {o.w2, o.w1, o.wo, o.wqkv};
+                for (int k = 0; k < 4; ++k) {
+                    wg[k].C = P + offs[k]; wg[k].C2 = e->fuse_m + offs[k]; wg[k].R = e->fuse_v + offs[k];
+                    wg[k].bias = (const float*)e->adam_state(ws);
+                    wg[k].colsum = dt == DT_BF16 ? (float*)(e->SH + offs[k] * 2) : nullptr;
+                }
+                CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, 3 * H, dqkv, 3 * H, e->W(o.wqkv), H, dx, H, nullptr, nullptr,
+                        nullptr, dsB, H, kNoDrop, 1, 0, st));
+            }
             auto launch_group = [&]() -> int {
                 if (inl) {
                     if (e->prof) CK((int)hipEventRecord(e->pev[2 * l], st));
-                    CK(gemm_grouped_tn_launch(dt, wg, 4, e->group_wgrad, st));
+                    CK(gemm_grouped_tn_launch(dt, wg, 4, e->group_wgrad, st, 0, fuse));
                     if (e->prof) CK((int)hipEventRecord(e->pev[2 * l + 1], st));
                     return MB_OK;
                 }
@@ -662,7 +680,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                 CK(fork(3));
                 CK(wgrad(dt, 3 * H, H, Tk, dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H, ss));
             }
-            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, 3 * H, dqkv, 3 * H, e->W(o.wqkv), H, dx, H, nullptr, nullptr,
+            if (!fuse) CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, 3 * H, dqkv, 3 * H, e->W(o.wqkv), H, dx, H, nullptr, nullptr,
                     nullptr, dsB, H, kNoDrop, 1, 0, st));
             if (ss != st && !grouped) {      // join: the stage's gradients are complete (and dY buffers reusable) once main passes this
                 CK((int)hipEventRecord(sev[4], ss));
@@ -768,13 +786,20 @@ static int enqueue_step(mb_bert_engine* e, int seg, int nseg, int B, int L, floa
     // backward stages: 0 = head, 1 .. NL = layers NL-1 .. 0, NL+1 = MAG + embeddings
     const int sb = nseg == 1 ? 0 : (seg == 0 ? 0 : 1 + seg * C);
     const int se = nseg == 1 ? NL + 2 : (seg + 1 < nseg ? 1 + (seg + 1) * C : NL + 2);
-    CK(mb_bert_backward(e, nullptr, lab, loss_scale, sb, se, st));
+    // (experiment) the layers' weights are updated by their own weight-gradient launches: single segment, known-zero gradients,
+    // in-line 128 x 128 grouped launches, the layers' GEMM weights at the head of the decay slab
+    const bool fuse = e->adam_in_wgrad && m && v && nseg == 1 && e->ow_pass && e->grouped && !e->deferred && e->group_wgrad == 128 && NL > 0 &&
+                      e->lo[0].wqkv == 0 && !e->prof;
+    e->fuse_m = fuse ? m : nullptr; e->fuse_v = fuse ? v : nullptr;
+    const int rb = mb_bert_backward(e, nullptr, lab, loss_scale, sb, se, st);
+    e->fuse_m = e->fuse_v = nullptr;
+    CK(rb);
     if (m && v && seg == nseg - 1) {
         const AdamArgs none = {};
         const size_t nd = e->n_decay, n = e->n_params;
         CK(e->prof_mark(2 * NL, st));
         // (with chunks on the side stream, what is left of the decay slab: the pooler weight .. the classifier weight)
-        CK(adamw_decay_range(e, m, v, nseg == 1 ? 0 : e->wp, nd, st));
+        CK(adamw_decay_range(e, m, v, (nseg == 1 && !fuse) ? 0 : e->wp, nd, st));
         CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
         CK(e->prof_mark(2 * NL + 1, st));
     }

@@ -233,6 +233,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
     const int c = (tid % TPR) * 8;
     const int n = n0 + c;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    AdamArgs adam = {};
+    float adam_omb1 = 0.f, adam_omb2 = 0.f, adam_decay = 0.f;
+    if constexpr (MODE == EPI_WGRAD_ADAM) {
+        adam = *(const AdamArgs*)p.bias;          // this step's scalars (the step prologue wrote them)
+        adam_omb1 = 1.0f - adam.beta1; adam_omb2 = 1.0f - adam.beta2; adam_decay = adam.lr * adam.weight_decay;
+    }
     const float (&bias8)[8] = pre.bias8;
     T* __restrict__ C = (T*)p.C;
     const DropKey& dkey = pre.key;
@@ -305,6 +311,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
 #pragma unroll
             for (int q = 0; q < 8; ++q) { v[q] *= res[q] * drop_mult(dkey, gidx + q); cs[q] += v[q]; }      // R = gelu'(u) saved by EPI_BIAS_GELU
             Vec8<T>::store(C + off, v);
+        } else if constexpr (MODE == EPI_WGRAD_ADAM) {
+            // the gradient never leaves the CU: HF-AdamW on this thread's eight parameters (adamw.hip: adam_update_store, same order of
+            // operations -> the same bits as storing the gradient and sweeping it later)
+            float* pp_ = (float*)p.C + off; float* pm_ = (float*)p.C2 + off; float* pv_ = (float*)const_cast<void*>(p.R) + off;
+            float pp[8], mm[8], vv[8];
+            Vec8<float>::load(pp_, pp); Vec8<float>::load(pm_, mm); Vec8<float>::load(pv_, vv);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float g = v[q] * adam.grad_scale;
+                mm[q] = adam.beta1 * mm[q] + adam_omb1 * g;
+                vv[q] = adam.beta2 * vv[q] + adam_omb2 * g * g;
+                pp[q] -= adam.step_size * (mm[q] / (sqrtf(vv[q]) + adam.eps));
+                if (adam_decay > 0.f) pp[q] -= adam_decay * pp[q];
+            }
+            Vec8<float>::store(pp_, pp); Vec8<float>::store(pm_, mm); Vec8<float>::store(pv_, vv);
+            if (p.colsum) Vec8<bf16>::store((bf16*)p.colsum + off, pp);
         } else if constexpr (MODE == EPI_ACCUM_F32) {
             float* dst = p.Cf + off;
             if (gridDim.y > 1) {
@@ -989,8 +1011,8 @@ __global__ void __launch_bounds__(NW * 64) gemm2_kernel(const GemmArgs p) {
 // gradients alone is at most ~2 blocks per CU (one under-filled round whose duration is set by the K = T loop latency,
 // not by its size); launched together they are one grid of ~7 blocks per CU that keeps every CU's LDS ring full.
 // Problem g owns blocks [first[g], first[g+1]) (multiples of 8, so block -> XCD mapping is unchanged).
-template <class T, int BM, int BN, int NSTAGE, int KB>
-__global__ void __launch_bounds__(256) gemm2_grouped_tn_kernel(const GroupedGemmArgs ga) {
+template <class T, int BM, int BN, int NSTAGE, int KB, int MODE>
+__device__ __forceinline__ void grouped_tn_block(const GroupedGemmArgs& ga) {
     __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB>::BYTES];
     // (A persistent variant that holds only one LDS slot per CU -- MB_GROUP_GRID = 128 / 256 / 384 blocks looping over the 432
     //  tiles -- was measured: no gain at 384, slower below; the launch is needed at full width to finish inside its layer.)
@@ -1028,7 +1050,19 @@ __global__ void __launch_bounds__(256) gemm2_grouped_tn_kernel(const GroupedGemm
         g = __builtin_amdgcn_readfirstlane(g);
         if (!tile_origin<BM, BN>(ga.g[g], m0, n0, (int)blockIdx.x - ga.first[g])) return;
     }
-    gemm2_body<T, BM, BN, true, true, EPI_ACCUM_F32, NSTAGE, KB>(ga.g[g], m0, n0, 0, smem);
+    // (EPI_WGRAD_ADAM: touching the tile's p | m | v patch in front of the k loop -- one dword per 128-byte line, so that the epilogue
+    //  finds it in the L2 / Infinity Cache -- was measured and lost: 91 instead of 80 us per launch, profiles/r05_adamw_in_wgrad_ab.txt)
+    gemm2_body<T, BM, BN, true, true, MODE, NSTAGE, KB>(ga.g[g], m0, n0, 0, smem);
+}
+template <class T, int BM, int BN, int NSTAGE, int KB>
+__global__ void __launch_bounds__(256) gemm2_grouped_tn_kernel(const GroupedGemmArgs ga) {
+    grouped_tn_block<T, BM, BN, NSTAGE, KB, EPI_ACCUM_F32>(ga);
+}
+// (experiment, kernels.h EPI_WGRAD_ADAM: the same launch with HF-AdamW in the epilogue -- a kernel of its own so that the symbol of the
+//  default one, which profiles and PMC tables are keyed by, stays what it was)
+template <class T, int BM, int BN, int NSTAGE, int KB>
+__global__ void __launch_bounds__(256) gemm2_grouped_tn_adam_kernel(const GroupedGemmArgs ga) {
+    grouped_tn_block<T, BM, BN, NSTAGE, KB, EPI_WGRAD_ADAM>(ga);
 }
 
 // ---------------------------------------------------------------------------------------------- host
@@ -1220,7 +1254,7 @@ static int launch_T(const GemmArgs& a, int layout, int mode, int splits, int til
 }
 
 template <class T, int BM, int BN>
-static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st, int stages) {
+static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st, int stages, bool adam) {
     constexpr int BKE = 128 / sizeof(T);
     constexpr int EPV = 16 / sizeof(T);
     GroupedGemmArgs ga;
@@ -1266,6 +1300,13 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st, int 
     // A group of few 64 x 64 tiles (MAG: 360 tiles for 512 slots, 8 MFMAs per wave and stage) is pure load latency: one k stage
     // costs one memory round trip divided by the stages in flight.  4 | 5 ring slots of 128-byte rows = 64 | 80 KB, still 2 blocks
     // per CU.  (The 128 x 128 groups measured slower with any deeper ring: 128 KB would leave one block per CU.)
+    if (adam) {          // (experiment: the default 128 x 128 two-slot configuration only)
+        if constexpr (BM == 128 && BN == 128) {
+            MB_GEMM_LAUNCH((gemm2_grouped_tn_adam_kernel<T, BM, BN, 2, 128>), dim3(grid), dim3(256), st, ga, ga.g, count);
+            return (int)hipGetLastError();
+        }
+        return MB_ERR_MODE;
+    }
     if constexpr (BM == 64 && BN == 64) {
         if (gst == 4) { MB_GEMM_LAUNCH((gemm2_grouped_tn_kernel<T, BM, BN, 4, 128>), dim3(grid), dim3(256), st, ga, ga.g, count); return (int)hipGetLastError(); }
         if (gst == 5) { MB_GEMM_LAUNCH((gemm2_grouped_tn_kernel<T, BM, BN, 5, 128>), dim3(grid), dim3(256), st, ga, ga.g, count); return (int)hipGetLastError(); }
@@ -1294,10 +1335,10 @@ int gemm_grouped_tn_ok(int dtype, const GemmArgs* probs, int count, int tile) {
     return 1;
 }
 
-int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st, int stages) {
+int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st, int stages, bool adam) {
     if (count < 1 || count > MB_MAX_GROUP) return MB_ERR_ARG;
-    if (dtype == DT_BF16) return tile == 128 ? launch_grouped<bf16, 128, 128>(probs, count, st, stages) : launch_grouped<bf16, 64, 64>(probs, count, st, stages);
-    if (dtype == DT_F32) return tile == 128 ? launch_grouped<float, 128, 128>(probs, count, st, stages) : launch_grouped<float, 64, 64>(probs, count, st, stages);
+    if (dtype == DT_BF16) return tile == 128 ? launch_grouped<bf16, 128, 128>(probs, count, st, stages, adam) : launch_grouped<bf16, 64, 64>(probs, count, st, stages, adam);
+    if (dtype == DT_F32) return tile == 128 ? launch_grouped<float, 128, 128>(probs, count, st, stages, adam) : launch_grouped<float, 64, 64>(probs, count, st, stages, adam);
     return MB_ERR_DTYPE;
 }
 

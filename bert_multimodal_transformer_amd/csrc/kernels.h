@@ -34,7 +34,12 @@ enum { EPI_BIAS = 0,          // C = alpha*acc + bias                           
        EPI_ADD_RES = 3,       // C = acc (+ R)                                          (T out)
        EPI_DGELU = 4,         // C = acc * R [* dropout], R = gelu'(u) saved by mode 1  (T out)
        EPI_ACCUM_F32 = 5,     // Cf += acc   (atomic when split-K)                      (fp32 out)
-       EPI_BIAS_F32 = 6 };    // Cf = alpha*acc + bias                                  (fp32 out)
+       EPI_BIAS_F32 = 6,      // Cf = alpha*acc + bias                                  (fp32 out)
+       // EXPERIMENT (MB_ADAMW_IN_WGRAD=1, grouped weight gradients of a single-process step whose gradient buffer is known-zero): the tile
+       // is not stored as a gradient at all -- the epilogue applies HF-AdamW (adamw.hip's arithmetic) to its own [BM][BN] patch of
+       // the parameters: C = p, C2 = m, R = v (fp32, the gradient's layout), colsum = bf16 shadow (or null), bias = AdamArgs in
+       // device memory.  Saves the gradient's round trip through HBM (8 of 30 B/parameter); measured in profiles/r05_adamw_in_wgrad_ab.txt
+       EPI_WGRAD_ADAM = 7 };
 
 struct AdamArgs {
     float lr, beta1, beta2, eps, weight_decay, step_size;   // step_size = lr*sqrt(1-b2^t)/(1-b1^t)
@@ -83,7 +88,7 @@ struct GroupedGemmArgs {
     int chunk;                      // > 0: tiles per XCD of the group-wide XCD-compact placement (gemm.hip); 0: per-problem regions
 };
 int gemm_grouped_tn_ok(int dtype, const GemmArgs* probs, int count, int tile);
-int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st, int stages = 0);   // stages: 0 = MB_GROUP_STAGES, 4 | 5 = deeper ring (64 x 64 tiles only)
+int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st, int stages = 0, bool adam = false);   // stages: 0 = MB_GROUP_STAGES, 4 | 5 = deeper ring (64 x 64 tiles only)
 
 // ------------------------------------------------------------------------------------------ row kernels (rowops.hip)
 // LayerNorm over the last dim H (H % 256 == 0, H <= 1024): y = (x-mean)*rstd*gamma + beta ; optional dropout on y.

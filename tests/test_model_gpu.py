@@ -605,6 +605,21 @@ def _trajectory(cdt, mode, nsteps=4, accum=1, layers=3, shapes=((5, 40), (5, 40)
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_adamw_inside_the_weight_gradient_epilogue_changes_nothing(cdt, monkeypatch):
+    """EXPERIMENT MB_ADAMW_IN_WGRAD=1 (csrc/kernels.h EPI_WGRAD_ADAM): the layers' grouped weight-gradient launches apply
+    HF-AdamW to their own tiles instead of storing a gradient for the optimizer sweep.  Same arithmetic in the same order, so in
+    deterministic mode four steps (dropout on, schedule moving, two shapes = two captured graphs) end with the SAME BITS in the
+    parameters, both Adam moments, the bf16 shadow and the logits; the gradient buffer reads as zeros afterwards."""
+    monkeypatch.setenv("MB_DETERMINISTIC", "1")
+    ref = _trajectory(cdt, True)
+    monkeypatch.setenv("MB_ADAMW_IN_WGRAD", "1")
+    fused = _trajectory(cdt, True)
+    for k in ("p", "m", "v", "shadow", "logits"):
+        assert torch.equal(fused[k], ref[k]), "%s differs with the update inside the weight-gradient epilogue" % k
+    assert float(fused["g"].abs().max()) == 0.0 and fused["stats"] == ref["stats"]
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 def test_step_graph_equals_launch_by_launch(cdt, monkeypatch):
     """mb_bert_train_step: the replayed whole-step hipGraph (dropout keys, lr and bias correction read from device memory,
     batch gathered by the step prologue) ends every step exactly where the kernels launched one by one end it: same dropout
