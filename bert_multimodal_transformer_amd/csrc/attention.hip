@@ -146,6 +146,39 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : 1) attn_b
     const int H = nh * 64;
     const size_t ld = (size_t)3 * H;
     const T* base = qkv + (size_t)b * L * ld + h * 64;
+#ifdef MB_ATTN_FUSE_PROBE
+    // COST PROBE (measurement build only, scripts/gpu_r05d.sh; the numbers it produces are garbage): what would it cost this kernel to
+    // compute its own dCtx tile -- dCtx[i][d] = sum_k dY[b*L + i][k] * Wo[k][h*64 + d], the out-projection's dgrad restricted to this
+    // (sample, head) -- instead of reading it?  The favourable case: a transposed bf16 copy of Wo exists, so both
+    // operands are "natural" fragments read straight from global memory (16 B per lane and k step); `dctx` plays dY (same [T][H]
+    // shape), 64 rows of `qkv` play the [64][768] panel of Wo^T (same bytes, same reuse across the blocks of a head).
+    if constexpr (sizeof(T) == 2 && LP == 64 && NW == 4) {
+        {
+            char* const img[3] = {Qi, Ki, Vi};
+            const T* const src[3] = {base, base + H, base + 2 * H};
+            const size_t lds[3] = {ld, ld, ld};
+            stage_heads<T, LP, NW * 64, 3>(img, PIT, src, lds, L);
+        }
+        const int i = wave * 16 + (lane & 15);
+        const T* arow = dctx + ((size_t)b * L + (i < L ? i : 0)) * H + (lane >> 4) * 8;          // this lane's dY row, its 8-element k chunk
+        const T* wrow = qkv + (size_t)(h * 64 + (lane & 15)) * ld + (lane >> 4) * 8;             // "Wo^T" rows h*64 + dt*16 + (lane & 15)
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int ks = 0; ks < H / 32; ++ks) {
+            const bf16x8 y = *(const bf16x8*)(arow + ks * 32);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) mma16(o[dt], *(const bf16x8*)(wrow + (size_t)dt * 16 * ld + ks * 32), y);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {             // o[dt][r] = dCtx[i][dt*16 + (lane>>4)*4 + r] -> the dO image
+            T* dst = (T*)(Oi + i * PIT) + dt * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[r] = from_f<T>(i < L ? o[dt][r] : 0.f);
+        }
+    } else
+#endif
     {
         char* const img[4] = {Qi, Ki, Vi, Oi};
         const T* const src[4] = {base, base + H, base + 2 * H, dctx + (size_t)b * L * H + h * 64};
