@@ -508,3 +508,21 @@ def test_bench_prices_a_kernel_trace():
     assert ad["bound"] == "hbm" and abs(ad["achieved"] - 14 * 110_853_121 / 250.0 * 1e-3) < 0.5
     assert doc["gemm_aggregate"]["gflop_per_step"] > 0 and not doc["replayed"]
     assert bench.price_trace(rows[:5], log, B, L, "bf16", 1, steps=3)[0] is None          # too short: a reason, not a crash
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts its own N ranks -- or exits non-zero with a message when the box has fewer
+    devices (RCCL needs one per rank), never a silent 1-GPU number.  Host logic only: the device count is patched."""
+    import types
+    import torch
+    import bench
+    a = types.SimpleNamespace(gpus=8)
+    monkeypatch.delenv("MB_DIST_BACKEND", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+    with pytest.raises(SystemExit) as ex:
+        bench.spawn_ranks(a)
+    assert "needs a ROCm GPU" in str(ex.value)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    with pytest.raises(SystemExit) as ex:
+        bench.spawn_ranks(a)
+    assert "only 4 device(s) visible" in str(ex.value) and ex.value.code not in (0, None)
