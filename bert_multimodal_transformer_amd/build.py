@@ -9,9 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmagbert_hip.so")
-SOURCES = ["gemm.hip", "rowops.hip", "mag.hip", "attention.hip", "xlnet_attention.hip", "xlnet_rowops.hip", "head.hip", "adamw.hip",
+SOURCES = ["gemm.hip", "gemm_pp.hip", "rowops.hip", "mag.hip", "attention.hip", "xlnet_attention.hip", "xlnet_rowops.hip", "head.hip", "adamw.hip",
            "engine.hip", "xlnet_engine.hip", "comm.hip"]
-HEADERS = ["common.h", "kernels.h", "attn_common.h", "engine_common.h", "comm.h", "mag_pack.h", os.path.join("..", "..", "include", "magbert_hip.h")]
+HEADERS = ["common.h", "kernels.h", "gemm_tile.h", "adamw_dev.h", "attn_common.h", "engine_common.h", "comm.h", "mag_pack.h", os.path.join("..", "..", "include", "magbert_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fvisibility=default",
          "-Wno-unused-result"]
 
@@ -69,7 +69,7 @@ def build_tools(force=False):
     root = os.path.dirname(HERE)
     outdir = os.path.join(root, "tools", "bin")
     outs = []
-    for name in ("step_bench", "gemm_bench", "launch_floor", "attn_bench", "adamw_bench", "event_capture_probe", "stream_handoff_probe"):
+    for name in ("step_bench", "gemm_bench", "launch_floor", "attn_bench", "adamw_bench", "event_capture_probe", "stream_handoff_probe", "mfma_lds_probe", "atomic_probe"):
         src = os.path.join(root, "tools", name + ".cpp")
         if not os.path.exists(src):
             continue

@@ -6,44 +6,9 @@
 // The flat layout puts every weight-decayed tensor first: elements [0, n_decay) decay, the rest do not.
 #include <cstdlib>
 #include "kernels.h"
+#include "adamw_dev.h"
 
 namespace mb {
-
-// one quad of four consecutive parameters
-struct AdamQuad { f32x4 p, g, m, v; };
-template <bool NT> __device__ __forceinline__ AdamQuad adam_load(const float* p, const float* g, const float* m, const float* v, size_t i) {
-    AdamQuad q;
-    if constexpr (NT) {          // streamed once per step, never re-read before it is rewritten: keep it out of the caches
-        q.p = __builtin_nontemporal_load((const f32x4*)(p + i)); q.g = __builtin_nontemporal_load((const f32x4*)(g + i));
-        q.m = __builtin_nontemporal_load((const f32x4*)(m + i)); q.v = __builtin_nontemporal_load((const f32x4*)(v + i));
-    } else {
-        q.p = *(const f32x4*)(p + i); q.g = *(const f32x4*)(g + i); q.m = *(const f32x4*)(m + i); q.v = *(const f32x4*)(v + i);
-    }
-    return q;
-}
-template <bool NT> __device__ __forceinline__ void adam_update_store(AdamQuad q, float* p, float* g, float* m, float* v, bf16* shadow, size_t i,
-                                                                     const AdamArgs& a, float omb1, float omb2, float decay, size_t n_decay,
-                                                                     size_t sh_begin, size_t sh_end, size_t keep_begin, size_t keep_end, int zero_grad) {
-    q.g *= a.grad_scale;
-    q.m = a.beta1 * q.m + omb1 * q.g;
-    q.v = a.beta2 * q.v + omb2 * q.g * q.g;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) q.p[r] -= a.step_size * (q.m[r] / (sqrtf(q.v[r]) + a.eps));
-    if (i < n_decay && decay > 0.f) q.p -= decay * q.p;
-    const bool zg = zero_grad && !(i >= keep_begin && i < keep_end);
-    if constexpr (NT) {
-        __builtin_nontemporal_store(q.p, (f32x4*)(p + i));
-        __builtin_nontemporal_store(q.m, (f32x4*)(m + i));
-        __builtin_nontemporal_store(q.v, (f32x4*)(v + i));
-        if (zg) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, (f32x4*)(g + i));
-    } else {
-        *(f32x4*)(p + i) = q.p;
-        *(f32x4*)(m + i) = q.m;
-        *(f32x4*)(v + i) = q.v;
-        if (zg) *(f32x4*)(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (shadow && i >= sh_begin && i < sh_end) store4(shadow + i, q.p);
-}
 
 // Variant kernel for experiments (MB_ADAMW_VAR): UNR quads in flight per thread, CHUNK: every block owns one contiguous range
 template <bool NT, int UNR, bool CHUNK>
@@ -83,6 +48,7 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float
     const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
     const float decay = a.lr * a.weight_decay;
     for (size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * 256) {
+#pragma clang fp contract(off)
         const size_t i = i4 * 4;
         f32x4 pv, gv, mv, vv;
         if constexpr (NT) {          // streamed once per step, never re-read before it is rewritten: keep it out of the caches
@@ -118,6 +84,8 @@ __global__ void adamw_tail_kernel(float* p, float* g, float* m, float* v, size_t
     if (dyn) a = *dyn;
     const size_t i = begin + threadIdx.x;
     if (i >= n) return;
+    {
+#pragma clang fp contract(off)
     const float gv = g[i] * a.grad_scale;
     const float mv = a.beta1 * m[i] + (1.0f - a.beta1) * gv;
     const float vv = a.beta2 * v[i] + (1.0f - a.beta2) * gv * gv;
@@ -125,6 +93,7 @@ __global__ void adamw_tail_kernel(float* p, float* g, float* m, float* v, size_t
     if (i < n_decay && a.lr * a.weight_decay > 0.f) pv -= a.lr * a.weight_decay * pv;
     p[i] = pv; m[i] = mv; v[i] = vv;
     if (zero_grad) g[i] = 0.f;
+    }
 }
 
 int adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, size_t n_decay, size_t sh_begin,

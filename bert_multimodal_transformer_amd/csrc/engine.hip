@@ -61,7 +61,14 @@ struct mb_bert_engine : StepMixin {
     // the layers' grouped weight-gradient launches update the parameters themselves and the optimizer sweep skips that range.
     int adam_in_wgrad = 0;
     float* fuse_m = nullptr; float* fuse_v = nullptr;      // Adam moments of the step being enqueued, when the fusion applies to it
-    int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128), 0 = four launches
+    // MB_ADAMW_RIDE=1 (kernels.h AdamRide): in a single-process single-call step the grouped weight-gradient launch of layer l carries
+    // the optimizer update of layer l+1's GEMM weights (whose gradients the launch before completed) as extra workgroups in the slots
+    // its tiles leave empty (256 x 128 tiles: 40 of 256 CUs; 128 x 128: 80 of 512 slots); the sweep at the end skips those layers.
+    int adam_ride = 1, ride_blocks = 0;
+    float* ride_m = nullptr; float* ride_v = nullptr;       // Adam moments of the step being enqueued, when riders apply to it
+    size_t ride_cursor = 0;                                 // the riders of the step being enqueued have taken [ride_cursor, wp) of the decay slab
+    long ride_params = 0;                                   // MB_ADAMW_RIDE_PARAMS: parameters per launch (0 = by the token count)
+    int group_wgrad = 256;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128 | 256 = 256 x 128 ping-pong), 0 = four launches
     bool grouped = false;          // the layer's four weight gradients are ONE launch
     bool deferred = false;         // ... on the side stream, joined one stage later (MB_OVERLAP_WGRAD=0: on the caller's stream, in line)
     float* attn_out = nullptr;     // mb_bert_set_attention_output: [num_layers][B][nh][L][L] fp32, filled by the next forwards
@@ -389,11 +396,17 @@ int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
     if (const char* v = getenv("MB_WGRAD_OVERWRITE")) e->ow_enable = atoi(v);
     if (const char* v = getenv("MB_ADAMW_KEEP")) e->keep_enable = atoi(v);
     if (const char* v = getenv("MB_ADAMW_IN_WGRAD")) e->adam_in_wgrad = atoi(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE")) e->adam_ride = atoi(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE_BLOCKS")) e->ride_blocks = atoi(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE_PARAMS")) e->ride_params = atol(v);
     if (const char* v = getenv("MB_DETERMINISTIC")) e->deterministic = atoi(v);
     if (const char* v = getenv("MB_ADAMW_OVERLAP")) e->opt_chunk = atoi(v);
     if (const char* v = getenv("MB_PREFETCH")) e->prefetch = atoi(v);
     if (const char* v = getenv("MB_PF_QKV")) e->pf_qkv = atoi(v);
-    e->grouped = (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->hidden_size % e->group_wgrad == 0 &&
+    if (e->adam_in_wgrad && !getenv("MB_GROUP_WGRAD")) e->group_wgrad = 128;      // (that experiment lives in the 128 x 128 kernel's epilogue)
+    // 256 = the 256 x 128 ping-pong tile (gemm_pp.hip; bf16 only): falls back to 128 where it does not divide the layer
+    if (e->group_wgrad == 256 && (cfg->dtype != DT_BF16 || cfg->hidden_size % 256 != 0 || cfg->intermediate_size % 256 != 0)) e->group_wgrad = 128;
+    e->grouped = (e->group_wgrad == 64 || e->group_wgrad == 128 || e->group_wgrad == 256) && cfg->hidden_size % e->group_wgrad == 0 &&
                  cfg->intermediate_size % e->group_wgrad == 0;
     e->deferred = e->overlap_wgrad && e->grouped;
 
@@ -607,7 +620,9 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             if (grouped)
                 for (GemmArgs& a : wg) a.overwrite = e->ow_pass ? 1 : 0;       // whole-tile, no split-K launches only
             const bool inl = grouped && !e->deferred;         // grouped launch in line on the caller's stream (no overlap)
-            if (grouped && !gemm_grouped_tn_ok(dt, wg, 4, e->group_wgrad)) return MB_ERR_SHAPE;
+            int wtile = e->group_wgrad;
+            if (grouped && wtile == 256 && !gemm_grouped_tn_ok(dt, wg, 4, 256)) wtile = 128;      // (fewer than three k stages: the 128 x 128 kernel)
+            if (grouped && !gemm_grouped_tn_ok(dt, wg, 4, wtile)) return MB_ERR_SHAPE;
             if (!grouped) {
             CK(fork(0));
             CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, ss));
@@ -662,16 +677,43 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                 CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, 3 * H, dqkv, 3 * H, e->W(o.wqkv), H, dx, H, nullptr, nullptr,
                         nullptr, dsB, H, kNoDrop, 1, 0, st));
             }
+            // riders: an optimizer update in the empty slots of this launch -- up to ride_params parameters from the TOP of what is
+            // final by now (the GEMM weights of layers l+1 .. NL-1, minus what earlier launches of this backward took): the sweep at the end
+            // of the step is then ONE range [0, ride_cursor) + the rest of the slabs
+            AdamRide ride = {};
+            if (inl && !fuse && e->ride_m && e->ride_v && l + 1 < NL && e->ride_cursor > e->lo[l + 1].wqkv) {
+                const size_t avail = e->ride_cursor - e->lo[l + 1].wqkv;
+                // what 40 CUs stream while the tiles multiply (~41 GB/s per CU; same-box sweeps in profiles/r06_adamw_ride_budget.txt,
+                // r06_adamw_ride_ab.txt: 2.5 M parameters at T = 2400, 3.5 M at T = 4096; more stretches the launch)
+                const size_t budget = e->ride_params > 0 ? (size_t)e->ride_params : std::min((size_t)1000 * (size_t)Tk, (size_t)1100000 + (size_t)590 * (size_t)Tk);
+                size_t take = std::min(avail, budget);
+                take = take / 1024 * 1024;
+                const size_t re = e->ride_cursor, rb = re - take;
+                const bool sh_ok = dt != DT_BF16 || (e->sh_begin <= rb && re <= e->sh_end);
+                if (take > 0 && rb % 4 == 0 && sh_ok) {
+                    int tiles = 0;
+                    const int bm = wtile == 256 ? 256 : wtile, bn = wtile == 256 ? 128 : wtile;
+                    for (const GemmArgs& a : wg) tiles += (a.M / bm) * (a.N / bn);
+                    const int slots = e->cu_count() * (wtile == 256 ? 1 : wtile == 128 ? 2 : 0);
+                    int blocks = e->ride_blocks > 0 ? e->ride_blocks : (slots - tiles) / 8 * 8;
+                    if (blocks >= 8) {
+                        const bool keep = e->keep_in_step() && e->stale_begin <= rb && re <= e->stale_end;
+                        ride = AdamRide{e->P + rb, e->G + rb, e->ride_m + rb, e->ride_v + rb, dt == DT_BF16 ? (bf16*)(e->SH + rb * 2) : nullptr,
+                                        take / 4, e->adam_state(ws), blocks, keep ? 0 : 1};
+                        e->ride_cursor = rb;
+                    }
+                }
+            }
             auto launch_group = [&]() -> int {
                 if (inl) {
                     if (e->prof) CK((int)hipEventRecord(e->pev[2 * l], st));
-                    CK(gemm_grouped_tn_launch(dt, wg, 4, e->group_wgrad, st, 0, fuse));
+                    CK(gemm_grouped_tn_launch(dt, wg, 4, wtile, st, 0, fuse, ride.blocks ? &ride : nullptr));
                     if (e->prof) CK((int)hipEventRecord(e->pev[2 * l + 1], st));
                     return MB_OK;
                 }
                 CK(fork(3));
                 if (e->prof) CK((int)hipEventRecord(e->pev[2 * l], ss));
-                CK(gemm_grouped_tn_launch(dt, wg, 4, e->group_wgrad, ss));
+                CK(gemm_grouped_tn_launch(dt, wg, 4, wtile, ss));
                 if (e->prof) CK((int)hipEventRecord(e->pev[2 * l + 1], ss));
                 return (int)hipEventRecord(sev[4], ss);       // "weight gradients (or updated weights) of layer l are final"
             };
@@ -791,15 +833,23 @@ static int enqueue_step(mb_bert_engine* e, int seg, int nseg, int B, int L, floa
     const bool fuse = e->adam_in_wgrad && m && v && nseg == 1 && e->ow_pass && e->grouped && !e->deferred && e->group_wgrad == 128 && NL > 0 &&
                       e->lo[0].wqkv == 0 && !e->prof;
     e->fuse_m = fuse ? m : nullptr; e->fuse_v = fuse ? v : nullptr;
+    // riders (MB_ADAMW_RIDE): layers 1 .. NL-1 are updated inside the weight-gradient launches of layers 0 .. NL-2; whether a launch
+    // really carried one is decided there, so the sweep below asks the engine which layers are still to do
+    const bool ride = e->adam_ride && !fuse && m && v && nseg == 1 && e->grouped && !e->deferred && NL > 1 && e->lo[0].wqkv == 0 && !e->prof &&
+                      (e->group_wgrad == 128 || e->group_wgrad == 256);
+    e->ride_m = ride ? m : nullptr; e->ride_v = ride ? v : nullptr;
+    e->ride_cursor = e->wp;
     const int rb = mb_bert_backward(e, nullptr, lab, loss_scale, sb, se, st);
     e->fuse_m = e->fuse_v = nullptr;
+    e->ride_m = e->ride_v = nullptr;
     CK(rb);
     if (m && v && seg == nseg - 1) {
         const AdamArgs none = {};
         const size_t nd = e->n_decay, n = e->n_params;
         CK(e->prof_mark(2 * NL, st));
         // (with chunks on the side stream, what is left of the decay slab: the pooler weight .. the classifier weight)
-        CK(adamw_decay_range(e, m, v, (nseg == 1 && !fuse) ? 0 : e->wp, nd, st));
+        if (ride) CK(adamw_decay_range(e, m, v, 0, e->ride_cursor, st));       // what no launch carried (layer 0 always)
+        CK(adamw_decay_range(e, m, v, (nseg == 1 && !fuse && !ride) ? 0 : e->wp, nd, st));
         CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
         CK(e->prof_mark(2 * NL + 1, st));
     }

@@ -218,6 +218,15 @@ struct StepMixin {
         if (deterministic && ws && G) { a.shadow = (long long*)(ws + ws_det) - det_begin; a.base = G; }
         return a;
     }
+    int cus = 0;                                       // compute units of the current device (AdamRide: slots a grouped launch leaves empty)
+    int cu_count() {
+        if (cus <= 0) {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = n;
+            if (cus <= 0) cus = 256;
+        }
+        return cus;
+    }
     bool grads_stale = false, ow_covers = false;       // ow_covers: the overwriting (grouped) launch covers [stale_begin, stale_end)
     size_t stale_begin = 0, stale_end = 0;
     int keep_enable = 1;

@@ -1,0 +1,301 @@
+// 256 x 128 bf16 GEMM tile run by EIGHT waves as two staggered four-wave groups ("ping-pong").
+//
+// Same math and the same callers as gemm.hip (the Linear layers under /root/reference/bert.py:221-229 and the weight gradients of
+// loss.backward(), /root/reference/multimodal_driver.py:378); what differs is who is on the matrix pipe when.
+//
+// Why: two co-resident 128 x 128 blocks per CU need the CU's whole 64 B/clk L2 -> LDS fill path at full MFMA rate and sit at ~50 %
+// of it.  One 256 x 128 tile moves 25 % fewer operand bytes per FLOP -- but eight waves behind ONE barrier issue DMA,
+// read LDS and run MFMA in lockstep: every SIMD's matrix pipe idles while both of its waves read fragments (the round-2 kernel that
+// lost).  Here the workgroup's two halves are offset by one barrier phase:
+//
+//     phase      2t                     2t+1                   2t+2
+//     group 0    LOAD(t)                COMP(t)                LOAD(t+1)
+//     group 1    COMP(t-1)              LOAD(t)                COMP(t)
+//
+//   LOAD(t): all fragment reads of k-stage t (64 registers: the wave's 64 x 64 quarter of its group's 128 x 128 half, two 32-deep
+//            slabs) and NOTHING else; nothing for the matrix pipe
+//   COMP(t): 32 MFMAs out of registers, with this wave's 6 DMA pieces of a later stage and the next LOAD's addresses between them
+// A SIMD hosts wave w (group 0) and wave w+4 (group 1): in every phase one of them feeds the matrix pipe while the other feeds the
+// LDS / DMA queues -- the complementary pairing MI355X_MICROARCH.md "Two waves per SIMD" item 5 asks for.  The two groups share the
+// B image (128 columns) and the barrier; group 0 owns tile rows 0-127, group 1 rows 128-255.
+//
+// Ring: three 48-KB slots.  In COMP(t) group 0 (phase 2t+1) requests its share of stage t+2, group 1 (phase 2t+2) its share of stage
+// t+3 -- into the slot stage t-1 resp. t lived in, whose last reader drained its reads before the barrier in front of that phase
+// (WAR).  Landing (RAW): a wave's pieces of stage t+1 are counted out (s_waitcnt vmcnt) in phase 2t+1 by BOTH groups -- group 0 at the
+// end of COMP(t), group 1 at the end of LOAD(t) -- i.e. before the barrier in front of the first read of stage t+1 (group 0, phase
+// 2t+2); every piece has had at least two phases to land by then.  Both groups run BOTH waits (no branch on the group in the loop):
+// the other one is free for group 0 (nothing younger outstanding) and a phase early for group 1.
+#include "gemm_tile.h"
+#include "adamw_dev.h"
+
+namespace mb {
+
+constexpr int kPpBM = 256, kPpBN = 128, kPpKB = 128, kPpSlots = 3, kPpWaves = 8;
+constexpr int kPpStage = (kPpBM + kPpBN) * kPpKB;       // 48 KB
+
+#ifdef MB_GEMM_LOOPTRACE
+// wave 0 (group 0) and wave 4 (group 1) stamp kPpIters k-stages from stage kPpFirst on, kPpPoints shader-clock stamps each:
+// 0 top of LOAD | 1 reads issued | 2 reads returned (+ group 1: stage t+1 landed) | 3 barrier passed | 4 MFMAs + DMA issued |
+// 5 group 0: stage t+1 landed  (the next stage's point 0 closes the second barrier)
+constexpr int kPpFirst = 4, kPpIters = 10, kPpPoints = 6;
+#endif
+
+// dst = s + v as a pinned statement (stays between the MFMAs it is written between)
+__device__ __forceinline__ void pinned_add(uint32_t& dst, uint32_t s, uint32_t v) { asm volatile("v_add_u32 %0, %1, %2" : "=v"(dst) : "s"(s), "v"(v)); }
+
+template <bool AK, bool BK, int MODE>
+__device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, const int n0, char* smem) {
+    typedef bf16 T;
+    constexpr int BM = kPpBM, BN = kPpBN, KB = kPpKB, NW = kPpWaves, STAGE = kPpStage;
+    constexpr int BKE = KB / 2;                    // 64 k per stage
+    constexpr int MT = 4, NT = 4, NSLAB = 2;       // a wave: 64 x 64 outputs, two 32-deep slabs per stage
+    typedef Dma<T, BM, AK, KB, NW> DA;
+    typedef Dma<T, BN, BK, KB, NW> DB;
+    constexpr int G = DA::NI + DB::NI;             // DMA pieces per wave per stage (4 + 2)
+    typedef typename DA::template Reader<MT, NSLAB> RA;
+    typedef typename DB::template Reader<NT, NSLAB> RB_;
+    constexpr int NRA = MT * RA::READS_PER_FRAG, NRB = NT * RB_::READS_PER_FRAG;
+    constexpr int NM = MT * NT * NSLAB;            // MFMAs per stage (32)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                     // waves w and w + 4 share a SIMD (MI355X_MICROARCH.md, LDS: dispatch order 0 -> 2 -> 1 -> 3)
+    const int wr = wave >> 1, wc = wave & 1;       // 4 x 2 waves; wr 0-1 = group 0
+    const int nt = p.K / BKE;                      // >= 3 (launcher)
+    const T* __restrict__ A = (const T*)p.A;
+    const T* __restrict__ B = (const T*)p.B;
+    // segmented B (GemmArgs::bseg), as in gemm2_body
+    int n0b = n0, seg_stages = 0;
+    uint32_t seg_extra = 0;
+    if (p.bseg > 0) {
+        if constexpr (BK) { B += (size_t)(n0 / p.bseg) * p.bseg_stride; n0b = n0 % p.bseg; }
+        else { seg_stages = p.bseg / BKE; seg_extra = (uint32_t)((p.bseg_stride - (size_t)p.bseg) * sizeof(T)); }
+    }
+    int seg_left = seg_stages;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto stamp = [&](int k) {
+        if (p.trace && tid == 0) p.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kTraceStride + k] = wall_clock64();
+    };
+#ifdef MB_GEMM_LOOPTRACE
+    __shared__ uint32_t lt[2][kPpIters * kPpPoints];
+#define PP_LT(t, j) do { if (p.trace && (t) >= kPpFirst && (t) < kPpFirst + kPpIters && (tid & 255) == 0) \
+                             lt[grp][((t) - kPpFirst) * kPpPoints + (j)] = (uint32_t)__builtin_readcyclecounter(); } while (0)
+#else
+#define PP_LT(t, j) do { } while (0)
+#endif
+    stamp(0);
+    EpiPre<T, BM, BN, MODE, NW> pre;
+    pre.fetch(p, m0, n0, tid);                     // the oldest loads in flight: counted out by the first vmcnt wait
+
+    RA ra;
+    RB_ rb;
+    const uint32_t lds0 = (uint32_t)(size_t)LDS_PTR(smem);
+    ra.init(lds0, wr * 64, 0, lane);
+    rb.init(lds0 + BM * KB, wc * 64, 0, lane);
+    // A wave's pieces of a stage are CONSECUTIVE 1-KB pieces of the image (wave * NI + i): one m0 per operand and stage, piece i is
+    // the instruction's immediate offset i * 1024 -- which the hardware adds to the LDS address AND to the memory address, so the
+    // lane offsets are taken back by i * 1024 and the descriptors' bases by kBias to keep them non-negative.
+    constexpr uint32_t kBias = 4096;
+    uint32_t va[DA::NI], vb[DB::NI];
+#pragma unroll
+    for (int i = 0; i < DA::NI; ++i) va[i] = DA::dma_voff_blk(wave * DA::NI + i, p.lda, m0, p.M, lane) + kBias - (uint32_t)i * 1024u;
+#pragma unroll
+    for (int i = 0; i < DB::NI; ++i) vb[i] = DB::dma_voff_blk(wave * DB::NI + i, p.ldb, n0b, p.N, lane) + kBias - (uint32_t)i * 1024u;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)A - kBias), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)B - kBias), 0, -1, 0x00020000);
+    const uint32_t ksa = DA::k_stride_bytes(p.lda) * BKE, ksb = DB::k_stride_bytes(p.ldb) * BKE;      // operand bytes per stage
+    uint32_t soa = 0, sob = 0;
+#ifdef MB_GEMM_ABLATE
+    const bool no_dma = (p.dbg & 1) != 0, no_reads = (p.dbg & 4) != 0, no_mfma = (p.dbg & 2) != 0;
+#else
+    constexpr bool no_dma = false, no_reads = false, no_mfma = false;
+#endif
+    // piece I (A pieces first) of this wave's share of the next stage in k order -> ring slot at byte offset `slot`
+    auto dma_piece = [&](auto ic, uint32_t slot) {
+        constexpr int I = decltype(ic)::value;
+        if (no_dma) return;
+        // (the immediate must be a literal: a template-dependent argument of the builtin fails the host pass)
+#define MB_PP_PIECE(RS, PTR, VOFF, SOFF, J) do { \
+            if constexpr ((J) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, PTR, 16, VOFF, SOFF, 0, 0); \
+            else if constexpr ((J) == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, PTR, 16, VOFF, SOFF, 1024, 0); \
+            else if constexpr ((J) == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, PTR, 16, VOFF, SOFF, 2048, 0); \
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, PTR, 16, VOFF, SOFF, 3072, 0); } while (0)
+        static_assert(DA::NI <= 4 && DB::NI <= 4, "immediate offsets reach 4095");
+        if constexpr (I < DA::NI)
+            MB_PP_PIECE(rsa, (__attribute__((address_space(3))) void*)LDS_PTR(smem + slot + wave * (DA::NI * 1024)), (int)va[I], (int)soa, I);
+        else
+            MB_PP_PIECE(rsb, (__attribute__((address_space(3))) void*)LDS_PTR(smem + slot + BM * KB + wave * (DB::NI * 1024)), (int)vb[I - DA::NI], (int)sob, I - DA::NI);
+#undef MB_PP_PIECE
+    };
+    auto dma_advance = [&]() {
+        soa += ksa; sob += ksb;
+        if (seg_stages > 0 && --seg_left == 0) { sob += seg_extra; seg_left = seg_stages; }
+    };
+    auto issue_stage = [&](uint32_t slot) {
+        static_for<G>([&](auto ic) { dma_piece(ic, slot); });
+        dma_advance();
+    };
+    // An instruction of the wave that is NOT on the matrix pipe costs a whole MFMA time (~16 clocks) while its SIMD partner issues
+    // MFMAs back to back, and ~4 clocks inside the MFMA stream itself (tools/mfma_lds_probe, profiles/r06_mfma_lds_probe.txt): so LOAD
+    // holds the fragment reads and nothing else -- their addresses are computed in the COMP phase before (addr_*), the DMA pieces
+    // ride between the MFMAs.
+    uint32_t addr_a[RA::NB], addr_b[RB_::NB];
+#pragma unroll
+    for (int j = 0; j < RA::NB; ++j) addr_a[j] = ra.base[j];
+#pragma unroll
+    for (int j = 0; j < RB_::NB; ++j) addr_b[j] = rb.base[j];
+    FragU fa[NSLAB][MT], fb[NSLAB][NT];
+    auto read_stage = [&]() {                      // every fragment of the stage addr_* points at, slab by slab
+        if (no_reads) return;
+        static_for<NSLAB>([&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            static_for<NRB>([&](auto rc) { rb.template emit_at<decltype(rc)::value, S>(fb[S], addr_b); });
+            static_for<NRA>([&](auto rc) { ra.template emit_at<decltype(rc)::value, S>(fa[S], addr_a); });
+        });
+    };
+    // COMP: the stage's MFMAs with (DMA ? this wave's pieces of its next stage : nothing) and the next stage's read addresses between them
+    constexpr int NADDR = RA::NB + RB_::NB;
+    auto comp_stage_ = [&](auto dmac, auto mfc, uint32_t slot, uint32_t nxt) {
+        constexpr bool DMA = decltype(dmac)::value, MF = decltype(mfc)::value;
+        constexpr int NF = (DMA ? G : 0) + NADDR;
+        static_for<NM>([&](auto mc) {
+            constexpr int M = decltype(mc)::value, S = M / (MT * NT), Q = M % (MT * NT);
+            if constexpr (MF) mma16_pinned(acc[Q / NT][Q % NT], fb[S][Q % NT].v, fa[S][Q / NT].v);
+            constexpr int f0 = M * NF / NM, f1 = (M + 1) * NF / NM;
+            static_for<f1 - f0>([&](auto fc) {
+                constexpr int F = f0 + decltype(fc)::value;
+                if constexpr (DMA && F < G) dma_piece(std::integral_constant<int, F>{}, slot);
+                else {
+                    constexpr int J = F - (DMA ? G : 0);
+                    if constexpr (J < RA::NB) pinned_add(addr_a[J], nxt, ra.base[J]);
+                    else pinned_add(addr_b[J - RA::NB], nxt, rb.base[J - RA::NB]);
+                }
+            });
+        });
+        if constexpr (DMA) dma_advance();
+    };
+    auto comp_stage = [&](auto dmac, uint32_t slot, uint32_t nxt) {
+#ifdef MB_GEMM_ABLATE
+        if (no_mfma) { comp_stage_(dmac, std::false_type{}, slot, nxt); return; }
+#endif
+        comp_stage_(dmac, std::true_type{}, slot, nxt);
+    };
+    typedef std::integral_constant<int, 1> W1;       // wait until only the newest stage is in flight
+    typedef std::integral_constant<int, 0> W0;       // drain
+    typedef std::integral_constant<int, -1> WN;      // nothing to wait for
+    auto land = [&](auto wc_) {
+        constexpr int W = decltype(wc_)::value;
+        if constexpr (W == 1) wait_vmcnt<G>();
+        else if constexpr (W == 0) wait_vmcnt<0>();
+    };
+
+    // Group 0 requests stage t+2 during COMP(t) (phase 2t+1), group 1 stage t+3 during ITS COMP(t) (phase 2t+2): the slot is the
+    // one stage t lived in, which both groups have read by then.  Either way a wave's pieces have >= 2 phases to land.
+    issue_stage(0u);
+    issue_stage((uint32_t)STAGE);
+    if (grp) { issue_stage(2u * STAGE); wait_vmcnt<2 * G>(); } else wait_vmcnt<G>();
+    __builtin_amdgcn_s_barrier();                    // stage 0 has landed for everybody
+    stamp(1);
+    if (grp) __builtin_amdgcn_s_barrier();           // group 1 runs one phase behind
+    uint32_t cur = 0u, dslot = grp ? 0u : 2u * STAGE;
+    // DM: 1 = every wave requests its next stage between the MFMAs, 2 = group 0 only (in front of the MFMAs), 0 = nobody
+    auto stage = [&](int t, auto dm, auto wc_) {
+        constexpr int DM = decltype(dm)::value;
+        (void)t;
+        // ---- LOAD(t)
+        PP_LT(t, 0);
+        read_stage();
+        PP_LT(t, 1);
+        lds_wait_all();
+        land(wc_);                                   // group 1: its share of stage t+1 has landed (group 0: nothing younger than stage t+1 yet)
+        PP_LT(t, 2);
+        __builtin_amdgcn_sched_barrier(0);           // the scalar bookkeeping of COMP stays behind the barrier (in LOAD it would cost ~16 clocks each)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        PP_LT(t, 3);
+        // ---- COMP(t)
+        const uint32_t nxt = cur == 2u * STAGE ? 0u : cur + STAGE;
+        if constexpr (DM == 2) { if (!grp) issue_stage(dslot); }
+        // the multiplying wave outranks its SIMD partner's reads: by age alone the older wave (group 0) wins BOTH ways and group 1's
+        // 32 MFMAs take ~930 clocks instead of ~510 (profiles/r06_pp_looptrace.txt)
+        if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(1);
+        comp_stage(std::integral_constant<bool, DM == 1>{}, dslot, nxt);
+        if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(0);
+        PP_LT(t, 4);
+        land(wc_);                                   // group 0: its share of stage t+1 (group 1: of stage t+2, a phase early -- it has had two)
+        PP_LT(t, 5);
+        __builtin_amdgcn_s_barrier();
+        cur = nxt;
+        dslot = dslot == 2u * STAGE ? 0u : dslot + STAGE;
+    };
+    typedef std::integral_constant<int, 0> D0;
+    typedef std::integral_constant<int, 1> D1;
+    typedef std::integral_constant<int, 2> D2;
+    int t = 0;
+    for (; t + 3 < nt; ++t) stage(t, D1{}, W1{});
+    stage(t, D2{}, W1{});
+    stage(t + 1, D0{}, W0{});
+    stage(t + 2, D0{}, WN{});
+    if (!grp) __builtin_amdgcn_s_barrier();          // pairs with group 1's last COMP
+    stamp(2);
+    gemm_epilogue<T, BM, BN, MODE, false, NW>(p, acc, m0, n0, wave, lane, smem, pre);
+    if (p.trace) {
+        stamp(3);
+        wait_vmcnt<0>();
+        stamp(4);
+#ifdef MB_GEMM_LOOPTRACE
+        if ((tid & 255) == 0) {
+            unsigned long long* dst = p.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kTraceStride + 8 + grp * kPpIters * kPpPoints;
+            for (int i = 0; i < kPpIters * kPpPoints; ++i) dst[i] = lt[grp][i];
+        }
+#endif
+    }
+#undef PP_LT
+}
+
+template <bool AK, bool BK, int MODE>
+__global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(1024))) char smem[kPpSlots * kPpStage];
+    int m0, n0;
+    if (!tile_origin<kPpBM, kPpBN>(p, m0, n0, blockIdx.x)) return;
+    gemm_pp_body<AK, BK, MODE>(p, m0, n0, smem);
+}
+
+// the weight gradients of a layer (dW = dY^T X: both operands k-major), one launch (gemm.hip: launch_grouped places the tiles)
+__global__ void __launch_bounds__(512) gemm_pp_grouped_tn_kernel(const GroupedGemmArgs ga) {
+    __shared__ __attribute__((aligned(1024))) char smem[kPpSlots * kPpStage];
+    if ((int)blockIdx.x < ga.ride.blocks) {          // rider: an optimizer update on a CU that has no tile (kernels.h AdamRide)
+        adam_ride_block<512, 3>(ga.ride, (int)blockIdx.x);
+        return;
+    }
+    int g, m0, n0;
+    if (!grouped_tile_origin<kPpBM, kPpBN>(ga, g, m0, n0)) return;
+    gemm_pp_body<true, true, EPI_ACCUM_F32>(ga.g[g], m0, n0, smem);
+}
+
+int gemm_pp_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hipStream_t st) {
+#define MB_PP(AKV, BKV, MODEV) \
+    if (ak == AKV && bk == BKV && mode == MODEV) { \
+        MB_GEMM_LAUNCH((gemm_pp_kernel<AKV, BKV, MODEV>), grid, dim3(512), st, p, &p, 1); \
+        return (int)hipGetLastError(); \
+    }
+    MB_PP(false, false, EPI_BIAS)
+    MB_PP(false, false, EPI_BIAS_GELU)
+    MB_PP(false, true, EPI_DGELU)
+    MB_PP(true, true, EPI_ACCUM_F32)
+#undef MB_PP
+    return MB_ERR_MODE;
+}
+
+int gemm_pp_grouped_launch(const GroupedGemmArgs& ga, int grid, hipStream_t st) {
+    MB_GEMM_LAUNCH(gemm_pp_grouped_tn_kernel, dim3(grid + ga.ride.blocks), dim3(512), st, ga, ga.g, ga.count);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mb

@@ -81,14 +81,28 @@ int gemm_launch(int dtype, int layout, int mode, const GemmArgs& a, int splits, 
 // Grouped wgrad (GEMM_TN, EPI_ACCUM_F32): `count` <= MB_MAX_GROUP (8) problems Cf_g[M_g][N_g] += A_g^T B_g in one launch.
 // Needs whole tiles and whole 128-byte K rows for every problem (gemm_grouped_tn_ok tells); tile = 64 | 128.
 #define MB_MAX_GROUP 8
+// An HF-AdamW update riding inside a grouped weight-gradient launch (MB_ADAMW_RIDE): `blocks` extra workgroups at the head of the grid
+// (a multiple of 8: the tiles' XCD placement is unchanged) update n4 quads of weight-decayed parameters -- the GEMM weights of the
+// layer whose gradients the PREVIOUS launch completed -- while the other workgroups multiply.  The update is HBM-bound, the tiles
+// are not, and the 256 x 128 launch leaves 40 of the 256 CUs without a tile.  p / g / m / v / shadow point at the range's first element.
+struct AdamRide {
+    float *p, *g, *m, *v;
+    bf16* shadow;             // bf16 operand shadow of the range or null
+    size_t n4;
+    const AdamArgs* dyn;      // this step's scalars (device memory: the step prologue writes them)
+    int blocks;               // 0 = no rider
+    int zero_grad;            // 0: the next backward overwrites these gradients (engine_common.h keep_in_step)
+};
 struct GroupedGemmArgs {
     GemmArgs g[MB_MAX_GROUP];
     int first[MB_MAX_GROUP + 1];    // first block (region placement) or first tile of the group-wide list (chunk > 0) of every problem
     int count;
     int chunk;                      // > 0: tiles per XCD of the group-wide XCD-compact placement (gemm.hip); 0: per-problem regions
+    AdamRide ride;                  // ride.blocks > 0: that many workgroups in front of the tiles run an optimizer update instead
 };
 int gemm_grouped_tn_ok(int dtype, const GemmArgs* probs, int count, int tile);
-int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st, int stages = 0, bool adam = false);   // stages: 0 = MB_GROUP_STAGES, 4 | 5 = deeper ring (64 x 64 tiles only)
+int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st, int stages = 0, bool adam = false,
+                           const AdamRide* ride = nullptr);   // stages: 0 = MB_GROUP_STAGES, 4 | 5 = deeper ring (64 x 64 tiles only)
 
 // ------------------------------------------------------------------------------------------ row kernels (rowops.hip)
 // LayerNorm over the last dim H (H % 256 == 0, H <= 1024): y = (x-mean)*rstd*gamma + beta ; optional dropout on y.

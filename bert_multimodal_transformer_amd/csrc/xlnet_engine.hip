@@ -221,9 +221,10 @@ int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out) {
     if (cfg->dtype != DT_F32 && cfg->dtype != DT_BF16) return MB_ERR_DTYPE;
     mb_xlnet_engine* e = new mb_xlnet_engine();
     if (const char* v = getenv("MB_GROUP_WGRAD")) e->group_wgrad = atoi(v);
+    if (e->group_wgrad == 256 && (cfg->dtype != DT_BF16 || cfg->d_model % 256 != 0 || cfg->d_inner % 256 != 0)) e->group_wgrad = 128;     // 256 x 128 ping-pong tile: bf16, whole tiles
     if (const char* v = getenv("MB_OVERLAP_WGRAD")) e->overlap_wgrad = atoi(v);
     if (const char* v = getenv("MB_WGRAD_OVERWRITE")) e->ow_enable = atoi(v);
-    e->deferred = e->overlap_wgrad && (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->d_inner % e->group_wgrad == 0 &&
+    e->deferred = e->overlap_wgrad && (e->group_wgrad == 64 || e->group_wgrad == 128 || e->group_wgrad == 256) && cfg->d_inner % e->group_wgrad == 0 &&
                   cfg->d_model % e->group_wgrad == 0;
     e->c = *cfg;
     if (const char* v = getenv("MB_DETERMINISTIC")) e->deterministic = atoi(v);
@@ -234,7 +235,7 @@ int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out) {
     if (e->lo[0].k - e->lo[0].q != (size_t)cfg->d_model * cfg->d_model || e->lo[0].v - e->lo[0].k != e->lo[0].k - e->lo[0].q) e->fuse_qkv = false;
     if (const char* v = getenv("MB_ADAMW_KEEP")) e->keep_enable = atoi(v);
     // lazy zeroing (engine_common.h): the seven GEMM weights of every layer, stored by the grouped launches of a pass that may overwrite
-    e->ow_covers = (e->group_wgrad == 64 || e->group_wgrad == 128) && cfg->d_inner % e->group_wgrad == 0 && cfg->d_model % e->group_wgrad == 0;
+    e->ow_covers = (e->group_wgrad == 64 || e->group_wgrad == 128 || e->group_wgrad == 256) && cfg->d_inner % e->group_wgrad == 0 && cfg->d_model % e->group_wgrad == 0;
     e->stale_begin = e->lo[0].q; e->stale_end = e->wsum;
     *out = e;
     return MB_OK;
@@ -449,7 +450,9 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                               wgrad_args(H, H, Rk - Rk1, ws + e->ws_pos + (size_t)Rk1 * H * es, H, dkr + (size_t)Rk1 * H * es, H,
                                          (float*)(ws + e->ws_rhalf), H)};                       // ... rows [Rk1, Rk) -> scratch
             const int nwg = Rk1 < Rk ? 8 : 7;
-            const bool grouped = e->group_wgrad > 0 && gemm_grouped_tn_ok(dt, wg, nwg, e->group_wgrad);
+            int wtile = e->group_wgrad;
+            if (wtile == 256 && !gemm_grouped_tn_ok(dt, wg, nwg, 256)) wtile = 128;      // (a short k range in the group: the 128 x 128 kernel)
+            const bool grouped = wtile > 0 && gemm_grouped_tn_ok(dt, wg, nwg, wtile);
             if (grouped) {
                 for (GemmArgs& a : wg) a.overwrite = e->ow_pass ? 1 : 0;
                 wg[7].overwrite = 1;
@@ -497,12 +500,12 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                 }
                 CK((int)hipEventRecord(e->evs[2 * l], st));                       // every dY of the layer is final on `st`
                 CK((int)hipStreamWaitEvent(e->side, e->evs[2 * l], 0));
-                CK(gemm_grouped_tn_launch(dt, wg, nwg, e->group_wgrad, e->side));
+                CK(gemm_grouped_tn_launch(dt, wg, nwg, wtile, e->side));
                 if (nwg == 8) CK(add_f32(G + o.r, (const float*)(ws + e->ws_rhalf), (size_t)H * H, e->side));
                 CK((int)hipEventRecord(e->evs[2 * l + 1], e->side));              // "weight gradients of layer l are final"
             } else if (grouped) {
                 CK(e->prof_mark(2 * l, st));
-                CK(gemm_grouped_tn_launch(dt, wg, nwg, e->group_wgrad, st));
+                CK(gemm_grouped_tn_launch(dt, wg, nwg, wtile, st));
                 CK(e->prof_mark(2 * l + 1, st));
                 if (nwg == 8) CK(add_f32(G + o.r, (const float*)(ws + e->ws_rhalf), (size_t)H * H, st));
             } else {

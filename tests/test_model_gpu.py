@@ -619,6 +619,24 @@ def test_adamw_inside_the_weight_gradient_epilogue_changes_nothing(cdt, monkeypa
     assert float(fused["g"].abs().max()) == 0.0 and fused["stats"] == ref["stats"]
 
 
+@pytest.mark.parametrize("cdt,tile", [(torch.float32, 128), (torch.bfloat16, 128), (torch.bfloat16, 256)])
+def test_adamw_riding_in_the_weight_gradient_launches_changes_nothing(cdt, tile, monkeypatch):
+    """MB_ADAMW_RIDE=1 (csrc/kernels.h AdamRide): the grouped weight-gradient launch of layer l carries the HF-AdamW update of layer
+    l+1's GEMM weights as extra workgroups (the CUs / slots its tiles leave empty) and the optimizer sweep at the end skips those
+    layers.  Same arithmetic per element, so in deterministic mode four steps (dropout on, schedule moving, two shapes = two captured
+    graphs) end with the SAME BITS in the parameters, both Adam moments, the bf16 shadow and the logits; the gradient buffer reads as
+    zeros afterwards.  tile 256 = the eight-wave ping-pong tile (csrc/gemm_pp.hip), whose launch leaves 40 CUs to the riders."""
+    monkeypatch.setenv("MB_DETERMINISTIC", "1")
+    monkeypatch.setenv("MB_GROUP_WGRAD", str(tile))
+    monkeypatch.setenv("MB_ADAMW_RIDE", "0")
+    ref = _trajectory(cdt, True)
+    monkeypatch.setenv("MB_ADAMW_RIDE", "1")
+    ride = _trajectory(cdt, True)
+    for k in ("p", "m", "v", "shadow", "logits"):
+        assert torch.equal(ride[k], ref[k]), "%s differs with the update riding in the weight-gradient launches" % k
+    assert float(ride["g"].abs().max()) == 0.0 and ride["stats"] == ref["stats"]
+
+
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 def test_step_graph_equals_launch_by_launch(cdt, monkeypatch):
     """mb_bert_train_step: the replayed whole-step hipGraph (dropout keys, lr and bias correction read from device memory,

@@ -31,13 +31,15 @@ static void* dev_rand(size_t n_bf16, uint32_t seed) {
 }
 
 int main(int argc, char** argv) {
-    int T = 2400, reps = 48, nset = 6, trace = 0, looptrace = 0;
+    int T = 2400, reps = 48, nset = 6, trace = 0, looptrace = 0, tile = 0, wtile = 128;
     std::string only;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i];
         if (k == "--T") T = atoi(argv[i + 1]); else if (k == "--reps") reps = atoi(argv[i + 1]);
         else if (k == "--nset") nset = atoi(argv[i + 1]); else if (k == "--only") only = argv[i + 1];
         else if (k == "--trace") trace = atoi(argv[i + 1]);
+        else if (k == "--tile") tile = atoi(argv[i + 1]);          // mb_gemm tile code for every case (0 = auto, 64 | 128 | 256)
+        else if (k == "--wtile") wtile = atoi(argv[i + 1]);        // grouped weight-gradient tile (64 | 128 | 256 = 256 x 128 ping-pong)
         else if (k == "--looptrace") { looptrace = atoi(argv[i + 1]); trace = trace || looptrace; }   // library built with -DMB_GEMM_LOOPTRACE
     }
     const int H = 768, I = 3072;
@@ -85,7 +87,33 @@ int main(int argc, char** argv) {
             if (!tr[(size_t)b * S]) continue;
             for (int k = 0; k < 5; ++k) ph[k].push_back((double)(tr[(size_t)b * S + k] - t00) * 0.01);
         }
-        if (looptrace) {
+        if (looptrace == 2) {
+            // gemm_pp.hip: waves 0 (group 0) and 4 (group 1), 10 k-stages x 6 stamps each
+            static const char* pn[6] = {"LOAD: issue reads", "LOAD: reads return (+g1: stage landed)", "barrier 1", "COMP: 32 MFMAs + DMA",
+                                        "COMP: stage landed (g0)", "barrier 2"};
+            constexpr int NP = 6, NI = 10;
+            for (int grp = 0; grp < 2; ++grp) {
+                std::vector<double> d[NP + 1];
+                for (int b = 0; b < nb; ++b) {
+                    if (!tr[(size_t)b * S]) continue;
+                    const unsigned long long* lt = &tr[(size_t)b * S + 8 + grp * NP * NI];
+                    for (int t = 0; t + 1 < NI; ++t) {
+                        if (!lt[(t + 1) * NP]) break;
+                        auto df = [&](int i1, int i0) { return (double)(uint32_t)((uint32_t)lt[i1] - (uint32_t)lt[i0]); };
+                        for (int k = 0; k < NP - 1; ++k) d[k].push_back(df(t * NP + k + 1, t * NP + k));
+                        d[NP - 1].push_back(df((t + 1) * NP, t * NP + NP - 1));
+                        d[NP].push_back(df((t + 1) * NP, t * NP));
+                    }
+                }
+                printf("    group %d: k-stage of wave %d, shader clocks (p10 / median / p90 / mean over %d samples)\n", grp, grp * 4, (int)d[0].size());
+                for (int k = 0; k <= NP; ++k) {
+                    if (d[k].empty()) continue;
+                    std::sort(d[k].begin(), d[k].end());
+                    double m = 0; for (double x : d[k]) m += x;
+                    printf("    %-40s %7.0f %7.0f %7.0f %7.0f\n", k < NP ? pn[k] : "whole stage", d[k][d[k].size() / 10], d[k][d[k].size() / 2], d[k][d[k].size() * 9 / 10], m / d[k].size());
+                }
+            }
+        } else if (looptrace) {
             // shader-clock stamps of wave 0, iterations 4 .. 22 of every block: where an iteration of the k loop goes
             static const char* pn[5] = {"wait for the stage (vmcnt)", "barrier", "DMA issue", "fragment reads + MFMA issue", "whole iteration"};
             std::vector<double> d[5];
@@ -124,7 +152,7 @@ int main(int argc, char** argv) {
             const int ldb = c.layout == NN ? c.N : c.K;
             (void)ldw;
             MCK(mb_gemm(MB_DT_BF16, c.layout, c.epi, c.M, c.N, c.K, sel(c.a, s), ld(c.a), W[c.b], ldb, out, c.N, oi2[s],
-                        c.epi == 4 ? colsum : nullptr, bias, c.r >= 0 ? sel(c.r, (s + 1) % nset) : nullptr, c.r >= 0 ? ld(c.r) : 0, 1.0f, &key, 1, 0, st));
+                        c.epi == 4 ? colsum : nullptr, bias, c.r >= 0 ? sel(c.r, (s + 1) % nset) : nullptr, c.r >= 0 ? ld(c.r) : 0, 1.0f, &key, 1, tile, st));
         };
         for (int i = 0; i < 4; ++i) launch(i);
         HCK(hipEventRecord(e0, st));
@@ -142,7 +170,7 @@ int main(int argc, char** argv) {
             const void* dY[4] = {xh[s], xi[s], xh[(s + 1) % nset], x3[s]};
             const void* X[4] = {xi[(s + 2) % nset], xh[(s + 2) % nset], xh[(s + 3) % nset], xh[(s + 4) % nset]};
             const int ldy[4] = {H, I, H, 3 * H}, ldx[4] = {I, H, H, H};
-            MCK(mb_gemm_grouped_wgrad(MB_DT_BF16, 4, gM, gN, Tp, dY, ldy, X, ldx, gW, gN, 128, st));
+            MCK(mb_gemm_grouped_wgrad(MB_DT_BF16, 4, gM, gN, Tp, dY, ldy, X, ldx, gW, gN, wtile, st));
         };
         for (int i = 0; i < 4; ++i) launch(i);
         HCK(hipEventRecord(e0, st));
