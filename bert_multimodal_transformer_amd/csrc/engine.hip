@@ -553,6 +553,25 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
     const int dt = c.dtype, H = c.hidden_size, I = c.intermediate_size, B = e->B, L = e->L, T = B * L, nh = c.num_heads;
     const int NL = c.num_layers;
     const int Tk = (int)align_up((size_t)T, 64);      // zero-padded reduction length of the wgrad GEMMs
+    // Riders (kernels.h AdamRide, enqueue_step): up to `budget` parameters from the TOP of what is final while layer l's backward runs --
+    // the GEMM weights of layers l+1 .. NL-1 minus what earlier launches of this backward took -- as `blocks` extra workgroups of a
+    // launch.  The sweep at the end of the step is then ONE range [0, ride_cursor) + the rest of the slabs.
+    auto take_ride = [&](int l, size_t budget, int blocks) -> AdamRide {
+        AdamRide r = {};
+        if (!e->ride_m || !e->ride_v || l + 1 >= e->c.num_layers || blocks < 8 || e->ride_cursor <= e->lo[l + 1].wqkv) return r;
+        size_t take = std::min(e->ride_cursor - e->lo[l + 1].wqkv, budget) / 1024 * 1024;
+        const size_t re = e->ride_cursor, rb = re - take;
+        const bool sh_ok = e->c.dtype != DT_BF16 || (e->sh_begin <= rb && re <= e->sh_end);
+        if (take == 0 || rb % 4 || !sh_ok) return r;
+        const bool keep = e->keep_in_step() && e->stale_begin <= rb && re <= e->stale_end;
+        r = AdamRide{e->P + rb, e->G + rb, e->ride_m + rb, e->ride_v + rb, e->c.dtype == DT_BF16 ? (bf16*)(e->SH + rb * 2) : nullptr,
+                     take / 4, e->adam_state(e->ws), blocks / 8 * 8, keep ? 0 : 1};
+        e->ride_cursor = rb;
+        return r;
+    };
+    // (Riders in the LayerNorm-backward launches -- 150 latency-bound workgroups on 256 CUs, 24 launches per step -- were built and
+    //  measured: no gain at any budget, +0.09 ms when they replace the weight-gradient riders: profiles/r06_adamw_ride_ln.txt.  What
+    //  pays is a CU that has NOTHING else to do for tens of microseconds.)
     if (stage_begin < 0) stage_begin = 0;
     if (stage_end > NL + 2) stage_end = NL + 2;
     if (stage_begin == 0) CK(e->begin_backward_pass(e->G, st));
@@ -677,32 +696,17 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                 CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, 3 * H, dqkv, 3 * H, e->W(o.wqkv), H, dx, H, nullptr, nullptr,
                         nullptr, dsB, H, kNoDrop, 1, 0, st));
             }
-            // riders: an optimizer update in the empty slots of this launch -- up to ride_params parameters from the TOP of what is
-            // final by now (the GEMM weights of layers l+1 .. NL-1, minus what earlier launches of this backward took): the sweep at the end
-            // of the step is then ONE range [0, ride_cursor) + the rest of the slabs
+            // riders: an optimizer update in the empty slots of this launch (take_ride, below the loop header)
             AdamRide ride = {};
-            if (inl && !fuse && e->ride_m && e->ride_v && l + 1 < NL && e->ride_cursor > e->lo[l + 1].wqkv) {
-                const size_t avail = e->ride_cursor - e->lo[l + 1].wqkv;
+            if (inl && !fuse) {
+                int tiles = 0;
+                const int bm = wtile == 256 ? 256 : wtile, bn = wtile == 256 ? 128 : wtile;
+                for (const GemmArgs& a : wg) tiles += (a.M / bm) * (a.N / bn);
+                const int slots = e->cu_count() * (wtile == 256 ? 1 : wtile == 128 ? 2 : 0);
                 // what 40 CUs stream while the tiles multiply (~41 GB/s per CU; same-box sweeps in profiles/r06_adamw_ride_budget.txt,
                 // r06_adamw_ride_ab.txt: 2.5 M parameters at T = 2400, 3.5 M at T = 4096; more stretches the launch)
                 const size_t budget = e->ride_params > 0 ? (size_t)e->ride_params : std::min((size_t)1000 * (size_t)Tk, (size_t)1100000 + (size_t)590 * (size_t)Tk);
-                size_t take = std::min(avail, budget);
-                take = take / 1024 * 1024;
-                const size_t re = e->ride_cursor, rb = re - take;
-                const bool sh_ok = dt != DT_BF16 || (e->sh_begin <= rb && re <= e->sh_end);
-                if (take > 0 && rb % 4 == 0 && sh_ok) {
-                    int tiles = 0;
-                    const int bm = wtile == 256 ? 256 : wtile, bn = wtile == 256 ? 128 : wtile;
-                    for (const GemmArgs& a : wg) tiles += (a.M / bm) * (a.N / bn);
-                    const int slots = e->cu_count() * (wtile == 256 ? 1 : wtile == 128 ? 2 : 0);
-                    int blocks = e->ride_blocks > 0 ? e->ride_blocks : (slots - tiles) / 8 * 8;
-                    if (blocks >= 8) {
-                        const bool keep = e->keep_in_step() && e->stale_begin <= rb && re <= e->stale_end;
-                        ride = AdamRide{e->P + rb, e->G + rb, e->ride_m + rb, e->ride_v + rb, dt == DT_BF16 ? (bf16*)(e->SH + rb * 2) : nullptr,
-                                        take / 4, e->adam_state(ws), blocks, keep ? 0 : 1};
-                        e->ride_cursor = rb;
-                    }
-                }
+                ride = take_ride(l, budget, e->ride_blocks > 0 ? e->ride_blocks : (slots - tiles) / 8 * 8);
             }
             auto launch_group = [&]() -> int {
                 if (inl) {
