@@ -890,15 +890,17 @@ class _FusedStep(object):
         replayed hipGraph (the step is a single-stream kernel sequence: replay costs ~12 us of host time and runs as fast as the
         stream launches).  Under data parallel (optimizer._dp set by distributed.DataParallel) the same call becomes
         mb_*_train_step_dp: a chain of linear graphs with the gradient exchange issued from C between them (distributed.Comm).
+        Gradient-accumulation micro-steps of a data-parallel rank (optimizer=None between two synchronising steps) are the plain
+        single call without exchange and optimizer; the step that ends the window exchanges the accumulated gradients.
         graph="launches" (or MB_STEP_GRAPH=0) keeps the single call but launches the kernels one by one.  Otherwise (foreign
-        optimizers, gradient accumulation under data parallel, MB_DP_ENGINE=0) the passes are driven from here: training_step +
-        optimizer.step(); graph=False forces that path, graph=True raises if the single call is unavailable.
+        optimizers, MB_DP_ENGINE=0) the passes are driven from here: training_step + optimizer.step(); graph=False forces that
+        path, graph=True raises if the single call is unavailable.
         Pass optimizer=None on gradient-accumulation micro-steps.  Returns the device loss scalar."""
         core = self._core
         dp = getattr(optimizer, "_dp", None) if optimizer is not None else None
         mdp = getattr(self, "_dp", None)
         if optimizer is None and mdp is not None and not mdp.sync and mdp.micro_ready() and graph is not False and \
-                os.environ.get("MB_OVERLAP_WGRAD", "0") in ("", "0"):
+                core.kind in ("bert", "xlnet") and os.environ.get("MB_OVERLAP_WGRAD", "0") in ("", "0"):
             # gradient-accumulation micro-step of a data-parallel rank (multimodal_driver.py:375-376, 383): nothing is exchanged, so it is the
             # plain single call without the optimizer (the backward accumulates); the exchange of the step that ends the window
             # moves the word-embedding table densely (distributed.DataParallel._micro_since_sync)

@@ -213,7 +213,11 @@ static int fork_to_comm(mb_comm* c, int seg, hipStream_t st) {
     hipEvent_t ev = c->fork_ev[(size_t)seg % c->fork_ev.size()];
     if (c->event_mode < 2) CK((int)hipEventRecord(ev, st));      // (modes 2, 3: recorded by the segment itself, dp_segment_end)
     static int dbg = -1;
-    if (dbg < 0) { const char* v = getenv("MB_DP_DEBUG"); dbg = v ? atoi(v) : 0; }
+    if (dbg < 0) {
+        const char* v = getenv("MB_DP_DEBUG"); dbg = v ? atoi(v) : 0;
+        if (dbg == 4) fprintf(stderr, "[magbert] WARNING: MB_DP_DEBUG=4 is a test switch -- the gradient exchange is NOT ordered behind the backward; "
+                                      "training results are wrong by design\n");
+    }
     if (dbg == 4) return MB_OK;          // NEGATIVE CONTROL of the equality tests: the hand-off is dropped, the exchange races the backward
     CK((int)hipStreamWaitEvent(c->cs, ev, 0));
     return MB_OK;
@@ -227,7 +231,11 @@ __global__ void dp_test_delay_kernel(long long ticks) {
 }
 static int test_delay_us() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("MB_DP_TEST_DELAY_US"); v = e ? atoi(e) : 0; if (v < 0) v = 0; }
+    if (v < 0) {
+        const char* e = getenv("MB_DP_TEST_DELAY_US"); v = e ? atoi(e) : 0; if (v < 0) v = 0;
+        if (v > 0) fprintf(stderr, "[magbert] WARNING: MB_DP_TEST_DELAY_US=%d is a test switch -- every backward segment of the data-parallel step "
+                                   "starts with a %d us spin kernel (baked into the captured graphs)\n", v, v);
+    }
     return v;
 }
 static bool is_capturing(hipStream_t st) {

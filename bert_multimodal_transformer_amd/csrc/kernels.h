@@ -274,6 +274,7 @@ int step_prologue(const PrologueArgs& a, hipStream_t st);
 struct ZeroRanges {
     uint32_t* p[MB_ZERO_MAX]; size_t ndw[MB_ZERO_MAX]; int n;
     void add(void* ptr, size_t bytes) { if (bytes && n < MB_ZERO_MAX) { p[n] = (uint32_t*)ptr; ndw[n] = bytes / 4; ++n; } }
+    bool full() const { return n >= MB_ZERO_MAX; }      // callers that collect an unbounded number of ranges flush (zero_fill_ranges) and reset at this point
 };
 int zero_fill(void* p, size_t bytes, hipStream_t st);
 int zero_fill_ranges(const ZeroRanges& z, hipStream_t st);

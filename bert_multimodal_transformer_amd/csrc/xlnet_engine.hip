@@ -639,6 +639,7 @@ static int xl_adamw_decay_range_dp(mb_xlnet_engine* e, const mb_comm* comm, cons
         CK(xl_adamw_decay_range(e, m, v, sl.mine_b, sl.mine_e, st));
         CK(xl_adamw_decay_range(e, m, v, sl.rem_b, sl.rem_e, st));
         if (!e->keep_in_step()) {
+            if (dead.n + 2 > MB_ZERO_MAX) { CK(zero_fill_ranges(dead, st)); dead = ZeroRanges{}; }       // (add() drops what does not fit)
             dead.add(e->G + c.first, (sl.mine_b - c.first) * 4);
             dead.add(e->G + sl.mine_e, (sl.rem_b - sl.mine_e) * 4);
         }

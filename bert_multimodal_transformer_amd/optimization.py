@@ -203,6 +203,10 @@ class AdamW(torch.optim.Optimizer):
         for item in self._plan:
             if item[0] == "flat" and all(item[2] is not c for c in cores):
                 cores.append(item[2])
+        # sharded optimizer update under data parallel (MB_DP_SHARD_OPT=1): a rank's moments outside its own slices are stale until
+        # gathered.  COLLECTIVE in that mode -- every rank must call state_dict() ("Checkpoints under data parallel").
+        for c in cores:
+            c.refresh_sharded_state(adam=True)
         sd["magbert"] = {"t": self._t,
                          "flat": [{"exp_avg": c._adam_m.detach().cpu(), "exp_avg_sq": c._adam_v.detach().cpu()} for c in cores]}
         return sd
