@@ -112,8 +112,11 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
 }
 
 // =============================================================================================== backward
+#ifndef MB_ATTN_BWD_OCC
+#define MB_ATTN_BWD_OCC 1          // waves per SIMD the eight-wave (L > 64) instantiation is compiled for (A/B builds: 4 = two workgroups per CU)
+#endif
 template <class T, int LP, int NW>
-__global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : 1) attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
+__global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : MB_ATTN_BWD_OCC) attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                            const T* __restrict__ dctx, T* __restrict__ dqkv,
                                                            float* __restrict__ dbias,
                                                            const float* __restrict__ head_scale, int L, int nh, DropKey drop,
@@ -130,7 +133,15 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : 1) attn_b
     constexpr int DSL = 64 / C::SLAB;
     constexpr int LSL = LP / C::SLAB;
     // four [row][d] images + the row vectors; the three column-sum tiles of the final flush reuse the Q image (dead by then)
-    __shared__ __attribute__((aligned(16))) char smem[4 * LP * PIT + 4 * LP * 4];
+    // ONE (L = 128, eight waves: every wave owns exactly one strip per sweep): the column sums of its dQ / dK / dV tiles (the fused QKV
+    // bias gradient) go to LDS as soon as the tile exists instead of living in 48 accumulator registers until the end, and sweep B
+    // walks the queries in two chunks (below): 222 -> 148 registers, 31.8 -> 30.4 us per launch at B = 32.  Capped at 128 registers
+    // (-DMB_ATTN_BWD_OCC=4: two workgroups per CU, ONE round for the 384 workgroups of B = 32, 20 registers spilled) it is 29.7 us --
+    // the launch was never two rounds of a fast kernel, two co-resident workgroups take twice as long each
+    // (profiles/r06_attn_bwd128_ab.txt).  L <= 64 keeps the register accumulators (13.5 vs 13.8 us).
+    constexpr bool ONE = (NT == NW) && LP > 64;
+    constexpr int CSW = ONE ? 3 * NW * 64 * 4 : 0;
+    __shared__ __attribute__((aligned(16))) char smem[4 * LP * PIT + 4 * LP * 4 + CSW];
     static_assert(LP * PIT >= 3 * NW * 64 * 4, "the Q image holds the three column-sum tiles of the flush");
     char* Qi = smem;
     char* Ki = smem + LP * PIT;
@@ -143,6 +154,15 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : 1) attn_b
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    float* csw1 = (float*)(smem + 4 * LP * PIT + 4 * LP * 4);      // ONE: [3][NW][64] column sums, written per tile
+    // column sums of one 16 x 64 output tile of this wave (rows >= L already zeroed by the caller) -> its slot of csw1
+    auto colsum_tile = [&](int which, int dt, const f32x4& o) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sred = row16_sum_to_lane15(o[r]);
+            if ((lane & 15) == 15) csw1[(which * NW + wave) * 64 + dt * 16 + (lane >> 4) * 4 + r] = sred;
+        }
+    };
     const int H = nh * 64;
     const size_t ld = (size_t)3 * H;
     const T* base = qkv + (size_t)b * L * ld + h * 64;
@@ -197,8 +217,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : 1) attn_b
     // (profiles/r02_attention_phases.txt).
     auto flush_all = [&]() {                 // called by every thread of the block (uniform)
         if (dbias == nullptr) return;
-        __syncthreads();                     // every wave is done with the Q image
-        float* csw = (float*)Qi;             // [3][NW][64]
+        __syncthreads();                     // every wave is done with the Q image (ONE: has written its column sums)
+        float* csw = ONE ? csw1 : (float*)Qi;             // [3][NW][64]
+        if constexpr (!ONE)
 #pragma unroll
         for (int which = 0; which < 3; ++which) {
             f32x4 (&c4)[4] = which == 0 ? cq : which == 1 ? ck : cv;
@@ -211,7 +232,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : 1) attn_b
                 }
         }
         stamp(6);
-        __syncthreads();
+        if constexpr (!ONE) __syncthreads();
         for (int j = threadIdx.x; j < 192; j += NW * 64) {
             const int which = j >> 6, col = j & 63;
             float t = 0.f;
@@ -244,6 +265,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : 1) attn_b
                 mma16(dp[jt], frag_nat<T>(Vi, PIT, jt * 16 + (lane & 15), sl, lane),
                       frag_nat<T>(Oi, PIT, strip * 16 + (lane & 15), sl, lane));
             }
+            // (L = 128: left alone the scheduler hoists the fragment loads of all eight tiles to the top -- 210 registers; fenced, the
+            //  sweep lives in 128 = two workgroups per CU)
+            if constexpr (LP > 64 && MB_ATTN_BWD_OCC > 1) __builtin_amdgcn_sched_barrier(0);
         }
         float mx = -3.0e38f;
 #pragma unroll
@@ -284,7 +308,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : 1) attn_b
                 mma16(o, AO::kmaj(Ki, PIT, sl, dt * 16 + (lane & 15), lane), AO::make(&sp[sl * AO::TILES]));
             o = o * hs;
             if (i < L) store4(dq_base + (size_t)i * ld + dt * 16 + (lane >> 4) * 4, o);
-            if (i < L) cq[dt] += o;
+            if constexpr (ONE) { if (dbias) colsum_tile(0, dt, i < L ? o : f32x4{0.f, 0.f, 0.f, 0.f}); }
+            else if (i < L) cq[dt] += o;
         }
     }
     __syncthreads();          // the row statistics of every strip are in LDS
@@ -292,55 +317,73 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : 1) attn_b
     stamp(3);
 
     // ------------------------------------------------------------------ sweep B: key strips -> dV, dK
+    // The queries are swept in chunks of CHT 16-row tiles: dV and dK are sums over the queries, accumulated tile by tile in the same
+    // order either way (same bits), but at L = 128 only 4 of the 8 tiles of S^T / dP^T are alive at a time -- 32 registers instead of 64.
+    constexpr int CHT = (LP > 64 && ONE) ? 4 : NT;            // query tiles per chunk
+    constexpr int NCH = NT / CHT, CSL = CHT / AO::TILES;      // chunks, k-slabs (along the queries) per chunk
+    static_assert(NT % CHT == 0 && CHT % AO::TILES == 0, "whole chunks of whole slabs");
 #pragma unroll 1
     for (int strip = wave; strip < NT; strip += NW) {
-        f32x4 sp[NT], dp[NT];
         const int j = strip * 16 + (lane & 15);          // this lane's key
-#pragma unroll
-        for (int it = 0; it < NT; ++it) {
-            sp[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dp[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int sl = 0; sl < DSL; ++sl) {
-                mma16(sp[it], frag_nat<T>(Qi, PIT, it * 16 + (lane & 15), sl, lane),
-                      frag_nat<T>(Ki, PIT, strip * 16 + (lane & 15), sl, lane));
-                mma16(dp[it], frag_nat<T>(Oi, PIT, it * 16 + (lane & 15), sl, lane),
-                      frag_nat<T>(Vi, PIT, strip * 16 + (lane & 15), sl, lane));
-            }
-        }
-        // sp[it][r] = S[i][j] (pre-scale), dp[it][r] = (dO V^T)[i][j],  i = it*16 + (lane>>4)*4 + r
         const float mbj = mbias[j];
+        f32x4 ov[4], okk[4];
 #pragma unroll
-        for (int it = 0; it < NT; ++it) {
-            const int i0 = it * 16 + (lane >> 4) * 4;
+        for (int dt = 0; dt < 4; ++dt) ov[dt] = okk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + r;
-                const float p = __expf(sp[it][r] * scale + mbj - rmax[i]) * rinv[i];
-                const float dm = drop_mult(drop, ((uint32_t)blockIdx.x * L + (uint32_t)i) * L + (uint32_t)j);
-                sp[it][r] = p * (dp[it][r] * dm - rD[i]) * scale;      // dS^T       -> dK
-                dp[it][r] = p * dm;                                    // dropped P^T -> dV
+        for (int ch = 0; ch < NCH; ++ch) {
+            f32x4 sp[CHT], dp[CHT];
+#pragma unroll
+            for (int il = 0; il < CHT; ++il) {
+                const int it = ch * CHT + il;
+                sp[il] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[il] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < DSL; ++sl) {
+                    mma16(sp[il], frag_nat<T>(Qi, PIT, it * 16 + (lane & 15), sl, lane),
+                          frag_nat<T>(Ki, PIT, strip * 16 + (lane & 15), sl, lane));
+                    mma16(dp[il], frag_nat<T>(Oi, PIT, it * 16 + (lane & 15), sl, lane),
+                          frag_nat<T>(Vi, PIT, strip * 16 + (lane & 15), sl, lane));
+                }
             }
+            // sp[il][r] = S[i][j] (pre-scale), dp[il][r] = (dO V^T)[i][j],  i = it*16 + (lane>>4)*4 + r
+#pragma unroll
+            for (int il = 0; il < CHT; ++il) {
+                const int i0 = (ch * CHT + il) * 16 + (lane >> 4) * 4;
+                const f32x4 rm4 = *(const f32x4*)(rmax + i0), ri4 = *(const f32x4*)(rinv + i0), rd4 = *(const f32x4*)(rD + i0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + r;
+                    const float p = __expf(sp[il][r] * scale + mbj - rm4[r]) * ri4[r];
+                    const float dm = drop_mult(drop, ((uint32_t)blockIdx.x * L + (uint32_t)i) * L + (uint32_t)j);
+                    sp[il][r] = p * (dp[il][r] * dm - rd4[r]) * scale;     // dS^T       -> dK
+                    dp[il][r] = p * dm;                                    // dropped P^T -> dV
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int sl = 0; sl < CSL; ++sl)
+                    mma16(ov[dt], AO::kmaj(Oi, PIT, ch * CSL + sl, dt * 16 + (lane & 15), lane), AO::make(&dp[sl * AO::TILES]));
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int sl = 0; sl < CSL; ++sl)
+                    mma16(okk[dt], AO::kmaj(Qi, PIT, ch * CSL + sl, dt * 16 + (lane & 15), lane), AO::make(&sp[sl * AO::TILES]));
+            if constexpr (NCH > 1) __builtin_amdgcn_sched_barrier(0);          // (one chunk's tiles alive at a time)
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int sl = 0; sl < LSL; ++sl)
-                mma16(o, AO::kmaj(Oi, PIT, sl, dt * 16 + (lane & 15), lane), AO::make(&dp[sl * AO::TILES]));
-            o = o * hs;
+            const f32x4 o = ov[dt] * hs;
             if (j < L) store4(dq_base + (size_t)j * ld + 2 * H + dt * 16 + (lane >> 4) * 4, o);
-            if (j < L) cv[dt] += o;
+            if constexpr (ONE) { if (dbias) colsum_tile(2, dt, j < L ? o : f32x4{0.f, 0.f, 0.f, 0.f}); }
+            else if (j < L) cv[dt] += o;
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int sl = 0; sl < LSL; ++sl)
-                mma16(o, AO::kmaj(Qi, PIT, sl, dt * 16 + (lane & 15), lane), AO::make(&sp[sl * AO::TILES]));
-            o = o * hs;
+            const f32x4 o = okk[dt] * hs;
             if (j < L) store4(dq_base + (size_t)j * ld + H + dt * 16 + (lane >> 4) * 4, o);
-            if (j < L) ck[dt] += o;
+            if constexpr (ONE) { if (dbias) colsum_tile(1, dt, j < L ? o : f32x4{0.f, 0.f, 0.f, 0.f}); }
+            else if (j < L) ck[dt] += o;
         }
     }
     stamp(4);
@@ -415,9 +458,8 @@ int attention_backward(int dtype, const void* qkv, const int64_t* mask, const vo
             case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
             case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
             case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
-            // 8 waves: all eight strips of a sweep at once, one block per CU (222 VGPRs, 76 KB of LDS).  Four waves with two strips each
-            // (two blocks per CU, one round for the 384 blocks of B = 32) need 487 VGPRs, 217 of them spilled when capped at 256: not built; this kernel capped at 128 VGPRs
-            // (two 8-wave blocks per CU, 118 registers spilled): 45 us against 36 us (scripts/exp/r3/attn128.sh).
+            // 8 waves: all eight strips of a sweep at once, one block per CU (148 VGPRs since round 6, 82 KB of LDS; see ONE in the kernel).
+            // Four waves with two strips each need 487 VGPRs, 217 of them spilled when capped at 256: not built.
             default: return launch_bwd<bf16, 128, 8>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
         }
     } else if (dtype == DT_F32) {
