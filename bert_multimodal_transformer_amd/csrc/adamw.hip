@@ -99,6 +99,12 @@ __global__ void adamw_tail_kernel(float* p, float* g, float* m, float* v, size_t
 int adamw_step(float* p, float* g, float* m, float* v, void* shadow, size_t n, size_t n_decay, size_t sh_begin,
                size_t sh_end, AdamArgs a, int zero_grad, hipStream_t st, const AdamArgs* dyn, size_t keep_begin, size_t keep_end) {
     if (n == 0) return MB_OK;
+    {   // MB_GEMM_LOG=1 (bench.py's in-run trace): how many parameters this sweep launch covers -- with riders (kernels.h AdamRide) the sweep at
+        // the end of a step is no longer "all of them"
+        static int log = -1;
+        if (log < 0) { const char* e = getenv("MB_GEMM_LOG"); log = e ? atoi(e) : 0; }
+        if (log) fprintf(stderr, "[magbert adamw] n=%zu\n", n);
+    }
     if ((n_decay % 4 && n_decay < n) || (sh_begin % 4) || (sh_end % 4) || (keep_begin % 4) || (keep_end % 4)) return MB_ERR_SHAPE;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return MB_ERR_SHAPE;
     const size_t n4 = n / 4;

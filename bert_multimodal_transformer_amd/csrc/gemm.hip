@@ -584,6 +584,11 @@ void gemm_log(const void* fn, hipStream_t st, const GemmArgs* p, int count) {
     fprintf(stderr, "[magbert gemm] %s problems=%d flop=%.0f M=%d N=%d K=%d\n", name ? name : "?", count, fl, p[0].M, p[0].N, p[0].K);
 }
 
+void gemm_log_ride(const AdamRide& r) {
+    if (g_gemm_log < 0) g_gemm_log = env_int("MB_GEMM_LOG", 0);
+    if (g_gemm_log && r.blocks > 0) fprintf(stderr, "[magbert ride] params=%zu blocks=%d\n", r.n4 * 4, r.blocks);
+}
+
 static unsigned long long* g_trace = nullptr;       // MB_GEMM_TRACE=1: device buffer of phase stamps, [kTraceBlocks][8]
 static int g_trace_on = -1, g_trace_blocks = 0;
 constexpr int kTraceBlocks = 8192 * 8 / kTraceStride;
@@ -814,6 +819,7 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st, int 
         static int g_big = -1;           // MB_GROUP_BIG: 1 = one wave per SIMD (4 waves, 128 x 64 wave tiles), 2 = 8-wave ping-pong (gemm_pp.hip)
         if (g_big < 0) g_big = env_int("MB_GROUP_BIG", 2);
         if (g_big == 2) return gemm_pp_grouped_launch(ga, grid, st);
+        gemm_log_ride(ga.ride);
         MB_GEMM_LAUNCH((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128>), dim3(grid + ga.ride.blocks), dim3(256), st, ga, ga.g, count);
         return (int)hipGetLastError();
     } else {
@@ -842,6 +848,7 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st, int 
     } else {
         MB_GEMM_LAUNCH((gemm2_grouped_tn_kernel<T, BM, BN, 2, 128>), dim3(grid + ga.ride.blocks), dim3(256), st, ga, ga.g, count);
     }
+    gemm_log_ride(ga.ride);
     return (int)hipGetLastError();
     }
 }

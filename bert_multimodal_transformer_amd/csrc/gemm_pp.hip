@@ -295,6 +295,7 @@ int gemm_pp_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hip
 
 int gemm_pp_grouped_launch(const GroupedGemmArgs& ga, int grid, hipStream_t st) {
     MB_GEMM_LAUNCH(gemm_pp_grouped_tn_kernel, dim3(grid + ga.ride.blocks), dim3(512), st, ga, ga.g, ga.count);
+    gemm_log_ride(ga.ride);
     return (int)hipGetLastError();
 }
 

@@ -543,6 +543,7 @@ struct Gemm2Smem { static constexpr int STAGE = (BM + BN) * KB;
 // host helpers defined in gemm.hip
 int gemm_env_int(const char* name, int dflt);
 void gemm_log(const void* fn, hipStream_t st, const GemmArgs* p, int count);
+void gemm_log_ride(const AdamRide& r);                                  // MB_GEMM_LOG=1: the optimizer update a grouped launch carried
 unsigned long long* gemm_trace_buffer(int blocks, hipStream_t st);     // null unless MB_GEMM_TRACE=1
 int gemm_dbg_flags();                                                   // MB_GEMM_DBG
 // 8-wave ping-pong kernels (gemm_pp.hip), bf16, 256 x 128 tiles.  MB_ERR_MODE: that (layout, epilogue) pair is not instantiated.

@@ -49,7 +49,7 @@ struct mb_xlnet_engine : StepMixin {
     float* P = nullptr; float* G = nullptr; char* SH = nullptr; char* ws = nullptr;
     const int64_t* ids = nullptr; const int64_t* seg = nullptr; const int64_t* mask = nullptr;
     int B = 0, L = 0, training = 0, padT = -1;
-    int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped weight-gradient launch (64 | 128), 0 = one by one
+    int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped weight-gradient launch (64 | 128 | 256 = 256 x 128 ping-pong), 0 = one by one
     // MB_OVERLAP_WGRAD=1: the grouped launch of layer l runs on an internal side stream under the dgrad chain of layer l-1 (round-1
     // default; measured equal to the in-line launch on the MAG-BERT engine, which keeps the step one in-order, graph-friendly sequence)
     int overlap_wgrad = 0;

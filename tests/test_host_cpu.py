@@ -487,7 +487,7 @@ def test_optimizer_shards_split_covers_every_element_once():
 
 
 def test_bench_prices_a_kernel_trace():
-    """bench.py's `roofline` comes from a kernel trace it takes itself (price_trace): steps are delimited by the two AdamW launches, every
+    """bench.py's `roofline` comes from a kernel trace it takes itself (price_trace): steps are delimited by the run of AdamW launches that ends each, every
     GEMM symbol is priced with the FLOPs the library logged for it (weight gradients: T, not the padded Tp), AdamW with 28 B/parameter."""
     import bench
     B, L, T, Tp = 48, 50, 2400, 2432
@@ -508,6 +508,22 @@ def test_bench_prices_a_kernel_trace():
     assert ad["bound"] == "hbm" and abs(ad["achieved"] - 14 * 110_853_121 / 250.0 * 1e-3) < 0.5
     assert doc["gemm_aggregate"]["gflop_per_step"] > 0 and not doc["replayed"]
     assert bench.price_trace(rows[:5], log, B, L, "bf16", 1, steps=3)[0] is None          # too short: a reason, not a crash
+    # riders (csrc/kernels.h AdamRide): part of the update runs inside the weight-gradient launches -- the sweep launches are priced with
+    # the parameters THEY cover (the library logs them), a step may end with three sweep launches instead of two
+    rows2, t = [], 0
+    for step in range(4):
+        for name, dur, n in ((gemm_a, 10_000, 3), (gemm_w, 40_000, 1), (adam, 100_000, 3)):
+            for _ in range(n):
+                rows2.append((t, t + dur, name)); t += dur + 500
+    log2 = log + "\n" + "\n".join(["[magbert ride] params=2500000 blocks=40", "[magbert adamw] n=50000000", "[magbert adamw] n=20000000", "[magbert adamw] n=10000000"])
+    doc2, roof2 = bench.price_trace(rows2, log2, B, L, "bf16", 110_853_121, steps=3)
+    ad2 = {r["kernel"][:20]: r for r in roof2}[adam[:20]]
+    assert doc2["kernels_per_step"] == 7.0 and ad2["launches_per_step"] == 3 and ad2["parameters_swept_per_step"] == 80_000_000
+    assert abs(ad2["achieved"] - 28 * 80_000_000 / 3 / 100.0 * 1e-3) < 0.5 and doc2["adamw_riders"]["parameters_per_launch"] == 2_500_000
+    top = bench.pick_roofline(doc2, roof2)
+    assert top["kernel"] and "dominant_by" in top
+    assert bench.kernel_base("_ZN2mb25gemm_pp_grouped_tn_kernelENS_15GroupedGemmArgsE") == bench.kernel_base("mb::gemm_pp_grouped_tn_kernel(mb::GroupedGemmArgs)")
+    assert bench.kernel_base("void mb::adamw_var_kernel<true, 2, true>(float*)") == "mb::adamw_var_kernel"
 
 
 def test_bench_refuses_to_run_fewer_ranks_than_asked(monkeypatch):

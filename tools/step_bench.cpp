@@ -4,7 +4,7 @@
 // HF-AdamW on one synthetic minibatch in prepare_bert_input's layout (/root/reference/multimodal_driver.py:143-180) -- from a
 // plain C++ process, so a GPU-box visit costs seconds instead of a Python/torch start-up, and rocprofv3 can wrap it.
 //
-//   step_bench [--steps K] [--warmup W] [--batch B] [--seq L] [--dtype bf16|fp32] [--visual V] [--layers N]
+//   step_bench [--model bert|xlnet] [--steps K] [--warmup W] [--batch B] [--seq L] [--dtype bf16|fp32] [--visual V] [--layers N]
 //              [--graph 0|1|2] [--h2d 0|1|2] [--nbatch n] [--dp 0|1] [--wire fp32|bf16] [--sparse 0|1] [--timing 0|1] [--shard 0|1]
 //   --dp 1:  the data-parallel step, mb_bert_train_step_dp, with a ONE-rank RCCL communicator created here through the C ABI
 //            (mb_comm_unique_id / mb_comm_create_rccl): the N > 1 code path -- graph chain, comm stream, events, ncclAllReduce /
@@ -36,7 +36,7 @@ struct Batch { int64_t *ids, *seg, *mask; float *vis, *aco, *lab; };
 
 int main(int argc, char** argv) {
     int steps = 30, warmup = 5, B = 48, L = 50, V = 47, A = 74, layers = 12, graph = 0, h2d = 0, nbatch = 4, dtype = MB_DT_BF16;
-    int dp = 0, wire = MB_DT_F32, sparse = 1, timing = 0, shard = 0;
+    int dp = 0, wire = MB_DT_F32, sparse = 1, timing = 0, shard = 0, xl = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i]; const char* v = argv[i + 1];
         if (k == "--steps") steps = atoi(v); else if (k == "--warmup") warmup = atoi(v); else if (k == "--batch") B = atoi(v);
@@ -45,6 +45,7 @@ int main(int argc, char** argv) {
         else if (k == "--dtype") dtype = strcmp(v, "fp32") == 0 ? MB_DT_F32 : MB_DT_BF16;
         else if (k == "--dp") dp = atoi(v); else if (k == "--sparse") sparse = atoi(v); else if (k == "--timing") timing = atoi(v);
         else if (k == "--shard") shard = atoi(v);
+        else if (k == "--model") xl = strcmp(v, "xlnet") == 0;       // MAG-XLNet (BASELINE.json configs[3]): the single-call step only (--graph 1|2)
         else if (k == "--wire") wire = strcmp(v, "bf16") == 0 ? MB_DT_BF16 : MB_DT_F32;
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 1; }
     }
@@ -54,9 +55,23 @@ int main(int argc, char** argv) {
     c.layer_norm_eps = 1e-12f; c.mag_layer_norm_eps = 1e-5f; c.beta_shift = 1.0f;
     c.hidden_dropout = 0.1f; c.attn_dropout = 0.1f; c.mag_dropout = 0.5f; c.dtype = dtype; c.max_batch = B; c.max_seq = L;
     mb_bert_engine* e = nullptr;
-    MCK(mb_bert_create(&c, &e));
-    const size_t n = mb_bert_param_count(e), nd = mb_bert_decay_count(e), wsb = mb_bert_workspace_bytes(e);
-    size_t shb, she; mb_bert_shadow_range(e, &shb, &she);
+    mb_xlnet_engine* ex = nullptr;
+    size_t n, nd, wsb, shb, she;
+    if (xl) {
+        if (!graph || dp) { fprintf(stderr, "--model xlnet: the single-call step only (--graph 1|2, no --dp)\n"); return 1; }
+        mb_xlnet_config xc = {};
+        xc.vocab_size = 32000; xc.d_model = 768; xc.n_layer = layers; xc.n_head = 12; xc.d_inner = 3072; xc.num_labels = 1;
+        xc.visual_dim = V; xc.acoustic_dim = A; xc.injection_index = 1;
+        xc.layer_norm_eps = 1e-12f; xc.mag_layer_norm_eps = 1e-5f; xc.beta_shift = 1.0f;
+        xc.dropout = 0.1f; xc.summary_last_dropout = 0.1f; xc.mag_dropout = 0.5f; xc.dtype = dtype; xc.max_batch = B; xc.max_seq = L;
+        MCK(mb_xlnet_create(&xc, &ex));
+        n = mb_xlnet_param_count(ex); nd = mb_xlnet_decay_count(ex); wsb = mb_xlnet_workspace_bytes(ex);
+        mb_xlnet_shadow_range(ex, &shb, &she);
+    } else {
+        MCK(mb_bert_create(&c, &e));
+        n = mb_bert_param_count(e); nd = mb_bert_decay_count(e); wsb = mb_bert_workspace_bytes(e);
+        mb_bert_shadow_range(e, &shb, &she);
+    }
     float *P, *G, *M, *Vv; void *SH, *WS;
     HCK(hipMalloc(&P, n * 4)); HCK(hipMalloc(&G, n * 4)); HCK(hipMalloc(&M, n * 4)); HCK(hipMalloc(&Vv, n * 4));
     HCK(hipMalloc(&SH, n * 2)); HCK(hipMalloc(&WS, wsb));
@@ -64,18 +79,20 @@ int main(int argc, char** argv) {
     {   // init law of the reference (N(0, 0.02), biases 0, LayerNorm 1/0)
         std::vector<float> h(n, 0.f);
         char name[160]; size_t off, numel; int nd_, dec; int64_t shp[4];
-        for (int i = 0; i < mb_bert_num_tensors(e); ++i) {
-            MCK(mb_bert_tensor_info(e, i, name, 160, &off, &numel, &nd_, shp, &dec));
+        const int ntens = xl ? mb_xlnet_num_tensors(ex) : mb_bert_num_tensors(e);
+        for (int i = 0; i < ntens; ++i) {
+            if (xl) MCK(mb_xlnet_tensor_info(ex, i, name, 160, &off, &numel, &nd_, shp, &dec));
+            else MCK(mb_bert_tensor_info(e, i, name, 160, &off, &numel, &nd_, shp, &dec));
             const std::string s = name;
-            const bool ln = s.find("LayerNorm") != std::string::npos;
+            const bool ln = s.find("LayerNorm") != std::string::npos || s.find("layer_norm") != std::string::npos;
             const bool bias = s.size() > 5 && s.compare(s.size() - 5, 5, ".bias") == 0;
             for (size_t j = 0; j < numel; ++j) h[off + j] = ln ? (bias ? 0.f : 1.f) : (bias ? 0.f : 0.02f * nrand());
         }
         HCK(hipMemcpy(P, h.data(), n * 4, hipMemcpyHostToDevice));
     }
-    MCK(mb_bert_bind(e, P, G, dtype == MB_DT_BF16 ? SH : nullptr, WS, wsb));
     hipStream_t st; HCK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    MCK(mb_bert_sync_weights(e, st));
+    if (xl) { MCK(mb_xlnet_bind(ex, P, G, dtype == MB_DT_BF16 ? SH : nullptr, WS, wsb)); MCK(mb_xlnet_sync_weights(ex, st)); }
+    else { MCK(mb_bert_bind(e, P, G, dtype == MB_DT_BF16 ? SH : nullptr, WS, wsb)); MCK(mb_bert_sync_weights(e, st)); }
 
     // synthetic batches (host pinned + device resident)
     const size_t T = (size_t)B * L;
@@ -131,6 +148,11 @@ int main(int argc, char** argv) {
                                       M, Vv, lr, b1, b2, eps, wd, t_opt, 1, 1.0f, 1.0f, graph, st, comm));
             return;
         }
+        if (xl) {
+            MCK(mb_xlnet_train_step(ex, b.ids, b.vis, b.aco, b.mask, b.seg, b.lab, B, L, 1234, (uint64_t)t_opt, logits, loss, loss + 1,
+                                    M, Vv, lr, b1, b2, eps, wd, t_opt, 1, 1.0f, 1.0f, graph, st));
+            return;
+        }
         if (graph) {
             MCK(mb_bert_train_step(e, b.ids, b.vis, b.aco, b.mask, b.seg, b.lab, B, L, 1234, (uint64_t)t_opt, logits, loss, loss + 1,
                                    M, Vv, lr, b1, b2, eps, wd, t_opt, 1, 1.0f, 1.0f, graph, st));
@@ -155,9 +177,9 @@ int main(int argc, char** argv) {
     float hl[2]; HCK(hipMemcpy(hl, loss, 8, hipMemcpyDeviceToHost));
     const double host_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / steps;
     const double wall_ms = std::chrono::duration<double, std::milli>(t2 - t0).count() / steps;
-    printf("step_bench dtype=%s B=%d L=%d V=%d layers=%d graph=%d h2d=%d : %.3f ms/step (events) %.3f ms/step (wall) host-enqueue %.3f ms/step "
+    printf("step_bench %sdtype=%s B=%d L=%d V=%d layers=%d graph=%d h2d=%d : %.3f ms/step (events) %.3f ms/step (wall) host-enqueue %.3f ms/step "
            "%.1f samples/s last-loss %.4f mean-loss %.4f\n",
-           dtype == MB_DT_BF16 ? "bf16" : "fp32", B, L, V, layers, graph, h2d, ms / steps, wall_ms, host_ms, B * 1e3 / (ms / steps), hl[0],
+           xl ? "model=xlnet " : "", dtype == MB_DT_BF16 ? "bf16" : "fp32", B, L, V, layers, graph, h2d, ms / steps, wall_ms, host_ms, B * 1e3 / (ms / steps), hl[0],
            hl[1] / (steps + warmup));
     if (comm) {
         float ex = 0.f; size_t pieces = 0, cbytes = 0;
@@ -166,6 +188,6 @@ int main(int argc, char** argv) {
                wire == MB_DT_BF16 ? "bf16" : "fp32", sparse, mb_comm_sharding(comm), pieces, cbytes * 1e-6, ex);
         mb_comm_destroy(comm);
     }
-    mb_bert_destroy(e);
+    if (xl) mb_xlnet_destroy(ex); else mb_bert_destroy(e);
     return 0;
 }
