@@ -140,10 +140,37 @@ int all_gather(mb_comm* c, void* buf, size_t bytes_per_rank, hipStream_t s) {
 
 namespace mb {
 
+// MB_DP_SYNTH_GBPS=r (measurement only, one-rank groups: profiles/r06_dp_chunks.txt): behind every all-reduce piece the comm stream runs a
+// copy of the piece onto itself by EIGHT workgroups, repeated until it has lasted bytes / r GB/s -- a stand-in for the time a ring
+// all-reduce spends on the xGMI links (8 GPUs, 7 links of ~153 GB/s: ~300 GB/s of algorithmic bandwidth), with the memory traffic of one,
+// so that the trade between seam cost (more, smaller pieces) and exposed tail (fewer, larger) shows on one GPU.  Results unchanged.
+__global__ void __launch_bounds__(256) dp_synth_load_kernel(float* g, size_t n4, long long ticks) {
+    const long long t0 = wall_clock64();           // 100 MHz
+    f32x4* p = (f32x4*)g;
+    do {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = p[i];
+    } while (wall_clock64() - t0 < ticks);
+}
+static int synth_gbps() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MB_DP_SYNTH_GBPS"); v = e ? atoi(e) : 0; if (v < 0) v = 0;
+        if (v > 0) fprintf(stderr, "[magbert] WARNING: MB_DP_SYNTH_GBPS=%d is a measurement switch -- every all-reduce piece is followed by a synthetic "
+                                   "load of bytes / %d GB/s on the comm stream\n", v, v);
+    }
+    return v;
+}
+
 int comm_all_reduce(mb_comm* c, float* g, size_t count, hipStream_t s) {
     if (!c || !g) return MB_ERR_ARG;
     if (count == 0) return MB_OK;
     ++c->pieces; c->bytes_reduced += count * (c->wire == DT_BF16 ? 2 : 4);
+    if (const int r = synth_gbps()) {
+        if (c->world == 1 && count % 4 == 0) {
+            const double us = (double)count * (c->wire == DT_BF16 ? 2.0 : 4.0) / ((double)r * 1e3);
+            hipLaunchKernelGGL(dp_synth_load_kernel, dim3(8), dim3(256), 0, s, g, count / 4, (long long)(us * 100.0));
+        }
+    }
     if (c->wire == DT_BF16) {
         // bf16 wire: every rank rounds its gradients once, the sum travels and is accumulated in bf16, moments and parameters stay
         // fp32.  Halves the bytes on the links (two GPUs share ONE xGMI link: the fp32 exchange lasts as long as the backward).
