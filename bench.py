@@ -178,7 +178,7 @@ def gemm_roofline(dtype_name, T, reps=30):
         ("dgrad ffn1 [T,3072]x[3072,768] +res", 1, NN, _lib.EPI_ADD_RES, T, H, I, xi, I, w1, H, x, 1),
         ("dgrad out  [T,768]x[768,768]", 1, NN, _lib.EPI_ADD_RES, T, H, H, x, H, w_o, H, None, 1),
         ("dgrad qkv  [T,2304]x[2304,768] +res", 1, NN, _lib.EPI_ADD_RES, T, H, 3 * H, dqkv, 3 * H, w_qkv, H, x, 1),
-        # the layer's four weight gradients are ONE grouped launch in the engine (csrc/gemm.hip gemm2_grouped_tn_kernel)
+        # the layer's four weight gradients are ONE grouped launch in the engine (csrc/gemm_pp.hip gemm_pp_grouped_tn_kernel: 256 x 128 ping-pong tiles)
         ("wgrad x4  grouped [768x3072|3072x768|768x768|2304x768] K=T", 1, "grouped", None, 0, 0, Tp, None, 0, None, 0, None, 1),
     ]
     gshape = [(H, I), (I, H), (H, H), (3 * H, H)]
@@ -187,7 +187,7 @@ def gemm_roofline(dtype_name, T, reps=30):
     ia = lambda v: (C.c_int * 4)(*v)
     pa = lambda ts: (C.c_void_p * 4)(*[t.data_ptr() for t in ts])
     gM, gN, gpY, gpX, gpW = ia([m for m, n in gshape]), ia([n for m, n in gshape]), pa(gY), pa(gX), pa(gW)
-    gtile = int(os.environ.get("MB_GROUP_WGRAD", "128")) or 128
+    gtile = int(os.environ.get("MB_GROUP_WGRAD", "256" if dtype_name == "bf16" else "128")) or 128       # the engine's default: csrc/engine.hip group_wgrad
     res = []
     for name, cnt, layout, epi, M, N, K, A, lda, Bm, ldb, R, splits in cases:
         def launch():
