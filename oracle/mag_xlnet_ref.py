@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE -- pure-torch fp32 CPU restatement of the MAG-XLNet hot path (BASELINE.json config 4).
 
 Restates MAG_XLNetModel.forward / MAG_XLNetForSequenceClassification.forward (xlnet.py:148-429, 443-527) for the only
-configuration the driver exercises (xlnet-base-cased: attn_type "bi", bi_data False, clamp_len -1, no target_mapping;
+configuration the driver exercises (xlnet-base-cased: attn_type "bi", bi_data False, clamp_len -1, target_mapping / the query stream since round 6;
 multimodal_driver.py:363-370; round 5: mems / mem_len, xlnet.py:81-91, 244-245, 276-293, 317-323, 363-365) and the transformers==3.0.2 XLNetLayer
 (XLNetRelativeAttention + XLNetFeedForward) and SequenceSummary it calls (xlnet.py:30,374-385,438,508).  Checked against
 the reference's own Python by oracle/make_golden.py (G6 fixtures).  Works in the reference's [L, B, .] layout internally.
@@ -35,7 +35,7 @@ class XLNetConfigLite(object):
 
 
 class XLNetRelativeAttention(nn.Module):
-    """3.0.2 XLNetRelativeAttention, single-stream branch (g is None)."""
+    """3.0.2 XLNetRelativeAttention: the content stream, and the query stream when `g` is given (two-stream attention)."""
 
     def __init__(self, c):
         super().__init__()
@@ -56,14 +56,8 @@ class XLNetRelativeAttention(nn.Module):
         x = x.reshape(s[0], s[1], s[2], s[3] - 1)
         return x[:, :, :, :klen]          # => bd[i, j] = raw[i, L - i + j]
 
-    def forward(self, h, attn_mask, r, seg_mat, head_mask=None, mems=None):
-        # 3.0.2 XLNetRelativeAttention.forward: keys and values over cat([mems, h]) (the cached hidden states of the previous
-        # segment, xlnet.py:374-385 passes mems[i]); queries over h only
-        cat = h if mems is None else torch.cat([mems, h], dim=0)
-        q = torch.einsum("ibh,hnd->ibnd", h, self.q)
-        k = torch.einsum("ibh,hnd->ibnd", cat, self.k)
-        v = torch.einsum("ibh,hnd->ibnd", cat, self.v)
-        kr = torch.einsum("ibh,hnd->ibnd", r, self.r)
+    def rel_attn_core(self, q, k, v, kr, seg_mat, attn_mask, head_mask):
+        """3.0.2 XLNetRelativeAttention.rel_attn_core: content + position + segment scores, mask, softmax, dropout, P.V"""
         ac = torch.einsum("ibnd,jbnd->bnij", q + self.r_w_bias, k)
         bd = self.rel_shift_bnij(torch.einsum("ibnd,jbnd->bnij", q + self.r_r_bias, kr), ac.shape[3])
         ef = torch.einsum("ibnd,snd->ibns", q + self.r_s_bias, self.seg_embed)
@@ -73,10 +67,30 @@ class XLNetRelativeAttention(nn.Module):
         p = self.dropout(F.softmax(score, dim=3))
         if head_mask is not None:           # xlnet.py:383 -> rel_attn_core: attn_prob = attn_prob * head_mask, after the dropout
             p = p * head_mask.view(1, -1, 1, 1)
+        return torch.einsum("bnij,jbnd->ibnd", p, v), p
+
+    def forward(self, h, attn_mask, r, seg_mat, head_mask=None, mems=None, g=None, attn_mask_g=None, target_mapping=None):
+        # 3.0.2 XLNetRelativeAttention.forward: keys and values over cat([mems, h]) (the cached hidden states of the previous
+        # segment, xlnet.py:374-385 passes mems[i]); queries over h only.  g (the query stream, xlnet.py:306-313, 374-385 with
+        # target_mapping [M, L, B]): queries from g, mapped onto the L positions, attend to the CONTENT stream's keys / values under
+        # attn_mask_g (no self-exemption), mapped back to the M prediction rows; same o projection and LayerNorm
+        cat = h if mems is None else torch.cat([mems, h], dim=0)
+        q = torch.einsum("ibh,hnd->ibnd", h, self.q)
+        k = torch.einsum("ibh,hnd->ibnd", cat, self.k)
+        v = torch.einsum("ibh,hnd->ibnd", cat, self.v)
+        kr = torch.einsum("ibh,hnd->ibnd", r, self.r)
+        vec, p = self.rel_attn_core(q, k, v, kr, seg_mat, attn_mask, head_mask)
         self.last_probs = p                 # what output_attentions returns (xlnet.py:387-427): [B, n_head, L, L], after the dropout
-        vec = torch.einsum("bnij,jbnd->ibnd", p, v)
         out = self.dropout(torch.einsum("ibnd,hnd->ibh", vec, self.o))
-        return self.layer_norm(out + h)
+        out_h = self.layer_norm(out + h)
+        if g is None:
+            return out_h
+        qg = torch.einsum("ibh,hnd->ibnd", g, self.q)
+        qg = torch.einsum("mbnd,mlb->lbnd", qg, target_mapping)
+        vec_g, _ = self.rel_attn_core(qg, k, v, kr, seg_mat, attn_mask_g, head_mask)
+        vec_g = torch.einsum("lbnd,mlb->mbnd", vec_g, target_mapping)
+        out_g = self.dropout(torch.einsum("ibnd,hnd->ibh", vec_g, self.o))
+        return out_h, self.layer_norm(out_g + g)
 
 
 class XLNetFeedForward(nn.Module):
@@ -99,8 +113,11 @@ class XLNetLayer(nn.Module):
         self.rel_attn = XLNetRelativeAttention(c)
         self.ff = XLNetFeedForward(c)
 
-    def forward(self, h, attn_mask, r, seg_mat, head_mask=None, mems=None):
-        return self.ff(self.rel_attn(h, attn_mask, r, seg_mat, head_mask, mems))
+    def forward(self, h, attn_mask, r, seg_mat, head_mask=None, mems=None, g=None, attn_mask_g=None, target_mapping=None):
+        if g is None:
+            return self.ff(self.rel_attn(h, attn_mask, r, seg_mat, head_mask, mems))
+        oh, og = self.rel_attn(h, attn_mask, r, seg_mat, head_mask, mems, g, attn_mask_g, target_mapping)
+        return self.ff(oh), self.ff(og)                                                 # 3.0.2 XLNetLayer: the same feed-forward on both streams
 
 
 class MAG_XLNetModel(nn.Module):
@@ -131,8 +148,10 @@ class MAG_XLNetModel(nn.Module):
         return new_mem.detach()
 
     def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask=None, inputs_embeds=None,
-                perm_mask=None, input_mask=None, mems=None, mem_len=None):
-        """mems: list of n_layer tensors [mlen, B, d] (the hidden states cached from the previous segment, xlnet.py:244-245,
+                perm_mask=None, input_mask=None, mems=None, mem_len=None, target_mapping=None):
+        """target_mapping: [B, M, L] (xlnet.py:238-240 permutes it to [M, L, B]) -> the query stream g runs next to h and the model
+        returns ITS last state, [B, M, d] (xlnet.py:306-313, 374-399);
+        mems: list of n_layer tensors [mlen, B, d] (the hidden states cached from the previous segment, xlnet.py:244-245,
         374-385) or None; mem_len: > 0 -> self.new_mems is set to the n_layer tensors cache_mem produces (xlnet.py:363-365,
         use_cache True)"""
         if head_mask is not None:            # xlnet.py:340-353: [n_head] -> every layer, [n_layer][n_head] as is
@@ -168,14 +187,22 @@ class MAG_XLNetModel(nn.Module):
             attn_mask = (data_mask[:, :, :, None] > 0).float()                          # xlnet.py:274-286 : [1 | L, klen, B, 1]
             eye = torch.eye(L) if mlen == 0 else torch.cat([torch.zeros(L, mlen), torch.eye(L)], dim=-1)      # xlnet.py:289-293
             non_tgt = ((attn_mask - eye[:, :, None, None]) > 0).float()                 # xlnet.py:288-296 : [L, klen, B, 1]
+            attn_mask_g = attn_mask
         else:
             non_tgt = torch.zeros(L, L + mlen, B, 1)                                    # (attn_mask None: nothing is masked)
+            attn_mask_g = torch.zeros(1, L + mlen, B, 1)
         h = self.dropout(emb if inputs_embeds is not None else self.word_embedding(ids))        # xlnet.py:301-305
         cat_ids = seg if mlen == 0 else torch.cat([torch.zeros(mlen, B, dtype=seg.dtype), seg], dim=0)      # xlnet.py:317-323: mem_pad
         seg_mat = (seg[:, None] != cat_ids[None, :]).long()                             # xlnet.py:326
         seg_mat = F.one_hot(seg_mat, num_classes=2).float()                             # xlnet.py:327
         dt = self.word_embedding.weight.dtype          # float32; float64 when a conditioning analysis runs the oracle in double
         non_tgt, seg_mat = non_tgt.to(dt), seg_mat.to(dt)
+        g = tm = None
+        if target_mapping is not None:                                                  # xlnet.py:238-240, 306-313
+            tm = target_mapping.permute(1, 2, 0).contiguous().to(dt)
+            g = self.dropout(self.mask_emb.expand(tm.shape[0], B, -1).to(dt))
+            attn_mask_g = attn_mask_g.to(dt).expand(L, -1, -1, -1) if attn_mask_g.shape[0] == 1 else attn_mask_g.to(dt)
+        self.hidden_g = []
         pos_emb = self.dropout(self.relative_positional_encoding(L, L + mlen, B).to(dt))       # xlnet.py:332-333
         self.new_mems = None if not mem_len else []
         for i, layer in enumerate(self.layer):
@@ -183,9 +210,16 @@ class MAG_XLNetModel(nn.Module):
                 self.new_mems.append(self.cache_mem(h, None if mems is None else mems[i], mem_len))
             if i == self.injection_index:
                 h = self.MAG(h, visual, acoustic)                                       # xlnet.py:371-372
-            h = layer(h, non_tgt, pos_emb, seg_mat, None if head_mask is None else head_mask[i],
-                      None if mems is None else mems[i])                                # xlnet.py:374-385
-        return self.dropout(h).permute(1, 0, 2).contiguous()                            # xlnet.py:396-399
+            if g is None:
+                h = layer(h, non_tgt, pos_emb, seg_mat, None if head_mask is None else head_mask[i],
+                          None if mems is None else mems[i])                            # xlnet.py:374-385
+            else:
+                self.hidden_g.append(g)
+                h, g = layer(h, non_tgt, pos_emb, seg_mat, None if head_mask is None else head_mask[i],
+                             None if mems is None else mems[i], g, attn_mask_g, tm)
+        if g is not None:
+            self.hidden_g.append(g)
+        return self.dropout(g if g is not None else h).permute(1, 0, 2).contiguous()   # xlnet.py:396-399
 
 
 class SequenceSummary(nn.Module):
@@ -211,9 +245,9 @@ class MAG_XLNetForSequenceClassification(nn.Module):
         self.logits_proj = nn.Linear(config.d_model, config.num_labels)
 
     def forward(self, input_ids, visual, acoustic, attention_mask, token_type_ids, labels=None, head_mask=None, inputs_embeds=None,
-                perm_mask=None, input_mask=None, mems=None, mem_len=None):
+                perm_mask=None, input_mask=None, mems=None, mem_len=None, target_mapping=None):
         out = self.transformer(input_ids, visual, acoustic, attention_mask, token_type_ids, head_mask, inputs_embeds, perm_mask, input_mask,
-                               mems, mem_len)
+                               mems, mem_len, target_mapping)
         logits = self.logits_proj(self.sequence_summary(out))                           # xlnet.py:506-509
         outputs = (logits,)
         if labels is not None:                                                          # xlnet.py:515-524

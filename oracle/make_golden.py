@@ -251,7 +251,8 @@ def gen_full(cb, modeling, bert):
 
 
 def gen_xlnet(modeling, xlnet):
-    """G6: MAG-XLNet -- eval logits (B=4, 48 at L=50; B=3 at L=128, B=2 at L=100; with input_mask / perm_mask at B=4), train-mode p=0 loss + per-tensor grad norms."""
+    """G6: MAG-XLNet -- eval logits (B=4, 48 at L=50; B=3 at L=128, B=2 at L=100; with input_mask / perm_mask at B=4), the query stream under
+    target_mapping (round 6), mems, train-mode p=0 loss + per-tensor grad norms."""
     from transformers.models.xlnet import modeling_xlnet as mx, configuration_xlnet as cx
     from oracle import weights
     from oracle import mag_xlnet_ref as X
@@ -294,6 +295,35 @@ def gen_xlnet(modeling, xlnet):
     out["logits_input_mask/B4_L50_seed31"] = a_im.numpy()
     out["logits_perm_mask/B4_L50_seed31"] = a_pm.numpy()
     out["perm_mask/B4_L50_rs77"] = perm.numpy().astype(np.uint8)
+    # round 6: target_mapping -> the query stream (xlnet.py:238-240, 306-313, 374-399; the head reads output_g, xlnet.py:396-399, 506-509).
+    # Typical use: M prediction positions per sample (one-hot rows of target_mapping), a perm_mask that hides the targets from everybody
+    # (the targets themselves included: the g stream has no self-exemption) next to the padding mask.
+    for (B, L, M, seed) in ((4, 50, 5, 41), (2, 100, 9, 42)):
+        ids, vis, aco, mask, seg, lab = _tb(weights.synthetic_xlnet_batch(B, L, 47, 74, seed=seed))
+        rs = np.random.RandomState(seed)
+        tm = np.zeros((B, M, L), np.float32)
+        pm = np.zeros((B, L, L), np.float32)
+        for b in range(B):
+            real = np.flatnonzero(mask[b].numpy() > 0)
+            tgt = np.sort(rs.choice(real, size=M, replace=False))
+            tm[b, np.arange(M), tgt] = 1.0
+            pm[b][:, tgt] = 1.0                                   # nobody sees a target token
+        tm_t, pm_t = torch.from_numpy(tm), torch.from_numpy(pm)
+        with torch.no_grad():
+            a_g = ref.transformer(ids, vis, aco, token_type_ids=seg, attention_mask=mask, perm_mask=pm_t, target_mapping=tm_t)[0]
+            b_g = mine.transformer(ids, vis, aco, mask, seg, perm_mask=pm_t, target_mapping=tm_t)
+            a_l = ref(ids, vis, aco, token_type_ids=seg, attention_mask=mask, perm_mask=pm_t, target_mapping=tm_t, labels=None)[0]
+            b_l = mine(ids, vis, aco, mask, seg, perm_mask=pm_t, target_mapping=tm_t)[0]
+            a_h = ref.transformer(ids, vis, aco, token_type_ids=seg, attention_mask=mask, perm_mask=pm_t)[0]
+        dg, dl = _maxdiff(a_g, b_g), _maxdiff(a_l, b_l)
+        print("G6 xlnet target_mapping B=%d L=%d M=%d: output_g max |diff| = %.3g (|g| max %.3g), logits %.3g; g differs from h at the targets by %.3g"
+              % (B, L, M, dg, float(a_g.abs().max()), dl, float((a_g - torch.einsum("bml,blh->bmh", tm_t, a_h)).abs().max())))
+        assert tuple(a_g.shape) == (B, M, 768) and dg < 2e-5 and dl < 2e-5
+        tag = "B%d_L%d_M%d_seed%d" % (B, L, M, seed)
+        out["target_mapping/tm/" + tag] = tm.astype(np.uint8)
+        out["target_mapping/perm/" + tag] = pm.astype(np.uint8)
+        out["target_mapping/output_g/" + tag] = a_g.numpy()
+        out["target_mapping/logits/" + tag] = a_l.numpy()
     # round 5: mems (xlnet.py:81-91, 244-245, 276-293, 317-323, 363-385).  Segment 1 runs with use_cache and mem_len set -> new_mems (the
     # hidden state in front of every layer); segment 2 consumes them (keys / values over cat([mem, h]), klen = mlen + L) and caches again
     for (B, L, ml, seed) in ((4, 24, 24, 36), (3, 50, 40, 37)):          # klen 48 (one strip group) and 90 (above the L = 64 kernel boundary)

@@ -136,3 +136,25 @@ def test_xlnet_oracle_mems(golden):
     for i in (0, 1, 2, 11):
         np.testing.assert_allclose(weights.strided_sample(mems1[i].numpy(), 64), g["mems/new_mems_seg1/%s/layer%d" % (tag, i)], atol=2e-5)
         np.testing.assert_allclose(weights.strided_sample(mems2[i].numpy(), 64), g["mems/new_mems_seg2/%s/layer%d" % (tag, i)], atol=2e-5)
+
+
+def test_xlnet_oracle_query_stream(golden):
+    """G6, round 6: target_mapping -> the two-stream attention (xlnet.py:238-240, 306-313, 374-399): the oracle's query stream output
+    [B, M, 768] and the head's logits on it vs the reference's own outputs."""
+    from oracle import mag_xlnet_ref as X
+    g = golden["g6_xlnet"]
+    torch.set_num_threads(8)
+    B, L, M, seed = 4, 50, 5, 41
+    tag = "B%d_L%d_M%d_seed%d" % (B, L, M, seed)
+    b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=seed)
+    ids, vis, aco, mask, seg = (torch.from_numpy(b[k]) for k in ("input_ids", "visual", "acoustic", "input_mask", "segment_ids"))
+    tm = torch.from_numpy(g["target_mapping/tm/" + tag].astype(np.float32))
+    pm = torch.from_numpy(g["target_mapping/perm/" + tag].astype(np.float32))
+    assert tuple(tm.shape) == (B, M, L) and float(tm.sum()) == B * M
+    m = X.load_deterministic(X.MAG_XLNetForSequenceClassification(X.XLNetConfigLite(), X.MultimodalConfig(1.0, 0.5), 47, 74)).eval()
+    with torch.no_grad():
+        out_g = m.transformer(ids, vis, aco, mask, seg, perm_mask=pm, target_mapping=tm)
+        logits = m(ids, vis, aco, mask, seg, perm_mask=pm, target_mapping=tm)[0]
+    assert len(m.transformer.hidden_g) == 13
+    np.testing.assert_allclose(out_g.numpy(), g["target_mapping/output_g/" + tag], atol=2e-5)
+    np.testing.assert_allclose(logits.numpy(), g["target_mapping/logits/" + tag], atol=2e-5)
