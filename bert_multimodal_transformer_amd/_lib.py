@@ -79,6 +79,9 @@ PROTOTYPES = {
     "mb_xlnet_set_head_mask": (_i, [_vp, _vp]),
     "mb_xlnet_set_perm_mask": (_i, [_vp, _vp]),
     "mb_xlnet_set_mems": (_i, [_vp, _vp, _i]),
+    "mb_xlnet_query_stream_scratch_bytes": (_sz, [_vp, _i, _i, _i]),
+    "mb_xlnet_query_stream_state_bytes": (_sz, [_vp, _i, _i]),
+    "mb_xlnet_query_stream": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _vp]),
     "mb_bert_mark_grads_zero": (_i, [_vp, _i]),
     "mb_xlnet_mark_grads_zero": (_i, [_vp, _i]),
     "mb_bert_materialize_grads": (_i, [_vp, _vp]),

@@ -613,6 +613,29 @@ class _Core(object):
             raise _lib.MagbertError("no forward has run")
         return self._act(p, B, L).clone()          # the engine's scratch is reused by the backward: hand out a copy
 
+    def xl_query_stream(self, target_mapping, B, L):
+        """MAG-XLNet's query stream (xlnet.py:238-240, 306-313, 374-399; include/magbert_hip.h: mb_xlnet_query_stream) as a post-pass
+        over the eval forward that just ran: target_mapping [B, M, L] -> (logits_g [B, num_labels], hidden_g: n_layers + 1 fp32
+        tensors [B, M, H], the last one = output_g)."""
+        if self.kind != "xlnet":
+            raise NotImplementedError("target_mapping is an argument of MAG-XLNet only")
+        tm = target_mapping.detach().to(self.device, torch.float32).contiguous()
+        if tm.dim() != 3 or tm.shape[0] != B or tm.shape[2] != L:
+            raise ValueError("target_mapping must be [batch, num_predict, seq_len] = [%d, M, %d], got %s" % (B, L, tuple(tm.shape)))
+        M, H = int(tm.shape[1]), self.config.hidden_size
+        need = self.lib.mb_xlnet_query_stream_scratch_bytes(self.handle, B, M, L)
+        scratch = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        base = (-scratch.data_ptr()) % 256
+        logits = torch.empty(B, self.config.num_labels, dtype=torch.float32, device=self.device)
+        with _Core._Hop(self):
+            _lib.check(self.lib.mb_xlnet_query_stream(self.handle, _lib.ptr(tm), M, C.c_void_p(scratch.data_ptr() + base), need,
+                                                      _lib.ptr(logits), self.stream()))
+        stride = self.lib.mb_xlnet_query_stream_state_bytes(self.handle, B, M)
+        es = 2 if self.dt == _lib.DT_BF16 else 4
+        states = tuple(scratch[base + i * stride: base + i * stride + B * M * H * es].view(self.compute_dtype).view(B, M, H).float()
+                       for i in range(self.n_layers + 1))
+        return logits, states
+
     def sequence_output(self, B, L):
         return self._act(self._fn("sequence_output")(self.handle), B, L)
 

@@ -202,7 +202,8 @@ int attention_trace_fetch(unsigned long long* host_out, int max_blocks);     // 
 int xlnet_attention_forward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
                             const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask, void* vec,
                             void* psave, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale = nullptr,
-                            const uint8_t* perm = nullptr);      // perm [B][L][L] bytes or null: != 0 <=> query i may not attend to key j (xlnet.py:265-296)
+                            const uint8_t* perm = nullptr,       // perm [B][L][L] bytes or null: != 0 <=> query i may not attend to key j (xlnet.py:265-296)
+                            int gstream = 0);                    // 1: the query stream's mask (attn_mask_g = data_mask, no i == j exemption; xlnet.py:288-296)
 int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
                              const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask,
                              const void* psave, const void* dvec, void* gsave, void* dqkv, void* dkr, float* d_rwb,
@@ -222,6 +223,12 @@ int xlnet_pos_emb(int dtype, void* out, int B, int L, int H, DropKey drop, hipSt
 // xs[b] = x[b, L-1, :] * dropout   (final dropout xlnet.py:396 + SequenceSummary "last") ; backward scatters into a zeroed dx
 int last_token_forward(int dtype, const void* x, void* xs, int B, int L, int H, DropKey drop, hipStream_t st);
 int last_token_backward(int dtype, const void* dxs, void* dx, int B, int L, int H, DropKey drop, hipStream_t st);
+// query stream under target_mapping tm [B][M][L] fp32 (xlnet.py:306-313, 374-399): the mask_emb row broadcast to [rows][H]; the
+// attention operand of the g stream (q = tm-mapped qg [B*M][H] onto the L positions, k | v copied from the content stream's
+// [T][3H]); the attention output mapped back to the M targets
+int xlnet_broadcast_row(int dtype, const float* row, void* out, int rows, int H, hipStream_t st);
+int xlnet_map_query(int dtype, const float* tm, const void* qg, const void* qkv_h, void* qkv_g, int B, int M, int L, int H, hipStream_t st);
+int xlnet_unmap_vec(int dtype, const float* tm, const void* vec, void* vecg, int B, int M, int L, int H, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------ head (head.hip)
 // pooled = tanh(z) ; logits = dropout(pooled) Wc^T + bc ; optional MSE loss (mean over B*nl) accumulated into loss[0]

@@ -28,6 +28,7 @@ struct XlParams {
     // query i may not attend to key j (the i == j exemption of non_tgt_mask, xlnet.py:288-296, still applies).  Forward only: the
     // backward works from the saved probabilities, which are exact zeros wherever a score was masked.
     const uint8_t* perm;
+    int gstream;                                                           // forward only: 1 = the query stream's mask, the i == j exemption dropped (attn_mask_g)
     GradAcc acc;                                                           // deterministic mode: where the bias / seg_embed column sums go (common.h)
 };
 
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_fwd_kernel(const T* __restric
                     const float bd = to_f(*(const T*)(raw + (lane & 15) * RPIT + p * (int)sizeof(T)));
                     float s = (ac[jt][r] + cK[j] + bd + (si == segv[j] ? e0 : e1)) * scale;
                     if (j >= L) s = kPadNeg;
-                    else if (i != j && (padf[j] || (xp.perm != nullptr && i < L && xp.perm[((size_t)b * L + i) * L + j] != 0))) s -= kXlMask;
+                    else if ((i != j || xp.gstream) && (padf[j] || (xp.perm != nullptr && i < L && xp.perm[((size_t)b * L + i) * L + j] != 0))) s -= kXlMask;
                     ac[jt][r] = s;
                     mx = fmaxf(mx, s);
                 }
@@ -712,8 +713,9 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv2_kernel(const T* __res
 
 int xlnet_attention_forward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
                             const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask, void* vec,
-                            void* psave, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale, const uint8_t* perm) {
-    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale, perm, GradAcc{nullptr, nullptr}};
+                            void* psave, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale, const uint8_t* perm,
+                            int gstream) {
+    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale, perm, gstream, GradAcc{nullptr, nullptr}};
     XL_DISPATCH({
         (void)NWQ; (void)NWK;
         hipLaunchKernelGGL((xl_attn_fwd_kernel<T, LP, NWF>), dim3(B * nh, LP / 16 / NWF), dim3(NWF * 64), 0, st, (const T*)qkv, (const T*)kr, xp,
@@ -728,7 +730,7 @@ int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const f
                              const float* head_scale, GradAcc acc) {
     static int g_kv2 = -1;            // MB_XL_KV2=0: the key / position side of the backward with the round-3 kernel at L <= 64 too (A/B)
     if (g_kv2 < 0) { const char* v = getenv("MB_XL_KV2"); g_kv2 = v ? atoi(v) : 1; }
-    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale, nullptr, acc};
+    XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale, nullptr, 0, acc};
     XL_DISPATCH({
         (void)NWF;
         hipLaunchKernelGGL((xl_attn_bwd_q_kernel<T, LP, NWQ>), dim3(B * nh, LP / 16 / NWQ), dim3(NWQ * 64), 0, st, (const T*)qkv, (const T*)kr,

@@ -799,6 +799,80 @@ int mb_xlnet_graph_stats(const mb_xlnet_engine* e, size_t* captures, size_t* lau
 }
 size_t mb_xlnet_trainable_count(const mb_xlnet_engine* e) { return e->n_trainable; }
 
+// ---------------------------------------------------------------------------------------------- query stream (target_mapping)
+// xlnet.py:238-240, 306-313, 374-399: with target_mapping [B][M][L] XLNetModel runs a second stream g [M][B][H] next to h.  g starts as
+// mask_emb, every layer projects it with the layer's q, maps the M query rows onto the L positions, attends over the CONTENT stream's
+// keys / values / positions of that layer under attn_mask_g (data_mask without the i == j exemption), maps the result back to the M
+// targets, then shares post_attention and the feed-forward block with h.  h never reads g, so the stream is a post-pass over what the
+// last EVAL forward left in the workspace (every layer's q | k | v and kr); nothing of that pass is overwritten -- all intermediates
+// live in the caller's scratch -- and MAG touches h only (xlnet.py:371-372).
+struct XlQsLayout { size_t state, state_stride, qg, qkv, vec, vecg, s1, y1, u, gl, s2, st, xs, z, pooled, bytes; };
+static XlQsLayout xl_qs_layout(const mb_xlnet_engine* e, int B, int M, int L) {
+    const mb_xlnet_config& c = e->c;
+    const size_t es = esize(c.dtype), H = c.d_model, I = c.d_inner;
+    const size_t R = align_up((size_t)B * M, 128), T = align_up((size_t)B * L, 128);      // (row counts padded as the workspace's are)
+    Carver w;
+    XlQsLayout q;
+    q.state_stride = align_up(R * H * es, 256);
+    q.state = w.take(q.state_stride * (c.n_layer + 1));
+    q.qg = w.take(R * H * es); q.qkv = w.take(T * 3 * H * es); q.vec = w.take(T * H * es); q.vecg = w.take(R * H * es);
+    q.s1 = w.take(R * H * es); q.y1 = w.take(R * H * es); q.u = w.take(R * I * es); q.gl = w.take(R * I * es); q.s2 = w.take(R * H * es);
+    q.st = w.take(R * 2 * 4);
+    q.xs = w.take((size_t)B * H * es); q.z = w.take((size_t)B * H * 4); q.pooled = w.take((size_t)B * H * 4);
+    q.bytes = w.off;
+    return q;
+}
+size_t mb_xlnet_query_stream_scratch_bytes(const mb_xlnet_engine* e, int B, int M, int L) {
+    if (!e || B < 1 || M < 1 || L < 1) return 0;
+    return xl_qs_layout(e, B, M, L).bytes;
+}
+size_t mb_xlnet_query_stream_state_bytes(const mb_xlnet_engine* e, int B, int M) {
+    if (!e || B < 1 || M < 1) return 0;
+    return xl_qs_layout(e, B, M, 1).state_stride;
+}
+int mb_xlnet_query_stream(mb_xlnet_engine* e, const float* target_mapping, int M, void* scratch, size_t scratch_bytes, float* logits_g,
+                          void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!e || !target_mapping || !scratch) return MB_ERR_ARG;
+    if (!e->P || !e->ws || !e->ran_forward) return MB_ERR_ARG;
+    if (e->training || e->in_step || e->mems) return MB_ERR_MODE;          // eval passes without memories only
+    const mb_xlnet_config& c = e->c;
+    const int dt = c.dtype, H = c.d_model, I = c.d_inner, B = e->B, L = e->L, nh = c.n_head, NL = c.n_layer, R = B * M;
+    if (M < 1 || M > c.max_seq) return MB_ERR_SHAPE;
+    const XlQsLayout q = xl_qs_layout(e, B, M, L);
+    if (scratch_bytes < q.bytes || ((uintptr_t)scratch & 255)) return MB_ERR_ARG;
+    float* P = e->P;
+    char* ws = e->ws;
+    char* sc = (char*)scratch;
+    auto state = [&](int i) { return sc + q.state + (size_t)i * q.state_stride; };
+    float* mean = (float*)(sc + q.st);
+    float* rstd = mean + align_up((size_t)R, 128);
+    CK(xlnet_broadcast_row(dt, P + e->mask_emb, state(0), R, H, st));                                                    // xlnet.py:306-310
+    for (int l = 0; l < NL; ++l) {
+        const XlLayerOff& o = e->lo[l];
+        const XlLayerWs& w = e->lw[l];
+        const char* g = state(l);
+        CK(gemm(dt, GEMM_NN, EPI_ADD_RES, R, H, H, g, H, e->W(o.q), H, sc + q.qg, H, nullptr, nullptr, nullptr, nullptr, 0, kNoDrop, 1, 0, st));
+        CK(xlnet_map_query(dt, target_mapping, sc + q.qg, ws + w.qkv, sc + q.qkv, B, M, L, H, st));
+        CK(xlnet_attention_forward(dt, sc + q.qkv, ws + w.kr, P + o.rwb, P + o.rrb, P + o.rsb, P + o.seg, e->seg, e->mask, sc + q.vec, nullptr,
+                                   B, L, nh, kNoDrop, st, e->head_mask ? e->head_mask + (size_t)l * nh : nullptr, e->perm, 1));
+        CK(xlnet_unmap_vec(dt, target_mapping, sc + q.vec, sc + q.vecg, B, M, L, H, st));
+        // post_attention and the feed-forward block, the content stream's weights on M rows per sample
+        CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, R, H, H, sc + q.vecg, H, e->W(o.o), H, sc + q.s1, H, nullptr, nullptr, nullptr, g, H, kNoDrop, 1, 0, st));
+        CK(ln_forward(dt, sc + q.s1, P + o.ralnw, P + o.ralnb, c.layer_norm_eps, sc + q.y1, mean, rstd, R, H, kNoDrop, st));
+        CK(gemm(dt, GEMM_NT, EPI_BIAS_GELU, R, I, H, sc + q.y1, H, e->W(o.w1), H, sc + q.u, I, sc + q.gl, nullptr, P + o.b1, nullptr, 0, kNoDrop, 1, 0, st));
+        CK(gemm(dt, GEMM_NT, EPI_BIAS_DROP_RES, R, H, I, sc + q.gl, I, e->W(o.w2), I, sc + q.s2, H, nullptr, nullptr, P + o.b2, sc + q.y1, H, kNoDrop, 1, 0, st));
+        CK(ln_forward(dt, sc + q.s2, P + o.fflnw, P + o.fflnb, c.layer_norm_eps, state(l + 1), mean, rstd, R, H, kNoDrop, st));
+    }
+    if (!logits_g) return MB_OK;
+    // the head on the query stream's output (xlnet.py:396-399 returns output_g first; 506-509: summary of its last row)
+    CK(last_token_forward(dt, state(NL), sc + q.xs, B, M, H, kNoDrop, st));
+    float* z = (float*)(sc + q.z);
+    CK(gemm(dt, GEMM_NT, EPI_BIAS_F32, B, H, H, sc + q.xs, H, e->W(e->wsum), H, nullptr, H, nullptr, z, P + e->bsum, nullptr, 0, kNoDrop, 1, 64, st));
+    CK(head_forward(z, P + e->wc, P + e->bc, nullptr, (float*)(sc + q.pooled), logits_g, nullptr, nullptr, B, H, c.num_labels, kNoDrop, st));
+    return MB_OK;
+}
+
 const void* mb_xlnet_hidden_state(const mb_xlnet_engine* e, int i) {      // input of layer i (before the MAG injection), i = n_layer: last output
     if (!e || !e->ws || i < 0 || i > e->c.n_layer) return nullptr;
     return e->ws + e->ws_x[i];

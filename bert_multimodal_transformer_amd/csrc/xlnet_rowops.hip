@@ -158,4 +158,70 @@ int last_token_backward(int dtype, const void* dxs, void* dx, int B, int L, int 
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------- query stream (xlnet.py:306-313, 374-399)
+// g0[b][m][:] = mask_emb  (xlnet.py:306-310: word_emb_q = mask_emb.expand(M, B, -1); eval: the dropout behind it is the identity)
+template <class T>
+__global__ void __launch_bounds__(256) xl_broadcast_row_kernel(const float* __restrict__ row, T* __restrict__ out, int rows, int H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    for (int col = lane * 4; col < H; col += 256) store4(out + (size_t)r * H + col, *(const f32x4*)(row + col));
+}
+// The fused q | k | v operand of the query-stream attention.  Row (b, l): q = sum_m target_mapping[b][m][l] * qg[b][m][:]
+// (einsum "mbnd,mlb->lbnd", modeling_xlnet's two-stream branch behind xlnet.py:374-385), k | v = the content stream's of the same
+// layer.  fp32 accumulation over m, zero weights skipped (one-hot mappings read one row).
+template <class T>
+__global__ void __launch_bounds__(256) xl_map_q_kernel(const float* __restrict__ tm, const T* __restrict__ qg, const T* __restrict__ qkv_h,
+                                                        T* __restrict__ qkv_g, int B, int M, int L, int H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;              // b * L + l
+    if (row >= B * L) return;
+    const int b = row / L, l = row - b * L;
+    const T* src = qkv_h + (size_t)row * 3 * H;
+    T* dst = qkv_g + (size_t)row * 3 * H;
+    for (int col = lane * 4; col < H; col += 256) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < M; ++m) {
+            const float w = tm[((size_t)b * M + m) * L + l];
+            if (w != 0.f) acc += w * load4(qg + ((size_t)b * M + m) * H + col);
+        }
+        store4(dst + col, acc);
+    }
+    for (int col = H + lane * 4; col < 3 * H; col += 256) store4(dst + col, load4(src + col));
+}
+// vecg[b][m][:] = sum_l target_mapping[b][m][l] * vec[b][l][:]   (einsum "lbnd,mlb->mbnd")
+template <class T>
+__global__ void __launch_bounds__(256) xl_unmap_vec_kernel(const float* __restrict__ tm, const T* __restrict__ vec, T* __restrict__ vecg,
+                                                            int B, int M, int L, int H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;              // b * M + m
+    if (row >= B * M) return;
+    const int b = row / M;
+    const float* w = tm + (size_t)row * L;
+    for (int col = lane * 4; col < H; col += 256) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int l = 0; l < L; ++l) {
+            const float wl = w[l];
+            if (wl != 0.f) acc += wl * load4(vec + ((size_t)b * L + l) * H + col);
+        }
+        store4(vecg + (size_t)row * H + col, acc);
+    }
+}
+int xlnet_broadcast_row(int dtype, const float* row, void* out, int rows, int H, hipStream_t st) {
+    if (rows <= 0) return MB_OK;
+    if (H % 4) return MB_ERR_SHAPE;
+    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((xl_broadcast_row_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, st, row, (T*)out, rows, H); })
+    return (int)hipGetLastError();
+}
+int xlnet_map_query(int dtype, const float* tm, const void* qg, const void* qkv_h, void* qkv_g, int B, int M, int L, int H, hipStream_t st) {
+    if (H % 4) return MB_ERR_SHAPE;
+    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((xl_map_q_kernel<T>), dim3((B * L + 3) / 4), dim3(256), 0, st, tm, (const T*)qg, (const T*)qkv_h, (T*)qkv_g, B, M, L, H); })
+    return (int)hipGetLastError();
+}
+int xlnet_unmap_vec(int dtype, const float* tm, const void* vec, void* vecg, int B, int M, int L, int H, hipStream_t st) {
+    if (H % 4) return MB_ERR_SHAPE;
+    MB_DISPATCH_T(dtype, { hipLaunchKernelGGL((xl_unmap_vec_kernel<T>), dim3((B * M + 3) / 4), dim3(256), 0, st, tm, (const T*)vec, (T*)vecg, B, M, L, H); })
+    return (int)hipGetLastError();
+}
+
 }  // namespace mb

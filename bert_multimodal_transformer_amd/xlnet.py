@@ -7,8 +7,8 @@ r_w_bias,seg_embed,layer_norm.*}, transformer.layer.{i}.ff.{layer_norm,layer_1,l
 sequence_summary.summary.*, logits_proj.*).  Built for the configuration the reference driver runs
 (multimodal_driver.py:363-370: attention_mask + token_type_ids; perm_mask / input_mask are built too (forward kernel + its
 adjoint); mems (forward and backward of MAG_XLNetForSequenceClassification; the base model under no_grad) and the new_mems return
-(config.mem_len, use_cache); target_mapping (the query stream)
-raises NotImplementedError; inputs_embeds, output_hidden_states / output_attentions (served from the activations the engine keeps for
+(config.mem_len, use_cache); target_mapping (the query stream g, xlnet.py:306-313, 374-399) for inference -- eval mode under
+torch.no_grad(), without mems / output_attentions; inputs_embeds, output_hidden_states / output_attentions (served from the activations the engine keeps for
 its backward) and head_mask (scales each head's attention output inside the kernels) are built, and MAG_XLNetModel's output is
 differentiable), sequence length <= 128, MAG injected in front of layer
 XLNET_INJECTION_INDEX (global_configs.py:19, xlnet.py:371-372).
@@ -80,7 +80,6 @@ class MAG_XLNetModel(_XlBase):
         """-> (output [B, L, d_model], (hidden_states), (attentions)) like xlnet.py:400-429.  `output` is the last layer's
         hidden state after the final dropout (xlnet.py:396) and carries an autograd edge into the engine: a head built on this
         model trains the whole stack, and inputs_embeds receives its gradient."""
-        _xl_unsupported(self, target_mapping)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
@@ -93,6 +92,12 @@ class MAG_XLNetModel(_XlBase):
         K = mlen + L
         core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, mems=stack, head_mask=head_mask,
                      inputs_embeds=inputs_embeds, perm=perm)
+        if target_mapping is not None:         # xlnet.py:396-399: the query stream's output [B, M, d_model] is what the model returns
+            _, gs = _xl_query_stream(self, target_mapping, B, L, mems, output_attentions)
+            outputs = (gs[-1],)
+            if output_hidden_states:
+                outputs = outputs + (_xl_interleave(core.hidden_states(B, L), gs),)
+            return outputs
         out = core.xl_model_output(B, K)[:, mlen:]
         if torch.is_grad_enabled():
             emb_edge = inputs_embeds if inputs_embeds is not None and inputs_embeds.requires_grad else None
@@ -155,10 +160,24 @@ def _xl_new_mems(core, mems, mlen, B, klen, mem_len):
     return tuple(out)
 
 
-def _xl_unsupported(model, target_mapping):
-    """The reference driver never passes it (multimodal_driver.py:363-370): the query stream of permutation-LM pre-training
-    (xlnet.py:306-313, 387-427) does not exist in a fine-tuning encoder (DESIGN.md section 7 lists the reference lines)."""
-    model._unsupported(target_mapping=target_mapping)
+def _xl_query_stream(model, target_mapping, B, L, mems, output_attentions):
+    """target_mapping [B, M, L] -> the query stream g (xlnet.py:238-240, 306-313, 374-399), run by the engine as a post-pass over the
+    forward that just finished (csrc/xlnet_engine.hip: mb_xlnet_query_stream).  The reference driver never passes it
+    (multimodal_driver.py:363-370), so it is built for inference: eval mode under torch.no_grad(), no mems, no attention
+    probabilities of the g stream.  -> (logits_g [B, num_labels], hidden_g: n_layer + 1 tensors [B, M, d_model])"""
+    if model.training or torch.is_grad_enabled():
+        raise NotImplementedError("target_mapping (the query stream) is built for inference: call model.eval() and run under "
+                                  "torch.no_grad()")
+    if mems is not None:
+        raise NotImplementedError("target_mapping together with mems")
+    if output_attentions:
+        raise NotImplementedError("output_attentions together with target_mapping (the g stream's probabilities are not kept)")
+    return model._core.xl_query_stream(target_mapping, B, L)
+
+
+def _xl_interleave(hs, gs):
+    """xlnet.py:412-416: with a query stream every hidden_states entry is the pair (h, g), flattened in layer order"""
+    return tuple(t for pair in zip(hs, gs) for t in pair)
 
 
 def _xl_front(model, input_ids, inputs_embeds, attention_mask, token_type_ids, input_mask=None, perm_mask=None):
@@ -211,7 +230,6 @@ class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
     def forward(self, input_ids, visual, acoustic, attention_mask=None, mems=None, perm_mask=None, target_mapping=None,
                 token_type_ids=None, input_mask=None, head_mask=None, inputs_embeds=None, use_cache=True, labels=None,
                 output_attentions=None, output_hidden_states=None):
-        _xl_unsupported(self, target_mapping)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else getattr(self.config, "output_hidden_states", False))
@@ -226,6 +244,9 @@ class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
         K = mlen + L
         logits = core.forward(input_ids, visual, acoustic, attention_mask, token_type_ids, None, self.training, mems=stack, head_mask=head_mask,
                               inputs_embeds=inputs_embeds, perm=perm)
+        gs = None
+        if target_mapping is not None:         # xlnet.py:396-399, 506-509: the head summarises output_g (its last target row)
+            logits, gs = _xl_query_stream(self, target_mapping, B, L, mems, output_attentions)
         if torch.is_grad_enabled():
             emb_edge = inputs_embeds if inputs_embeds is not None and inputs_embeds.requires_grad else None
             logits = _EngineFn.apply(core.anchor, logits, core, emb_edge)
@@ -234,7 +255,8 @@ class MAG_XLNetForSequenceClassification(_FusedStep, _XlBase):
         if mem_len is not None and mem_len > 0 and use_cache is True:          # xlnet.py:363-365, 406-407, 511-513: (logits, mems, ...)
             outputs = outputs + (_xl_new_mems(core, mems, mlen, B, K, mem_len),)
         if output_hidden_states:
-            outputs = outputs + (tuple(h[:, mlen:] for h in core.hidden_states(B, K)),)
+            hs = tuple(h[:, mlen:] for h in core.hidden_states(B, K))
+            outputs = outputs + (hs if gs is None else _xl_interleave(hs, gs),)
         if output_attentions:
             outputs = outputs + (tuple(a[:, :, mlen:] for a in core.xl_attentions(B, K, self.training)),)
         if labels is not None:                                        # xlnet.py:515-524

@@ -306,9 +306,27 @@ int mb_xlnet_set_head_mask(mb_xlnet_engine* e, const float* head_mask);
 /* perm_mask / input_mask (xlnet.py:258-296): bytes [B][L][L] in device memory, sticky until reset with NULL; perm[b][i][j] != 0 <=>
  * data_mask[i, j, b] = input_mask[j, b] + perm_mask[i, j, b] > 0, i.e. query i may not attend to key j (i == j is always allowed:
  * non_tgt_mask, xlnet.py:288-296).  Combined with the attention_mask argument of the passes by OR.  Explicit forwards /
- * backwards only (mb_xlnet_train_step returns MB_ERR_MODE while it is set).  The content stream (h) only: target_mapping and the
- * query stream it feeds are not built. */
+ * backwards only (mb_xlnet_train_step returns MB_ERR_MODE while it is set).  Masks the content stream (h) and, without the i == j
+ * exemption, the query stream of mb_xlnet_query_stream (attn_mask_g, xlnet.py:288-296). */
 int mb_xlnet_set_perm_mask(mb_xlnet_engine* e, const uint8_t* perm);
+/* target_mapping -> the query stream g (xlnet.py:238-240, 306-313, 374-399; replaces the `g` half of XLNetLayer's two-stream
+ * attention, transformers modeling_xlnet XLNetRelativeAttention.forward behind xlnet.py:374-385).  A post-pass over the last
+ * mb_xlnet_forward, which must have been an EVAL pass (training == 0) without mems (else MB_ERR_MODE) and whose attention_mask /
+ * token_type_ids buffers must still be alive: g starts as mask_emb on M rows per sample, every layer projects it with the
+ * layer's q, maps it onto the L positions with target_mapping (fp32 [B][M][L], device; one-hot rows in the usual use, any weights
+ * accepted), attends over that layer's content-stream keys / values / positions under the perm_mask / attention_mask WITHOUT the
+ * self exemption, maps the result back to the M targets and shares post_attention + feed-forward with h.  head_mask / perm_mask
+ * apply as set.  Nothing of the forward is overwritten (a backward after it is still valid; g itself has no backward here).
+ * scratch: caller-owned device memory, 256-byte aligned, >= mb_xlnet_query_stream_scratch_bytes(e, B, M, L) for the forward's B, L.
+ * On return its first n_layer + 1 blocks of mb_xlnet_query_stream_state_bytes(e, B, M) bytes each hold g in front of layer i
+ * ([B][M][d_model], activation dtype; XLNetModel's hidden_states_g) -- block n_layer is output_g, what XLNetModel returns first when
+ * target_mapping is given (xlnet.py:396-399; the final dropout is the identity in eval).  logits_g (fp32 [B][num_labels], device)
+ * or NULL: SequenceSummary("last") + logits_proj on output_g's last row, as MAG_XLNetForSequenceClassification reads
+ * transformer_outputs[0] (xlnet.py:506-509). */
+size_t mb_xlnet_query_stream_scratch_bytes(const mb_xlnet_engine* e, int B, int M, int L);
+size_t mb_xlnet_query_stream_state_bytes(const mb_xlnet_engine* e, int B, int M);
+int mb_xlnet_query_stream(mb_xlnet_engine* e, const float* target_mapping, int M, void* scratch, size_t scratch_bytes,
+                          float* logits_g, void* stream);
 /* mems (xlnet.py:81-91, 244-245, 374-385: the hidden states cached from the previous segment; keys / values of layer l run over
  * cat([mems[l], h]), klen = mlen + qlen <= max_seq).  Explicit mb_xlnet_forward / mb_xlnet_backward passes only (the single-call
  * steps return MB_ERR_MODE while it is set).  The caller passes the segment as klen rows per sample whose first mlen rows are

@@ -755,6 +755,81 @@ def test_input_mask_and_perm_mask_match_reference_golden_fp32(golden):
         m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, input_mask=1.0 - mask.float())
 
 
+@pytest.mark.parametrize("B,L,M,seed,cdt,tol_g,tol", [(4, 50, 5, 41, torch.float32, 1e-3, 1e-3), (2, 100, 9, 42, torch.float32, 1e-3, 1e-3),
+                                                      (4, 50, 5, 41, torch.bfloat16, 1e-1, 5e-2)])
+def test_query_stream_matches_reference_golden(golden, B, L, M, seed, cdt, tol_g, tol):
+    """f-4, target_mapping (xlnet.py:238-240, 306-313, 374-399): the query stream g -- mask_emb on M target rows per sample, per layer the
+    layer's q projection, the map onto the L positions, attention over the content stream's keys / values under the perm_mask WITHOUT
+    the self exemption, the map back, post_attention + feed-forward -- against what the REFERENCE's own xlnet.py returned for the same
+    inputs (oracle/make_golden.py gen_xlnet): output_g [B, M, 768] (what MAG_XLNetModel returns first) and the classifier's logits on
+    it.  fp32: the north-star 1e-3; bf16 activations: 1e-1 on LayerNorm outputs of magnitude ~3.8 (bf16 spacing there 1.6e-2, twelve
+    layers deep), logits 5e-2 as the other bf16 eval tests."""
+    g = golden["g6_xlnet"]
+    tag = "B%d_L%d_M%d_seed%d" % (B, L, M, seed)
+    m = build(cdt=cdt).eval()
+    ids, vis, aco, mask, seg, lab = tb(weights.synthetic_xlnet_batch(B, L, 47, 74, seed=seed), DEV)
+    tm = torch.from_numpy(g["target_mapping/tm/" + tag].astype(np.float32)).to(DEV)
+    pm = torch.from_numpy(g["target_mapping/perm/" + tag].astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        plain = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, perm_mask=pm)[0].cpu().numpy()
+        r = m.transformer(ids, vis, aco, token_type_ids=seg, attention_mask=mask, perm_mask=pm, target_mapping=tm, output_hidden_states=True)
+        logits = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, perm_mask=pm, target_mapping=tm)[0].cpu().numpy()
+        again = m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, perm_mask=pm)[0].cpu().numpy()
+    out_g = r[0].cpu().numpy()
+    ref_g, ref_l = g["target_mapping/output_g/" + tag], g["target_mapping/logits/" + tag]
+    e_g, e_l = float(np.abs(out_g - ref_g).max()), float(np.abs(logits - ref_l).max())
+    print("query stream %s %s: output_g err %.2e (|g| max %.2f), logits err %.2e; the g head differs from the h head by %.2e"
+          % (tag, cdt, e_g, float(np.abs(ref_g).max()), e_l, float(np.abs(ref_l - plain).max())))
+    assert out_g.shape == (B, M, 768) and e_g <= tol_g and e_l <= tol
+    assert np.array_equal(plain, again)                       # the post-pass leaves nothing behind in the engine
+    # hidden_states: (h_0, g_0, h_1, g_1, ...) (xlnet.py:412-416); g_0 is mask_emb on every row
+    hs = r[1]
+    assert len(hs) == 2 * 13 and tuple(hs[0].shape) == (B, L, 768) and tuple(hs[1].shape) == (B, M, 768)
+    me = m.transformer.mask_emb.detach().float().view(1, 1, 768)
+    assert float((hs[1] - me.to(hs[1].dtype).float()).abs().max()) <= (0.0 if cdt == torch.float32 else 1e-2)
+    assert float((hs[-1] - r[0]).abs().max()) == 0.0
+
+
+def test_query_stream_general_mapping_and_argument_checks():
+    """A target_mapping with fractional weights (two positions per target) against the oracle run live; the modes the stream is not
+    built for raise."""
+    B, L, M, layers = 3, 40, 4, 3
+    m = build(layers=layers).eval()
+    o = oracle(layers=layers).eval()
+    b = weights.synthetic_xlnet_batch(B, L, 47, 74, seed=51)
+    ids, vis, aco, mask, seg, lab = tb(b, DEV)
+    rs = np.random.RandomState(5)
+    tm = np.zeros((B, M, L), np.float32)
+    for bb in range(B):
+        for mm in range(M):
+            i, j = rs.choice(np.arange(L - 12, L), size=2, replace=False)
+            tm[bb, mm, i], tm[bb, mm, j] = 0.75, 0.25
+    pm = (rs.rand(B, L, L) < 0.2).astype(np.float32)
+    tm_t, pm_t = torch.from_numpy(tm), torch.from_numpy(pm)
+    hm = torch.from_numpy(rs.rand(layers, 12).astype(np.float32))
+    with torch.no_grad():
+        got = m.transformer(ids, vis, aco, token_type_ids=seg, attention_mask=mask, perm_mask=pm_t.to(DEV), target_mapping=tm_t.to(DEV),
+                            head_mask=hm.to(DEV))[0].cpu()
+        c = tb(b)
+        want = o.transformer(c[0], c[1], c[2], c[3], c[4], perm_mask=pm_t, target_mapping=tm_t, head_mask=hm)
+    err = float((got - want).abs().max())
+    print("query stream, fractional mapping + head_mask + random perm_mask: output_g err %.2e (|g| max %.2f)" % (err, float(want.abs().max())))
+    assert err <= 1e-3
+    with pytest.raises(NotImplementedError):                 # autograd on
+        m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, target_mapping=tm_t.to(DEV))
+    with torch.no_grad():
+        with pytest.raises(NotImplementedError):
+            m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, target_mapping=tm_t.to(DEV), output_attentions=True)
+        with pytest.raises(NotImplementedError):
+            m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, target_mapping=tm_t.to(DEV),
+              mems=[torch.zeros(8, B, 768) for _ in range(layers)])
+        with pytest.raises(ValueError):
+            m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, target_mapping=tm_t[:, :, :-1].to(DEV))
+        m.train()
+        with pytest.raises(NotImplementedError):
+            m(ids, vis, aco, token_type_ids=seg, attention_mask=mask, target_mapping=tm_t.to(DEV))
+
+
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 def test_perm_mask_gradients_vs_oracle(cdt):
     """train mode (every dropout p = 0), a random perm_mask plus ragged padding, L = 72 (two strip groups): logits and every
