@@ -922,7 +922,9 @@ def main():
                    "peak": 8000.0, "unit": "GB/s", "frac": round(ach_h / 8.0, 4), "traffic": None, "avg_us": round(adamw_in_step_us, 2),
                    "launches_per_step": 2, "ms_per_step": round(adamw_in_step_us * 1e-3, 4), "algorithmic_bytes": int(alg),
                    "bytes_moved_by_design": int(moved), "achieved_on_bytes_moved_gbs": round(moved / adamw_in_step_us * 1e-3, 1),
-                   "timing": "HIP events on the launch stream, in-step (first launch issued -> second complete, median of 6 steps)"}
+                   "timing": "HIP events on the launch stream, in-step (first launch issued -> second complete, median of 6 steps); the engine's "
+                             "profiling mode turns the AdamW riders off, so this is the WHOLE update as the end-of-step sweep (the timed steps of `value` "
+                             "run with riders: roofline_trace prices the sweep they leave)"}
         # HBM-side bytes per launch: PMC counters cannot be collected from inside this process; they are REPLAYED from the committed
         # rocprofv3 passes over this same step (profiles/pmc_traffic.json, written by scripts/gpu_artifacts.sh)
         try:
@@ -933,7 +935,7 @@ def main():
                     e = pm.get("kernels", {}).get(key)
                     if blk is not None and e:
                         blk["traffic"] = e["fetch_bytes"] + e["write_bytes"]
-                        blk["traffic_unit"] = "bytes/launch" if key != "adamw" else "bytes/step (both launches)"
+                        blk["traffic_unit"] = "bytes/launch" if key != "adamw" else "bytes/step (the sweep launches of the committed pass: riders on, %s M parameters swept)" % round(e.get("algorithmic_bytes", 0) / 28e6, 1)
                         blk["traffic_replayed"] = True
                         blk["traffic_source"] = pm["source"]
                         blk.setdefault("algorithmic_bytes", e.get("algorithmic_bytes"))
@@ -967,7 +969,7 @@ def main():
                     if "adamw" in top["kernel"]:
                         e_ = pm_["kernels"].get("adamw")
                         if e_:
-                            top["traffic"] = (e_["fetch_bytes"] + e_["write_bytes"]) // 2
+                            top["traffic"] = (e_["fetch_bytes"] + e_["write_bytes"]) // int(e_.get("launches_per_step", 2))
                     else:
                         e_ = next((v_ for k_, v_ in pm_.get("by_symbol", {}).items() if top["kernel"].startswith(k_) or k_.startswith(top["kernel"][:90])), None)
                         if e_:

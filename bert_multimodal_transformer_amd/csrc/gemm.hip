@@ -535,6 +535,21 @@ __global__ void __launch_bounds__(NW * 64) gemm2_kernel(const GemmArgs p) {
     gemm2_body<T, BM, BN, AK, BK, MODE, NSTAGE, KB, KS, NW>(p, m0, n0, blockIdx.y, smem);
 }
 
+// The same kernel with AdamW riders (kernels.h AdamRide) in front of its tiles: a 64 x 64 launch of 456 tiles leaves 312 of the 768 block
+// slots (three 48-KB rings per CU) empty on CUs whose memory pipes are mostly idle -- the tiles are bound by LDS reads and MFMA issue, the
+// update by HBM.  A symbol of its own: the plain kernel's name is what profiles and PMC tables are keyed by.
+template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB>
+__global__ void __launch_bounds__(256) gemm2_ride_kernel(const GemmArgs p, const AdamRide ride) {
+    __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB, false>::BYTES];
+    if ((int)blockIdx.x < ride.blocks) {
+        adam_ride_block<256, 3>(ride, (int)blockIdx.x);
+        return;
+    }
+    int m0, n0;
+    if (!tile_origin<BM, BN>(p, m0, n0, (int)blockIdx.x - ride.blocks)) return;
+    gemm2_body<T, BM, BN, AK, BK, MODE, NSTAGE, KB, false, 4>(p, m0, n0, 0, smem);
+}
+
 // Grouped wgrad: up to MB_MAX_GROUP independent dW += dY^T X problems in ONE launch.  Each of a layer's four weight
 // gradients alone is at most ~2 blocks per CU (one under-filled round whose duration is set by the K = T loop latency,
 // not by its size); launched together they are one grid of ~7 blocks per CU that keeps every CU's LDS ring full.
@@ -707,6 +722,41 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
     } else {
         MB_GEMM_LAUNCH((gemm_kernel<T, BM, BN, AK, BK, MODE>), grid, dim3(256), st, p, &p, 1);
     }
+    return (int)hipGetLastError();
+}
+
+// A dgrad launch (GEMM_NN, EPI_ADD_RES, bf16) that the 64 x 64 three-slot kernel takes, with riders: -> the padded tile count of that launch
+// (what launch_tile / launch_cfg above would pick for it), 0 = not this kernel.  `fill` = false: only asks.
+static int nn_ride_cfg(const GemmArgs& a, GemmArgs& p) {
+    constexpr int BKE = 64, EPV = 8;
+    p = a;
+    if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
+    static int plain = -1;          // every selection switch of launch_tile / launch_cfg at its default (else: the plain launch, no riders)
+    if (plain < 0)
+        plain = (env_int("MB_GEMM_TRACE", 0) == 0 && env_int("MB_GEMM_TILE_N768", 64) == 64 && env_int("MB_GEMM_64_STAGES", 3) == 3 &&
+                 env_int("MB_GEMM_KSPLIT", 0) == 0) ? 1 : 0;
+    if (g_impl == 1 || g_stages > 0 || !plain || a.bseg > 0) return 0;
+    const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (t128 >= 224 || a.N % 64 != 0 || a.N % 8 != 0 || a.ldc % 8 != 0) return 0;
+    if ((a.K % BKE) || (a.lda % EPV) || (a.ldb % EPV) || (((uintptr_t)a.A | (uintptr_t)a.B) % 16) || a.K / BKE < 2) return 0;
+    const int tiles = choose_regions<64, 64>(p);
+    if (tiles > 512) return 0;
+    p.kchunk = p.K;
+    p.dbg = g_dbg;
+    p.trace = nullptr;
+    return tiles;
+}
+int gemm_nn_ride_tiles(int dtype, const GemmArgs& a) {
+    GemmArgs p;
+    return dtype == DT_BF16 ? nn_ride_cfg(a, p) : 0;
+}
+int gemm_nn_ride_launch(int dtype, const GemmArgs& a, const AdamRide& ride, hipStream_t st) {
+    GemmArgs p;
+    const int tiles = dtype == DT_BF16 ? nn_ride_cfg(a, p) : 0;
+    if (tiles <= 0 || ride.blocks <= 0 || (ride.blocks & 7)) return MB_ERR_MODE;
+    gemm_log((const void*)(gemm2_ride_kernel<bf16, 64, 64, false, true, EPI_ADD_RES, 3, 128>), st, &p, 1);
+    gemm_log_ride(ride);
+    hipLaunchKernelGGL((gemm2_ride_kernel<bf16, 64, 64, false, true, EPI_ADD_RES, 3, 128>), dim3(tiles + ride.blocks), dim3(256), 0, st, p, ride);
     return (int)hipGetLastError();
 }
 

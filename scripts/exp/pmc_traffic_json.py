@@ -21,13 +21,21 @@ pick = lambda t, key: next(((n, v) for k, (n, v) in t.items() if key in k), (0, 
 doc = {"workload": tag, "kernels": {},
        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/bin/step_bench (separate passes, kernels launched one by one), "
                  "FETCH x2 on gfx950 per MI355X_MICROARCH.md, calibrated on the optimizer's known read volume"}
-nf, f = pick(fe, "grouped_tn_kernelIDF16bLi128"); nw, w = pick(wr, "grouped_tn_kernelIDF16bLi128")
+# the layers' grouped weight gradient: the ping-pong kernel (round 6), else the 128 x 128 grouped kernel
+key = "gemm_pp_grouped_tn_kernel" if any("gemm_pp_grouped_tn_kernel" in k for k in fe) else "grouped_tn_kernelIDF16bLi128"
+nf, f = pick(fe, key); nw, w = pick(wr, key)
 doc["kernels"]["wgrad_grouped"] = {"fetch_bytes": int(2 * f * 1024), "write_bytes": int(w * 1024), "algorithmic_bytes": 88080384,
-                                   "note": "per launch; algorithmic = dY 33.6 MB + X 26.1 MB read + dW 28.3 MB stored (known-zero gradients)"}
-nf, f = pick(fe, "adamw"); nw, w = pick(wr, "adamw")
-# two launches per step (decay / no-decay group): the table holds the mean over both, so x2 = bytes per step
-doc["kernels"]["adamw"] = {"fetch_bytes": int(2 * f * 1024 * 2), "write_bytes": int(w * 1024 * 2), "algorithmic_bytes": 28 * 110853121,
-                           "note": "per step (both launches); reads p, g, m, v = 16 B/param = 1.774 GB: the calibration point of the x2 correction"}
+                                   "note": "per launch (mean over the 12 layers' launches); algorithmic = dY 33.6 MB + X 26.1 MB read + dW 28.3 MB stored "
+                                           "(known-zero gradients).  Since round 6 eleven of the twelve launches also carry AdamW riders "
+                                           "(csrc/kernels.h AdamRide: ~2.43 M parameters each = 39 MB read + 44 MB written by design), included here"}
+steps = max(1, nf // 12)                      # 12 layers -> one grouped launch per layer and step
+na, f = pick(fe, "adamw"); nw, w = pick(wr, "adamw")
+lps = max(1, round(na / steps))               # sweep launches per step: 2 without riders (decay / no-decay), 3 with (two decay ranges around the ridden one)
+ridden = 11 * 2432000 if lps == 3 else 0
+doc["kernels"]["adamw"] = {"fetch_bytes": int(2 * f * 1024 * lps), "write_bytes": int(w * 1024 * lps), "launches_per_step": lps,
+                           "algorithmic_bytes": 28 * (110853121 - ridden),
+                           "note": "per step (the %d sweep launches%s); reads p, g, m, v = 16 B/param: the calibration point of the x2 correction"
+                                   % (lps, "; %.1f M of the 110.9 M parameters are updated by riders inside the weight-gradient launches instead" % (ridden / 1e6) if ridden else "")}
 # every symbol both passes saw, keyed by the first 90 characters of its name (what pmc_reduce.py keeps): bench.py looks its
 # in-run trace's dominant symbol up here, whichever kernel that is
 doc["by_symbol"] = {k: {"launches": n, "fetch_bytes": int(2 * v * 1024), "write_bytes": int(wr[k][1] * 1024)}

@@ -9,9 +9,8 @@ with open(path) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")))
 rows.sort()
-ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[2]]
-# two adamw launches per step (decay / no-decay): step boundary = end of every 2nd
-ends = ad[1::2]
+is_ad = [("adamw" in r[2] and "tail" not in r[2]) for r in rows]
+ends = [i for i in range(len(rows)) if is_ad[i] and (i + 1 == len(rows) or not is_ad[i + 1])]      # a step ends at the last launch of its AdamW run
 lo, hi = ends[-steps - 1] + 1, ends[-1] + 1
 seg = rows[lo:hi]
 t0, t1 = seg[0][0], max(r[1] for r in seg)
