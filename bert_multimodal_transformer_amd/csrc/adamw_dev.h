@@ -52,6 +52,7 @@ template <bool NT> __device__ __forceinline__ void adam_update_store(AdamQuad q,
 // stored.  Same arithmetic, same order as adamw_var_kernel (adam_update_store, contraction off): the same bits.
 template <int NTHREADS, int UNR>
 __device__ __forceinline__ void adam_ride_block(const AdamRide& r, int rb) {
+    if (r.n4 == 0) return;
     const AdamArgs a = *r.dyn;
     const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
     const float decay = a.lr * a.weight_decay;

@@ -647,6 +647,9 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                 for (GemmArgs& a : wg) a.overwrite = e->ow_pass ? 1 : 0;       // whole-tile, no split-K launches only
             const bool inl = grouped && !e->deferred;         // grouped launch in line on the caller's stream (no overlap)
             // dX = dY . W + R (GEMM_NN, EPI_ADD_RES), with riders when the launch is the 64 x 64 three-slot kernel and leaves block slots free
+            // (Touching the forward activations the grouped weight gradient multiplies with -- g, y1, x_l, 22 MB from HBM -- makes that launch
+            //  1.2 .. 3.2 us faster, but every carrier tried pays more than that: separate launches 3 x 4.7 us, the attention backward +1.8 ..
+            //  2.2 us (register or LDS-DMA loads), these riders +3.3 us per dgrad launch: profiles/r06_wgrad_operand_touch.txt)
             auto dgrad_res = [&](int Mo, int No, int Ko, const void* dY, int ldy, const void* Wt, int ldw, void* dX, int ldx, const void* R, int ldr) -> int {
                 if (e->ride_dgrad && inl && e->ride_m) {
                     GemmArgs a = {};

@@ -539,14 +539,20 @@ __global__ void __launch_bounds__(NW * 64) gemm2_kernel(const GemmArgs p) {
 // slots (three 48-KB rings per CU) empty on CUs whose memory pipes are mostly idle -- the tiles are bound by LDS reads and MFMA issue, the
 // update by HBM.  A symbol of its own: the plain kernel's name is what profiles and PMC tables are keyed by.
 template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB>
-__global__ void __launch_bounds__(256) gemm2_ride_kernel(const GemmArgs p, const AdamRide ride) {
+__global__ void __launch_bounds__(256, 3) gemm2_ride_kernel(const GemmArgs p, const AdamRide ride) {
+    // (three waves per SIMD = three blocks per CU, like the plain kernel: left alone the rider branch took the kernel to 200 registers,
+    //  two blocks per CU, and the 456 tiles to a second round -- +3.7 us per launch whatever the riders did)
     __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB, false>::BYTES];
-    if ((int)blockIdx.x < ride.blocks) {
-        adam_ride_block<256, 3>(ride, (int)blockIdx.x);
+    // riders LAST in the grid (unlike the grouped launch, whose riders want whole CUs): the tiles are placed as in the plain launch, at most
+    // two per CU, and the riders take what is left.  In front of the tiles, 128 rider workgroups that did almost nothing cost the launch
+    // 3.3 us -- some CUs then hold three tiles (profiles/r06_wgrad_operand_touch.txt)
+    const int tiles = (int)gridDim.x - ride.blocks;
+    if ((int)blockIdx.x >= tiles) {
+        adam_ride_block<256, 2>(ride, (int)blockIdx.x - tiles);
         return;
     }
     int m0, n0;
-    if (!tile_origin<BM, BN>(p, m0, n0, (int)blockIdx.x - ride.blocks)) return;
+    if (!tile_origin<BM, BN>(p, m0, n0, (int)blockIdx.x)) return;
     gemm2_body<T, BM, BN, AK, BK, MODE, NSTAGE, KB, false, 4>(p, m0, n0, 0, smem);
 }
 
@@ -601,7 +607,7 @@ void gemm_log(const void* fn, hipStream_t st, const GemmArgs* p, int count) {
 
 void gemm_log_ride(const AdamRide& r) {
     if (g_gemm_log < 0) g_gemm_log = env_int("MB_GEMM_LOG", 0);
-    if (g_gemm_log && r.blocks > 0) fprintf(stderr, "[magbert ride] params=%zu blocks=%d\n", r.n4 * 4, r.blocks);
+    if (g_gemm_log && r.blocks > 0 && r.n4 > 0) fprintf(stderr, "[magbert ride] params=%zu blocks=%d\n", r.n4 * 4, r.blocks);      // (not the touch-only riders)
 }
 
 static unsigned long long* g_trace = nullptr;       // MB_GEMM_TRACE=1: device buffer of phase stamps, [kTraceBlocks][8]
