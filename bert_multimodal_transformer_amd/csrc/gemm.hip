@@ -565,9 +565,13 @@ __device__ __forceinline__ void grouped_tn_block(const GroupedGemmArgs& ga) {
     __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB>::BYTES];
     // (A persistent variant that holds only one LDS slot per CU -- MB_GROUP_GRID = 128 / 256 / 384 blocks looping over the 432
     //  tiles -- was measured: no gain at 384, slower below; the launch is needed at full width to finish inside its layer.)
-    if ((int)blockIdx.x < ga.ride.blocks) {          // rider: an optimizer update in a slot no tile needs (kernels.h AdamRide)
-        adam_ride_block<256, 3>(ga.ride, (int)blockIdx.x);
-        return;
+    // rider: an optimizer update in a slot no tile needs (kernels.h AdamRide).  Only the layers' groups (128 x 128 and larger tiles) carry
+    // them: the branch costs registers (the 64 x 64 kernels of MAG's group went from 48 - 72 to 196 - 200 with it)
+    if constexpr (BM >= 128) {
+        if ((int)blockIdx.x < ga.ride.blocks) {
+            adam_ride_block<256, 3>(ga.ride, (int)blockIdx.x);
+            return;
+        }
     }
     int g, m0, n0;
     if (!grouped_tile_origin<BM, BN>(ga, g, m0, n0)) return;
@@ -830,7 +834,7 @@ static int launch_grouped(const GemmArgs* probs, int count, hipStream_t st, int 
     ga.count = count;
     ga.ride = AdamRide{};
     if (ride && ride->blocks > 0 && ride->n4 > 0) {
-        if (ride->blocks % 8 || adam) return MB_ERR_ARG;
+        if (ride->blocks % 8 || adam || BM < 128) return MB_ERR_ARG;
         ga.ride = *ride;
     }
     static int g_map = -1;           // MB_GROUP_MAP=0: round-1 placement (eight XCD regions inside every problem)

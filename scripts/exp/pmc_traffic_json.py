@@ -31,7 +31,15 @@ doc["kernels"]["wgrad_grouped"] = {"fetch_bytes": int(2 * f * 1024), "write_byte
 steps = max(1, nf // 12)                      # 12 layers -> one grouped launch per layer and step
 na, f = pick(fe, "adamw"); nw, w = pick(wr, "adamw")
 lps = max(1, round(na / steps))               # sweep launches per step: 2 without riders (decay / no-decay), 3 with (two decay ranges around the ridden one)
-ridden = 11 * 2432000 if lps == 3 else 0
+# parameters the sweep launches of one step cover: the library's own log of the pass (MB_GEMM_LOG=1: one "[magbert adamw] n=" line per launch)
+swept = None
+try:
+    ns = [int(l.split("=")[1]) for l in open(d + "/pmc_adamw_log.txt") if l.startswith("[magbert adamw] n=")]
+    if len(ns) >= lps:
+        swept = sum(ns[-lps:])
+except OSError:
+    pass
+ridden = (110853121 - swept) if swept else (11 * 2432000 if lps == 3 else 0)
 doc["kernels"]["adamw"] = {"fetch_bytes": int(2 * f * 1024 * lps), "write_bytes": int(w * 1024 * lps), "launches_per_step": lps,
                            "algorithmic_bytes": 28 * (110853121 - ridden),
                            "note": "per step (the %d sweep launches%s); reads p, g, m, v = 16 B/param: the calibration point of the x2 correction"

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 f=$(find /tmp/p_tr -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 scripts/exp/instep_json.py $f 8 "bert B=48 L=50 bf16" $O/instep_kernels.json > $O/instep_kernels.txt
 f=$(find /tmp/p_tr -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/step_kernel_stats.csv
 for set in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && rm -rf /tmp/p_$set && timeout 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/p_$set -o p -- $SB --graph 2 --h2d 2 --steps 6 --warmup 2 > /dev/null 2>&1 )
+  ( cd /tmp && rm -rf /tmp/p_$set && MB_GEMM_LOG=1 timeout 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/p_$set -o p -- $SB --graph 2 --h2d 2 --steps 6 --warmup 2 2>&1 > /dev/null | grep "magbert adamw" | tail -n 8 > $O/pmc_adamw_log.txt )
   f=$(find /tmp/p_$set -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 scripts/exp/pmc_reduce.py $f $set > $O/pmc_$set.txt
 done
 python3 scripts/exp/pmc_traffic_json.py $O "bert B=48 L=50 bf16" $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1 && cp $O/pmc_traffic.json profiles/pmc_traffic.json
