@@ -68,10 +68,12 @@ struct mb_bert_engine : StepMixin {
     float* ride_m = nullptr; float* ride_v = nullptr;       // Adam moments of the step being enqueued, when riders apply to it
     size_t ride_cursor = 0;                                 // the riders of the step being enqueued have taken [ride_cursor, wp) of the decay slab
     long ride_params = 0;                                   // MB_ADAMW_RIDE_PARAMS: parameters per launch (0 = by the token count)
-    // MB_ADAMW_RIDE_DGRAD=1: riders also in the two 64 x 64 dgrad launches of a layer (ffn1, qkv: 456 tiles in 768 block slots at T = 2400;
-    // kernels.h gemm_nn_ride_launch).  _PARAMS: parameters per such launch (0 = by the launch's FLOPs), _BLOCKS: rider workgroups (0 = every free slot)
-    int ride_dgrad = 1, ride_dgrad_blocks = 0;
-    long ride_dgrad_params = 0;
+    // MB_ADAMW_RIDE_DGRAD >= 1: riders also in the two 64 x 64 dgrad launches of a layer (ffn1, qkv: 456 tiles in 768 block slots at T = 2400;
+    // kernels.h gemm_nn_ride_launch), 2 (default): and in the 128 x 128 ffn2 dgrad (456 tiles in 512 slots: 56 CUs hold one tile).
+    // _PARAMS: parameters per 64 x 64 launch (0 = by the launch's FLOPs), _DGELU_PARAMS: per ffn2 launch (0 = 14,336 per free slot),
+    // _BLOCKS: rider workgroups (0 = every free slot).  Same box: 3.422 ms off | 3.411 (1) | 3.401 (2)  (profiles/r06_adamw_ride_dgrad.txt)
+    int ride_dgrad = 2, ride_dgrad_blocks = 0;
+    long ride_dgrad_params = 0, ride_dgelu_params = 0;      // (MB_ADAMW_RIDE_DGRAD=2: also the ffn2 dgrad; _DGELU_PARAMS: parameters per such launch)
     int group_wgrad = 256;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128 | 256 = 256 x 128 ping-pong), 0 = four launches
     bool grouped = false;          // the layer's four weight gradients are ONE launch
     bool deferred = false;         // ... on the side stream, joined one stage later (MB_OVERLAP_WGRAD=0: on the caller's stream, in line)
@@ -406,6 +408,7 @@ int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
     if (const char* v = getenv("MB_ADAMW_RIDE_DGRAD")) e->ride_dgrad = atoi(v);
     if (const char* v = getenv("MB_ADAMW_RIDE_DGRAD_BLOCKS")) e->ride_dgrad_blocks = atoi(v);
     if (const char* v = getenv("MB_ADAMW_RIDE_DGRAD_PARAMS")) e->ride_dgrad_params = atol(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE_DGELU_PARAMS")) e->ride_dgelu_params = atol(v);
     if (const char* v = getenv("MB_DETERMINISTIC")) e->deterministic = atoi(v);
     if (const char* v = getenv("MB_ADAMW_OVERLAP")) e->opt_chunk = atoi(v);
     if (const char* v = getenv("MB_PREFETCH")) e->prefetch = atoi(v);
@@ -650,24 +653,30 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             // (Touching the forward activations the grouped weight gradient multiplies with -- g, y1, x_l, 22 MB from HBM -- makes that launch
             //  1.2 .. 3.2 us faster, but every carrier tried pays more than that: separate launches 3 x 4.7 us, the attention backward +1.8 ..
             //  2.2 us (register or LDS-DMA loads), these riders +3.3 us per dgrad launch: profiles/r06_wgrad_operand_touch.txt)
-            auto dgrad_res = [&](int Mo, int No, int Ko, const void* dY, int ldy, const void* Wt, int ldw, void* dX, int ldx, const void* R, int ldr) -> int {
-                if (e->ride_dgrad && inl && e->ride_m) {
+            // (mode EPI_DGELU: the ffn2 dgrad with the fused bias gradient `colsum`; 56 of its CUs hold one tile instead of two)
+            auto dgrad_ride = [&](int mode, int Mo, int No, int Ko, const void* dY, int ldy, const void* Wt, int ldw, void* dX, int ldx, const void* R, int ldr,
+                                  float* colsum) -> int {
+                if (e->ride_dgrad && inl && e->ride_m && (mode == EPI_ADD_RES || e->ride_dgrad >= 2)) {
                     GemmArgs a = {};
                     a.A = dY; a.B = Wt; a.M = Mo; a.N = No; a.K = Ko; a.lda = ldy; a.ldb = ldw; a.C = dX; a.ldc = ldx; a.R = R; a.ldr = ldr;
-                    a.alpha = 1.0f; a.drop = kNoDrop; a.kchunk = Ko;
-                    const int tiles = gemm_nn_ride_tiles(dt, a);
-                    const int blocks = tiles > 0 ? (e->ride_dgrad_blocks > 0 ? e->ride_dgrad_blocks : 3 * e->cu_count() - tiles) / 8 * 8 : 0;
+                    a.alpha = 1.0f; a.drop = kNoDrop; a.kchunk = Ko; a.colsum = colsum; a.acc = acc;
+                    int per_cu = 0;
+                    const int tiles = gemm_nn_ride_tiles(dt, mode, a, &per_cu);
+                    const int blocks = tiles > 0 ? (e->ride_dgrad_blocks > 0 ? e->ride_dgrad_blocks : per_cu * e->cu_count() - tiles) / 8 * 8 : 0;
                     if (blocks >= 8) {
                         // what the free slots stream while the tiles multiply, by the launch's size: 1.25 M parameters next to 11.3 GFLOP.  The
                         // riders share SIMDs with the tiles here (every instruction of theirs costs the partner wave an MFMA slot), so the
                         // gain is small and turns at ~1.5 M: same box, 3.566 ms without | 3.544 at 1 - 1.5 M | 3.578 at 2.5 M per launch; in
                         // place of the weight-gradient riders 3.62 (profiles/r06_adamw_ride_dgrad.txt)
-                        const size_t budget = e->ride_dgrad_params > 0 ? (size_t)e->ride_dgrad_params
-                                                                       : (size_t)(1.25e6 * ((double)Mo * No * Ko) / (2400.0 * 768.0 * 3072.0)) / 1024 * 1024;
+                        size_t budget = e->ride_dgrad_params > 0 ? (size_t)e->ride_dgrad_params
+                                                                 : (size_t)(1.25e6 * ((double)Mo * No * Ko) / (2400.0 * 768.0 * 3072.0)) / 1024 * 1024;
+                        if (mode == EPI_DGELU) budget = e->ride_dgelu_params > 0 ? (size_t)e->ride_dgelu_params : (size_t)blocks * 14336;      // (56 half-idle CUs)
                         const AdamRide r = take_ride(l, budget, blocks);
-                        if (r.blocks) return gemm_nn_ride_launch(dt, a, r, st);
+                        if (r.blocks) return gemm_nn_ride_launch(dt, mode, a, r, st);
                     }
                 }
+                if (mode == EPI_DGELU)
+                    return gemm(dt, GEMM_NN, EPI_DGELU, Mo, No, Ko, dY, ldy, Wt, ldw, dX, ldx, nullptr, colsum, nullptr, R, ldr, kNoDrop, 1, 0, st, 0, 0, acc);
                 return gemm(dt, GEMM_NN, EPI_ADD_RES, Mo, No, Ko, dY, ldy, Wt, ldw, dX, ldx, nullptr, nullptr, nullptr, R, ldr, kNoDrop, 1, 0, st);
             };
             int wtile = e->group_wgrad;
@@ -678,13 +687,12 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, ss));
             }
             // du = (dzd . W2) * gelu'(u), with the intermediate bias gradient (column sums of du) fused into the epilogue
-            CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, du, I, nullptr, G + o.b1, nullptr,
-                    ws + w.u, I, kNoDrop, 1, 0, st, 0, 0, acc));
+            CK(dgrad_ride(EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, du, I, ws + w.u, I, G + o.b1));
             if (!grouped) {
             CK(fork(1));
             CK(wgrad(dt, I, H, Tk, du, I, ws + w.y1, H, G + o.w1, H, ss));
             }
-            CK(dgrad_res(T, H, I, du, I, e->W(o.w1), H, dy1, H, dsA, H));
+            CK(dgrad_ride(EPI_ADD_RES, T, H, I, du, I, e->W(o.w1), H, dy1, H, dsA, H, nullptr));
             // LN1 + dropout backward
             Prefetch pf_attn = {e->prefetch ? e->W(o.wqkv) : nullptr, (size_t)4 * H * H * (dt == DT_BF16 ? 2 : 4), nullptr};
             if (e->prefetch && e->pf_qkv > 0) {
@@ -756,7 +764,7 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                 CK(fork(3));
                 CK(wgrad(dt, 3 * H, H, Tk, dqkv, 3 * H, ws + e->ws_x[l], H, G + o.wqkv, H, ss));
             }
-            if (!fuse) CK(dgrad_res(T, H, 3 * H, dqkv, 3 * H, e->W(o.wqkv), H, dx, H, dsB, H));
+            if (!fuse) CK(dgrad_ride(EPI_ADD_RES, T, H, 3 * H, dqkv, 3 * H, e->W(o.wqkv), H, dx, H, dsB, H, nullptr));
             if (ss != st && !grouped) {      // join: the stage's gradients are complete (and dY buffers reusable) once main passes this
                 CK((int)hipEventRecord(sev[4], ss));
                 CK((int)hipStreamWaitEvent(st, sev[4], 0));

@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(NW * 64) gemm2_kernel(const GemmArgs p) {
 // slots (three 48-KB rings per CU) empty on CUs whose memory pipes are mostly idle -- the tiles are bound by LDS reads and MFMA issue, the
 // update by HBM.  A symbol of its own: the plain kernel's name is what profiles and PMC tables are keyed by.
 template <class T, int BM, int BN, bool AK, bool BK, int MODE, int NSTAGE, int KB>
-__global__ void __launch_bounds__(256, 3) gemm2_ride_kernel(const GemmArgs p, const AdamRide ride) {
+__global__ void __launch_bounds__(256, BM == 64 ? 3 : 2) gemm2_ride_kernel(const GemmArgs p, const AdamRide ride) {
     // (three waves per SIMD = three blocks per CU, like the plain kernel: left alone the rider branch took the kernel to 200 registers,
     //  two blocks per CU, and the 456 tiles to a second round -- +3.7 us per launch whatever the riders did)
     __shared__ __attribute__((aligned(1024))) char smem[Gemm2Smem<BM, BN, NSTAGE, KB, false>::BYTES];
@@ -735,38 +735,51 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// A dgrad launch (GEMM_NN, EPI_ADD_RES, bf16) that the 64 x 64 three-slot kernel takes, with riders: -> the padded tile count of that launch
-// (what launch_tile / launch_cfg above would pick for it), 0 = not this kernel.  `fill` = false: only asks.
-static int nn_ride_cfg(const GemmArgs& a, GemmArgs& p) {
+// A dgrad launch (GEMM_NN, bf16) with riders, for the two configurations that leave block slots free at T = 2400:
+//   EPI_ADD_RES, N = 768  : the 64 x 64 three-slot kernel, 456 tiles in 768 slots (three 48-KB rings per CU)
+//   EPI_DGELU,  N = 3072  : the 128 x 128 two-slot kernel, 456 tiles in 512 slots -- 56 CUs hold ONE tile and are half idle throughout
+// -> the padded tile count of the launch launch_tile / launch_cfg above would make of `a` (and the block slots per CU), 0 = another kernel.
+static int nn_ride_cfg(int mode, const GemmArgs& a, GemmArgs& p, int* per_cu) {
     constexpr int BKE = 64, EPV = 8;
     p = a;
     if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
     static int plain = -1;          // every selection switch of launch_tile / launch_cfg at its default (else: the plain launch, no riders)
     if (plain < 0)
         plain = (env_int("MB_GEMM_TRACE", 0) == 0 && env_int("MB_GEMM_TILE_N768", 64) == 64 && env_int("MB_GEMM_64_STAGES", 3) == 3 &&
-                 env_int("MB_GEMM_KSPLIT", 0) == 0) ? 1 : 0;
+                 env_int("MB_GEMM_KSPLIT", 0) == 0 && env_int("MB_GEMM_TILE_BIG", 0) == 0) ? 1 : 0;
     if (g_impl == 1 || g_stages > 0 || !plain || a.bseg > 0) return 0;
+    if (mode != EPI_ADD_RES && mode != EPI_DGELU) return 0;
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (t128 >= 224 || a.N % 64 != 0 || a.N % 8 != 0 || a.ldc % 8 != 0) return 0;
+    const bool big = t128 >= 224;
+    if (big != (mode == EPI_DGELU)) return 0;
+    const int bn = big ? 128 : 64;
+    if (a.N % bn != 0 || a.N % 8 != 0 || a.ldc % 8 != 0) return 0;
     if ((a.K % BKE) || (a.lda % EPV) || (a.ldb % EPV) || (((uintptr_t)a.A | (uintptr_t)a.B) % 16) || a.K / BKE < 2) return 0;
-    const int tiles = choose_regions<64, 64>(p);
+    const int tiles = big ? choose_regions<128, 128>(p) : choose_regions<64, 64>(p);
     if (tiles > 512) return 0;
+    if (per_cu) *per_cu = big ? 2 : 3;
     p.kchunk = p.K;
     p.dbg = g_dbg;
     p.trace = nullptr;
+    if (mode == EPI_DGELU && p.colsum == nullptr && p.Cf != nullptr) { p.colsum = p.Cf; p.Cf = nullptr; }      // (as engine_common.h gemm())
     return tiles;
 }
-int gemm_nn_ride_tiles(int dtype, const GemmArgs& a) {
+int gemm_nn_ride_tiles(int dtype, int mode, const GemmArgs& a, int* per_cu) {
     GemmArgs p;
-    return dtype == DT_BF16 ? nn_ride_cfg(a, p) : 0;
+    return dtype == DT_BF16 ? nn_ride_cfg(mode, a, p, per_cu) : 0;
 }
-int gemm_nn_ride_launch(int dtype, const GemmArgs& a, const AdamRide& ride, hipStream_t st) {
+int gemm_nn_ride_launch(int dtype, int mode, const GemmArgs& a, const AdamRide& ride, hipStream_t st) {
     GemmArgs p;
-    const int tiles = dtype == DT_BF16 ? nn_ride_cfg(a, p) : 0;
+    const int tiles = dtype == DT_BF16 ? nn_ride_cfg(mode, a, p, nullptr) : 0;
     if (tiles <= 0 || ride.blocks <= 0 || (ride.blocks & 7)) return MB_ERR_MODE;
-    gemm_log((const void*)(gemm2_ride_kernel<bf16, 64, 64, false, true, EPI_ADD_RES, 3, 128>), st, &p, 1);
     gemm_log_ride(ride);
-    hipLaunchKernelGGL((gemm2_ride_kernel<bf16, 64, 64, false, true, EPI_ADD_RES, 3, 128>), dim3(tiles + ride.blocks), dim3(256), 0, st, p, ride);
+    if (mode == EPI_DGELU) {
+        gemm_log((const void*)(gemm2_ride_kernel<bf16, 128, 128, false, true, EPI_DGELU, 2, 128>), st, &p, 1);
+        hipLaunchKernelGGL((gemm2_ride_kernel<bf16, 128, 128, false, true, EPI_DGELU, 2, 128>), dim3(tiles + ride.blocks), dim3(256), 0, st, p, ride);
+    } else {
+        gemm_log((const void*)(gemm2_ride_kernel<bf16, 64, 64, false, true, EPI_ADD_RES, 3, 128>), st, &p, 1);
+        hipLaunchKernelGGL((gemm2_ride_kernel<bf16, 64, 64, false, true, EPI_ADD_RES, 3, 128>), dim3(tiles + ride.blocks), dim3(256), 0, st, p, ride);
+    }
     return (int)hipGetLastError();
 }
 

@@ -100,11 +100,12 @@ struct GroupedGemmArgs {
     int chunk;                      // > 0: tiles per XCD of the group-wide XCD-compact placement (gemm.hip); 0: per-problem regions
     AdamRide ride;                  // ride.blocks > 0: that many workgroups in front of the tiles run an optimizer update instead
 };
-// A dgrad launch (GEMM_NN, EPI_ADD_RES) with riders: gemm_nn_ride_tiles -> the tile count (padded to 8) of the 64 x 64 three-slot bf16
-// launch gemm_launch would make of `a`, or 0 when it would pick anything else; gemm_nn_ride_launch: that launch with ride.blocks
-// (a multiple of 8) rider workgroups in front of the tiles (MB_ERR_MODE when gemm_nn_ride_tiles says 0).
-int gemm_nn_ride_tiles(int dtype, const GemmArgs& a);
-int gemm_nn_ride_launch(int dtype, const GemmArgs& a, const AdamRide& ride, hipStream_t st);
+// A dgrad launch (GEMM_NN; mode EPI_ADD_RES or EPI_DGELU) with riders: gemm_nn_ride_tiles -> the tile count (padded to 8) of the launch
+// gemm_launch would make of `a` when that is one of the two kernels that leave block slots free (64 x 64 three-slot, 128 x 128 two-slot;
+// *per_cu = block slots per CU), else 0; gemm_nn_ride_launch: that launch with ride.blocks (a multiple of 8) rider workgroups behind the
+// tiles (MB_ERR_MODE when gemm_nn_ride_tiles says 0).
+int gemm_nn_ride_tiles(int dtype, int mode, const GemmArgs& a, int* per_cu);
+int gemm_nn_ride_launch(int dtype, int mode, const GemmArgs& a, const AdamRide& ride, hipStream_t st);
 int gemm_grouped_tn_ok(int dtype, const GemmArgs* probs, int count, int tile);
 int gemm_grouped_tn_launch(int dtype, const GemmArgs* probs, int count, int tile, hipStream_t st, int stages = 0, bool adam = false,
                            const AdamRide* ride = nullptr);   // stages: 0 = MB_GROUP_STAGES, 4 | 5 = deeper ring (64 x 64 tiles only)
