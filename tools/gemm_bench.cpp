@@ -68,6 +68,11 @@ int main(int argc, char** argv) {
         {"dgrad ffn1 [T,3072]x[3072,768] +res", NN, 3, T, H, I, 1, 2, 0, 0},
         {"dgrad out  [T,768]x[768,768]", NN, 3, T, H, H, 0, 1, -1, 0},
         {"dgrad qkv  [T,2304]x[2304,768] +res", NN, 3, T, H, 3 * H, 2, 0, 0, 0},
+        // --only probe: half the k range of the three N = 768, K >= 2304 launches -- what ONE block of a two-way split-K would run
+        // (with --tile 128: 114 blocks, one per CU, as 228 such blocks would sit on 228 CUs)
+        {"probe half-K ffn2  [T,1536]x[768,1536]^T +bias+drop+res", NT, 2, T, H, I / 2, 1, 3, 0, 0},
+        {"probe half-K dffn1 [T,1536]x[1536,768] +res", NN, 3, T, H, I / 2, 1, 2, 0, 0},
+        {"probe half-K dqkv  [T,1152]x[1152,768] +res", NN, 3, T, H, 3 * H / 2, 2, 0, 0, 0},
     };
     void* W[4] = {wqkv, wo, w1, w2};
     const int ldw[4] = {H, H, H, I};
@@ -145,6 +150,7 @@ int main(int argc, char** argv) {
     };
     for (const Case& c : cases) {
         if (!only.empty() && !strstr(c.name, only.c_str())) continue;
+        if (only.empty() && strstr(c.name, "probe")) continue;          // (the probes only on request)
         auto launch = [&](int i) {
             const int s = i % nset;
             void* out = c.c == 0 ? o3[s] : c.c == 1 ? oi[s] : o3[s];
