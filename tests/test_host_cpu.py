@@ -542,3 +542,39 @@ def test_bench_refuses_to_run_fewer_ranks_than_asked(monkeypatch):
     with pytest.raises(SystemExit) as ex:
         bench.spawn_ranks(a)
     assert "only 4 device(s) visible" in str(ex.value) and ex.value.code not in (0, None)
+
+
+def test_rider_branches_do_not_cost_a_gemm_kernel_its_residency(tmp_path):
+    """kernels.h AdamRide: the rider branch (an AdamW update with several quads in flight) sits inside GEMM kernels, and registers are
+    allocated for the larger of a kernel's branches.  Round 6 found it had silently taken the 64 x 64 dgrad kernel from three blocks per
+    CU to two (200 registers: a second round of tiles, +3.7 us per launch) and MAG's 64 x 64 grouped kernels from 48-72 registers to
+    ~200.  Checked on the code-object metadata of the objects build() produced: blocks per CU by registers >= blocks per CU by LDS."""
+    import shutil
+    from bert_multimodal_transformer_amd import build as mb_build
+    mb_build.build(verbose=False)
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("llvm-objdump / llvm-readelf not in this image")
+    obj = shutil.copy(os.path.join(mb_build.LIBDIR, "obj", "gemm.o"), tmp_path / "gemm.o")
+    subprocess.run([objdump, "--offloading", str(obj)], check=True, capture_output=True, cwd=tmp_path)
+    dev = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    notes = subprocess.run([readelf, "--notes", str(tmp_path / dev[0])], check=True, capture_output=True, text=True).stdout
+    kernels, cur = {}, {}
+    for line in notes.splitlines():
+        m = re.match(r"\s+-?\s*\.(name|vgpr_count|vgpr_spill_count|group_segment_fixed_size|wavefront_size):\s+(\S+)", line)
+        if m:
+            cur[m.group(1)] = m.group(2)
+            if m.group(1) == "wavefront_size":
+                kernels[cur["name"]] = (int(cur["vgpr_count"]), int(cur["group_segment_fixed_size"]), int(cur.get("vgpr_spill_count", 0)))
+                cur = {}
+    by_reg = lambda v: 512 // ((v + 7) // 8 * 8)           # waves per SIMD = 256-thread blocks per CU
+    by_lds = lambda l: (160 * 1024) // l
+    checked = 0
+    for name, (vgpr, lds, spill) in kernels.items():
+        if "gemm2_ride_kernelIDF16b" in name or "gemm2_grouped_tn_kernelIDF16bLi64ELi64E" in name:
+            assert spill == 0 and by_reg(vgpr) >= min(by_lds(lds), 8), (name, vgpr, lds, spill)
+            checked += 1
+    assert checked >= 3, sorted(kernels)[:5]
+    # the layers' grouped kernels carry riders and stay at two blocks per CU (64 KB of LDS each)
+    g128 = [v for n, v in kernels.items() if "gemm2_grouped_tn_kernelIDF16bLi128ELi128ELi2ELi128E" in n]
+    assert g128 and by_reg(g128[0][0]) >= 2 and g128[0][2] == 0, g128
