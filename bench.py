@@ -540,8 +540,18 @@ def price_trace(rows, gemm_log, B, L, dtype, n_update, steps, model="bert"):
         f = flops.get(k) or flops.get(k.split("(")[0]) or flops_base.get(kernel_base(k))
         if f:
             per = f[1] / f[0]
-            roof.append(dict(row, bound="mfma", flop_per_launch=per, achieved=round(per / us * 1e-6, 1), peak=peak, unit="TFLOP/s",
-                             frac=round(per / us * 1e-6 / peak, 4), gflop_per_step=round(per * n / steps * 1e-9, 2)))
+            rr = dict(row, bound="mfma", flop_per_launch=per, achieved=round(per / us * 1e-6, 1), peak=peak, unit="TFLOP/s",
+                      frac=round(per / us * 1e-6 / peak, 4), gflop_per_step=round(per * n / steps * 1e-9, 2))
+            if ridden and "grouped_tn" in k and n % steps == 0 and n // steps > 1:
+                # the layers' grouped weight gradient carries AdamW riders in every launch but the FIRST of a step (nothing is final yet when
+                # the top layer's runs): that launch is the kernel's own duration, the average above includes the riders' tail
+                mine = [e_ - s_ for s_, e_, kk in seg if kk == k]
+                first = [mine[i] for i in range(0, len(mine), n // steps)]
+                us0 = sum(first) / len(first) / 1e3
+                rr["rider_free_avg_us"] = round(us0, 2)
+                rr["rider_free_frac"] = round(per / us0 * 1e-6 / peak, 4)
+                rr["rider_note"] = "avg_us / frac include the AdamW riders of 11 of the 12 launches per step; rider_free_* = the step's first launch (top layer: no rider)"
+            roof.append(rr)
         elif "adamw" in k and "tail" not in k:
             per_step = int(round(n / steps))                      # sweep launches per step
             n_swept = sum(swept[-per_step:]) if len(swept) >= per_step and per_step > 0 else n_update

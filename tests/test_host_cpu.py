@@ -522,6 +522,19 @@ def test_bench_prices_a_kernel_trace():
     assert abs(ad2["achieved"] - 28 * 80_000_000 / 3 / 100.0 * 1e-3) < 0.5 and doc2["adamw_riders"]["parameters_per_launch"] == 2_500_000
     top = bench.pick_roofline(doc2, roof2)
     assert top["kernel"] and "dominant_by" in top
+    # ... and the grouped launch's own duration is the step's FIRST launch (the top layer carries no rider), reported next to the average
+    rows3, t = [], 0
+    for step in range(4):
+        for name, dur, n in ((gemm_w, 40_000, 1), (gemm_a, 10_000, 1), (gemm_w, 50_000, 2), (adam, 100_000, 3)):
+            for _ in range(n):
+                rows3.append((t, t + dur, name)); t += dur + 500
+    log3 = "\n".join(["[magbert gemm] %s problems=4 flop=%d M=768 N=3072 K=%d" % (gemm_w, 2 * Tp * 768 * 3072 * 4, Tp)] * 3 +
+                     ["[magbert gemm] %s problems=1 flop=%d M=%d N=768 K=768" % (gemm_a, 2 * T * 768 * 768, T), "[magbert ride] params=2500000 blocks=40",
+                      "[magbert adamw] n=50000000", "[magbert adamw] n=20000000", "[magbert adamw] n=10000000"])
+    _, roof3 = bench.price_trace(rows3, log3, B, L, "bf16", 110_853_121, steps=3)
+    w3 = {r["kernel"][:20]: r for r in roof3}[gemm_w[:20]]
+    assert w3["launches_per_step"] == 3 and abs(w3["avg_us"] - 140.0 / 3) < 0.01 and w3["rider_free_avg_us"] == 40.0
+    assert abs(w3["rider_free_frac"] / w3["frac"] - (140.0 / 3) / 40.0) < 1e-2
     assert bench.kernel_base("_ZN2mb25gemm_pp_grouped_tn_kernelENS_15GroupedGemmArgsE") == bench.kernel_base("mb::gemm_pp_grouped_tn_kernel(mb::GroupedGemmArgs)")
     assert bench.kernel_base("void mb::adamw_var_kernel<true, 2, true>(float*)") == "mb::adamw_var_kernel"
 
