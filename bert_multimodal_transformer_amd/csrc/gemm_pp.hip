@@ -28,6 +28,10 @@
 #include "gemm_tile.h"
 #include "adamw_dev.h"
 
+#ifndef MB_RIDE_UNR
+#define MB_RIDE_UNR 3          // quads in flight per thread and pipeline stage of a rider workgroup (A/B builds: -DMB_RIDE_UNR=4|5|6)
+#endif
+
 namespace mb {
 
 constexpr int kPpBM = 256, kPpBN = 128, kPpKB = 128, kPpSlots = 3, kPpWaves = 8;
@@ -271,7 +275,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmArgs p) {
 __global__ void __launch_bounds__(512) gemm_pp_grouped_tn_kernel(const GroupedGemmArgs ga) {
     __shared__ __attribute__((aligned(1024))) char smem[kPpSlots * kPpStage];
     if ((int)blockIdx.x < ga.ride.blocks) {          // rider: an optimizer update on a CU that has no tile (kernels.h AdamRide)
-        adam_ride_block<512, 3>(ga.ride, (int)blockIdx.x);
+        adam_ride_block<512, MB_RIDE_UNR>(ga.ride, (int)blockIdx.x);
         return;
     }
     int g, m0, n0;
