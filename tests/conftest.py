@@ -26,3 +26,22 @@ def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
+
+
+@pytest.fixture(autouse=True)
+def _free_big_tmp_files(request):
+    """The multi-process tests hand their results over as torch.save files of 150-450 MB each (flat parameters, moments); pytest keeps every
+    test's tmp_path until the session ends (and the last three sessions' after that), which filled /tmp of a GPU box when the suite ran
+    twice in one call ("No space left on device" inside a worker's torch.save).  Files above 1 MB go when their test is over."""
+    yield
+    if "tmp_path" not in request.fixturenames:
+        return
+    try:
+        p = request.getfixturevalue("tmp_path")
+        for root, _, files in os.walk(str(p)):
+            for f in files:
+                fp = os.path.join(root, f)
+                if os.path.isfile(fp) and not os.path.islink(fp) and os.path.getsize(fp) > (1 << 20):
+                    os.remove(fp)
+    except Exception:          # noqa: BLE001  (cleanup only)
+        pass
