@@ -29,16 +29,14 @@ def free_port():
 
 
 @pytest.fixture(autouse=True)
-def _free_big_tmp_files(request):
+def _free_big_tmp_files(tmp_path):
     """The multi-process tests hand their results over as torch.save files of 150-450 MB each (flat parameters, moments); pytest keeps every
-    test's tmp_path until the session ends (and the last three sessions' after that), which filled /tmp of a GPU box when the suite ran
-    twice in one call ("No space left on device" inside a worker's torch.save).  Files above 1 MB go when their test is over."""
+    test's tmp_path until the session ends (and the last three sessions' after that): one run of the GPU suite left 68 GB in /tmp of a
+    79-GB box, a second run in the same call died with "No space left on device" inside a worker's torch.save.  Files above 1 MB go
+    when their test is over."""
     yield
-    if "tmp_path" not in request.fixturenames:
-        return
     try:
-        p = request.getfixturevalue("tmp_path")
-        for root, _, files in os.walk(str(p)):
+        for root, _, files in os.walk(str(tmp_path)):
             for f in files:
                 fp = os.path.join(root, f)
                 if os.path.isfile(fp) and not os.path.islink(fp) and os.path.getsize(fp) > (1 << 20):
