@@ -17,6 +17,7 @@
 //   sweep B (key strips)  : recompute P^T from the stashed row statistics -> dV = Pd^T dO, dK = dS^T Q
 // Dropout masks are regenerated from the counter hash (common.h), index ((b*nh+h)*L + i)*L + j.
 #include "attn_common.h"
+#include "adamw_dev.h"
 
 namespace mb {
 
@@ -116,11 +117,11 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
 #define MB_ATTN_BWD_OCC 1          // waves per SIMD the eight-wave (L > 64) instantiation is compiled for (A/B builds: 4 = two workgroups per CU)
 #endif
 template <class T, int LP, int NW>
-__global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : MB_ATTN_BWD_OCC) attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
-                                                           const T* __restrict__ dctx, T* __restrict__ dqkv,
-                                                           float* __restrict__ dbias,
-                                                           const float* __restrict__ head_scale, int L, int nh, DropKey drop,
-                                                           unsigned long long* __restrict__ trace, GradAcc acc) {
+__device__ __forceinline__ void attn_bwd_body(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                              const T* __restrict__ dctx, T* __restrict__ dqkv,
+                                              float* __restrict__ dbias,
+                                              const float* __restrict__ head_scale, int L, int nh, DropKey drop,
+                                              unsigned long long* __restrict__ trace, GradAcc acc) {
     // MB_ATTN_TRACE=1: phase stamps of every block (100 MHz wall clock): 0 entry, 1 operands staged, 2 query sweep done,
     // 3 dQ bias flushed, 4 key sweep done, 5 exit
     auto stamp = [&](int k) { if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * 8 + k] = wall_clock64(); };
@@ -391,6 +392,30 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : MB_ATTN_B
     stamp(5);
 }
 
+template <class T, int LP, int NW>
+__global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : MB_ATTN_BWD_OCC) attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                           const T* __restrict__ dctx, T* __restrict__ dqkv,
+                                                           float* __restrict__ dbias,
+                                                           const float* __restrict__ head_scale, int L, int nh, DropKey drop,
+                                                           unsigned long long* __restrict__ trace, GradAcc acc) {
+    attn_bwd_body<T, LP, NW>(qkv, mask, dctx, dqkv, dbias, head_scale, L, nh, drop, trace, acc);
+}
+// The same launch with AdamW riders (kernels.h AdamRide) behind its `nblk` (batch, head) workgroups.  L <= 64: 576 workgroups in 1024
+// slots, a latency-bound kernel with the memory pipes mostly idle; L = 128: one workgroup per CU, 384 of them = one and a half rounds --
+// the riders get the 128 CUs the second round leaves empty.  A symbol of its own (the plain kernel is what profiles are keyed by).
+template <class T, int LP, int NW>
+__global__ void __launch_bounds__(NW * 64, (NW == 4 && LP <= 64) ? 2 : MB_ATTN_BWD_OCC) attn_bwd_ride_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                           const T* __restrict__ dctx, T* __restrict__ dqkv,
+                                                           float* __restrict__ dbias,
+                                                           const float* __restrict__ head_scale, int L, int nh, DropKey drop,
+                                                           GradAcc acc, const AdamRide ride, int nblk) {
+    if ((int)blockIdx.x >= nblk) {
+        adam_ride_block<NW * 64, 2>(ride, (int)blockIdx.x - nblk);
+        return;
+    }
+    attn_bwd_body<T, LP, NW>(qkv, mask, dctx, dqkv, dbias, head_scale, L, nh, drop, nullptr, acc);
+}
+
 // =============================================================================================== host
 static unsigned long long* g_attn_trace = nullptr;      // MB_ATTN_TRACE=1 (measurement tooling): [blocks][8] stamps of the last backward
 static int g_attn_trace_on = -1, g_attn_trace_blocks = 0;
@@ -420,10 +445,27 @@ static int launch_fwd(const void* qkv, const int64_t* mask, void* ctx, float* pr
 }
 template <class T, int LP, int NW>
 static int launch_bwd(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, float* dbias, const float* hsc, int B,
-                      int L, int nh, DropKey drop, hipStream_t st, GradAcc acc) {
+                      int L, int nh, DropKey drop, hipStream_t st, GradAcc acc, const AdamRide* ride) {
+    if constexpr (sizeof(T) == 2) {
+        if (ride != nullptr && ride->blocks > 0 && ride->n4 > 0) {
+            gemm_log_ride(*ride);
+            hipLaunchKernelGGL((attn_bwd_ride_kernel<T, LP, NW>), dim3(B * nh + ride->blocks), dim3(NW * 64), 0, st, (const T*)qkv, mask,
+                               (const T*)dctx, (T*)dqkv, dbias, hsc, L, nh, drop, acc, *ride, B * nh);
+            return (int)hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((attn_bwd_kernel<T, LP, NW>), dim3(B * nh), dim3(NW * 64), 0, st, (const T*)qkv, mask,
                        (const T*)dctx, (T*)dqkv, dbias, hsc, L, nh, drop, attn_trace_buffer(B * nh), acc);
     return (int)hipGetLastError();
+}
+// workgroups that fit the LAST round of a backward launch of nblk (batch, head) workgroups (bf16; 0 = no riders for this shape)
+int attention_backward_free_slots(int dtype, int L, int nblk, int cus) {
+    if (dtype != DT_BF16 || L < 1 || L > 128) return 0;
+    const int LP = (L + 31) / 32 * 32;
+    const int per_cu = LP <= 32 ? 3 : LP <= 64 ? 4 : 1;      // (registers / LDS of the bf16 ride instantiations: 148 | 126 registers, 19 | 38 KB; 57 | 82 KB: one block)
+    const int slots = per_cu * cus;
+    const int rounds = (nblk + slots - 1) / slots;
+    return rounds * slots - nblk;
 }
 
 int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx, int B, int L, int nh, DropKey drop,
@@ -449,25 +491,25 @@ int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx
 }
 
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx, void* dqkv,
-                       float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale, GradAcc acc) {
+                       float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st, const float* head_scale, GradAcc acc, const AdamRide* ride) {
     (void)ctx;   // D_i is recomputed as sum_j dP_ij P_ij, the forward output is not needed
     if (L < 1 || L > 128) return MB_ERR_SHAPE;
     const int LP = (L + 31) / 32 * 32;
     if (dtype == DT_BF16) {
         switch (LP) {
-            case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
-            case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
-            case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
+            case 32: return launch_bwd<bf16, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, ride);
+            case 64: return launch_bwd<bf16, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, ride);
+            case 96: return launch_bwd<bf16, 96, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, ride);
             // 8 waves: all eight strips of a sweep at once, one block per CU (148 VGPRs since round 6, 82 KB of LDS; see ONE in the kernel).
             // Four waves with two strips each need 487 VGPRs, 217 of them spilled when capped at 256: not built.
-            default: return launch_bwd<bf16, 128, 8>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
+            default: return launch_bwd<bf16, 128, 8>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, ride);
         }
     } else if (dtype == DT_F32) {
         switch (LP) {
-            case 32: return launch_bwd<float, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
-            case 64: return launch_bwd<float, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
-            case 96: return launch_bwd<float, 96, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);
-            default: return launch_bwd<float, 128, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc);   // 2 waves: LDS budget
+            case 32: return launch_bwd<float, 32, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, ride);
+            case 64: return launch_bwd<float, 64, 4>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, ride);
+            case 96: return launch_bwd<float, 96, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, ride);
+            default: return launch_bwd<float, 128, 2>(qkv, mask, dctx, dqkv, dbias, head_scale, B, L, nh, drop, st, acc, ride);   // 2 waves: LDS budget
         }
     }
     return MB_ERR_DTYPE;

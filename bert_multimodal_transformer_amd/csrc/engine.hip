@@ -73,6 +73,8 @@ struct mb_bert_engine : StepMixin {
     // _PARAMS: parameters per 64 x 64 launch (0 = by the launch's FLOPs), _DGELU_PARAMS: per ffn2 launch (0 = 14,336 per free slot),
     // _BLOCKS: rider workgroups (0 = every free slot).  Same box: 3.422 ms off | 3.411 (1) | 3.401 (2)  (profiles/r06_adamw_ride_dgrad.txt)
     int ride_dgrad = 2, ride_dgrad_blocks = 0;
+    int ride_attn = 1, ride_attn_blocks = 0;                // MB_ADAMW_RIDE_ATTN: riders in the attention backward launch (_BLOCKS, _PARAMS: as above)
+    long ride_attn_params = 0;
     long ride_dgrad_params = 0, ride_dgelu_params = 0;      // (MB_ADAMW_RIDE_DGRAD=2: also the ffn2 dgrad; _DGELU_PARAMS: parameters per such launch)
     int group_wgrad = 256;         // MB_GROUP_WGRAD: tile of the per-layer grouped wgrad launch (64 | 128 | 256 = 256 x 128 ping-pong), 0 = four launches
     bool grouped = false;          // the layer's four weight gradients are ONE launch
@@ -409,6 +411,9 @@ int mb_bert_create(const mb_bert_config* cfg, mb_bert_engine** out) {
     if (const char* v = getenv("MB_ADAMW_RIDE_DGRAD_BLOCKS")) e->ride_dgrad_blocks = atoi(v);
     if (const char* v = getenv("MB_ADAMW_RIDE_DGRAD_PARAMS")) e->ride_dgrad_params = atol(v);
     if (const char* v = getenv("MB_ADAMW_RIDE_DGELU_PARAMS")) e->ride_dgelu_params = atol(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE_ATTN")) e->ride_attn = atoi(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE_ATTN_BLOCKS")) e->ride_attn_blocks = atoi(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE_ATTN_PARAMS")) e->ride_attn_params = atol(v);
     if (const char* v = getenv("MB_DETERMINISTIC")) e->deterministic = atoi(v);
     if (const char* v = getenv("MB_ADAMW_OVERLAP")) e->opt_chunk = atoi(v);
     if (const char* v = getenv("MB_PREFETCH")) e->prefetch = atoi(v);
@@ -718,9 +723,26 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.wo), H, ws + e->ws_dctx, H, nullptr, nullptr, nullptr,
                     nullptr, 0, kNoDrop, 1, 0, st));
             // attention backward; the fused-QKV bias gradient (column sums of dqkv) is accumulated inside the kernel
+            // (riders: the launch's empty block slots -- L <= 64: 448 of 1024 next to a latency-bound kernel; L = 128: the 128 CUs its second
+            //  round leaves idle -- carry a piece of the optimizer update; MB_ADAMW_RIDE_ATTN=0 turns them off)
+            AdamRide ra = {};
+            if (e->ride_attn && inl && e->ride_m) {
+                int free_slots = attention_backward_free_slots(dt, L, B * nh, e->cu_count());
+                if (e->ride_attn_blocks > 0) free_slots = e->ride_attn_blocks;
+                const int blocks = std::min(free_slots, 2 * e->cu_count()) / 8 * 8;
+                if (blocks >= 8) {
+                    // L = 128: 128 whole CUs for about half the launch (~41 GB/s each): 20,480 parameters per rider workgroup -- same box, B = 32:
+                    // 4.743 ms without | 4.68 at 1.5 M | 4.652 at 2.6 M (this) | 4.66 at 3.5 M | 4.74 at 5 M per launch.  L <= 64: shared CUs, but
+                    // the kernel is latency-bound and barely notices: 3.320 ms without | 3.289 at 1.5 M | 3.263 at 2 M | 3.257 at 2.5 M (this:
+                    // 1,040 per token) | 3.270 at 3 M (profiles/r06_adamw_ride_attn.txt)
+                    const size_t budget = e->ride_attn_params > 0 ? (size_t)e->ride_attn_params
+                                                                  : (L > 64 ? (size_t)blocks * 20480 : (size_t)1040 * (size_t)T);
+                    ra = take_ride(l, budget / 1024 * 1024, blocks);
+                }
+            }
             CK(attention_backward(dt, ws + w.qkv, e->mask, ws + w.ctx, ws + e->ws_dctx, dqkv, G + o.bqkv, B, L, nh,
                                   e->key(SITE_LAYER0 + 4 * l + 0, c.attn_dropout), st,
-                                  e->head_mask ? e->head_mask + (size_t)l * nh : nullptr, acc));
+                                  e->head_mask ? e->head_mask + (size_t)l * nh : nullptr, acc, ra.blocks ? &ra : nullptr));
             // (experiment) the update inside the launch: the tile of the gradient becomes the new parameters -- so every reader of the
             // OLD weights of this layer (the qkv dgrad below) goes first
             const bool fuse = inl && e->fuse_m && e->fuse_v && e->ow_pass && e->group_wgrad == 128;

@@ -93,6 +93,7 @@ struct AdamRide {
     int blocks;               // 0 = no rider
     int zero_grad;            // 0: the next backward overwrites these gradients (engine_common.h keep_in_step)
 };
+void gemm_log_ride(const AdamRide& r);      // MB_GEMM_LOG=1: "[magbert ride] params=... blocks=..." for a launch that carries riders (gemm.hip)
 struct GroupedGemmArgs {
     GemmArgs g[MB_MAX_GROUP];
     int first[MB_MAX_GROUP + 1];    // first block (region placement) or first tile of the group-wide list (chunk > 0) of every problem
@@ -200,7 +201,9 @@ int attention_forward(int dtype, const void* qkv, const int64_t* mask, void* ctx
 // dbias (fp32 [3H], may be null): += column sums of dqkv (bias grads of the fused QKV Linear)
 int attention_backward(int dtype, const void* qkv, const int64_t* mask, const void* ctx, const void* dctx,
                        void* dqkv, float* dbias, int B, int L, int nh, DropKey drop, hipStream_t st,
-                       const float* head_scale = nullptr, GradAcc acc = {});
+                       const float* head_scale = nullptr, GradAcc acc = {},
+                       const struct AdamRide* ride = nullptr);      // bf16: AdamW riders behind the (batch, head) workgroups (AdamRide below)
+int attention_backward_free_slots(int dtype, int L, int nblk, int cus);      // workgroups that fit the last round of that launch
 int attention_trace_fetch(unsigned long long* host_out, int max_blocks);     // MB_ATTN_TRACE=1: stamps of the last attention_backward
 
 // ------------------------------------------------------------------------------------------ XLNet (xlnet_attention.hip, xlnet_rowops.hip)
