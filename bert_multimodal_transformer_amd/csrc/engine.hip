@@ -661,28 +661,9 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
             // (mode EPI_DGELU: the ffn2 dgrad with the fused bias gradient `colsum`; 56 of its CUs hold one tile instead of two)
             auto dgrad_ride = [&](int mode, int Mo, int No, int Ko, const void* dY, int ldy, const void* Wt, int ldw, void* dX, int ldx, const void* R, int ldr,
                                   float* colsum) -> int {
-                if (e->ride_dgrad && inl && e->ride_m && (mode == EPI_ADD_RES || e->ride_dgrad >= 2)) {
-                    GemmArgs a = {};
-                    a.A = dY; a.B = Wt; a.M = Mo; a.N = No; a.K = Ko; a.lda = ldy; a.ldb = ldw; a.C = dX; a.ldc = ldx; a.R = R; a.ldr = ldr;
-                    a.alpha = 1.0f; a.drop = kNoDrop; a.kchunk = Ko; a.colsum = colsum; a.acc = acc;
-                    int per_cu = 0;
-                    const int tiles = gemm_nn_ride_tiles(dt, mode, a, &per_cu);
-                    const int blocks = tiles > 0 ? (e->ride_dgrad_blocks > 0 ? e->ride_dgrad_blocks : per_cu * e->cu_count() - tiles) / 8 * 8 : 0;
-                    if (blocks >= 8) {
-                        // what the free slots stream while the tiles multiply, by the launch's size: 1.25 M parameters next to 11.3 GFLOP.  The
-                        // riders share SIMDs with the tiles here (every instruction of theirs costs the partner wave an MFMA slot), so the
-                        // gain is small and turns at ~1.5 M: same box, 3.566 ms without | 3.544 at 1 - 1.5 M | 3.578 at 2.5 M per launch; in
-                        // place of the weight-gradient riders 3.62 (profiles/r06_adamw_ride_dgrad.txt)
-                        size_t budget = e->ride_dgrad_params > 0 ? (size_t)e->ride_dgrad_params
-                                                                 : (size_t)(1.25e6 * ((double)Mo * No * Ko) / (2400.0 * 768.0 * 3072.0)) / 1024 * 1024;
-                        if (mode == EPI_DGELU) budget = e->ride_dgelu_params > 0 ? (size_t)e->ride_dgelu_params : (size_t)blocks * 14336;      // (56 half-idle CUs)
-                        const AdamRide r = take_ride(l, budget, blocks);
-                        if (r.blocks) return gemm_nn_ride_launch(dt, mode, a, r, st);
-                    }
-                }
-                if (mode == EPI_DGELU)
-                    return gemm(dt, GEMM_NN, EPI_DGELU, Mo, No, Ko, dY, ldy, Wt, ldw, dX, ldx, nullptr, colsum, nullptr, R, ldr, kNoDrop, 1, 0, st, 0, 0, acc);
-                return gemm(dt, GEMM_NN, EPI_ADD_RES, Mo, No, Ko, dY, ldy, Wt, ldw, dX, ldx, nullptr, nullptr, nullptr, R, ldr, kNoDrop, 1, 0, st);
+                const RideOpts ro = {e->ride_dgrad, e->ride_dgrad_blocks, e->ride_dgrad_params, e->ride_dgelu_params};
+                return dgrad_with_riders(dt, mode, Mo, No, Ko, dY, ldy, Wt, ldw, dX, ldx, R, ldr, colsum, kNoDrop, acc, st, inl && e->ride_m != nullptr, ro,
+                                         e->cu_count(), [&](size_t budget, int blocks) { return take_ride(l, budget, blocks); });
             };
             int wtile = e->group_wgrad;
             if (grouped && wtile == 256 && !gemm_grouped_tn_ok(dt, wg, 4, 256)) wtile = 128;      // (fewer than three k stages: the 128 x 128 kernel)

@@ -115,6 +115,36 @@ inline int gemm(int dtype, int layout, int mode, int M, int N, int K, const void
     return gemm_launch(dtype, layout, mode, a, splits, tile, st);
 }
 
+// dX = dY . W + R (EPI_ADD_RES) or (dY . W) * gelu'(R) with the bias gradient `colsum` (EPI_DGELU), GEMM_NN: the plain launch, or -- when
+// riders are active, the launch is one of the two kernels that leave block slots free (kernels.h gemm_nn_ride_tiles) and `take(budget,
+// blocks)` hands out a piece of the optimizer update (kernels.h AdamRide) -- the same launch with rider workgroups behind its tiles.
+// Budgets: what the free slots stream while the tiles multiply, by the launch's size: 1.25 M parameters next to 11.3 GFLOP for the 64 x 64
+// kernel (the riders share SIMDs with the tiles: every instruction of theirs costs the partner wave an MFMA slot, so the gain is small and
+// turns at ~1.5 M: same box 3.566 ms without | 3.544 at 1 - 1.5 M | 3.578 at 2.5 M per launch), 14,336 per free slot of the 128 x 128
+// kernel (56 CUs that hold one tile instead of two)  (profiles/r06_adamw_ride_dgrad.txt)
+struct RideOpts { int dgrad = 2, dgrad_blocks = 0; long dgrad_params = 0, dgelu_params = 0; };
+template <class Take>
+inline int dgrad_with_riders(int dt, int mode, int Mo, int No, int Ko, const void* dY, int ldy, const void* Wt, int ldw, void* dX, int ldx, const void* R,
+                             int ldr, float* colsum, DropKey drop, GradAcc acc, hipStream_t st, bool active, const RideOpts& ro, int cus, Take&& take) {
+    if (active && ro.dgrad && (mode == EPI_ADD_RES || ro.dgrad >= 2)) {
+        GemmArgs a = {};
+        a.A = dY; a.B = Wt; a.M = Mo; a.N = No; a.K = Ko; a.lda = ldy; a.ldb = ldw; a.C = dX; a.ldc = ldx; a.R = R; a.ldr = ldr;
+        a.alpha = 1.0f; a.drop = drop; a.kchunk = Ko; a.colsum = colsum; a.acc = acc;
+        int per_cu = 0;
+        const int tiles = gemm_nn_ride_tiles(dt, mode, a, &per_cu);
+        const int blocks = tiles > 0 ? (ro.dgrad_blocks > 0 ? ro.dgrad_blocks : per_cu * cus - tiles) / 8 * 8 : 0;
+        if (blocks >= 8) {
+            size_t budget = ro.dgrad_params > 0 ? (size_t)ro.dgrad_params : (size_t)(1.25e6 * ((double)Mo * No * Ko) / (2400.0 * 768.0 * 3072.0)) / 1024 * 1024;
+            if (mode == EPI_DGELU) budget = ro.dgelu_params > 0 ? (size_t)ro.dgelu_params : (size_t)blocks * 14336;
+            const AdamRide r = take(budget, blocks);
+            if (r.blocks) return gemm_nn_ride_launch(dt, mode, a, r, st);
+        }
+    }
+    if (mode == EPI_DGELU)
+        return gemm(dt, GEMM_NN, EPI_DGELU, Mo, No, Ko, dY, ldy, Wt, ldw, dX, ldx, nullptr, colsum, nullptr, R, ldr, drop, 1, 0, st, 0, 0, acc);
+    return gemm(dt, GEMM_NN, EPI_ADD_RES, Mo, No, Ko, dY, ldy, Wt, ldw, dX, ldx, nullptr, nullptr, nullptr, R, ldr, drop, 1, 0, st);
+}
+
 // operands of one weight gradient dW[Mo][No] += dY[rows][Mo]^T X[rows][No] (GEMM_TN, EPI_ACCUM_F32)
 inline GemmArgs wgrad_args(int Mo, int No, int rows, const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw) {
     GemmArgs a = {};

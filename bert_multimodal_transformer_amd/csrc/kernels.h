@@ -218,7 +218,9 @@ int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const f
                              const void* psave, const void* dvec, void* gsave, void* dqkv, void* dkr, float* d_rwb,
                              float* d_rrb, float* d_rsb, float* d_seg, int B, int L, int nh, DropKey drop, hipStream_t st,
                              const float* head_scale = nullptr,      // head_scale [nh] or null: head_mask of the layer
-                             GradAcc acc = {});                      // deterministic mode: the four bias / seg_embed column sums (common.h)
+                             GradAcc acc = {},                       // deterministic mode: the four bias / seg_embed column sums (common.h)
+                             const struct AdamRide* ride_q = nullptr, const struct AdamRide* ride_kv = nullptr);      // bf16, L <= 64: riders of the two launches
+int xlnet_attention_backward_free_slots(int dtype, int L, int nblk, int cus);
 // out[t] = dropout(word[ids[t]])  (xlnet.py:304-305) ; backward scatter-adds into dword
 int gather_drop_forward(int dtype, const int64_t* ids, const float* word, void* out, int rows, int H, DropKey drop, hipStream_t st);
 int gather_drop_backward(int dtype, const void* dout, const int64_t* ids, float* dword, int rows, int H, DropKey drop, hipStream_t st, GradAcc acc = {});

@@ -14,6 +14,7 @@
 //   xl_attn_bwd_kv : dv = Pd^T dO ; dk = G^T (q + r_w_bias) ; dkr[p] = sum_i G[i, p-L+i] (q_i + r_r_bias)
 #include <cstdlib>
 #include "attn_common.h"
+#include "adamw_dev.h"
 
 namespace mb {
 
@@ -247,11 +248,11 @@ __device__ __forceinline__ void flush_colsums(f32x4 (* const (&c4)[N])[4], float
 
 // ================================================================================================ backward, query side
 template <class T, int LP, int NW>
-__global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restrict__ qkv, const T* __restrict__ kr, XlParams xp,
-                                                                const T* __restrict__ psave, const T* __restrict__ dvec,
-                                                                T* __restrict__ gsave, T* __restrict__ dqkv, float* d_rwb,
-                                                                float* d_rrb, float* d_rsb, float* d_seg, int L, int nh,
-                                                                DropKey drop) {
+__device__ __forceinline__ void xl_attn_bwd_q_body(const T* __restrict__ qkv, const T* __restrict__ kr, XlParams xp,
+                                                   const T* __restrict__ psave, const T* __restrict__ dvec,
+                                                   T* __restrict__ gsave, T* __restrict__ dqkv, float* d_rwb,
+                                                   float* d_rrb, float* d_rsb, float* d_seg, int L, int nh,
+                                                   DropKey drop) {
     drop.resolve();
     typedef AttnCfg<T> C;
     constexpr int PIT = C::ROWB + 16;
@@ -421,6 +422,29 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restr
         flush_colsums<NW, 5>(tiles, dst, (float*)sstr, lane, wave, xp.acc);
     }
 }
+template <class T, int LP, int NW>
+__global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_kernel(const T* __restrict__ qkv, const T* __restrict__ kr, XlParams xp,
+                                                                const T* __restrict__ psave, const T* __restrict__ dvec,
+                                                                T* __restrict__ gsave, T* __restrict__ dqkv, float* d_rwb,
+                                                                float* d_rrb, float* d_rsb, float* d_seg, int L, int nh,
+                                                                DropKey drop) {
+    xl_attn_bwd_q_body<T, LP, NW>(qkv, kr, xp, psave, dvec, gsave, dqkv, d_rwb, d_rrb, d_rsb, d_seg, L, nh, drop);
+}
+// ... with AdamW riders (kernels.h AdamRide) behind its `nblk` (batch, head) workgroups: 576 blocks in 768 slots at L = 50 (one strip group:
+// gridDim.y == 1), a latency-bound kernel -- as attention.hip's attn_bwd_ride_kernel
+template <class T, int LP, int NW>
+__global__ void __launch_bounds__(NW * 64) xl_attn_bwd_q_ride_kernel(const T* __restrict__ qkv, const T* __restrict__ kr, XlParams xp,
+                                                                     const T* __restrict__ psave, const T* __restrict__ dvec,
+                                                                     T* __restrict__ gsave, T* __restrict__ dqkv, float* d_rwb,
+                                                                     float* d_rrb, float* d_rsb, float* d_seg, int L, int nh,
+                                                                     DropKey drop, const AdamRide ride, int nblk) {
+    if ((int)blockIdx.x >= nblk) {
+        adam_ride_block<NW * 64, 2>(ride, (int)blockIdx.x - nblk);
+        return;
+    }
+    xl_attn_bwd_q_body<T, LP, NW>(qkv, kr, xp, psave, dvec, gsave, dqkv, d_rwb, d_rrb, d_rsb, d_seg, L, nh, drop);
+}
+
 
 // ================================================================================================ backward, key / position side
 template <class T, int LP, int NW>
@@ -563,10 +587,10 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv_kernel(const T* __rest
 // 2-byte loads in transposed order: 48 dependent round trips per wave), no strips and no barriers for the key side; the position
 // side gathers its diagonals out of the LDS image instead of out of HBM.  46.6 KB of LDS: three blocks per CU.
 template <class T, int LP, int NW>
-__global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv2_kernel(const T* __restrict__ qkv, XlParams xp, const T* __restrict__ psave,
-                                                                  const T* __restrict__ gsave, const T* __restrict__ dvec,
-                                                                  T* __restrict__ dqkv, T* __restrict__ dkr, int L, int nh,
-                                                                  DropKey drop) {
+__device__ __forceinline__ void xl_attn_bwd_kv2_body(const T* __restrict__ qkv, XlParams xp, const T* __restrict__ psave,
+                                                     const T* __restrict__ gsave, const T* __restrict__ dvec,
+                                                     T* __restrict__ dqkv, T* __restrict__ dkr, int L, int nh,
+                                                     DropKey drop) {
     drop.resolve();
     typedef AttnCfg<T> C;
     constexpr int PIT = C::ROWB + 16;
@@ -690,6 +714,25 @@ __global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv2_kernel(const T* __res
         __builtin_amdgcn_wave_barrier();
     }
 }
+template <class T, int LP, int NW>
+__global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv2_kernel(const T* __restrict__ qkv, XlParams xp, const T* __restrict__ psave,
+                                                                  const T* __restrict__ gsave, const T* __restrict__ dvec,
+                                                                  T* __restrict__ dqkv, T* __restrict__ dkr, int L, int nh,
+                                                                  DropKey drop) {
+    xl_attn_bwd_kv2_body<T, LP, NW>(qkv, xp, psave, gsave, dvec, dqkv, dkr, L, nh, drop);
+}
+template <class T, int LP, int NW>
+__global__ void __launch_bounds__(NW * 64) xl_attn_bwd_kv2_ride_kernel(const T* __restrict__ qkv, XlParams xp, const T* __restrict__ psave,
+                                                                       const T* __restrict__ gsave, const T* __restrict__ dvec,
+                                                                       T* __restrict__ dqkv, T* __restrict__ dkr, int L, int nh,
+                                                                       DropKey drop, const AdamRide ride, int nblk) {
+    if ((int)blockIdx.x >= nblk) {
+        adam_ride_block<NW * 64, 2>(ride, (int)blockIdx.x - nblk);
+        return;
+    }
+    xl_attn_bwd_kv2_body<T, LP, NW>(qkv, xp, psave, gsave, dvec, dqkv, dkr, L, nh, drop);
+}
+
 
 // ================================================================================================ host
 // LP = L rounded up to 32 / 64 / 128; NW_* = waves (query strips per block for the two query-side kernels, whose grid has
@@ -723,20 +766,46 @@ int xlnet_attention_forward(int dtype, const void* qkv, const void* kr, const fl
     })
 }
 
+// block slots the two backward launches of nblk (batch, head) workgroups leave free in their last round, when they can carry riders
+// (bf16, L <= 64: 51 / 47 KB of LDS = three blocks per CU each); 0 = no riders for this shape
+int xlnet_attention_backward_free_slots(int dtype, int L, int nblk, int cus) {
+    if (dtype != DT_BF16 || L < 1 || L > 64) return 0;
+    static int kv2 = -1;
+    if (kv2 < 0) { const char* v = getenv("MB_XL_KV2"); kv2 = v ? atoi(v) : 1; }
+    if (!kv2) return 0;
+    const int slots = 3 * cus, rounds = (nblk + slots - 1) / slots;
+    return rounds * slots - nblk;
+}
+
 int xlnet_attention_backward(int dtype, const void* qkv, const void* kr, const float* r_w_bias, const float* r_r_bias,
                              const float* r_s_bias, const float* seg_embed, const int64_t* seg, const int64_t* mask,
                              const void* psave, const void* dvec, void* gsave, void* dqkv, void* dkr, float* d_rwb,
                              float* d_rrb, float* d_rsb, float* d_seg, int B, int L, int nh, DropKey drop, hipStream_t st,
-                             const float* head_scale, GradAcc acc) {
+                             const float* head_scale, GradAcc acc, const AdamRide* ride_q, const AdamRide* ride_kv) {
     static int g_kv2 = -1;            // MB_XL_KV2=0: the key / position side of the backward with the round-3 kernel at L <= 64 too (A/B)
     if (g_kv2 < 0) { const char* v = getenv("MB_XL_KV2"); g_kv2 = v ? atoi(v) : 1; }
     XlParams xp = {r_w_bias, r_r_bias, r_s_bias, seg_embed, seg, mask, head_scale, nullptr, 0, acc};
     XL_DISPATCH({
         (void)NWF;
+        bool q_done = false;
+        if constexpr (sizeof(T) == 2 && LP <= 64 && LP / 16 / NWQ == 1) {
+            if (ride_q != nullptr && ride_q->blocks > 0 && ride_q->n4 > 0) {
+                gemm_log_ride(*ride_q);
+                hipLaunchKernelGGL((xl_attn_bwd_q_ride_kernel<T, LP, NWQ>), dim3(B * nh + ride_q->blocks, 1), dim3(NWQ * 64), 0, st, (const T*)qkv,
+                                   (const T*)kr, xp, (const T*)psave, (const T*)dvec, (T*)gsave, (T*)dqkv, d_rwb, d_rrb, d_rsb, d_seg, L, nh, drop,
+                                   *ride_q, B * nh);
+                q_done = true;
+            }
+        }
+        if (!q_done)
         hipLaunchKernelGGL((xl_attn_bwd_q_kernel<T, LP, NWQ>), dim3(B * nh, LP / 16 / NWQ), dim3(NWQ * 64), 0, st, (const T*)qkv, (const T*)kr,
                            xp, (const T*)psave, (const T*)dvec, (T*)gsave, (T*)dqkv, d_rwb, d_rrb, d_rsb, d_seg, L, nh, drop);
         if constexpr (sizeof(T) == 2 && LP <= 64) {
-            if (g_kv2)
+            if (g_kv2 && ride_kv != nullptr && ride_kv->blocks > 0 && ride_kv->n4 > 0) {
+                gemm_log_ride(*ride_kv);
+                hipLaunchKernelGGL((xl_attn_bwd_kv2_ride_kernel<T, LP, NWK>), dim3(B * nh + ride_kv->blocks), dim3(NWK * 64), 0, st, (const T*)qkv, xp,
+                                   (const T*)psave, (const T*)gsave, (const T*)dvec, (T*)dqkv, (T*)dkr, L, nh, drop, *ride_kv, B * nh);
+            } else if (g_kv2)
                 hipLaunchKernelGGL((xl_attn_bwd_kv2_kernel<T, LP, NWK>), dim3(B * nh), dim3(NWK * 64), 0, st, (const T*)qkv, xp,
                                    (const T*)psave, (const T*)gsave, (const T*)dvec, (T*)dqkv, (T*)dkr, L, nh, drop);
             else

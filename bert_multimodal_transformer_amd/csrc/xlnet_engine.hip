@@ -56,6 +56,14 @@ struct mb_xlnet_engine : StepMixin {
     bool deferred = false;
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> evs;   // [2 * n_layer]: fork, done
+    // AdamW riders (kernels.h AdamRide; as engine.hip).  This engine's grouped weight gradient fills the chip (504 tiles in 512 slots), so
+    // the hosts are the ffn1 / ffn2 / out dgrad launches and the relative-attention backward: MB_ADAMW_RIDE=0 turns them off
+    int adam_ride = 1;
+    RideOpts ride_opts;
+    int ride_attn = 1, ride_attn_blocks = 0;
+    long ride_attn_params = 0;
+    float* ride_m = nullptr; float* ride_v = nullptr;
+    size_t ride_cursor = 0;
     bool ws_zeroed = false;
     uint64_t seed = 0, step = 0;
     float* logits = nullptr;
@@ -230,6 +238,14 @@ int mb_xlnet_create(const mb_xlnet_config* cfg, mb_xlnet_engine** out) {
     if (const char* v = getenv("MB_DETERMINISTIC")) e->deterministic = atoi(v);
     xl_build_layout(e);
     if (const char* v = getenv("MB_XL_FUSE_QKV")) e->fuse_qkv = atoi(v) != 0;
+    if (const char* v = getenv("MB_ADAMW_RIDE")) e->adam_ride = atoi(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE_DGRAD")) e->ride_opts.dgrad = atoi(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE_DGRAD_BLOCKS")) e->ride_opts.dgrad_blocks = atoi(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE_DGRAD_PARAMS")) e->ride_opts.dgrad_params = atol(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE_DGELU_PARAMS")) e->ride_opts.dgelu_params = atol(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE_ATTN")) e->ride_attn = atoi(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE_ATTN_BLOCKS")) e->ride_attn_blocks = atoi(v);
+    if (const char* v = getenv("MB_ADAMW_RIDE_ATTN_PARAMS")) e->ride_attn_params = atol(v);
     if (const char* v = getenv("MB_XL_SPLIT_R")) e->split_r = atoi(v) != 0;
     if (const char* pv = getenv("MB_PREFETCH")) e->prefetch = atoi(pv);
     if (e->lo[0].k - e->lo[0].q != (size_t)cfg->d_model * cfg->d_model || e->lo[0].v - e->lo[0].k != e->lo[0].k - e->lo[0].q) e->fuse_qkv = false;
@@ -400,6 +416,22 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
     const float pd = c.dropout;
     const bool hd = e->training && pd > 0.f;
     const GradAcc acc = e->acc_of(ws, G);          // deterministic mode (MB_DETERMINISTIC=1): where the multi-writer sums go (as engine.hip)
+    // Riders (kernels.h AdamRide, xl_enqueue_step): up to `budget` parameters from the TOP of what is final while layer l's backward runs -- the
+    // GEMM weights of layers l+1 .. NL-1 (q | k | v | o | r | layer_1 | layer_2, contiguous per layer; r's second k half has been added by then)
+    // minus what earlier launches took -- as `blocks` extra workgroups of a launch.  The sweep at the end is [0, ride_cursor) + the rest.
+    auto take_ride = [&](int l, size_t budget, int blocks) -> AdamRide {
+        AdamRide r = {};
+        if (!e->ride_m || !e->ride_v || l + 1 >= NL || blocks < 8 || e->ride_cursor <= e->lo[l + 1].q) return r;
+        const size_t take = std::min(e->ride_cursor - e->lo[l + 1].q, budget) / 1024 * 1024;
+        const size_t re = e->ride_cursor, rb = re - take;
+        const bool sh_ok = dt != DT_BF16 || (e->sh_begin <= rb && re <= e->sh_end);
+        if (take == 0 || rb % 4 || !sh_ok) return r;
+        const bool keep = e->keep_in_step() && e->stale_begin <= rb && re <= e->stale_end;
+        r = AdamRide{P + rb, G + rb, e->ride_m + rb, e->ride_v + rb, dt == DT_BF16 ? (bf16*)(e->SH + rb * 2) : nullptr, take / 4, e->adam_state(ws),
+                     blocks / 8 * 8, keep ? 0 : 1};
+        e->ride_cursor = rb;
+        return r;
+    };
     for (int stage = stage_begin; stage < stage_end; ++stage) {
         if (stage == 0) {
             CK(head_backward(dt, dlogits, e->logits, labels, loss_scale, (const float*)(ws + e->ws_head_pooled), P + e->wc,
@@ -458,11 +490,13 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                 wg[7].overwrite = 1;
             }
             if (!grouped) CK(wgrad(dt, H, I, Tk, dzdA, H, ws + w.g, I, G + o.w2, I, st));
-            CK(gemm(dt, GEMM_NN, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, du, I, nullptr, G + o.b1, nullptr, ws + w.u, I,
-                    e->key(XS_LAYER0 + 8 * l + 2, pd), 1, 0, st, 0, 0, acc));
+            const bool riding = grouped && !e->deferred && e->ride_m != nullptr;
+            auto take_l = [&](size_t budget, int blocks) { return take_ride(l, budget, blocks); };
+            CK(dgrad_with_riders(dt, EPI_DGELU, T, I, H, dzdA, H, e->W(o.w2), I, du, I, ws + w.u, I, G + o.b1, e->key(XS_LAYER0 + 8 * l + 2, pd), acc, st,
+                                 riding, e->ride_opts, e->cu_count(), take_l));
             if (!grouped) CK(wgrad(dt, I, H, Tk, du, I, ws + w.y1, H, G + o.w1, H, st));
-            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, I, du, I, e->W(o.w1), H, t1, H, nullptr, nullptr, nullptr, dsA, H,
-                    kNoDrop, 1, 0, st));
+            CK(dgrad_with_riders(dt, EPI_ADD_RES, T, H, I, du, I, e->W(o.w1), H, t1, H, dsA, H, nullptr, kNoDrop, GradAcc{}, st, riding, e->ride_opts,
+                                 e->cu_count(), take_l));
             // ---- relative attention block
             CK(ln_backward_partials(dt, t1, ws + w.s1, P + o.ralnw, (const float*)(ws + w.st1), (const float*)(ws + w.st1) + T, dsB,
                                     hd ? dzdB : nullptr, lnp_b, &nblk, T, H, e->key(XS_LAYER0 + 8 * l + 1, pd), st,
@@ -486,12 +520,27 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                                              mag_slabs ? NL + 1 : NL, nblk, H, dst, st, acc));
             }
             if (!grouped) CK(wgrad(dt, H, H, Tk, dzdB, H, ws + w.vec, H, G + o.o, H, st));
-            CK(gemm(dt, GEMM_NN, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.o), H, ws + e->ws_dvec, H, nullptr, nullptr, nullptr, nullptr, 0,
-                    kNoDrop, 1, 0, st));
+            CK(dgrad_with_riders(dt, EPI_ADD_RES, T, H, H, dzdB, H, e->W(o.o), H, ws + e->ws_dvec, H, nullptr, 0, nullptr, kNoDrop, GradAcc{}, st, riding,
+                                 e->ride_opts, e->cu_count(), take_l));
+            // (riders of the two relative-attention backward launches: 576 workgroups in 768 slots each at L = 50, latency-bound hosts)
+            AdamRide rq = {}, rkv = {};
+            if (riding && e->ride_attn) {
+                int free_slots = xlnet_attention_backward_free_slots(dt, L, B * nh, e->cu_count());
+                if (e->ride_attn_blocks > 0 && free_slots > 0) free_slots = e->ride_attn_blocks;
+                const int blocks = std::min(free_slots, 2 * e->cu_count()) / 8 * 8;
+                if (blocks >= 8) {
+                    // same box, B = 48 L = 50: 4.253 ms without riders | 4.212 dgrad hosts only | 4.155 at 1.25 M + 0.83 M in the two attention launches |
+                    // 4.129 at 1.8 M + 1.2 M (this: 750 per token) | 4.128 at 2.4 M + 1.6 M   (profiles/r06_xlnet_riders.txt)
+                    const size_t budget = e->ride_attn_params > 0 ? (size_t)e->ride_attn_params : (size_t)750 * (size_t)T;
+                    rq = take_ride(l, budget / 1024 * 1024, blocks);
+                    rkv = take_ride(l, (budget * 2 / 3) / 1024 * 1024, blocks);
+                }
+            }
             CK(xlnet_attention_backward(dt, ws + w.qkv, ws + w.kr, P + o.rwb, P + o.rrb, P + o.rsb, P + o.seg, e->seg, e->mask,
                                         ws + w.psave, ws + e->ws_dvec, ws + e->ws_gsave, dqkv, dkr, G + o.rwb, G + o.rrb,
                                         G + o.rsb, G + o.seg, B, L, nh, e->key(XS_LAYER0 + 8 * l + 0, pd), st,
-                                        e->head_mask ? e->head_mask + (size_t)l * nh : nullptr, acc));
+                                        e->head_mask ? e->head_mask + (size_t)l * nh : nullptr, acc, rq.blocks ? &rq : nullptr,
+                                        rkv.blocks ? &rkv : nullptr));
             if (grouped && e->deferred) {
                 if (!e->side) {
                     CK((int)hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
@@ -567,6 +616,7 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
 }
 
 // ------------------------------------------------------------------------------------------------ whole step (as mb_bert_train_step)
+static int xl_adamw_decay_range(mb_xlnet_engine* e, float* m, float* v, size_t b, size_t en, hipStream_t st);
 static int xl_enqueue_step(mb_xlnet_engine* e, int B, int L, float* logits, float* loss, float* loss_run, float* m, float* v,
                            float loss_scale, hipStream_t st) {
     char* ws = e->ws;
@@ -574,8 +624,24 @@ static int xl_enqueue_step(mb_xlnet_engine* e, int B, int L, float* logits, floa
     CK(mb_xlnet_forward(e, (const int64_t*)(ws + e->ws_in_ids), (const float*)(ws + e->ws_in_vis), (const float*)(ws + e->ws_in_aco),
                         (const int64_t*)(ws + e->ws_in_mask), (const int64_t*)(ws + e->ws_in_seg), lab, B, L, 1, 0, 0, logits, loss,
                         loss_run, st));
-    CK(mb_xlnet_backward(e, nullptr, lab, loss_scale, 0, e->c.n_layer + 2, st));
-    if (m && v) {
+    // riders (MB_ADAMW_RIDE): layers 1 .. NL-1 are updated inside launches of the backward of layers 0 .. NL-2 (mb_xlnet_backward: take_ride);
+    // whether a launch really carried one is decided there, so the sweep below asks the engine what is still to do
+    const bool ride = e->adam_ride && m && v && e->c.dtype == DT_BF16 && e->group_wgrad > 0 && !e->deferred && e->c.n_layer > 1 && e->lo[0].q == 0 &&
+                      !e->prof && !e->mems;
+    e->ride_m = ride ? m : nullptr; e->ride_v = ride ? v : nullptr;
+    e->ride_cursor = e->wsum;
+    const int rb = mb_xlnet_backward(e, nullptr, lab, loss_scale, 0, e->c.n_layer + 2, st);
+    e->ride_m = e->ride_v = nullptr;
+    CK(rb);
+    if (m && v && ride) {
+        const AdamArgs none = {};
+        const size_t nd = e->n_decay, n = e->n_trainable;
+        CK(e->prof_mark(2 * e->c.n_layer, st));
+        CK(xl_adamw_decay_range(e, m, v, 0, e->ride_cursor, st));          // what no launch carried (layer 0 always)
+        CK(xl_adamw_decay_range(e, m, v, e->wsum, nd, st));
+        CK(adamw_step(e->P + nd, e->G + nd, m + nd, v + nd, nullptr, n - nd, 0, 0, 0, none, 1, st, e->adam_state(ws) + 1));
+        CK(e->prof_mark(2 * e->c.n_layer + 1, st));
+    } else if (m && v) {
         const AdamArgs none = {};
         const size_t nd = e->n_decay, n = e->n_trainable;        // the frozen mask_emb slot behind n_trainable is never updated
         void* sh = e->c.dtype == DT_BF16 ? (void*)e->SH : nullptr;

@@ -637,6 +637,22 @@ def test_adamw_riding_in_the_weight_gradient_launches_changes_nothing(cdt, tile,
     assert float(ride["g"].abs().max()) == 0.0 and ride["stats"] == ref["stats"]
 
 
+def test_adamw_riders_of_every_host_change_nothing_at_a_benchmark_like_width(monkeypatch):
+    """The same property at T = 1,200 tokens (B = 24, L = 50), where EVERY host carries riders: the ping-pong weight gradient's idle CUs,
+    the 64 x 64 ffn1 / qkv dgrads' free slots, the 128 x 128 ffn2 dgrad (needs >= 224 tiles: not reached by the small shapes above) and the
+    attention backward.  bf16, deterministic mode, four steps over two shapes: bit-identical parameters, moments, shadow and logits."""
+    monkeypatch.setenv("MB_DETERMINISTIC", "1")
+    monkeypatch.setenv("MB_GROUP_WGRAD", "256")
+    shapes = ((24, 50), (24, 50), (5, 40), (24, 50))
+    monkeypatch.setenv("MB_ADAMW_RIDE", "0")
+    ref = _trajectory(torch.bfloat16, True, shapes=shapes)
+    monkeypatch.setenv("MB_ADAMW_RIDE", "1")
+    ride = _trajectory(torch.bfloat16, True, shapes=shapes)
+    for k in ("p", "m", "v", "shadow", "logits"):
+        assert torch.equal(ride[k], ref[k]), "%s differs with riders in every host" % k
+    assert float(ride["g"].abs().max()) == 0.0 and ride["stats"] == ref["stats"]
+
+
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 def test_step_graph_equals_launch_by_launch(cdt, monkeypatch):
     """mb_bert_train_step: the replayed whole-step hipGraph (dropout keys, lr and bias correction read from device memory,

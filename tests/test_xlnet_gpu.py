@@ -744,6 +744,22 @@ def test_xlnet_single_call_step_equals_python_driven_passes():
         assert run["stats"] == ((2, 4) if mode is True else (0, 0))
 
 
+def test_xlnet_adamw_riders_change_nothing(monkeypatch):
+    """MB_ADAMW_RIDE (csrc/kernels.h AdamRide) in the MAG-XLNet engine: the ffn1 / ffn2 / out dgrad launches of layer l carry the HF-AdamW update
+    of layers l+1.. as rider workgroups and the sweep at the end of the step skips what they did.  Same arithmetic per element, so in
+    deterministic mode four bf16 steps (dropout on, schedule moving, two shapes -- one wide enough for the 128 x 128 ffn2 host: T = 1,200) end
+    with the SAME BITS in the parameters; gradients read as zeros, the frozen mask_emb slot is untouched."""
+    monkeypatch.setenv("MB_DETERMINISTIC", "1")
+    shapes = ((24, 50), (24, 50), (5, 40), (24, 50))
+    monkeypatch.setenv("MB_ADAMW_RIDE", "0")
+    ref = _xl_trajectory(True, torch.bfloat16, shapes=shapes)
+    monkeypatch.setenv("MB_ADAMW_RIDE", "1")
+    ride = _xl_trajectory(True, torch.bfloat16, shapes=shapes)
+    assert torch.equal(ride["p"], ref["p"]), "parameters differ with the update riding in the backward launches: max %.3e" % float((ride["p"] - ref["p"]).abs().max())
+    assert torch.allclose(ride["losses"], ref["losses"], rtol=1e-6, atol=0.0) and float(ride["g"].abs().max()) == 0.0      # (the batch mean is a float atomic sum)
+    assert torch.equal(ride["frozen"], ref["frozen"]) and ride["stats"] == ref["stats"]
+
+
 def test_input_mask_and_perm_mask_match_reference_golden_fp32(golden):
     """xlnet.py:258-296: `input_mask` (1 = padding) in place of attention_mask gives the same logits, and a `perm_mask` [B, L, L]
     (1 = query i may not attend to key j; the i == j exemption of non_tgt_mask stays) moves them to what the REFERENCE's own
