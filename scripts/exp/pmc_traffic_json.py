@@ -43,7 +43,7 @@ ridden = (110853121 - swept) if swept else (11 * 2432000 if lps == 3 else 0)
 doc["kernels"]["adamw"] = {"fetch_bytes": int(2 * f * 1024 * lps), "write_bytes": int(w * 1024 * lps), "launches_per_step": lps,
                            "algorithmic_bytes": 28 * (110853121 - ridden),
                            "note": "per step (the %d sweep launches%s); reads p, g, m, v = 16 B/param: the calibration point of the x2 correction"
-                                   % (lps, "; %.1f M of the 110.9 M parameters are updated by riders inside the weight-gradient and dgrad launches instead" % (ridden / 1e6) if ridden else "")}
+                                   % (lps, "; %.1f M of the 110.9 M parameters are updated by riders inside the weight-gradient, dgrad and attention-backward launches instead" % (ridden / 1e6) if ridden else "")}
 # every symbol both passes saw, keyed by the first 90 characters of its name (what pmc_reduce.py keeps): bench.py looks its
 # in-run trace's dominant symbol up here, whichever kernel that is
 doc["by_symbol"] = {k: {"launches": n, "fetch_bytes": int(2 * v * 1024), "write_bytes": int(wr[k][1] * 1024)}
