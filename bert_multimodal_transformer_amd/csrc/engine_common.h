@@ -132,7 +132,8 @@ inline int dgrad_with_riders(int dt, int mode, int Mo, int No, int Ko, const voi
         a.alpha = 1.0f; a.drop = drop; a.kchunk = Ko; a.colsum = colsum; a.acc = acc;
         int per_cu = 0;
         const int tiles = gemm_nn_ride_tiles(dt, mode, a, &per_cu);
-        const int blocks = tiles > 0 ? (ro.dgrad_blocks > 0 ? ro.dgrad_blocks : per_cu * cus - tiles) / 8 * 8 : 0;
+        const int slots = per_cu * cus, rounds = tiles > 0 ? (tiles + slots - 1) / slots : 0;      // (the riders take what the LAST round leaves free)
+        const int blocks = tiles > 0 ? (ro.dgrad_blocks > 0 ? ro.dgrad_blocks : rounds * slots - tiles) / 8 * 8 : 0;
         if (blocks >= 8) {
             size_t budget = ro.dgrad_params > 0 ? (size_t)ro.dgrad_params : (size_t)(1.25e6 * ((double)Mo * No * Ko) / (2400.0 * 768.0 * 3072.0)) / 1024 * 1024;
             if (mode == EPI_DGELU) budget = ro.dgelu_params > 0 ? (size_t)ro.dgelu_params : (size_t)blocks * 14336;

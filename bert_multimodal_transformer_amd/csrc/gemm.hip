@@ -744,19 +744,25 @@ static int nn_ride_cfg(int mode, const GemmArgs& a, GemmArgs& p, int* per_cu) {
     p = a;
     if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
     static int plain = -1;          // every selection switch of launch_tile / launch_cfg at its default (else: the plain launch, no riders)
-    if (plain < 0)
-        plain = (env_int("MB_GEMM_TRACE", 0) == 0 && env_int("MB_GEMM_TILE_N768", 64) == 64 && env_int("MB_GEMM_64_STAGES", 3) == 3 &&
+    static int narrow64 = -1;       // the narrow launches run the 64 x 64 kernel (the 128 x 64 ping-pong tile has its own riders: none yet)
+    if (plain < 0) {
+        plain = (env_int("MB_GEMM_TRACE", 0) == 0 && env_int("MB_GEMM_64_STAGES", 3) == 3 &&
                  env_int("MB_GEMM_KSPLIT", 0) == 0 && env_int("MB_GEMM_TILE_BIG", 0) == 0) ? 1 : 0;
+        narrow64 = env_int("MB_GEMM_TILE_N768", 64) == 64 ? 1 : 0;
+    }
     if (g_impl == 1 || g_stages > 0 || !plain || a.bseg > 0) return 0;
     if (mode != EPI_ADD_RES && mode != EPI_DGELU) return 0;
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const bool big = t128 >= 224;
+    if (!big && !narrow64) return 0;
     if (big != (mode == EPI_DGELU)) return 0;
     const int bn = big ? 128 : 64;
     if (a.N % bn != 0 || a.N % 8 != 0 || a.ldc % 8 != 0) return 0;
     if ((a.K % BKE) || (a.lda % EPV) || (a.ldb % EPV) || (((uintptr_t)a.A | (uintptr_t)a.B) % 16) || a.K / BKE < 2) return 0;
     const int tiles = big ? choose_regions<128, 128>(p) : choose_regions<64, 64>(p);
-    if (tiles > 512) return 0;
+    // (beyond 512 tiles the plain launch of the 64 x 64 shapes is another kernel -- two slots, five blocks per CU; the 128 x 128 kernel stays the
+    //  same and simply takes more rounds: at T = 4096 its 768 tiles are one and a half, the riders get the slots the second round leaves free)
+    if (tiles > (big ? 4096 : 512)) return 0;
     if (per_cu) *per_cu = big ? 2 : 3;
     p.kchunk = p.K;
     p.dbg = g_dbg;
@@ -783,11 +789,36 @@ int gemm_nn_ride_launch(int dtype, int mode, const GemmArgs& a, const AdamRide& 
     return (int)hipGetLastError();
 }
 
-static int g_tile_n768 = -1;       // MB_GEMM_TILE_N768: tile code for auto-selected narrow GEMMs (64 | 12864 | 128)
+static int g_tile_n768 = -1;       // MB_GEMM_TILE_N768: tile code for auto-selected narrow GEMMs (64 | 12864 | 12872 | 128)
+
+// Tile code 12872: the 128 x 64 eight-wave ping-pong tile (gemm_pp.hip, bf16).  What it cannot take -- a layout / epilogue pair that is
+// not instantiated, a k range that is not whole 128-deep stages or shorter than three of them, a segmented B, more than `pn_max` padded
+// tiles (one tile per CU: a second round costs more than the 64 x 64 kernel's three blocks per CU) -- runs the 64 x 64 configuration.
+template <class T, bool AK, bool BK, int MODE>
+static int launch_pn(const GemmArgs& a, int splits, bool forced, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        GemmArgs p = a;
+        const int tiles = choose_regions<128, 64>(p);
+        if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
+        bool ok = splits <= 1 && g_impl != 1 && p.bseg <= 0 && (p.K % 128 == 0) && p.K / 128 >= 3 && (p.lda % 8 == 0) && (p.ldb % 8 == 0) &&
+                  (((uintptr_t)p.A | (uintptr_t)p.B) % 16 == 0) && (forced || tiles <= 256);
+        if (AK) ok = ok && (p.M % 128 == 0);
+        if (BK) ok = ok && (p.N % 64 == 0);
+        if (ok) {
+            p.kchunk = p.K;
+            p.dbg = g_dbg;
+            p.trace = (g_trace_on != 0) ? trace_buffer(tiles, st) : nullptr;
+            const int rc = gemm_pn_launch(AK, BK, MODE, p, dim3(tiles), st);
+            if (rc != MB_ERR_MODE) return rc;
+        }
+    }
+    return launch_cfg<T, 64, 64, AK, BK, MODE>(a, splits, st);
+}
 static int g_tile_big = -1;        // MB_GEMM_TILE_BIG: 1 = 256 x 128 eight-wave tiles where they make ONE round on the chip (default 0: measured slower)
 
 template <class T, bool AK, bool BK, int MODE>
 static int launch_tile(const GemmArgs& a, int splits, int tile, hipStream_t st) {
+    const bool forced = tile != 0;
     if (tile == 0) {   // heuristic: fill >= ~1 wave of the 256 CUs
         const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (splits < 1 ? 1 : splits);
         if (g_tile_n768 < 0) g_tile_n768 = env_int("MB_GEMM_TILE_N768", 64);
@@ -803,6 +834,7 @@ static int launch_tile(const GemmArgs& a, int splits, int tile, hipStream_t st) 
     if (tile == 256) tile = 128;
     if (tile == 128) return launch_cfg<T, 128, 128, AK, BK, MODE>(a, splits, st);
     if (tile == 12864) return launch_cfg<T, 128, 64, AK, BK, MODE>(a, splits, st);
+    if (tile == 12872) return launch_pn<T, AK, BK, MODE>(a, splits, forced, st);
     return launch_cfg<T, 64, 64, AK, BK, MODE>(a, splits, st);
 }
 

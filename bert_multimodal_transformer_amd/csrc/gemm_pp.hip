@@ -36,6 +36,12 @@ namespace mb {
 
 constexpr int kPpBM = 256, kPpBN = 128, kPpKB = 128, kPpSlots = 3, kPpWaves = 8;
 constexpr int kPpStage = (kPpBM + kPpBN) * kPpKB;       // 48 KB
+// The narrow form for the N = 768 launches (T = 2400: 228 tiles, one per CU, where 256 x 128 would make 60): 128 x 64 outputs, 128 k
+// per stage (256-byte k rows) -- the SAME 48-KB stage, the same six DMA pieces per wave; a wave owns 32 x 32 outputs and four
+// 32-deep slabs: 16 MFMAs and 16 (row image) / 24-32 (k-major) fragment reads per stage.  25 % fewer operand bytes per FLOP than
+// the 64 x 64 tiles those launches run otherwise (they are bound by the L2 -> LDS fill).
+constexpr int kPnBM = 128, kPnBN = 64, kPnKB = 256;
+static_assert((kPnBM + kPnBN) * kPnKB == kPpStage, "both forms share the ring geometry");
 
 #ifdef MB_GEMM_LOOPTRACE
 // wave 0 (group 0) and wave 4 (group 1) stamp kPpIters k-stages from stage kPpFirst on, kPpPoints shader-clock stamps each:
@@ -47,12 +53,12 @@ constexpr int kPpFirst = 4, kPpIters = 10, kPpPoints = 6;
 // dst = s + v as a pinned statement (stays between the MFMAs it is written between)
 __device__ __forceinline__ void pinned_add(uint32_t& dst, uint32_t s, uint32_t v) { asm volatile("v_add_u32 %0, %1, %2" : "=v"(dst) : "s"(s), "v"(v)); }
 
-template <bool AK, bool BK, int MODE>
+template <int BM, int BN, int KB, bool AK, bool BK, int MODE>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, const int n0, char* smem) {
     typedef bf16 T;
-    constexpr int BM = kPpBM, BN = kPpBN, KB = kPpKB, NW = kPpWaves, STAGE = kPpStage;
-    constexpr int BKE = KB / 2;                    // 64 k per stage
-    constexpr int MT = 4, NT = 4, NSLAB = 2;       // a wave: 64 x 64 outputs, two 32-deep slabs per stage
+    constexpr int NW = kPpWaves, STAGE = (BM + BN) * KB;
+    constexpr int BKE = KB / 2;                    // 64 (128) k per stage
+    constexpr int MT = BM / 64, NT = BN / 32, NSLAB = BKE / 32;       // a wave: 64 x 64 (32 x 32) outputs, two (four) 32-deep slabs per stage
     typedef Dma<T, BM, AK, KB, NW> DA;
     typedef Dma<T, BN, BK, KB, NW> DB;
     constexpr int G = DA::NI + DB::NI;             // DMA pieces per wave per stage (4 + 2)
@@ -100,8 +106,8 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
     RA ra;
     RB_ rb;
     const uint32_t lds0 = (uint32_t)(size_t)LDS_PTR(smem);
-    ra.init(lds0, wr * 64, 0, lane);
-    rb.init(lds0 + BM * KB, wc * 64, 0, lane);
+    ra.init(lds0, wr * (BM / 4), 0, lane);
+    rb.init(lds0 + BM * KB, wc * (BN / 2), 0, lane);
     // A wave's pieces of a stage are CONSECUTIVE 1-KB pieces of the image (wave * NI + i): one m0 per operand and stage, piece i is
     // the instruction's immediate offset i * 1024 -- which the hardware adds to the LDS address AND to the memory address, so the
     // lane offsets are taken back by i * 1024 and the descriptors' bases by kBias to keep them non-negative.
@@ -268,7 +274,15 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(1024))) char smem[kPpSlots * kPpStage];
     int m0, n0;
     if (!tile_origin<kPpBM, kPpBN>(p, m0, n0, blockIdx.x)) return;
-    gemm_pp_body<AK, BK, MODE>(p, m0, n0, smem);
+    gemm_pp_body<kPpBM, kPpBN, kPpKB, AK, BK, MODE>(p, m0, n0, smem);
+}
+
+template <bool AK, bool BK, int MODE>
+__global__ void __launch_bounds__(512) gemm_pn_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(1024))) char smem[kPpSlots * kPpStage];
+    int m0, n0;
+    if (!tile_origin<kPnBM, kPnBN>(p, m0, n0, blockIdx.x)) return;
+    gemm_pp_body<kPnBM, kPnBN, kPnKB, AK, BK, MODE>(p, m0, n0, smem);
 }
 
 // the weight gradients of a layer (dW = dY^T X: both operands k-major), one launch (gemm.hip: launch_grouped places the tiles)
@@ -280,7 +294,7 @@ __global__ void __launch_bounds__(512) gemm_pp_grouped_tn_kernel(const GroupedGe
     }
     int g, m0, n0;
     if (!grouped_tile_origin<kPpBM, kPpBN>(ga, g, m0, n0)) return;
-    gemm_pp_body<true, true, EPI_ACCUM_F32>(ga.g[g], m0, n0, smem);
+    gemm_pp_body<kPpBM, kPpBN, kPpKB, true, true, EPI_ACCUM_F32>(ga.g[g], m0, n0, smem);
 }
 
 int gemm_pp_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hipStream_t st) {
@@ -294,6 +308,21 @@ int gemm_pp_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hip
     MB_PP(false, true, EPI_DGELU)
     MB_PP(true, true, EPI_ACCUM_F32)
 #undef MB_PP
+    return MB_ERR_MODE;
+}
+
+// the 128 x 64 form (bf16; K a multiple of 128, at least three stages): the N = 768 forward and dgrad launches
+int gemm_pn_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hipStream_t st) {
+#define MB_PN(AKV, BKV, MODEV) \
+    if (ak == AKV && bk == BKV && mode == MODEV) { \
+        MB_GEMM_LAUNCH((gemm_pn_kernel<AKV, BKV, MODEV>), grid, dim3(512), st, p, &p, 1); \
+        return (int)hipGetLastError(); \
+    }
+    MB_PN(false, false, EPI_BIAS)
+    MB_PN(false, false, EPI_BIAS_DROP_RES)
+    MB_PN(false, false, EPI_ADD_RES)
+    MB_PN(false, true, EPI_ADD_RES)
+#undef MB_PN
     return MB_ERR_MODE;
 }
 
