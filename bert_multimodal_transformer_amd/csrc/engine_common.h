@@ -122,6 +122,11 @@ inline int gemm(int dtype, int layout, int mode, int M, int N, int K, const void
 // kernel (the riders share SIMDs with the tiles: every instruction of theirs costs the partner wave an MFMA slot, so the gain is small and
 // turns at ~1.5 M: same box 3.566 ms without | 3.544 at 1 - 1.5 M | 3.578 at 2.5 M per launch), 14,336 per free slot of the 128 x 128
 // kernel (56 CUs that hold one tile instead of two)  (profiles/r06_adamw_ride_dgrad.txt)
+inline long ride_pn_params() {       // MB_ADAMW_RIDE_PN_PARAMS: parameters per narrow dgrad launch on the 128 x 64 tile (0 = by the launch's size)
+    static long v = -1;
+    if (v < 0) { const char* e = getenv("MB_ADAMW_RIDE_PN_PARAMS"); v = e ? atol(e) : 0; }
+    return v;
+}
 struct RideOpts { int dgrad = 2, dgrad_blocks = 0; long dgrad_params = 0, dgelu_params = 0; };
 template <class Take>
 inline int dgrad_with_riders(int dt, int mode, int Mo, int No, int Ko, const void* dY, int ldy, const void* Wt, int ldw, void* dX, int ldx, const void* R,
@@ -137,6 +142,10 @@ inline int dgrad_with_riders(int dt, int mode, int Mo, int No, int Ko, const voi
         if (blocks >= 8) {
             size_t budget = ro.dgrad_params > 0 ? (size_t)ro.dgrad_params : (size_t)(1.25e6 * ((double)Mo * No * Ko) / (2400.0 * 768.0 * 3072.0)) / 1024 * 1024;
             if (mode == EPI_DGELU) budget = ro.dgelu_params > 0 ? (size_t)ro.dgelu_params : (size_t)blocks * 14336;
+            // the 128 x 64 ping-pong tile (one per CU): the riders are whole idle CUs, ~41 GB/s each for the launch's duration
+            else if (per_cu == 1) budget = ride_pn_params() > 0 ? (size_t)ride_pn_params() : (size_t)(blocks * 16384.0 * ((double)Mo * No * Ko) / (2400.0 * 768.0 * 3072.0)) / 1024 * 1024;
+            // (16 K parameters per rider CU next to 11.3 GFLOP: more stretches the launch -- 26 K: +1 % per step, 40 K: +6 %; none at all: +0.4 %;
+            //  profiles/r06_pn_default_ab.txt)
             const AdamRide r = take(budget, blocks);
             if (r.blocks) return gemm_nn_ride_launch(dt, mode, a, r, st);
         }

@@ -735,26 +735,54 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// Tile code 12872: the 128 x 64 eight-wave ping-pong tile (gemm_pp.hip, bf16) -- the default of the narrow (N = 768) launches since round 6.
+// -> the padded tile count of the launch, 0 = this problem runs the 64 x 64 configuration: a k range that is not whole 128-deep stages or
+// shorter than three of them, a segmented B, split-K, and (unless the caller named the tile) more than 256 padded tiles -- one tile per
+// CU: a second round costs more than the 64 x 64 kernel's three blocks per CU (T = 4096: 384 tiles) -- or fewer than 168: small problems
+// keep the finer 64 x 64 grid.
+static int g_tile_n768 = -1;       // MB_GEMM_TILE_N768: tile code for auto-selected narrow GEMMs (12872 | 64 | 12864 | 128)
+static int tile_n768() {
+    if (g_tile_n768 < 0) g_tile_n768 = env_int("MB_GEMM_TILE_N768", 12872);
+    return g_tile_n768;
+}
+static int pn_cfg(const GemmArgs& a, bool ak, bool bk, int splits, bool forced, GemmArgs& p) {
+    p = a;
+    const int tiles = choose_regions<128, 64>(p);
+    if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
+    bool ok = splits <= 1 && g_impl != 1 && g_stages <= 0 && p.bseg <= 0 && (p.K % 128 == 0) && p.K / 128 >= 3 && (p.lda % 8 == 0) && (p.ldb % 8 == 0) &&
+              (((uintptr_t)p.A | (uintptr_t)p.B) % 16 == 0) && (forced || (tiles <= 256 && tiles >= 168));
+    if (ak) ok = ok && (p.M % 128 == 0);
+    if (bk) ok = ok && (p.N % 64 == 0);
+    if (!ok) return 0;
+    p.kchunk = p.K;
+    p.dbg = g_dbg;
+    p.trace = nullptr;
+    return tiles;
+}
+
 // A dgrad launch (GEMM_NN, bf16) with riders, for the two configurations that leave block slots free at T = 2400:
 //   EPI_ADD_RES, N = 768  : the 64 x 64 three-slot kernel, 456 tiles in 768 slots (three 48-KB rings per CU)
 //   EPI_DGELU,  N = 3072  : the 128 x 128 two-slot kernel, 456 tiles in 512 slots -- 56 CUs hold ONE tile and are half idle throughout
 // -> the padded tile count of the launch launch_tile / launch_cfg above would make of `a` (and the block slots per CU), 0 = another kernel.
-static int nn_ride_cfg(int mode, const GemmArgs& a, GemmArgs& p, int* per_cu) {
+static int nn_ride_cfg(int mode, const GemmArgs& a, GemmArgs& p, int* per_cu, bool* pn = nullptr) {
     constexpr int BKE = 64, EPV = 8;
     p = a;
+    if (pn) *pn = false;
     if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
     static int plain = -1;          // every selection switch of launch_tile / launch_cfg at its default (else: the plain launch, no riders)
-    static int narrow64 = -1;       // the narrow launches run the 64 x 64 kernel (the 128 x 64 ping-pong tile has its own riders: none yet)
-    if (plain < 0) {
+    if (plain < 0)
         plain = (env_int("MB_GEMM_TRACE", 0) == 0 && env_int("MB_GEMM_64_STAGES", 3) == 3 &&
                  env_int("MB_GEMM_KSPLIT", 0) == 0 && env_int("MB_GEMM_TILE_BIG", 0) == 0) ? 1 : 0;
-        narrow64 = env_int("MB_GEMM_TILE_N768", 64) == 64 ? 1 : 0;
-    }
     if (g_impl == 1 || g_stages > 0 || !plain || a.bseg > 0) return 0;
     if (mode != EPI_ADD_RES && mode != EPI_DGELU) return 0;
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const bool big = t128 >= 224;
-    if (!big && !narrow64) return 0;
+    if (!big && tile_n768() == 12872) {
+        // the 128 x 64 ping-pong tile: ONE tile per CU (144 KB of LDS), the riders are whole idle CUs like the grouped weight gradient's
+        const int tiles = mode == EPI_ADD_RES ? pn_cfg(a, false, true, 1, false, p) : 0;
+        if (tiles > 0) { if (per_cu) *per_cu = 1; if (pn) *pn = true; return tiles; }
+        p = a;
+    } else if (!big && tile_n768() != 64) return 0;
     if (big != (mode == EPI_DGELU)) return 0;
     const int bn = big ? 128 : 64;
     if (a.N % bn != 0 || a.N % 8 != 0 || a.ldc % 8 != 0) return 0;
@@ -776,8 +804,10 @@ int gemm_nn_ride_tiles(int dtype, int mode, const GemmArgs& a, int* per_cu) {
 }
 int gemm_nn_ride_launch(int dtype, int mode, const GemmArgs& a, const AdamRide& ride, hipStream_t st) {
     GemmArgs p;
-    const int tiles = dtype == DT_BF16 ? nn_ride_cfg(mode, a, p, nullptr) : 0;
+    bool pn = false;
+    const int tiles = dtype == DT_BF16 ? nn_ride_cfg(mode, a, p, nullptr, &pn) : 0;
     if (tiles <= 0 || ride.blocks <= 0 || (ride.blocks & 7)) return MB_ERR_MODE;
+    if (pn) return gemm_pn_ride_launch(p, ride, dim3(tiles), st);
     gemm_log_ride(ride);
     if (mode == EPI_DGELU) {
         gemm_log((const void*)(gemm2_ride_kernel<bf16, 128, 128, false, true, EPI_DGELU, 2, 128>), st, &p, 1);
@@ -789,27 +819,15 @@ int gemm_nn_ride_launch(int dtype, int mode, const GemmArgs& a, const AdamRide& 
     return (int)hipGetLastError();
 }
 
-static int g_tile_n768 = -1;       // MB_GEMM_TILE_N768: tile code for auto-selected narrow GEMMs (64 | 12864 | 12872 | 128)
-
-// Tile code 12872: the 128 x 64 eight-wave ping-pong tile (gemm_pp.hip, bf16).  What it cannot take -- a layout / epilogue pair that is
-// not instantiated, a k range that is not whole 128-deep stages or shorter than three of them, a segmented B, more than `pn_max` padded
-// tiles (one tile per CU: a second round costs more than the 64 x 64 kernel's three blocks per CU) -- runs the 64 x 64 configuration.
 template <class T, bool AK, bool BK, int MODE>
 static int launch_pn(const GemmArgs& a, int splits, bool forced, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
-        GemmArgs p = a;
-        const int tiles = choose_regions<128, 64>(p);
-        if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
-        bool ok = splits <= 1 && g_impl != 1 && p.bseg <= 0 && (p.K % 128 == 0) && p.K / 128 >= 3 && (p.lda % 8 == 0) && (p.ldb % 8 == 0) &&
-                  (((uintptr_t)p.A | (uintptr_t)p.B) % 16 == 0) && (forced || tiles <= 256);
-        if (AK) ok = ok && (p.M % 128 == 0);
-        if (BK) ok = ok && (p.N % 64 == 0);
-        if (ok) {
-            p.kchunk = p.K;
-            p.dbg = g_dbg;
+        GemmArgs p;
+        const int tiles = pn_cfg(a, AK, BK, splits, forced, p);
+        if (tiles > 0) {
             p.trace = (g_trace_on != 0) ? trace_buffer(tiles, st) : nullptr;
             const int rc = gemm_pn_launch(AK, BK, MODE, p, dim3(tiles), st);
-            if (rc != MB_ERR_MODE) return rc;
+            if (rc != MB_ERR_MODE) return rc;      // (a layout / epilogue pair that is not instantiated: 64 x 64)
         }
     }
     return launch_cfg<T, 64, 64, AK, BK, MODE>(a, splits, st);
@@ -821,9 +839,8 @@ static int launch_tile(const GemmArgs& a, int splits, int tile, hipStream_t st) 
     const bool forced = tile != 0;
     if (tile == 0) {   // heuristic: fill >= ~1 wave of the 256 CUs
         const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (splits < 1 ? 1 : splits);
-        if (g_tile_n768 < 0) g_tile_n768 = env_int("MB_GEMM_TILE_N768", 64);
         if (g_tile_big < 0) g_tile_big = env_int("MB_GEMM_TILE_BIG", 0);
-        tile = (t128 >= 224) ? 128 : g_tile_n768;
+        tile = (t128 >= 224) ? 128 : tile_n768();
         // one 256 x 128 tile per CU: taken when the whole output is a single, reasonably full round of the 256 CUs
         const long t256 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
         if (g_tile_big && sizeof(T) == 2 && splits <= 1 && (t256 <= 256 || g_tile_big == 2) && t256 >= 168) tile = 256;      // (2: also when it takes more than one round)
@@ -834,7 +851,7 @@ static int launch_tile(const GemmArgs& a, int splits, int tile, hipStream_t st) 
     if (tile == 256) tile = 128;
     if (tile == 128) return launch_cfg<T, 128, 128, AK, BK, MODE>(a, splits, st);
     if (tile == 12864) return launch_cfg<T, 128, 64, AK, BK, MODE>(a, splits, st);
-    if (tile == 12872) return launch_pn<T, AK, BK, MODE>(a, splits, forced, st);
+    if (tile == 12872) return launch_pn<T, AK, BK, MODE>(a, splits, forced, st);      // (falls back to 64 x 64 by itself)
     return launch_cfg<T, 64, 64, AK, BK, MODE>(a, splits, st);
 }
 

@@ -41,6 +41,10 @@ constexpr int kPpStage = (kPpBM + kPpBN) * kPpKB;       // 48 KB
 // 32-deep slabs: 16 MFMAs and 16 (row image) / 24-32 (k-major) fragment reads per stage.  25 % fewer operand bytes per FLOP than
 // the 64 x 64 tiles those launches run otherwise (they are bound by the L2 -> LDS fill).
 constexpr int kPnBM = 128, kPnBN = 64, kPnKB = 256;
+#ifndef MB_PN_KSW
+#define MB_PN_KSW 0            // 1 = k-split waves in the narrow tile (measured: the loop gains 9 %, the four-partial epilogue takes it back)
+#endif
+constexpr bool kPnKsw = MB_PN_KSW != 0;
 static_assert((kPnBM + kPnBN) * kPnKB == kPpStage, "both forms share the ring geometry");
 
 #ifdef MB_GEMM_LOOPTRACE
@@ -53,19 +57,30 @@ constexpr int kPpFirst = 4, kPpIters = 10, kPpPoints = 6;
 // dst = s + v as a pinned statement (stays between the MFMAs it is written between)
 __device__ __forceinline__ void pinned_add(uint32_t& dst, uint32_t s, uint32_t v) { asm volatile("v_add_u32 %0, %1, %2" : "=v"(dst) : "s"(s), "v"(v)); }
 
-template <int BM, int BN, int KB, bool AK, bool BK, int MODE>
+// KSW (the narrow tile): the four waves of a group split the STAGE's k range instead of the group's outputs -- wave w multiplies slab w
+// of every stage for the group's whole 64 x 64 half (16 accumulator tiles, partial sums added in the epilogue).  Half the fragment
+// reads per MFMA of the 32 x 32-per-wave split: 8 (12 with a k-major B) instead of 16 (24) per stage, and both phases of the loop were
+// as long as those reads take (profiles/r06_pn_looptrace.txt: COMP 464 clocks for 272 of MFMA next to a partner issuing 16 reads).
+template <int BM, int BN, int KB, bool AK, bool BK, int MODE, bool KSW = false>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, const int n0, char* smem) {
     typedef bf16 T;
     constexpr int NW = kPpWaves, STAGE = (BM + BN) * KB;
     constexpr int BKE = KB / 2;                    // 64 (128) k per stage
-    constexpr int MT = BM / 64, NT = BN / 32, NSLAB = BKE / 32;       // a wave: 64 x 64 (32 x 32) outputs, two (four) 32-deep slabs per stage
+    static_assert(!KSW || BKE / 32 == 4, "k-split waves: one 32-deep slab per wave and stage");
+    // a wave: 64 x 64 (32 x 32) outputs, two (four) 32-deep slabs per stage; KSW: the group's 64 x 64, one slab
+    constexpr int MT = KSW ? BM / 32 : BM / 64, NT = KSW ? BN / 16 : BN / 32, NSLAB = KSW ? 1 : BKE / 32;
     typedef Dma<T, BM, AK, KB, NW> DA;
     typedef Dma<T, BN, BK, KB, NW> DB;
     constexpr int G = DA::NI + DB::NI;             // DMA pieces per wave per stage (4 + 2)
     typedef typename DA::template Reader<MT, NSLAB> RA;
     typedef typename DB::template Reader<NT, NSLAB> RB_;
     constexpr int NRA = MT * RA::READS_PER_FRAG, NRB = NT * RB_::READS_PER_FRAG;
-    constexpr int NM = MT * NT * NSLAB;            // MFMAs per stage (32)
+    constexpr int NM = MT * NT * NSLAB;            // MFMAs per stage (32 | 16)
+#ifdef MB_PP_SPREAD
+    constexpr bool SPREAD = MB_PP_SPREAD != 0;     // (A/B builds)
+#else
+    constexpr bool SPREAD = NM < 32;               // DMA pieces at even distances over the MFMAs of COMP (else: behind the first MFMAs)
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,6 +103,22 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The narrow tile has four accumulator tiles per wave: slab after slab into the same four, an MFMA meets its predecessor on that
+    // tile four issues later.  NACC > 1: the slabs of a stage accumulate into NACC separate sets (summed behind the k loop), 16
+    // independent chains like the 256 x 128 form.
+#ifdef MB_PN_NACC
+    constexpr int NACC = MB_PN_NACC;
+#else
+    constexpr int NACC = (MT * NT >= 16) ? 1 : (NSLAB < 16 / (MT * NT) ? NSLAB : 16 / (MT * NT));
+#endif
+    static_assert(NSLAB % NACC == 0, "whole slabs per accumulator set");
+    f32x4 accx[NACC > 1 ? NACC - 1 : 1][MT][NT];
+#pragma unroll
+    for (int a = 0; a < (NACC > 1 ? NACC - 1 : 1); ++a)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) accx[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto stamp = [&](int k) {
         if (p.trace && tid == 0) p.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kTraceStride + k] = wall_clock64();
@@ -106,8 +137,13 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
     RA ra;
     RB_ rb;
     const uint32_t lds0 = (uint32_t)(size_t)LDS_PTR(smem);
-    ra.init(lds0, wr * (BM / 4), 0, lane);
-    rb.init(lds0 + BM * KB, wc * (BN / 2), 0, lane);
+    if constexpr (KSW) {
+        ra.init(lds0, grp * (BM / 2), wave & 3, lane);
+        rb.init(lds0 + BM * KB, 0, wave & 3, lane);
+    } else {
+        ra.init(lds0, wr * (BM / 4), 0, lane);
+        rb.init(lds0 + BM * KB, wc * (BN / 2), 0, lane);
+    }
     // A wave's pieces of a stage are CONSECUTIVE 1-KB pieces of the image (wave * NI + i): one m0 per operand and stage, piece i is
     // the instruction's immediate offset i * 1024 -- which the hardware adds to the LDS address AND to the memory address, so the
     // lane offsets are taken back by i * 1024 and the descriptors' bases by kBias to keep them non-negative.
@@ -174,19 +210,33 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
     auto comp_stage_ = [&](auto dmac, auto mfc, uint32_t slot, uint32_t nxt) {
         constexpr bool DMA = decltype(dmac)::value, MF = decltype(mfc)::value;
         constexpr int NF = (DMA ? G : 0) + NADDR;
+        auto addr_add = [&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            if constexpr (J < RA::NB) pinned_add(addr_a[J], nxt, ra.base[J]);
+            else pinned_add(addr_b[J - RA::NB], nxt, rb.base[J - RA::NB]);
+        };
         static_for<NM>([&](auto mc) {
             constexpr int M = decltype(mc)::value, S = M / (MT * NT), Q = M % (MT * NT);
-            if constexpr (MF) mma16_pinned(acc[Q / NT][Q % NT], fb[S][Q % NT].v, fa[S][Q / NT].v);
-            constexpr int f0 = M * NF / NM, f1 = (M + 1) * NF / NM;
-            static_for<f1 - f0>([&](auto fc) {
-                constexpr int F = f0 + decltype(fc)::value;
-                if constexpr (DMA && F < G) dma_piece(std::integral_constant<int, F>{}, slot);
-                else {
-                    constexpr int J = F - (DMA ? G : 0);
-                    if constexpr (J < RA::NB) pinned_add(addr_a[J], nxt, ra.base[J]);
-                    else pinned_add(addr_b[J - RA::NB], nxt, rb.base[J - RA::NB]);
-                }
-            });
+            if constexpr (MF) {
+                if constexpr (S % NACC == 0) mma16_pinned(acc[Q / NT][Q % NT], fb[S][Q % NT].v, fa[S][Q / NT].v);
+                else mma16_pinned(accx[S % NACC - 1][Q / NT][Q % NT], fb[S][Q % NT].v, fa[S][Q / NT].v);
+            }
+            if constexpr (SPREAD) {
+                // the narrow tile has 16 MFMAs for the same six pieces: one behind (almost) every MFMA, each piece held the wave's issue for
+                // ~30 clocks (COMP 464 clocks for 272 of MFMA, profiles/r06_pn_looptrace.txt) -- a piece every ~2.7 MFMAs is what the
+                // 256 x 128 form has and pays nothing for
+                constexpr int d0 = DMA ? (M * G + NM - 1) / NM : 0, d1 = DMA ? ((M + 1) * G + NM - 1) / NM : 0;
+                static_for<d1 - d0>([&](auto fc) { dma_piece(std::integral_constant<int, d0 + decltype(fc)::value>{}, slot); });
+                constexpr int a0 = M * NADDR / NM, a1 = (M + 1) * NADDR / NM;
+                static_for<a1 - a0>([&](auto fc) { addr_add(std::integral_constant<int, a0 + decltype(fc)::value>{}); });
+            } else {
+                constexpr int f0 = M * NF / NM, f1 = (M + 1) * NF / NM;
+                static_for<f1 - f0>([&](auto fc) {
+                    constexpr int F = f0 + decltype(fc)::value;
+                    if constexpr (DMA && F < G) dma_piece(std::integral_constant<int, F>{}, slot);
+                    else addr_add(std::integral_constant<int, F - (DMA ? G : 0)>{});
+                });
+            }
         });
         if constexpr (DMA) dma_advance();
     };
@@ -212,7 +262,16 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
     if (grp) { issue_stage(2u * STAGE); wait_vmcnt<2 * G>(); } else wait_vmcnt<G>();
     __builtin_amdgcn_s_barrier();                    // stage 0 has landed for everybody
     stamp(1);
-    if (grp) __builtin_amdgcn_s_barrier();           // group 1 runs one phase behind
+#ifndef MB_PP_ONE_BARRIER
+#define MB_PP_ONE_BARRIER 1
+#endif
+    // ONE barrier per k-stage (MB_PP_ONE_BARRIER, default): group 0 meets it behind its COMP, group 1 behind its LOAD -- the pair that
+    // carries the ring's hazards (a wave's share of stage t+1 has landed; the slot the next DMA pieces go to has been read by everybody).
+    // The other pair of the two-barrier form (group 0 behind LOAD, group 1 behind COMP) only forced the alternation, which the first pair
+    // restores every stage anyway: group 0 leaves it into a LOAD, group 1 into a COMP.  An eight-wave barrier costs ~200 clocks of a
+    // ~750-clock phase (profiles/r06_pn_looptrace.txt).
+    constexpr bool ONEB = MB_PP_ONE_BARRIER != 0;
+    if (!ONEB && grp) __builtin_amdgcn_s_barrier();  // (two-barrier form) group 1 runs one phase behind
     uint32_t cur = 0u, dslot = grp ? 0u : 2u * STAGE;
     // DM: 1 = every wave requests its next stage between the MFMAs, 2 = group 0 only (in front of the MFMAs), 0 = nobody
     auto stage = [&](int t, auto dm, auto wc_) {
@@ -226,7 +285,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
         land(wc_);                                   // group 1: its share of stage t+1 has landed (group 0: nothing younger than stage t+1 yet)
         PP_LT(t, 2);
         __builtin_amdgcn_sched_barrier(0);           // the scalar bookkeeping of COMP stays behind the barrier (in LOAD it would cost ~16 clocks each)
-        __builtin_amdgcn_s_barrier();
+        if (!ONEB || grp) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         PP_LT(t, 3);
         // ---- COMP(t)
@@ -240,7 +299,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
         PP_LT(t, 4);
         land(wc_);                                   // group 0: its share of stage t+1 (group 1: of stage t+2, a phase early -- it has had two)
         PP_LT(t, 5);
-        __builtin_amdgcn_s_barrier();
+        if (!ONEB || !grp) __builtin_amdgcn_s_barrier();
         cur = nxt;
         dslot = dslot == 2u * STAGE ? 0u : dslot + STAGE;
     };
@@ -252,9 +311,18 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
     stage(t, D2{}, W1{});
     stage(t + 1, D0{}, W0{});
     stage(t + 2, D0{}, WN{});
-    if (!grp) __builtin_amdgcn_s_barrier();          // pairs with group 1's last COMP
+    if (!ONEB && !grp) __builtin_amdgcn_s_barrier(); // (two-barrier form) pairs with group 1's last COMP
+    if constexpr (NACC > 1) {
+#pragma unroll
+        for (int a = 0; a < NACC - 1; ++a)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] += accx[a][i][j];
+    }
     stamp(2);
-    gemm_epilogue<T, BM, BN, MODE, false, NW>(p, acc, m0, n0, wave, lane, smem, pre);
+    if constexpr (KSW) gemm_epilogue<T, BM, BN, MODE, true, NW, 2>(p, acc, m0, n0, wave, lane, smem, pre);
+    else gemm_epilogue<T, BM, BN, MODE, false, NW>(p, acc, m0, n0, wave, lane, smem, pre);
     if (p.trace) {
         stamp(3);
         wait_vmcnt<0>();
@@ -282,7 +350,20 @@ __global__ void __launch_bounds__(512) gemm_pn_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(1024))) char smem[kPpSlots * kPpStage];
     int m0, n0;
     if (!tile_origin<kPnBM, kPnBN>(p, m0, n0, blockIdx.x)) return;
-    gemm_pp_body<kPnBM, kPnBN, kPnKB, AK, BK, MODE>(p, m0, n0, smem);
+    gemm_pp_body<kPnBM, kPnBN, kPnKB, AK, BK, MODE, kPnKsw>(p, m0, n0, smem);
+}
+
+// a narrow dgrad launch (dX = dY W + R) with riders: 228 tiles at T = 2400 leave whole CUs idle (16 once the grid's padding is counted
+// per XCD); the riders come FIRST in the grid (multiples of 8: the tiles keep their XCDs) and each takes a CU to itself
+__global__ void __launch_bounds__(512) gemm_pn_ride_kernel(const GemmArgs p, const AdamRide ride) {
+    __shared__ __attribute__((aligned(1024))) char smem[kPpSlots * kPpStage];
+    if ((int)blockIdx.x < ride.blocks) {
+        adam_ride_block<512, MB_RIDE_UNR>(ride, (int)blockIdx.x);
+        return;
+    }
+    int m0, n0;
+    if (!tile_origin<kPnBM, kPnBN>(p, m0, n0, (int)blockIdx.x - ride.blocks)) return;
+    gemm_pp_body<kPnBM, kPnBN, kPnKB, false, true, EPI_ADD_RES, kPnKsw>(p, m0, n0, smem);
 }
 
 // the weight gradients of a layer (dW = dY^T X: both operands k-major), one launch (gemm.hip: launch_grouped places the tiles)
@@ -324,6 +405,13 @@ int gemm_pn_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hip
     MB_PN(false, true, EPI_ADD_RES)
 #undef MB_PN
     return MB_ERR_MODE;
+}
+
+int gemm_pn_ride_launch(const GemmArgs& p, const AdamRide& ride, dim3 grid, hipStream_t st) {
+    gemm_log_ride(ride);
+    gemm_log((const void*)gemm_pn_ride_kernel, st, &p, 1);
+    hipLaunchKernelGGL(gemm_pn_ride_kernel, dim3(grid.x + ride.blocks), dim3(512), 0, st, p, ride);
+    return (int)hipGetLastError();
 }
 
 int gemm_pp_grouped_launch(const GroupedGemmArgs& ga, int grid, hipStream_t st) {

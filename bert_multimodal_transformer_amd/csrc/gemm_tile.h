@@ -134,18 +134,23 @@ struct EpiPre {
 
 // KS (k-split waves): every wave holds a partial sum of the WHOLE tile (its quarter of every k-stage); the four partial tiles
 // are staged side by side and added in the row-major pass.
-template <class T, int BM, int BN, int MODE, bool KS, int NW = 4>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS ? BM / 16 : BM / (8 * NW)][KS ? BN / 16 : BN / 32],
-                                              int m0, int n0, int wave, int lane, char* smem,
+// NG > 1 (with KS; the eight-wave 128 x 64 tile of gemm_pp.hip): NG groups of four k-split waves, group g owns tile rows
+// [g * BM / NG, (g + 1) * BM / NG) -- its four partial tiles are staged behind those of the groups before it.
+template <class T, int BM, int BN, int MODE, bool KS, int NW = 4, int NG = 1>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS ? BM / NG / 16 : BM / (8 * NW)][KS ? BN / 16 : BN / 32],
+                                              int m0, int n0, int wave, int lane, char* smem_,
                                               const EpiPre<T, BM, BN, MODE, NW>& pre) {
     typedef EpiPre<T, BM, BN, MODE, NW> Pre;
+    static_assert(NG == 1 || (KS && NW == 4 * NG), "groups are groups of four k-split waves");
     constexpr int WM = NW / 2;                      // waves along m (each wave: BM / WM rows x BN / 2 columns)
-    constexpr int MT = KS ? BM / 16 : BM / (16 * WM), NT = KS ? BN / 16 : BN / 32;
+    constexpr int GR = BM / NG;                     // rows of a staged tile
+    constexpr int MT = KS ? GR / 16 : BM / (16 * WM), NT = KS ? BN / 16 : BN / 32;
     constexpr int RBY = BN * 4;                     // staged row bytes (fp32)
-    constexpr int REG = BM * RBY;                   // one staged tile
+    constexpr int REG = GR * RBY;                   // one staged tile
     constexpr int NSUM = KS ? 4 : 1;
     constexpr int TPR = Pre::TPR, RPP = Pre::RPP, NR = Pre::NR;
     const int wr = KS ? 0 : (wave >> 1), wc = KS ? 0 : (wave & 1);
+    char* const smem = smem_;
     char* stage = smem + (KS ? wave * REG : 0);
     __syncthreads();                                // every wave is done with the operand stages
 #pragma unroll
@@ -164,6 +169,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
             const int cc = tid % BN, nn = n0 + cc;
 #pragma unroll 4
             for (int r = tid / BN; r < BM; r += RPP2) {
+                static_assert(NG == 1, "(the grouped form has no column-masked store)");
                 const int m = m0 + r;
                 if (m >= p.M || nn >= pre.cvalid) continue;
                 const int o = r * RBY + (((cc >> 2) ^ (r & 7)) << 4) + (cc & 3) * 4;
@@ -201,12 +207,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[KS
         float v[8];
         {
             const int ch = c >> 2;
-            f32x4 a = *(const f32x4*)(smem + r * RBY + ((ch ^ (r & 7)) << 4));
-            f32x4 b = *(const f32x4*)(smem + r * RBY + (((ch + 1) ^ (r & 7)) << 4));
+            const int rl = NG > 1 ? r % GR : r;                                      // row inside its group's staged tiles
+            const char* sb = smem + (NG > 1 ? (r / GR) * (4 * REG) : 0) + rl * RBY;
+            f32x4 a = *(const f32x4*)(sb + ((ch ^ (rl & 7)) << 4));
+            f32x4 b = *(const f32x4*)(sb + (((ch + 1) ^ (rl & 7)) << 4));
 #pragma unroll
             for (int w = 1; w < NSUM; ++w) {
-                a += *(const f32x4*)(smem + w * REG + r * RBY + ((ch ^ (r & 7)) << 4));
-                b += *(const f32x4*)(smem + w * REG + r * RBY + (((ch + 1) ^ (r & 7)) << 4));
+                a += *(const f32x4*)(sb + w * REG + ((ch ^ (rl & 7)) << 4));
+                b += *(const f32x4*)(sb + w * REG + (((ch + 1) ^ (rl & 7)) << 4));
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) { v[q] = a[q]; v[4 + q] = b[q]; }
@@ -549,6 +557,7 @@ int gemm_dbg_flags();                                                   // MB_GE
 // 8-wave ping-pong kernels (gemm_pp.hip), bf16, 256 x 128 tiles.  MB_ERR_MODE: that (layout, epilogue) pair is not instantiated.
 int gemm_pp_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hipStream_t st);
 int gemm_pn_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hipStream_t st);      // 128 x 64 tiles, 128 k per stage
+int gemm_pn_ride_launch(const GemmArgs& p, const AdamRide& ride, dim3 grid, hipStream_t st);         // dgrad (row, k-major, + residual) with rider workgroups in front
 int gemm_pp_grouped_launch(const GroupedGemmArgs& ga, int grid, hipStream_t st);      // grid = tiles only: ga.ride.blocks are added
 #define MB_GEMM_LAUNCH(KERN, grid, block, st, arg, plog, cnt) \
     do { gemm_log((const void*)(KERN), st, plog, cnt); hipLaunchKernelGGL((KERN), grid, block, 0, st, arg); } while (0)

@@ -637,13 +637,16 @@ def test_adamw_riding_in_the_weight_gradient_launches_changes_nothing(cdt, tile,
     assert float(ride["g"].abs().max()) == 0.0 and ride["stats"] == ref["stats"]
 
 
-def test_adamw_riders_of_every_host_change_nothing_at_a_benchmark_like_width(monkeypatch):
+@pytest.mark.parametrize("B", [24, 48])
+def test_adamw_riders_of_every_host_change_nothing_at_a_benchmark_like_width(B, monkeypatch):
     """The same property at T = 1,200 tokens (B = 24, L = 50), where EVERY host carries riders: the ping-pong weight gradient's idle CUs,
     the 64 x 64 ffn1 / qkv dgrads' free slots, the 128 x 128 ffn2 dgrad (needs >= 224 tiles: not reached by the small shapes above) and the
-    attention backward.  bf16, deterministic mode, four steps over two shapes: bit-identical parameters, moments, shadow and logits."""
+    attention backward -- and at the benchmark's own T = 2,400 (B = 48), where the ffn1 / qkv dgrads run the 128 x 64 ping-pong tile and
+    their riders are the 16 CUs its 228 tiles leave idle (csrc/gemm_pp.hip gemm_pn_ride_kernel).  bf16, deterministic mode, four steps over
+    two shapes: bit-identical parameters, moments, shadow and logits."""
     monkeypatch.setenv("MB_DETERMINISTIC", "1")
     monkeypatch.setenv("MB_GROUP_WGRAD", "256")
-    shapes = ((24, 50), (24, 50), (5, 40), (24, 50))
+    shapes = ((B, 50), (B, 50), (5, 40), (B, 50))
     monkeypatch.setenv("MB_ADAMW_RIDE", "0")
     ref = _trajectory(torch.bfloat16, True, shapes=shapes)
     monkeypatch.setenv("MB_ADAMW_RIDE", "1")
