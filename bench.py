@@ -565,7 +565,7 @@ def price_trace(rows, gemm_log, B, L, dtype, n_update, steps, model="bert"):
            "kernels": table}
     if ridden:
         doc["adamw_riders"] = {"launches_logged": len(ridden), "parameters_per_launch": int(sum(ridden) / len(ridden)),
-                               "note": "HF-AdamW of already-final layers as extra workgroups of the grouped weight-gradient launches and of the ffn1 / qkv / ffn2 dgrad launches (gemm2_ride_kernel); those launches' durations above include it"}
+                               "note": "HF-AdamW of already-final layers as extra workgroups of the grouped weight-gradient launches and of the ffn1 / qkv / ffn2 dgrad launches (gemm_pn_ride_kernel, gemm2_ride_kernel); those launches' durations above include it"}
     gemm_ms = sum(x["ms_per_step"] for x in roof if x["bound"] == "mfma")
     gemm_gf = sum(x["gflop_per_step"] for x in roof if x["bound"] == "mfma")
     if gemm_ms > 0:

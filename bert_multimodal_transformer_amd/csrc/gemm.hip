@@ -748,9 +748,11 @@ static int tile_n768() {
 static int pn_cfg(const GemmArgs& a, bool ak, bool bk, int splits, bool forced, GemmArgs& p) {
     p = a;
     const int tiles = choose_regions<128, 64>(p);
+    static int pn_max = -1;         // MB_GEMM_PN_MAX (measurement switch): the largest padded tile count the auto selection takes
+    if (pn_max < 0) pn_max = env_int("MB_GEMM_PN_MAX", 256);
     if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
     bool ok = splits <= 1 && g_impl != 1 && g_stages <= 0 && p.bseg <= 0 && (p.K % 128 == 0) && p.K / 128 >= 3 && (p.lda % 8 == 0) && (p.ldb % 8 == 0) &&
-              (((uintptr_t)p.A | (uintptr_t)p.B) % 16 == 0) && (forced || (tiles <= 256 && tiles >= 168));
+              (((uintptr_t)p.A | (uintptr_t)p.B) % 16 == 0) && (forced || (tiles <= pn_max && tiles >= 168));
     if (ak) ok = ok && (p.M % 128 == 0);
     if (bk) ok = ok && (p.N % 64 == 0);
     if (!ok) return 0;
@@ -772,7 +774,7 @@ static int nn_ride_cfg(int mode, const GemmArgs& a, GemmArgs& p, int* per_cu, bo
     static int plain = -1;          // every selection switch of launch_tile / launch_cfg at its default (else: the plain launch, no riders)
     if (plain < 0)
         plain = (env_int("MB_GEMM_TRACE", 0) == 0 && env_int("MB_GEMM_64_STAGES", 3) == 3 &&
-                 env_int("MB_GEMM_KSPLIT", 0) == 0 && env_int("MB_GEMM_TILE_BIG", 0) == 0) ? 1 : 0;
+                 env_int("MB_GEMM_KSPLIT", 0) == 0 && (env_int("MB_GEMM_TILE_BIG", 0) & ~4) == 0) ? 1 : 0;
     if (g_impl == 1 || g_stages > 0 || !plain || a.bseg > 0) return 0;
     if (mode != EPI_ADD_RES && mode != EPI_DGELU) return 0;
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
@@ -843,7 +845,8 @@ static int launch_tile(const GemmArgs& a, int splits, int tile, hipStream_t st) 
         tile = (t128 >= 224) ? 128 : tile_n768();
         // one 256 x 128 tile per CU: taken when the whole output is a single, reasonably full round of the 256 CUs
         const long t256 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
-        if (g_tile_big && sizeof(T) == 2 && splits <= 1 && (t256 <= 256 || g_tile_big == 2) && t256 >= 168) tile = 256;      // (2: also when it takes more than one round)
+        // (2: also when it takes more than one round; 4: the forward launches only -- row x row operands --, the dgrad launches keep their riders)
+        if (g_tile_big && (g_tile_big != 4 || (!AK && !BK)) && sizeof(T) == 2 && splits <= 1 && (t256 <= 256 || g_tile_big == 2) && t256 >= 168) tile = 256;
     }
     if constexpr (sizeof(T) == 2) {
         if (tile == 256) return launch_cfg<T, 256, 128, AK, BK, MODE>(a, splits, st);

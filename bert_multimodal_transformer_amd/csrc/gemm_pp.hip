@@ -109,7 +109,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
 #ifdef MB_PN_NACC
     constexpr int NACC = MB_PN_NACC;
 #else
-    constexpr int NACC = (MT * NT >= 16) ? 1 : (NSLAB < 16 / (MT * NT) ? NSLAB : 16 / (MT * NT));
+    constexpr int NACC = 1;        // (measured with 4 sets in the narrow tile: the same loop, profiles/r06_pn_nacc.txt -- the chain is not what COMP waits for)
 #endif
     static_assert(NSLAB % NACC == 0, "whole slabs per accumulator set");
     f32x4 accx[NACC > 1 ? NACC - 1 : 1][MT][NT];
@@ -156,7 +156,22 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)A - kBias), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)B - kBias), 0, -1, 0x00020000);
     const uint32_t ksa = DA::k_stride_bytes(p.lda) * BKE, ksb = DB::k_stride_bytes(p.ldb) * BKE;      // operand bytes per stage
-    uint32_t soa = 0, sob = 0;
+    // MB_PP_SPLIT_DMA=1 (experiment): the DMA pieces of a stage are issued in two halves: pieces [0, GA) behind the fragment reads of a
+    // LOAD (the wave waits for LDS there anyway), pieces [GA, G) between the MFMAs of a COMP.  The narrow tile's COMP takes ~440 clocks
+    // for 272 of MFMA whatever sits next to them (six pieces or three, spread or not, one accumulator chain or four, 16 partner reads
+    // or 8: profiles/r06_pn_looptrace.txt, r06_pn_nacc.txt, r06_pn_ksw.txt, r06_pp_split_dma.txt).  GA <= DA::NI: the first half is operand
+    // A only.  soa_a / dslot_a belong to the first half, soa_b / sob / dslot to the second (group 1's second half runs a stage ahead).
+#ifndef MB_PP_ONE_BARRIER
+#define MB_PP_ONE_BARRIER 1
+#endif
+#ifndef MB_PP_SPLIT_DMA
+#define MB_PP_SPLIT_DMA 0      // measured (profiles/r06_pp_split_dma.txt): stand-alone -0.5 .. -1 us per launch, in the step nothing (+0.2 %); off
+#endif
+    constexpr bool ONEB = MB_PP_ONE_BARRIER != 0;   // one barrier per k-stage (below)
+    constexpr int GA = MB_PP_SPLIT_DMA ? G / 2 : 0;
+    static_assert(GA == 0 || ONEB, "the split DMA issue is written for the one-barrier loop");
+    static_assert(GA <= DA::NI, "the LOAD half holds pieces of operand A only");
+    uint32_t soa_a = 0, soa_b = 0, sob = 0;
 #ifdef MB_GEMM_ABLATE
     const bool no_dma = (p.dbg & 1) != 0, no_reads = (p.dbg & 4) != 0, no_mfma = (p.dbg & 2) != 0;
 #else
@@ -174,19 +189,25 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, PTR, 16, VOFF, SOFF, 3072, 0); } while (0)
         static_assert(DA::NI <= 4 && DB::NI <= 4, "immediate offsets reach 4095");
         if constexpr (I < DA::NI)
-            MB_PP_PIECE(rsa, (__attribute__((address_space(3))) void*)LDS_PTR(smem + slot + wave * (DA::NI * 1024)), (int)va[I], (int)soa, I);
+            MB_PP_PIECE(rsa, (__attribute__((address_space(3))) void*)LDS_PTR(smem + slot + wave * (DA::NI * 1024)), (int)va[I], (int)(I < GA ? soa_a : soa_b), I);
         else
             MB_PP_PIECE(rsb, (__attribute__((address_space(3))) void*)LDS_PTR(smem + slot + BM * KB + wave * (DB::NI * 1024)), (int)vb[I - DA::NI], (int)sob, I - DA::NI);
 #undef MB_PP_PIECE
     };
-    auto dma_advance = [&]() {
-        soa += ksa; sob += ksb;
+    auto dma_advance_a = [&]() { soa_a += ksa; };
+    auto dma_advance = [&]() {                       // (the COMP half)
+        soa_b += ksa; sob += ksb;
         if (seg_stages > 0 && --seg_left == 0) { sob += seg_extra; seg_left = seg_stages; }
     };
-    auto issue_stage = [&](uint32_t slot) {
-        static_for<G>([&](auto ic) { dma_piece(ic, slot); });
+    auto issue_half_a = [&](uint32_t slot) {
+        static_for<GA>([&](auto ic) { dma_piece(ic, slot); });
+        dma_advance_a();
+    };
+    auto issue_half_b = [&](uint32_t slot) {
+        static_for<G - GA>([&](auto ic) { dma_piece(std::integral_constant<int, GA + decltype(ic)::value>{}, slot); });
         dma_advance();
     };
+    auto issue_stage = [&](uint32_t slot) { issue_half_a(slot); issue_half_b(slot); };
     // An instruction of the wave that is NOT on the matrix pipe costs a whole MFMA time (~16 clocks) while its SIMD partner issues
     // MFMAs back to back, and ~4 clocks inside the MFMA stream itself (tools/mfma_lds_probe, profiles/r06_mfma_lds_probe.txt): so LOAD
     // holds the fragment reads and nothing else -- their addresses are computed in the COMP phase before (addr_*), the DMA pieces
@@ -209,7 +230,8 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
     constexpr int NADDR = RA::NB + RB_::NB;
     auto comp_stage_ = [&](auto dmac, auto mfc, uint32_t slot, uint32_t nxt) {
         constexpr bool DMA = decltype(dmac)::value, MF = decltype(mfc)::value;
-        constexpr int NF = (DMA ? G : 0) + NADDR;
+        constexpr int GB = G - GA;                  // pieces of this phase
+        constexpr int NF = (DMA ? GB : 0) + NADDR;
         auto addr_add = [&](auto jc) {
             constexpr int J = decltype(jc)::value;
             if constexpr (J < RA::NB) pinned_add(addr_a[J], nxt, ra.base[J]);
@@ -225,16 +247,16 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
                 // the narrow tile has 16 MFMAs for the same six pieces: one behind (almost) every MFMA, each piece held the wave's issue for
                 // ~30 clocks (COMP 464 clocks for 272 of MFMA, profiles/r06_pn_looptrace.txt) -- a piece every ~2.7 MFMAs is what the
                 // 256 x 128 form has and pays nothing for
-                constexpr int d0 = DMA ? (M * G + NM - 1) / NM : 0, d1 = DMA ? ((M + 1) * G + NM - 1) / NM : 0;
-                static_for<d1 - d0>([&](auto fc) { dma_piece(std::integral_constant<int, d0 + decltype(fc)::value>{}, slot); });
+                constexpr int d0 = DMA ? (M * GB + NM - 1) / NM : 0, d1 = DMA ? ((M + 1) * GB + NM - 1) / NM : 0;
+                static_for<d1 - d0>([&](auto fc) { dma_piece(std::integral_constant<int, GA + d0 + decltype(fc)::value>{}, slot); });
                 constexpr int a0 = M * NADDR / NM, a1 = (M + 1) * NADDR / NM;
                 static_for<a1 - a0>([&](auto fc) { addr_add(std::integral_constant<int, a0 + decltype(fc)::value>{}); });
             } else {
                 constexpr int f0 = M * NF / NM, f1 = (M + 1) * NF / NM;
                 static_for<f1 - f0>([&](auto fc) {
                     constexpr int F = f0 + decltype(fc)::value;
-                    if constexpr (DMA && F < G) dma_piece(std::integral_constant<int, F>{}, slot);
-                    else addr_add(std::integral_constant<int, F - (DMA ? G : 0)>{});
+                    if constexpr (DMA && F < GB) dma_piece(std::integral_constant<int, GA + F>{}, slot);
+                    else addr_add(std::integral_constant<int, F - (DMA ? GB : 0)>{});
                 });
             }
         });
@@ -259,20 +281,16 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
     // one stage t lived in, which both groups have read by then.  Either way a wave's pieces have >= 2 phases to land.
     issue_stage(0u);
     issue_stage((uint32_t)STAGE);
-    if (grp) { issue_stage(2u * STAGE); wait_vmcnt<2 * G>(); } else wait_vmcnt<G>();
+    if (grp) { issue_half_b(2u * STAGE); wait_vmcnt<2 * G - GA>(); } else wait_vmcnt<G>();      // (group 1's COMP half runs a stage ahead)
     __builtin_amdgcn_s_barrier();                    // stage 0 has landed for everybody
     stamp(1);
-#ifndef MB_PP_ONE_BARRIER
-#define MB_PP_ONE_BARRIER 1
-#endif
     // ONE barrier per k-stage (MB_PP_ONE_BARRIER, default): group 0 meets it behind its COMP, group 1 behind its LOAD -- the pair that
     // carries the ring's hazards (a wave's share of stage t+1 has landed; the slot the next DMA pieces go to has been read by everybody).
     // The other pair of the two-barrier form (group 0 behind LOAD, group 1 behind COMP) only forced the alternation, which the first pair
     // restores every stage anyway: group 0 leaves it into a LOAD, group 1 into a COMP.  An eight-wave barrier costs ~200 clocks of a
     // ~750-clock phase (profiles/r06_pn_looptrace.txt).
-    constexpr bool ONEB = MB_PP_ONE_BARRIER != 0;
     if (!ONEB && grp) __builtin_amdgcn_s_barrier();  // (two-barrier form) group 1 runs one phase behind
-    uint32_t cur = 0u, dslot = grp ? 0u : 2u * STAGE;
+    uint32_t cur = 0u, dslot = grp ? 0u : 2u * STAGE, dslot_a = 2u * STAGE;
     // DM: 1 = every wave requests its next stage between the MFMAs, 2 = group 0 only (in front of the MFMAs), 0 = nobody
     auto stage = [&](int t, auto dm, auto wc_) {
         constexpr int DM = decltype(dm)::value;
@@ -280,9 +298,11 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
         // ---- LOAD(t)
         PP_LT(t, 0);
         read_stage();
+        if constexpr (GA > 0 && DM != 0) issue_half_a(dslot_a);      // stage t+2, first half (both groups)
         PP_LT(t, 1);
         lds_wait_all();
-        land(wc_);                                   // group 1: its share of stage t+1 has landed (group 0: nothing younger than stage t+1 yet)
+        if constexpr (ONEB && GA > 0) { if (grp) land(wc_); }        // (group 0 has stage t+1 AND the half just issued in flight: no wait here)
+        else land(wc_);                              // group 1: its share of stage t+1 has landed (group 0: nothing younger than stage t+1 yet)
         PP_LT(t, 2);
         __builtin_amdgcn_sched_barrier(0);           // the scalar bookkeeping of COMP stays behind the barrier (in LOAD it would cost ~16 clocks each)
         if (!ONEB || grp) __builtin_amdgcn_s_barrier();
@@ -290,18 +310,20 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p, const int m0, co
         PP_LT(t, 3);
         // ---- COMP(t)
         const uint32_t nxt = cur == 2u * STAGE ? 0u : cur + STAGE;
-        if constexpr (DM == 2) { if (!grp) issue_stage(dslot); }
+        if constexpr (DM == 2) { if (!grp) issue_half_b(dslot); }
         // the multiplying wave outranks its SIMD partner's reads: by age alone the older wave (group 0) wins BOTH ways and group 1's
         // 32 MFMAs take ~930 clocks instead of ~510 (profiles/r06_pp_looptrace.txt)
         if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(1);
         comp_stage(std::integral_constant<bool, DM == 1>{}, dslot, nxt);
         if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(0);
         PP_LT(t, 4);
-        land(wc_);                                   // group 0: its share of stage t+1 (group 1: of stage t+2, a phase early -- it has had two)
+        if constexpr (ONEB && GA > 0) { if (!grp) land(wc_); }
+        else land(wc_);                              // group 0: its share of stage t+1 (group 1: of stage t+2, a phase early -- it has had two)
         PP_LT(t, 5);
         if (!ONEB || !grp) __builtin_amdgcn_s_barrier();
         cur = nxt;
         dslot = dslot == 2u * STAGE ? 0u : dslot + STAGE;
+        dslot_a = dslot_a == 2u * STAGE ? 0u : dslot_a + STAGE;
     };
     typedef std::integral_constant<int, 0> D0;
     typedef std::integral_constant<int, 1> D1;
