@@ -715,9 +715,12 @@ int mb_bert_backward(mb_bert_engine* e, const float* dlogits, const float* label
                     // L = 128: 128 whole CUs for about half the launch (~41 GB/s each): 20,480 parameters per rider workgroup -- same box, B = 32:
                     // 4.743 ms without | 4.68 at 1.5 M | 4.652 at 2.6 M (this) | 4.66 at 3.5 M | 4.74 at 5 M per launch.  L <= 64: shared CUs, but
                     // the kernel is latency-bound and barely notices: 3.320 ms without | 3.289 at 1.5 M | 3.263 at 2 M | 3.257 at 2.5 M (this:
-                    // 1,040 per token) | 3.270 at 3 M (profiles/r06_adamw_ride_attn.txt)
+                    // 1,040 per token) | 3.270 at 3 M (profiles/r06_adamw_ride_attn.txt).  Later in the round the dgrad launches around it moved to
+                    // the 128 x 64 ping-pong tile, whose 16 idle CUs carry 0.2 - 0.26 M where the 64 x 64 kernel's free slots carried 1.25 M:
+                    // with the sweep that much longer the optimum moved up -- 3.169 ms at 2.5 M | 3.157 at 3 M | 3.152 at 3.5 M | 3.140 at 4 M
+                    // (this: 1,650 per token) | 3.140 at 4.5 M (profiles/r06_ride_budget3.txt)
                     const size_t budget = e->ride_attn_params > 0 ? (size_t)e->ride_attn_params
-                                                                  : (L > 64 ? (size_t)blocks * 20480 : (size_t)1040 * (size_t)T);
+                                                                  : (L > 64 ? (size_t)blocks * 20480 : (size_t)1650 * (size_t)T);
                     ra = take_ride(l, budget / 1024 * 1024, blocks);
                 }
             }

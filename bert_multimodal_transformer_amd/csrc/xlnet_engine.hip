@@ -49,7 +49,8 @@ struct mb_xlnet_engine : StepMixin {
     float* P = nullptr; float* G = nullptr; char* SH = nullptr; char* ws = nullptr;
     const int64_t* ids = nullptr; const int64_t* seg = nullptr; const int64_t* mask = nullptr;
     int B = 0, L = 0, training = 0, padT = -1;
-    int group_wgrad = 128;         // MB_GROUP_WGRAD: tile of the per-layer grouped weight-gradient launch (64 | 128 | 256 = 256 x 128 ping-pong), 0 = one by one
+    int group_wgrad = 256;         // MB_GROUP_WGRAD: tile of the per-layer grouped weight-gradient launch (64 | 128 | 256 = 256 x 128 ping-pong), 0 = one by one
+                                   // (256 since the ping-pong loop has one barrier per stage: 3.895 -> 3.872 ms, profiles/r06_ride_budget3.txt; fp32 / odd widths: 128)
     // MB_OVERLAP_WGRAD=1: the grouped launch of layer l runs on an internal side stream under the dgrad chain of layer l-1 (round-1
     // default; measured equal to the in-line launch on the MAG-BERT engine, which keeps the step one in-order, graph-friendly sequence)
     int overlap_wgrad = 0;
@@ -531,7 +532,9 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                 if (blocks >= 8) {
                     // same box, B = 48 L = 50: 4.253 ms without riders | 4.212 dgrad hosts only | 4.155 at 1.25 M + 0.83 M in the two attention launches |
                     // 4.129 at 1.8 M + 1.2 M (this: 750 per token) | 4.128 at 2.4 M + 1.6 M   (profiles/r06_xlnet_riders.txt)
-                    const size_t budget = e->ride_attn_params > 0 ? (size_t)e->ride_attn_params : (size_t)750 * (size_t)T;
+                    // (later in the round, with the 128 x 64 tile's smaller dgrad riders: 4.040 ms at 1.8 M | 4.021 at 2.4 M | 4.011 at 3 M -- this:
+                    //  1,250 per token; profiles/r06_final_defaults.txt)
+                    const size_t budget = e->ride_attn_params > 0 ? (size_t)e->ride_attn_params : (size_t)1250 * (size_t)T;
                     rq = take_ride(l, budget / 1024 * 1024, blocks);
                     rkv = take_ride(l, (budget * 2 / 3) / 1024 * 1024, blocks);
                 }
