@@ -476,6 +476,44 @@ def kernel_base(name):
     return k[5:] if k.startswith("void ") else k
 
 
+def kernel_literals(name):
+    """`mb::<function><a, b, ...>` for a kernel whose template arguments are all bool / int literals -- from the mangled symbol the library
+    logs (_ZN2mb14gemm_pn_kernelILb0ELb0ELi2EEEvNS_8GemmArgsE) or from what rocprofv3 prints for such a kernel (void mb::gemm_pn_kernel<false,
+    false, 2>(mb::GemmArgs)): the key the two instantiations of one template are told apart by.  None for anything else."""
+    if name.startswith("_ZN2mb"):
+        j = 6
+        while j < len(name) and name[j].isdigit():
+            j += 1
+        if j == 6:
+            return None
+        n = int(name[6:j])
+        fn, rest = name[j:j + n], name[j + n:]
+        if not rest.startswith("I"):
+            return None
+        args, i = [], 1
+        while i < len(rest) and rest[i] == "L":
+            e = rest.find("E", i)
+            if e < 0 or rest[i + 1] not in "bijlmxy":
+                return None
+            v = rest[i + 2:e]
+            v = ("-" + v[1:]) if v.startswith("n") else v
+            if not v.lstrip("-").isdigit():
+                return None
+            args.append(("true" if v != "0" else "false") if rest[i + 1] == "b" else v)
+            i = e + 1
+        if i >= len(rest) or rest[i] != "E" or not args:
+            return None
+        return "mb::%s<%s>" % (fn, ", ".join(args))
+    k = name.split("(")[0].strip()
+    k = k[5:] if k.startswith("void ") else k
+    if k.startswith("mb::") and k.endswith(">") and "<" in k:
+        fn, a = k[:-1].split("<", 1)
+        args = [x.strip() for x in a.split(",")]
+        if all(x in ("true", "false") or x.lstrip("-").isdigit() for x in args):
+            return "%s<%s>" % (fn, ", ".join(args))
+    return None
+
+
 def price_trace(rows, gemm_log, B, L, dtype, n_update, steps, model="bert"):
     """rows: (start ns, end ns, kernel name) of a kernel trace of consecutive training steps (a run of AdamW sweep launches ends a step);
     gemm_log: the library's MB_GEMM_LOG=1 lines of the same run.  -> (per-kernel table over the last `steps` steps, roofline rows: every
@@ -529,6 +567,7 @@ def price_trace(rows, gemm_log, B, L, dtype, n_update, steps, model="bert"):
     for b_, qs in seen.items():
         if len(qs) == 1:
             flops_base[b_] = qs[0]
+    flops_lit = {kernel_literals(name): q for name, q in flops.items() if kernel_literals(name)}      # (instantiations of one template)
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
     ks = sorted(agg.items(), key=lambda kv_: -kv_[1][1])
     table, roof = [], []
@@ -537,7 +576,7 @@ def price_trace(rows, gemm_log, B, L, dtype, n_update, steps, model="bert"):
         row = {"kernel": short, "launches_per_step": round(n / steps, 2), "avg_us": round(t / n / 1e3, 2), "ms_per_step": round(t / steps / 1e6, 4)}
         table.append(row)
         us = t / n / 1e3
-        f = flops.get(k) or flops.get(k.split("(")[0]) or flops_base.get(kernel_base(k))
+        f = flops.get(k) or flops.get(k.split("(")[0]) or flops_lit.get(kernel_literals(k)) or flops_base.get(kernel_base(k))
         if f:
             per = f[1] / f[0]
             rr = dict(row, bound="mfma", flop_per_launch=per, achieved=round(per / us * 1e-6, 1), peak=peak, unit="TFLOP/s",

@@ -508,6 +508,19 @@ def test_bench_prices_a_kernel_trace():
     assert ad["bound"] == "hbm" and abs(ad["achieved"] - 14 * 110_853_121 / 250.0 * 1e-3) < 0.5
     assert doc["gemm_aggregate"]["gflop_per_step"] > 0 and not doc["replayed"]
     assert bench.price_trace(rows[:5], log, B, L, "bf16", 1, steps=3)[0] is None          # too short: a reason, not a crash
+    # two instantiations of one template with literal arguments only (csrc/gemm_pp.hip gemm_pn_kernel): rocprofv3 prints them demangled,
+    # the library logs the mangled symbols -- told apart by their template arguments
+    pn_f, pn_d = "void mb::gemm_pn_kernel<false, false, 2>(mb::GemmArgs)", "void mb::gemm_pn_kernel<false, true, 3>(mb::GemmArgs)"
+    rows3, t = [], 0
+    for step in range(4):
+        for name, dur, n in ((pn_f, 20_000, 2), (pn_d, 10_000, 1), (adam, 100_000, 1)):
+            for _ in range(n):
+                rows3.append((t, t + dur, name)); t += dur + 500
+    log3 = "\n".join(["[magbert gemm] _ZN2mb14gemm_pn_kernelILb0ELb0ELi2EEEvNS_8GemmArgsE problems=1 flop=%d M=%d N=768 K=3072" % (2 * T * 768 * 3072, T)] * 2 +
+                     ["[magbert gemm] _ZN2mb14gemm_pn_kernelILb0ELb1ELi3EEEvNS_8GemmArgsE problems=1 flop=%d M=%d N=768 K=768" % (2 * T * 768 * 768, T)])
+    doc3, roof3 = bench.price_trace(rows3, log3, B, L, "bf16", 110_853_121, steps=3)
+    by3 = {r["kernel"]: r for r in roof3}
+    assert abs(by3[pn_f.split("(")[0]]["flop_per_launch"] - 2 * T * 768 * 3072) < 1 and abs(by3[pn_d.split("(")[0]]["flop_per_launch"] - 2 * T * 768 * 768) < 1
     # riders (csrc/kernels.h AdamRide): part of the update runs inside the weight-gradient launches -- the sweep launches are priced with
     # the parameters THEY cover (the library logs them), a step may end with three sweep launches instead of two
     rows2, t = [], 0
