@@ -41,7 +41,10 @@ void mb_make_dropkey(uint64_t seed, uint64_t step, uint32_t site, float p, mb_dr
  * layout 2 (TN): A[K][M], B[K][N]          wgrad    dW += dY^T X   (fp32 accumulate, split-K)
  * epilogue: 0 C=alpha*acc+bias | 1 u=acc+bias: C=gelu'(u), C2=gelu(u) | 2 C=dropout(acc+bias)+R | 3 C=acc+R | 4 C=acc*R (R = the gelu'(u) saved by 1)
  *           5 Cf+=acc (fp32) | 6 Cf=alpha*acc+bias (fp32)
- * With epilogue 4, Cf (fp32 [N], may be NULL) receives += the column sums of C: the bias gradient of the Linear in front. */
+ * With epilogue 4, Cf (fp32 [N], may be NULL) receives += the column sums of C: the bias gradient of the Linear in front.
+ * tile: 0 = chosen by shape (what the engines pass) | 64 | 128 | 12864 (128 x 64, four waves) | 256 (256 x 128 eight-wave ping-pong, bf16)
+ *       | 12872 (128 x 64 eight-wave ping-pong, bf16: the choice for N = 768 at one tile per CU); a tile that cannot take the problem
+ *       (dtype, epilogue, k range) falls back to the next smaller one.  splits > 1: split-K (layout 2 only). */
 int mb_gemm(int dtype, int layout, int epilogue, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
             void* C, int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, float alpha,
             const mb_dropkey* drop, int splits, int tile, void* stream);
@@ -57,7 +60,8 @@ int mb_debug_attention_trace(unsigned long long* host_out, int max_blocks);
 
 /* `count` (<= 4) weight gradients dW_g[M_g][N_g] += dY_g[K][M_g]^T X_g[K][N_g] in ONE launch (fp32 accumulate) -- the
  * four torch.nn.Linear weight gradients autograd produces per BertLayer (mm_backward under loss.backward(),
- * multimodal_driver.py:378).  Every M_g, N_g must be a multiple of `tile` (64 | 128) and K a multiple of 128 bytes. */
+ * multimodal_driver.py:378).  Every M_g, N_g must be a multiple of `tile` (64 | 128 | 256 = the 256 x 128 ping-pong tile, bf16: M_g % 256, N_g % 128) and K a
+ * multiple of 128 bytes. */
 int mb_gemm_grouped_wgrad(int dtype, int count, const int* M, const int* N, int K, const void* const* dY, const int* ldy,
                           const void* const* X, const int* ldx, float* const* dW, const int* ldw, int tile, void* stream);
 
