@@ -19,6 +19,10 @@
 // LDS / DMA queues -- the complementary pairing MI355X_MICROARCH.md "Two waves per SIMD" item 5 asks for.  The two groups share the
 // B image (128 columns) and the barrier; group 0 owns tile rows 0-127, group 1 rows 128-255.
 //
+// (That is the two-barrier form the kernel was built in, and the picture the phase names come from.  The default since late round 6 keeps
+//  ONE of the two barriers per stage -- group 0 meets it behind COMP, group 1 behind LOAD; see MB_PP_ONE_BARRIER in the body -- with the
+//  same per-wave instruction order, DMA schedule and waits.  gemm_pn_kernel is the same loop on a 128 x 64 tile with 128 k per stage.)
+//
 // Ring: three 48-KB slots.  In COMP(t) group 0 (phase 2t+1) requests its share of stage t+2, group 1 (phase 2t+2) its share of stage
 // t+3 -- into the slot stage t-1 resp. t lived in, whose last reader drained its reads before the barrier in front of that phase
 // (WAR).  Landing (RAW): a wave's pieces of stage t+1 are counted out (s_waitcnt vmcnt) in phase 2t+1 by BOTH groups -- group 0 at the
