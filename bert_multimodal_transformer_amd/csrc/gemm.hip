@@ -745,31 +745,43 @@ static int tile_n768() {
     if (g_tile_n768 < 0) g_tile_n768 = env_int("MB_GEMM_TILE_N768", 12872);
     return g_tile_n768;
 }
-static int pn_cfg(const GemmArgs& a, bool ak, bool bk, int splits, bool forced, GemmArgs& p) {
-    p = a;
-    const int tiles = choose_regions<128, 64>(p);
-    static int pn_max = -1;         // MB_GEMM_PN_MAX (measurement switch): the largest padded tile count the auto selection takes
-    if (pn_max < 0) pn_max = env_int("MB_GEMM_PN_MAX", 256);
+// `tall` in: 1 = only the 256 x 64 form (tile code 25672), 0 = only 128 x 64 (12872), -1 = whichever makes one round (the auto selection:
+// 128 x 64 first; the tall form -- 64-deep stages, K >= 192 -- where that one would need a second round, MB_GEMM_PT=0 turns it off);
+// out: which one it is.
+static int pn_cfg(const GemmArgs& a, bool ak, bool bk, int splits, bool forced, GemmArgs& p, int* tall = nullptr) {
+    const int want = tall ? *tall : 0;
+    if (tall) *tall = 0;
+    static int pn_max = -1, pt_on = -1;         // MB_GEMM_PN_MAX (measurement switch): the largest padded tile count the auto selection takes
+    if (pn_max < 0) { pn_max = env_int("MB_GEMM_PN_MAX", 256); pt_on = env_int("MB_GEMM_PT", 1); }
     if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
-    bool ok = splits <= 1 && g_impl != 1 && g_stages <= 0 && p.bseg <= 0 && (p.K % 128 == 0) && p.K / 128 >= 3 && (p.lda % 8 == 0) && (p.ldb % 8 == 0) &&
-              (((uintptr_t)p.A | (uintptr_t)p.B) % 16 == 0) && (forced || (tiles <= pn_max && tiles >= 168));
-    if (ak) ok = ok && (p.M % 128 == 0);
-    if (bk) ok = ok && (p.N % 64 == 0);
-    if (!ok) return 0;
-    p.kchunk = p.K;
-    p.dbg = g_dbg;
-    p.trace = nullptr;
-    return tiles;
+    const bool common = splits <= 1 && g_impl != 1 && g_stages <= 0 && a.bseg <= 0 && (a.lda % 8 == 0) && (a.ldb % 8 == 0) &&
+                        (((uintptr_t)a.A | (uintptr_t)a.B) % 16 == 0) && (!bk || a.N % 64 == 0);
+    if (!common) return 0;
+    for (int form = 0; form < 2; ++form) {
+        if ((want == 0 && form == 1) || (want == 1 && form == 0) || (form == 1 && want < 0 && !pt_on)) continue;
+        p = a;
+        const int tiles = form ? choose_regions<256, 64>(p) : choose_regions<128, 64>(p);
+        const int ke = form ? 64 : 128, bm = form ? 256 : 128;
+        bool ok = (p.K % ke == 0) && p.K / ke >= 3 && (forced || (tiles <= pn_max && tiles >= 168));
+        if (ak) ok = ok && (p.M % bm == 0);
+        if (!ok) continue;
+        p.kchunk = p.K;
+        p.dbg = g_dbg;
+        p.trace = nullptr;
+        if (tall) *tall = form;
+        return tiles;
+    }
+    return 0;
 }
 
 // A dgrad launch (GEMM_NN, bf16) with riders, for the two configurations that leave block slots free at T = 2400:
 //   EPI_ADD_RES, N = 768  : the 64 x 64 three-slot kernel, 456 tiles in 768 slots (three 48-KB rings per CU)
 //   EPI_DGELU,  N = 3072  : the 128 x 128 two-slot kernel, 456 tiles in 512 slots -- 56 CUs hold ONE tile and are half idle throughout
 // -> the padded tile count of the launch launch_tile / launch_cfg above would make of `a` (and the block slots per CU), 0 = another kernel.
-static int nn_ride_cfg(int mode, const GemmArgs& a, GemmArgs& p, int* per_cu, bool* pn = nullptr) {
+static int nn_ride_cfg(int mode, const GemmArgs& a, GemmArgs& p, int* per_cu, int* pn = nullptr) {      // *pn: 0 four-wave kernels, 1 = 128 x 64 ping-pong, 2 = 256 x 64
     constexpr int BKE = 64, EPV = 8;
     p = a;
-    if (pn) *pn = false;
+    if (pn) *pn = 0;
     if (g_impl < 0) { g_impl = env_int("MB_GEMM_IMPL", 0); g_stages = env_int("MB_GEMM_STAGES", 0); g_dbg = env_int("MB_GEMM_DBG", 0); }
     static int plain = -1;          // every selection switch of launch_tile / launch_cfg at its default (else: the plain launch, no riders)
     if (plain < 0)
@@ -781,8 +793,9 @@ static int nn_ride_cfg(int mode, const GemmArgs& a, GemmArgs& p, int* per_cu, bo
     const bool big = t128 >= 224;
     if (!big && tile_n768() == 12872) {
         // the 128 x 64 ping-pong tile: ONE tile per CU (144 KB of LDS), the riders are whole idle CUs like the grouped weight gradient's
-        const int tiles = mode == EPI_ADD_RES ? pn_cfg(a, false, true, 1, false, p) : 0;
-        if (tiles > 0) { if (per_cu) *per_cu = 1; if (pn) *pn = true; return tiles; }
+        int tall = -1;
+        const int tiles = mode == EPI_ADD_RES ? pn_cfg(a, false, true, 1, false, p, &tall) : 0;
+        if (tiles > 0) { if (per_cu) *per_cu = 1; if (pn) *pn = 1 + tall; return tiles; }
         p = a;
     } else if (!big && tile_n768() != 64) return 0;
     if (big != (mode == EPI_DGELU)) return 0;
@@ -791,8 +804,12 @@ static int nn_ride_cfg(int mode, const GemmArgs& a, GemmArgs& p, int* per_cu, bo
     if ((a.K % BKE) || (a.lda % EPV) || (a.ldb % EPV) || (((uintptr_t)a.A | (uintptr_t)a.B) % 16) || a.K / BKE < 2) return 0;
     const int tiles = big ? choose_regions<128, 128>(p) : choose_regions<64, 64>(p);
     // (beyond 512 tiles the plain launch of the 64 x 64 shapes is another kernel -- two slots, five blocks per CU; the 128 x 128 kernel stays the
-    //  same and simply takes more rounds: at T = 4096 its 768 tiles are one and a half, the riders get the slots the second round leaves free)
-    if (tiles > (big ? 4096 : 512)) return 0;
+    //  same and simply takes more rounds: at T = 4096 its 768 tiles are one and a half -- riders in the slots its second round leaves free were
+    //  measured: 3.7 M parameters stretch the launch from 33 to 47 us, the step gains nothing (4.72 vs 4.72 ms) and loses 0.4 % once the narrow
+    //  dgrads carry riders of their own, profiles/r06_c5_dgelu_riders.txt, r06_pt_first_ab.txt; MB_ADAMW_RIDE_DGELU_ROUNDS=1 allows them)
+    static int dgelu_rounds = -1;
+    if (dgelu_rounds < 0) dgelu_rounds = env_int("MB_ADAMW_RIDE_DGELU_ROUNDS", 0);
+    if (tiles > (big && dgelu_rounds ? 4096 : 512)) return 0;
     if (per_cu) *per_cu = big ? 2 : 3;
     p.kchunk = p.K;
     p.dbg = g_dbg;
@@ -806,10 +823,10 @@ int gemm_nn_ride_tiles(int dtype, int mode, const GemmArgs& a, int* per_cu) {
 }
 int gemm_nn_ride_launch(int dtype, int mode, const GemmArgs& a, const AdamRide& ride, hipStream_t st) {
     GemmArgs p;
-    bool pn = false;
+    int pn = 0;
     const int tiles = dtype == DT_BF16 ? nn_ride_cfg(mode, a, p, nullptr, &pn) : 0;
     if (tiles <= 0 || ride.blocks <= 0 || (ride.blocks & 7)) return MB_ERR_MODE;
-    if (pn) return gemm_pn_ride_launch(p, ride, dim3(tiles), st);
+    if (pn) return gemm_pn_ride_launch(p, ride, dim3(tiles), st, pn == 2);
     gemm_log_ride(ride);
     if (mode == EPI_DGELU) {
         gemm_log((const void*)(gemm2_ride_kernel<bf16, 128, 128, false, true, EPI_DGELU, 2, 128>), st, &p, 1);
@@ -822,13 +839,13 @@ int gemm_nn_ride_launch(int dtype, int mode, const GemmArgs& a, const AdamRide& 
 }
 
 template <class T, bool AK, bool BK, int MODE>
-static int launch_pn(const GemmArgs& a, int splits, bool forced, hipStream_t st) {
+static int launch_pn(const GemmArgs& a, int splits, bool forced, hipStream_t st, int tall = -1) {
     if constexpr (sizeof(T) == 2) {
         GemmArgs p;
-        const int tiles = pn_cfg(a, AK, BK, splits, forced, p);
+        const int tiles = pn_cfg(a, AK, BK, splits, forced, p, &tall);
         if (tiles > 0) {
             p.trace = (g_trace_on != 0) ? trace_buffer(tiles, st) : nullptr;
-            const int rc = gemm_pn_launch(AK, BK, MODE, p, dim3(tiles), st);
+            const int rc = gemm_pn_launch(AK, BK, MODE, p, dim3(tiles), st, tall == 1);
             if (rc != MB_ERR_MODE) return rc;      // (a layout / epilogue pair that is not instantiated: 64 x 64)
         }
     }
@@ -854,7 +871,8 @@ static int launch_tile(const GemmArgs& a, int splits, int tile, hipStream_t st) 
     if (tile == 256) tile = 128;
     if (tile == 128) return launch_cfg<T, 128, 128, AK, BK, MODE>(a, splits, st);
     if (tile == 12864) return launch_cfg<T, 128, 64, AK, BK, MODE>(a, splits, st);
-    if (tile == 12872) return launch_pn<T, AK, BK, MODE>(a, splits, forced, st);      // (falls back to 64 x 64 by itself)
+    if (tile == 12872) return launch_pn<T, AK, BK, MODE>(a, splits, forced, st, forced ? 0 : -1);      // (falls back to 64 x 64 by itself)
+    if (tile == 25672) return launch_pn<T, AK, BK, MODE>(a, splits, forced, st, 1);                    // the 256 x 64 form by name
     return launch_cfg<T, 64, 64, AK, BK, MODE>(a, splits, st);
 }
 

@@ -49,6 +49,10 @@ constexpr int kPnBM = 128, kPnBN = 64, kPnKB = 256;
 #define MB_PN_KSW 0            // 1 = k-split waves in the narrow tile (measured: the loop gains 9 %, the four-partial epilogue takes it back)
 #endif
 constexpr bool kPnKsw = MB_PN_KSW != 0;
+// The tall form for the same launches at T = 4096 (MOSEI shape: 128 x 64 would make 384 tiles = one and a half rounds): 256 x 64 outputs,
+// 64 k per stage -- 40-KB stages, five DMA pieces per wave; a wave owns 64 x 32 outputs and two slabs (16 MFMAs, 12 / 16 reads per
+// stage).  16 x 12 = 192 tiles at T = 4096: one round, and 64 CUs left to the riders.
+constexpr int kPtBM = 256, kPtBN = 64, kPtKB = 128;
 static_assert((kPnBM + kPnBN) * kPnKB == kPpStage, "both forms share the ring geometry");
 
 #ifdef MB_GEMM_LOOPTRACE
@@ -392,6 +396,24 @@ __global__ void __launch_bounds__(512) gemm_pn_ride_kernel(const GemmArgs p, con
     gemm_pp_body<kPnBM, kPnBN, kPnKB, false, true, EPI_ADD_RES, kPnKsw>(p, m0, n0, smem);
 }
 
+template <bool AK, bool BK, int MODE>
+__global__ void __launch_bounds__(512) gemm_pt_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(1024))) char smem[kPpSlots * (kPtBM + kPtBN) * kPtKB];
+    int m0, n0;
+    if (!tile_origin<kPtBM, kPtBN>(p, m0, n0, blockIdx.x)) return;
+    gemm_pp_body<kPtBM, kPtBN, kPtKB, AK, BK, MODE>(p, m0, n0, smem);
+}
+__global__ void __launch_bounds__(512) gemm_pt_ride_kernel(const GemmArgs p, const AdamRide ride) {
+    __shared__ __attribute__((aligned(1024))) char smem[kPpSlots * (kPtBM + kPtBN) * kPtKB];
+    if ((int)blockIdx.x < ride.blocks) {
+        adam_ride_block<512, MB_RIDE_UNR>(ride, (int)blockIdx.x);
+        return;
+    }
+    int m0, n0;
+    if (!tile_origin<kPtBM, kPtBN>(p, m0, n0, (int)blockIdx.x - ride.blocks)) return;
+    gemm_pp_body<kPtBM, kPtBN, kPtKB, false, true, EPI_ADD_RES>(p, m0, n0, smem);
+}
+
 // the weight gradients of a layer (dW = dY^T X: both operands k-major), one launch (gemm.hip: launch_grouped places the tiles)
 __global__ void __launch_bounds__(512) gemm_pp_grouped_tn_kernel(const GroupedGemmArgs ga) {
     __shared__ __attribute__((aligned(1024))) char smem[kPpSlots * kPpStage];
@@ -419,10 +441,11 @@ int gemm_pp_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hip
 }
 
 // the 128 x 64 form (bf16; K a multiple of 128, at least three stages): the N = 768 forward and dgrad launches
-int gemm_pn_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hipStream_t st) {
+int gemm_pn_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hipStream_t st, bool tall) {
 #define MB_PN(AKV, BKV, MODEV) \
     if (ak == AKV && bk == BKV && mode == MODEV) { \
-        MB_GEMM_LAUNCH((gemm_pn_kernel<AKV, BKV, MODEV>), grid, dim3(512), st, p, &p, 1); \
+        if (tall) MB_GEMM_LAUNCH((gemm_pt_kernel<AKV, BKV, MODEV>), grid, dim3(512), st, p, &p, 1); \
+        else MB_GEMM_LAUNCH((gemm_pn_kernel<AKV, BKV, MODEV>), grid, dim3(512), st, p, &p, 1); \
         return (int)hipGetLastError(); \
     }
     MB_PN(false, false, EPI_BIAS)
@@ -433,10 +456,15 @@ int gemm_pn_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hip
     return MB_ERR_MODE;
 }
 
-int gemm_pn_ride_launch(const GemmArgs& p, const AdamRide& ride, dim3 grid, hipStream_t st) {
+int gemm_pn_ride_launch(const GemmArgs& p, const AdamRide& ride, dim3 grid, hipStream_t st, bool tall) {
     gemm_log_ride(ride);
-    gemm_log((const void*)gemm_pn_ride_kernel, st, &p, 1);
-    hipLaunchKernelGGL(gemm_pn_ride_kernel, dim3(grid.x + ride.blocks), dim3(512), 0, st, p, ride);
+    if (tall) {
+        gemm_log((const void*)gemm_pt_ride_kernel, st, &p, 1);
+        hipLaunchKernelGGL(gemm_pt_ride_kernel, dim3(grid.x + ride.blocks), dim3(512), 0, st, p, ride);
+    } else {
+        gemm_log((const void*)gemm_pn_ride_kernel, st, &p, 1);
+        hipLaunchKernelGGL(gemm_pn_ride_kernel, dim3(grid.x + ride.blocks), dim3(512), 0, st, p, ride);
+    }
     return (int)hipGetLastError();
 }
 

@@ -556,8 +556,8 @@ unsigned long long* gemm_trace_buffer(int blocks, hipStream_t st);     // null u
 int gemm_dbg_flags();                                                   // MB_GEMM_DBG
 // 8-wave ping-pong kernels (gemm_pp.hip), bf16, 256 x 128 tiles.  MB_ERR_MODE: that (layout, epilogue) pair is not instantiated.
 int gemm_pp_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hipStream_t st);
-int gemm_pn_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hipStream_t st);      // 128 x 64 tiles, 128 k per stage
-int gemm_pn_ride_launch(const GemmArgs& p, const AdamRide& ride, dim3 grid, hipStream_t st);         // dgrad (row, k-major, + residual) with rider workgroups in front
+int gemm_pn_launch(bool ak, bool bk, int mode, const GemmArgs& p, dim3 grid, hipStream_t st, bool tall = false);      // 128 x 64 tiles, 128 k per stage (tall: 256 x 64, 64 k)
+int gemm_pn_ride_launch(const GemmArgs& p, const AdamRide& ride, dim3 grid, hipStream_t st, bool tall = false);         // dgrad (row, k-major, + residual) with rider workgroups in front
 int gemm_pp_grouped_launch(const GroupedGemmArgs& ga, int grid, hipStream_t st);      // grid = tiles only: ga.ride.blocks are added
 #define MB_GEMM_LAUNCH(KERN, grid, block, st, arg, plog, cnt) \
     do { gemm_log((const void*)(KERN), st, plog, cnt); hipLaunchKernelGGL((KERN), grid, block, 0, st, arg); } while (0)

@@ -43,7 +43,8 @@ void mb_make_dropkey(uint64_t seed, uint64_t step, uint32_t site, float p, mb_dr
  *           5 Cf+=acc (fp32) | 6 Cf=alpha*acc+bias (fp32)
  * With epilogue 4, Cf (fp32 [N], may be NULL) receives += the column sums of C: the bias gradient of the Linear in front.
  * tile: 0 = chosen by shape (what the engines pass) | 64 | 128 | 12864 (128 x 64, four waves) | 256 (256 x 128 eight-wave ping-pong, bf16)
- *       | 12872 (128 x 64 eight-wave ping-pong, bf16: the choice for N = 768 at one tile per CU); a tile that cannot take the problem
+ *       | 12872 (128 x 64 eight-wave ping-pong, bf16: the choice for N = 768 at one tile per CU) | 25672 (256 x 64, the same at T = 4096);
+ *       a tile that cannot take the problem
  *       (dtype, epilogue, k range) falls back to the next smaller one.  splits > 1: split-K (layout 2 only). */
 int mb_gemm(int dtype, int layout, int epilogue, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
             void* C, int ldc, void* C2, float* Cf, const float* bias, const void* R, int ldr, float alpha,

@@ -637,16 +637,18 @@ def test_adamw_riding_in_the_weight_gradient_launches_changes_nothing(cdt, tile,
     assert float(ride["g"].abs().max()) == 0.0 and ride["stats"] == ref["stats"]
 
 
-@pytest.mark.parametrize("B", [24, 48])
-def test_adamw_riders_of_every_host_change_nothing_at_a_benchmark_like_width(B, monkeypatch):
+@pytest.mark.parametrize("B,L", [(24, 50), (48, 50), (32, 128)])
+def test_adamw_riders_of_every_host_change_nothing_at_a_benchmark_like_width(B, L, monkeypatch):
     """The same property at T = 1,200 tokens (B = 24, L = 50), where EVERY host carries riders: the ping-pong weight gradient's idle CUs,
     the 64 x 64 ffn1 / qkv dgrads' free slots, the 128 x 128 ffn2 dgrad (needs >= 224 tiles: not reached by the small shapes above) and the
     attention backward -- and at the benchmark's own T = 2,400 (B = 48), where the ffn1 / qkv dgrads run the 128 x 64 ping-pong tile and
-    their riders are the 16 CUs its 228 tiles leave idle (csrc/gemm_pp.hip gemm_pn_ride_kernel).  bf16, deterministic mode, four steps over
-    two shapes: bit-identical parameters, moments, shadow and logits."""
+    their riders are the 16 CUs its 228 tiles leave idle (csrc/gemm_pp.hip gemm_pn_ride_kernel), and at the MOSEI shape T = 4,096 (B = 32,
+    L = 128), where they run the 256 x 64 form (192 tiles, 64 rider CUs: gemm_pt_ride_kernel) and the attention backward's riders are the
+    128 CUs its second round leaves empty.  bf16, deterministic mode, four steps over two shapes: bit-identical parameters, moments,
+    shadow and logits."""
     monkeypatch.setenv("MB_DETERMINISTIC", "1")
     monkeypatch.setenv("MB_GROUP_WGRAD", "256")
-    shapes = ((B, 50), (B, 50), (5, 40), (B, 50))
+    shapes = ((B, L), (B, L), (5, 40), (B, L))
     monkeypatch.setenv("MB_ADAMW_RIDE", "0")
     ref = _trajectory(torch.bfloat16, True, shapes=shapes)
     monkeypatch.setenv("MB_ADAMW_RIDE", "1")

@@ -70,7 +70,9 @@ def gemm(dt, tdt, layout, epi, M, N, K, A, B, bias=None, R=None, alpha=1.0, drop
 @pytest.mark.parametrize("M,N,K,tile", [(150, 192, 128, 64), (2400, 768, 768, 0), (300, 256, 3072, 128), (48, 768, 768, 64),
                                         (2400, 3072, 768, 0), (2400, 2304, 768, 256), (300, 136, 192, 256),   # 256 = eight-wave 256 x 128 tiles (bf16; fp32 falls back to 128)
                                         # 12872 = eight-wave 128 x 64 tiles, 128 k per stage (bf16; what it cannot take runs 64 x 64)
-                                        (2400, 768, 3072, 12872), (2400, 768, 768, 12872), (300, 200, 384, 12872), (130, 64, 512, 12872)])
+                                        (2400, 768, 3072, 12872), (2400, 768, 768, 12872), (300, 200, 384, 12872), (130, 64, 512, 12872),
+                                        # 25672 = eight-wave 256 x 64 tiles, 64 k per stage (the same launches at T = 4096)
+                                        (4096, 768, 3072, 25672), (4096, 768, 768, 0), (600, 200, 192, 25672), (260, 64, 320, 25672)])
 def test_gemm_nt_epilogues(dt, tdt, M, N, K, tile):
     A, B = rnd((M, K), 1, tdt), rnd((N, K), 2, tdt, 0.1)     # asymmetric operands: a transposed C-write cannot pass
     bias = rnd((N,), 3, torch.float32)
@@ -94,7 +96,8 @@ def test_gemm_nt_epilogues(dt, tdt, M, N, K, tile):
 @pytest.mark.parametrize("dt,tdt", DTS)
 @pytest.mark.parametrize("M,N,K,tile", [(150, 192, 128, 64), (2400, 768, 3072, 0), (2400, 3072, 768, 128), (2400, 768, 2304, 64),
                                         (100, 128, 64, 128), (2400, 768, 768, 128), (2400, 3072, 768, 0), (500, 384, 192, 256),
-                                        (2400, 768, 3072, 12872), (2400, 768, 2304, 12872), (150, 192, 384, 12872), (2400, 768, 768, 12872)])
+                                        (2400, 768, 3072, 12872), (2400, 768, 2304, 12872), (150, 192, 384, 12872), (2400, 768, 768, 12872),
+                                        (4096, 768, 3072, 0), (4096, 768, 2304, 25672), (300, 192, 192, 25672)])
 def test_gemm_nn_dgrad(dt, tdt, M, N, K, tile):
     A, B = rnd((M, K), 5, tdt), rnd((K, N), 6, tdt, 0.1)     # B stored [K][N]
     R = rnd((M, N), 7, tdt)
