@@ -533,8 +533,9 @@ int mb_xlnet_backward(mb_xlnet_engine* e, const float* dlogits, const float* lab
                     // same box, B = 48 L = 50: 4.253 ms without riders | 4.212 dgrad hosts only | 4.155 at 1.25 M + 0.83 M in the two attention launches |
                     // 4.129 at 1.8 M + 1.2 M (this: 750 per token) | 4.128 at 2.4 M + 1.6 M   (profiles/r06_xlnet_riders.txt)
                     // (later in the round, with the 128 x 64 tile's smaller dgrad riders: 4.040 ms at 1.8 M | 4.021 at 2.4 M | 4.011 at 3 M -- this:
-                    //  1,250 per token; profiles/r06_final_defaults.txt)
-                    const size_t budget = e->ride_attn_params > 0 ? (size_t)e->ride_attn_params : (size_t)1250 * (size_t)T;
+                    //  1,250 per token; profiles/r06_final_defaults.txt; and further: 4.000 at 3 M | 3.983 at 4.2 M | 3.965 at 5.4 M, where the two
+                    //  hosts take everything that is final -- this: 2,250 per token; profiles/r06_xlnet_ride_budget2.txt)
+                    const size_t budget = e->ride_attn_params > 0 ? (size_t)e->ride_attn_params : (size_t)2250 * (size_t)T;
                     rq = take_ride(l, budget / 1024 * 1024, blocks);
                     rkv = take_ride(l, (budget * 2 / 3) / 1024 * 1024, blocks);
                 }
